@@ -1,0 +1,473 @@
+// HBM-bound kernels of the FCN-8s path: input preprocessing, 2x2 max-pool
+// (forward / backward with fused ReLU mask), fused softmax-cross-entropy
+// (loss + dlogits in one pass over the logits), softmax+argmax, confusion
+// matrix, column sums (bias gradients), optimizer updates and the small weight
+// re-layouts.  16-byte vector accesses, grid-stride loops capped at 2048 blocks.
+#include "fcn8s_internal.h"
+#include <math.h>
+
+namespace fcn8s {
+
+static inline int cap_blocks(long long work, int per_block)
+{
+    long long b = (work + per_block - 1) / per_block;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---- K0: uint8/float RGB -> float BGR - mean, padded to 4 channels ---------
+__global__ void preprocess_kernel(const void* img, int dtype, float4* out, long long npix)
+{
+    const float m0 = 103.939f, m1 = 116.779f, m2 = 123.68f;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix;
+         p += (long long)gridDim.x * blockDim.x) {
+        float r, g, b;
+        if (dtype == 0) {
+            const uint8_t* q = (const uint8_t*)img + p * 3;
+            r = q[0]; g = q[1]; b = q[2];
+        } else {
+            const float* q = (const float*)img + p * 3;
+            r = q[0]; g = q[1]; b = q[2];
+        }
+        out[p] = make_float4(b - m0, g - m1, r - m2, 0.f);
+    }
+}
+void launch_preprocess(const void* img, int dtype, float* out4, long long npix, hipStream_t s)
+{
+    hipLaunchKernelGGL(preprocess_kernel, dim3(cap_blocks(npix, 256)), dim3(256), 0, s, img, dtype,
+                       (float4*)out4, npix);
+}
+
+// ---- K2: max-pool 2x2/2 (C % 4 == 0, H,W even) ------------------------------
+__global__ void maxpool_fwd_kernel(const float4* x, float4* y, int N, int H, int W, int C4)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)N * Ho * Wo * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long t = i / C4;
+        const int w = (int)(t % Wo); t /= Wo;
+        const int h = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const long long base = (((long long)n * H + 2 * h) * W + 2 * w) * C4 + c;
+        const float4 a = x[base], b = x[base + C4], cc = x[base + (long long)W * C4], d = x[base + (long long)W * C4 + C4];
+        float4 m;
+        m.x = fmaxf(fmaxf(a.x, b.x), fmaxf(cc.x, d.x));
+        m.y = fmaxf(fmaxf(a.y, b.y), fmaxf(cc.y, d.y));
+        m.z = fmaxf(fmaxf(a.z, b.z), fmaxf(cc.z, d.z));
+        m.w = fmaxf(fmaxf(a.w, b.w), fmaxf(cc.w, d.w));
+        y[i] = m;
+    }
+}
+void launch_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t s)
+{
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(cap_blocks(total, 256)), dim3(256), 0, s,
+                       (const float4*)x, (float4*)y, N, H, W, C / 4);
+}
+
+// gradient to the first maximal element of the window; optional ReLU mask of
+// the producing conv (x is that conv's post-ReLU output): dx *= (x > 0).
+static __device__ __forceinline__ void route(float a, float b, float c, float d, float g, int relu,
+                                            float& oa, float& ob, float& oc, float& od)
+{
+    int bi = 0; float m = a;
+    if (b > m) { m = b; bi = 1; }
+    if (c > m) { m = c; bi = 2; }
+    if (d > m) { m = d; bi = 3; }
+    if (relu && !(m > 0.f)) g = 0.f;
+    oa = bi == 0 ? g : 0.f; ob = bi == 1 ? g : 0.f; oc = bi == 2 ? g : 0.f; od = bi == 3 ? g : 0.f;
+}
+__global__ void maxpool_bwd_kernel(const float4* x, const float4* dy, float4* dx, int N, int H, int W,
+                                   int C4, int relu)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)N * Ho * Wo * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long t = i / C4;
+        const int w = (int)(t % Wo); t /= Wo;
+        const int h = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const long long b0 = (((long long)n * H + 2 * h) * W + 2 * w) * C4 + c;
+        const long long b1 = b0 + C4, b2 = b0 + (long long)W * C4, b3 = b2 + C4;
+        const float4 a = x[b0], b = x[b1], cc = x[b2], d = x[b3], g = dy[i];
+        float4 oa, ob, oc, od;
+        route(a.x, b.x, cc.x, d.x, g.x, relu, oa.x, ob.x, oc.x, od.x);
+        route(a.y, b.y, cc.y, d.y, g.y, relu, oa.y, ob.y, oc.y, od.y);
+        route(a.z, b.z, cc.z, d.z, g.z, relu, oa.z, ob.z, oc.z, od.z);
+        route(a.w, b.w, cc.w, d.w, g.w, relu, oa.w, ob.w, oc.w, od.w);
+        dx[b0] = oa; dx[b1] = ob; dx[b2] = oc; dx[b3] = od;
+    }
+}
+void launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C,
+                        int relu_mask, hipStream_t s)
+{
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(cap_blocks(total, 256)), dim3(256), 0, s,
+                       (const float4*)x, (const float4*)dy, (float4*)dx, N, H, W, C / 4, relu_mask);
+}
+
+// ---- block reduction helper --------------------------------------------------
+static __device__ __forceinline__ double block_sum(double v, double* sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    return t;   // valid in thread 0
+}
+
+// ---- K10: fused softmax cross-entropy (loss partial sums + dlogits) ---------
+constexpr int XENT_PIX_PER_BLOCK = 1024;
+int softmax_xent_blocks(long long npix)
+{
+    long long b = (npix + XENT_PIX_PER_BLOCK - 1) / XENT_PIX_PER_BLOCK;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+template <int C>   // C % 4 == 0: registers hold the pixel's logits
+__global__ __launch_bounds__(256) void softmax_xent_kernel_c(const float* logits, const uint8_t* labels,
+                                                             float* dlogits, double* partials,
+                                                             long long npix, float gscale)
+{
+    __shared__ double sh[4];
+    double lsum = 0;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix;
+         p += (long long)gridDim.x * blockDim.x) {
+        float v[C];
+        const float4* src = reinterpret_cast<const float4*>(logits + p * C);
+#pragma unroll
+        for (int i = 0; i < C / 4; ++i) { const float4 t = src[i]; v[4*i] = t.x; v[4*i+1] = t.y; v[4*i+2] = t.z; v[4*i+3] = t.w; }
+        float m = v[0];
+#pragma unroll
+        for (int i = 1; i < C; ++i) m = fmaxf(m, v[i]);
+        float e[C]; float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < C; ++i) { e[i] = expf(v[i] - m); s += e[i]; }
+        const int lab = labels[p];
+        float vl = 0.f;
+#pragma unroll
+        for (int i = 0; i < C; ++i) vl = (i == lab) ? v[i] : vl;
+        lsum += (double)(m + logf(s) - vl);
+        if (dlogits) {
+            const float inv = gscale / s;
+            float4* dst = reinterpret_cast<float4*>(dlogits + p * C);
+#pragma unroll
+            for (int i = 0; i < C / 4; ++i) {
+                float4 t;
+                t.x = e[4*i] * inv - ((4*i) == lab ? gscale : 0.f);
+                t.y = e[4*i+1] * inv - ((4*i+1) == lab ? gscale : 0.f);
+                t.z = e[4*i+2] * inv - ((4*i+2) == lab ? gscale : 0.f);
+                t.w = e[4*i+3] * inv - ((4*i+3) == lab ? gscale : 0.f);
+                dst[i] = t;
+            }
+        }
+    }
+    const double t = block_sum(lsum, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(256) void softmax_xent_kernel_any(const float* logits, const uint8_t* labels,
+                                                               float* dlogits, double* partials,
+                                                               long long npix, int C, float gscale)
+{
+    __shared__ double sh[4];
+    double lsum = 0;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix;
+         p += (long long)gridDim.x * blockDim.x) {
+        const float* l = logits + p * C;
+        float m = l[0];
+        for (int i = 1; i < C; ++i) m = fmaxf(m, l[i]);
+        float s = 0.f;
+        for (int i = 0; i < C; ++i) s += expf(l[i] - m);
+        const int lab = labels[p];
+        lsum += (double)(m + logf(s) - l[lab]);
+        if (dlogits) {
+            const float inv = gscale / s;
+            for (int i = 0; i < C; ++i) dlogits[p * C + i] = expf(l[i] - m) * inv - (i == lab ? gscale : 0.f);
+        }
+    }
+    const double t = block_sum(lsum, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+void launch_softmax_xent(const float* logits, const uint8_t* labels, float* dlogits, double* partials,
+                         long long npix, int C, float grad_scale, hipStream_t s)
+{
+    const int blocks = softmax_xent_blocks(npix);
+    if (C == 20)
+        hipLaunchKernelGGL(softmax_xent_kernel_c<20>, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, npix, grad_scale);
+    else if (C == 4)
+        hipLaunchKernelGGL(softmax_xent_kernel_c<4>, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, npix, grad_scale);
+    else
+        hipLaunchKernelGGL(softmax_xent_kernel_any, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, npix, C, grad_scale);
+}
+
+__global__ void finalize_loss_kernel(const double* partials, int nparts, long long npix, const float* regsum,
+                                     float rate, float* loss_out)
+{
+    __shared__ double sh[4];
+    double v = 0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) v += partials[i];
+    const double t = block_sum(v, sh);
+    if (threadIdx.x == 0) {
+        const float ce = (float)(t / (double)npix);
+        const float reg = regsum ? 0.5f * rate * regsum[0] : 0.f;
+        loss_out[0] = ce + reg;
+    }
+}
+void launch_finalize_loss(const double* partials, int nparts, long long npix, const float* regsum,
+                          float rate, float* loss_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(256), 0, s, partials, nparts, npix, regsum, rate, loss_out);
+}
+
+// ---- K13: softmax -> argmax (of the softmax output, lowest index on ties) ----
+__global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* logits, float* sm, long long* am,
+                                                             long long npix, int C)
+{
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix;
+         p += (long long)gridDim.x * blockDim.x) {
+        const float* l = logits + p * C;
+        float m = l[0];
+        for (int i = 1; i < C; ++i) m = fmaxf(m, l[i]);
+        float s = 0.f;
+        for (int i = 0; i < C; ++i) s += expf(l[i] - m);
+        int best = 0; float bv = -1.f;
+        for (int i = 0; i < C; ++i) {
+            const float v = expf(l[i] - m) / s;
+            if (sm) sm[p * C + i] = v;
+            if (v > bv) { bv = v; best = i; }
+        }
+        if (am) am[p] = best;
+    }
+}
+void launch_softmax_argmax(const float* logits, float* softmax_out, long long* argmax_out,
+                           long long npix, int C, hipStream_t s)
+{
+    hipLaunchKernelGGL(softmax_argmax_kernel, dim3(cap_blocks(npix, 256)), dim3(256), 0, s, logits,
+                       softmax_out, argmax_out, npix, C);
+}
+
+// ---- K14: confusion matrix conf[label*C + pred] += 1 --------------------------
+__global__ __launch_bounds__(256) void confusion_kernel(const uint8_t* labels, const long long* pred,
+                                                        long long npix, unsigned long long* conf, int C)
+{
+    extern __shared__ unsigned int hist[];
+    const int bins = C * C;
+    for (int i = threadIdx.x; i < bins; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix;
+         p += (long long)gridDim.x * blockDim.x) {
+        const int l = labels[p]; const int q = (int)pred[p];
+        if (l < C && q >= 0 && q < C) atomicAdd(&hist[l * C + q], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += blockDim.x)
+        if (hist[i]) atomicAdd(&conf[i], (unsigned long long)hist[i]);
+}
+void launch_confusion(const uint8_t* labels, const long long* pred, long long npix,
+                      unsigned long long* conf, int C, hipStream_t s)
+{
+    int blocks = cap_blocks(npix, 256 * 16);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(confusion_kernel, dim3(blocks), dim3(256), C * C * sizeof(unsigned int), s,
+                       labels, pred, npix, conf, C);
+}
+
+// ---- column sums (bias gradients): out[c] += sum_r x[r, c] --------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, float* out, long long rows, int C,
+                                                     long long rows_per_block)
+{
+    __shared__ float sh[256];
+    const int CT = C < 64 ? 32 : 64;              // column tile handled by this block
+    const int rgroups = 256 / CT;
+    const int c = blockIdx.y * CT + (threadIdx.x % CT);
+    const int rg = threadIdx.x / CT;
+    const long long r0 = blockIdx.x * rows_per_block;
+    const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+    float acc = 0.f;
+    if (c < C)
+        for (long long r = r0 + rg; r < r1; r += rgroups) acc += x[r * C + c];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        for (int g = 1; g < rgroups; ++g) acc += sh[g * CT + (threadIdx.x % CT)];
+        unsafeAtomicAdd(out + c, acc);
+    }
+}
+void launch_colsum(const float* x, float* out, long long rows, int C, hipStream_t s)
+{
+    const int CT = C < 64 ? 32 : 64;
+    const int ctiles = (C + CT - 1) / CT;
+    long long rblocks = (rows + 1023) / 1024;
+    const long long maxb = 2048 / ctiles > 0 ? 2048 / ctiles : 1;
+    if (rblocks > maxb) rblocks = maxb;
+    if (rblocks < 1) rblocks = 1;
+    const long long rpb = (rows + rblocks - 1) / rblocks;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)rblocks, ctiles), dim3(256), 0, s, x, out, rows, C, rpb);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, float* out, long long n)
+{
+    __shared__ double sh[4];
+    double v = 0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        v += (double)x[i] * x[i];
+    const double t = block_sum(v, sh);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, (float)t);
+}
+void launch_sumsq(const float* x, float* out, long long n, hipStream_t s)
+{
+    hipLaunchKernelGGL(sumsq_kernel, dim3(cap_blocks(n, 1024)), dim3(256), 0, s, x, out, n);
+}
+
+__global__ void axpy_kernel(float* y, const float* x, float a, long long n)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] += a * x[i];
+}
+void launch_axpy(float* y, const float* x, float a, long long n, hipStream_t s)
+{
+    hipLaunchKernelGGL(axpy_kernel, dim3(cap_blocks(n, 256)), dim3(256), 0, s, y, x, a, n);
+}
+
+// ---- K12: optimizers over the flat buffers -------------------------------------
+__global__ __launch_bounds__(256) void tf_adam_kernel(float4* theta, const float4* g, float4* m, float4* v,
+                                                      long long n4, float lr_t, float b1, float b2, float eps,
+                                                      float gs)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 t = theta[i], gg = g[i], mm = m[i], vv = v[i];
+#define ADAM1(F) { const float gr = gg.F * gs; mm.F = b1 * mm.F + (1.f - b1) * gr; vv.F = b2 * vv.F + (1.f - b2) * gr * gr; \
+                   t.F -= lr_t * mm.F / (sqrtf(vv.F) + eps); }
+        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+        theta[i] = t; m[i] = mm; v[i] = vv;
+    }
+}
+__global__ void tf_adam_tail_kernel(float* theta, const float* g, float* m, float* v, long long n0, long long n,
+                                    float lr_t, float b1, float b2, float eps, float gs)
+{
+    const long long i = n0 + threadIdx.x;
+    if (i < n) {
+        const float gr = g[i] * gs;
+        m[i] = b1 * m[i] + (1.f - b1) * gr; v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
+        theta[i] -= lr_t * m[i] / (sqrtf(v[i]) + eps);
+    }
+}
+void launch_tf_adam(float* theta, const float* g, float* m, float* v, long long n,
+                    float lr_t, float b1, float b2, float eps, float gscale, hipStream_t s)
+{
+    const long long n4 = n / 4;
+    if (n4 > 0)
+        hipLaunchKernelGGL(tf_adam_kernel, dim3(cap_blocks(n4, 256)), dim3(256), 0, s, (float4*)theta, (const float4*)g,
+                           (float4*)m, (float4*)v, n4, lr_t, b1, b2, eps, gscale);
+    if (n4 * 4 < n)
+        hipLaunchKernelGGL(tf_adam_tail_kernel, dim3(1), dim3(4), 0, s, theta, g, m, v, n4 * 4, n, lr_t, b1, b2, eps, gscale);
+}
+__global__ __launch_bounds__(256) void sgd_momentum_kernel(float* theta, const float* g, float* buf, long long n,
+                                                           float lr, float mom, float gs)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float b = mom * buf[i] + g[i] * gs;
+        buf[i] = b;
+        theta[i] -= lr * b;
+    }
+}
+void launch_sgd_momentum(float* theta, const float* g, float* buf, long long n, float lr, float mom, float gscale, hipStream_t s)
+{
+    hipLaunchKernelGGL(sgd_momentum_kernel, dim3(cap_blocks(n, 256)), dim3(256), 0, s, theta, g, buf, n, lr, mom, gscale);
+}
+
+// ---- weight re-layouts ---------------------------------------------------------
+// wt[T-1-t][co][ci] = w[t][ci][co]   (data-gradient weights of a SAME conv)
+__global__ void flip_transpose_kernel(const float* w, float* wt, int taps, int Cin, int Cout)
+{
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+    const float* src = w + (long long)t * Cin * Cout;
+    float* dst = wt + (long long)(taps - 1 - t) * Cin * Cout;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int ci = ci0 + r, co = co0 + threadIdx.x;
+        tile[r][threadIdx.x] = (ci < Cin && co < Cout) ? src[(long long)ci * Cout + co] : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int co = co0 + r, ci = ci0 + threadIdx.x;
+        if (co < Cout && ci < Cin) dst[(long long)co * Cin + ci] = tile[threadIdx.x][r];
+    }
+}
+void launch_flip_transpose(const float* w, float* wt, int taps, int Cin, int Cout, hipStream_t s)
+{
+    dim3 grid((Cout + 31) / 32, (Cin + 31) / 32, taps);
+    hipLaunchKernelGGL(flip_transpose_kernel, grid, dim3(32, 8), 0, s, w, wt, taps, Cin, Cout);
+}
+// w4[t][ci<Cinp][co] = ci < Cin ? w[t][ci][co] : 0
+__global__ void pad_cin_kernel(const float* w, float* w4, int taps, int Cin, int Cinp, int Cout)
+{
+    const long long total = (long long)taps * Cinp * Cout;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        const int ci = (int)((i / Cout) % Cinp);
+        const int t = (int)(i / ((long long)Cout * Cinp));
+        w4[i] = ci < Cin ? w[((long long)t * Cin + ci) * Cout + co] : 0.f;
+    }
+}
+void launch_pad_cin(const float* w, float* w4, int taps, int Cin, int Cinp, int Cout, hipStream_t s)
+{
+    hipLaunchKernelGGL(pad_cin_kernel, dim3(cap_blocks((long long)taps * Cinp * Cout, 256)), dim3(256), 0, s, w, w4, taps, Cin, Cinp, Cout);
+}
+// wp[(py*S+px)][(t*2+v)][ci][co] = w[py+S*t][px+S*v][co][ci]   (K = 2S)
+__global__ void tconv_phase_pack_kernel(const float* w, float* wp, int K, int S, int C)
+{
+    const long long total = (long long)S * S * 4 * C * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % C);
+        const int ci = (int)((i / C) % C);
+        const int tv = (int)((i / ((long long)C * C)) % 4);
+        const int ph = (int)(i / ((long long)C * C * 4));
+        const int py = ph / S, px = ph % S, t = tv / 2, v = tv % 2;
+        const int ky = py + S * t, kx = px + S * v;
+        wp[i] = w[(((long long)ky * K + kx) * C + co) * C + ci];
+    }
+}
+void launch_tconv_phase_pack(const float* w, float* wp, int K, int S, int C, hipStream_t s)
+{
+    hipLaunchKernelGGL(tconv_phase_pack_kernel, dim3(cap_blocks((long long)S * S * 4 * C * C, 256)), dim3(256), 0, s, w, wp, K, S, C);
+}
+
+__global__ void dropout_mask_kernel(float* mask, long long n, float keep, unsigned long long seed, unsigned int stream)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        mask[i] = philox_uniform((unsigned long long)i, seed, stream) < keep ? 1.f : 0.f;
+}
+void launch_dropout_mask(float* mask, long long n, float keep_prob, unsigned long long seed, unsigned int stream_id, hipStream_t s)
+{
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(cap_blocks(n, 256)), dim3(256), 0, s, mask, n, keep_prob, seed, stream_id);
+}
+
+// Box-Muller normal; truncated: redraw beyond 2 sigma (tf.truncated_normal_initializer)
+__global__ void init_normal_kernel(float* w, long long n, float stddev, int truncated, unsigned long long seed, unsigned int stream)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float z = 0.f;
+        for (int attempt = 0; attempt < 16; ++attempt) {
+            const float u1 = philox_uniform((unsigned long long)i * 32 + 2 * attempt, seed, stream);
+            const float u2 = philox_uniform((unsigned long long)i * 32 + 2 * attempt + 1, seed, stream);
+            z = sqrtf(-2.f * logf(fmaxf(u1, 1e-12f))) * cosf(6.28318530718f * u2);
+            if (!truncated || fabsf(z) <= 2.f) break;
+        }
+        w[i] = z * stddev;
+    }
+}
+void launch_init_normal(float* w, long long n, float stddev, int truncated, unsigned long long seed, unsigned int stream_id, hipStream_t s)
+{
+    hipLaunchKernelGGL(init_normal_kernel, dim3(cap_blocks(n, 256)), dim3(256), 0, s, w, n, stddev, truncated, seed, stream_id);
+}
+
+}  // namespace fcn8s

@@ -1,0 +1,111 @@
+// Internal launcher interface shared by the HIP translation units.
+// gfx950 only.  All pointers are device pointers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fcn8s {
+
+// ---------------------------------------------------------------------------
+// Implicit-GEMM convolution on the f32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+//   Y[m, j] = epilogue( alpha * sum_{tap, c} X[src(m, tap), c] * W[tap*Cin + c, j] )
+//
+// m runs over an (N, Ma, Mb) grid.  src(m,tap) = (n, in_scale*a + dy, in_scale*b + dx),
+// (dy,dx) = (ty,tx)*tap_step + tap_off, zero outside [0,Hi)x[0,Wi).
+// The output row of m is pixel (n, out_scale*a + out_offy, out_scale*b + out_offx)
+// of an (N,Ho,Wo,ldy) tensor; rows falling outside are not stored.
+// gridDim.z enumerates "phases" (transposed-conv sub-pixel phases): phase z uses
+// weights w + z*w_phase_stride and adds (z / phases_x, z % phases_x) to the output offsets.
+// One parameterisation therefore covers: 3x3 / 7x7 / 1x1 SAME convs, their data
+// gradients (flipped+transposed weights), the strided conv that is the data
+// gradient of a transposed conv, and the transposed conv itself (s*s phases of 2x2 convs).
+// ---------------------------------------------------------------------------
+struct IgemmArgs {
+    const float* x; const float* w; const float* bias; const float* addend; const float* mask;
+    float* y;
+    int N, Ma, Mb; long long M;
+    int Hi, Wi, Cin, ldx;
+    int KW, in_scale, tap_step, tap_off, Ktot;
+    int Ho, Wo, Cout, ldy;
+    int out_scale, out_offy, out_offx;
+    int phases_x; long long w_phase_stride;
+    float alpha; int relu; float mask_scale;
+    int dropout; float keep_prob; unsigned long long seed; unsigned int stream_id;
+};
+void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// Weight-gradient GEMM on the f32 MFMA:
+//   C[tap][i][j] += alpha * sum_p A[srcA(p, tap), i] * B[p, j]
+// p runs over the (N, Pa, Pb) pixel grid of B; srcA = (n, a_scale*a + dy, a_scale*b + dx).
+// Split over p across gridDim.y with float atomics into a zero-initialised C.
+// ---------------------------------------------------------------------------
+struct WgradArgs {
+    const float* A; const float* B; float* C;
+    int N, Pa, Pb; long long P;
+    int Ha, Wa, Adim, lda, Areal;      // A tensor (N,Ha,Wa,lda); Adim channels loadable (mult of 4); Areal rows stored
+    int Bdim, ldb;                     // B tensor (N,Pa,Pb,ldb); Bdim channels (mult of 4)
+    int KW, a_scale, tap_off, ntaps;   // dy = ty + tap_off
+    int ldc;                           // C[tap] is [Areal][ldc]
+    float alpha;
+    float* colsum;                     // optional: colsum[j] += sum_p B[p,j]  (bias gradient), or nullptr
+};
+void launch_wgrad(const WgradArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// Element-wise / reduction kernels (HBM-bound)
+// ---------------------------------------------------------------------------
+void launch_preprocess(const void* img, int dtype, float* out4, long long npix, hipStream_t s);
+void launch_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t s);
+void launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C,
+                        int relu_mask, hipStream_t s);
+// partials: double[>= softmax_xent_blocks(npix)]
+int  softmax_xent_blocks(long long npix);
+void launch_softmax_xent(const float* logits, const uint8_t* labels, float* dlogits, double* partials,
+                         long long npix, int C, float grad_scale, hipStream_t s);
+// loss_out[0] = sum(partials)/npix + 0.5*rate*regsum[0]
+void launch_finalize_loss(const double* partials, int nparts, long long npix, const float* regsum,
+                          float rate, float* loss_out, hipStream_t s);
+void launch_softmax_argmax(const float* logits, float* softmax_out, long long* argmax_out,
+                           long long npix, int C, hipStream_t s);
+void launch_confusion(const uint8_t* labels, const long long* pred, long long npix,
+                      unsigned long long* conf, int C, hipStream_t s);
+void launch_colsum(const float* x, float* out, long long rows, int C, hipStream_t s);      // out[c] += sum_r x[r,c]
+void launch_sumsq(const float* x, float* out, long long n, hipStream_t s);                  // out[0] += sum x^2
+void launch_axpy(float* y, const float* x, float a, long long n, hipStream_t s);           // y += a*x
+void launch_tf_adam(float* theta, const float* g, float* m, float* v, long long n,
+                    float lr_t, float b1, float b2, float eps, float gscale, hipStream_t s);
+void launch_sgd_momentum(float* theta, const float* g, float* buf, long long n,
+                         float lr, float mom, float gscale, hipStream_t s);
+// weight re-layouts (run once per step, tiny next to the convs)
+void launch_flip_transpose(const float* w, float* wt, int taps, int Cin, int Cout, hipStream_t s); // wt[T-1-t][co][ci] = w[t][ci][co]
+void launch_pad_cin(const float* w, float* w4, int taps, int Cin, int Cinp, int Cout, hipStream_t s);
+void launch_tconv_phase_pack(const float* w, float* wp, int K, int S, int C, hipStream_t s);
+void launch_dropout_mask(float* mask, long long n, float keep_prob, unsigned long long seed,
+                         unsigned int stream_id, hipStream_t s);
+void launch_init_normal(float* w, long long n, float stddev, int truncated, unsigned long long seed,
+                        unsigned int stream_id, hipStream_t s);
+
+// counter-based RNG shared by the fused dropout epilogue and the mask dump
+__host__ __device__ inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+__host__ __device__ inline uint32_t philox_u32(unsigned long long idx, unsigned long long seed, uint32_t stream)
+{
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = stream, c3 = 0x9E3779B9u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+__host__ __device__ inline float philox_uniform(unsigned long long idx, unsigned long long seed, uint32_t stream)
+{
+    return (float)(philox_u32(idx, seed, stream) >> 8) * (1.0f / 16777216.0f);   // [0,1)
+}
+
+}  // namespace fcn8s

@@ -1,0 +1,376 @@
+// Implicit-GEMM convolution kernels for gfx950 on the exact-f32 matrix core
+// instruction v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD = the fp32 vector peak,
+// bit-for-bit an fmaf chain).  Two kernels carry 99.6 % of FCN-8s' FLOPs:
+//
+//   igemm_fwd_kernel   : forward conv / data gradient / transposed conv (phases)
+//   wgrad_kernel       : weight gradient (reduction over pixels, split-K + atomics)
+//
+// Data layout: NHWC activations, [tap][Cin][Cout] weights, so that
+//   * the A operand (pixels x channels) is staged into LDS as [row][k] with k
+//     contiguous (16-B global loads along channels, ds_read_b128 per lane row),
+//   * the B operand (k x cout) is staged as [k][col] (ds_read_b32, lanes = columns).
+// Block = 256 threads = 4 wave64; K is consumed 16 at a time (8 MFMA k-steps),
+// global->register->LDS double-buffered with one barrier per K-tile.
+#include "fcn8s_internal.h"
+
+namespace fcn8s {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ===========================================================================
+// forward / dgrad / transposed-conv implicit GEMM
+// ===========================================================================
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
+{
+    constexpr int BK = 16, LDA = 20, LDB = BN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_LD = BM * 4 / 256;
+    constexpr int B_F4 = 4 * BN;                 // float4 per B tile
+    constexpr int B_LD = (B_F4 + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(TM >= 1 && TN >= 1, "tile");
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDA + 2 * BK * LDB];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int pz = blockIdx.z;
+    const int pzy = pz / p.phases_x, pzx = pz - pzy * p.phases_x;
+    const float* __restrict__ Wp = p.w + (long long)pz * p.w_phase_stride;
+    const int offy = p.out_offy + pzy, offx = p.out_offx + pzx;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int MaMb = p.Ma * p.Mb;
+
+    long long a_base[A_LD];
+    int a_iy[A_LD], a_ix[A_LD];
+    bool a_ok[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int row = (tid + i * 256) >> 2;
+        const long long m = m0 + row;
+        a_ok[i] = m < p.M;
+        const long long mm = a_ok[i] ? m : 0;
+        const int n = (int)(mm / MaMb);
+        const int r = (int)(mm - (long long)n * MaMb);
+        const int a = r / p.Mb, b = r - a * p.Mb;
+        a_iy[i] = a * p.in_scale; a_ix[i] = b * p.in_scale;
+        a_base[i] = (long long)n * p.Hi * p.Wi;
+    }
+    const int a_c4 = (tid & 3) * 4;
+
+    float4 ra[A_LD], rb[B_LD];
+    auto gload = [&](int kt) {
+        const int kg = kt * BK + a_c4;
+        const bool kok = kg < p.Ktot;
+        const int tap = kg / p.Cin, ci = kg - tap * p.Cin;
+        const int ty = tap / p.KW, tx = tap - ty * p.KW;
+        const int dy = ty * p.tap_step + p.tap_off, dx = tx * p.tap_step + p.tap_off;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+            const bool ok = a_ok[i] && kok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            ra[i] = ok ? ldg4(p.x + (a_base[i] + (long long)iy * p.Wi + ix) * p.ldx + ci)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int f = tid + i * 256;
+            const int k = f / (BN / 4), j = (f - k * (BN / 4)) * 4;
+            const int kg2 = kt * BK + k, col = n0 + j;
+            const bool ok = (B_F4 % 256 == 0 || f < B_F4) && kg2 < p.Ktot && col < p.Cout;
+            rb[i] = ok ? ldg4(Wp + (long long)kg2 * p.Cout + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int row = (tid + i * 256) >> 2;
+            *reinterpret_cast<float4*>(&As[buf * BM * LDA + row * LDA + a_c4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int f = tid + i * 256;
+            if (B_F4 % 256 == 0 || f < B_F4) {
+                const int k = f / (BN / 4), j = (f - k * (BN / 4)) * 4;
+                *reinterpret_cast<float4*>(&Bs[buf * BK * LDB + k * LDB + j]) = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const float* A = As + buf * BM * LDA + (wm * TM * 32 + (lane & 31)) * LDA + (lane >> 5) * 4;
+        const float* B = Bs + buf * BK * LDB + ((lane >> 5) * 4) * LDB + wn * TN * 32 + (lane & 31);
+#pragma unroll
+        for (int kk2 = 0; kk2 < 2; ++kk2) {
+            float4 af[TM];
+            float bf[TN][4];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) af[tm] = *reinterpret_cast<const float4*>(A + tm * 32 * LDA + kk2 * 8);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[tn][j] = B[(kk2 * 8 + j) * LDB + tn * 32];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const float av = j == 0 ? af[tm].x : j == 1 ? af[tm].y : j == 2 ? af[tm].z : af[tm].w;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[tn][j], acc[tm][tn], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    const int nkt = (p.Ktot + BK - 1) / BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) gload(kt + 1);
+        compute(cur);
+        if (kt + 1 < nkt) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: row -> output offset table in LDS, then fused bias/add/relu/mask/dropout
+    long long* rowoff = reinterpret_cast<long long*>(smem);
+    if (tid < BM) {
+        const long long m = m0 + tid;
+        long long off = -1;
+        if (m < p.M) {
+            const int n = (int)(m / MaMb);
+            const int r = (int)(m - (long long)n * MaMb);
+            const int a = r / p.Mb, b = r - a * p.Mb;
+            const int oy = a * p.out_scale + offy, ox = b * p.out_scale + offx;
+            if ((unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo)
+                off = (((long long)n * p.Ho + oy) * p.Wo + ox) * p.ldy;
+        }
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
+        if (col >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const long long off = rowoff[row];
+                if (off < 0) continue;
+                float v = acc[tm][tn][r] * p.alpha + bv;
+                if (p.addend) v += p.addend[off + col];
+                if (p.relu) v = v > 0.f ? v : 0.f;
+                if (p.mask) v = p.mask[off + col] > 0.f ? v * p.mask_scale : 0.f;
+                if (p.dropout) {
+                    const float u = philox_uniform((unsigned long long)(off + col), p.seed, p.stream_id);
+                    v = u < p.keep_prob ? v / p.keep_prob : 0.f;
+                }
+                p.y[off + col] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_igemm_cfg(const IgemmArgs& a, int phases, hipStream_t s)
+{
+    dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN), (unsigned)phases);
+    hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
+}
+
+void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s)
+{
+    if (a.Cout <= 32)      launch_igemm_cfg<128, 32, 4, 1>(a, phases, s);
+    else if (a.Cout <= 64) launch_igemm_cfg<128, 64, 2, 2>(a, phases, s);
+    else                   launch_igemm_cfg<128, 128, 2, 2>(a, phases, s);
+}
+
+// ===========================================================================
+// weight gradient
+// ===========================================================================
+template <int BM, int BN, int WM, int WN, int WK>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int chunk)
+{
+    constexpr int BK = 16, LDA = BM, LDB = BN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_F4 = BK * BM / 4, B_F4 = BK * BN / 4;
+    constexpr int A_LD = (A_F4 + 255) / 256, B_LD = (B_F4 + 255) / 256;
+    static_assert(WM * WN * WK == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA + 2 * BK * LDB];
+    float* As = smem;
+    float* Bs = smem + 2 * BK * LDA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave / (WM * WN), wmn = wave % (WM * WN);
+    const int wm = wmn / WN, wn = wmn % WN;
+    const int ntj = (p.Bdim + BN - 1) / BN;
+    const int ti = blockIdx.x / ntj, tj = blockIdx.x - ti * ntj;
+    const int i0 = ti * BM, j0 = tj * BN;
+    const int tap = blockIdx.z;
+    const int ty = tap / p.KW, tx = tap - ty * p.KW;
+    const int dy = ty + p.tap_off, dx = tx + p.tap_off;
+    const long long pbeg = (long long)blockIdx.y * chunk;
+    const long long pend = (pbeg + chunk < p.P) ? pbeg + chunk : p.P;
+    const int PaPb = p.Pa * p.Pb;
+    const bool do_colsum = p.colsum != nullptr && tap == 0 && ti == 0 && wm == 0;
+
+    float4 ra[A_LD], rb[B_LD];
+    auto gload = [&](long long pk) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int f = tid + i * 256;
+            const int pix = f / (BM / 4), c = (f - pix * (BM / 4)) * 4;
+            const long long pp = pk + pix;
+            bool ok = (A_F4 % 256 == 0 || f < A_F4) && pp < pend && (i0 + c) < p.Adim;
+            long long off = 0;
+            if (ok) {
+                const int n = (int)(pp / PaPb);
+                const int r = (int)(pp - (long long)n * PaPb);
+                const int a = r / p.Pb, b = r - a * p.Pb;
+                const int iy = a * p.a_scale + dy, ix = b * p.a_scale + dx;
+                ok = (unsigned)iy < (unsigned)p.Ha && (unsigned)ix < (unsigned)p.Wa;
+                off = (((long long)n * p.Ha + iy) * p.Wa + ix) * p.lda + i0 + c;
+            }
+            ra[i] = ok ? ldg4(p.A + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int f = tid + i * 256;
+            const int pix = f / (BN / 4), c = (f - pix * (BN / 4)) * 4;
+            const long long pp = pk + pix;
+            const bool ok = (B_F4 % 256 == 0 || f < B_F4) && pp < pend && (j0 + c) < p.Bdim;
+            rb[i] = ok ? ldg4(p.B + pp * p.ldb + j0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int f = tid + i * 256;
+            if (A_F4 % 256 == 0 || f < A_F4) {
+                const int pix = f / (BM / 4), c = (f - pix * (BM / 4)) * 4;
+                *reinterpret_cast<float4*>(&As[buf * BK * LDA + pix * LDA + c]) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int f = tid + i * 256;
+            if (B_F4 % 256 == 0 || f < B_F4) {
+                const int pix = f / (BN / 4), c = (f - pix * (BN / 4)) * 4;
+                *reinterpret_cast<float4*>(&Bs[buf * BK * LDB + pix * LDB + c]) = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+    f32x16 accs[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[j][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+
+    auto compute = [&](int buf) {
+        const float* A = As + buf * BK * LDA + (lane >> 5) * LDA + wm * TM * 32 + (lane & 31);
+        const float* B = Bs + buf * BK * LDB + (lane >> 5) * LDB + wn * TN * 32 + (lane & 31);
+        constexpr int KK = 8 / WK;
+#pragma unroll
+        for (int q = 0; q < KK; ++q) {
+            const int kk = wk * KK + q;
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) af[tm] = A[kk * 2 * LDA + tm * 32];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bf[tn] = B[kk * 2 * LDB + tn * 32];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
+            if (do_colsum) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    accs[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(1.0f, bf[tn], accs[tn], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nkt = (int)((pend - pbeg + BK - 1) / BK);
+    if (nkt <= 0) return;
+    gload(pbeg);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) gload(pbeg + (long long)(kt + 1) * BK);
+        compute(cur);
+        if (kt + 1 < nkt) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* Ct = p.C + (long long)tap * p.Areal * p.ldc;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = j0 + wn * TN * 32 + tn * 32 + (lane & 31);
+        if (col >= p.Bdim) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < p.Areal) unsafeAtomicAdd(Ct + (long long)row * p.ldc + col, acc[tm][tn][r] * p.alpha);
+            }
+        if (do_colsum && lane < 32) unsafeAtomicAdd(p.colsum + col, accs[tn][0]);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int WK>
+static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
+{
+    const int nti = (a.Adim + BM - 1) / BM, ntj = (a.Bdim + BN - 1) / BN;
+    const long long tiles = (long long)nti * ntj * a.ntaps;
+    // split the pixel reduction so that ~8 blocks per CU are in flight
+    long long want = (2048 + tiles - 1) / tiles;
+    long long maxsplit = (a.P + 255) / 256;            // at least 256 pixels per block
+    if (want > maxsplit) want = maxsplit;
+    if (want < 1) want = 1;
+    long long chunk = (a.P + want - 1) / want;
+    chunk = (chunk + 15) / 16 * 16;
+    const int splits = (int)((a.P + chunk - 1) / chunk);
+    dim3 grid((unsigned)(nti * ntj), (unsigned)splits, (unsigned)a.ntaps);
+    hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK>), grid, dim3(256), 0, s, a, (int)chunk);
+}
+
+void launch_wgrad(const WgradArgs& a, hipStream_t s)
+{
+    const bool small_i = a.Adim <= 32, small_j = a.Bdim <= 32;
+    if (small_i && small_j)      launch_wgrad_cfg<32, 32, 1, 1, 4>(a, s);
+    else if (small_i)            launch_wgrad_cfg<32, 64, 1, 2, 2>(a, s);
+    else if (small_j)            launch_wgrad_cfg<64, 32, 2, 1, 2>(a, s);
+    else if (a.Adim <= 64 || a.Bdim <= 64) launch_wgrad_cfg<64, 64, 2, 2, 1>(a, s);
+    else                         launch_wgrad_cfg<128, 128, 2, 2, 1>(a, s);
+}
+
+}  // namespace fcn8s

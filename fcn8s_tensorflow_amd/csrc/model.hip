@@ -1,0 +1,1017 @@
+// Host side of libfcn8s_hip.so: the model handle (variables, HBM arena,
+// optimizer slots, metric accumulators) and the launch sequences that replace
+// the reference's three hot sess.run sites (fcn8s_tensorflow.py:554-572,
+// 685-689, 764-770).  Everything is enqueued on one HIP stream; the only host
+// synchronisations are the ones the reference's fetches imply (loss, metrics,
+// predictions).
+#include "../../include/fcn8s_hip.h"
+#include "fcn8s_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace fcn8s;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct ParamInfo {
+    std::string name;
+    int ndim;
+    int64_t shape[4];
+    size_t offset, numel;
+};
+
+struct ProfGroup {
+    std::string name;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    double flops = 0, bytes = 0;
+    int64_t launches = 0;
+};
+
+struct Act { float* p = nullptr; size_t n = 0; int H = 0, W = 0, C = 0; };
+
+const int kConvsPerBlock[5] = {2, 2, 3, 3, 3};
+
+}  // namespace
+
+struct fcn8s_model {
+    int C = 20, fc6k = 7, device = 0;
+    int widths[7] = {64, 128, 256, 512, 512, 4096, 4096};
+    uint64_t seed = 0;
+    std::vector<ParamInfo> params;
+    std::map<std::string, int> index;
+    size_t total = 0;
+    size_t bucket_off[FCN8S_NUM_BUCKETS] = {0, 0, 0}, bucket_n[FCN8S_NUM_BUCKETS] = {0, 0, 0};
+    float *d_params = nullptr, *d_grads = nullptr, *d_m = nullptr, *d_v = nullptr, *d_wt = nullptr;
+    bool own_params = false, own_grads = false;
+    float *d_w1pad = nullptr, *d_tph[3] = {nullptr, nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    int64_t step = 0;
+    // workspace for the current (N,H,W)
+    int N = 0, H = 0, W = 0;
+    char* arena = nullptr; size_t arena_bytes = 0;
+    std::map<std::string, Act> acts;
+    float *dlogits = nullptr, *da3 = nullptr, *da4 = nullptr, *ds7 = nullptr, *gskip3 = nullptr, *gskip4 = nullptr;
+    float *gbuf[2] = {nullptr, nullptr};
+    int gcur = 0;
+    void* d_images = nullptr; uint8_t* d_labels = nullptr;
+    float *d_loss = nullptr, *d_regsum = nullptr, *d_softmax = nullptr;
+    double* d_partials = nullptr; long long* d_pred = nullptr;
+    unsigned long long* d_conf = nullptr;
+    double loss_sum = 0; int64_t loss_cnt = 0;
+    float keep_prob = 1.f, l2_rate = 0.f;
+    uint32_t drop_stream = 0;
+    bool have_forward = false, have_loss = false, train_mode = false;
+    int next_bucket = 0;
+    const uint8_t* cur_labels = nullptr;
+    bool profile = false;
+    std::vector<ProfGroup> groups;
+    std::string err;
+};
+
+namespace {
+
+int fail(fcn8s_model* m, int code, const std::string& msg)
+{
+    if (m) m->err = msg;
+    g_last_error = msg;
+    return code;
+}
+#define HIPCHK(m, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+    return fail(m, e_ == hipErrorOutOfMemory ? FCN8S_ERR_OOM : FCN8S_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+void build_param_table(int C, const int widths[7], int fc6k, std::vector<ParamInfo>& out, size_t& total,
+                       size_t boff[3], size_t bn[3])
+{
+    out.clear();
+    size_t off = 0;
+    auto add = [&](const std::string& name, std::initializer_list<int64_t> shp) {
+        ParamInfo p; p.name = name; p.ndim = (int)shp.size(); p.numel = 1;
+        int i = 0; for (auto s : shp) { p.shape[i++] = s; p.numel *= (size_t)s; }
+        for (; i < 4; ++i) p.shape[i] = 1;
+        p.offset = off; off = align_up(off + p.numel, 64);   // 256-byte aligned tensors
+        out.push_back(p);
+    };
+    int cin = 3;
+    size_t conv4_start = 0, fc6_start = 0;
+    for (int b = 0; b < 5; ++b)
+        for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
+            char nm[32]; snprintf(nm, sizeof nm, "conv%d_%d", b + 1, i);
+            if (b == 3 && i == 1) conv4_start = off;
+            add(std::string(nm) + "/filter", {3, 3, cin, widths[b]});
+            add(std::string(nm) + "/biases", {widths[b]});
+            cin = widths[b];
+        }
+    fc6_start = off;
+    add("fc6/weights", {fc6k, fc6k, widths[4], widths[5]});
+    add("fc6/biases", {widths[5]});
+    add("fc7/weights", {1, 1, widths[5], widths[6]});
+    add("fc7/biases", {widths[6]});
+    add("pool3_1x1/kernel", {1, 1, widths[2], C});
+    add("pool3_1x1/bias", {C});
+    add("pool4_1x1/kernel", {1, 1, widths[3], C});
+    add("pool4_1x1/bias", {C});
+    add("fc7_1x1/kernel", {1, 1, widths[6], C});
+    add("fc7_1x1/bias", {C});
+    add("fc7_conv2d_trans/kernel", {4, 4, C, C});
+    add("fc7_conv2d_trans/bias", {C});
+    add("fc7_pool4_conv2d_trans/kernel", {4, 4, C, C});
+    add("fc7_pool4_conv2d_trans/bias", {C});
+    add("fc7_pool4_pool3_conv2d_trans/kernel", {16, 16, C, C});
+    add("fc7_pool4_pool3_conv2d_trans/bias", {C});
+    total = off;
+    // gradient buckets in backward-production order: {fc6.., decoder} | {conv4, conv5} | {conv1..conv3}
+    boff[0] = fc6_start;   bn[0] = total - fc6_start;
+    boff[1] = conv4_start; bn[1] = fc6_start - conv4_start;
+    boff[2] = 0;           bn[2] = conv4_start;
+}
+
+void resolve_cfg(const fcn8s_config* cfg, int& C, int widths[7], int& fc6k)
+{
+    static const int def[7] = {64, 128, 256, 512, 512, 4096, 4096};
+    C = cfg->num_classes;
+    fc6k = cfg->fc6_ksize > 0 ? cfg->fc6_ksize : 7;
+    for (int i = 0; i < 7; ++i) widths[i] = cfg->widths[i] > 0 ? cfg->widths[i] : def[i];
+}
+
+const ParamInfo& P(const fcn8s_model* m, const std::string& n) { return m->params[m->index.at(n)]; }
+float* Wp(fcn8s_model* m, const std::string& n) { return m->d_params + P(m, n).offset; }
+float* Gp(fcn8s_model* m, const std::string& n) { return m->d_grads + P(m, n).offset; }
+float* WTp(fcn8s_model* m, const std::string& n) { return m->d_wt + P(m, n).offset; }
+
+// ---- profiling wrappers -------------------------------------------------------
+int group_id(fcn8s_model* m, const char* name)
+{
+    for (size_t i = 0; i < m->groups.size(); ++i) if (m->groups[i].name == name) return (int)i;
+    ProfGroup g; g.name = name; m->groups.push_back(g);
+    return (int)m->groups.size() - 1;
+}
+struct ProfScope {
+    fcn8s_model* m; int gid = -1; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(fcn8s_model* m_, const char* group, double flops, double bytes) : m(m_)
+    {
+        if (!m->profile) return;
+        gid = group_id(m, group);
+        hipEventCreate(&a); hipEventCreate(&b);
+        hipEventRecord(a, m->stream);
+        m->groups[gid].flops += flops; m->groups[gid].bytes += bytes; m->groups[gid].launches += 1;
+    }
+    ~ProfScope()
+    {
+        if (gid < 0) return;
+        hipEventRecord(b, m->stream);
+        m->groups[gid].ev.emplace_back(a, b);
+    }
+};
+
+// ---- layer launchers ------------------------------------------------------------
+struct Epi { const float* bias = nullptr; const float* addend = nullptr; const float* mask = nullptr;
+             float alpha = 1.f; int relu = 0; float mask_scale = 1.f; int dropout = 0; float keep = 1.f;
+             uint32_t stream_id = 0; };
+
+// SAME conv (or its data gradient when `w` holds flipped+transposed weights)
+void conv_same(fcn8s_model* m, const char* group, const float* x, const float* w, float* y,
+               int N, int H, int W, int Cin, int Cout, int K, const Epi& e, hipStream_t s, int real_cin = 0)
+{
+    IgemmArgs a{};
+    a.x = x; a.w = w; a.bias = e.bias; a.addend = e.addend; a.mask = e.mask; a.y = y;
+    a.N = N; a.Ma = H; a.Mb = W; a.M = (long long)N * H * W;
+    a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldx = Cin;
+    a.KW = K; a.in_scale = 1; a.tap_step = 1; a.tap_off = -(K - 1) / 2; a.Ktot = K * K * Cin;
+    a.Ho = H; a.Wo = W; a.Cout = Cout; a.ldy = Cout;
+    a.out_scale = 1; a.out_offy = 0; a.out_offx = 0; a.phases_x = 1; a.w_phase_stride = 0;
+    a.alpha = e.alpha; a.relu = e.relu; a.mask_scale = e.mask_scale;
+    a.dropout = e.dropout; a.keep_prob = e.keep; a.seed = m ? m->seed : 0; a.stream_id = e.stream_id;
+    const double rc = real_cin ? real_cin : Cin;
+    const double flops = 2.0 * a.M * K * K * rc * Cout;
+    const double bytes = 4.0 * (a.M * rc + (double)a.M * Cout + (double)K * K * rc * Cout);
+    if (m) { ProfScope ps(m, group, flops, bytes); launch_igemm(a, 1, s); }
+    else launch_igemm(a, 1, s);
+}
+
+// transposed conv forward (k = 2s) as s*s phase-specific 2x2 convs; wp = phase-packed weights
+void tconv_fwd(fcn8s_model* m, const float* x, const float* wp, const float* bias, const float* addend,
+               float* y, int N, int Hi, int Wi, int C, int K, int S, hipStream_t s)
+{
+    IgemmArgs a{};
+    a.x = x; a.w = wp; a.bias = bias; a.addend = addend; a.mask = nullptr; a.y = y;
+    a.N = N; a.Ma = Hi + 1; a.Mb = Wi + 1; a.M = (long long)N * a.Ma * a.Mb;
+    a.Hi = Hi; a.Wi = Wi; a.Cin = C; a.ldx = C;
+    a.KW = 2; a.in_scale = 1; a.tap_step = -1; a.tap_off = 0; a.Ktot = 4 * C;
+    a.Ho = Hi * S; a.Wo = Wi * S; a.Cout = C; a.ldy = C;
+    a.out_scale = S; a.out_offy = -(K - S) / 2; a.out_offx = -(K - S) / 2;
+    a.phases_x = S; a.w_phase_stride = 4LL * C * C;
+    a.alpha = 1.f; a.relu = 0; a.mask_scale = 1.f; a.dropout = 0;
+    const double opix = (double)N * Hi * S * Wi * S;
+    if (m) { ProfScope ps(m, "tconv_fwd", 2.0 * opix * 4 * C * C, 4.0 * (opix * C * (addend ? 2 : 1) + (double)N * Hi * Wi * C)); launch_igemm(a, S * S, s); }
+    else launch_igemm(a, S * S, s);
+}
+
+// data gradient of the transposed conv = stride-S conv of dy with the natural [kh,kw,Cout,Cin] kernel
+void tconv_dgrad(fcn8s_model* m, const float* dy, const float* w, float* dx, int N, int Hi, int Wi, int C,
+                 int K, int S, hipStream_t s)
+{
+    IgemmArgs a{};
+    a.x = dy; a.w = w; a.y = dx;
+    a.N = N; a.Ma = Hi; a.Mb = Wi; a.M = (long long)N * Hi * Wi;
+    a.Hi = Hi * S; a.Wi = Wi * S; a.Cin = C; a.ldx = C;
+    a.KW = K; a.in_scale = S; a.tap_step = 1; a.tap_off = -(K - S) / 2; a.Ktot = K * K * C;
+    a.Ho = Hi; a.Wo = Wi; a.Cout = C; a.ldy = C;
+    a.out_scale = 1; a.phases_x = 1; a.alpha = 1.f; a.mask_scale = 1.f;
+    const double flops = 2.0 * a.M * K * K * C * C;
+    if (m) { ProfScope ps(m, "tconv_dgrad", flops, 4.0 * ((double)N * Hi * S * Wi * S * C + (double)a.M * C)); launch_igemm(a, 1, s); }
+    else launch_igemm(a, 1, s);
+}
+
+void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* dz, float* dw, float* db,
+                int N, int H, int W, int Cin, int Cout, int K, float alpha, hipStream_t s, int real_cin = 0)
+{
+    WgradArgs a{};
+    a.A = x; a.B = dz; a.C = dw;
+    a.N = N; a.Pa = H; a.Pb = W; a.P = (long long)N * H * W;
+    a.Ha = H; a.Wa = W; a.Adim = Cin; a.lda = Cin; a.Areal = real_cin ? real_cin : Cin;
+    a.Bdim = Cout; a.ldb = Cout;
+    a.KW = K; a.a_scale = 1; a.tap_off = -(K - 1) / 2; a.ntaps = K * K;
+    a.ldc = Cout; a.alpha = alpha; a.colsum = db;
+    const double rc = a.Areal;
+    const double flops = 2.0 * a.P * K * K * rc * Cout;
+    const double bytes = 4.0 * (a.P * rc + (double)a.P * Cout + (double)K * K * rc * Cout);
+    if (m) { ProfScope ps(m, group, flops, bytes); launch_wgrad(a, s); }
+    else launch_wgrad(a, s);
+}
+
+void tconv_wgrad(fcn8s_model* m, const float* x, const float* dy, float* dw, int N, int Hi, int Wi, int C,
+                 int K, int S, hipStream_t s)
+{
+    WgradArgs a{};
+    a.A = dy; a.B = x; a.C = dw;
+    a.N = N; a.Pa = Hi; a.Pb = Wi; a.P = (long long)N * Hi * Wi;
+    a.Ha = Hi * S; a.Wa = Wi * S; a.Adim = C; a.lda = C; a.Areal = C;
+    a.Bdim = C; a.ldb = C;
+    a.KW = K; a.a_scale = S; a.tap_off = -(K - S) / 2; a.ntaps = K * K;
+    a.ldc = C; a.alpha = 1.f; a.colsum = nullptr;
+    if (m) { ProfScope ps(m, "tconv_wgrad", 2.0 * a.P * K * K * C * C, 4.0 * ((double)N * Hi * S * Wi * S * C + (double)a.P * C)); launch_wgrad(a, s); }
+    else launch_wgrad(a, s);
+}
+
+// ---- workspace --------------------------------------------------------------------
+int ensure_workspace(fcn8s_model* m, int N, int H, int W)
+{
+    if (N <= 0) return fail(m, FCN8S_ERR_SHAPE, "batch size must be positive");
+    if (H <= 0 || W <= 0 || H % 32 || W % 32)
+        return fail(m, FCN8S_ERR_SHAPE, "image height and width must be positive multiples of 32 (five 2x2 pools, then x2, x2, x8 upsampling must line up with the skip connections)");
+    if (m->arena && m->N == N && m->H == H && m->W == W) return FCN8S_OK;
+    if (m->arena) { hipStreamSynchronize(m->stream); hipFree(m->arena); m->arena = nullptr; }
+    m->acts.clear();
+    m->have_forward = m->have_loss = false;
+    const int C = m->C;
+    struct Item { std::string name; size_t n; int h, w, c; float** extra; };
+    std::vector<Item> items;
+    auto add = [&](const std::string& nm, int h, int w, int c, float** extra = nullptr) {
+        items.push_back({nm, (size_t)N * h * w * c, h, w, c, extra});
+    };
+    add("x0", H, W, 4);
+    int h = H, w = W;
+    for (int b = 0; b < 5; ++b) {
+        for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
+            char nm[32]; snprintf(nm, sizeof nm, "conv%d_%d", b + 1, i);
+            add(nm, h, w, m->widths[b]);
+        }
+        h /= 2; w /= 2;
+        char nm[32]; snprintf(nm, sizeof nm, "pool%d", b + 1);
+        add(nm, h, w, m->widths[b]);
+    }
+    const int h5 = H / 32, w5 = W / 32, h4 = H / 16, w4 = W / 16, h3 = H / 8, w3 = W / 8;
+    add("fc6", h5, w5, m->widths[5]);
+    add("fc7", h5, w5, m->widths[6]);
+    add("s7", h5, w5, C); add("p4", h4, w4, C); add("p3", h3, w3, C);
+    add("a4", h4, w4, C); add("a3", h3, w3, C); add("logits", H, W, C);
+    add("dlogits", H, W, C, &m->dlogits);
+    add("da3", h3, w3, C, &m->da3); add("da4", h4, w4, C, &m->da4); add("ds7", h5, w5, C, &m->ds7);
+    add("gskip3", h3, w3, m->widths[2], &m->gskip3); add("gskip4", h4, w4, m->widths[3], &m->gskip4);
+    size_t gmax = (size_t)N * H * W * m->widths[0];
+    for (int b = 0, hh = H, ww = W; b < 5; ++b, hh /= 2, ww /= 2) {
+        size_t n = (size_t)N * hh * ww * m->widths[b]; if (n > gmax) gmax = n;
+    }
+    { size_t n = (size_t)N * h5 * w5 * (size_t)std::max(m->widths[5], m->widths[6]); if (n > gmax) gmax = n; }
+    items.push_back({"gbuf0", gmax, 0, 0, 0, &m->gbuf[0]});
+    items.push_back({"gbuf1", gmax, 0, 0, 0, &m->gbuf[1]});
+    items.push_back({"softmax", (size_t)N * H * W * C, H, W, C, &m->d_softmax});
+
+    size_t bytes = 0;
+    std::vector<size_t> offs;
+    for (auto& it : items) { offs.push_back(bytes); bytes = align_up(bytes + it.n * sizeof(float), 256); }
+    const size_t npix = (size_t)N * H * W;
+    const size_t o_img = bytes;  bytes = align_up(bytes + npix * 3 * sizeof(float), 256);
+    const size_t o_lab = bytes;  bytes = align_up(bytes + npix, 256);
+    const size_t o_pred = bytes; bytes = align_up(bytes + npix * sizeof(long long), 256);
+    const size_t o_part = bytes; bytes = align_up(bytes + 4096 * sizeof(double), 256);
+    hipError_t e = hipMalloc((void**)&m->arena, bytes);
+    if (e != hipSuccess) { m->arena = nullptr; return fail(m, FCN8S_ERR_OOM, std::string("workspace hipMalloc failed: ") + hipGetErrorString(e)); }
+    m->arena_bytes = bytes;
+    for (size_t i = 0; i < items.size(); ++i) {
+        float* p = (float*)(m->arena + offs[i]);
+        if (items[i].extra) *items[i].extra = p;
+        Act a; a.p = p; a.n = items[i].n; a.H = items[i].h; a.W = items[i].w; a.C = items[i].c;
+        m->acts[items[i].name] = a;
+    }
+    m->d_images = m->arena + o_img; m->d_labels = (uint8_t*)(m->arena + o_lab);
+    m->d_pred = (long long*)(m->arena + o_pred); m->d_partials = (double*)(m->arena + o_part);
+    m->N = N; m->H = H; m->W = W;
+    return FCN8S_OK;
+}
+
+float* A(fcn8s_model* m, const char* n) { return m->acts.at(n).p; }
+
+// ---- forward ------------------------------------------------------------------------
+int stage_inputs(fcn8s_model* m, const void* images, int dtype, const uint8_t* labels, int where,
+                 const void** img_dev, const uint8_t** lab_dev)
+{
+    const size_t npix = (size_t)m->N * m->H * m->W;
+    if (where == FCN8S_HOST) {
+        const size_t ib = npix * 3 * (dtype == FCN8S_IMG_U8 ? 1 : 4);
+        HIPCHK(m, hipMemcpyAsync(m->d_images, images, ib, hipMemcpyHostToDevice, m->stream));
+        *img_dev = m->d_images;
+        if (labels) {
+            HIPCHK(m, hipMemcpyAsync(m->d_labels, labels, npix, hipMemcpyHostToDevice, m->stream));
+            *lab_dev = m->d_labels;
+        } else *lab_dev = nullptr;
+    } else { *img_dev = images; *lab_dev = labels; }
+    return FCN8S_OK;
+}
+
+void prepare_forward_weights(fcn8s_model* m)
+{
+    hipStream_t s = m->stream;
+    launch_pad_cin(Wp(m, "conv1_1/filter"), m->d_w1pad, 9, 3, 4, m->widths[0], s);
+    launch_tconv_phase_pack(Wp(m, "fc7_conv2d_trans/kernel"), m->d_tph[0], 4, 2, m->C, s);
+    launch_tconv_phase_pack(Wp(m, "fc7_pool4_conv2d_trans/kernel"), m->d_tph[1], 4, 2, m->C, s);
+    launch_tconv_phase_pack(Wp(m, "fc7_pool4_pool3_conv2d_trans/kernel"), m->d_tph[2], 16, 8, m->C, s);
+}
+
+int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, bool train)
+{
+    hipStream_t s = m->stream;
+    const int N = m->N, H = m->H, W = m->W, C = m->C;
+    prepare_forward_weights(m);
+    { ProfScope ps(m, "preprocess", 0, (double)N * H * W * (16 + (dtype ? 12 : 3))); launch_preprocess(img_dev, dtype, A(m, "x0"), (long long)N * H * W, s); }
+    const float* x = A(m, "x0");
+    int h = H, w = W, cin = 4;
+    for (int b = 0; b < 5; ++b) {
+        for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
+            char nm[32]; snprintf(nm, sizeof nm, "conv%d_%d", b + 1, i);
+            const bool first = (b == 0 && i == 1);
+            Epi e; e.bias = Wp(m, std::string(nm) + "/biases"); e.relu = 1;
+            const float* wt = first ? m->d_w1pad : Wp(m, std::string(nm) + "/filter");
+            conv_same(m, first ? "conv1_1_fwd" : "conv3x3_fwd", x, wt, A(m, nm), N, h, w, cin, m->widths[b], 3, e, s, first ? 3 : 0);
+            x = A(m, nm); cin = m->widths[b];
+        }
+        char pn[32]; snprintf(pn, sizeof pn, "pool%d", b + 1);
+        { ProfScope ps(m, "maxpool_fwd", 0, 4.0 * N * h * w * cin * 1.25); launch_maxpool_fwd(x, A(m, pn), N, h, w, cin, s); }
+        x = A(m, pn); h /= 2; w /= 2;
+    }
+    const int h5 = h, w5 = w;
+    const bool drop = train && keep_prob < 1.f;
+    m->drop_stream = (uint32_t)(2 * m->step);
+    {
+        Epi e; e.bias = Wp(m, "fc6/biases"); e.relu = 1; e.dropout = drop; e.keep = keep_prob; e.stream_id = m->drop_stream;
+        conv_same(m, "fc6_fwd", x, Wp(m, "fc6/weights"), A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, e, s);
+    }
+    {
+        Epi e; e.bias = Wp(m, "fc7/biases"); e.relu = 1; e.dropout = drop; e.keep = keep_prob; e.stream_id = m->drop_stream + 1;
+        conv_same(m, "fc7_fwd", A(m, "fc6"), Wp(m, "fc7/weights"), A(m, "fc7"), N, h5, w5, m->widths[5], m->widths[6], 1, e, s);
+    }
+    // decoder (fcn8s_tensorflow.py:171-233)
+    { Epi e; e.bias = Wp(m, "pool3_1x1/bias"); e.alpha = 0.0001f;
+      conv_same(m, "score1x1_fwd", A(m, "pool3"), Wp(m, "pool3_1x1/kernel"), A(m, "p3"), N, H / 8, W / 8, m->widths[2], C, 1, e, s); }
+    { Epi e; e.bias = Wp(m, "pool4_1x1/bias"); e.alpha = 0.01f;
+      conv_same(m, "score1x1_fwd", A(m, "pool4"), Wp(m, "pool4_1x1/kernel"), A(m, "p4"), N, H / 16, W / 16, m->widths[3], C, 1, e, s); }
+    { Epi e; e.bias = Wp(m, "fc7_1x1/bias");
+      conv_same(m, "score1x1_fwd", A(m, "fc7"), Wp(m, "fc7_1x1/kernel"), A(m, "s7"), N, h5, w5, m->widths[6], C, 1, e, s); }
+    tconv_fwd(m, A(m, "s7"), m->d_tph[0], Wp(m, "fc7_conv2d_trans/bias"), A(m, "p4"), A(m, "a4"), N, h5, w5, C, 4, 2, s);
+    tconv_fwd(m, A(m, "a4"), m->d_tph[1], Wp(m, "fc7_pool4_conv2d_trans/bias"), A(m, "p3"), A(m, "a3"), N, H / 16, W / 16, C, 4, 2, s);
+    tconv_fwd(m, A(m, "a3"), m->d_tph[2], Wp(m, "fc7_pool4_pool3_conv2d_trans/bias"), nullptr, A(m, "logits"), N, H / 8, W / 8, C, 16, 8, s);
+    m->have_forward = true; m->train_mode = train; m->keep_prob = keep_prob;
+    return FCN8S_OK;
+}
+
+const char* kDecoderKernels[6] = {"pool3_1x1/kernel", "pool4_1x1/kernel", "fc7_1x1/kernel", "fc7_conv2d_trans/kernel",
+                                  "fc7_pool4_conv2d_trans/kernel", "fc7_pool4_pool3_conv2d_trans/kernel"};
+
+int compute_loss(fcn8s_model* m, const uint8_t* lab_dev, float l2_rate, bool with_grad)
+{
+    hipStream_t s = m->stream;
+    const long long npix = (long long)m->N * m->H * m->W;
+    const int nb = softmax_xent_blocks(npix);
+    { ProfScope ps(m, "softmax_xent", 0, (double)npix * (m->C * 4 * (with_grad ? 2 : 1) + 1));
+      launch_softmax_xent(A(m, "logits"), lab_dev, with_grad ? m->dlogits : nullptr, m->d_partials, npix, m->C, 1.0f / (float)npix, s); }
+    const float* reg = nullptr;
+    if (l2_rate != 0.f) {
+        hipMemsetAsync(m->d_regsum, 0, sizeof(float), s);
+        for (auto k : kDecoderKernels) launch_sumsq(Wp(m, k), m->d_regsum, (long long)P(m, k).numel, s);
+        reg = m->d_regsum;
+    }
+    launch_finalize_loss(m->d_partials, nb, npix, reg, l2_rate, m->d_loss, s);
+    m->l2_rate = l2_rate; m->have_loss = true;
+    return FCN8S_OK;
+}
+
+// ---- backward --------------------------------------------------------------------------
+void prepare_backward_weights(fcn8s_model* m)
+{
+    hipStream_t s = m->stream;
+    ProfScope ps(m, "weight_relayout", 0, 8.0 * m->total);
+    int cin = 3;
+    for (int b = 0; b < 5; ++b)
+        for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
+            char nm[32]; snprintf(nm, sizeof nm, "conv%d_%d/filter", b + 1, i);
+            if (!(b == 0 && i == 1)) launch_flip_transpose(Wp(m, nm), WTp(m, nm), 9, cin, m->widths[b], s);
+            cin = m->widths[b];
+        }
+    launch_flip_transpose(Wp(m, "fc6/weights"), WTp(m, "fc6/weights"), m->fc6k * m->fc6k, m->widths[4], m->widths[5], s);
+    launch_flip_transpose(Wp(m, "fc7/weights"), WTp(m, "fc7/weights"), 1, m->widths[5], m->widths[6], s);
+    launch_flip_transpose(Wp(m, "pool3_1x1/kernel"), WTp(m, "pool3_1x1/kernel"), 1, m->widths[2], m->C, s);
+    launch_flip_transpose(Wp(m, "pool4_1x1/kernel"), WTp(m, "pool4_1x1/kernel"), 1, m->widths[3], m->C, s);
+    launch_flip_transpose(Wp(m, "fc7_1x1/kernel"), WTp(m, "fc7_1x1/kernel"), 1, m->widths[6], m->C, s);
+}
+
+void l2_grad(fcn8s_model* m, const char* kernel)
+{
+    if (m->l2_rate != 0.f) launch_axpy(Gp(m, kernel), Wp(m, kernel), m->l2_rate, (long long)P(m, kernel).numel, m->stream);
+}
+
+void backward_bucket0(fcn8s_model* m)
+{
+    hipStream_t s = m->stream;
+    const int N = m->N, H = m->H, W = m->W, C = m->C;
+    const int h5 = H / 32, w5 = W / 32, h4 = H / 16, w4 = W / 16, h3 = H / 8, w3 = W / 8;
+    const float inv_keep = (m->train_mode && m->keep_prob < 1.f) ? 1.f / m->keep_prob : 1.f;
+    hipMemsetAsync(m->d_grads, 0, m->total * sizeof(float), s);
+    prepare_backward_weights(m);
+    // logits = tconv16x16s8(a3)
+    tconv_wgrad(m, A(m, "a3"), m->dlogits, Gp(m, "fc7_pool4_pool3_conv2d_trans/kernel"), N, h3, w3, C, 16, 8, s);
+    { ProfScope ps(m, "bias_grad", 0, 4.0 * N * H * W * C); launch_colsum(m->dlogits, Gp(m, "fc7_pool4_pool3_conv2d_trans/bias"), (long long)N * H * W, C, s); }
+    tconv_dgrad(m, m->dlogits, Wp(m, "fc7_pool4_pool3_conv2d_trans/kernel"), m->da3, N, h3, w3, C, 16, 8, s);
+    l2_grad(m, "fc7_pool4_pool3_conv2d_trans/kernel");
+    // a3 = tconv4x4s2(a4) + p3 ; p3 = conv1x1(pool3 * 1e-4)
+    conv_wgrad(m, "score1x1_wgrad", A(m, "pool3"), m->da3, Gp(m, "pool3_1x1/kernel"), Gp(m, "pool3_1x1/bias"), N, h3, w3, m->widths[2], C, 1, 0.0001f, s);
+    l2_grad(m, "pool3_1x1/kernel");
+    { Epi e; e.alpha = 0.0001f; conv_same(m, "score1x1_dgrad", m->da3, WTp(m, "pool3_1x1/kernel"), m->gskip3, N, h3, w3, C, m->widths[2], 1, e, s); }
+    tconv_wgrad(m, A(m, "a4"), m->da3, Gp(m, "fc7_pool4_conv2d_trans/kernel"), N, h4, w4, C, 4, 2, s);
+    launch_colsum(m->da3, Gp(m, "fc7_pool4_conv2d_trans/bias"), (long long)N * h3 * w3, C, s);
+    tconv_dgrad(m, m->da3, Wp(m, "fc7_pool4_conv2d_trans/kernel"), m->da4, N, h4, w4, C, 4, 2, s);
+    l2_grad(m, "fc7_pool4_conv2d_trans/kernel");
+    // a4 = tconv4x4s2(s7) + p4 ; p4 = conv1x1(pool4 * 1e-2)
+    conv_wgrad(m, "score1x1_wgrad", A(m, "pool4"), m->da4, Gp(m, "pool4_1x1/kernel"), Gp(m, "pool4_1x1/bias"), N, h4, w4, m->widths[3], C, 1, 0.01f, s);
+    l2_grad(m, "pool4_1x1/kernel");
+    { Epi e; e.alpha = 0.01f; conv_same(m, "score1x1_dgrad", m->da4, WTp(m, "pool4_1x1/kernel"), m->gskip4, N, h4, w4, C, m->widths[3], 1, e, s); }
+    tconv_wgrad(m, A(m, "s7"), m->da4, Gp(m, "fc7_conv2d_trans/kernel"), N, h5, w5, C, 4, 2, s);
+    launch_colsum(m->da4, Gp(m, "fc7_conv2d_trans/bias"), (long long)N * h4 * w4, C, s);
+    tconv_dgrad(m, m->da4, Wp(m, "fc7_conv2d_trans/kernel"), m->ds7, N, h5, w5, C, 4, 2, s);
+    l2_grad(m, "fc7_conv2d_trans/kernel");
+    // s7 = conv1x1(fc7)
+    conv_wgrad(m, "score1x1_wgrad", A(m, "fc7"), m->ds7, Gp(m, "fc7_1x1/kernel"), Gp(m, "fc7_1x1/bias"), N, h5, w5, m->widths[6], C, 1, 1.f, s);
+    l2_grad(m, "fc7_1x1/kernel");
+    { Epi e; e.mask = A(m, "fc7"); e.mask_scale = inv_keep;
+      conv_same(m, "score1x1_dgrad", m->ds7, WTp(m, "fc7_1x1/kernel"), m->gbuf[0], N, h5, w5, C, m->widths[6], 1, e, s); }
+    // fc7
+    conv_wgrad(m, "fc7_wgrad", A(m, "fc6"), m->gbuf[0], Gp(m, "fc7/weights"), Gp(m, "fc7/biases"), N, h5, w5, m->widths[5], m->widths[6], 1, 1.f, s);
+    { Epi e; e.mask = A(m, "fc6"); e.mask_scale = inv_keep;
+      conv_same(m, "fc7_dgrad", m->gbuf[0], WTp(m, "fc7/weights"), m->gbuf[1], N, h5, w5, m->widths[6], m->widths[5], 1, e, s); }
+    // fc6
+    conv_wgrad(m, "fc6_wgrad", A(m, "pool5"), m->gbuf[1], Gp(m, "fc6/weights"), Gp(m, "fc6/biases"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, 1.f, s);
+    { Epi e; conv_same(m, "fc6_dgrad", m->gbuf[1], WTp(m, "fc6/weights"), m->gbuf[0], N, h5, w5, m->widths[5], m->widths[4], m->fc6k, e, s); }
+    m->gcur = 0;   // gbuf[0] holds d(pool5)
+}
+
+// blocks [b_hi .. b_lo] (1-based VGG block numbers), going backwards
+void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
+{
+    hipStream_t s = m->stream;
+    const int N = m->N;
+    for (int b = b_hi; b >= b_lo; --b) {
+        const int h = m->H >> (b - 1), w = m->W >> (b - 1);      // resolution of this block's convs
+        const int cw = m->widths[b - 1];
+        const int nconv = kConvsPerBlock[b - 1];
+        char last[32]; snprintf(last, sizeof last, "conv%d_%d", b, nconv);
+        // d(pool_b) in gbuf[gcur] -> dZ of the last conv (ReLU mask fused)
+        { ProfScope ps(m, "maxpool_bwd", 0, 4.0 * N * h * w * cw * 2.25);
+          launch_maxpool_bwd(A(m, last), m->gbuf[m->gcur], m->gbuf[m->gcur ^ 1], N, h, w, cw, 1, s); }
+        m->gcur ^= 1;
+        for (int i = nconv; i >= 1; --i) {
+            char nm[32]; snprintf(nm, sizeof nm, "conv%d_%d", b, i);
+            const float* dz = m->gbuf[m->gcur];
+            const float* xin; int cin; int real_cin = 0;
+            char inname[32];
+            if (i > 1) { snprintf(inname, sizeof inname, "conv%d_%d", b, i - 1); xin = A(m, inname); cin = cw; }
+            else if (b > 1) { snprintf(inname, sizeof inname, "pool%d", b - 1); xin = A(m, inname); cin = m->widths[b - 2]; }
+            else { xin = A(m, "x0"); cin = 4; real_cin = 3; }
+            const bool first = (b == 1 && i == 1);
+            conv_wgrad(m, first ? "conv1_1_wgrad" : "conv3x3_wgrad", xin, dz, Gp(m, std::string(nm) + "/filter"), Gp(m, std::string(nm) + "/biases"),
+                       N, h, w, cin, cw, 3, 1.f, s, real_cin);
+            if (first) break;
+            Epi e;
+            if (i > 1) { e.mask = xin; e.mask_scale = 1.f; }               // ReLU of the previous conv
+            else if (b == 5) e.addend = m->gskip4;                        // d(pool4) also receives the pool4_1x1 path
+            else if (b == 4) e.addend = m->gskip3;                        // d(pool3) also receives the pool3_1x1 path
+            conv_same(m, "conv3x3_dgrad", dz, WTp(m, std::string(nm) + "/filter"), m->gbuf[m->gcur ^ 1], N, h, w, cw, cin, 3, e, s);
+            m->gcur ^= 1;
+        }
+    }
+}
+
+int do_backward_bucket(fcn8s_model* m, int bucket)
+{
+    if (!m->have_loss || !m->train_mode) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: call fcn8s_forward_loss first");
+    if (bucket != m->next_bucket) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: buckets must be run in order 0,1,2");
+    if (bucket == 0) backward_bucket0(m);
+    else if (bucket == 1) backward_blocks(m, 5, 4);
+    else backward_blocks(m, 3, 1);
+    m->next_bucket = bucket + 1;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(m, FCN8S_ERR_HIP, std::string("backward launch: ") + hipGetErrorString(e));
+    return FCN8S_OK;
+}
+
+int ensure_opt_state(fcn8s_model* m)
+{
+    if (m->d_m) return FCN8S_OK;
+    HIPCHK(m, hipMalloc((void**)&m->d_m, m->total * sizeof(float)));
+    HIPCHK(m, hipMalloc((void**)&m->d_v, m->total * sizeof(float)));
+    HIPCHK(m, hipMemsetAsync(m->d_m, 0, m->total * sizeof(float), m->stream));
+    HIPCHK(m, hipMemsetAsync(m->d_v, 0, m->total * sizeof(float), m->stream));
+    return FCN8S_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+size_t fcn8s_param_floats(const fcn8s_config* cfg)
+{
+    if (!cfg || cfg->num_classes <= 0) return 0;
+    int C, widths[7], k; resolve_cfg(cfg, C, widths, k);
+    std::vector<ParamInfo> t; size_t total, bo[3], bn[3];
+    build_param_table(C, widths, k, t, total, bo, bn);
+    return total;
+}
+
+int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
+{
+    if (!cfg || !out) return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_create: null argument");
+    if (cfg->num_classes <= 0 || cfg->num_classes % 4 != 0 || cfg->num_classes > 64)
+        return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_create: num_classes must be a positive multiple of 4, at most 64");
+    fcn8s_model* m = new fcn8s_model();
+    resolve_cfg(cfg, m->C, m->widths, m->fc6k);
+    for (int i = 0; i < 7; ++i)
+        if (m->widths[i] % 4) { delete m; return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_create: channel widths must be multiples of 4"); }
+    if (m->fc6k % 2 == 0) { delete m; return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_create: fc6_ksize must be odd"); }
+    m->device = cfg->device_id; m->seed = cfg->seed;
+    hipError_t e = hipSetDevice(m->device);
+    if (e != hipSuccess) { delete m; return fail(nullptr, FCN8S_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e) + " (libfcn8s_hip needs an AMD GPU; there is no CPU fallback)"); }
+    build_param_table(m->C, m->widths, m->fc6k, m->params, m->total, m->bucket_off, m->bucket_n);
+    for (size_t i = 0; i < m->params.size(); ++i) m->index[m->params[i].name] = (int)i;
+    const size_t bytes = m->total * sizeof(float);
+    auto bail = [&](const char* what, hipError_t err) { std::string msg = std::string(what) + ": " + hipGetErrorString(err); fcn8s_destroy(m); return fail(nullptr, FCN8S_ERR_OOM, msg); };
+    if (cfg->ext_params) m->d_params = (float*)cfg->ext_params;
+    else { if ((e = hipMalloc((void**)&m->d_params, bytes)) != hipSuccess) return bail("hipMalloc(params)", e); m->own_params = true; hipMemset(m->d_params, 0, bytes); }
+    if (cfg->ext_grads) m->d_grads = (float*)cfg->ext_grads;
+    else { if ((e = hipMalloc((void**)&m->d_grads, bytes)) != hipSuccess) return bail("hipMalloc(grads)", e); m->own_grads = true; hipMemset(m->d_grads, 0, bytes); }
+    if ((e = hipMalloc((void**)&m->d_wt, bytes)) != hipSuccess) return bail("hipMalloc(wt)", e);
+    if ((e = hipMalloc((void**)&m->d_w1pad, 9 * 4 * (size_t)m->widths[0] * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+    const size_t cc = (size_t)m->C * m->C;
+    if ((e = hipMalloc((void**)&m->d_tph[0], 16 * cc * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&m->d_tph[1], 16 * cc * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&m->d_tph[2], 256 * cc * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&m->d_loss, 2 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+    m->d_regsum = m->d_loss + 1;
+    if ((e = hipMalloc((void**)&m->d_conf, cc * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    hipMemset(m->d_conf, 0, cc * sizeof(unsigned long long));
+    hipMemset(m->d_loss, 0, 2 * sizeof(float));
+    *out = m;
+    return FCN8S_OK;
+}
+
+int fcn8s_destroy(fcn8s_model* m)
+{
+    if (!m) return FCN8S_OK;
+    hipDeviceSynchronize();
+    for (auto& g : m->groups) for (auto& ev : g.ev) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    if (m->own_params && m->d_params) hipFree(m->d_params);
+    if (m->own_grads && m->d_grads) hipFree(m->d_grads);
+    if (m->d_m) hipFree(m->d_m);
+    if (m->d_v) hipFree(m->d_v);
+    if (m->d_wt) hipFree(m->d_wt);
+    if (m->d_w1pad) hipFree(m->d_w1pad);
+    for (int i = 0; i < 3; ++i) if (m->d_tph[i]) hipFree(m->d_tph[i]);
+    if (m->d_loss) hipFree(m->d_loss);
+    if (m->d_conf) hipFree(m->d_conf);
+    if (m->arena) hipFree(m->arena);
+    delete m;
+    return FCN8S_OK;
+}
+
+const char* fcn8s_last_error(const fcn8s_model* m) { return m ? m->err.c_str() : g_last_error.c_str(); }
+
+int fcn8s_set_stream(fcn8s_model* m, void* s) { if (!m) return FCN8S_ERR_BAD_ARG; m->stream = (hipStream_t)s; return FCN8S_OK; }
+int fcn8s_synchronize(fcn8s_model* m) { if (!m) return FCN8S_ERR_BAD_ARG; HIPCHK(m, hipStreamSynchronize(m->stream)); return FCN8S_OK; }
+
+int fcn8s_num_params(const fcn8s_model* m) { return m ? (int)m->params.size() : 0; }
+int fcn8s_param_info(const fcn8s_model* m, int i, const char** name, int32_t* ndim, int64_t shape[4], int64_t* off)
+{
+    if (!m || i < 0 || i >= (int)m->params.size()) return FCN8S_ERR_BAD_ARG;
+    const ParamInfo& p = m->params[i];
+    if (name) *name = p.name.c_str();
+    if (ndim) *ndim = p.ndim;
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = p.shape[k];
+    if (off) *off = (int64_t)p.offset;
+    return FCN8S_OK;
+}
+int fcn8s_param_index(const fcn8s_model* m, const char* name)
+{
+    if (!m || !name) return -1;
+    auto it = m->index.find(name);
+    return it == m->index.end() ? -1 : it->second;
+}
+static int xfer_named(fcn8s_model* m, float* base, const char* name, void* host, size_t n, bool to_dev)
+{
+    if (!m || !name || !host) return fail(m, FCN8S_ERR_BAD_ARG, "null argument");
+    const int i = fcn8s_param_index(m, name);
+    if (i < 0) return fail(m, FCN8S_ERR_NOT_FOUND, std::string("unknown variable '") + name + "'");
+    const ParamInfo& p = m->params[i];
+    if (n != p.numel) return fail(m, FCN8S_ERR_SHAPE, std::string("variable '") + name + "' has " + std::to_string(p.numel) + " elements, got " + std::to_string(n));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (to_dev) HIPCHK(m, hipMemcpy(base + p.offset, host, n * sizeof(float), hipMemcpyHostToDevice));
+    else HIPCHK(m, hipMemcpy(host, base + p.offset, n * sizeof(float), hipMemcpyDeviceToHost));
+    return FCN8S_OK;
+}
+int fcn8s_set_param(fcn8s_model* m, const char* name, const float* host, size_t n) { return xfer_named(m, m ? m->d_params : nullptr, name, (void*)host, n, true); }
+int fcn8s_get_param(fcn8s_model* m, const char* name, float* host, size_t n) { return xfer_named(m, m ? m->d_params : nullptr, name, host, n, false); }
+int fcn8s_get_grad(fcn8s_model* m, const char* name, float* host, size_t n) { return xfer_named(m, m ? m->d_grads : nullptr, name, host, n, false); }
+void* fcn8s_param_buffer(fcn8s_model* m, size_t* n) { if (!m) return nullptr; if (n) *n = m->total; return m->d_params; }
+void* fcn8s_grad_buffer(fcn8s_model* m, size_t* n) { if (!m) return nullptr; if (n) *n = m->total; return m->d_grads; }
+int fcn8s_bucket_range(const fcn8s_model* m, int b, size_t* off, size_t* n)
+{
+    if (!m || b < 0 || b >= FCN8S_NUM_BUCKETS) return FCN8S_ERR_BAD_ARG;
+    if (off) *off = m->bucket_off[b];
+    if (n) *n = m->bucket_n[b];
+    return FCN8S_OK;
+}
+
+int fcn8s_init_params(fcn8s_model* m, uint64_t seed)
+{
+    if (!m) return FCN8S_ERR_BAD_ARG;
+    HIPCHK(m, hipMemsetAsync(m->d_params, 0, m->total * sizeof(float), m->stream));
+    uint32_t sid = 1000;
+    for (auto& p : m->params) {
+        ++sid;
+        if (p.ndim == 1) continue;                                   // biases zero
+        float std; int trunc = 0;
+        const bool vgg = p.name.find("/filter") != std::string::npos || p.name.find("/weights") != std::string::npos;
+        if (vgg) std = sqrtf(2.0f / (float)(p.shape[0] * p.shape[1] * p.shape[2]));
+        else if (p.name.find("trans") != std::string::npos) { std = 0.01f; trunc = 1; }   // :160
+        else { std = 0.001f; trunc = 1; }                                                     // :159
+        launch_init_normal(m->d_params + p.offset, (long long)p.numel, std, trunc, seed, sid, m->stream);
+    }
+    HIPCHK(m, hipGetLastError());
+    return FCN8S_OK;
+}
+
+int fcn8s_forward_loss(fcn8s_model* m, const void* images, int dtype, const uint8_t* labels, int N, int H, int W,
+                       float keep_prob, float l2_rate, int where)
+{
+    if (!m || !images || !labels) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_forward_loss: null argument");
+    if (!(keep_prob > 0.f && keep_prob <= 1.f)) return fail(m, FCN8S_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
+    int rc = ensure_workspace(m, N, H, W); if (rc) return rc;
+    const void* img; const uint8_t* lab;
+    rc = stage_inputs(m, images, dtype, labels, where, &img, &lab); if (rc) return rc;
+    rc = forward(m, img, dtype, keep_prob, true); if (rc) return rc;
+    rc = compute_loss(m, lab, l2_rate, true); if (rc) return rc;
+    m->next_bucket = 0;
+    HIPCHK(m, hipGetLastError());
+    return FCN8S_OK;
+}
+
+int fcn8s_backward_bucket(fcn8s_model* m, int bucket)
+{
+    if (!m || bucket < 0 || bucket >= FCN8S_NUM_BUCKETS) return fail(m, FCN8S_ERR_BAD_ARG, "bad bucket");
+    return do_backward_bucket(m, bucket);
+}
+
+int fcn8s_apply_update(fcn8s_model* m, int optimizer, float lr, float grad_scale)
+{
+    if (!m) return FCN8S_ERR_BAD_ARG;
+    const int64_t t = m->step + 1;
+    if (optimizer == FCN8S_OPT_TF_ADAM) {
+        int rc = ensure_opt_state(m); if (rc) return rc;
+        const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+        const float lr_t = lr * (float)std::sqrt(1.0 - std::pow((double)b2, (double)t)) / (float)(1.0 - std::pow((double)b1, (double)t));
+        ProfScope ps(m, "adam", 0, 28.0 * m->total);
+        launch_tf_adam(m->d_params, m->d_grads, m->d_m, m->d_v, (long long)m->total, lr_t, b1, b2, eps, grad_scale, m->stream);
+    } else if (optimizer == FCN8S_OPT_SGD_MOMENTUM) {
+        int rc = ensure_opt_state(m); if (rc) return rc;
+        ProfScope ps(m, "sgd_momentum", 0, 20.0 * m->total);
+        launch_sgd_momentum(m->d_params, m->d_grads, m->d_m, (long long)m->total, lr, 0.9f, grad_scale, m->stream);
+    } else if (optimizer != FCN8S_OPT_NONE) return fail(m, FCN8S_ERR_BAD_ARG, "unknown optimizer");
+    m->step = t;
+    HIPCHK(m, hipGetLastError());
+    return FCN8S_OK;
+}
+
+int fcn8s_read_loss(fcn8s_model* m, float* loss_out)
+{
+    if (!m || !loss_out) return FCN8S_ERR_BAD_ARG;
+    HIPCHK(m, hipMemcpyAsync(loss_out, m->d_loss, sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    return FCN8S_OK;
+}
+
+int fcn8s_train_step(fcn8s_model* m, const void* images, int dtype, const uint8_t* labels, int N, int H, int W,
+                     float lr, float keep_prob, float l2_rate, int where, float* loss_out, int64_t* step_out)
+{
+    int rc = fcn8s_forward_loss(m, images, dtype, labels, N, H, W, keep_prob, l2_rate, where); if (rc) return rc;
+    for (int b = 0; b < FCN8S_NUM_BUCKETS; ++b) { rc = do_backward_bucket(m, b); if (rc) return rc; }
+    rc = fcn8s_apply_update(m, FCN8S_OPT_TF_ADAM, lr, 1.f); if (rc) return rc;
+    if (loss_out) { rc = fcn8s_read_loss(m, loss_out); if (rc) return rc; }
+    if (step_out) *step_out = m->step;
+    return FCN8S_OK;
+}
+
+int fcn8s_eval_step(fcn8s_model* m, const void* images, int dtype, const uint8_t* labels, int N, int H, int W,
+                    float l2_rate, int where)
+{
+    if (!m || !images || !labels) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_eval_step: null argument");
+    int rc = ensure_workspace(m, N, H, W); if (rc) return rc;
+    const void* img; const uint8_t* lab;
+    rc = stage_inputs(m, images, dtype, labels, where, &img, &lab); if (rc) return rc;
+    rc = forward(m, img, dtype, 1.0f, false); if (rc) return rc;
+    rc = compute_loss(m, lab, l2_rate, false); if (rc) return rc;
+    const long long npix = (long long)N * H * W;
+    { ProfScope ps(m, "softmax_argmax", 0, (double)npix * (m->C * 4 + 8)); launch_softmax_argmax(A(m, "logits"), nullptr, m->d_pred, npix, m->C, m->stream); }
+    launch_confusion(lab, m->d_pred, npix, m->d_conf, m->C, m->stream);
+    float loss = 0.f;
+    rc = fcn8s_read_loss(m, &loss); if (rc) return rc;          // tf.metrics.mean(total_loss): one sample per batch
+    m->loss_sum += (double)loss; m->loss_cnt += 1;
+    return FCN8S_OK;
+}
+
+int fcn8s_metrics_reset(fcn8s_model* m)
+{
+    if (!m) return FCN8S_ERR_BAD_ARG;
+    HIPCHK(m, hipMemsetAsync(m->d_conf, 0, (size_t)m->C * m->C * sizeof(unsigned long long), m->stream));
+    m->loss_sum = 0; m->loss_cnt = 0;
+    return FCN8S_OK;
+}
+
+int fcn8s_metrics_raw(fcn8s_model* m, int64_t* conf, double* loss_sum, int64_t* loss_cnt)
+{
+    if (!m) return FCN8S_ERR_BAD_ARG;
+    if (conf) {
+        HIPCHK(m, hipMemcpyAsync(conf, m->d_conf, (size_t)m->C * m->C * sizeof(int64_t), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+    }
+    if (loss_sum) *loss_sum = m->loss_sum;
+    if (loss_cnt) *loss_cnt = m->loss_cnt;
+    return FCN8S_OK;
+}
+
+int fcn8s_metrics_set_raw(fcn8s_model* m, const int64_t* conf, double loss_sum, int64_t loss_cnt)
+{
+    if (!m || !conf) return FCN8S_ERR_BAD_ARG;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    HIPCHK(m, hipMemcpy(m->d_conf, conf, (size_t)m->C * m->C * sizeof(int64_t), hipMemcpyHostToDevice));
+    m->loss_sum = loss_sum; m->loss_cnt = loss_cnt;
+    return FCN8S_OK;
+}
+
+int fcn8s_metrics_get(fcn8s_model* m, double* mean_loss, double* mean_iou, double* accuracy)
+{
+    if (!m) return FCN8S_ERR_BAD_ARG;
+    const int C = m->C;
+    std::vector<int64_t> cm((size_t)C * C);
+    int rc = fcn8s_metrics_raw(m, cm.data(), nullptr, nullptr); if (rc) return rc;
+    // tf.metrics.mean_iou: iou_c = diag/(row+col-diag), mean over classes with a non-zero denominator
+    double iou_sum = 0, tot = 0, diag = 0; int valid = 0;
+    for (int c = 0; c < C; ++c) {
+        double row = 0, col = 0;
+        for (int k = 0; k < C; ++k) { row += (double)cm[(size_t)c * C + k]; col += (double)cm[(size_t)k * C + c]; }
+        const double d = (double)cm[(size_t)c * C + c];
+        const double den = row + col - d;
+        if (den > 0) { iou_sum += d / den; ++valid; }
+        tot += row; diag += d;
+    }
+    if (mean_loss) *mean_loss = m->loss_cnt > 0 ? m->loss_sum / (double)m->loss_cnt : 0.0;
+    if (mean_iou) *mean_iou = valid > 0 ? iou_sum / valid : 0.0;
+    if (accuracy) *accuracy = tot > 0 ? diag / tot : 0.0;
+    return FCN8S_OK;
+}
+
+int fcn8s_predict(fcn8s_model* m, const void* images, int dtype, int N, int H, int W, int argmax, void* out, int where)
+{
+    if (!m || !images || !out) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_predict: null argument");
+    int rc = ensure_workspace(m, N, H, W); if (rc) return rc;
+    const void* img; const uint8_t* lab;
+    rc = stage_inputs(m, images, dtype, nullptr, where, &img, &lab); if (rc) return rc;
+    rc = forward(m, img, dtype, 1.0f, false); if (rc) return rc;
+    const long long npix = (long long)N * H * W;
+    if (where == FCN8S_DEVICE) {
+        ProfScope ps(m, "softmax_argmax", 0, (double)npix * (m->C * 4 + 8));
+        if (argmax) launch_softmax_argmax(A(m, "logits"), nullptr, (long long*)out, npix, m->C, m->stream);
+        else launch_softmax_argmax(A(m, "logits"), (float*)out, nullptr, npix, m->C, m->stream);
+        HIPCHK(m, hipGetLastError());
+        return FCN8S_OK;
+    }
+    if (argmax) {
+        launch_softmax_argmax(A(m, "logits"), nullptr, m->d_pred, npix, m->C, m->stream);
+        HIPCHK(m, hipMemcpyAsync(out, m->d_pred, npix * sizeof(long long), hipMemcpyDeviceToHost, m->stream));
+    } else {
+        launch_softmax_argmax(A(m, "logits"), m->d_softmax, nullptr, npix, m->C, m->stream);
+        HIPCHK(m, hipMemcpyAsync(out, m->d_softmax, npix * m->C * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    }
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    return FCN8S_OK;
+}
+
+int64_t fcn8s_global_step(const fcn8s_model* m) { return m ? m->step : -1; }
+int fcn8s_set_global_step(fcn8s_model* m, int64_t s) { if (!m || s < 0) return FCN8S_ERR_BAD_ARG; m->step = s; return FCN8S_OK; }
+
+int fcn8s_get_opt_state(fcn8s_model* m, float* hm, float* hv, size_t n)
+{
+    if (!m || n != m->total) return fail(m, FCN8S_ERR_BAD_ARG, "optimizer state size mismatch");
+    int rc = ensure_opt_state(m); if (rc) return rc;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (hm) HIPCHK(m, hipMemcpy(hm, m->d_m, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (hv) HIPCHK(m, hipMemcpy(hv, m->d_v, n * sizeof(float), hipMemcpyDeviceToHost));
+    return FCN8S_OK;
+}
+int fcn8s_set_opt_state(fcn8s_model* m, const float* hm, const float* hv, size_t n)
+{
+    if (!m || n != m->total) return fail(m, FCN8S_ERR_BAD_ARG, "optimizer state size mismatch");
+    int rc = ensure_opt_state(m); if (rc) return rc;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (hm) HIPCHK(m, hipMemcpy(m->d_m, hm, n * sizeof(float), hipMemcpyHostToDevice));
+    if (hv) HIPCHK(m, hipMemcpy(m->d_v, hv, n * sizeof(float), hipMemcpyHostToDevice));
+    return FCN8S_OK;
+}
+
+int fcn8s_get_activation(fcn8s_model* m, const char* name, float* host, size_t n)
+{
+    if (!m || !name || !host) return FCN8S_ERR_BAD_ARG;
+    if (!m->have_forward) return fail(m, FCN8S_ERR_STATE, "no forward pass has been run");
+    auto it = m->acts.find(name);
+    if (it == m->acts.end()) return fail(m, FCN8S_ERR_NOT_FOUND, std::string("unknown activation '") + name + "'");
+    if (n != it->second.n) return fail(m, FCN8S_ERR_SHAPE, std::string("activation '") + name + "' has " + std::to_string(it->second.n) + " elements");
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    HIPCHK(m, hipMemcpy(host, it->second.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return FCN8S_OK;
+}
+
+int fcn8s_get_dropout_masks(fcn8s_model* m, float* h6, size_t n6, float* h7, size_t n7)
+{
+    if (!m || !m->have_forward) return fail(m, FCN8S_ERR_STATE, "no forward pass has been run");
+    const Act& a6 = m->acts.at("fc6"); const Act& a7 = m->acts.at("fc7");
+    if (n6 != a6.n || n7 != a7.n) return fail(m, FCN8S_ERR_SHAPE, "mask size mismatch");
+    const float keep = (m->train_mode ? m->keep_prob : 1.f);
+    float* tmp = m->gbuf[0] == nullptr ? nullptr : m->d_softmax;   // scratch (large enough: N*H*W*C >= fc sizes is not guaranteed) -> allocate
+    (void)tmp;
+    float* d = nullptr;
+    const size_t nmax = n6 > n7 ? n6 : n7;
+    HIPCHK(m, hipMalloc((void**)&d, nmax * sizeof(float)));
+    launch_dropout_mask(d, (long long)n6, keep, m->seed, m->drop_stream, m->stream);
+    hipMemcpyAsync(h6, d, n6 * sizeof(float), hipMemcpyDeviceToHost, m->stream);
+    hipStreamSynchronize(m->stream);
+    launch_dropout_mask(d, (long long)n7, keep, m->seed, m->drop_stream + 1, m->stream);
+    hipMemcpyAsync(h7, d, n7 * sizeof(float), hipMemcpyDeviceToHost, m->stream);
+    hipStreamSynchronize(m->stream);
+    hipFree(d);
+    return FCN8S_OK;
+}
+
+int fcn8s_profile_enable(fcn8s_model* m, int on) { if (!m) return FCN8S_ERR_BAD_ARG; m->profile = on != 0; return FCN8S_OK; }
+int fcn8s_profile_reset(fcn8s_model* m)
+{
+    if (!m) return FCN8S_ERR_BAD_ARG;
+    hipStreamSynchronize(m->stream);
+    for (auto& g : m->groups) { for (auto& ev : g.ev) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); } g.ev.clear(); g.flops = g.bytes = 0; g.launches = 0; }
+    return FCN8S_OK;
+}
+int fcn8s_profile_num_groups(const fcn8s_model* m) { return m ? (int)m->groups.size() : 0; }
+int fcn8s_profile_get(fcn8s_model* m, int gi, const char** name, double* total_ms, int64_t* launches, double* flops, double* bytes)
+{
+    if (!m || gi < 0 || gi >= (int)m->groups.size()) return FCN8S_ERR_BAD_ARG;
+    ProfGroup& g = m->groups[gi];
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    double ms = 0;
+    for (auto& ev : g.ev) { float t = 0; if (hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) ms += t; }
+    if (name) *name = g.name.c_str();
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = g.launches;
+    if (flops) *flops = g.flops;
+    if (bytes) *bytes = g.bytes;
+    return FCN8S_OK;
+}
+
+// ---- single ops ------------------------------------------------------------------------------
+#define OPCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(nullptr, FCN8S_ERR_HIP, hipGetErrorString(e_)); } while (0)
+
+int fcn8s_op_preprocess(void* stream, const void* images, int dtype, float* out4, int64_t npix)
+{ launch_preprocess(images, dtype, out4, npix, (hipStream_t)stream); OPCHK(); return FCN8S_OK; }
+
+int fcn8s_op_conv2d(void* stream, const float* x, const float* w, const float* bias, float* y,
+                    int N, int H, int W, int Cin, int Cout, int K, int relu)
+{
+    if (Cin % 4 || Cout % 4 || K % 2 == 0) return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d: Cin, Cout must be multiples of 4 and K odd");
+    Epi e; e.bias = bias; e.relu = relu;
+    conv_same(nullptr, "", x, w, y, N, H, W, Cin, Cout, K, e, (hipStream_t)stream);
+    OPCHK(); return FCN8S_OK;
+}
+
+int fcn8s_op_conv2d_bwd(void* stream, const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                        int N, int H, int W, int Cin, int Cout, int K)
+{
+    if (Cin % 4 || Cout % 4 || K % 2 == 0) return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d_bwd: Cin, Cout must be multiples of 4 and K odd");
+    hipStream_t s = (hipStream_t)stream;
+    if (dw) {
+        hipMemsetAsync(dw, 0, (size_t)K * K * Cin * Cout * sizeof(float), s);
+        if (db) hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), s);
+        conv_wgrad(nullptr, "", x, dy, dw, db, N, H, W, Cin, Cout, K, 1.f, s);
+    } else if (db) { hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), s); launch_colsum(dy, db, (long long)N * H * W, Cout, s); }
+    if (dx) {
+        float* wt = nullptr;
+        if (hipMalloc((void**)&wt, (size_t)K * K * Cin * Cout * sizeof(float)) != hipSuccess) return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc");
+        launch_flip_transpose(w, wt, K * K, Cin, Cout, s);
+        Epi e; conv_same(nullptr, "", dy, wt, dx, N, H, W, Cout, Cin, K, e, s);
+        hipStreamSynchronize(s); hipFree(wt);
+    }
+    OPCHK(); return FCN8S_OK;
+}
+
+int fcn8s_op_maxpool2x2(void* stream, const float* x, float* y, int N, int H, int W, int C)
+{
+    if (C % 4 || H % 2 || W % 2) return fail(nullptr, FCN8S_ERR_BAD_ARG, "maxpool: C%4, H%2, W%2 must be 0");
+    launch_maxpool_fwd(x, y, N, H, W, C, (hipStream_t)stream); OPCHK(); return FCN8S_OK;
+}
+int fcn8s_op_maxpool2x2_bwd(void* stream, const float* x, const float* dy, float* dx, int N, int H, int W, int C, int relu_mask)
+{
+    if (C % 4 || H % 2 || W % 2) return fail(nullptr, FCN8S_ERR_BAD_ARG, "maxpool: C%4, H%2, W%2 must be 0");
+    launch_maxpool_bwd(x, dy, dx, N, H, W, C, relu_mask, (hipStream_t)stream); OPCHK(); return FCN8S_OK;
+}
+
+int fcn8s_op_conv2d_transpose(void* stream, const float* x, const float* w, const float* bias, const float* addend, float* y,
+                              int N, int Hi, int Wi, int C, int K, int S)
+{
+    if (C % 4 || K != 2 * S) return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d_transpose: needs C%4==0 and K == 2*S");
+    hipStream_t s = (hipStream_t)stream;
+    float* wp = nullptr;
+    if (hipMalloc((void**)&wp, (size_t)S * S * 4 * C * C * sizeof(float)) != hipSuccess) return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc");
+    launch_tconv_phase_pack(w, wp, K, S, C, s);
+    tconv_fwd(nullptr, x, wp, bias, addend, y, N, Hi, Wi, C, K, S, s);
+    hipStreamSynchronize(s); hipFree(wp);
+    OPCHK(); return FCN8S_OK;
+}
+
+int fcn8s_op_conv2d_transpose_bwd(void* stream, const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                                  int N, int Hi, int Wi, int C, int K, int S)
+{
+    if (C % 4 || K != 2 * S) return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d_transpose_bwd: needs C%4==0 and K == 2*S");
+    hipStream_t s = (hipStream_t)stream;
+    if (dw) { hipMemsetAsync(dw, 0, (size_t)K * K * C * C * sizeof(float), s); tconv_wgrad(nullptr, x, dy, dw, N, Hi, Wi, C, K, S, s); }
+    if (db) { hipMemsetAsync(db, 0, (size_t)C * sizeof(float), s); launch_colsum(dy, db, (long long)N * Hi * S * Wi * S, C, s); }
+    if (dx) tconv_dgrad(nullptr, dy, w, dx, N, Hi, Wi, C, K, S, s);
+    OPCHK(); return FCN8S_OK;
+}
+
+int fcn8s_op_softmax_xent(void* stream, const float* logits, const uint8_t* labels, float* dlogits, float* loss_dev, int64_t npix, int C)
+{
+    hipStream_t s = (hipStream_t)stream;
+    double* part = nullptr;
+    if (hipMalloc((void**)&part, 4096 * sizeof(double)) != hipSuccess) return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc");
+    launch_softmax_xent(logits, labels, dlogits, part, npix, C, 1.0f / (float)npix, s);
+    launch_finalize_loss(part, softmax_xent_blocks(npix), npix, nullptr, 0.f, loss_dev, s);
+    hipStreamSynchronize(s); hipFree(part);
+    OPCHK(); return FCN8S_OK;
+}
+int fcn8s_op_softmax_argmax(void* stream, const float* logits, float* sm, int64_t* am, int64_t npix, int C)
+{ launch_softmax_argmax(logits, sm, (long long*)am, npix, C, (hipStream_t)stream); OPCHK(); return FCN8S_OK; }
+int fcn8s_op_confusion(void* stream, const uint8_t* labels, const int64_t* pred, int64_t npix, int64_t* conf, int C)
+{ launch_confusion(labels, (const long long*)pred, npix, (unsigned long long*)conf, C, (hipStream_t)stream); OPCHK(); return FCN8S_OK; }
+int fcn8s_op_tf_adam(void* stream, float* theta, const float* g, float* mm, float* v, int64_t n, int t, float lr, float b1, float b2, float eps, float gs)
+{
+    const float lr_t = lr * (float)std::sqrt(1.0 - std::pow((double)b2, (double)t)) / (float)(1.0 - std::pow((double)b1, (double)t));
+    launch_tf_adam(theta, g, mm, v, n, lr_t, b1, b2, eps, gs, (hipStream_t)stream); OPCHK(); return FCN8S_OK;
+}
+int fcn8s_op_sgd_momentum(void* stream, float* theta, const float* g, float* buf, int64_t n, float lr, float mom, float gs)
+{ launch_sgd_momentum(theta, g, buf, n, lr, mom, gs, (hipStream_t)stream); OPCHK(); return FCN8S_OK; }
+
+}  // extern "C"

@@ -1,0 +1,330 @@
+"""Thin Python owner of one `fcn8s_model` handle (one process, one GPU).
+
+PyTorch-ROCm is plumbing here: it owns the flat parameter / gradient buffers
+(so that `torch.distributed` = RCCL can all-reduce them and a torch optimizer
+can update them) and provides the HIP stream.  All arithmetic of the FCN-8s
+path happens inside libfcn8s_hip.so.
+
+Data-parallel training: one Engine per rank, the minibatch is
+sharded by the caller, gradients are all-reduced in three buckets in
+backward-production order ({fc6, fc7, decoder} | {conv5, conv4} | {conv3..1});
+bucket b's all-reduce runs on RCCL's stream while bucket b+1's backward kernels
+run on the compute stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+class Engine:
+    def __init__(self, num_classes, widths=None, fc6_ksize=7, device_id=0, seed=0, process_group=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("fcn8s_tensorflow_amd needs an AMD GPU (gfx950); there is no CPU fallback for the hot path")
+        self.torch = torch
+        self.device = torch.device("cuda", device_id)
+        torch.cuda.set_device(self.device)
+        self.num_classes = int(num_classes)
+        self.pg = process_group
+        cfg = L.Config()
+        cfg.num_classes = int(num_classes)
+        cfg.fc6_ksize = int(fc6_ksize)
+        for i in range(7):
+            cfg.widths[i] = int(widths[i]) if widths else 0
+        cfg.device_id = device_id
+        cfg.seed = int(seed)
+        n = L.lib.fcn8s_param_floats(C.byref(cfg))
+        if n == 0:
+            raise ValueError("invalid model configuration (num_classes must be a positive multiple of 4)")
+        self.flat_params = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.flat_grads = torch.zeros(n, dtype=torch.float32, device=self.device)
+        cfg.ext_params = self.flat_params.data_ptr()
+        cfg.ext_grads = self.flat_grads.data_ptr()
+        h = C.c_void_p()
+        L.check(L.lib.fcn8s_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.widths = tuple(widths) if widths else (64, 128, 256, 512, 512, 4096, 4096)
+        self.specs = OrderedDict()          # name -> (shape, offset)
+        for i in range(L.lib.fcn8s_num_params(self.h)):
+            name = C.c_char_p(); nd = C.c_int32(); shp = (C.c_int64 * 4)(); off = C.c_int64()
+            L.check(L.lib.fcn8s_param_info(self.h, i, C.byref(name), C.byref(nd), C.byref(shp), C.byref(off)), self.h)
+            self.specs[name.value.decode()] = (tuple(int(shp[k]) for k in range(nd.value)), int(off.value))
+        self.buckets = []
+        for b in range(L.NUM_BUCKETS):
+            o = C.c_size_t(); m = C.c_size_t()
+            L.check(L.lib.fcn8s_bucket_range(self.h, b, C.byref(o), C.byref(m)), self.h)
+            self.buckets.append((o.value, m.value))
+        self._sync_stream()
+
+    # ---- plumbing ---------------------------------------------------------------------
+    def _sync_stream(self):
+        L.check(L.lib.fcn8s_set_stream(self.h, C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)), self.h)
+
+    def close(self):
+        if getattr(self, "h", None) is not None:
+            self.torch.cuda.synchronize(self.device)
+            L.lib.fcn8s_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def world_size(self):
+        d = _dist()
+        return d.get_world_size(self.pg) if d else 1
+
+    @property
+    def rank(self):
+        d = _dist()
+        return d.get_rank(self.pg) if d else 0
+
+    # ---- variables -----------------------------------------------------------------------
+    def param_view(self, name):
+        shape, off = self.specs[name]
+        return self.flat_params[off:off + int(np.prod(shape))].view(*shape)
+
+    def grad_view(self, name):
+        shape, off = self.specs[name]
+        return self.flat_grads[off:off + int(np.prod(shape))].view(*shape)
+
+    def set_params(self, params):
+        for k, v in params.items():
+            if k not in self.specs:
+                raise ValueError("unknown variable '%s'" % k)
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            if tuple(a.shape) != self.specs[k][0]:
+                raise ValueError("variable '%s' has shape %s, expected %s" % (k, a.shape, self.specs[k][0]))
+            L.check(L.lib.fcn8s_set_param(self.h, k.encode(), a.ctypes.data_as(C.c_void_p), a.size), self.h)
+
+    def get_params(self):
+        out = OrderedDict()
+        for k, (shape, _) in self.specs.items():
+            a = np.empty(shape, np.float32)
+            L.check(L.lib.fcn8s_get_param(self.h, k.encode(), a.ctypes.data_as(C.c_void_p), a.size), self.h)
+            out[k] = a
+        return out
+
+    def get_grads(self):
+        out = OrderedDict()
+        for k, (shape, _) in self.specs.items():
+            a = np.empty(shape, np.float32)
+            L.check(L.lib.fcn8s_get_grad(self.h, k.encode(), a.ctypes.data_as(C.c_void_p), a.size), self.h)
+            out[k] = a
+        return out
+
+    def init_params(self, seed=0):
+        self._sync_stream()
+        L.check(L.lib.fcn8s_init_params(self.h, int(seed)), self.h)
+
+    def broadcast_params(self, src=0):
+        d = _dist()
+        if d and self.world_size > 1:
+            d.broadcast(self.flat_params, src=src, group=self.pg)
+
+    @property
+    def global_step(self):
+        return int(L.lib.fcn8s_global_step(self.h))
+
+    @global_step.setter
+    def global_step(self, v):
+        L.check(L.lib.fcn8s_set_global_step(self.h, int(v)), self.h)
+
+    def get_opt_state(self):
+        n = self.flat_params.numel()
+        m = np.empty(n, np.float32); v = np.empty(n, np.float32)
+        L.check(L.lib.fcn8s_get_opt_state(self.h, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), n), self.h)
+        return m, v
+
+    def set_opt_state(self, m, v):
+        m = np.ascontiguousarray(m, np.float32); v = np.ascontiguousarray(v, np.float32)
+        L.check(L.lib.fcn8s_set_opt_state(self.h, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), m.size), self.h)
+
+    # ---- input marshalling -----------------------------------------------------------------
+    def _images(self, images):
+        """-> (keepalive, pointer, dtype code, where, (N,H,W))"""
+        torch = self.torch
+        if isinstance(images, torch.Tensor):
+            t = images
+            if t.dim() != 4 or t.shape[-1] != 3:
+                raise ValueError("images must have shape (batch, height, width, 3)")
+            if t.dtype not in (torch.uint8, torch.float32):
+                t = t.float()
+            if t.is_cuda:
+                t = t.contiguous()
+                return t, C.c_void_p(t.data_ptr()), (L.IMG_U8 if t.dtype == torch.uint8 else L.IMG_F32), L.DEVICE, tuple(t.shape[:3])
+            images = t.numpy()
+        a = np.asarray(images)
+        if a.ndim != 4 or a.shape[-1] != 3:
+            raise ValueError("images must be an array-like of rank 4 with shape (batch, height, width, 3)")
+        if a.dtype != np.uint8:
+            a = a.astype(np.float32, copy=False)
+        a = np.ascontiguousarray(a)
+        return a, a.ctypes.data_as(C.c_void_p), (L.IMG_U8 if a.dtype == np.uint8 else L.IMG_F32), L.HOST, a.shape[:3]
+
+    def _labels(self, labels, nhw, where):
+        """Accepts one-hot (N,H,W,C) like the reference (fcn8s_tensorflow.py:110, 429-433)
+        or class-id maps (N,H,W); ships uint8 class ids to the device."""
+        torch = self.torch
+        if isinstance(labels, torch.Tensor):
+            t = labels
+            if t.dim() == 4:
+                if t.shape[-1] != self.num_classes:
+                    raise ValueError("one-hot labels must have %d channels" % self.num_classes)
+                t = t.argmax(-1)
+            if tuple(t.shape) != tuple(nhw):
+                raise ValueError("labels shape %s does not match images %s" % (tuple(t.shape), tuple(nhw)))
+            t = t.to(torch.uint8).contiguous()
+            if where == L.DEVICE:
+                t = t.to(self.device)
+                return t, C.c_void_p(t.data_ptr())
+            labels = t.cpu().numpy()
+        a = np.asarray(labels)
+        if a.ndim == 4:
+            if a.shape[-1] != self.num_classes:
+                raise ValueError("one-hot labels must have %d channels, got %d" % (self.num_classes, a.shape[-1]))
+            a = np.argmax(a, axis=-1)
+        if tuple(a.shape) != tuple(nhw):
+            raise ValueError("labels shape %s does not match images %s" % (tuple(a.shape), tuple(nhw)))
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        if where == L.DEVICE:
+            t = torch.from_numpy(a).to(self.device)
+            return t, C.c_void_p(t.data_ptr())
+        return a, a.ctypes.data_as(C.c_void_p)
+
+    # ---- hot path ----------------------------------------------------------------------------
+    def train_step(self, images, labels, learning_rate, keep_prob=0.5, l2_rate=0.0,
+                   optimizer=L.OPT_TF_ADAM, fetch_loss=True):
+        """sess.run([train_op, total_loss, global_step]) (fcn8s_tensorflow.py:554-572)."""
+        self._sync_stream()
+        ka_i, pi, dt, where, nhw = self._images(images)
+        ka_l, pl = self._labels(labels, nhw, where)
+        N, H, W = (int(x) for x in nhw)
+        ws = self.world_size
+        loss = C.c_float(0.0)
+        if ws == 1 and optimizer == L.OPT_TF_ADAM:
+            step = C.c_int64(0)
+            L.check(L.lib.fcn8s_train_step(self.h, pi, dt, pl, N, H, W, float(learning_rate), float(keep_prob),
+                                           float(l2_rate), where, C.byref(loss) if fetch_loss else None,
+                                           C.byref(step)), self.h)
+            return (float(loss.value) if fetch_loss else None), int(step.value)
+        L.check(L.lib.fcn8s_forward_loss(self.h, pi, dt, pl, N, H, W, float(keep_prob), float(l2_rate), where), self.h)
+        works = []
+        d = _dist()
+        for b in range(L.NUM_BUCKETS):
+            L.check(L.lib.fcn8s_backward_bucket(self.h, b), self.h)
+            if ws > 1:
+                off, n = self.buckets[b]
+                works.append(d.all_reduce(self.flat_grads[off:off + n], op=d.ReduceOp.SUM, group=self.pg, async_op=True))
+        for w in works:
+            w.wait()
+        L.check(L.lib.fcn8s_apply_update(self.h, optimizer, float(learning_rate), 1.0 / ws), self.h)
+        if fetch_loss:
+            L.check(L.lib.fcn8s_read_loss(self.h, C.byref(loss)), self.h)
+        return (float(loss.value) if fetch_loss else None), self.global_step
+
+    def forward_backward(self, images, labels, keep_prob=1.0, l2_rate=0.0):
+        """Gradients only (no update): returns the loss; gradients via get_grads()/grad_view()."""
+        self._sync_stream()
+        ka_i, pi, dt, where, nhw = self._images(images)
+        ka_l, pl = self._labels(labels, nhw, where)
+        N, H, W = (int(x) for x in nhw)
+        L.check(L.lib.fcn8s_forward_loss(self.h, pi, dt, pl, N, H, W, float(keep_prob), float(l2_rate), where), self.h)
+        for b in range(L.NUM_BUCKETS):
+            L.check(L.lib.fcn8s_backward_bucket(self.h, b), self.h)
+        loss = C.c_float(0.0)
+        L.check(L.lib.fcn8s_read_loss(self.h, C.byref(loss)), self.h)
+        return float(loss.value)
+
+    def apply_update(self, learning_rate, optimizer=L.OPT_TF_ADAM, grad_scale=1.0):
+        self._sync_stream()
+        L.check(L.lib.fcn8s_apply_update(self.h, optimizer, float(learning_rate), float(grad_scale)), self.h)
+
+    def eval_step(self, images, labels, l2_rate=0.0):
+        """sess.run(metric_update_ops) (fcn8s_tensorflow.py:685-689), keep_prob = 1."""
+        self._sync_stream()
+        ka_i, pi, dt, where, nhw = self._images(images)
+        ka_l, pl = self._labels(labels, nhw, where)
+        N, H, W = (int(x) for x in nhw)
+        L.check(L.lib.fcn8s_eval_step(self.h, pi, dt, pl, N, H, W, float(l2_rate), where), self.h)
+
+    def metrics_reset(self):
+        self._sync_stream()
+        L.check(L.lib.fcn8s_metrics_reset(self.h), self.h)
+
+    def metrics_raw(self):
+        Cn = self.num_classes
+        cm = np.zeros((Cn, Cn), np.int64); ls = C.c_double(); lc = C.c_int64()
+        L.check(L.lib.fcn8s_metrics_raw(self.h, cm.ctypes.data_as(C.c_void_p), C.byref(ls), C.byref(lc)), self.h)
+        return cm, float(ls.value), int(lc.value)
+
+    def metrics_allreduce(self):
+        """Sum the confusion matrix and the per-batch loss samples over ranks."""
+        d = _dist()
+        if not d or self.world_size == 1:
+            return
+        torch = self.torch
+        cm, ls, lc = self.metrics_raw()
+        t = torch.cat([torch.from_numpy(cm.reshape(-1)).double(), torch.tensor([ls, float(lc)], dtype=torch.float64)]).to(self.device)
+        d.all_reduce(t, group=self.pg)
+        t = t.cpu()
+        cm = t[:-2].round().long().numpy().reshape(cm.shape).astype(np.int64)
+        L.check(L.lib.fcn8s_metrics_set_raw(self.h, np.ascontiguousarray(cm).ctypes.data_as(C.c_void_p), float(t[-2]), int(round(float(t[-1])))), self.h)
+
+    def metrics_get(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        L.check(L.lib.fcn8s_metrics_get(self.h, C.byref(a), C.byref(b), C.byref(c)), self.h)
+        return float(a.value), float(b.value), float(c.value)
+
+    def predict(self, images, argmax=True):
+        """sess.run(predictions_argmax | softmax_output) (fcn8s_tensorflow.py:764-770)."""
+        self._sync_stream()
+        ka_i, pi, dt, where, nhw = self._images(images)
+        N, H, W = (int(x) for x in nhw)
+        torch = self.torch
+        if where == L.DEVICE:
+            out = torch.empty((N, H, W), dtype=torch.int64, device=self.device) if argmax else \
+                torch.empty((N, H, W, self.num_classes), dtype=torch.float32, device=self.device)
+            L.check(L.lib.fcn8s_predict(self.h, pi, dt, N, H, W, int(bool(argmax)), C.c_void_p(out.data_ptr()), where), self.h)
+            return out
+        out = np.empty((N, H, W), np.int64) if argmax else np.empty((N, H, W, self.num_classes), np.float32)
+        L.check(L.lib.fcn8s_predict(self.h, pi, dt, N, H, W, int(bool(argmax)), out.ctypes.data_as(C.c_void_p), where), self.h)
+        return out
+
+    # ---- introspection (tests, bench) -----------------------------------------------------------
+    def activation(self, name, shape):
+        a = np.empty(shape, np.float32)
+        L.check(L.lib.fcn8s_get_activation(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size), self.h)
+        return a
+
+    def dropout_masks(self, shape6, shape7):
+        m6 = np.empty(shape6, np.float32); m7 = np.empty(shape7, np.float32)
+        L.check(L.lib.fcn8s_get_dropout_masks(self.h, m6.ctypes.data_as(C.c_void_p), m6.size, m7.ctypes.data_as(C.c_void_p), m7.size), self.h)
+        return m6, m7
+
+    def profile(self, on=True):
+        L.check(L.lib.fcn8s_profile_enable(self.h, int(on)), self.h)
+
+    def profile_reset(self):
+        L.check(L.lib.fcn8s_profile_reset(self.h), self.h)
+
+    def profile_results(self):
+        out = OrderedDict()
+        for g in range(L.lib.fcn8s_profile_num_groups(self.h)):
+            name = C.c_char_p(); ms = C.c_double(); n = C.c_int64(); fl = C.c_double(); by = C.c_double()
+            L.check(L.lib.fcn8s_profile_get(self.h, g, C.byref(name), C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), self.h)
+            out[name.value.decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+        return out

@@ -1,0 +1,169 @@
+/* fcn8s_hip.h -- C ABI of libfcn8s_hip.so, the MI355X (gfx950) replacement for
+ * the TensorFlow session behind pierluigiferrari/fcn8s_tensorflow's `FCN8s`.
+ *
+ * The reference has no FFI: its hot path sits behind `tf.Session.run`
+ * feed/fetch calls made by class FCN8s (fcn8s_tensorflow.py).  Each entry point
+ * below cites the `sess.run` site (or graph-building method) it replaces.
+ * Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * Conventions
+ *   - all tensors NHWC, C-contiguous; weights in the TensorFlow layouts
+ *     (conv HWIO [kh,kw,Cin,Cout]; conv2d_transpose [kh,kw,Cout,Cin]);
+ *   - variables are addressed by the reference's variable names
+ *     ("conv1_1/filter" ... "fc7_pool4_pool3_conv2d_trans/bias",
+ *     fcn8s_tensorflow.py:331-350);
+ *   - every function returns FCN8S_OK (0) or an error code; the text is
+ *     available from fcn8s_last_error();
+ *   - `where` = FCN8S_HOST: pointers are host memory (copied in/out on the
+ *     model's stream); FCN8S_DEVICE: pointers are device memory on the model's
+ *     GPU and the call is stream-ordered;
+ *   - a model is not thread-safe; one model per process per GPU
+ *     (the reference is single-threaded, one tf.Session, :65).
+ */
+#ifndef FCN8S_HIP_H
+#define FCN8S_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCN8S_OK            0
+#define FCN8S_ERR_BAD_ARG   1   /* facade raises ValueError */
+#define FCN8S_ERR_SHAPE     2   /* H or W not a multiple of 32, N<=0 ... (TF: InvalidArgumentError at tf.add :213/:224) */
+#define FCN8S_ERR_OOM       3
+#define FCN8S_ERR_HIP       4
+#define FCN8S_ERR_STATE     5   /* call order violated (e.g. backward before forward) */
+#define FCN8S_ERR_NOT_FOUND 6   /* unknown variable / activation name */
+
+#define FCN8S_HOST   0
+#define FCN8S_DEVICE 1
+
+#define FCN8S_IMG_U8  0   /* uint8 RGB  [N,H,W,3] */
+#define FCN8S_IMG_F32 1   /* float32 RGB [N,H,W,3] */
+
+#define FCN8S_OPT_TF_ADAM      0  /* tf.train.AdamOptimizer, fcn8s_tensorflow.py:256 */
+#define FCN8S_OPT_SGD_MOMENTUM 1  /* BASELINE.json config 3 */
+#define FCN8S_OPT_NONE         2  /* caller updates the parameter buffer itself (torch optimizer over views) */
+
+#define FCN8S_NUM_BUCKETS 3       /* gradient buckets in backward-production order */
+
+typedef struct fcn8s_model fcn8s_model;
+
+typedef struct fcn8s_config {
+    int32_t  num_classes;   /* FCN8s(num_classes=...), :19 */
+    int32_t  fc6_ksize;     /* 7 (convolutionalized VGG-16 fc6); 0 -> 7 */
+    int32_t  widths[7];     /* conv1..conv5, fc6, fc7 channel counts; zeros -> 64,128,256,512,512,4096,4096 */
+    int32_t  device_id;     /* HIP device ordinal */
+    uint64_t seed;          /* dropout Philox key (per-rank seed for DP) */
+    void*    ext_params;    /* optional caller-owned DEVICE buffer of fcn8s_param_floats() floats, or NULL */
+    void*    ext_grads;     /* optional caller-owned DEVICE buffer of the same size, or NULL */
+} fcn8s_config;
+
+/* ---- lifetime: FCN8s.__init__ :19-125 / close :946-952 ------------------- */
+size_t      fcn8s_param_floats(const fcn8s_config* cfg);             /* size of the flat parameter buffer */
+int         fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out);
+int         fcn8s_destroy(fcn8s_model* m);
+const char* fcn8s_last_error(const fcn8s_model* m);                  /* m may be NULL: last create() error */
+int         fcn8s_set_stream(fcn8s_model* m, void* hip_stream);      /* run on the caller's stream (e.g. torch's current stream) */
+int         fcn8s_synchronize(fcn8s_model* m);
+
+/* ---- variables (graph.get_tensor_by_name, :331-350; Saver :124,:927,:943) --- */
+int    fcn8s_num_params(const fcn8s_model* m);
+int    fcn8s_param_info(const fcn8s_model* m, int index, const char** name, int32_t* ndim,
+                        int64_t shape[4], int64_t* offset_floats);
+int    fcn8s_param_index(const fcn8s_model* m, const char* name);    /* -1 if unknown */
+int    fcn8s_set_param(fcn8s_model* m, const char* name, const float* host, size_t nfloats);
+int    fcn8s_get_param(fcn8s_model* m, const char* name, float* host, size_t nfloats);
+int    fcn8s_get_grad(fcn8s_model* m, const char* name, float* host, size_t nfloats);
+void*  fcn8s_param_buffer(fcn8s_model* m, size_t* nfloats);          /* DEVICE pointers, flat, name->offset via param_info */
+void*  fcn8s_grad_buffer(fcn8s_model* m, size_t* nfloats);
+int    fcn8s_bucket_range(const fcn8s_model* m, int bucket, size_t* offset_floats, size_t* nfloats);
+int    fcn8s_init_params(fcn8s_model* m, uint64_t seed);              /* synthetic init: He-normal VGG, truncated-normal decoder (:159-160) */
+
+/* ---- training: sess.run([train_op,total_loss,global_step]) :554-572 -------- *
+ * images: [N,H,W,3]; label_ids: uint8 class ids [N,H,W] (the argmax of the
+ * one-hot rows the reference feeds, :110).  loss_out / step_out may be NULL
+ * (then the call does not synchronise with the host).                          */
+int fcn8s_train_step(fcn8s_model* m, const void* images, int image_dtype, const uint8_t* label_ids,
+                     int N, int H, int W, float learning_rate, float keep_prob, float l2_rate,
+                     int where, float* loss_out, int64_t* step_out);
+
+/* split-phase form for data-parallel training: forward + loss, then backward
+ * one gradient bucket at a time (bucket b's gradients are final when
+ * fcn8s_backward_bucket(m,b) returns, stream-ordered), then the update.
+ * `grad_scale` multiplies the gradients inside the update (1/world_size).      */
+int fcn8s_forward_loss(fcn8s_model* m, const void* images, int image_dtype, const uint8_t* label_ids,
+                       int N, int H, int W, float keep_prob, float l2_rate, int where);
+int fcn8s_backward_bucket(fcn8s_model* m, int bucket);
+int fcn8s_apply_update(fcn8s_model* m, int optimizer, float learning_rate, float grad_scale);
+int fcn8s_read_loss(fcn8s_model* m, float* loss_out);                /* synchronises */
+
+/* ---- evaluation: sess.run(metric_update_ops) :685-689; reset :674; values :692 */
+int fcn8s_eval_step(fcn8s_model* m, const void* images, int image_dtype, const uint8_t* label_ids,
+                    int N, int H, int W, float l2_rate, int where);
+int fcn8s_metrics_reset(fcn8s_model* m);
+int fcn8s_metrics_get(fcn8s_model* m, double* mean_loss, double* mean_iou, double* accuracy);
+/* raw accumulators (for cross-rank reduction): confusion[C*C] row = label, col = prediction */
+int fcn8s_metrics_raw(fcn8s_model* m, int64_t* confusion, double* loss_sum, int64_t* loss_count);
+int fcn8s_metrics_set_raw(fcn8s_model* m, const int64_t* confusion, double loss_sum, int64_t loss_count);
+
+/* ---- prediction: sess.run(predictions_argmax | softmax_output) :764-770 ---- *
+ * argmax != 0: out = int64 [N,H,W]; else out = float32 softmax [N,H,W,C].        */
+int fcn8s_predict(fcn8s_model* m, const void* images, int image_dtype, int N, int H, int W,
+                  int argmax, void* out, int where);
+
+/* ---- state that must round-trip: global_step :246,:526; Adam slots ---------- */
+int64_t fcn8s_global_step(const fcn8s_model* m);
+int     fcn8s_set_global_step(fcn8s_model* m, int64_t step);
+int     fcn8s_get_opt_state(fcn8s_model* m, float* host_m, float* host_v, size_t nfloats);
+int     fcn8s_set_opt_state(fcn8s_model* m, const float* host_m, const float* host_v, size_t nfloats);
+
+/* ---- introspection for parity tests ----------------------------------------- *
+ * names: "pool3","pool4","fc7","logits", "conv1_1"... (post-ReLU activations)     */
+int fcn8s_get_activation(fcn8s_model* m, const char* name, float* host, size_t nfloats);
+int fcn8s_get_dropout_masks(fcn8s_model* m, float* host_mask6, size_t n6, float* host_mask7, size_t n7);
+
+/* ---- in-library HIP-event timing of kernel groups (bench.py roofline) -------- *
+ * groups: "conv3x3_fwd","conv3x3_dgrad","conv3x3_wgrad","fc_fwd","fc_dgrad","fc_wgrad",...
+ * Fills total milliseconds, number of launches, algorithmic flops and bytes.    */
+int fcn8s_profile_enable(fcn8s_model* m, int on);
+int fcn8s_profile_reset(fcn8s_model* m);
+int fcn8s_profile_num_groups(const fcn8s_model* m);
+int fcn8s_profile_get(fcn8s_model* m, int group, const char** name, double* total_ms,
+                      int64_t* launches, double* flops, double* bytes);
+
+/* ---- single ops on DEVICE pointers (unit parity tests; same kernels the model
+ * uses).  `stream` may be NULL (default stream).                                 */
+int fcn8s_op_preprocess(void* stream, const void* images, int image_dtype, float* out4, int64_t npix);
+int fcn8s_op_conv2d(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,
+                    int N, int H, int W, int Cin, int Cout, int K, int relu);
+int fcn8s_op_conv2d_bwd(void* stream, const float* x, const float* w_hwio, const float* dy,
+                        float* dx, float* dw, float* db,
+                        int N, int H, int W, int Cin, int Cout, int K);
+int fcn8s_op_maxpool2x2(void* stream, const float* x, float* y, int N, int H, int W, int C);
+int fcn8s_op_maxpool2x2_bwd(void* stream, const float* x, const float* dy, float* dx,
+                            int N, int H, int W, int C, int relu_mask);
+int fcn8s_op_conv2d_transpose(void* stream, const float* x, const float* w_kkoi, const float* bias,
+                              const float* addend, float* y,
+                              int N, int Hi, int Wi, int C, int K, int S);
+int fcn8s_op_conv2d_transpose_bwd(void* stream, const float* x, const float* w_kkoi, const float* dy,
+                                  float* dx, float* dw, float* db,
+                                  int N, int Hi, int Wi, int C, int K, int S);
+int fcn8s_op_softmax_xent(void* stream, const float* logits, const uint8_t* label_ids, float* dlogits,
+                          float* loss_out_dev, int64_t npix, int C);
+int fcn8s_op_softmax_argmax(void* stream, const float* logits, float* softmax_out, int64_t* argmax_out,
+                            int64_t npix, int C);
+int fcn8s_op_confusion(void* stream, const uint8_t* label_ids, const int64_t* pred_ids, int64_t npix,
+                       int64_t* conf, int C);
+int fcn8s_op_tf_adam(void* stream, float* theta, const float* g, float* m, float* v, int64_t n, int t,
+                     float lr, float beta1, float beta2, float eps, float grad_scale);
+int fcn8s_op_sgd_momentum(void* stream, float* theta, const float* g, float* buf, int64_t n,
+                          float lr, float momentum, float grad_scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCN8S_HIP_H */

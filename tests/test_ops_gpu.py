@@ -1,0 +1,203 @@
+"""Parity of every HIP kernel (called through the C ABI's op-level entry points)
+against the CPU oracle on the same seeded inputs.  Tolerances are stated per test;
+fp32 accumulation-order differences only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fcn8s_oracle as orc  # noqa: E402  (checker only)
+
+
+def _lib():
+    from fcn8s_tensorflow_amd import _lib
+    return _lib
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, K
+    (2, 8, 16, 4, 64, 3),
+    (1, 32, 32, 64, 64, 3),
+    (2, 16, 8, 64, 128, 3),
+    (1, 8, 8, 128, 256, 3),
+    (1, 6, 10, 32, 64, 7),
+    (2, 4, 4, 256, 128, 1),
+    (1, 16, 16, 256, 20, 1),
+    (1, 3, 5, 8, 20, 3),
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,K", CONV_CASES)
+def test_conv2d_fwd_bwd(N, H, W, Cin, Cout, K):
+    L = _lib()
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((K, K, Cin, Cout)) / np.sqrt(K * K * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    dy = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    xt = torch.tensor(x).permute(0, 3, 1, 2).double().requires_grad_(True)
+    wt = torch.tensor(w).double().requires_grad_(True)
+    bt = torch.tensor(b).double().requires_grad_(True)
+    yt = orc.conv2d_same_t(xt, wt, bt, relu=False)
+    yt.backward(torch.tensor(dy).permute(0, 3, 1, 2).double())
+    y_ref = yt.detach().permute(0, 2, 3, 1).numpy()
+    dx_ref = xt.grad.permute(0, 2, 3, 1).numpy(); dw_ref = wt.grad.numpy(); db_ref = bt.grad.numpy()
+
+    dx_, dw_, db_, y_ = torch.empty(N, H, W, Cin).cuda(), torch.empty(K, K, Cin, Cout).cuda(), torch.empty(Cout).cuda(), torch.empty(N, H, W, Cout).cuda()
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    L.check(L.lib.fcn8s_op_conv2d(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), N, H, W, Cin, Cout, K, 0))
+    L.check(L.lib.fcn8s_op_conv2d_bwd(None, ptr(xd), ptr(wd), ptr(dyd), ptr(dx_), ptr(dw_), ptr(db_), N, H, W, Cin, Cout, K))
+    torch.cuda.synchronize()
+    assert rel_err(y_.cpu().numpy(), y_ref) < 2e-5
+    assert rel_err(dx_.cpu().numpy(), dx_ref) < 2e-5
+    assert rel_err(dw_.cpu().numpy(), dw_ref) < 2e-5
+    assert rel_err(db_.cpu().numpy(), db_ref) < 2e-5
+    # ReLU epilogue
+    L.check(L.lib.fcn8s_op_conv2d(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), N, H, W, Cin, Cout, K, 1))
+    assert rel_err(y_.cpu().numpy(), np.maximum(y_ref, 0)) < 2e-5
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 8, 8, 64), (1, 4, 6, 8), (1, 32, 64, 128)])
+def test_maxpool(N, H, W, C):
+    L = _lib()
+    rng = np.random.default_rng(2)
+    x = np.maximum(rng.standard_normal((N, H, W, C)), 0).astype(np.float32)   # post-ReLU, many exact zeros (ties)
+    dy = rng.standard_normal((N, H // 2, W // 2, C)).astype(np.float32)
+    xt = torch.tensor(x).permute(0, 3, 1, 2).requires_grad_(True)
+    yt = orc.maxpool2x2_t(xt)
+    xd, dyd = dev(x), dev(dy)
+    y_ = torch.empty(N, H // 2, W // 2, C).cuda(); dx_ = torch.empty(N, H, W, C).cuda()
+    L.check(L.lib.fcn8s_op_maxpool2x2(None, ptr(xd), ptr(y_), N, H, W, C))
+    np.testing.assert_array_equal(y_.cpu().numpy(), yt.detach().permute(0, 2, 3, 1).numpy())
+    # backward with the fused ReLU mask == autograd through relu(pre)->pool when x = relu(pre)
+    pre = torch.tensor(x).permute(0, 3, 1, 2).clone()
+    pre[pre == 0] = -1.0
+    pre.requires_grad_(True)
+    orc.maxpool2x2_t(torch.relu(pre)).backward(torch.tensor(dy).permute(0, 3, 1, 2))
+    L.check(L.lib.fcn8s_op_maxpool2x2_bwd(None, ptr(xd), ptr(dyd), ptr(dx_), N, H, W, C, 1))
+    np.testing.assert_array_equal(dx_.cpu().numpy(), pre.grad.permute(0, 2, 3, 1).numpy())
+
+
+@pytest.mark.parametrize("N,Hi,Wi,C,K,S", [(2, 3, 5, 20, 4, 2), (1, 4, 4, 20, 16, 8), (1, 2, 3, 8, 4, 2), (2, 8, 16, 20, 16, 8)])
+def test_conv2d_transpose_fwd_bwd(N, Hi, Wi, C, K, S):
+    L = _lib()
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((N, Hi, Wi, C)).astype(np.float32)
+    w = (rng.standard_normal((K, K, C, C)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    add = rng.standard_normal((N, Hi * S, Wi * S, C)).astype(np.float32)
+    dy = rng.standard_normal((N, Hi * S, Wi * S, C)).astype(np.float32)
+    xt = torch.tensor(x).permute(0, 3, 1, 2).double().requires_grad_(True)
+    wt = torch.tensor(w).double().requires_grad_(True)
+    bt = torch.tensor(b).double().requires_grad_(True)
+    yt = orc.conv2d_transpose_same_t(xt, wt, bt, S) + torch.tensor(add).permute(0, 3, 1, 2).double()
+    yt.backward(torch.tensor(dy).permute(0, 3, 1, 2).double())
+    xd, wd, bd, ad, dyd = dev(x), dev(w), dev(b), dev(add), dev(dy)
+    y_ = torch.empty(N, Hi * S, Wi * S, C).cuda()
+    dx_, dw_, db_ = torch.empty(N, Hi, Wi, C).cuda(), torch.empty(K, K, C, C).cuda(), torch.empty(C).cuda()
+    L.check(L.lib.fcn8s_op_conv2d_transpose(None, ptr(xd), ptr(wd), ptr(bd), ptr(ad), ptr(y_), N, Hi, Wi, C, K, S))
+    L.check(L.lib.fcn8s_op_conv2d_transpose_bwd(None, ptr(xd), ptr(wd), ptr(dyd), ptr(dx_), ptr(dw_), ptr(db_), N, Hi, Wi, C, K, S))
+    torch.cuda.synchronize()
+    assert rel_err(y_.cpu().numpy(), yt.detach().permute(0, 2, 3, 1).numpy()) < 2e-5
+    assert rel_err(dx_.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy()) < 2e-5
+    assert rel_err(dw_.cpu().numpy(), wt.grad.numpy()) < 2e-5
+    assert rel_err(db_.cpu().numpy(), bt.grad.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("npix,Cc", [(1000, 20), (4096, 20), (333, 4), (257, 12)])
+def test_softmax_xent_and_argmax(npix, Cc):
+    L = _lib()
+    rng = np.random.default_rng(4)
+    logits = (rng.standard_normal((npix, Cc)) * 3).astype(np.float32)
+    labels = rng.integers(0, Cc, npix).astype(np.uint8)
+    lt = torch.tensor(logits).double().requires_grad_(True)
+    loss = torch.nn.functional.cross_entropy(lt, torch.tensor(labels.astype(np.int64)))
+    loss.backward()
+    ld, lab = dev(logits), dev(labels)
+    dl = torch.empty(npix, Cc).cuda(); lo = torch.zeros(1).cuda()
+    L.check(L.lib.fcn8s_op_softmax_xent(None, ptr(ld), ptr(lab), ptr(dl), ptr(lo), npix, Cc))
+    assert abs(float(lo.cpu()) - float(loss.detach())) < 1e-5 * max(1.0, abs(float(loss.detach())))
+    assert np.abs(dl.cpu().numpy() - lt.grad.numpy()).max() < 1e-6
+    sm = torch.empty(npix, Cc).cuda(); am = torch.empty(npix, dtype=torch.int64).cuda()
+    L.check(L.lib.fcn8s_op_softmax_argmax(None, ptr(ld), ptr(sm), ptr(am), npix, Cc))
+    sm_ref = orc.softmax(logits)
+    assert np.abs(sm.cpu().numpy() - sm_ref).max() < 1e-6
+    np.testing.assert_array_equal(am.cpu().numpy(), np.argmax(sm_ref, -1))
+
+
+def test_argmax_ties_lowest_index():
+    L = _lib()
+    logits = np.zeros((64, 20), np.float32)
+    logits[:, 7] = 1.0; logits[:, 11] = 1.0       # exact tie -> lowest index (7)
+    am = torch.empty(64, dtype=torch.int64).cuda()
+    ld = dev(logits)
+    L.check(L.lib.fcn8s_op_softmax_argmax(None, ptr(ld), None, ptr(am), 64, 20))
+    torch.cuda.synchronize()
+    assert (am.cpu().numpy() == 7).all()
+
+
+def test_confusion_matrix():
+    L = _lib()
+    rng = np.random.default_rng(5)
+    n, Cc = 100000, 20
+    lab = rng.integers(0, Cc, n).astype(np.uint8); pred = rng.integers(0, Cc, n).astype(np.int64)
+    conf = torch.zeros(Cc * Cc, dtype=torch.int64).cuda()
+    labd, predd = dev(lab), dev(pred)
+    for _ in range(2):
+        L.check(L.lib.fcn8s_op_confusion(None, ptr(labd), ptr(predd), n, ptr(conf), Cc))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(conf.cpu().numpy().reshape(Cc, Cc), 2 * orc.confusion_matrix(lab, pred, Cc))
+
+
+def test_optimizers():
+    L = _lib()
+    rng = np.random.default_rng(6)
+    n = 100003
+    th = rng.standard_normal(n).astype(np.float32); m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    thd, md, vd = dev(th), dev(m), dev(v)
+    for t in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32)
+        th, m, v = orc.tf_adam_step(th, g, m, v, t, 1e-3)
+        gd = dev(g)
+        L.check(L.lib.fcn8s_op_tf_adam(None, ptr(thd), ptr(gd), ptr(md), ptr(vd), n, t, 1e-3, 0.9, 0.999, 1e-8, 1.0))
+        torch.cuda.synchronize()
+    assert np.abs(thd.cpu().numpy() - th).max() < 2e-6
+    assert np.abs(md.cpu().numpy() - m).max() < 1e-6 and np.abs(vd.cpu().numpy() - v).max() < 1e-6
+    buf = np.zeros(n, np.float32); bd = dev(buf); th2 = th.copy(); th2d = dev(th2)
+    for _ in range(3):
+        g = rng.standard_normal(n).astype(np.float32)
+        th2, buf = orc.sgd_momentum_step(th2, g, buf, 1e-2)
+        gd = dev(g)
+        L.check(L.lib.fcn8s_op_sgd_momentum(None, ptr(th2d), ptr(gd), ptr(bd), n, 1e-2, 0.9, 1.0))
+        torch.cuda.synchronize()
+    assert np.abs(th2d.cpu().numpy() - th2).max() < 2e-6
+
+
+def test_preprocess():
+    L = _lib()
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (2, 4, 8, 3), dtype=np.uint8)
+    out = torch.empty(2, 4, 8, 4).cuda()
+    imgd = dev(img)
+    L.check(L.lib.fcn8s_op_preprocess(None, ptr(imgd), 0, ptr(out), 2 * 4 * 8))
+    torch.cuda.synchronize()
+    ref = orc.preprocess_t(torch.tensor(img).float()).numpy()
+    o = out.cpu().numpy()
+    np.testing.assert_allclose(o[..., :3], ref, rtol=0, atol=1e-5)
+    assert (o[..., 3] == 0).all()
