@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""FCN-8s training throughput on MI355X (BASELINE.json metric).
+
+One "step" = one full training step of the hot path (forward, softmax-CE loss,
+backward through every VGG + decoder variable, TF-Adam update) on one synthetic
+1024x512 batch of 16 images per GPU, inputs already resident in HBM.
+`python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ...`:
+one process per GPU, gradients all-reduced over RCCL/xGMI in three buckets that
+overlap with the backward pass (weak scaling: 16 images per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_GFLOP_PER_IMG_512x1024 = 445.04
+TRAIN_GFLOP_PER_IMG_512x1024 = 1333.3
+PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(h, w, seconds_budget=30.0):
+    """CPU restatement of the reference graph (oracle, kind 'port'), timed on this
+    host's cores on a bounded sample: bs1 training steps (fwd + bwd + TF-Adam) at
+    the bench resolution.  TF1 itself is not installable here."""
+    import torch
+    from oracle import fcn8s_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = orc.init_params(20, seed=0)
+    img, lab = orc.synthetic_batch(1, h, w)
+    onehot = orc.one_hot(lab, 20).astype(np.float32)
+    m = {k: np.zeros_like(v) for k, v in P.items()}
+    v_ = {k: np.zeros_like(v) for k, v in P.items()}
+    n, t0, t = 0, time.perf_counter(), 0
+    while True:
+        _, g, _ = orc.loss_and_grads(P, img, onehot)
+        t += 1
+        for k in P:
+            P[k], m[k], v_[k] = orc.tf_adam_step(P[k], g[k], m[k], v_[k], t, 1e-4)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget * 0.5 or n >= 3:
+            break
+    return {"value": round(n / el, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d training step(s) (fwd+bwd+TF-Adam) of 1 image %dx%d on torch-CPU fp32, %.1f s" % (n, w, h, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--optimizer", default="adam", choices=["adam", "sgd"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from fcn8s_tensorflow_amd import _lib as L
+    from fcn8s_tensorflow_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world == 1 and args.gpus > 1:
+        print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus), file=sys.stderr)
+        sys.exit(2)
+
+    N, H, W = args.batch, args.height, args.width
+    eng = Engine(20, device_id=local_rank, seed=1234 + rank)
+    eng.init_params(seed=0)                       # He-normal VGG, reference decoder init (same on every rank)
+    eng.broadcast_params(0)
+    rng = np.random.default_rng(1234 + rank)      # SURVEY 8d synthetic inputs
+    images = torch.from_numpy(rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)).cuda()
+    labels = torch.from_numpy(rng.integers(0, 20, (N, H, W), dtype=np.uint8)).cuda()
+    opt = L.OPT_TF_ADAM if args.optimizer == "adam" else L.OPT_SGD_MOMENTUM
+
+    def step():
+        if args.mode == "train":
+            eng.train_step(images, labels, 1e-4, keep_prob=0.5, l2_rate=0.0, optimizer=opt, fetch_loss=False)
+        else:
+            eng.predict(images, argmax=True)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.profile(True)
+    eng.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_results()
+    eng.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = eng.forward_backward(images, labels, keep_prob=1.0) if args.mode == "train" else None
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = N * world * args.steps / dt
+        scale = (H * W) / (512.0 * 1024.0)
+        gflop_img = (TRAIN_GFLOP_PER_IMG_512x1024 if args.mode == "train" else FWD_GFLOP_PER_IMG_512x1024) * scale
+        # dominant kernel family (by time) among the MFMA convolution groups
+        mf = {k: v for k, v in prof.items() if v["flops"] > 0 and v["launches"] > 0}
+        dom = max(mf, key=lambda k: mf[k]["ms"]) if mf else None
+        roof = None
+        if dom:
+            g = mf[dom]
+            ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+            roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 4),
+                    "algorithmic_gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 3)}
+        out = {
+            "metric": "training images/sec at 1024x512 bs16" if args.mode == "train" else "inference images/sec at 1024x512",
+            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "FCN-8s (VGG-16, fc6 7x7, 20 classes) %s step, %dx%d, %d images/GPU, %s, keep_prob 0.5"
+                                   % (args.mode, W, H, N, "TF-Adam" if args.optimizer == "adam" else "SGD+momentum"),
+                       "global_batch": N * world, "parallelism": "dp%d" % world},
+            "step_tflops": round(gflop_img * N * world * args.steps / dt / 1e3, 2),
+            "step_frac_of_f32_peak": round(gflop_img * N * args.steps / dt / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+            "roofline": roof,
+            "kernel_groups_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+            "kernel_groups_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0},
+            "kernel_groups_gbs": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in prof.items() if v["flops"] == 0 and v["ms"] > 0},
+            "final_loss": loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(H, W)
+            except Exception as ex:  # the oracle is only a reported baseline
+                out["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+"""Whole-path parity: the HIP library (through the C ABI) against the CPU oracle on
+the same seeded inputs.  Tolerances: logits within 1e-3 absolute (BASELINE.json
+north_star), argmax identical wherever the oracle's top-2 softmax margin exceeds
+1e-4, gradients within 2e-3 relative to each tensor's max magnitude."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fcn8s_oracle as orc  # noqa: E402  (checker only)
+
+SMALL = (8, 16, 32, 64, 64, 128, 128)
+
+
+def make_engine(widths=None, C=20, seed=0):
+    from fcn8s_tensorflow_amd.engine import Engine
+    return Engine(C, widths=widths, device_id=0, seed=seed)
+
+
+def batch(n, h, w, C=20, seed=0):
+    rng = np.random.default_rng(seed)
+    return (rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8), rng.integers(0, C, (n, h, w), dtype=np.uint8))
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(b).max() + 1e-30))
+
+
+def argmax_agree(pred, sm_ref, margin=1e-4):
+    ref = np.argmax(sm_ref, -1)
+    srt = np.sort(sm_ref, -1)
+    safe = (srt[..., -1] - srt[..., -2]) > margin
+    return (pred[safe] == ref[safe]).all(), float((~safe).mean())
+
+
+@pytest.mark.parametrize("widths,n,h,w", [(SMALL, 2, 64, 96), (None, 1, 32, 64)])
+def test_forward_logits_and_argmax(widths, n, h, w):
+    P = orc.init_params(20, widths or orc.DEFAULT_WIDTHS, seed=1, decoder_std_scale=30.0, bias_std=0.05)
+    img, _ = batch(n, h, w)
+    e = make_engine(widths)
+    e.set_params(P)
+    pred = e.predict(img, argmax=True)
+    assert pred.dtype == np.int64 and pred.shape == (n, h, w)
+    logits = e.activation("logits", (n, h, w, 20))
+    ref, acts = orc.forward(P, img, keep=True)
+    assert np.abs(logits - ref).max() < 1e-3 * max(1.0, np.abs(ref).max())
+    for name in ("pool3", "pool4", "fc7"):
+        a = e.activation(name, acts[name].shape)
+        assert rel(a, acts[name]) < 1e-4, name
+    sm_ref = orc.softmax(ref)
+    ok, frac_close = argmax_agree(pred, sm_ref)
+    assert ok and frac_close < 0.05
+    sm = e.predict(img, argmax=False)
+    assert sm.dtype == np.float32 and np.abs(sm - orc.softmax(logits)).max() < 1e-6   # kernel vs softmax of its own logits
+    assert np.abs(sm - sm_ref).max() < 1e-3                                          # end to end vs the oracle
+    # float32 images take the same path as uint8 (the reference feeds either)
+    pred_f = e.predict(img.astype(np.float32), argmax=True)
+    np.testing.assert_array_equal(pred_f, pred)
+    e.close()
+
+
+@pytest.mark.parametrize("widths,n,h,w,l2", [(SMALL, 2, 64, 64, 0.0), (SMALL, 1, 32, 96, 1e-2), (None, 1, 32, 32, 0.0)])
+def test_gradients(widths, n, h, w, l2):
+    P = orc.init_params(20, widths or orc.DEFAULT_WIDTHS, seed=2, decoder_std_scale=30.0, bias_std=0.05)
+    img, lab = batch(n, h, w, seed=3)
+    e = make_engine(widths)
+    e.set_params(P)
+    loss = e.forward_backward(img, orc.one_hot(lab, 20), keep_prob=1.0, l2_rate=l2)   # one-hot like the reference feeds
+    loss_ref, g_ref, _ = orc.loss_and_grads(P, img, orc.one_hot(lab, 20).astype(np.float32), l2_rate=l2)
+    assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    g = e.get_grads()
+    for k in g_ref:
+        assert rel(g[k], g_ref[k]) < 2e-3, (k, rel(g[k], g_ref[k]))
+    e.close()
+
+
+def test_dropout_statistics_and_parity():
+    widths = SMALL
+    P = orc.init_params(20, widths, seed=4, decoder_std_scale=30.0, bias_std=0.05)
+    img, lab = batch(2, 64, 64, seed=5)
+    e = make_engine(widths, seed=1234)
+    e.set_params(P)
+    loss = e.forward_backward(img, lab, keep_prob=0.5)
+    m6, m7 = e.dropout_masks((2, 2, 2, widths[5]), (2, 2, 2, widths[6]))
+    assert set(np.unique(m6)) <= {0.0, 1.0} and 0.3 < m6.mean() < 0.7 and 0.3 < m7.mean() < 0.7
+    assert not np.array_equal(m6, m7)
+    loss_ref, g_ref, _ = orc.loss_and_grads(P, img, orc.one_hot(lab, 20).astype(np.float32), keep_prob=0.5, masks=(m6, m7))
+    assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    g = e.get_grads()
+    for k in g_ref:
+        assert rel(g[k], g_ref[k]) < 2e-3, k
+    e.close()
+
+
+def test_tf_adam_training_steps():
+    """Three fused train steps (sess.run(train_op)): each step is checked against the oracle's
+    gradient + TF-Adam update started from the library's own pre-step state, so that Adam's
+    sign-like first steps (update ~ lr*g/|g|) cannot amplify round-off in near-zero gradients
+    into a chaotic divergence between the two trajectories."""
+    widths = SMALL
+    P = orc.init_params(20, widths, seed=6, decoder_std_scale=30.0, bias_std=0.05)
+    e = make_engine(widths)
+    e.set_params(P)
+    lr = 1e-3
+
+    def unflat(flat):
+        return {k: flat[off:off + int(np.prod(shp))].reshape(shp).copy() for k, (shp, off) in e.specs.items()}
+
+    for t in range(1, 4):
+        before = e.get_params()
+        mflat, vflat = e.get_opt_state()
+        m, v_ = unflat(mflat), unflat(vflat)
+        img, lab = batch(2, 32, 64, seed=10 + t)
+        loss, step = e.train_step(img, lab, learning_rate=lr, keep_prob=1.0, l2_rate=1e-3)
+        assert step == t
+        loss_ref, g_ref, _ = orc.loss_and_grads(before, img, orc.one_hot(lab, 20).astype(np.float32), l2_rate=1e-3)
+        assert abs(loss - loss_ref) < 2e-4 * max(1.0, abs(loss_ref))
+        got = e.get_params()
+        for k in before:
+            want, _, _ = orc.tf_adam_step(before[k], g_ref[k], m[k], v_[k], t, lr)
+            d = np.abs(got[k] - want)
+            solid = np.abs(g_ref[k]) > 1e-3 * np.abs(g_ref[k]).max()       # gradient well above round-off
+            assert d[solid].max(initial=0.0) < 2e-5, (k, t, d[solid].max(initial=0.0))
+            assert d.max() <= 2.5 * lr, (k, t)                                # sign flips of ~0 gradients are bounded by 2*lr_t
+    assert e.global_step == 3
+    e.close()
+
+
+def test_eval_metrics():
+    widths = SMALL
+    P = orc.init_params(20, widths, seed=7, decoder_std_scale=30.0, bias_std=0.05)
+    e = make_engine(widths)
+    e.set_params(P)
+    sm = orc.StreamingMetrics(20)
+    e.metrics_reset()
+    for i, n in enumerate((2, 1, 2)):            # ragged batches: the per-batch loss mean weighs them equally
+        img, lab = batch(n, 32, 64, seed=20 + i)
+        lab[:, :, :16] = 3                        # leave some classes absent from the ground truth
+        e.eval_step(img, orc.one_hot(lab, 20))
+        loss, l, p = orc.eval_step(P, img, orc.one_hot(lab, 20).astype(np.float32))
+        sm.update(loss, l, p)
+    loss, miou, acc = e.metrics_get()
+    rl, rm, ra = sm.values()
+    cm, _, cnt = e.metrics_raw()
+    assert cnt == 3 and cm.sum() == 5 * 32 * 64
+    assert abs(loss - rl) < 1e-4 * max(1, abs(rl))
+    mism = np.abs(cm - sm.cm).sum()
+    assert mism <= 0.002 * cm.sum()               # only near-tie pixels may differ
+    if mism == 0:
+        assert abs(miou - rm) < 1e-12 and abs(acc - ra) < 1e-12
+    e.metrics_reset()
+    assert e.metrics_raw()[0].sum() == 0
+    e.close()
+
+
+def test_errors_are_python_exceptions():
+    e = make_engine(SMALL)
+    img, lab = batch(1, 48, 64)
+    with pytest.raises(ValueError):
+        e.predict(img)                            # 48 is not a multiple of 32
+    with pytest.raises(ValueError):
+        e.set_params({"nope/filter": np.zeros(3, np.float32)})
+    with pytest.raises(ValueError):
+        e.train_step(batch(1, 32, 32)[0], np.zeros((1, 32, 16), np.uint8), 1e-3)
+    e.close()
