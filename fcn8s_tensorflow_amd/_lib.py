@@ -29,6 +29,9 @@ _p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _i64, _dp, _i64p, _fp = C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_float)
 SIGNATURES = {
     "fcn8s_param_floats": (_sz, [C.POINTER(Config)]),
+    "fcn8s_layout_num_params": (_i, [C.POINTER(Config)]),
+    "fcn8s_layout_param": (_i, [C.POINTER(Config), _i, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(_i64 * 4), _i64p]),
+    "fcn8s_layout_bucket": (_i, [C.POINTER(Config), _i, C.POINTER(_sz), C.POINTER(_sz)]),
     "fcn8s_create": (_i, [C.POINTER(Config), C.POINTER(_p)]),
     "fcn8s_destroy": (_i, [_p]),
     "fcn8s_last_error": (C.c_char_p, [_p]),

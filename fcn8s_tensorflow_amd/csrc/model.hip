@@ -567,6 +567,38 @@ size_t fcn8s_param_floats(const fcn8s_config* cfg)
     return total;
 }
 
+int fcn8s_layout_num_params(const fcn8s_config* cfg)
+{
+    if (!cfg || cfg->num_classes <= 0) return 0;
+    int C, widths[7], k; resolve_cfg(cfg, C, widths, k);
+    std::vector<ParamInfo> t; size_t total, bo[3], bn[3];
+    build_param_table(C, widths, k, t, total, bo, bn);
+    return (int)t.size();
+}
+int fcn8s_layout_param(const fcn8s_config* cfg, int index, char name_out[64], int32_t* ndim, int64_t shape[4], int64_t* off)
+{
+    if (!cfg || cfg->num_classes <= 0) return FCN8S_ERR_BAD_ARG;
+    int C, widths[7], k; resolve_cfg(cfg, C, widths, k);
+    std::vector<ParamInfo> t; size_t total, bo[3], bn[3];
+    build_param_table(C, widths, k, t, total, bo, bn);
+    if (index < 0 || index >= (int)t.size()) return FCN8S_ERR_BAD_ARG;
+    if (name_out) { strncpy(name_out, t[index].name.c_str(), 63); name_out[63] = 0; }
+    if (ndim) *ndim = t[index].ndim;
+    if (shape) for (int i = 0; i < 4; ++i) shape[i] = t[index].shape[i];
+    if (off) *off = (int64_t)t[index].offset;
+    return FCN8S_OK;
+}
+int fcn8s_layout_bucket(const fcn8s_config* cfg, int bucket, size_t* off, size_t* n)
+{
+    if (!cfg || cfg->num_classes <= 0 || bucket < 0 || bucket >= FCN8S_NUM_BUCKETS) return FCN8S_ERR_BAD_ARG;
+    int C, widths[7], k; resolve_cfg(cfg, C, widths, k);
+    std::vector<ParamInfo> t; size_t total, bo[3], bn[3];
+    build_param_table(C, widths, k, t, total, bo, bn);
+    if (off) *off = bo[bucket];
+    if (n) *n = bn[bucket];
+    return FCN8S_OK;
+}
+
 int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
 {
     if (!cfg || !out) return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_create: null argument");
@@ -883,8 +915,6 @@ int fcn8s_get_dropout_masks(fcn8s_model* m, float* h6, size_t n6, float* h7, siz
     const Act& a6 = m->acts.at("fc6"); const Act& a7 = m->acts.at("fc7");
     if (n6 != a6.n || n7 != a7.n) return fail(m, FCN8S_ERR_SHAPE, "mask size mismatch");
     const float keep = (m->train_mode ? m->keep_prob : 1.f);
-    float* tmp = m->gbuf[0] == nullptr ? nullptr : m->d_softmax;   // scratch (large enough: N*H*W*C >= fc sizes is not guaranteed) -> allocate
-    (void)tmp;
     float* d = nullptr;
     const size_t nmax = n6 > n7 ? n6 : n7;
     HIPCHK(m, hipMalloc((void**)&d, nmax * sizeof(float)));

@@ -62,8 +62,14 @@ typedef struct fcn8s_config {
     void*    ext_grads;     /* optional caller-owned DEVICE buffer of the same size, or NULL */
 } fcn8s_config;
 
-/* ---- lifetime: FCN8s.__init__ :19-125 / close :946-952 ------------------- */
+/* ---- layout of the flat variable buffer; pure host logic, needs no GPU ------- */
 size_t      fcn8s_param_floats(const fcn8s_config* cfg);             /* size of the flat parameter buffer */
+int         fcn8s_layout_num_params(const fcn8s_config* cfg);
+int         fcn8s_layout_param(const fcn8s_config* cfg, int index, char name_out[64], int32_t* ndim,
+                               int64_t shape[4], int64_t* offset_floats);
+int         fcn8s_layout_bucket(const fcn8s_config* cfg, int bucket, size_t* offset_floats, size_t* nfloats);
+
+/* ---- lifetime: FCN8s.__init__ :19-125 / close :946-952 ------------------- */
 int         fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out);
 int         fcn8s_destroy(fcn8s_model* m);
 const char* fcn8s_last_error(const fcn8s_model* m);                  /* m may be NULL: last create() error */

@@ -22,6 +22,30 @@ def batch(n, h, w, C=20, seed=0):
     return (rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8), rng.integers(0, C, (n, h, w), dtype=np.uint8))
 
 
+def pool_near_ties(P, img, tol=2e-5):
+    """Max-pool's argmax is discontinuous: when the two largest entries of a 2x2 window agree to
+    fp32 round-off, the GPU and the oracle may legitimately route that window's gradient to
+    different pixels.  Gradient-parity cases are chosen away from such windows."""
+    _, acts = orc.forward(P, img, keep=True)
+    n = 0
+    for b, nconv in enumerate(orc.CONVS_PER_BLOCK, start=1):
+        x = acts["conv%d_%d" % (b, nconv)]
+        N, H, W, Cc = x.shape
+        w = np.sort(x.reshape(N, H // 2, 2, W // 2, 2, Cc).transpose(0, 1, 3, 5, 2, 4).reshape(-1, 4), -1)
+        n += int(((w[:, 3] > 0) & ((w[:, 3] - w[:, 2]) <= tol * np.abs(w[:, 3]))).sum())
+    return n
+
+
+def tie_free_case(widths, n, h, w, seed):
+    """First (params, images, labels) at or after `seed` without pool near-ties."""
+    for s in range(seed, seed + 20):
+        P = orc.init_params(20, widths or orc.DEFAULT_WIDTHS, seed=s, decoder_std_scale=30.0, bias_std=0.05)
+        img, lab = batch(n, h, w, seed=s + 100)
+        if pool_near_ties(P, img) == 0:
+            return P, img, lab
+    raise RuntimeError("no tie-free case found")
+
+
 def rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(b).max() + 1e-30))
 
@@ -61,8 +85,7 @@ def test_forward_logits_and_argmax(widths, n, h, w):
 
 @pytest.mark.parametrize("widths,n,h,w,l2", [(SMALL, 2, 64, 64, 0.0), (SMALL, 1, 32, 96, 1e-2), (None, 1, 32, 32, 0.0)])
 def test_gradients(widths, n, h, w, l2):
-    P = orc.init_params(20, widths or orc.DEFAULT_WIDTHS, seed=2, decoder_std_scale=30.0, bias_std=0.05)
-    img, lab = batch(n, h, w, seed=3)
+    P, img, lab = tie_free_case(widths, n, h, w, seed=2)
     e = make_engine(widths)
     e.set_params(P)
     loss = e.forward_backward(img, orc.one_hot(lab, 20), keep_prob=1.0, l2_rate=l2)   # one-hot like the reference feeds
@@ -76,8 +99,7 @@ def test_gradients(widths, n, h, w, l2):
 
 def test_dropout_statistics_and_parity():
     widths = SMALL
-    P = orc.init_params(20, widths, seed=4, decoder_std_scale=30.0, bias_std=0.05)
-    img, lab = batch(2, 64, 64, seed=5)
+    P, img, lab = tie_free_case(widths, 2, 64, 64, seed=4)
     e = make_engine(widths, seed=1234)
     e.set_params(P)
     loss = e.forward_backward(img, lab, keep_prob=0.5)
@@ -110,18 +132,20 @@ def test_tf_adam_training_steps():
         before = e.get_params()
         mflat, vflat = e.get_opt_state()
         m, v_ = unflat(mflat), unflat(vflat)
-        img, lab = batch(2, 32, 64, seed=10 + t)
+        for s in range(10 * t, 10 * t + 20):          # a batch without max-pool near-ties at the current weights
+            img, lab = batch(2, 32, 64, seed=s)
+            if pool_near_ties(before, img) == 0:
+                break
         loss, step = e.train_step(img, lab, learning_rate=lr, keep_prob=1.0, l2_rate=1e-3)
         assert step == t
         loss_ref, g_ref, _ = orc.loss_and_grads(before, img, orc.one_hot(lab, 20).astype(np.float32), l2_rate=1e-3)
         assert abs(loss - loss_ref) < 2e-4 * max(1.0, abs(loss_ref))
         got = e.get_params()
+        g_gpu = e.get_grads()                     # the gradients the fused update consumed
         for k in before:
-            want, _, _ = orc.tf_adam_step(before[k], g_ref[k], m[k], v_[k], t, lr)
-            d = np.abs(got[k] - want)
-            solid = np.abs(g_ref[k]) > 1e-3 * np.abs(g_ref[k]).max()       # gradient well above round-off
-            assert d[solid].max(initial=0.0) < 2e-5, (k, t, d[solid].max(initial=0.0))
-            assert d.max() <= 2.5 * lr, (k, t)                                # sign flips of ~0 gradients are bounded by 2*lr_t
+            assert rel(g_gpu[k], g_ref[k]) < 2e-3, (k, t)
+            want, _, _ = orc.tf_adam_step(before[k], g_gpu[k], m[k], v_[k], t, lr)
+            assert np.abs(got[k] - want).max() < 2e-6, (k, t, np.abs(got[k] - want).max())
     assert e.global_step == 3
     e.close()
 
