@@ -1,0 +1,311 @@
+"""Drop-in for `data_generator.batch_generator.BatchGenerator`
+(reference: data_generator/batch_generator.py:14-494) -- the host feeder of the hot path.
+
+Contract kept (pinned by tests/golden/batchgen_contract.npz, captured from the reference):
+  * constructor / `generate()` / `process_all()` keyword names and defaults;
+  * image <-> ground-truth pairing `left_part + ground_truth_suffix + '.' + ext` inside the
+    mirrored sub-directory (:101-119), `DataError` on missing files / empty datasets;
+  * an infinite generator yielding `np.array(images)` uint8 (n,H,W,3) and ground truth either
+    bool one-hot (n,H,W,C) (`np.eye(C, dtype=bool)[gt]`, helpers/ground_truth_conversion_utils.py:84-88)
+    or the id maps (n,H,W); the last batch of a pass is SHORT (:244), the list is reshuffled at wrap;
+  * the order of `np.random` / `random` draws per sample (crop y, crop x, brightness, flip,
+    translate, scale), so seeded runs place crops where the reference does.
+
+Not kept: OpenCV and `scipy.misc` are not available offline; PNG I/O, bilinear / nearest resize
+use Pillow, flips and translations use NumPy.  Interpolated pixel values can differ from
+cv2.INTER_LINEAR by rounding; ground-truth resampling (nearest) is exact.  The two helper
+conversions the reference calls without importing (`convert_between_IDs_and_colors`,
+`convert_IDs_to_IDs_partial`, :258/:264 -> NameError there) work here.
+"""
+from __future__ import annotations
+
+import os
+import pathlib
+import random
+import sys
+from glob import glob
+from math import ceil
+
+import numpy as np
+
+from .ground_truth_conversion_utils import (convert_between_IDs_and_colors, convert_IDs_to_IDs,
+                                            convert_IDs_to_IDs_partial, convert_IDs_to_one_hot)
+
+try:
+    from tqdm import trange
+except Exception:  # pragma: no cover
+    def trange(n, **kw):
+        return range(n)
+
+
+class DataError(Exception):
+    def __init__(self, value):
+        self.value = value
+
+    def __str__(self):
+        return repr(self.value)
+
+
+def _imread(path):
+    from PIL import Image
+    return np.asarray(Image.open(path))
+
+
+def _imsave(path, array):
+    from PIL import Image
+    Image.fromarray(array).save(path)
+
+
+def _resize(array, height, width, nearest):
+    from PIL import Image
+    return np.asarray(Image.fromarray(array).resize((width, height), Image.NEAREST if nearest else Image.BILINEAR))
+
+
+def _shift(array, x_shift, y_shift, fill):
+    """Integer translation with constant border (cv2.warpAffine with a pure translation matrix)."""
+    out = np.full_like(array, 0 if fill is None else fill)
+    h, w = array.shape[:2]
+    ys, yd = (slice(0, h - y_shift), slice(y_shift, h)) if y_shift >= 0 else (slice(-y_shift, h), slice(0, h + y_shift))
+    xs, xd = (slice(0, w - x_shift), slice(x_shift, w)) if x_shift >= 0 else (slice(-x_shift, w), slice(0, w + x_shift))
+    if abs(y_shift) < h and abs(x_shift) < w:
+        out[yd, xd] = array[ys, xs]
+    return out
+
+
+def _brightness(image, min=0.5, max=2.0):
+    """Scale the HSV value channel by a random factor, saturating at 255 (:473-488)."""
+    factor = np.random.uniform(min, max)
+    img = image.astype(np.float32)
+    v = img.max(axis=2, keepdims=True)
+    scaled = np.where(v * factor > 255, 255.0 / np.maximum(v, 1.0), factor)
+    return np.clip(np.rint(img * scaled), 0, 255).astype(np.uint8)
+
+
+def _place_or_crop(array, out_h, out_w, ymin, xmin, fill):
+    """Random-crop semantics of :268-322: per axis either cut a window starting at (ymin/xmin)
+    or place the whole extent on a `fill` canvas at that offset."""
+    h, w = array.shape[:2]
+    canvas = np.full((out_h, out_w) + array.shape[2:], 0 if fill is None else fill, dtype=array.dtype)
+    src_y, dst_y = (slice(ymin, ymin + out_h), slice(0, out_h)) if h >= out_h else (slice(0, h), slice(ymin, ymin + h))
+    src_x, dst_x = (slice(xmin, xmin + out_w), slice(0, out_w)) if w >= out_w else (slice(0, w), slice(xmin, xmin + w))
+    canvas[dst_y, dst_x] = array[src_y, src_x]
+    return canvas
+
+
+class BatchGenerator:
+
+    def __init__(self,
+                 image_dirs,
+                 image_file_extension='png',
+                 ground_truth_dirs=None,
+                 image_name_split_separator=None,
+                 ground_truth_suffix=None,
+                 check_existence=True,
+                 num_classes=None,
+                 root_dir=None,
+                 export_dir=None):
+        '''Arguments as data_generator/batch_generator.py:27-74.'''
+        self.image_dirs = image_dirs
+        self.ground_truth_dirs = ground_truth_dirs
+        self.root_dir = root_dir
+        self.export_dir = export_dir
+        self.image_paths = []
+        self.ground_truth_paths = {}
+        self.num_classes = num_classes
+        self.dataset_size = 0
+        self.ground_truth = False
+
+        if (ground_truth_dirs is not None) and (len(image_dirs) != len(ground_truth_dirs)):
+            raise ValueError("`image_dirs` and `ground_truth_dirs` must contain the same number of elements.")
+
+        ext = image_file_extension.lower()
+        for i, image_dir in enumerate(image_dirs):
+            for dir_path, _, _ in os.walk(image_dir, topdown=True):
+                found = glob(os.path.join(dir_path, '*.' + ext))
+                if not found:
+                    continue
+                self.image_paths += found
+                if ground_truth_dirs is None:
+                    continue
+                gt_dir = os.path.join(ground_truth_dirs[i], os.path.basename(os.path.normpath(dir_path)))
+                for image_path in found:
+                    image_name = os.path.basename(image_path)
+                    left_part = image_name.split(image_name_split_separator, 1)[0]
+                    gt_path = os.path.join(gt_dir, left_part + ground_truth_suffix + '.' + ext)
+                    if check_existence and not os.path.isfile(gt_path):
+                        raise DataError("The dataset contains an image file '{}' for which the corresponding ground truth image file does not exist at '{}'.".format(image_path, gt_path))
+                    self.ground_truth_paths[image_name] = gt_path
+
+        self.dataset_size = len(self.image_paths)
+        if self.dataset_size == 0:
+            raise DataError("No images with the given file extension '{}' were found in the given image directories.".format(ext))
+        if (ground_truth_dirs is not None) and (len(self.ground_truth_paths) != self.dataset_size):
+            raise DataError('Ground truth directories were given, but the number of ground truth images found does not match the number of images. Number of images: {}. Number of ground truth images: {}'.format(self.dataset_size, len(self.ground_truth_paths)))
+        if len(self.ground_truth_paths) > 0:
+            self.ground_truth = True
+
+    def get_num_files(self):
+        return self.dataset_size
+
+    def shard(self, rank, world_size):
+        """Data-parallel helper (not in the reference): keep every world_size-th file, starting at rank."""
+        self.image_paths = sorted(self.image_paths)[rank::world_size]
+        self.dataset_size = len(self.image_paths)
+        return self
+
+    # -- one sample ---------------------------------------------------------------------------
+    def _load(self, image_path, convert_colors_to_ids, convert_ids_to_ids):
+        image = _imread(image_path)
+        gt = None
+        if self.ground_truth:
+            gt = _imread(self.ground_truth_paths[os.path.basename(image_path)])
+            if convert_colors_to_ids is not False:
+                gt = convert_between_IDs_and_colors(gt, convert_colors_to_ids, gt_dtype=gt.dtype)
+            if convert_ids_to_ids is not False:
+                if isinstance(convert_ids_to_ids, np.ndarray):
+                    gt = convert_IDs_to_IDs(gt, convert_ids_to_ids)
+                if isinstance(convert_ids_to_ids, dict):
+                    gt = convert_IDs_to_IDs_partial(gt, convert_ids_to_ids)
+        return image, gt
+
+    def _augment(self, image, gt, void_class_id, random_crop, crop, resize, brightness, flip, translate, scale, gray):
+        h, w, ch = image.shape
+        if random_crop:
+            y_range, x_range = h - random_crop[0], w - random_crop[1]
+            ymin = np.random.randint(0, abs(y_range) + 1)
+            xmin = np.random.randint(0, abs(x_range) + 1)
+            image = _place_or_crop(image, random_crop[0], random_crop[1], ymin, xmin, 0)
+            if gt is not None:
+                gt = _place_or_crop(gt, random_crop[0], random_crop[1], ymin, xmin, void_class_id)
+            h, w = random_crop
+        if crop:
+            image = np.copy(image[crop[0]:h - crop[1], crop[2]:w - crop[3]])
+            gt = np.copy(gt[crop[0]:h - crop[1], crop[2]:w - crop[3]])       # unconditional in the reference too (:326)
+        if resize:
+            image = _resize(image, resize[0], resize[1], nearest=False)
+            if gt is not None:
+                gt = _resize(gt, resize[0], resize[1], nearest=True)
+            h, w = resize
+        if brightness:
+            if np.random.uniform(0, 1) >= (1 - brightness[2]):
+                image = _brightness(image, min=brightness[0], max=brightness[1])
+        if flip:
+            if np.random.uniform(0, 1) >= (1 - flip):
+                image = np.ascontiguousarray(image[:, ::-1])
+                if gt is not None:
+                    gt = np.ascontiguousarray(gt[:, ::-1])
+        if translate:
+            if np.random.uniform(0, 1) >= (1 - translate[2]):
+                x = np.random.randint(translate[0][0], translate[0][1] + 1)
+                y = np.random.randint(translate[1][0], translate[1][1] + 1)
+                x_shift = random.choice([-x, x])
+                y_shift = random.choice([-y, y])
+                image = _shift(image, x_shift, y_shift, 0)
+                if gt is not None:
+                    gt = _shift(gt, x_shift, y_shift, void_class_id)
+        if scale:
+            if np.random.uniform(0, 1) >= (1 - scale[2]):
+                factor = np.random.uniform(scale[0], scale[1])
+                sh, sw = int(h * factor), int(w * factor)
+                yo, xo = abs(int((h - sh) / 2)), abs(int((w - sw) / 2))
+
+                def rescale(a, nearest, fill):
+                    patch = _resize(a, sh, sw, nearest)
+                    if factor <= 1:
+                        canvas = np.full((h, w) + a.shape[2:], 0 if fill is None else fill, dtype=a.dtype)
+                        canvas[yo:yo + sh, xo:xo + sw] = patch
+                        return canvas
+                    return np.copy(patch[yo:h + yo, xo:w + xo])
+                image = rescale(image, False, 0)
+                if gt is not None:
+                    gt = rescale(gt, True, void_class_id)
+        if gray:
+            lum = image[..., 0] * 0.299 + image[..., 1] * 0.587 + image[..., 2] * 0.114
+            image = np.expand_dims(np.clip(np.rint(lum), 0, 255).astype(np.uint8), axis=2)
+        return image, gt
+
+    def generate(self,
+                 batch_size,
+                 convert_colors_to_ids=False,
+                 convert_ids_to_ids=False,
+                 convert_to_one_hot=True,
+                 void_class_id=None,
+                 random_crop=False,
+                 crop=False,
+                 resize=False,
+                 brightness=False,
+                 flip=False,
+                 translate=False,
+                 scale=False,
+                 gray=False,
+                 to_disk=False,
+                 shuffle=True):
+        '''Arguments and yields as data_generator/batch_generator.py:156-219.'''
+        if (convert_to_one_hot or (convert_colors_to_ids is not False) or (convert_ids_to_ids is not False)) and not self.ground_truth:
+            raise ValueError("Cannot convert ground truth data: No ground truth data given.")
+        if convert_to_one_hot and self.num_classes is None:
+            raise ValueError("One-hot conversion requires that you pass an integer value for `num_classes` in the constructor, but `num_classes` is `None`.")
+
+        if shuffle:
+            random.shuffle(self.image_paths)
+        current = 0
+        while True:
+            if current >= len(self.image_paths):
+                if shuffle:
+                    random.shuffle(self.image_paths)
+                current = 0
+            images, gt_images = [], []
+            for image_path in self.image_paths[current:current + batch_size]:      # short at the end of a pass
+                image, gt = self._load(image_path, convert_colors_to_ids, convert_ids_to_ids)
+                image, gt = self._augment(image, gt, void_class_id, random_crop, crop, resize, brightness, flip,
+                                          translate, scale, gray)
+                if convert_to_one_hot:
+                    gt = convert_IDs_to_one_hot(gt, self.num_classes)
+                if to_disk:
+                    self._export(image_path, image, gt)
+                images.append(image)
+                if self.ground_truth:
+                    gt_images.append(gt)
+            current += batch_size
+            if self.ground_truth:
+                yield np.array(images), np.array(gt_images)
+            else:
+                yield np.array(images)
+
+    def _export(self, image_path, image, gt):
+        target = os.path.join(self.export_dir, os.path.relpath(image_path, start=self.root_dir))
+        pathlib.Path(os.path.dirname(target)).mkdir(parents=True, exist_ok=True)
+        _imsave(target, image if image.shape[-1] != 1 else image[..., 0])
+        if self.ground_truth:
+            gt_path = self.ground_truth_paths[os.path.basename(image_path)]
+            gt_target = os.path.join(self.export_dir, os.path.relpath(gt_path, start=self.root_dir))
+            pathlib.Path(os.path.dirname(gt_target)).mkdir(parents=True, exist_ok=True)
+            _imsave(gt_target, gt)
+
+    def process_all(self,
+                    convert_colors_to_ids=False,
+                    convert_ids_to_ids=False,
+                    convert_to_one_hot=False,
+                    void_class_id=None,
+                    random_crop=False,
+                    crop=False,
+                    resize=False,
+                    brightness=False,
+                    flip=False,
+                    translate=False,
+                    scale=False,
+                    gray=False,
+                    to_disk=True,
+                    shuffle=False,
+                    batch_size=1):
+        '''data_generator/batch_generator.py:419-469: run `generate()` once over the whole dataset.'''
+        gen = self.generate(batch_size=batch_size, convert_colors_to_ids=convert_colors_to_ids,
+                            convert_ids_to_ids=convert_ids_to_ids, convert_to_one_hot=convert_to_one_hot,
+                            void_class_id=void_class_id, random_crop=random_crop, crop=crop, resize=resize,
+                            brightness=brightness, flip=flip, translate=translate, scale=scale, gray=gray,
+                            to_disk=to_disk, shuffle=shuffle)
+        tr = trange(ceil(self.dataset_size / batch_size), file=sys.stdout)
+        if hasattr(tr, 'set_description'):
+            tr.set_description('Processing images')
+        for _ in tr:
+            next(gen)

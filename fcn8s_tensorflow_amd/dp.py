@@ -1,0 +1,70 @@
+"""Data-parallel plumbing of the FCN-8s path (new functionality: the reference is single-device).
+
+One process per GPU; the minibatch is sharded over ranks (independent images) and the
+only exchange is a SUM all-reduce of the flat gradient buffer, issued bucket by bucket in
+backward-production order so that RCCL moves bucket b over xGMI while the compute stream runs
+bucket b+1's backward kernels.  With equal shard sizes, (1/world) * sum of the local mean-loss
+gradients equals the gradient of the global mean loss; the 1/world factor is folded into the
+optimizer kernel (`grad_scale`), not applied as a separate pass over the 538 MB buffer.
+
+Backend-agnostic (`nccl` = RCCL on the GPU box, `gloo` in the CPU tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+
+def dist_or_none():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def layout(num_classes, widths=None, fc6_ksize=7):
+    """(specs, total_floats, buckets) of the flat variable buffer -- host logic of the C library,
+    needs no GPU.  specs: name -> (shape, offset); buckets: [(offset, n)] in backward order."""
+    from collections import OrderedDict
+    from . import _lib as L
+    cfg = L.Config()
+    cfg.num_classes = int(num_classes); cfg.fc6_ksize = int(fc6_ksize)
+    for i in range(7):
+        cfg.widths[i] = int(widths[i]) if widths else 0
+    total = L.lib.fcn8s_param_floats(C.byref(cfg))
+    if total == 0:
+        raise ValueError("invalid model configuration")
+    specs = OrderedDict()
+    for i in range(L.lib.fcn8s_layout_num_params(C.byref(cfg))):
+        name = C.create_string_buffer(64); nd = C.c_int32(); shp = (C.c_int64 * 4)(); off = C.c_int64()
+        L.check(L.lib.fcn8s_layout_param(C.byref(cfg), i, name, C.byref(nd), C.byref(shp), C.byref(off)))
+        specs[name.value.decode()] = (tuple(int(shp[k]) for k in range(nd.value)), int(off.value))
+    buckets = []
+    for b in range(L.NUM_BUCKETS):
+        o = C.c_size_t(); n = C.c_size_t()
+        L.check(L.lib.fcn8s_layout_bucket(C.byref(cfg), b, C.byref(o), C.byref(n)))
+        buckets.append((o.value, n.value))
+    return specs, total, buckets
+
+
+class BucketReducer:
+    """Issues one asynchronous SUM all-reduce per gradient bucket and waits for all of them."""
+
+    def __init__(self, flat_grads, buckets, group=None):
+        self.flat = flat_grads
+        self.buckets = buckets
+        self.group = group
+        self.works = []
+
+    def reduce_bucket(self, b):
+        d = dist_or_none()
+        if d is None or d.get_world_size(self.group) == 1:
+            return
+        off, n = self.buckets[b]
+        self.works.append(d.all_reduce(self.flat[off:off + n], op=d.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+    def grad_scale(self):
+        d = dist_or_none()
+        return 1.0 if d is None else 1.0 / d.get_world_size(self.group)

@@ -19,6 +19,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import _lib as L
+from .dp import BucketReducer
 
 
 def _dist():
@@ -222,16 +223,12 @@ class Engine:
                                            C.byref(step)), self.h)
             return (float(loss.value) if fetch_loss else None), int(step.value)
         L.check(L.lib.fcn8s_forward_loss(self.h, pi, dt, pl, N, H, W, float(keep_prob), float(l2_rate), where), self.h)
-        works = []
-        d = _dist()
+        red = BucketReducer(self.flat_grads, self.buckets, self.pg)
         for b in range(L.NUM_BUCKETS):
             L.check(L.lib.fcn8s_backward_bucket(self.h, b), self.h)
-            if ws > 1:
-                off, n = self.buckets[b]
-                works.append(d.all_reduce(self.flat_grads[off:off + n], op=d.ReduceOp.SUM, group=self.pg, async_op=True))
-        for w in works:
-            w.wait()
-        L.check(L.lib.fcn8s_apply_update(self.h, optimizer, float(learning_rate), 1.0 / ws), self.h)
+            red.reduce_bucket(b)          # RCCL moves bucket b while the next bucket's backward runs
+        red.wait()
+        L.check(L.lib.fcn8s_apply_update(self.h, optimizer, float(learning_rate), red.grad_scale()), self.h)
         if fetch_loss:
             L.check(L.lib.fcn8s_read_loss(self.h, C.byref(loss)), self.h)
         return (float(loss.value) if fetch_loss else None), self.global_step

@@ -1,0 +1,522 @@
+"""Drop-in for `fcn8s_tensorflow.FCN8s` (reference: fcn8s_tensorflow.py:17-952).
+
+Same constructor, `train / evaluate / predict / predict_and_save / save /
+load_variables / close` signatures, keyword names, defaults, validation
+messages and bookkeeping attributes.  The TensorFlow session behind them is
+replaced by `engine.Engine` (ctypes -> libfcn8s_hip.so, hand-written gfx950
+kernels).  Host-side control flow below restates the reference's loops; the
+three `sess.run` sites (:554-572, :685-689, :764-770) become
+`Engine.train_step / eval_step / predict`.
+
+Differences a maintainer must know (also listed in INTEGRATION.md):
+  * TensorFlow SavedModel / Saver files cannot be read or written without
+    TensorFlow.  `save()` keeps the reference's directory naming scheme
+    (:904-920) but stores `variables.npz` + `fcn8s_meta.json`;
+    `vgg16_dir` must hold `vgg16_weights.npz` (variables named as in the
+    reference, e.g. `conv1_1/filter`) or be the string 'synthetic[:seed]'.
+  * Labels may also be passed as uint8 class-id maps (N,H,W); one-hot
+    (N,H,W,C) input as in the reference is converted on the host.
+  * Data-parallel training: launch one process per GPU with torch.distributed
+    initialised (RCCL); every rank feeds its own shard of the minibatch.
+"""
+from __future__ import annotations
+
+import json
+import os
+import shutil
+import sys
+import time
+import warnings
+from collections import deque
+from glob import glob
+
+import numpy as np
+
+try:
+    from tqdm import trange
+except Exception:  # pragma: no cover
+    def trange(n, **kw):
+        class _R:
+            def __init__(self, n): self.n = n
+            def __iter__(self): return iter(range(self.n))
+            def set_description(self, *a, **k): pass
+            def set_postfix(self, *a, **k): pass
+        return _R(n)
+
+from . import _lib as L
+from .engine import Engine
+
+_SAVERS = {'saved_model', 'train_saver'}
+
+
+class FCN8s:
+
+    def __init__(self, model_load_dir=None, tags=None, vgg16_dir=None, num_classes=None, variables_load_dir=None,
+                 device_id=None, seed=0, widths=None, fc6_ksize=7):
+        '''
+        Arguments (first five: fcn8s_tensorflow.py:19-35; the rest are additions):
+            model_load_dir (string, optional): directory written by `save(saver='saved_model')`.
+            tags (list, optional): kept for signature parity; checked against the saved tags if given.
+            vgg16_dir (string, optional): directory with `vgg16_weights.npz`, or 'synthetic[:seed]'.
+            num_classes (int, optional): number of segmentation classes (multiple of 4).
+            variables_load_dir (string, optional): path prefix written by `save(saver='train_saver')`.
+            device_id (int, optional): HIP device; defaults to LOCAL_RANK or 0.
+            seed (int): dropout seed (rank is added in data-parallel runs).
+        '''
+        if (model_load_dir is None) and (vgg16_dir is None or num_classes is None):
+            raise ValueError("You must provide either both `model_load_dir` and `tags` or both `vgg16_dir` and `num_classes`.")
+
+        self.variables_load_dir = variables_load_dir
+        self.model_load_dir = model_load_dir
+        self.tags = tags
+        self.vgg16_dir = vgg16_dir
+        self.vgg16_tag = 'vgg16'
+        self.num_classes = num_classes
+
+        self.variables_updated = False
+        self.eval_dataset = None
+
+        self.metric_names = []
+        self.metric_values = []
+        self.best_metric_values = []
+        self.metric_value_tensors = []   # kept for attribute parity; hold metric names here
+        self.metric_update_ops = []
+
+        self.training_loss = None
+        self.best_training_loss = 99999999.9
+        self.g_step = None
+
+        if device_id is None:
+            device_id = int(os.environ.get("LOCAL_RANK", "0"))
+        rank = int(os.environ.get("RANK", "0"))
+
+        if model_load_dir is not None:
+            meta = _read_meta(model_load_dir)
+            if tags is not None and meta.get("tags") is not None and not set(tags) <= set(meta["tags"]):
+                raise RuntimeError("MetaGraphDef associated with tags {} could not be found in SavedModel (available: {}).".format(tags, meta["tags"]))
+            self.num_classes = int(meta["num_classes"])
+            self.engine = Engine(self.num_classes, widths=meta.get("widths"), fc6_ksize=meta.get("fc6_ksize", 7),
+                                 device_id=device_id, seed=seed + rank)
+            _load_checkpoint(self.engine, os.path.join(model_load_dir, "variables", "variables.npz"), with_state=True)
+        else:
+            self.engine = Engine(num_classes, widths=widths, fc6_ksize=fc6_ksize, device_id=device_id, seed=seed + rank)
+            self._load_vgg16()
+            if variables_load_dir is not None:
+                self.load_variables(variables_load_dir)
+        self.engine.broadcast_params(0)
+        self.engine.metrics_reset()
+
+    # fcn8s_tensorflow.py:127-152 -- the encoder weights enter here
+    def _load_vgg16(self):
+        d = str(self.vgg16_dir)
+        if d.startswith('synthetic'):
+            s = int(d.split(':', 1)[1]) if ':' in d else 0
+            self.engine.init_params(seed=s)
+            return
+        npz = os.path.join(d, 'vgg16_weights.npz')
+        if os.path.isfile(npz):
+            self.engine.init_params(seed=0)          # decoder: truncated normal (:159-160); encoder overwritten below
+            data = np.load(npz)
+            params = {k: data[k] for k in data.files if k in self.engine.specs}
+            missing = [k for k in self.engine.specs if ('conv' in k.split('/')[0] and 'trans' not in k or k.startswith('fc6/') or k.startswith('fc7/')) and k not in params]
+            if missing:
+                raise ValueError("vgg16_weights.npz lacks variables: {}".format(missing[:5]))
+            self.engine.set_params(params)
+            return
+        if os.path.isfile(os.path.join(d, 'saved_model.pb')):
+            raise NotImplementedError("'{}' holds a TensorFlow SavedModel; its variables bundle cannot be read without TensorFlow. "
+                                      "Export the variables to vgg16_weights.npz (names as in the reference, e.g. 'conv1_1/filter', HWIO layout).".format(d))
+        raise ValueError("`vgg16_dir` must contain vgg16_weights.npz or be 'synthetic[:seed]', got '{}'.".format(d))
+
+    def _initialize_metrics(self, metrics):
+        '''fcn8s_tensorflow.py:371-397'''
+        self.metric_names = []
+        self.best_metric_values = []
+        self.metric_update_ops = []
+        self.metric_value_tensors = []
+        if 'loss' in metrics:
+            self.metric_names.append('loss'); self.best_metric_values.append(99999999.9)
+            self.metric_update_ops.append('mean_loss_update_op'); self.metric_value_tensors.append('mean_loss_value')
+        if 'mean_iou' in metrics:
+            self.metric_names.append('mean_iou'); self.best_metric_values.append(0.0)
+            self.metric_update_ops.append('mean_iou_update_op'); self.metric_value_tensors.append('mean_iou_value')
+        if 'accuracy' in metrics:
+            self.metric_names.append('accuracy'); self.best_metric_values.append(0.0)
+            self.metric_update_ops.append('acc_update_op'); self.metric_value_tensors.append('acc_value')
+
+    def train(self,
+              train_generator,
+              epochs,
+              steps_per_epoch,
+              learning_rate_schedule,
+              keep_prob=0.5,
+              l2_regularization=0.0,
+              eval_dataset='train',
+              eval_frequency=5,
+              val_generator=None,
+              val_steps=None,
+              metrics={},
+              save_during_training=False,
+              save_dir=None,
+              save_best_only=True,
+              save_tags=['default'],
+              save_name='',
+              save_frequency=5,
+              saver='saved_model',
+              monitor='loss',
+              record_summaries=True,
+              summaries_frequency=10,
+              summaries_dir=None,
+              summaries_name=None,
+              training_loss_display_averaging=3):
+        '''Trains the model; arguments as fcn8s_tensorflow.py:424-503.  Summaries are written as
+        JSON lines (`<summaries_dir>/<summaries_name>/scalars.jsonl`) instead of TensorBoard
+        event files; if `summaries_dir` is None nothing is recorded.'''
+        if not eval_dataset in ['train', 'val']:
+            raise ValueError("`eval_dataset` must be one of 'train' or 'val', but is '{}'.".format(eval_dataset))
+
+        if (eval_dataset == 'val') and ((val_generator is None) or (val_steps is None)):
+            raise ValueError("When eval_dataset == 'val', a `val_generator` and `val_steps` must be passed.")
+
+        for metric in metrics:
+            if not metric in ['loss', 'mean_iou', 'accuracy']:
+                raise ValueError("{} is not a valid metric. Valid metrics are ['loss', mean_iou', 'accuracy']".format(metric))
+
+        if (not monitor in metrics) and (not monitor == 'loss'):
+            raise ValueError('You are trying to monitor {}, but it is not in `metrics` and is therefore not being computed.'.format(monitor))
+
+        self.eval_dataset = eval_dataset
+
+        self.g_step = self.engine.global_step
+        learning_rate = learning_rate_schedule(self.g_step)
+
+        self._initialize_metrics(metrics)
+
+        training_writer = evaluation_writer = None
+        if record_summaries and summaries_dir is not None and self.engine.rank == 0:
+            training_writer = _ScalarLog(os.path.join(summaries_dir, summaries_name or 'training'))
+            if len(metrics) > 0:
+                evaluation_writer = _ScalarLog(os.path.join(summaries_dir, (summaries_name or 'training') + '_eval'))
+
+        for epoch in range(1, epochs + 1):
+
+            loss_history = deque(maxlen=training_loss_display_averaging)
+
+            tr = trange(steps_per_epoch, file=sys.stdout, disable=self.engine.rank != 0)
+            tr.set_description('Epoch {}/{}'.format(epoch, epochs))
+
+            for train_step in tr:
+
+                batch_images, batch_labels = next(train_generator)
+
+                current_loss, self.g_step = self.engine.train_step(batch_images, batch_labels,
+                                                                   learning_rate=learning_rate,
+                                                                   keep_prob=keep_prob,
+                                                                   l2_rate=l2_regularization)
+                if training_writer is not None and ((self.g_step - 1) % summaries_frequency == 0):
+                    training_writer.add(self.g_step, total_loss=current_loss, learning_rate=learning_rate)
+
+                self.variables_updated = True
+
+                loss_history.append(current_loss)
+                losses = np.array(loss_history)
+                self.training_loss = np.mean(losses)
+
+                tr.set_postfix(ordered_dict={'loss': self.training_loss,
+                                             'learning rate': learning_rate})
+
+                learning_rate = learning_rate_schedule(self.g_step)
+
+            if (len(metrics) > 0) and (epoch % eval_frequency == 0):
+
+                if eval_dataset == 'train':
+                    data_generator = train_generator
+                    num_batches = steps_per_epoch
+                    description = 'Evaluation on training dataset'
+                elif eval_dataset == 'val':
+                    data_generator = val_generator
+                    num_batches = val_steps
+                    description = 'Evaluation on validation dataset'
+
+                self._evaluate(data_generator=data_generator,
+                               metrics=metrics,
+                               num_batches=num_batches,
+                               l2_regularization=l2_regularization,
+                               description=description)
+
+                if evaluation_writer is not None:
+                    evaluation_writer.add(self.g_step, **dict(zip(self.metric_names, self.metric_values)))
+
+            if save_during_training and (epoch % save_frequency == 0):
+
+                save = False
+                if save_best_only:
+                    if (monitor == 'loss' and
+                        (not 'loss' in self.metric_names) and
+                        self.training_loss < self.best_training_loss):
+                        save = True
+                    else:
+                        i = self.metric_names.index(monitor)
+                        if (monitor == 'loss') and (self.metric_values[i] < self.best_metric_values[i]):
+                            save = True
+                        elif (monitor in ['accuracry', 'mean_iou']) and (self.metric_values[i] > self.best_metric_values[i]):
+                            save = True          # ('accuracry': the reference's spelling, :626 -- accuracy never triggers a save there either)
+                    if save:
+                        print('New best {} value, saving model.'.format(monitor))
+                    else:
+                        print('No improvement over previous best {} value, not saving model.'.format(monitor))
+                else:
+                    save = True
+
+                if save:
+                    self.save(model_save_dir=save_dir,
+                              saver=saver,
+                              tags=save_tags,
+                              name=save_name,
+                              include_global_step=True,
+                              include_last_training_loss=True,
+                              include_metrics=(len(self.metric_names) > 0))
+
+            if self.training_loss < self.best_training_loss:
+                self.best_training_loss = self.training_loss
+
+            if epoch % eval_frequency == 0:
+
+                for i, metric_name in enumerate(self.metric_names):
+                    if (metric_name == 'loss') and (self.metric_values[i] < self.best_metric_values[i]):
+                        self.best_metric_values[i] = self.metric_values[i]
+                    elif (metric_name in ['accuracry', 'mean_iou']) and (self.metric_values[i] > self.best_metric_values[i]):
+                        self.best_metric_values[i] = self.metric_values[i]
+
+    def _evaluate(self, data_generator, metrics, num_batches, l2_regularization, description='Running evaluation'):
+        '''fcn8s_tensorflow.py:660-697'''
+        self.engine.metrics_reset()
+
+        tr = trange(num_batches, file=sys.stdout, disable=self.engine.rank != 0)
+        tr.set_description(description)
+
+        for step in tr:
+            batch_images, batch_labels = next(data_generator)
+            self.engine.eval_step(batch_images, batch_labels, l2_rate=l2_regularization)
+
+        self.engine.metrics_allreduce()
+        values = dict(zip(('loss', 'mean_iou', 'accuracy'), self.engine.metrics_get()))
+        self.metric_values = [values[n] for n in self.metric_names]
+
+        evaluation_results_string = ''
+        for i, metric_name in enumerate(self.metric_names):
+            evaluation_results_string += metric_name + ': {:.4f}  '.format(self.metric_values[i])
+        if self.engine.rank == 0:
+            print(evaluation_results_string)
+
+    def evaluate(self, data_generator, num_batches, metrics={'loss', 'mean_iou', 'accuracy'}, l2_regularization=0.0, dataset='val'):
+        '''fcn8s_tensorflow.py:699-741'''
+        for metric in metrics:
+            if not metric in ['loss', 'mean_iou', 'accuracy']:
+                raise ValueError("{} is not a valid metric. Valid metrics are ['loss', mean_iou', 'accuracy']".format(metric))
+
+        if not dataset in {'train', 'val'}:
+            raise ValueError("`dataset` must be either 'train' or 'val'.")
+
+        self._initialize_metrics(metrics)
+
+        self._evaluate(data_generator, metrics, num_batches, l2_regularization, description='Running evaluation')
+
+        if dataset == 'val':
+            self.eval_dataset = 'val'
+        else:
+            self.eval_dataset = 'train'
+
+    def predict(self, images, argmax=True):
+        '''fcn8s_tensorflow.py:743-770.  `images`: array-like of rank 4 (a list of HWC arrays works).
+        Returns int64 class ids (N,H,W) or the float32 softmax (N,H,W,C).'''
+        if isinstance(images, (list, tuple)):
+            images = np.asarray(images)
+        return self.engine.predict(images, argmax=argmax)
+
+    def predict_and_save(self,
+                         results_dir,
+                         images_dir,
+                         color_map,
+                         resize=False,
+                         image_file_extension='png',
+                         include_unprocessed_image=False,
+                         arrangement='vertical',
+                         overwrite_existing=True):
+        '''fcn8s_tensorflow.py:772-855 (PIL instead of scipy.misc / helpers.visualization_utils).'''
+        from PIL import Image
+
+        if overwrite_existing and os.path.exists(results_dir):
+            shutil.rmtree(results_dir)
+        os.makedirs(results_dir)
+
+        image_paths = glob(os.path.join(images_dir, '*.' + image_file_extension))
+        num_images = len(image_paths)
+
+        print('The segmented images will be saved to "{}"'.format(results_dir))
+
+        tr = trange(num_images, file=sys.stdout)
+        tr.set_description('Processing images')
+
+        for i in tr:
+            filepath = image_paths[i]
+            pil = Image.open(filepath).convert('RGB')
+            if resize and not np.array_equal((pil.height, pil.width), resize):
+                pil = pil.resize((resize[1], resize[0]), Image.BILINEAR)
+            image = np.asarray(pil)
+            img_height, img_width, img_ch = image.shape
+
+            prediction = self.predict([image], argmax=False)
+            processed = print_segmentation_onto_image(image=image, prediction=prediction, color_map=color_map)
+
+            if include_unprocessed_image:
+                if arrangement == 'vertical':
+                    canvas = Image.new('RGB', (img_width, 2 * img_height))
+                    canvas.paste(processed, (0, 0)); canvas.paste(pil, (0, img_height))
+                else:
+                    canvas = Image.new('RGB', (2 * img_width, img_height))
+                    canvas.paste(processed, (0, 0)); canvas.paste(pil, (img_width, 0))
+                processed = canvas
+
+            processed.save(os.path.join(results_dir, os.path.basename(filepath)))
+
+    def save(self,
+             model_save_dir,
+             saver,
+             tags=['default'],
+             name=None,
+             include_global_step=True,
+             include_last_training_loss=True,
+             include_metrics=True,
+             force_save=False):
+        '''fcn8s_tensorflow.py:857-936: same guard, same validation, same directory name.'''
+        if (not self.variables_updated) and (not force_save):
+            print("Abort: Nothing to save, no training has been performed since the model was last saved.")
+            return
+
+        if not saver in _SAVERS:
+            raise ValueError("Unexpected value for `saver`: Can be either 'saved_model' or 'train_saver', but received '{}'.".format(saver))
+
+        if self.training_loss is None:
+            include_last_training_loss = False
+
+        model_name = 'saved_model'
+        if not name is None:
+            model_name += '_' + name
+        if include_global_step:
+            self.g_step = self.engine.global_step
+            model_name += '_(globalstep-{})'.format(self.g_step)
+        if include_last_training_loss:
+            model_name += '_(trainloss-{:.4f})'.format(self.training_loss)
+        if include_metrics:
+            if self.eval_dataset == 'val':
+                model_name += '_(eval_on_val_dataset)'
+            else:
+                model_name += '_(eval_on_train_dataset)'
+            for i in range(len(self.metric_names)):
+                model_name += '_({}-{:.4f})'.format(self.metric_names[i], self.metric_values[i])
+        if not (include_global_step or include_last_training_loss or include_metrics) and (name is None):
+            model_name += '_{}'.format(time.time())
+
+        if self.engine.rank == 0:
+            target = os.path.join(model_save_dir, model_name)
+            if saver == 'saved_model':
+                if os.path.exists(target):
+                    raise AssertionError("Export directory already exists. Please specify a different export directory: {}".format(target))
+                os.makedirs(os.path.join(target, 'variables'))
+                _save_checkpoint(self.engine, os.path.join(target, 'variables', 'variables.npz'))
+                _write_meta(target, self.engine, tags)
+            else:
+                os.makedirs(target, exist_ok=True)
+                _save_checkpoint(self.engine, os.path.join(target, 'variables.npz'))
+                _write_meta(target, self.engine, tags)
+                _prune_checkpoints(model_save_dir, keep=5)          # Saver(max_to_keep=5), :927-930
+        self.last_saved_model_name = model_name
+
+        self.variables_updated = False
+
+    def load_variables(self, path):
+        '''fcn8s_tensorflow.py:938-944.  `path` is the prefix `<dir>/<model_name>/variables`
+        (as passed to tf.train.Saver.restore) or the `.npz` file itself.'''
+        f = path if path.endswith('.npz') else path + '.npz'
+        if not os.path.isfile(f):
+            raise ValueError("The passed save_path is not a valid checkpoint: {}".format(path))
+        _load_checkpoint(self.engine, f, with_state=True)
+
+    def close(self):
+        '''fcn8s_tensorflow.py:946-952'''
+        self.engine.close()
+        print("The session has been closed.")
+
+
+# ---------------------------------------------------------------------------------------------
+# checkpoint format: variables by reference name + Adam slots + global_step
+# ---------------------------------------------------------------------------------------------
+def _save_checkpoint(engine, path):
+    arrays = dict(engine.get_params())
+    m, v = engine.get_opt_state()
+    arrays['__adam_m__'] = m
+    arrays['__adam_v__'] = v
+    arrays['optimizer/global_step'] = np.asarray(engine.global_step, dtype=np.int64)
+    tmp = path + '.tmp.npz'
+    np.savez(tmp, **arrays)
+    os.replace(tmp, path)
+
+
+def _load_checkpoint(engine, path, with_state=True):
+    data = np.load(path)
+    engine.set_params({k: data[k] for k in data.files if k in engine.specs})
+    if with_state:
+        if '__adam_m__' in data.files:
+            engine.set_opt_state(data['__adam_m__'], data['__adam_v__'])
+        if 'optimizer/global_step' in data.files:
+            engine.global_step = int(data['optimizer/global_step'])
+
+
+def _write_meta(target, engine, tags):
+    with open(os.path.join(target, 'fcn8s_meta.json'), 'w') as f:
+        json.dump({'format': 'fcn8s_tensorflow_amd/1', 'num_classes': engine.num_classes, 'widths': list(engine.widths),
+                   'fc6_ksize': engine.specs['fc6/weights'][0][0], 'tags': list(tags) if tags else None,
+                   'global_step': engine.global_step}, f)
+
+
+def _read_meta(model_dir):
+    f = os.path.join(model_dir, 'fcn8s_meta.json')
+    if not os.path.isfile(f):
+        if os.path.isfile(os.path.join(model_dir, 'saved_model.pb')):
+            raise NotImplementedError("'{}' is a TensorFlow SavedModel; it cannot be loaded without TensorFlow.".format(model_dir))
+        raise IOError("SavedModel file does not exist at: {}".format(model_dir))
+    with open(f) as fh:
+        return json.load(fh)
+
+
+def _prune_checkpoints(save_dir, keep):
+    dirs = [d for d in glob(os.path.join(save_dir, 'saved_model*')) if os.path.isfile(os.path.join(d, 'variables.npz'))]
+    dirs.sort(key=os.path.getmtime)
+    for d in dirs[:-keep]:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+class _ScalarLog:
+    def __init__(self, logdir):
+        os.makedirs(logdir, exist_ok=True)
+        self.path = os.path.join(logdir, 'scalars.jsonl')
+
+    def add(self, step, **scalars):
+        with open(self.path, 'a') as f:
+            f.write(json.dumps(dict(step=int(step), **{k: float(v) for k, v in scalars.items()})) + '\n')
+
+
+def print_segmentation_onto_image(image, prediction, color_map):
+    '''helpers/visualization_utils.py:7-52: RGBA overlay of the argmax map (returns a PIL image).'''
+    from PIL import Image
+    if (image.shape[0] != prediction.shape[1]) or (image.shape[1] != prediction.shape[2]):
+        raise ValueError("'image' and 'prediction' must have the same height and width, but image has spatial dimensions ({}, {}) and prediction has spatial dimensions ({}, {}).".format(image.shape[0], image.shape[1], prediction.shape[1], prediction.shape[2]))
+    mask = np.zeros(shape=(image.shape[0], image.shape[1], 4), dtype=np.uint8)
+    segmentation_map = np.squeeze(np.argmax(prediction, axis=-1))
+    for segmentation_class, color_value in color_map.items():
+        mask[segmentation_map == segmentation_class] = color_value
+    mask = Image.fromarray(mask, mode='RGBA')
+    out = Image.fromarray(np.asarray(image, dtype=np.uint8)).convert('RGB')
+    out.paste(mask, box=None, mask=mask)
+    return out

@@ -1,0 +1,70 @@
+"""world_size-2 data-parallel path on CPU (gloo): the bucketed SUM all-reduce + 1/world scaling
+reproduces the gradient of the global-mean loss.  Gradients come from the oracle (checker); the
+code under test is fcn8s_tensorflow_amd.dp (bucket table from the C library, BucketReducer)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+WIDTHS = (4, 4, 8, 8, 8, 16, 16)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _flat(specs, total, grads):
+    flat = np.zeros(total, np.float32)
+    for k, (shape, off) in specs.items():
+        flat[off:off + grads[k].size] = grads[k].reshape(-1)
+    return flat
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import fcn8s_oracle as orc
+    from fcn8s_tensorflow_amd import dp
+    specs, total, buckets = dp.layout(4, WIDTHS, 3)
+    P = orc.init_params(4, WIDTHS, fc6_ksize=3, seed=0, decoder_std_scale=50.0, bias_std=0.1)
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (2 * world, 32, 32, 3), dtype=np.uint8)
+    lab = rng.integers(0, 4, (2 * world, 32, 32), dtype=np.uint8)
+    sl = slice(2 * rank, 2 * rank + 2)                                 # this rank's shard
+    _, g_local, _ = orc.loss_and_grads(P, img[sl], orc.one_hot(lab[sl], 4).astype(np.float32), l2_rate=0.01)
+    flat = torch.from_numpy(_flat(specs, total, g_local))
+    red = dp.BucketReducer(flat, buckets)
+    for b in range(len(buckets)):
+        red.reduce_bucket(b)
+    red.wait()
+    flat *= red.grad_scale()
+    _, g_global, _ = orc.loss_and_grads(P, img, orc.one_hot(lab, 4).astype(np.float32), l2_rate=0.01)
+    want = _flat(specs, total, g_global)
+    err = float(np.abs(flat.numpy() - want).max() / np.abs(want).max())
+    # confusion-matrix / loss reduction used by evaluate(): sums over ranks
+    cm = torch.tensor(orc.confusion_matrix(lab[sl], (lab[sl] + rank) % 4, 4).reshape(-1)).double()
+    dist.all_reduce(cm)
+    out[rank] = (err, float(cm.sum()), red.grad_scale())
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_global_batch_gradient():
+    world = 2
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == world
+    for r in range(world):
+        err, cm_total, scale = out[r]
+        assert err < 1e-5, err
+        assert cm_total == 2 * world * 32 * 32 and scale == 0.5
+
+
+def test_bucket_reducer_is_a_noop_without_process_group():
+    from fcn8s_tensorflow_amd import dp
+    t = torch.ones(10)
+    red = dp.BucketReducer(t, [(0, 5), (5, 5)])
+    red.reduce_bucket(0); red.reduce_bucket(1); red.wait()
+    assert red.grad_scale() == 1.0 and (t == 1).all()

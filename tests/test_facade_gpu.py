@@ -1,0 +1,145 @@
+"""The FCN8s facade (drop-in for fcn8s_tensorflow.FCN8s) end to end on the GPU: training loop,
+evaluation, prediction, save / resume, the reference's validation errors, and the RCCL code path
+with a one-rank process group."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fcn8s_oracle as orc  # noqa: E402  (checker only)
+
+SMALL = (8, 16, 32, 64, 64, 128, 128)
+
+
+def gen(n, h, w, seed, onehot=True):
+    rng = np.random.default_rng(seed)
+    while True:
+        img = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        lab = rng.integers(0, 20, (n, h, w), dtype=np.uint8)
+        lab[:, : h // 2] = (img[:, : h // 2, :, 0] > 127).astype(np.uint8) * 5      # learnable structure
+        yield img, (orc.one_hot(lab, 20) if onehot else lab)
+
+
+def make(**kw):
+    from fcn8s_tensorflow_amd.fcn8s import FCN8s
+    return FCN8s(vgg16_dir='synthetic:3', num_classes=20, widths=SMALL, **kw)
+
+
+def test_constructor_validation():
+    from fcn8s_tensorflow_amd.fcn8s import FCN8s
+    with pytest.raises(ValueError, match="You must provide either both"):
+        FCN8s()
+    with pytest.raises(ValueError):
+        FCN8s(vgg16_dir='/nonexistent/dir', num_classes=20, widths=SMALL)
+
+
+def test_train_evaluate_predict_save_resume(tmp_path, capsys):
+    m = make()
+    g = gen(2, 32, 64, 0)
+    with pytest.raises(ValueError, match="`eval_dataset` must be one of"):
+        m.train(g, 1, 1, lambda s: 1e-3, eval_dataset='test')
+    with pytest.raises(ValueError, match="not a valid metric"):
+        m.train(g, 1, 1, lambda s: 1e-3, metrics={'f1'})
+    with pytest.raises(ValueError, match="You are trying to monitor"):
+        m.train(g, 1, 1, lambda s: 1e-3, monitor='mean_iou')
+    with pytest.raises(ValueError, match="a `val_generator` and `val_steps` must be passed"):
+        m.train(g, 1, 1, lambda s: 1e-3, eval_dataset='val')
+
+    m.save(str(tmp_path), 'saved_model')                      # nothing trained yet
+    assert "Abort: Nothing to save" in capsys.readouterr().out
+
+    lrs = []
+    def schedule(step):
+        lrs.append(step)
+        return 1e-3 if step < 4 else 5e-4
+    m.train(g, epochs=2, steps_per_epoch=3, learning_rate_schedule=schedule, keep_prob=0.5, l2_regularization=1e-4,
+            eval_dataset='val', eval_frequency=1, val_generator=gen(2, 32, 64, 1), val_steps=2,
+            metrics={'loss', 'mean_iou', 'accuracy'}, save_during_training=True, save_dir=str(tmp_path),
+            save_best_only=True, save_frequency=1, saver='saved_model', monitor='loss',
+            summaries_dir=str(tmp_path / 'tb'), summaries_name='run', training_loss_display_averaging=3)
+    assert m.g_step == 6 and lrs == [0, 1, 2, 3, 4, 5, 6]
+    assert m.metric_names == ['loss', 'mean_iou', 'accuracy'] and len(m.metric_values) == 3
+    assert np.isfinite(m.training_loss) and m.variables_updated is False
+    saved = [d for d in os.listdir(tmp_path) if d.startswith('saved_model_(globalstep-')]
+    assert saved and all('(eval_on_val_dataset)' in d and '(trainloss-' in d and '(mean_iou-' in d for d in saved)
+    assert os.path.isfile(tmp_path / 'tb' / 'run' / 'scalars.jsonl')
+
+    m.evaluate(gen(2, 32, 64, 2), num_batches=2, metrics={'loss', 'mean_iou'}, dataset='val')
+    assert m.metric_names == ['loss', 'mean_iou'] and m.eval_dataset == 'val'
+    out = capsys.readouterr().out
+    assert 'loss: ' in out and 'mean_iou: ' in out
+    with pytest.raises(ValueError, match="`dataset` must be either"):
+        m.evaluate(g, 1, dataset='test')
+
+    img = next(gen(1, 32, 64, 9))[0][0]
+    pred = m.predict([img])                                    # a Python list of HWC arrays, as the reference allows
+    assert pred.shape == (1, 32, 64) and pred.dtype == np.int64
+    sm = m.predict([img], argmax=False)
+    assert sm.shape == (1, 32, 64, 20) and np.allclose(sm.sum(-1), 1, atol=1e-5)
+    np.testing.assert_array_equal(np.argmax(sm, -1), pred)
+
+    # train_saver + resume: parameters, Adam slots and global_step round-trip
+    m.variables_updated = True
+    m.save(str(tmp_path / 'ck'), 'train_saver', name='x', include_metrics=False)
+    name = m.last_saved_model_name
+    assert name.startswith('saved_model_x_(globalstep-6)_(trainloss-')
+    with pytest.raises(ValueError, match="Unexpected value for `saver`"):
+        m.variables_updated = True
+        m.save(str(tmp_path), 'pickle')
+    params = m.engine.get_params(); mom = m.engine.get_opt_state()
+    m.close()
+    assert "The session has been closed." in capsys.readouterr().out
+
+    m2 = make(variables_load_dir=str(tmp_path / 'ck' / name / 'variables'))
+    assert m2.engine.global_step == 6
+    for k, v in m2.engine.get_params().items():
+        np.testing.assert_array_equal(v, params[k])
+    np.testing.assert_array_equal(m2.engine.get_opt_state()[0], mom[0])
+    np.testing.assert_array_equal(m2.predict([img]), pred)
+    m2.close()
+
+    from fcn8s_tensorflow_amd.fcn8s import FCN8s
+    m3 = FCN8s(model_load_dir=str(tmp_path / saved[-1]), tags=['default'])
+    assert m3.num_classes == 20 and m3.engine.global_step in (3, 6)
+    m3.close()
+
+
+def test_predict_and_save(tmp_path):
+    from PIL import Image
+    m = make()
+    src = tmp_path / 'in'; src.mkdir()
+    rng = np.random.default_rng(0)
+    for i in range(2):
+        Image.fromarray(rng.integers(0, 256, (32, 64, 3), dtype=np.uint8)).save(src / ('f%d.png' % i))
+    m.predict_and_save(str(tmp_path / 'out'), str(src), {c: (0, 255, 0, 127) for c in range(20)}, include_unprocessed_image=True)
+    outs = sorted(os.listdir(tmp_path / 'out'))
+    assert outs == ['f0.png', 'f1.png'] and Image.open(tmp_path / 'out' / 'f0.png').size == (64, 64)
+    m.close()
+
+
+def test_rccl_path_with_one_rank_process_group():
+    """Exercises the split-phase train step (forward_loss / backward_bucket / all-reduce / update)
+    under an initialised nccl (= RCCL) process group; 8-GPU runs are the driver's."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from fcn8s_tensorflow_amd.engine import Engine
+        from fcn8s_tensorflow_amd import _lib as L
+        P = orc.init_params(20, SMALL, seed=1, decoder_std_scale=30.0, bias_std=0.05)
+        img, lab = next(gen(2, 32, 64, 4, onehot=False))
+        a = Engine(20, widths=SMALL); a.set_params(P)
+        b = Engine(20, widths=SMALL); b.set_params(P)
+        la, _ = a.train_step(img, lab, 1e-3, keep_prob=1.0)                               # fused C call
+        lb, _ = b.train_step(img, lab, 1e-3, keep_prob=1.0, optimizer=L.OPT_SGD_MOMENTUM)   # split-phase path
+        assert abs(la - lb) < 1e-6
+        ga, gb = a.get_grads(), b.get_grads()
+        for k in ga:
+            assert np.abs(ga[k] - gb[k]).max() <= 1e-4 * (np.abs(ga[k]).max() + 1e-30), k   # only atomics order differs
+        a.metrics_reset(); a.eval_step(img, lab); a.metrics_allreduce()
+        assert a.metrics_raw()[0].sum() == lab.size
+        a.close(); b.close()
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,95 @@
+"""The host feeder drop-in (BatchGenerator + label conversions) against golden vectors captured
+from the reference (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from fcn8s_tensorflow_amd import ground_truth_conversion_utils as gt
+from fcn8s_tensorflow_amd.batch_generator import BatchGenerator, DataError
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_one_hot_and_lut_golden():
+    d = np.load(os.path.join(GOLD, "onehot.npz"))
+    oh = gt.convert_IDs_to_one_hot(d["ids"], 20)
+    assert oh.dtype == np.bool_
+    np.testing.assert_array_equal(oh, d["onehot"])
+    np.testing.assert_array_equal(gt.convert_one_hot_to_IDs(oh), d["back"])
+    l = np.load(os.path.join(GOLD, "id_lut.npz"))
+    np.testing.assert_array_equal(gt.convert_IDs_to_IDs(l["raw"], l["lut"]), l["mapped"])
+    assert l["lut"].max() == 19 and (np.unique(l["lut"]) == np.arange(20)).all()      # 35 ids -> 20 trainIds, 0 = void
+    out = gt.convert_IDs_to_IDs_partial(np.array([[1, 2], [3, 1]]), {1: 9})
+    assert out.tolist() == [[9, 2], [3, 9]]
+    cm = {(255, 0, 0): 1, (0, 255, 0): 2}
+    col = np.array([[[255, 0, 0], [0, 255, 0]], [[0, 255, 0], [9, 9, 9]]], np.uint8)
+    assert gt.convert_between_IDs_and_colors(col, cm).tolist() == [[1, 2], [2, 0]]
+
+
+@pytest.fixture()
+def dataset(tmp_path):
+    d = np.load(os.path.join(GOLD, "batchgen_contract.npz"))
+    idir, gdir = tmp_path / "img" / "city", tmp_path / "gt" / "city"
+    idir.mkdir(parents=True); gdir.mkdir(parents=True)
+    for i in range(3):
+        Image.fromarray(d["imgs"][i]).save(idir / ("city_%06d_leftImg8bit.png" % i))
+        Image.fromarray(d["gts"][i]).save(gdir / ("city_%06d_gtFine_labelIds.png" % i))
+    gen = BatchGenerator(image_dirs=[str(tmp_path / "img")], image_file_extension="png",
+                         ground_truth_dirs=[str(tmp_path / "gt")], image_name_split_separator="leftImg8bit",
+                         ground_truth_suffix="gtFine_labelIds", check_existence=True, num_classes=20)
+    gen.image_paths.sort()
+    return gen, d, tmp_path
+
+
+def test_generate_matches_reference_contract(dataset):
+    gen, d, _ = dataset
+    assert gen.get_num_files() == int(d["num_files"]) == 3
+    g = gen.generate(batch_size=2, convert_to_one_hot=True, shuffle=False)
+    for b in range(3):                                  # full batch, short last batch, wrap-around
+        x, y = next(g)
+        assert x.dtype == np.uint8 and y.dtype == np.bool_
+        np.testing.assert_array_equal(x, d["x%d" % b]); np.testing.assert_array_equal(y, d["y%d" % b])
+    x, y = next(gen.generate(batch_size=3, convert_to_one_hot=False, shuffle=False))
+    np.testing.assert_array_equal(x, d["x_ids"]); np.testing.assert_array_equal(y, d["y_ids"])
+    assert y.dtype == np.uint8 and y.shape == (3, 8, 16)
+
+
+def test_random_crop_places_like_the_reference(dataset):
+    gen, d, _ = dataset
+    np.random.seed(7)                                   # same seed as the fixture capture
+    x, y = next(gen.generate(batch_size=3, convert_to_one_hot=False, random_crop=(12, 10), void_class_id=0, shuffle=False))
+    np.testing.assert_array_equal(x, d["x_crop"]); np.testing.assert_array_equal(y, d["y_crop"])
+
+
+def test_augmentations_keep_shapes_and_labels_consistent(dataset):
+    gen, d, _ = dataset
+    np.random.seed(0)
+    g = gen.generate(batch_size=3, convert_to_one_hot=True, void_class_id=0, brightness=(0.5, 2.0, 1.0), flip=1.0,
+                     translate=((1, 3), (1, 2), 1.0), scale=(0.6, 1.4, 1.0), resize=(16, 32), shuffle=False)
+    x, y = next(g)
+    assert x.shape == (3, 16, 32, 3) and y.shape == (3, 16, 32, 20) and (y.sum(-1) == 1).all()
+    x2, y2 = next(gen.generate(batch_size=3, convert_to_one_hot=False, flip=1.0, shuffle=False))
+    np.testing.assert_array_equal(x2, d["imgs"][:, :, ::-1]); np.testing.assert_array_equal(y2, d["gts"][:, :, ::-1])
+    xg, _ = next(gen.generate(batch_size=1, convert_to_one_hot=False, gray=True, shuffle=False))
+    assert xg.shape == (1, 8, 16, 1)
+
+
+def test_errors_and_process_all(dataset, tmp_path):
+    gen, d, root = dataset
+    with pytest.raises(DataError):
+        BatchGenerator(image_dirs=[str(root / "gt" / "nothing")])
+    os.remove(root / "gt" / "city" / "city_000001_gtFine_labelIds.png")
+    with pytest.raises(DataError):
+        BatchGenerator(image_dirs=[str(root / "img")], ground_truth_dirs=[str(root / "gt")],
+                       image_name_split_separator="leftImg8bit", ground_truth_suffix="gtFine_labelIds")
+    nogt = BatchGenerator(image_dirs=[str(root / "img")])
+    with pytest.raises(ValueError):
+        next(nogt.generate(batch_size=1))               # one-hot conversion without ground truth
+    imgs = next(nogt.generate(batch_size=2, convert_to_one_hot=False, shuffle=False))
+    assert isinstance(imgs, np.ndarray) and imgs.shape == (2, 8, 16, 3)
+    exp = BatchGenerator(image_dirs=[str(root / "img")], root_dir=str(root), export_dir=str(root / "out"))
+    exp.process_all(resize=(4, 8), batch_size=2)
+    assert sorted(os.listdir(root / "out" / "img" / "city")) == sorted(os.listdir(root / "img" / "city"))
+    assert np.asarray(Image.open(root / "out" / "img" / "city" / "city_000000_leftImg8bit.png")).shape == (4, 8, 3)
