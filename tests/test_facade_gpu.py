@@ -62,7 +62,7 @@ def test_train_evaluate_predict_save_resume(tmp_path, capsys):
     assert m.g_step == 6 and lrs == [0, 1, 2, 3, 4, 5, 6]
     assert m.metric_names == ['loss', 'mean_iou', 'accuracy'] and len(m.metric_values) == 3
     assert np.isfinite(m.training_loss) and m.variables_updated is False
-    saved = [d for d in os.listdir(tmp_path) if d.startswith('saved_model_(globalstep-')]
+    saved = [d for d in os.listdir(tmp_path) if d.startswith('saved_model__(globalstep-')]   # save_name='' -> 'saved_model_' + '' + '_(globalstep-..', as in the reference
     assert saved and all('(eval_on_val_dataset)' in d and '(trainloss-' in d and '(mean_iou-' in d for d in saved)
     assert os.path.isfile(tmp_path / 'tb' / 'run' / 'scalars.jsonl')
 
