@@ -52,6 +52,10 @@ struct WgradArgs {
     float* colsum;                     // optional: colsum[j] += sum_p B[p,j]  (bias gradient), or nullptr
 };
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
+// 3x3 SAME conv weight (+bias) gradient, all nine taps per block; returns false if the shape is not
+// covered (Cin % 64, Cout % 64, W % 16), in which case the caller falls back to launch_wgrad.
+bool launch_wgrad3x3(const float* X, const float* dZ, float* dW, float* db, int N, int H, int W, int Cin, int Cout,
+                     hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // Element-wise / reduction kernels (HBM-bound)

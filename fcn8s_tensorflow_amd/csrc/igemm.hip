@@ -16,13 +16,24 @@
 namespace fcn8s {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BK_ = 16;
 
 static __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // ===========================================================================
 // forward / dgrad / transposed-conv implicit GEMM
 // ===========================================================================
-template <int BM, int BN, int WM, int WN>
+// FAST = (Cin % 16 == 0, Cout % BN == 0, one phase): no K / N predicates, the (tap, ci) position of
+// the next K-tile and the per-row source pointers are advanced incrementally (no integer division in
+// the loop) and every global load is unconditional (out-of-image rows read a safe address and are
+// zeroed by a select), which keeps the loop free of exec-mask branches.
+static __device__ __attribute__((noinline)) float dropout_apply(float v, unsigned long long idx, unsigned long long seed,
+                                                               unsigned int stream, float keep)
+{
+    return philox_uniform(idx, seed, stream) < keep ? v / keep : 0.f;
+}
+
+template <int BM, int BN, int WM, int WN, bool FAST>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
 {
     constexpr int BK = 16, LDA = 20, LDB = BN;
@@ -64,7 +75,50 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
     const int a_c4 = (tid & 3) * 4;
 
     float4 ra[A_LD], rb[B_LD];
+    // ---- FAST path state: position of the next tile to load
+    int f_ci0 = 0, f_ty = 0, f_tx = 0;
+    const float* a_ptr[A_LD];
+    bool a_val[A_LD];
+    const float* b_ptr[B_LD];
+    auto set_tap = [&]() {
+        const int dy = f_ty * p.tap_step + p.tap_off, dx = f_tx * p.tap_step + p.tap_off;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+            a_val[i] = a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const long long pix = a_val[i] ? a_base[i] + (long long)iy * p.Wi + ix : 0;
+            a_ptr[i] = p.x + pix * p.ldx + a_c4;
+        }
+    };
+    if (FAST) {
+        set_tap();
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int f = tid + i * 256;
+            const int k = f / (BN / 4), j = (f - k * (BN / 4)) * 4;
+            b_ptr[i] = Wp + (long long)k * p.Cout + n0 + j;
+        }
+    }
+    auto gload_fast = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const float4 v = ldg4(a_ptr[i] + f_ci0);
+            ra[i] = a_val[i] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            if (B_F4 % 256 == 0 || tid + i * 256 < B_F4) rb[i] = ldg4(b_ptr[i]);
+            b_ptr[i] += (long long)BK * p.Cout;
+        }
+        f_ci0 += BK;
+        if (f_ci0 == p.Cin) {
+            f_ci0 = 0;
+            if (++f_tx == p.KW) { f_tx = 0; ++f_ty; }
+            set_tap();           // one tap past the end computes pointers that are never dereferenced
+        }
+    };
     auto gload = [&](int kt) {
+        if (FAST) { gload_fast(); return; }
         const int kg = kt * BK + a_c4;
         const bool kok = kg < p.Ktot;
         const int tap = kg / p.Cin, ci = kg - tap * p.Cin;
@@ -180,10 +234,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
                 if (p.addend) v += p.addend[off + col];
                 if (p.relu) v = v > 0.f ? v : 0.f;
                 if (p.mask) v = p.mask[off + col] > 0.f ? v * p.mask_scale : 0.f;
-                if (p.dropout) {
-                    const float u = philox_uniform((unsigned long long)(off + col), p.seed, p.stream_id);
-                    v = u < p.keep_prob ? v / p.keep_prob : 0.f;
-                }
+                if (p.dropout) v = dropout_apply(v, (unsigned long long)(off + col), p.seed, p.stream_id, p.keep_prob);
                 p.y[off + col] = v;
             }
         }
@@ -194,7 +245,9 @@ template <int BM, int BN, int WM, int WN>
 static void launch_igemm_cfg(const IgemmArgs& a, int phases, hipStream_t s)
 {
     dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN), (unsigned)phases);
-    hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
+    const bool fast = phases == 1 && a.Cin % 16 == 0 && a.Cout % BN == 0 && a.Ktot % a.Cin == 0;
+    if (fast) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);
+    else      hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);
 }
 
 void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s)
@@ -207,7 +260,9 @@ void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s)
 // ===========================================================================
 // weight gradient
 // ===========================================================================
-template <int BM, int BN, int WM, int WN, int WK>
+// FAST = (Adim % BM == 0, Bdim % BN == 0, Pb >= 16): pixel coordinates of each thread's load slots
+// are advanced incrementally (16 pixels per K-tile), loads are unconditional + select.
+template <int BM, int BN, int WM, int WN, int WK, bool FAST>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int chunk)
 {
     constexpr int BK = 16, LDA = BM, LDB = BN;
@@ -234,7 +289,54 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
     const bool do_colsum = p.colsum != nullptr && tap == 0 && ti == 0 && wm == 0;
 
     float4 ra[A_LD], rb[B_LD];
+    // ---- FAST path state (position of the next tile to load)
+    int s_n[A_LD], s_a[A_LD], s_b[A_LD], s_left[A_LD];   // A slots: pixel coords + pixels left before pend
+    const float* b_ptr[B_LD]; int b_left[B_LD];
+    if (FAST) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int f = tid + i * 256;
+            const int pix = f / (BM / 4);
+            const long long pp = pbeg + pix;
+            const long long q = pp < p.P ? pp : 0;
+            s_n[i] = (int)(q / PaPb);
+            const int r = (int)(q - (long long)s_n[i] * PaPb);
+            s_a[i] = r / p.Pb; s_b[i] = r - s_a[i] * p.Pb;
+            s_left[i] = (int)(pend - pp);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int f = tid + i * 256;
+            const int pix = f / (BN / 4), c = (f - pix * (BN / 4)) * 4;
+            b_ptr[i] = p.B + (pbeg + pix) * p.ldb + j0 + c;
+            b_left[i] = (int)(pend - (pbeg + pix));
+        }
+    }
+    auto gload_fast = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int f = tid + i * 256;
+            const int c = (f % (BM / 4)) * 4;
+            const int iy = s_a[i] * p.a_scale + dy, ix = s_b[i] * p.a_scale + dx;
+            const bool ok = s_left[i] > 0 && (unsigned)iy < (unsigned)p.Ha && (unsigned)ix < (unsigned)p.Wa;
+            const long long pixi = ok ? ((long long)s_n[i] * p.Ha + iy) * p.Wa + ix : 0;
+            const float4 v = ldg4(p.A + pixi * p.lda + i0 + c);
+            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            s_left[i] -= BK;
+            s_b[i] += BK;
+            if (s_b[i] >= p.Pb) { s_b[i] -= p.Pb; if (++s_a[i] >= p.Pa) { s_a[i] = 0; ++s_n[i]; } }
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const bool ok = b_left[i] > 0;
+            const float4 v = ldg4(ok ? b_ptr[i] : p.B);
+            rb[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            b_ptr[i] += (long long)BK * p.ldb;
+            b_left[i] -= BK;
+        }
+    };
     auto gload = [&](long long pk) {
+        if (FAST) { gload_fast(); return; }
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             const int f = tid + i * 256;
@@ -346,13 +448,155 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
     }
 }
 
+
+// ===========================================================================
+// 3x3 weight gradient, all nine taps per block
+// ===========================================================================
+// dW[ky][kx][ci][co] += sum_p X[p + (ky-1, kx-1)][ci] * dZ[p][co] for a 64(ci) x 64(co) tile and ALL
+// nine taps: the K-tile is a run of 16 consecutive pixels of one image row; its 3 x 18 input halo and
+// the 16 dZ rows are staged in LDS once and feed 9 x 8 MFMA k-steps per wave (each wave: 32x32 tile,
+// nine accumulators).  Compared with one tap per block this reads X and dZ ~4x less often
+// (66 flop per staged byte instead of 16-32) and amortises the per-K-tile bookkeeping over 72 MFMAs.
+// The bias gradient (column sums of dZ) is accumulated from the LDS copy by wave 0 of the ci-tile-0 blocks.
+struct Wgrad9Args {
+    const float* X; const float* dZ; float* dW; float* db;
+    int N, H, W, Cin, Cout;
+    long long nseg; int segs_per_block;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wgrad9Args p)
+{
+    constexpr int XROWS = 54, XF4 = XROWS * 16, X_LD = (XF4 + 255) / 256;   // 3 x 18 halo pixels, 64 channels
+    __shared__ __attribute__((aligned(16))) float smem[2 * (XROWS * 64 + 16 * 64)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
+    const int nco = p.Cout / 64;
+    const int ti = blockIdx.x / nco, tj = blockIdx.x - ti * nco;
+    const int i0 = ti * 64, j0 = tj * 64;
+    const int wsegs = p.W / 16;
+    const long long s0 = (long long)blockIdx.y * p.segs_per_block;
+    long long s1 = s0 + p.segs_per_block; if (s1 > p.nseg) s1 = p.nseg;
+    const int nkt = (int)(s1 - s0);
+    if (nkt <= 0) return;
+    // position of the next segment to load (block-uniform)
+    int n, h, ws;
+    {
+        const long long per_img = (long long)p.H * wsegs;
+        n = (int)(s0 / per_img);
+        const int r = (int)(s0 - (long long)n * per_img);
+        h = r / wsegs; ws = r - h * wsegs;
+    }
+    int x_dy[X_LD], x_col[X_LD], x_c[X_LD];
+#pragma unroll
+    for (int i = 0; i < X_LD; ++i) {
+        const int f = tid + i * 256;
+        const int prow = f / 16;
+        x_dy[i] = prow / 18 - 1; x_col[i] = prow % 18 - 1; x_c[i] = (f % 16) * 4;
+    }
+    const int d_px = tid / 16, d_c = (tid % 16) * 4;
+
+    float4 rx[X_LD], rd;
+    auto gload = [&]() {
+        const int w0 = ws * 16;
+#pragma unroll
+        for (int i = 0; i < X_LD; ++i) {
+            const int iy = h + x_dy[i], ix = w0 + x_col[i];
+            const bool ok = (XF4 % 256 == 0 || tid + i * 256 < XF4) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const long long pix = ok ? ((long long)n * p.H + iy) * p.W + ix : 0;
+            const float4 v = ldg4(p.X + pix * p.Cin + i0 + x_c[i]);
+            rx[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        rd = ldg4(p.dZ + (((long long)n * p.H + h) * p.W + w0 + d_px) * p.Cout + j0 + d_c);
+        if (++ws == wsegs) { ws = 0; if (++h == p.H) { h = 0; ++n; } }
+    };
+    auto sstore = [&](int buf) {
+        float* Xs = smem + buf * (XROWS * 64 + 16 * 64);
+        float* Ds = Xs + XROWS * 64;
+#pragma unroll
+        for (int i = 0; i < X_LD; ++i) {
+            const int f = tid + i * 256;
+            if (XF4 % 256 == 0 || f < XF4) *reinterpret_cast<float4*>(&Xs[(f / 16) * 64 + x_c[i]]) = rx[i];
+        }
+        *reinterpret_cast<float4*>(&Ds[d_px * 64 + d_c]) = rd;
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = p.db != nullptr && ti == 0 && wave == 0;
+
+    auto compute = [&](int buf) {
+        const float* Xs = smem + buf * (XROWS * 64 + 16 * 64);
+        const float* Ds = Xs + XROWS * 64;
+        const float* Xb = Xs + half * 64 + wm * 32 + (lane & 31);
+        const float* Db = Ds + half * 64 + wn * 32 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float b = Db[kk * 2 * 64];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float a = Xb[(ky * 18 + kk * 2 + kx) * 64];
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ky * 3 + kx], 0, 0, 0);
+                }
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int px = 0; px < 16; ++px) bsum += Ds[px * 64 + lane];
+        }
+    };
+
+    gload();
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) gload();
+        compute(cur);
+        if (kt + 1 < nkt) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    const int col = j0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* Ct = p.dW + (long long)t * p.Cin * p.Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            unsafeAtomicAdd(Ct + (long long)row * p.Cout + col, acc[t][r]);
+        }
+    }
+    if (do_bias) unsafeAtomicAdd(p.db + j0 + lane, bsum);
+}
+
+bool launch_wgrad3x3(const float* X, const float* dZ, float* dW, float* db, int N, int H, int W, int Cin, int Cout,
+                     hipStream_t s)
+{
+    if (Cin % 64 || Cout % 64 || W % 16) return false;
+    Wgrad9Args a{X, dZ, dW, db, N, H, W, Cin, Cout, (long long)N * H * (W / 16), 0};
+    const int tiles = (Cin / 64) * (Cout / 64);
+    long long splits = 4096 / tiles;                   // ~16 blocks per CU in total
+    if (splits < 1) splits = 1;
+    if (splits > (a.nseg + 7) / 8) splits = (a.nseg + 7) / 8;      // at least 8 K-tiles per block
+    if (splits < 1) splits = 1;
+    a.segs_per_block = (int)((a.nseg + splits - 1) / splits);
+    splits = (a.nseg + a.segs_per_block - 1) / a.segs_per_block;
+    hipLaunchKernelGGL(wgrad3x3_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, a);
+    return true;
+}
+
 template <int BM, int BN, int WM, int WN, int WK>
 static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
 {
     const int nti = (a.Adim + BM - 1) / BM, ntj = (a.Bdim + BN - 1) / BN;
     const long long tiles = (long long)nti * ntj * a.ntaps;
     // split the pixel reduction so that ~8 blocks per CU are in flight
-    long long want = (2048 + tiles - 1) / tiles;
+    long long want = 2048 / tiles;                     // floor: stay just under a whole number of resident rounds
     long long maxsplit = (a.P + 255) / 256;            // at least 256 pixels per block
     if (want > maxsplit) want = maxsplit;
     if (want < 1) want = 1;
@@ -360,7 +604,10 @@ static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
     chunk = (chunk + 15) / 16 * 16;
     const int splits = (int)((a.P + chunk - 1) / chunk);
     dim3 grid((unsigned)(nti * ntj), (unsigned)splits, (unsigned)a.ntaps);
-    hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK>), grid, dim3(256), 0, s, a, (int)chunk);
+    constexpr bool full_tiles = (BK_ * BM / 4) % 256 == 0 && (BK_ * BN / 4) % 256 == 0;
+    const bool fast = full_tiles && a.Adim % BM == 0 && a.Bdim % BN == 0 && a.Pb >= 16;
+    if (fast) hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK, true>), grid, dim3(256), 0, s, a, (int)chunk);
+    else      hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK, false>), grid, dim3(256), 0, s, a, (int)chunk);
 }
 
 void launch_wgrad(const WgradArgs& a, hipStream_t s)

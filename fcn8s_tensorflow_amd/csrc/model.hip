@@ -70,7 +70,7 @@ struct fcn8s_model {
     bool have_forward = false, have_loss = false, train_mode = false;
     int next_bucket = 0;
     const uint8_t* cur_labels = nullptr;
-    bool profile = false;
+    bool profile = false, profile_detail = false;
     std::vector<ProfGroup> groups;
     std::string err;
 };
@@ -156,10 +156,10 @@ int group_id(fcn8s_model* m, const char* name)
 }
 struct ProfScope {
     fcn8s_model* m; int gid = -1; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(fcn8s_model* m_, const char* group, double flops, double bytes) : m(m_)
+    ProfScope(fcn8s_model* m_, const char* group, double flops, double bytes, const char* layer = nullptr) : m(m_)
     {
         if (!m->profile) return;
-        gid = group_id(m, group);
+        gid = (m->profile_detail && layer) ? group_id(m, (std::string(group) + ":" + layer).c_str()) : group_id(m, group);
         hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a, m->stream);
         m->groups[gid].flops += flops; m->groups[gid].bytes += bytes; m->groups[gid].launches += 1;
@@ -179,7 +179,8 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
 
 // SAME conv (or its data gradient when `w` holds flipped+transposed weights)
 void conv_same(fcn8s_model* m, const char* group, const float* x, const float* w, float* y,
-               int N, int H, int W, int Cin, int Cout, int K, const Epi& e, hipStream_t s, int real_cin = 0)
+               int N, int H, int W, int Cin, int Cout, int K, const Epi& e, hipStream_t s, int real_cin = 0,
+               const char* layer = nullptr)
 {
     IgemmArgs a{};
     a.x = x; a.w = w; a.bias = e.bias; a.addend = e.addend; a.mask = e.mask; a.y = y;
@@ -193,7 +194,7 @@ void conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
     const double rc = real_cin ? real_cin : Cin;
     const double flops = 2.0 * a.M * K * K * rc * Cout;
     const double bytes = 4.0 * (a.M * rc + (double)a.M * Cout + (double)K * K * rc * Cout);
-    if (m) { ProfScope ps(m, group, flops, bytes); launch_igemm(a, 1, s); }
+    if (m) { ProfScope ps(m, group, flops, bytes, layer); launch_igemm(a, 1, s); }
     else launch_igemm(a, 1, s);
 }
 
@@ -232,7 +233,8 @@ void tconv_dgrad(fcn8s_model* m, const float* dy, const float* w, float* dx, int
 }
 
 void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* dz, float* dw, float* db,
-                int N, int H, int W, int Cin, int Cout, int K, float alpha, hipStream_t s, int real_cin = 0)
+                int N, int H, int W, int Cin, int Cout, int K, float alpha, hipStream_t s, int real_cin = 0,
+                const char* layer = nullptr)
 {
     WgradArgs a{};
     a.A = x; a.B = dz; a.C = dw;
@@ -244,8 +246,9 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
     const double rc = a.Areal;
     const double flops = 2.0 * a.P * K * K * rc * Cout;
     const double bytes = 4.0 * (a.P * rc + (double)a.P * Cout + (double)K * K * rc * Cout);
-    if (m) { ProfScope ps(m, group, flops, bytes); launch_wgrad(a, s); }
-    else launch_wgrad(a, s);
+    const bool nine = K == 3 && alpha == 1.f && !real_cin;
+    if (m) { ProfScope ps(m, group, flops, bytes, layer); if (!(nine && launch_wgrad3x3(x, dz, dw, db, N, H, W, Cin, Cout, s))) launch_wgrad(a, s); }
+    else if (!(nine && launch_wgrad3x3(x, dz, dw, db, N, H, W, Cin, Cout, s))) launch_wgrad(a, s);
 }
 
 void tconv_wgrad(fcn8s_model* m, const float* x, const float* dy, float* dw, int N, int Hi, int Wi, int C,
@@ -371,7 +374,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
             const bool first = (b == 0 && i == 1);
             Epi e; e.bias = Wp(m, std::string(nm) + "/biases"); e.relu = 1;
             const float* wt = first ? m->d_w1pad : Wp(m, std::string(nm) + "/filter");
-            conv_same(m, first ? "conv1_1_fwd" : "conv3x3_fwd", x, wt, A(m, nm), N, h, w, cin, m->widths[b], 3, e, s, first ? 3 : 0);
+            conv_same(m, first ? "conv1_1_fwd" : "conv3x3_fwd", x, wt, A(m, nm), N, h, w, cin, m->widths[b], 3, e, s, first ? 3 : 0, nm);
             x = A(m, nm); cin = m->widths[b];
         }
         char pn[32]; snprintf(pn, sizeof pn, "pool%d", b + 1);
@@ -516,13 +519,13 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
             else { xin = A(m, "x0"); cin = 4; real_cin = 3; }
             const bool first = (b == 1 && i == 1);
             conv_wgrad(m, first ? "conv1_1_wgrad" : "conv3x3_wgrad", xin, dz, Gp(m, std::string(nm) + "/filter"), Gp(m, std::string(nm) + "/biases"),
-                       N, h, w, cin, cw, 3, 1.f, s, real_cin);
+                       N, h, w, cin, cw, 3, 1.f, s, real_cin, nm);
             if (first) break;
             Epi e;
             if (i > 1) { e.mask = xin; e.mask_scale = 1.f; }               // ReLU of the previous conv
             else if (b == 5) e.addend = m->gskip4;                        // d(pool4) also receives the pool4_1x1 path
             else if (b == 4) e.addend = m->gskip3;                        // d(pool3) also receives the pool3_1x1 path
-            conv_same(m, "conv3x3_dgrad", dz, WTp(m, std::string(nm) + "/filter"), m->gbuf[m->gcur ^ 1], N, h, w, cw, cin, 3, e, s);
+            conv_same(m, "conv3x3_dgrad", dz, WTp(m, std::string(nm) + "/filter"), m->gbuf[m->gcur ^ 1], N, h, w, cw, cin, 3, e, s, 0, nm);
             m->gcur ^= 1;
         }
     }
@@ -928,7 +931,7 @@ int fcn8s_get_dropout_masks(fcn8s_model* m, float* h6, size_t n6, float* h7, siz
     return FCN8S_OK;
 }
 
-int fcn8s_profile_enable(fcn8s_model* m, int on) { if (!m) return FCN8S_ERR_BAD_ARG; m->profile = on != 0; return FCN8S_OK; }
+int fcn8s_profile_enable(fcn8s_model* m, int on) { if (!m) return FCN8S_ERR_BAD_ARG; m->profile = on != 0; m->profile_detail = on == 2; return FCN8S_OK; }
 int fcn8s_profile_reset(fcn8s_model* m)
 {
     if (!m) return FCN8S_ERR_BAD_ARG;

@@ -313,7 +313,7 @@ class Engine:
         return m6, m7
 
     def profile(self, on=True):
-        L.check(L.lib.fcn8s_profile_enable(self.h, int(on)), self.h)
+        L.check(L.lib.fcn8s_profile_enable(self.h, int(on)), self.h)     # 2 = per-layer groups
 
     def profile_reset(self):
         L.check(L.lib.fcn8s_profile_reset(self.h), self.h)

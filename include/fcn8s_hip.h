@@ -134,7 +134,8 @@ int fcn8s_get_dropout_masks(fcn8s_model* m, float* host_mask6, size_t n6, float*
 
 /* ---- in-library HIP-event timing of kernel groups (bench.py roofline) -------- *
  * groups: "conv3x3_fwd","conv3x3_dgrad","conv3x3_wgrad","fc_fwd","fc_dgrad","fc_wgrad",...
- * Fills total milliseconds, number of launches, algorithmic flops and bytes.    */
+ * Fills total milliseconds, number of launches, algorithmic flops and bytes.
+ * fcn8s_profile_enable(m, 2) splits the conv groups per layer ("conv3x3_fwd:conv1_2").  */
 int fcn8s_profile_enable(fcn8s_model* m, int on);
 int fcn8s_profile_reset(fcn8s_model* m);
 int fcn8s_profile_num_groups(const fcn8s_model* m);
