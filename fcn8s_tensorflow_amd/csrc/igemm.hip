@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
     // ---- FAST path state: position of the next tile to load
     int f_ci0 = 0, f_ty = 0, f_tx = 0;
     const float* a_ptr[A_LD];
-    bool a_val[A_LD];
+    bool a_val[A_LD], a_ldok[A_LD];      // a_ldok: validity of the rows of the tile currently held in ra[]
     const float* b_ptr[B_LD];
     auto set_tap = [&]() {
         const int dy = f_ty * p.tap_step + p.tap_off, dx = f_tx * p.tap_step + p.tap_off;
@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
     auto gload_fast = [&]() {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            const float4 v = ldg4(a_ptr[i] + f_ci0);
-            ra[i] = a_val[i] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[i] = ldg4(a_ptr[i] + f_ci0);      // zeroing of out-of-image rows is deferred to sstore so that
+            a_ldok[i] = a_val[i];                 // the wave does not wait for the load before its MFMAs
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             const int row = (tid + i * 256) >> 2;
+            if (FAST && !a_ldok[i]) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(&As[buf * BM * LDA + row * LDA + a_c4]) = ra[i];
         }
 #pragma unroll
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
     // ---- FAST path state (position of the next tile to load)
     int s_n[A_LD], s_a[A_LD], s_b[A_LD], s_left[A_LD];   // A slots: pixel coords + pixels left before pend
     const float* b_ptr[B_LD]; int b_left[B_LD];
+    bool a_ldok[A_LD], b_ldok[B_LD];
     if (FAST) {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
@@ -320,8 +322,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
             const int iy = s_a[i] * p.a_scale + dy, ix = s_b[i] * p.a_scale + dx;
             const bool ok = s_left[i] > 0 && (unsigned)iy < (unsigned)p.Ha && (unsigned)ix < (unsigned)p.Wa;
             const long long pixi = ok ? ((long long)s_n[i] * p.Ha + iy) * p.Wa + ix : 0;
-            const float4 v = ldg4(p.A + pixi * p.lda + i0 + c);
-            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[i] = ldg4(p.A + pixi * p.lda + i0 + c);
+            a_ldok[i] = ok;                        // select deferred to sstore
             s_left[i] -= BK;
             s_b[i] += BK;
             if (s_b[i] >= p.Pb) { s_b[i] -= p.Pb; if (++s_a[i] >= p.Pa) { s_a[i] = 0; ++s_n[i]; } }
@@ -329,8 +331,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             const bool ok = b_left[i] > 0;
-            const float4 v = ldg4(ok ? b_ptr[i] : p.B);
-            rb[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = ldg4(ok ? b_ptr[i] : p.B);
+            b_ldok[i] = ok;
             b_ptr[i] += (long long)BK * p.ldb;
             b_left[i] -= BK;
         }
@@ -369,6 +371,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
             const int f = tid + i * 256;
             if (A_F4 % 256 == 0 || f < A_F4) {
                 const int pix = f / (BM / 4), c = (f - pix * (BM / 4)) * 4;
+                if (FAST && !a_ldok[i]) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(&As[buf * BK * LDA + pix * LDA + c]) = ra[i];
             }
         }
@@ -377,6 +380,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
             const int f = tid + i * 256;
             if (B_F4 % 256 == 0 || f < B_F4) {
                 const int pix = f / (BN / 4), c = (f - pix * (BN / 4)) * 4;
+                if (FAST && !b_ldok[i]) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(&Bs[buf * BK * LDB + pix * LDB + c]) = rb[i];
             }
         }
@@ -496,6 +500,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wgrad9Args p)
     const int d_px = tid / 16, d_c = (tid % 16) * 4;
 
     float4 rx[X_LD], rd;
+    bool okx[X_LD];
     auto gload = [&]() {
         const int w0 = ws * 16;
 #pragma unroll
@@ -503,8 +508,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wgrad9Args p)
             const int iy = h + x_dy[i], ix = w0 + x_col[i];
             const bool ok = (XF4 % 256 == 0 || tid + i * 256 < XF4) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const long long pix = ok ? ((long long)n * p.H + iy) * p.W + ix : 0;
-            const float4 v = ldg4(p.X + pix * p.Cin + i0 + x_c[i]);
-            rx[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            rx[i] = ldg4(p.X + pix * p.Cin + i0 + x_c[i]);
+            okx[i] = ok;                           // zeroing deferred to sstore (no wait before the MFMAs)
         }
         rd = ldg4(p.dZ + (((long long)n * p.H + h) * p.W + w0 + d_px) * p.Cout + j0 + d_c);
         if (++ws == wsegs) { ws = 0; if (++h == p.H) { h = 0; ++n; } }
@@ -515,7 +520,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wgrad9Args p)
 #pragma unroll
         for (int i = 0; i < X_LD; ++i) {
             const int f = tid + i * 256;
-            if (XF4 % 256 == 0 || f < XF4) *reinterpret_cast<float4*>(&Xs[(f / 16) * 64 + x_c[i]]) = rx[i];
+            if (XF4 % 256 == 0 || f < XF4)
+                *reinterpret_cast<float4*>(&Xs[(f / 16) * 64 + x_c[i]]) = okx[i] ? rx[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         *reinterpret_cast<float4*>(&Ds[d_px * 64 + d_c]) = rd;
     };
