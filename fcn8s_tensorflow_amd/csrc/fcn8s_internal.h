@@ -57,6 +57,10 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s);
 bool launch_wgrad3x3(const float* X, const float* dZ, float* dW, float* db, int N, int H, int W, int Cin, int Cout,
                      hipStream_t s);
 
+// conv1_1 (3 -> 64 channels, 4-channel padded input) weight + bias gradient, VALU, HBM-bound;
+// returns false if the shape is not covered (Cout != 64 or W % 64).
+bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, int N, int H, int W, int Cout, hipStream_t s);
+
 // ---------------------------------------------------------------------------
 // Element-wise / reduction kernels (HBM-bound)
 // ---------------------------------------------------------------------------

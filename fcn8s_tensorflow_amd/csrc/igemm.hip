@@ -596,6 +596,108 @@ bool launch_wgrad3x3(const float* X, const float* dZ, float* dW, float* db, int 
     return true;
 }
 
+// ===========================================================================
+// conv1_1 weight gradient (Cin = 3 padded to 4, Cout = 64): HBM-bound (reads the 134 MB/image dZ once),
+// far too skinny for the matrix core (M = 3).  VALU kernel: a block walks 64-pixel row segments; thread
+// (cq, pg) owns couts 4cq..4cq+3 and pixels {pg, pg+16, pg+32, pg+48} of the segment and keeps all
+// 27 x 4 partial sums in registers; the 3 x 66 input halo sits in LDS as float4 (b, g, r, 0) and is
+// read with broadcast ds_read_b128.  One cross-thread reduction + atomics per block at the very end.
+// ===========================================================================
+struct Conv1WgradArgs { const float4* X4; const float* dZ; float* dW; float* db; int N, H, W; long long nseg; int segs_per_block; };
+
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float4 xs[3 * 66];
+    __shared__ float red[4 * 16 * 112];
+    const int tid = threadIdx.x, cq = tid & 15, pg = tid >> 4;
+    const int wsegs = p.W / 64;
+    const long long s0 = (long long)blockIdx.x * p.segs_per_block;
+    long long s1 = s0 + p.segs_per_block; if (s1 > p.nseg) s1 = p.nseg;
+    float acc[27][4];
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = 0.f;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long s = s0; s < s1; ++s) {
+        const long long per_img = (long long)p.H * wsegs;
+        const int n = (int)(s / per_img);
+        const int r = (int)(s - (long long)n * per_img);
+        const int h = r / wsegs, w0 = (r - h * wsegs) * 64;
+        // dZ for this thread's four pixels (issued first: longest latency)
+        float4 dz[4];
+        const float* dzrow = p.dZ + (((long long)n * p.H + h) * p.W + w0) * 64 + cq * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dz[j] = *reinterpret_cast<const float4*>(dzrow + (long long)(j * 16 + pg) * 64);
+        __syncthreads();                      // previous segment's readers are done with xs
+        if (tid < 198) {
+            const int ky = tid / 66, col = tid - ky * 66;
+            const int iy = h + ky - 1, ix = w0 + col - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = p.X4[((long long)n * p.H + iy) * p.W + ix];
+            xs[tid] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int px = j * 16 + pg;
+            const float4 d = dz[j];
+            bs[0] += d.x; bs[1] += d.y; bs[2] += d.z; bs[3] += d.w;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4 x = xs[ky * 66 + px + kx];
+                    const int t = (ky * 3 + kx) * 3;
+                    acc[t][0] += x.x * d.x; acc[t][1] += x.x * d.y; acc[t][2] += x.x * d.z; acc[t][3] += x.x * d.w;
+                    acc[t + 1][0] += x.y * d.x; acc[t + 1][1] += x.y * d.y; acc[t + 1][2] += x.y * d.z; acc[t + 1][3] += x.y * d.w;
+                    acc[t + 2][0] += x.z * d.x; acc[t + 2][1] += x.z * d.y; acc[t + 2][2] += x.z * d.z; acc[t + 2][3] += x.z * d.w;
+                }
+        }
+    }
+    // reduce over the 16 pixel groups: lanes with equal cq inside a wave (xor 16, 32), then across waves via LDS
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = acc[t][q];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[t][q] = v;
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { float v = bs[q]; v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); bs[q] = v; }
+    if (lane < 16) {
+        float* dst = red + (wave * 16 + lane) * 112;
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[t * 4 + q] = acc[t][q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[108 + q] = bs[q];
+    }
+    __syncthreads();
+    // 16 cq x 112 values, summed over the 4 waves
+    for (int i = tid; i < 16 * 112; i += 256) {
+        const int c = i / 112, v = i - c * 112;
+        const float sum = red[(0 * 16 + c) * 112 + v] + red[(1 * 16 + c) * 112 + v] + red[(2 * 16 + c) * 112 + v] + red[(3 * 16 + c) * 112 + v];
+        if (v < 108) unsafeAtomicAdd(p.dW + (v >> 2) * 64 + c * 4 + (v & 3), sum);     // dW[tap*3+ci][co]
+        else if (p.db) unsafeAtomicAdd(p.db + c * 4 + (v - 108), sum);
+    }
+}
+
+bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, int N, int H, int W, int Cout, hipStream_t s)
+{
+    if (Cout != 64 || W % 64) return false;
+    Conv1WgradArgs a{(const float4*)X4, dZ, dW, db, N, H, W, (long long)N * H * (W / 64), 0};
+    long long blocks = a.nseg < 2048 ? a.nseg : 2048;
+    a.segs_per_block = (int)((a.nseg + blocks - 1) / blocks);
+    blocks = (a.nseg + a.segs_per_block - 1) / a.segs_per_block;
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return true;
+}
+
 template <int BM, int BN, int WM, int WN, int WK>
 static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
 {

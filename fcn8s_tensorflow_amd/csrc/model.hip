@@ -247,8 +247,14 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
     const double flops = 2.0 * a.P * K * K * rc * Cout;
     const double bytes = 4.0 * (a.P * rc + (double)a.P * Cout + (double)K * K * rc * Cout);
     const bool nine = K == 3 && alpha == 1.f && !real_cin;
-    if (m) { ProfScope ps(m, group, flops, bytes, layer); if (!(nine && launch_wgrad3x3(x, dz, dw, db, N, H, W, Cin, Cout, s))) launch_wgrad(a, s); }
-    else if (!(nine && launch_wgrad3x3(x, dz, dw, db, N, H, W, Cin, Cout, s))) launch_wgrad(a, s);
+    const bool first = K == 3 && alpha == 1.f && real_cin == 3 && Cin == 4;
+    auto run = [&]() {
+        if (nine && launch_wgrad3x3(x, dz, dw, db, N, H, W, Cin, Cout, s)) return;
+        if (first && launch_conv1_wgrad(x, dz, dw, db, N, H, W, Cout, s)) return;
+        launch_wgrad(a, s);
+    };
+    if (m) { ProfScope ps(m, group, flops, bytes, layer); run(); }
+    else run();
 }
 
 void tconv_wgrad(fcn8s_model* m, const float* x, const float* dy, float* dw, int N, int Hi, int Wi, int C,

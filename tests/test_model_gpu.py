@@ -83,7 +83,8 @@ def test_forward_logits_and_argmax(widths, n, h, w):
     e.close()
 
 
-@pytest.mark.parametrize("widths,n,h,w,l2", [(SMALL, 2, 64, 64, 0.0), (SMALL, 1, 32, 96, 1e-2), (None, 1, 32, 32, 0.0)])
+@pytest.mark.parametrize("widths,n,h,w,l2", [(SMALL, 2, 64, 64, 0.0), (SMALL, 1, 32, 96, 1e-2), (None, 1, 32, 32, 0.0),
+                                                (None, 2, 32, 64, 0.0)])   # full width, W % 64 == 0: the specialised conv1_1 / 3x3 wgrad kernels
 def test_gradients(widths, n, h, w, l2):
     P, img, lab = tie_free_case(widths, n, h, w, seed=2)
     e = make_engine(widths)
