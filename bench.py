@@ -26,6 +26,20 @@ PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/pmc_traffic.json, written by tools/pmc_summary.py); None if not collected."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        for name, v in d.get("kernels", {}).items():
+            if name.replace(" ", "").startswith("voidfcn8s::" + kernel.replace(" ", "")) or name.replace(" ", "").startswith("fcn8s::" + kernel.replace(" ", "")):
+                return {"hbm_mb_per_launch": v["hbm_mb_per_launch"], "fetch_mb": v["fetch_mb_per_launch"],
+                        "write_mb": v["write_mb_per_launch"], "source": d.get("source")}
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(h, w, seconds_budget=30.0):
     """CPU restatement of the reference graph (oracle, kind 'port'), timed on this
     host's cores on a bounded sample: bs1 training steps (fwd + bwd + TF-Adam) at
@@ -127,16 +141,20 @@ def main():
         scale = (H * W) / (512.0 * 1024.0)
         gflop_img = (TRAIN_GFLOP_PER_IMG_512x1024 if args.mode == "train" else FWD_GFLOP_PER_IMG_512x1024) * scale
         # dominant kernel family (by time) among the MFMA convolution groups
-        mf = {k: v for k, v in prof.items() if v["flops"] > 0 and v["launches"] > 0}
-        dom = max(mf, key=lambda k: mf[k]["ms"]) if mf else None
+        # (the library keeps a second view of its HIP-event timings keyed by kernel symbol: "kernel:<name>")
+        kern = {k[7:]: v for k, v in prof.items() if k.startswith("kernel:") and v["flops"] > 0 and v["launches"] > 0}
+        prof = {k: v for k, v in prof.items() if not k.startswith("kernel:")}
+        dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
         roof = None
         if dom:
-            g = mf[dom]
+            g = kern[dom]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom),
                     "launches": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 4),
-                    "algorithmic_gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 3)}
+                    "algorithmic_gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 3),
+                    "algorithmic_mb_per_launch": round(g["bytes"] / g["launches"] / 1e6, 2),
+                    "share_of_step_time": round(g["ms"] / (dt * 1e3), 3)}
         out = {
             "metric": "training images/sec at 1024x512 bs16" if args.mode == "train" else "inference images/sec at 1024x512",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -6,6 +6,9 @@
 
 namespace fcn8s {
 
+// symbol of the MFMA kernel the last launch_* call used (for the per-kernel profile view)
+extern thread_local const char* g_last_kernel;
+
 // ---------------------------------------------------------------------------
 // Implicit-GEMM convolution on the f32 MFMA (v_mfma_f32_32x32x2_f32).
 //

@@ -12,13 +12,30 @@
 // Block = 256 threads = 4 wave64; K is consumed 16 at a time (8 MFMA k-steps),
 // global->register->LDS double-buffered with one barrier per K-tile.
 #include "fcn8s_internal.h"
+#include <cstdlib>
+#include <string>
 
 namespace fcn8s {
+
+thread_local const char* g_last_kernel = nullptr;
+#define FCN8S_STR2(x) #x
+#define FCN8S_STR(x) FCN8S_STR2(x)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK_ = 16;
 
 static __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// XCD-aware block order.  The dispatcher places workgroup p on XCD p % 8 (observed, speed only -- results
+// never depend on it); each XCD has a private 4 MiB L2.  Give every XCD one CONTIGUOUS run of logical tile
+// ids, so that tiles which share operand panels (the N-tiles of one M-tile; spatially adjacent M-tiles whose
+// halos overlap) run concurrently behind the same L2 instead of being dealt round-robin across all eight.
+// Bijective for any total (guide section 5.5 T1).
+static __device__ __forceinline__ unsigned xcd_swizzle(unsigned p, unsigned total)
+{
+    const unsigned q = total >> 3, r = total & 7u, xcd = p & 7u, i = p >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
 
 // ===========================================================================
 // forward / dgrad / transposed-conv implicit GEMM
@@ -33,13 +50,14 @@ static __device__ __attribute__((noinline)) float dropout_apply(float v, unsigne
     return philox_uniform(idx, seed, stream) < keep ? v / keep : 0.f;
 }
 
-template <int BM, int BN, int WM, int WN, bool FAST>
-__global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
+template <int BM, int BN, int WM, int WN, int MODE, int BK>
+__global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) void igemm_fwd_kernel(const IgemmArgs p)
 {
-    constexpr int BK = 16, LDA = 20, LDB = BN;
+    constexpr bool FAST = MODE != 0;
+    constexpr int LDA = BK + 4, LDB = BN, F4R = BK / 4;     // F4R float4 per A row; LDA*4 B row stride keeps ds_read_b128 conflict-free
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_LD = BM * 4 / 256;
-    constexpr int B_F4 = 4 * BN;                 // float4 per B tile
+    constexpr int A_LD = BM * F4R / 256;
+    constexpr int B_F4 = BK * BN / 4;            // float4 per B tile
     constexpr int B_LD = (B_F4 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves");
     static_assert(TM >= 1 && TN >= 1, "tile");
@@ -53,8 +71,12 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
     const int pzy = pz / p.phases_x, pzx = pz - pzy * p.phases_x;
     const float* __restrict__ Wp = p.w + (long long)pz * p.w_phase_stride;
     const int offy = p.out_offy + pzy, offx = p.out_offx + pzx;
-    const long long m0 = (long long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    const unsigned ntn = (unsigned)((p.Cout + BN - 1) / BN);
+    // 1-D grid of M-tiles x N-tiles, N fastest: the N-tiles of one M-tile (same A panel) and the next
+    // M-tiles (overlapping halos) are neighbours in the XCD's contiguous run of logical ids.
+    const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const long long m0 = (long long)(lid / ntn) * BM;
+    const int n0 = (int)(lid % ntn) * BN;
     const int MaMb = p.Ma * p.Mb;
 
     long long a_base[A_LD];
@@ -62,7 +84,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
     bool a_ok[A_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-        const int row = (tid + i * 256) >> 2;
+        const int row = (tid + i * 256) / F4R;
         const long long m = m0 + row;
         a_ok[i] = m < p.M;
         const long long mm = a_ok[i] ? m : 0;
@@ -72,15 +94,23 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
         a_iy[i] = a * p.in_scale; a_ix[i] = b * p.in_scale;
         a_base[i] = (long long)n * p.Hi * p.Wi;
     }
-    const int a_c4 = (tid & 3) * 4;
+    const int a_c4 = (tid % F4R) * 4;
 
     float4 ra[A_LD], rb[B_LD];
-    // ---- FAST path state: position of the next tile to load
-    int f_ci0 = 0, f_ty = 0, f_tx = 0;
-    const float* a_ptr[A_LD];
-    bool a_val[A_LD], a_ldok[A_LD];      // a_ldok: validity of the rows of the tile currently held in ra[]
+    // ---- FAST path state: position of the next tile to load.
+    // MODE 2 (tap inner): K order = channel chunk OUTER, tap INNER -- the k*k taps of one 16-channel slice
+    //   re-read (shifted) the same few KB per block, which stay in L1/L2, instead of sweeping the whole halo
+    //   once per tap (that order missed L2 on every tap: rocprof FETCH_SIZE 4-6 GB per launch against
+    //   ~0.5 GB algorithmic).  Used when the filter bank is small enough to stay cached (3x3 layers).
+    // MODE 1 (tap outer): huge filter banks (fc6: 411 MB) are streamed contiguously instead.
+    constexpr bool TAP_INNER = MODE == 2;
+    int f_ci0 = 0, f_ty = 0, f_tx = 0, f_tap = 0;
+    const int ntaps = FAST ? p.Ktot / p.Cin : 1;
+    const float* a_ptr[A_LD];                // MODE 1: row pointer for the current tap; MODE 2: tap-offset-0 pointer
+    unsigned a_mask[A_LD];                   // MODE 2: bit t set = tap t of this row lies inside the image (<= 32 taps)
+    bool a_val[A_LD], a_ldok[A_LD];          // a_ldok: validity of the rows of the tile currently held in ra[]
     const float* b_ptr[B_LD];
-    auto set_tap = [&]() {
+    auto set_tap = [&]() {                   // MODE 1 only
         const int dy = f_ty * p.tap_step + p.tap_off, dx = f_tx * p.tap_step + p.tap_off;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
@@ -91,7 +121,19 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
         }
     };
     if (FAST) {
-        set_tap();
+        if (TAP_INNER) {
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                unsigned mk = 0;
+                for (int t = 0; t < ntaps; ++t) {
+                    const int ty = t / p.KW, tx = t - ty * p.KW;
+                    const int iy = a_iy[i] + ty * p.tap_step + p.tap_off, ix = a_ix[i] + tx * p.tap_step + p.tap_off;
+                    if (a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) mk |= 1u << t;
+                }
+                a_mask[i] = mk;
+                a_ptr[i] = p.x + (a_base[i] + (long long)a_iy[i] * p.Wi + a_ix[i]) * p.ldx + a_c4;
+            }
+        } else set_tap();
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             const int f = tid + i * 256;
@@ -100,21 +142,39 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
         }
     }
     auto gload_fast = [&]() {
+        if (TAP_INNER) {
+            // block-uniform tap offsets (scalar registers)
+            const long long delta = ((long long)(f_ty * p.tap_step + p.tap_off) * p.Wi + (f_tx * p.tap_step + p.tap_off)) * p.ldx + f_ci0;
+            const long long boff = ((long long)f_tap * p.Cin + f_ci0) * p.Cout;
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            ra[i] = ldg4(a_ptr[i] + f_ci0);      // zeroing of out-of-image rows is deferred to sstore so that
-            a_ldok[i] = a_val[i];                 // the wave does not wait for the load before its MFMAs
-        }
+            for (int i = 0; i < A_LD; ++i) {
+                const bool ok = (a_mask[i] >> f_tap) & 1u;
+                ra[i] = ldg4(ok ? a_ptr[i] + delta : p.x);  // zeroing of out-of-image rows is deferred to sstore so
+                a_ldok[i] = ok;                              // that the wave does not wait for the load before its MFMAs
+            }
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            if (B_F4 % 256 == 0 || tid + i * 256 < B_F4) rb[i] = ldg4(b_ptr[i]);
-            b_ptr[i] += (long long)BK * p.Cout;
-        }
-        f_ci0 += BK;
-        if (f_ci0 == p.Cin) {
-            f_ci0 = 0;
+            for (int i = 0; i < B_LD; ++i)
+                if (B_F4 % 256 == 0 || tid + i * 256 < B_F4) rb[i] = ldg4(b_ptr[i] + boff);
+            ++f_tap;
             if (++f_tx == p.KW) { f_tx = 0; ++f_ty; }
-            set_tap();           // one tap past the end computes pointers that are never dereferenced
+            if (f_tap == ntaps) { f_tap = 0; f_tx = 0; f_ty = 0; f_ci0 += BK; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                ra[i] = ldg4(a_ptr[i] + f_ci0);
+                a_ldok[i] = a_val[i];
+            }
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) {
+                if (B_F4 % 256 == 0 || tid + i * 256 < B_F4) rb[i] = ldg4(b_ptr[i]);
+                b_ptr[i] += (long long)BK * p.Cout;
+            }
+            f_ci0 += BK;
+            if (f_ci0 == p.Cin) {
+                f_ci0 = 0;
+                if (++f_tx == p.KW) { f_tx = 0; ++f_ty; }
+                set_tap();           // one tap past the end computes pointers that are never dereferenced
+            }
         }
     };
     auto gload = [&](int kt) {
@@ -143,7 +203,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            const int row = (tid + i * 256) >> 2;
+            const int row = (tid + i * 256) / F4R;
             if (FAST && !a_ldok[i]) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(&As[buf * BM * LDA + row * LDA + a_c4]) = ra[i];
         }
@@ -169,7 +229,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
         const float* A = As + buf * BM * LDA + (wm * TM * 32 + (lane & 31)) * LDA + (lane >> 5) * 4;
         const float* B = Bs + buf * BK * LDB + ((lane >> 5) * 4) * LDB + wn * TN * 32 + (lane & 31);
 #pragma unroll
-        for (int kk2 = 0; kk2 < 2; ++kk2) {
+        for (int kk2 = 0; kk2 < BK / 8; ++kk2) {
             float4 af[TM];
             float bf[TN][4];
 #pragma unroll
@@ -242,20 +302,28 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs p)
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BKF = 16>
 static void launch_igemm_cfg(const IgemmArgs& a, int phases, hipStream_t s)
 {
-    dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN), (unsigned)phases);
-    const bool fast = phases == 1 && a.Cin % 16 == 0 && a.Cout % BN == 0 && a.Ktot % a.Cin == 0;
-    if (fast) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);
-    else      hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);
+    dim3 grid((unsigned)(((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN)), 1, (unsigned)phases);
+    const bool fast = phases == 1 && a.Cin % BKF == 0 && a.Cout % BN == 0 && a.Ktot % a.Cin == 0;
+    // filter bank small enough to live in L2 / MALL -> tap-inner K order (and at most 32 taps for the bit mask)
+    const bool tap_inner = fast && (double)a.Ktot * a.Cout * 4.0 <= 64e6 && a.Ktot / a.Cin <= 32;
+    const int mode = !fast ? 0 : (tap_inner ? 2 : 1);
+    static const std::string base = "igemm_fwd_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", ";
+    static const std::string tags[3] = {base + "0, 16>", base + "1, " + std::to_string(BKF) + ">", base + "2, " + std::to_string(BKF) + ">"};
+    g_last_kernel = tags[mode].c_str();
+    if (mode == 2)      hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 2, BKF>), grid, dim3(256), 0, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 1, BKF>), grid, dim3(256), 0, s, a);
+    else                hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 0, 16>), grid, dim3(256), 0, s, a);
 }
 
+static const bool g_bk32 = getenv("FCN8S_BK32") != nullptr;   // tuning switch (K-tile depth of the FAST path)
 void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s)
 {
     if (a.Cout <= 32)      launch_igemm_cfg<128, 32, 4, 1>(a, phases, s);
-    else if (a.Cout <= 64) launch_igemm_cfg<128, 64, 2, 2>(a, phases, s);
-    else                   launch_igemm_cfg<128, 128, 2, 2>(a, phases, s);
+    else if (a.Cout <= 64) { if (g_bk32) launch_igemm_cfg<128, 64, 2, 2, 32>(a, phases, s); else launch_igemm_cfg<128, 64, 2, 2>(a, phases, s); }
+    else                   { if (g_bk32) launch_igemm_cfg<128, 128, 2, 2, 32>(a, phases, s); else launch_igemm_cfg<128, 128, 2, 2>(a, phases, s); }
 }
 
 // ===========================================================================
@@ -263,7 +331,7 @@ void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s)
 // ===========================================================================
 // FAST = (Adim % BM == 0, Bdim % BN == 0, Pb >= 16): pixel coordinates of each thread's load slots
 // are advanced incrementally (16 pixels per K-tile), loads are unconditional + select.
-template <int BM, int BN, int WM, int WN, int WK, bool FAST>
+template <int BM, int BN, int WM, int WN, int WK, bool FAST, bool COLSUM>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int chunk)
 {
     constexpr int BK = 16, LDA = BM, LDB = BN;
@@ -287,7 +355,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
     const long long pbeg = (long long)blockIdx.y * chunk;
     const long long pend = (pbeg + chunk < p.P) ? pbeg + chunk : p.P;
     const int PaPb = p.Pa * p.Pb;
-    const bool do_colsum = p.colsum != nullptr && tap == 0 && ti == 0 && wm == 0;
+    const bool do_colsum = COLSUM && p.colsum != nullptr && tap == 0 && ti == 0 && wm == 0;
 
     float4 ra[A_LD], rb[B_LD];
     // ---- FAST path state (position of the next tile to load)
@@ -387,11 +455,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
     };
 
     f32x16 acc[TM][TN];
-    f32x16 accs[TN];
+    f32x16 accs[COLSUM ? TN : 1];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accs[j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) if (COLSUM) accs[j][r] = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -415,10 +483,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
-            if (do_colsum) {
+            if (COLSUM && do_colsum) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    accs[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(1.0f, bf[tn], accs[tn], 0, 0, 0);
+                    accs[COLSUM ? tn : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(1.0f, bf[tn], accs[COLSUM ? tn : 0], 0, 0, 0);
             }
         }
     };
@@ -448,7 +516,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
                 const int row = i0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < p.Areal) unsafeAtomicAdd(Ct + (long long)row * p.ldc + col, acc[tm][tn][r] * p.alpha);
             }
-        if (do_colsum && lane < 32) unsafeAtomicAdd(p.colsum + col, accs[tn][0]);
+        if (COLSUM && do_colsum && lane < 32) unsafeAtomicAdd(p.colsum + col, accs[COLSUM ? tn : 0][0]);
     }
 }
 
@@ -475,10 +543,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wgrad9Args p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
     const int nco = p.Cout / 64;
-    const int ti = blockIdx.x / nco, tj = blockIdx.x - ti * nco;
+    const unsigned ntiles = (unsigned)(p.Cin / 64) * nco;
+    const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);       // 1-D grid: (pixel split) x (ci, co) tile, tile fastest
+    const unsigned tile = lid % ntiles, split = lid / ntiles;
+    const int ti = tile / nco, tj = tile - ti * nco;
     const int i0 = ti * 64, j0 = tj * 64;
     const int wsegs = p.W / 16;
-    const long long s0 = (long long)blockIdx.y * p.segs_per_block;
+    const long long s0 = (long long)split * p.segs_per_block;
     long long s1 = s0 + p.segs_per_block; if (s1 > p.nseg) s1 = p.nseg;
     const int nkt = (int)(s1 - s0);
     if (nkt <= 0) return;
@@ -592,7 +663,8 @@ bool launch_wgrad3x3(const float* X, const float* dZ, float* dW, float* db, int 
     if (splits < 1) splits = 1;
     a.segs_per_block = (int)((a.nseg + splits - 1) / splits);
     splits = (a.nseg + a.segs_per_block - 1) / a.segs_per_block;
-    hipLaunchKernelGGL(wgrad3x3_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, a);
+    g_last_kernel = "wgrad3x3_kernel";
+    hipLaunchKernelGGL(wgrad3x3_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, a);
     return true;
 }
 
@@ -694,6 +766,7 @@ bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, 
     long long blocks = a.nseg < 2048 ? a.nseg : 2048;
     a.segs_per_block = (int)((a.nseg + blocks - 1) / blocks);
     blocks = (a.nseg + a.segs_per_block - 1) / a.segs_per_block;
+    g_last_kernel = "conv1_wgrad_kernel";
     hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
     return true;
 }
@@ -714,8 +787,14 @@ static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
     dim3 grid((unsigned)(nti * ntj), (unsigned)splits, (unsigned)a.ntaps);
     constexpr bool full_tiles = (BK_ * BM / 4) % 256 == 0 && (BK_ * BN / 4) % 256 == 0;
     const bool fast = full_tiles && a.Adim % BM == 0 && a.Bdim % BN == 0 && a.Pb >= 16;
-    if (fast) hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK, true>), grid, dim3(256), 0, s, a, (int)chunk);
-    else      hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK, false>), grid, dim3(256), 0, s, a, (int)chunk);
+    // big tiles: keep the bias-gradient accumulators out of the register budget (separate column-sum pass)
+    constexpr bool fused_colsum = BM * BN < 128 * 128;
+    WgradArgs b = a;
+    if (!fused_colsum && a.colsum) { launch_colsum(a.B, a.colsum, a.P, a.Bdim, s); b.colsum = nullptr; }
+    static const std::string tag = "wgrad_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ">";
+    g_last_kernel = tag.c_str();
+    if (fast) hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK, true, fused_colsum>), grid, dim3(256), 0, s, b, (int)chunk);
+    else      hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK, false, fused_colsum>), grid, dim3(256), 0, s, b, (int)chunk);
 }
 
 void launch_wgrad(const WgradArgs& a, hipStream_t s)

@@ -29,7 +29,8 @@ struct ParamInfo {
 
 struct ProfGroup {
     std::string name;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;          // owned
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_shared;   // borrowed from another group (per-kernel-symbol view)
     double flops = 0, bytes = 0;
     int64_t launches = 0;
 };
@@ -155,10 +156,11 @@ int group_id(fcn8s_model* m, const char* name)
     return (int)m->groups.size() - 1;
 }
 struct ProfScope {
-    fcn8s_model* m; int gid = -1; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(fcn8s_model* m_, const char* group, double flops, double bytes, const char* layer = nullptr) : m(m_)
+    fcn8s_model* m; int gid = -1; hipEvent_t a = nullptr, b = nullptr; double fl = 0, by = 0;
+    ProfScope(fcn8s_model* m_, const char* group, double flops, double bytes, const char* layer = nullptr) : m(m_), fl(flops), by(bytes)
     {
         if (!m->profile) return;
+        fcn8s::g_last_kernel = nullptr;
         gid = (m->profile_detail && layer) ? group_id(m, (std::string(group) + ":" + layer).c_str()) : group_id(m, group);
         hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a, m->stream);
@@ -169,6 +171,11 @@ struct ProfScope {
         if (gid < 0) return;
         hipEventRecord(b, m->stream);
         m->groups[gid].ev.emplace_back(a, b);
+        if (fcn8s::g_last_kernel) {          // second view of the same launch, keyed by the kernel symbol that ran
+            const int k = group_id(m, (std::string("kernel:") + fcn8s::g_last_kernel).c_str());
+            m->groups[k].flops += fl; m->groups[k].bytes += by; m->groups[k].launches += 1;
+            m->groups[k].ev_shared.emplace_back(a, b);
+        }
     }
 };
 
@@ -942,7 +949,7 @@ int fcn8s_profile_reset(fcn8s_model* m)
 {
     if (!m) return FCN8S_ERR_BAD_ARG;
     hipStreamSynchronize(m->stream);
-    for (auto& g : m->groups) { for (auto& ev : g.ev) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); } g.ev.clear(); g.flops = g.bytes = 0; g.launches = 0; }
+    for (auto& g : m->groups) { for (auto& ev : g.ev) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); } g.ev.clear(); g.ev_shared.clear(); g.flops = g.bytes = 0; g.launches = 0; }
     return FCN8S_OK;
 }
 int fcn8s_profile_num_groups(const fcn8s_model* m) { return m ? (int)m->groups.size() : 0; }
@@ -953,6 +960,7 @@ int fcn8s_profile_get(fcn8s_model* m, int gi, const char** name, double* total_m
     HIPCHK(m, hipStreamSynchronize(m->stream));
     double ms = 0;
     for (auto& ev : g.ev) { float t = 0; if (hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) ms += t; }
+    for (auto& ev : g.ev_shared) { float t = 0; if (hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) ms += t; }
     if (name) *name = g.name.c_str();
     if (total_ms) *total_ms = ms;
     if (launches) *launches = g.launches;

@@ -22,6 +22,8 @@ def main():
     torch.cuda.synchronize()
     tot = 0
     for k, v in e.profile_results().items():
+        if k.startswith("kernel:"):
+            continue
         ms = v["ms"] / args.steps; tot += ms
         extra = "%7.1f TF/s" % (v["flops"] / v["ms"] / 1e9) if v["flops"] else "%7.1f GB/s" % (v["bytes"] / v["ms"] / 1e6)
         print("%-34s %8.3f ms  %s" % (k, ms, extra))
