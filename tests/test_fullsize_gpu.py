@@ -1,0 +1,100 @@
+"""BASELINE.json's full-size configurations on the GPU.
+
+config 2: 1024x512 bs1 fp32 inference -- logits within 1e-3 of the CPU oracle, per-pixel argmax identical
+          wherever the oracle's top-2 logit gap exceeds twice that tolerance.
+config 3: 1024x512 bs16 training step -- too large for the CPU oracle in a test, so it is checked through
+          size-independent properties: closed-form loss / bias gradient at zero decoder weights, batch
+          linearity of the gradients (what data-parallel training relies on), and determinism of the forward."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fcn8s_oracle as orc  # noqa: E402  (checker only)
+
+
+def test_config2_inference_1024x512_bs1_vs_oracle():
+    from fcn8s_tensorflow_amd.engine import Engine
+    P = orc.init_params(20, seed=0, decoder_std_scale=30.0, bias_std=0.05)      # lively decoder so the margins are real
+    img, _ = orc.synthetic_batch(1, 512, 1024)
+    e = Engine(20)
+    e.set_params(P)
+    pred = e.predict(img, argmax=True)
+    logits = e.activation("logits", (1, 512, 1024, 20))
+    ref = orc.forward(P, img)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert float(np.abs(logits - ref).max()) < 1e-3 * scale
+    # argmax must agree wherever the oracle's top-2 logit gap exceeds twice the logit tolerance
+    # (closer pairs are legitimately ambiguous under fp32 summation-order differences)
+    srt = np.sort(ref, -1)
+    safe = (srt[..., -1] - srt[..., -2]) > 2e-3 * scale
+    assert safe.mean() > 0.95, safe.mean()
+    ref_arg = np.argmax(orc.softmax(ref), -1)
+    assert (pred[safe] == ref_arg[safe]).all(), int((pred[safe] != ref_arg[safe]).sum())
+    assert (pred != ref_arg).mean() < 1e-3                  # and the ambiguous pixels are a negligible fraction
+    # with the reference's own decoder init (sigma 1e-3 / 1e-2, fcn8s_tensorflow.py:159-160) the logits are tiny;
+    # check them in relative terms as well
+    P2 = orc.init_params(20, seed=0)
+    e.set_params(P2)
+    e.predict(img)
+    l2 = e.activation("logits", (1, 512, 1024, 20))
+    r2 = orc.forward(P2, img)
+    assert float(np.abs(l2 - r2).max()) < 1e-3 * max(float(np.abs(r2).max()), 1e-30) + 1e-12
+    e.close()
+
+
+def test_config3_training_step_1024x512_bs16_properties():
+    import torch
+    from fcn8s_tensorflow_amd.engine import Engine
+    N, H, W, C = 16, 512, 1024, 20
+    e = Engine(C, seed=3)
+    e.init_params(seed=0)
+    img, lab = orc.synthetic_batch(N, H, W)
+    imgd, labd = torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda()
+
+    # (1) all decoder kernels and biases zero -> logits == 0 -> loss = ln C and
+    #     d loss / d (last bias)[c] = 1/C - count_c / npix   (closed form, any size)
+    zero = {k: np.zeros(s[0], np.float32) for k, s in e.specs.items() if "1x1" in k or "trans" in k}
+    e.set_params(zero)
+    loss = e.forward_backward(imgd, labd, keep_prob=1.0)
+    assert abs(loss - np.log(C)) < 1e-5
+    gb = e.grad_view("fc7_pool4_pool3_conv2d_trans/bias").cpu().numpy()
+    want = 1.0 / C - np.bincount(lab.ravel(), minlength=C) / lab.size
+    assert np.abs(gb - want).max() < 1e-6
+    # every encoder gradient is exactly zero (the decoder passes nothing back)
+    assert float(e.grad_view("conv1_1/filter").abs().max()) == 0.0 and float(e.grad_view("fc6/weights").abs().max()) == 0.0
+
+    # (2) batch linearity: grad(batch of 16) == mean of grad(first 8), grad(last 8)  (keep_prob 1)
+    e.init_params(seed=1)
+    e.forward_backward(imgd, labd, keep_prob=1.0)
+    g_full = e.flat_grads.clone()
+    e.forward_backward(imgd[:8], labd[:8], keep_prob=1.0)
+    g_a = e.flat_grads.clone()
+    e.forward_backward(imgd[8:], labd[8:], keep_prob=1.0)
+    g_mean = 0.5 * (g_a + e.flat_grads)
+    for name in ("conv1_1/filter", "conv3_2/filter", "conv5_3/biases", "fc6/weights", "fc7/weights", "pool4_1x1/kernel",
+                 "fc7_pool4_pool3_conv2d_trans/kernel"):
+        shape, off = e.specs[name]
+        n = int(np.prod(shape))
+        a, b = g_full[off:off + n], g_mean[off:off + n]
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-12, name
+
+    # (3) forward determinism (no atomics on the forward path): identical logits bit for bit
+    p1 = e.predict(imgd[:2], argmax=False).clone()
+    p2 = e.predict(imgd[:2], argmax=False)
+    assert torch.equal(p1, p2)
+
+    # (4) full-size directional-derivative check of the whole backward pass: along theta - eps*g the loss
+    #     must change by -eps*|g|^2 to first order (eps shrunk until the step is inside the linear regime)
+    l0 = e.forward_backward(imgd[:4], labd[:4], keep_prob=1.0)
+    g = e.flat_grads.clone()
+    theta = e.flat_params.clone()                       # torch view of the library's parameter buffer
+    norm2 = float((g.double() ** 2).sum())
+    ratios = []
+    for target in (3e-5, 1e-5, 4e-6):                    # fp32 loss resolution ~2.4e-7 bounds how small this can go
+        e.flat_params.copy_(theta - (target / norm2) * g)
+        l1 = e.forward_backward(imgd[:4], labd[:4], keep_prob=1.0)
+        ratios.append((l0 - l1) / target)
+    e.flat_params.copy_(theta)
+    assert any(0.75 < r < 1.25 for r in ratios[1:]), ratios
+    e.close()
