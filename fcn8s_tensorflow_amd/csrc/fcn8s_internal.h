@@ -55,10 +55,10 @@ struct WgradArgs {
     float* colsum;                     // optional: colsum[j] += sum_p B[p,j]  (bias gradient), or nullptr
 };
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
-// 3x3 SAME conv weight (+bias) gradient, all nine taps per block; returns false if the shape is not
-// covered (Cin % 64, Cout % 64, W % 16), in which case the caller falls back to launch_wgrad.
-bool launch_wgrad3x3(const float* X, const float* dZ, float* dW, float* db, int N, int H, int W, int Cin, int Cout,
-                     hipStream_t s);
+// 3x3 / 7x7 SAME conv weight (+bias) gradient, several taps per block (3x3: all nine, 7x7: one filter row);
+// returns false if the shape is not covered (K, Cin % 64, Cout % 64, W % 16): the caller then uses launch_wgrad.
+bool launch_wgrad_taps(const float* X, const float* dZ, float* dW, float* db, int N, int H, int W, int Cin, int Cout,
+                       int K, hipStream_t s);
 
 // conv1_1 (3 -> 64 channels, 4-channel padded input) weight + bias gradient, VALU, HBM-bound;
 // returns false if the shape is not covered (Cout != 64 or W % 64).

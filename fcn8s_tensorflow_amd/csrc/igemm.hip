@@ -318,12 +318,11 @@ static void launch_igemm_cfg(const IgemmArgs& a, int phases, hipStream_t s)
     else                hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 0, 16>), grid, dim3(256), 0, s, a);
 }
 
-static const bool g_bk32 = getenv("FCN8S_BK32") != nullptr;   // tuning switch (K-tile depth of the FAST path)
 void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s)
 {
     if (a.Cout <= 32)      launch_igemm_cfg<128, 32, 4, 1>(a, phases, s);
-    else if (a.Cout <= 64) { if (g_bk32) launch_igemm_cfg<128, 64, 2, 2, 32>(a, phases, s); else launch_igemm_cfg<128, 64, 2, 2>(a, phases, s); }
-    else                   { if (g_bk32) launch_igemm_cfg<128, 128, 2, 2, 32>(a, phases, s); else launch_igemm_cfg<128, 128, 2, 2>(a, phases, s); }
+    else if (a.Cout <= 64) launch_igemm_cfg<128, 64, 2, 2>(a, phases, s);
+    else                   launch_igemm_cfg<128, 128, 2, 2>(a, phases, s);      // (K-tile depth 32 and 256x64 tiles measured slower: fewer resident waves)
 }
 
 // ===========================================================================
@@ -522,9 +521,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
 
 
 // ===========================================================================
-// 3x3 weight gradient, all nine taps per block
+// k x k weight gradient, several taps per block (3x3: all nine; 7x7: one filter row)
 // ===========================================================================
-// dW[ky][kx][ci][co] += sum_p X[p + (ky-1, kx-1)][ci] * dZ[p][co] for a 64(ci) x 64(co) tile and ALL
+// dW[ky][kx][ci][co] += sum_p X[p + (ky-1, kx-1)][ci] * dZ[p][co] for a 64(ci) x 64(co) tile and (3x3) ALL
 // nine taps: the K-tile is a run of 16 consecutive pixels of one image row; its 3 x 18 input halo and
 // the 16 dZ rows are staged in LDS once and feed 9 x 8 MFMA k-steps per wave (each wave: 32x32 tile,
 // nine accumulators).  Compared with one tap per block this reads X and dZ ~4x less often
@@ -536,16 +535,22 @@ struct Wgrad9Args {
     long long nseg; int segs_per_block;
 };
 
-__global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wgrad9Args p)
+// KH x KW taps per block (3x3: all nine; 7x7: one filter row of seven, the row index comes from the grid).
+template <int K, int KH, int KW>
+__global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const Wgrad9Args p)
 {
-    constexpr int XROWS = 54, XF4 = XROWS * 16, X_LD = (XF4 + 255) / 256;   // 3 x 18 halo pixels, 64 channels
-    __shared__ __attribute__((aligned(16))) float smem[2 * (XROWS * 64 + 16 * 64)];
+    constexpr int PAD = (K - 1) / 2, HCOLS = 16 + KW - 1, XROWS = KH * HCOLS, NT = KH * KW;
+    constexpr int XF4 = XROWS * 16, X_LD = (XF4 + 255) / 256, BUF = XROWS * 64 + 16 * 64;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
     const int nco = p.Cout / 64;
     const unsigned ntiles = (unsigned)(p.Cin / 64) * nco;
-    const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);       // 1-D grid: (pixel split) x (ci, co) tile, tile fastest
-    const unsigned tile = lid % ntiles, split = lid / ntiles;
+    constexpr unsigned NKY = K / KH;                               // filter-row groups handled by different blocks
+    const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);       // 1-D grid: (pixel split, filter row, (ci, co) tile), tile fastest
+    const unsigned tile = lid % ntiles, rest = lid / ntiles;
+    const unsigned kyb = rest % NKY, split = rest / NKY;
+    const int ky0 = (int)kyb * KH;
     const int ti = tile / nco, tj = tile - ti * nco;
     const int i0 = ti * 64, j0 = tj * 64;
     const int wsegs = p.W / 16;
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wgrad9Args p)
     for (int i = 0; i < X_LD; ++i) {
         const int f = tid + i * 256;
         const int prow = f / 16;
-        x_dy[i] = prow / 18 - 1; x_col[i] = prow % 18 - 1; x_c[i] = (f % 16) * 4;
+        x_dy[i] = ky0 + prow / HCOLS - PAD; x_col[i] = prow % HCOLS - PAD; x_c[i] = (f % 16) * 4;
     }
     const int d_px = tid / 16, d_c = (tid % 16) * 4;
 
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wgrad9Args p)
         if (++ws == wsegs) { ws = 0; if (++h == p.H) { h = 0; ++n; } }
     };
     auto sstore = [&](int buf) {
-        float* Xs = smem + buf * (XROWS * 64 + 16 * 64);
+        float* Xs = smem + buf * BUF;
         float* Ds = Xs + XROWS * 64;
 #pragma unroll
         for (int i = 0; i < X_LD; ++i) {
@@ -597,16 +602,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wgrad9Args p)
         *reinterpret_cast<float4*>(&Ds[d_px * 64 + d_c]) = rd;
     };
 
-    f32x16 acc[9];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
-    const bool do_bias = p.db != nullptr && ti == 0 && wave == 0;
+    const bool do_bias = p.db != nullptr && ti == 0 && kyb == 0 && wave == 0;
 
     auto compute = [&](int buf) {
-        const float* Xs = smem + buf * (XROWS * 64 + 16 * 64);
+        const float* Xs = smem + buf * BUF;
         const float* Ds = Xs + XROWS * 64;
         const float* Xb = Xs + half * 64 + wm * 32 + (lane & 31);
         const float* Db = Ds + half * 64 + wn * 32 + (lane & 31);
@@ -614,11 +619,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wgrad9Args p)
         for (int kk = 0; kk < 8; ++kk) {
             const float b = Db[kk * 2 * 64];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float a = Xb[(ky * 18 + kk * 2 + kx) * 64];
-                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ky * 3 + kx], 0, 0, 0);
+                for (int kx = 0; kx < KW; ++kx) {
+                    const float a = Xb[(ky * HCOLS + kk * 2 + kx) * 64];
+                    acc[ky * KW + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ky * KW + kx], 0, 0, 0);
                 }
         }
         if (do_bias) {
@@ -640,8 +645,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wgrad9Args p)
 
     const int col = j0 + wn * 32 + (lane & 31);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        float* Ct = p.dW + (long long)t * p.Cin * p.Cout;
+    for (int t = 0; t < NT; ++t) {
+        float* Ct = p.dW + (long long)((ky0 + t / KW) * K + t % KW) * p.Cin * p.Cout;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -651,20 +656,20 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wgrad9Args p)
     if (do_bias) unsafeAtomicAdd(p.db + j0 + lane, bsum);
 }
 
-bool launch_wgrad3x3(const float* X, const float* dZ, float* dW, float* db, int N, int H, int W, int Cin, int Cout,
-                     hipStream_t s)
+bool launch_wgrad_taps(const float* X, const float* dZ, float* dW, float* db, int N, int H, int W, int Cin, int Cout,
+                       int K, hipStream_t s)
 {
-    if (Cin % 64 || Cout % 64 || W % 16) return false;
+    if ((K != 3 && K != 7) || Cin % 64 || Cout % 64 || W % 16) return false;
     Wgrad9Args a{X, dZ, dW, db, N, H, W, Cin, Cout, (long long)N * H * (W / 16), 0};
-    const int tiles = (Cin / 64) * (Cout / 64);
-    long long splits = 4096 / tiles;                   // ~16 blocks per CU in total
+    const long long work = (long long)(Cin / 64) * (Cout / 64) * (K == 3 ? 1 : 7);
+    long long splits = 4096 / work;                    // ~16 blocks per CU in total
     if (splits < 1) splits = 1;
     if (splits > (a.nseg + 7) / 8) splits = (a.nseg + 7) / 8;      // at least 8 K-tiles per block
     if (splits < 1) splits = 1;
     a.segs_per_block = (int)((a.nseg + splits - 1) / splits);
     splits = (a.nseg + a.segs_per_block - 1) / a.segs_per_block;
-    g_last_kernel = "wgrad3x3_kernel";
-    hipLaunchKernelGGL(wgrad3x3_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, a);
+    if (K == 3) { g_last_kernel = "wgrad_taps_kernel<3, 3, 3>"; hipLaunchKernelGGL((wgrad_taps_kernel<3, 3, 3>), dim3((unsigned)(work * splits)), dim3(256), 0, s, a); }
+    else        { g_last_kernel = "wgrad_taps_kernel<7, 1, 7>"; hipLaunchKernelGGL((wgrad_taps_kernel<7, 1, 7>), dim3((unsigned)(work * splits)), dim3(256), 0, s, a); }
     return true;
 }
 

@@ -253,10 +253,10 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
     const double rc = a.Areal;
     const double flops = 2.0 * a.P * K * K * rc * Cout;
     const double bytes = 4.0 * (a.P * rc + (double)a.P * Cout + (double)K * K * rc * Cout);
-    const bool nine = K == 3 && alpha == 1.f && !real_cin;
+    const bool taps = (K == 3 || K == 7) && alpha == 1.f && !real_cin;
     const bool first = K == 3 && alpha == 1.f && real_cin == 3 && Cin == 4;
     auto run = [&]() {
-        if (nine && launch_wgrad3x3(x, dz, dw, db, N, H, W, Cin, Cout, s)) return;
+        if (taps && launch_wgrad_taps(x, dz, dw, db, N, H, W, Cin, Cout, K, s)) return;
         if (first && launch_conv1_wgrad(x, dz, dw, db, N, H, W, Cout, s)) return;
         launch_wgrad(a, s);
     };

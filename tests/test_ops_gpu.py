@@ -40,6 +40,8 @@ CONV_CASES = [
     (2, 4, 4, 256, 128, 1),
     (1, 16, 16, 256, 20, 1),
     (1, 3, 5, 8, 20, 3),
+    (2, 4, 16, 64, 128, 7),     # 7x7 with W % 16 == 0, C % 64 == 0: the one-filter-row-per-block wgrad kernel
+    (2, 8, 32, 128, 64, 3),     # 3x3, all-nine-taps wgrad kernel, two ci tiles
 ]
 
 

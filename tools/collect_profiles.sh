@@ -1,0 +1,14 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): bench line, rocprofv3 kernel stats and the two PMC passes of the same
+# bench command.  Outputs under gpurun_out/prof_<tag>/ ; copy what should be judged into profiles/.
+TAG=${1:-r01}
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+python bench.py --steps 10 --warmup 3 > $OUT/bench_train_bs16.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2>> $OUT/bench.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> $OUT/bench.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> $OUT/bench.err
+python tools/pmc_summary.py $OUT/pmc_fetch/bench_counter_collection.csv $OUT/pmc_write/bench_counter_collection.csv $OUT/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline ($TAG)" > $OUT/pmc_summary.txt
+python bench.py --steps 10 --warmup 3 --mode infer --batch 1 --no-cpu-baseline > $OUT/bench_infer_bs1.json 2>> $OUT/bench.err
+cat $OUT/bench_train_bs16.json
