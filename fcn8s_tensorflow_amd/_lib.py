@@ -47,6 +47,7 @@ SIGNATURES = {
     "fcn8s_grad_buffer": (_p, [_p, C.POINTER(_sz)]),
     "fcn8s_bucket_range": (_i, [_p, _i, C.POINTER(_sz), C.POINTER(_sz)]),
     "fcn8s_init_params": (_i, [_p, C.c_uint64]),
+    "fcn8s_onehot_to_ids": (_i, [_p, _p, _i, _i64, _i, _p, _p]),
     "fcn8s_train_step": (_i, [_p, _p, _i, _p, _i, _i, _i, _f, _f, _f, _i, _fp, _i64p]),
     "fcn8s_forward_loss": (_i, [_p, _p, _i, _p, _i, _i, _i, _f, _f, _i]),
     "fcn8s_backward_bucket": (_i, [_p, _i]),

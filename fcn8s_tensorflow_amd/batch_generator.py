@@ -92,6 +92,32 @@ def _place_or_crop(array, out_h, out_w, ymin, xmin, fill):
     return canvas
 
 
+def prefetch(generator, depth=2):
+    """Runs `generator` in a background thread and hands its batches over through a bounded queue, so that
+    PNG decoding / augmentation of batch t+1 overlaps the GPU's step on batch t (the reference's loop is
+    strictly serial, fcn8s_tensorflow.py:551).  Not in the reference; wrap the generator you pass to train()."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    done = object()
+
+    def work():
+        try:
+            for item in generator:
+                q.put(item)
+        except BaseException as ex:          # surface the worker's exception in the consumer
+            q.put(ex)
+        q.put(done)
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        item = q.get()
+        if item is done:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        yield item
+
+
 class BatchGenerator:
 
     def __init__(self,

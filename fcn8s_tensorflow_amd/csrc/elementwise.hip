@@ -252,6 +252,27 @@ void launch_softmax_argmax(const float* logits, float* softmax_out, long long* a
                        softmax_out, argmax_out, npix, C);
 }
 
+// ---- one-hot rows -> uint8 class ids (first non-zero entry; counts rows that are not one-hot) ------------
+template <typename T>
+__global__ __launch_bounds__(256) void onehot_to_ids_kernel(const T* oh, long long npix, int C, uint8_t* ids, int* bad)
+{
+    int nbad = 0;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+        const T* row = oh + p * C;
+        int first = -1, cnt = 0;
+        for (int c = 0; c < C; ++c) if (row[c] != 0) { if (first < 0) first = c; ++cnt; }
+        ids[p] = (uint8_t)(first < 0 ? 0 : first);
+        nbad += cnt != 1;
+    }
+    if (bad && nbad) atomicAdd(bad, nbad);
+}
+void launch_onehot_to_ids(const void* oh, int elem_bytes, long long npix, int C, uint8_t* ids, int* bad, hipStream_t s)
+{
+    const int blocks = cap_blocks(npix, 256);
+    if (elem_bytes == 1) hipLaunchKernelGGL(onehot_to_ids_kernel<uint8_t>, dim3(blocks), dim3(256), 0, s, (const uint8_t*)oh, npix, C, ids, bad);
+    else                 hipLaunchKernelGGL(onehot_to_ids_kernel<uint32_t>, dim3(blocks), dim3(256), 0, s, (const uint32_t*)oh, npix, C, ids, bad);
+}
+
 // ---- K14: confusion matrix conf[label*C + pred] += 1 --------------------------
 __global__ __launch_bounds__(256) void confusion_kernel(const uint8_t* labels, const long long* pred,
                                                         long long npix, unsigned long long* conf, int C)

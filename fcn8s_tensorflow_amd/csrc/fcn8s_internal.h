@@ -80,6 +80,7 @@ void launch_finalize_loss(const double* partials, int nparts, long long npix, co
                           float rate, float* loss_out, hipStream_t s);
 void launch_softmax_argmax(const float* logits, float* softmax_out, long long* argmax_out,
                            long long npix, int C, hipStream_t s);
+void launch_onehot_to_ids(const void* oh, int elem_bytes, long long npix, int C, uint8_t* ids, int* bad, hipStream_t s);
 void launch_confusion(const uint8_t* labels, const long long* pred, long long npix,
                       unsigned long long* conf, int C, hipStream_t s);
 void launch_colsum(const float* x, float* out, long long rows, int C, hipStream_t s);      // out[c] += sum_r x[r,c]

@@ -972,6 +972,12 @@ int fcn8s_profile_get(fcn8s_model* m, int gi, const char** name, double* total_m
 // ---- single ops ------------------------------------------------------------------------------
 #define OPCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(nullptr, FCN8S_ERR_HIP, hipGetErrorString(e_)); } while (0)
 
+int fcn8s_onehot_to_ids(void* stream, const void* onehot, int elem_bytes, int64_t npix, int C, uint8_t* ids, int32_t* bad)
+{
+    if (!onehot || !ids || (elem_bytes != 1 && elem_bytes != 4) || C <= 0 || C > 255) return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_onehot_to_ids: bad argument");
+    launch_onehot_to_ids(onehot, elem_bytes, npix, C, ids, bad, (hipStream_t)stream); OPCHK(); return FCN8S_OK;
+}
+
 int fcn8s_op_preprocess(void* stream, const void* images, int dtype, float* out4, int64_t npix)
 { launch_preprocess(images, dtype, out4, npix, (hipStream_t)stream); OPCHK(); return FCN8S_OK; }
 

@@ -65,6 +65,7 @@ class Engine:
             o = C.c_size_t(); m = C.c_size_t()
             L.check(L.lib.fcn8s_bucket_range(self.h, b, C.byref(o), C.byref(m)), self.h)
             self.buckets.append((o.value, m.value))
+        self._label_checks_left = 2
         self._sync_stream()
 
     # ---- plumbing ---------------------------------------------------------------------
@@ -155,17 +156,19 @@ class Engine:
         L.check(L.lib.fcn8s_set_opt_state(self.h, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), m.size), self.h)
 
     # ---- input marshalling -----------------------------------------------------------------
-    def _images(self, images):
+    def _images(self, images, force_device=False):
         """-> (keepalive, pointer, dtype code, where, (N,H,W))"""
         torch = self.torch
+        if isinstance(images, (list, tuple)):
+            images = np.asarray(images)
         if isinstance(images, torch.Tensor):
             t = images
             if t.dim() != 4 or t.shape[-1] != 3:
                 raise ValueError("images must have shape (batch, height, width, 3)")
             if t.dtype not in (torch.uint8, torch.float32):
                 t = t.float()
-            if t.is_cuda:
-                t = t.contiguous()
+            if t.is_cuda or force_device:
+                t = t.to(self.device).contiguous()
                 return t, C.c_void_p(t.data_ptr()), (L.IMG_U8 if t.dtype == torch.uint8 else L.IMG_F32), L.DEVICE, tuple(t.shape[:3])
             images = t.numpy()
         a = np.asarray(images)
@@ -174,45 +177,80 @@ class Engine:
         if a.dtype != np.uint8:
             a = a.astype(np.float32, copy=False)
         a = np.ascontiguousarray(a)
+        if force_device:
+            t = torch.from_numpy(a).to(self.device)
+            return t, C.c_void_p(t.data_ptr()), (L.IMG_U8 if a.dtype == np.uint8 else L.IMG_F32), L.DEVICE, a.shape[:3]
         return a, a.ctypes.data_as(C.c_void_p), (L.IMG_U8 if a.dtype == np.uint8 else L.IMG_F32), L.HOST, a.shape[:3]
 
-    def _labels(self, labels, nhw, where):
-        """Accepts one-hot (N,H,W,C) like the reference (fcn8s_tensorflow.py:110, 429-433)
-        or class-id maps (N,H,W); ships uint8 class ids to the device."""
+    def _onehot_to_ids(self, t, nhw):
+        """One-hot rows (N,H,W,C) on the device -> uint8 class ids on the device (library kernel).
+        The first batches are also checked for being one-hot (costs one host sync each)."""
         torch = self.torch
-        if isinstance(labels, torch.Tensor):
+        if t.shape[-1] != self.num_classes:
+            raise ValueError("one-hot labels must have %d channels, got %d" % (self.num_classes, t.shape[-1]))
+        if tuple(t.shape[:3]) != tuple(nhw):
+            raise ValueError("labels shape %s does not match images %s" % (tuple(t.shape), tuple(nhw)))
+        if t.dtype in (torch.bool, torch.uint8, torch.int8):
+            eb = 1
+        elif t.dtype in (torch.int32, torch.float32):
+            eb = 4
+        else:
+            t = t.to(torch.int32); eb = 4
+        t = t.to(self.device).contiguous()
+        npix = int(nhw[0]) * int(nhw[1]) * int(nhw[2])
+        ids = torch.empty(tuple(int(x) for x in nhw), dtype=torch.uint8, device=self.device)
+        check = self._label_checks_left > 0
+        bad = torch.zeros(1, dtype=torch.int32, device=self.device) if check else None
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(L.lib.fcn8s_onehot_to_ids(stream, C.c_void_p(t.data_ptr()), eb, npix, self.num_classes,
+                                          C.c_void_p(ids.data_ptr()), C.c_void_p(bad.data_ptr()) if check else None))
+        if check:
+            self._label_checks_left -= 1
+            nbad = int(bad.item())
+            if nbad:
+                raise ValueError("labels must be one-hot along the last axis (%d of %d rows are not); "
+                                 "soft labels are not supported" % (nbad, npix))
+        return ids
+
+    def _inputs(self, images, labels):
+        """Marshals one (images, labels) feed.  One-hot labels (the reference's format, fcn8s_tensorflow.py:110,
+        429-433) are shipped to the GPU and reduced to uint8 class ids there -- an np.argmax over the
+        168 MB one-hot batch on the host would cost more than the whole training step."""
+        torch = self.torch
+        lab_is_tensor = isinstance(labels, torch.Tensor)
+        lab_rank = labels.dim() if lab_is_tensor else np.ndim(labels)
+        onehot = lab_rank == 4
+        ka_i, pi, dt, where, nhw = self._images(images, force_device=onehot or (lab_is_tensor and labels.is_cuda))
+        if onehot:
+            t = labels if lab_is_tensor else torch.from_numpy(np.ascontiguousarray(labels))
+            ids = self._onehot_to_ids(t, nhw)
+            return (ka_i, ids), pi, dt, C.c_void_p(ids.data_ptr()), where, nhw
+        if lab_rank != 3:
+            raise ValueError("labels must be one-hot (batch, height, width, num_classes) or class ids (batch, height, width)")
+        if lab_is_tensor:
             t = labels
-            if t.dim() == 4:
-                if t.shape[-1] != self.num_classes:
-                    raise ValueError("one-hot labels must have %d channels" % self.num_classes)
-                t = t.argmax(-1)
             if tuple(t.shape) != tuple(nhw):
                 raise ValueError("labels shape %s does not match images %s" % (tuple(t.shape), tuple(nhw)))
             t = t.to(torch.uint8).contiguous()
             if where == L.DEVICE:
                 t = t.to(self.device)
-                return t, C.c_void_p(t.data_ptr())
+                return (ka_i, t), pi, dt, C.c_void_p(t.data_ptr()), where, nhw
             labels = t.cpu().numpy()
         a = np.asarray(labels)
-        if a.ndim == 4:
-            if a.shape[-1] != self.num_classes:
-                raise ValueError("one-hot labels must have %d channels, got %d" % (self.num_classes, a.shape[-1]))
-            a = np.argmax(a, axis=-1)
         if tuple(a.shape) != tuple(nhw):
             raise ValueError("labels shape %s does not match images %s" % (tuple(a.shape), tuple(nhw)))
         a = np.ascontiguousarray(a, dtype=np.uint8)
         if where == L.DEVICE:
             t = torch.from_numpy(a).to(self.device)
-            return t, C.c_void_p(t.data_ptr())
-        return a, a.ctypes.data_as(C.c_void_p)
+            return (ka_i, t), pi, dt, C.c_void_p(t.data_ptr()), where, nhw
+        return (ka_i, a), pi, dt, a.ctypes.data_as(C.c_void_p), where, nhw
 
     # ---- hot path ----------------------------------------------------------------------------
     def train_step(self, images, labels, learning_rate, keep_prob=0.5, l2_rate=0.0,
                    optimizer=L.OPT_TF_ADAM, fetch_loss=True):
         """sess.run([train_op, total_loss, global_step]) (fcn8s_tensorflow.py:554-572)."""
         self._sync_stream()
-        ka_i, pi, dt, where, nhw = self._images(images)
-        ka_l, pl = self._labels(labels, nhw, where)
+        ka, pi, dt, pl, where, nhw = self._inputs(images, labels)
         N, H, W = (int(x) for x in nhw)
         ws = self.world_size
         loss = C.c_float(0.0)
@@ -236,8 +274,7 @@ class Engine:
     def forward_backward(self, images, labels, keep_prob=1.0, l2_rate=0.0):
         """Gradients only (no update): returns the loss; gradients via get_grads()/grad_view()."""
         self._sync_stream()
-        ka_i, pi, dt, where, nhw = self._images(images)
-        ka_l, pl = self._labels(labels, nhw, where)
+        ka, pi, dt, pl, where, nhw = self._inputs(images, labels)
         N, H, W = (int(x) for x in nhw)
         L.check(L.lib.fcn8s_forward_loss(self.h, pi, dt, pl, N, H, W, float(keep_prob), float(l2_rate), where), self.h)
         for b in range(L.NUM_BUCKETS):
@@ -253,8 +290,7 @@ class Engine:
     def eval_step(self, images, labels, l2_rate=0.0):
         """sess.run(metric_update_ops) (fcn8s_tensorflow.py:685-689), keep_prob = 1."""
         self._sync_stream()
-        ka_i, pi, dt, where, nhw = self._images(images)
-        ka_l, pl = self._labels(labels, nhw, where)
+        ka, pi, dt, pl, where, nhw = self._inputs(images, labels)
         N, H, W = (int(x) for x in nhw)
         L.check(L.lib.fcn8s_eval_step(self.h, pi, dt, pl, N, H, W, float(l2_rate), where), self.h)
 

@@ -89,6 +89,14 @@ void*  fcn8s_grad_buffer(fcn8s_model* m, size_t* nfloats);
 int    fcn8s_bucket_range(const fcn8s_model* m, int bucket, size_t* offset_floats, size_t* nfloats);
 int    fcn8s_init_params(fcn8s_model* m, uint64_t seed);              /* synthetic init: He-normal VGG, truncated-normal decoder (:159-160) */
 
+/* ---- labels: the reference feeds one-hot rows [N,H,W,C] (placeholder int32 :110, bool from the generator,
+ * helpers/ground_truth_conversion_utils.py:84-88).  The kernels consume uint8 class ids; this converts a
+ * DEVICE one-hot tensor (elem_bytes 1 = bool/uint8, 4 = int32/float32 bit patterns, non-zero = set) into
+ * ids on the device: ids[p] = first c with onehot[p,c] != 0 (= np.argmax of a one-hot row).  `bad_count`
+ * (device, may be NULL) receives the number of rows that are not one-hot.                                */
+int fcn8s_onehot_to_ids(void* stream, const void* onehot_dev, int elem_bytes, int64_t npix, int C,
+                        uint8_t* ids_dev, int32_t* bad_count_dev);
+
 /* ---- training: sess.run([train_op,total_loss,global_step]) :554-572 -------- *
  * images: [N,H,W,3]; label_ids: uint8 class ids [N,H,W] (the argmax of the
  * one-hot rows the reference feeds, :110).  loss_out / step_out may be NULL

@@ -93,3 +93,20 @@ def test_errors_and_process_all(dataset, tmp_path):
     exp.process_all(resize=(4, 8), batch_size=2)
     assert sorted(os.listdir(root / "out" / "img" / "city")) == sorted(os.listdir(root / "img" / "city"))
     assert np.asarray(Image.open(root / "out" / "img" / "city" / "city_000000_leftImg8bit.png")).shape == (4, 8, 3)
+
+
+def test_prefetch_wrapper_preserves_order_and_errors(dataset):
+    from fcn8s_tensorflow_amd.batch_generator import prefetch
+    gen, d, _ = dataset
+    g = prefetch(gen.generate(batch_size=2, convert_to_one_hot=True, shuffle=False), depth=2)
+    for b in range(3):
+        x, y = next(g)
+        np.testing.assert_array_equal(x, d["x%d" % b]); np.testing.assert_array_equal(y, d["y%d" % b])
+
+    def boom():
+        yield 1
+        raise KeyError("x")
+    p = prefetch(boom())
+    assert next(p) == 1
+    with pytest.raises(KeyError):
+        next(p)
