@@ -251,13 +251,24 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
         }
     };
 
-    const int nkt = (p.Ktot + BK - 1) / BK;
-    gload(0);
+    // split-K (gridDim.y > 1, MODE 1 only, linear epilogue): this block reduces K-tiles [kt0, kt0 + nkt)
+    const int nkt_all = (p.Ktot + BK - 1) / BK;
+    const int kt0 = (int)((long long)nkt_all * blockIdx.y / gridDim.y);
+    const int nkt = (int)((long long)nkt_all * (blockIdx.y + 1) / gridDim.y) - kt0;
+    if (MODE == 1 && kt0 > 0) {
+        const int tap0 = kt0 * BK / p.Cin;
+        f_ci0 = kt0 * BK - tap0 * p.Cin;
+        f_ty = tap0 / p.KW; f_tx = tap0 - f_ty * p.KW;
+        set_tap();
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) b_ptr[i] += (long long)kt0 * BK * p.Cout;
+    }
+    gload(kt0);
     sstore(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) gload(kt + 1);
+        if (kt + 1 < nkt) gload(kt0 + kt + 1);
         compute(cur);
         if (kt + 1 < nkt) sstore(cur ^ 1);
         __syncthreads();
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
     for (int tn = 0; tn < TN; ++tn) {
         const int col = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
         if (col >= p.Cout) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+        const float bv = (p.bias && blockIdx.y == 0) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -292,6 +303,7 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
                 const long long off = rowoff[row];
                 if (off < 0) continue;
                 float v = acc[tm][tn][r] * p.alpha + bv;
+                if (MODE == 1 && gridDim.y > 1) { unsafeAtomicAdd(p.y + off + col, v); continue; }   // split-K partial
                 if (p.addend) v += p.addend[off + col];
                 if (p.relu) v = v > 0.f ? v : 0.f;
                 if (p.mask) v = p.mask[off + col] > 0.f ? v * p.mask_scale : 0.f;
@@ -313,6 +325,13 @@ static void launch_igemm_cfg(const IgemmArgs& a, int phases, hipStream_t s)
     static const std::string base = "igemm_fwd_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", ";
     static const std::string tags[3] = {base + "0, 16>", base + "1, " + std::to_string(BKF) + ">", base + "2, " + std::to_string(BKF) + ">"};
     g_last_kernel = tags[mode].c_str();
+    // few output tiles but a very long reduction (fc6 data gradient: 256 tiles, K = 200704): split K over
+    // gridDim.y and combine with fp32 atomics -- only when the epilogue is linear
+    if (mode == 1 && !a.relu && !a.mask && !a.dropout && !a.addend && a.out_scale == 1 && a.ldy == a.Cout &&
+        grid.x < 512 && a.Ktot / BKF >= 512) {
+        unsigned ks = 1024 / grid.x; if (ks > 8) ks = 8;
+        if (ks >= 2) { grid.y = ks; hipMemsetAsync(a.y, 0, (size_t)a.M * a.Cout * sizeof(float), s); }
+    }
     if (mode == 2)      hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 2, BKF>), grid, dim3(256), 0, s, a);
     else if (mode == 1) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 1, BKF>), grid, dim3(256), 0, s, a);
     else                hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 0, 16>), grid, dim3(256), 0, s, a);
