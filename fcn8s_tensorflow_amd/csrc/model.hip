@@ -972,6 +972,33 @@ int fcn8s_profile_get(fcn8s_model* m, int gi, const char** name, double* total_m
 // ---- single ops ------------------------------------------------------------------------------
 #define OPCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(nullptr, FCN8S_ERR_HIP, hipGetErrorString(e_)); } while (0)
 
+uint32_t fcn8s_crc32c(const void* data, size_t n, uint32_t crc)
+{
+    static uint32_t table[8][256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            table[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
+        init = true;
+    }
+    const uint8_t* p = (const uint8_t*)data;
+    uint32_t c = crc ^ 0xFFFFFFFFu;
+    while (n >= 8) {                                   // slice-by-8
+        uint32_t lo, hi; memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+            table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
+        p += 8; n -= 8;
+    }
+    while (n--) c = table[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
 int fcn8s_onehot_to_ids(void* stream, const void* onehot, int elem_bytes, int64_t npix, int C, uint8_t* ids, int32_t* bad)
 {
     if (!onehot || !ids || (elem_bytes != 1 && elem_bytes != 4) || C <= 0 || C > 255) return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_onehot_to_ids: bad argument");

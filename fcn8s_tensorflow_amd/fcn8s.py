@@ -9,13 +9,16 @@ three `sess.run` sites (:554-572, :685-689, :764-770) become
 `Engine.train_step / eval_step / predict`.
 
 Differences a maintainer must know (also listed in INTEGRATION.md):
-  * TensorFlow SavedModel / Saver files cannot be read or written without
-    TensorFlow.  `save()` keeps the reference's directory naming scheme
-    (:904-920) but stores `variables.npz` + `fcn8s_meta.json`;
-    `vgg16_dir` must hold `vgg16_weights.npz` (variables named as in the
-    reference, e.g. `conv1_1/filter`) or be the string 'synthetic[:seed]'.
+  * Variables stored by TensorFlow (the VGG-16 SavedModel for `vgg16_dir`,
+    FCN-8s SavedModels / Saver checkpoints for `model_load_dir`,
+    `variables_load_dir`, `load_variables`) are READ through `tf_bundle.py`
+    (tensor-bundle format, no TensorFlow needed; graph files are ignored).
+    `save()` keeps the reference's directory naming scheme (:904-920) but
+    stores `variables.npz` + `fcn8s_meta.json`; `export_tf_variables()` writes
+    a TF-restorable bundle.  `vgg16_dir` may also hold `vgg16_weights.npz` or
+    be the string 'synthetic[:seed]'.
   * Labels may also be passed as uint8 class-id maps (N,H,W); one-hot
-    (N,H,W,C) input as in the reference is converted on the host.
+    (N,H,W,C) input as in the reference is reduced to ids on the GPU.
   * Data-parallel training: launch one process per GPU with torch.distributed
     initialised (RCCL); every rank feeds its own shard of the minibatch.
 """
@@ -44,6 +47,7 @@ except Exception:  # pragma: no cover
         return _R(n)
 
 from . import _lib as L
+from . import tf_bundle
 from .engine import Engine
 
 _SAVERS = {'saved_model', 'train_saver'}
@@ -55,9 +59,11 @@ class FCN8s:
                  device_id=None, seed=0, widths=None, fc6_ksize=7):
         '''
         Arguments (first five: fcn8s_tensorflow.py:19-35; the rest are additions):
-            model_load_dir (string, optional): directory written by `save(saver='saved_model')`.
+            model_load_dir (string, optional): directory written by `save(saver='saved_model')`, or a TensorFlow
+                SavedModel directory written by the reference (its variables bundle is read).
             tags (list, optional): kept for signature parity; checked against the saved tags if given.
-            vgg16_dir (string, optional): directory with `vgg16_weights.npz`, or 'synthetic[:seed]'.
+            vgg16_dir (string, optional): the VGG-16 SavedModel directory (variables bundle), a directory with
+                `vgg16_weights.npz`, or 'synthetic[:seed]'.
             num_classes (int, optional): number of segmentation classes (multiple of 4).
             variables_load_dir (string, optional): path prefix written by `save(saver='train_saver')`.
             device_id (int, optional): HIP device; defaults to LOCAL_RANK or 0.
@@ -90,7 +96,17 @@ class FCN8s:
             device_id = int(os.environ.get("LOCAL_RANK", "0"))
         rank = int(os.environ.get("RANK", "0"))
 
-        if model_load_dir is not None:
+        tf_prefix = tf_bundle.find_bundle_prefix(model_load_dir) if model_load_dir is not None else None
+        if model_load_dir is not None and tf_prefix is not None and not os.path.isfile(os.path.join(model_load_dir, 'fcn8s_meta.json')):
+            # a TensorFlow SavedModel / Saver checkpoint written by the reference (:922-934): variables, Adam slots, global_step
+            tensors = tf_bundle.read_bundle(tf_prefix)
+            if 'fc7_1x1/bias' not in tensors:
+                raise ValueError("'{}' does not hold an FCN-8s checkpoint (no variable 'fc7_1x1/bias').".format(model_load_dir))
+            self.num_classes = int(tensors['fc7_1x1/bias'].shape[0])
+            w = tuple(int(tensors[k].shape[-1]) for k in ('conv1_2/filter', 'conv2_2/filter', 'conv3_3/filter', 'conv4_3/filter', 'conv5_3/filter', 'fc6/weights', 'fc7/weights'))
+            self.engine = Engine(self.num_classes, widths=w, fc6_ksize=int(tensors['fc6/weights'].shape[0]), device_id=device_id, seed=seed + rank)
+            _load_tf_tensors(self.engine, tensors, with_state=True)
+        elif model_load_dir is not None:
             meta = _read_meta(model_load_dir)
             if tags is not None and meta.get("tags") is not None and not set(tags) <= set(meta["tags"]):
                 raise RuntimeError("MetaGraphDef associated with tags {} could not be found in SavedModel (available: {}).".format(tags, meta["tags"]))
@@ -113,6 +129,16 @@ class FCN8s:
             s = int(d.split(':', 1)[1]) if ':' in d else 0
             self.engine.init_params(seed=s)
             return
+        prefix = tf_bundle.find_bundle_prefix(d)
+        if prefix is not None:                       # the reference's VGG-16 SavedModel (README.md:42): variables bundle
+            self.engine.init_params(seed=0)          # decoder: truncated normal (:159-160); encoder overwritten below
+            tensors = tf_bundle.read_bundle(prefix)
+            params = {k: v for k, v in tensors.items() if k in self.engine.specs and (k.startswith('conv') or k.startswith('fc6/') or k.startswith('fc7/'))}
+            missing = [k for k in self.engine.specs if (k.startswith('conv') or k.startswith('fc6/') or k.startswith('fc7/')) and k not in params]
+            if missing:
+                raise ValueError("the VGG-16 checkpoint lacks variables: {}".format(missing[:5]))
+            self.engine.set_params(params)
+            return
         npz = os.path.join(d, 'vgg16_weights.npz')
         if os.path.isfile(npz):
             self.engine.init_params(seed=0)          # decoder: truncated normal (:159-160); encoder overwritten below
@@ -123,10 +149,7 @@ class FCN8s:
                 raise ValueError("vgg16_weights.npz lacks variables: {}".format(missing[:5]))
             self.engine.set_params(params)
             return
-        if os.path.isfile(os.path.join(d, 'saved_model.pb')):
-            raise NotImplementedError("'{}' holds a TensorFlow SavedModel; its variables bundle cannot be read without TensorFlow. "
-                                      "Export the variables to vgg16_weights.npz (names as in the reference, e.g. 'conv1_1/filter', HWIO layout).".format(d))
-        raise ValueError("`vgg16_dir` must contain vgg16_weights.npz or be 'synthetic[:seed]', got '{}'.".format(d))
+        raise ValueError("`vgg16_dir` must contain a TensorFlow SavedModel (variables/variables.index), vgg16_weights.npz, or be 'synthetic[:seed]', got '{}'.".format(d))
 
     def _initialize_metrics(self, metrics):
         '''fcn8s_tensorflow.py:371-397'''
@@ -438,10 +461,27 @@ class FCN8s:
     def load_variables(self, path):
         '''fcn8s_tensorflow.py:938-944.  `path` is the prefix `<dir>/<model_name>/variables`
         (as passed to tf.train.Saver.restore) or the `.npz` file itself.'''
+        if os.path.isfile(path + '.index'):          # a tf.train.Saver checkpoint written by the reference
+            _load_tf_tensors(self.engine, tf_bundle.read_bundle(path), with_state=True)
+            return
         f = path if path.endswith('.npz') else path + '.npz'
         if not os.path.isfile(f):
             raise ValueError("The passed save_path is not a valid checkpoint: {}".format(path))
         _load_checkpoint(self.engine, f, with_state=True)
+
+    def export_tf_variables(self, prefix, include_optimizer_state=True):
+        '''Not in the reference: writes all variables (and the Adam slots / global_step under the names
+        tf.train.AdamOptimizer(name='adam_optimizer') gives them) as a TensorFlow tensor bundle
+        `<prefix>.index` + `<prefix>.data-00000-of-00001`, restorable with tf.train.Saver.'''
+        tensors = dict(self.engine.get_params())
+        if include_optimizer_state:
+            m, v = self.engine.get_opt_state()
+            for k, (shape, off) in self.engine.specs.items():
+                n = int(np.prod(shape))
+                tensors[k + tf_bundle.ADAM_M_SUFFIX] = m[off:off + n].reshape(shape)
+                tensors[k + tf_bundle.ADAM_V_SUFFIX] = v[off:off + n].reshape(shape)
+            tensors['optimizer/global_step'] = np.asarray(self.engine.global_step, dtype=np.int32)
+        tf_bundle.write_bundle(prefix, tensors)
 
     def close(self):
         '''fcn8s_tensorflow.py:946-952'''
@@ -471,6 +511,26 @@ def _load_checkpoint(engine, path, with_state=True):
             engine.set_opt_state(data['__adam_m__'], data['__adam_v__'])
         if 'optimizer/global_step' in data.files:
             engine.global_step = int(data['optimizer/global_step'])
+
+
+def _load_tf_tensors(engine, tensors, with_state=True):
+    engine.set_params({k: v for k, v in tensors.items() if k in engine.specs})
+    if not with_state:
+        return
+    n = engine.flat_params.numel()
+    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32); found = False
+    for k, (shape, off) in engine.specs.items():
+        cnt = int(np.prod(shape))
+        if k + tf_bundle.ADAM_M_SUFFIX in tensors and k + tf_bundle.ADAM_V_SUFFIX in tensors:
+            m[off:off + cnt] = tensors[k + tf_bundle.ADAM_M_SUFFIX].reshape(-1)
+            v[off:off + cnt] = tensors[k + tf_bundle.ADAM_V_SUFFIX].reshape(-1)
+            found = True
+    if found:
+        engine.set_opt_state(m, v)
+    for key in ('optimizer/global_step', 'global_step'):
+        if key in tensors:
+            engine.global_step = int(np.asarray(tensors[key]).reshape(-1)[0])
+            break
 
 
 def _write_meta(target, engine, tags):

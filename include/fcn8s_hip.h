@@ -140,6 +140,9 @@ int     fcn8s_set_opt_state(fcn8s_model* m, const float* host_m, const float* ho
 int fcn8s_get_activation(fcn8s_model* m, const char* name, float* host, size_t nfloats);
 int fcn8s_get_dropout_masks(fcn8s_model* m, float* host_mask6, size_t n6, float* host_mask7, size_t n7);
 
+/* ---- host helper for the TF tensor-bundle writer (tf_bundle.py): CRC-32C (Castagnoli) of a host buffer ----- */
+uint32_t fcn8s_crc32c(const void* data, size_t nbytes, uint32_t crc);
+
 /* ---- in-library HIP-event timing of kernel groups (bench.py roofline) -------- *
  * groups: "conv3x3_fwd","conv3x3_dgrad","conv3x3_wgrad","fc_fwd","fc_dgrad","fc_wgrad",...
  * Fills total milliseconds, number of launches, algorithmic flops and bytes.

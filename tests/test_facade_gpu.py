@@ -206,3 +206,44 @@ def test_onehot_labels_are_converted_on_the_gpu_and_validated():
     with pytest.raises(ValueError, match="one-hot"):
         e2.forward_backward(img, bad, keep_prob=1.0)
     e.close(); e2.close()
+
+
+def test_tensorflow_checkpoint_files_round_trip(tmp_path):
+    """The reference's on-disk variable format (TF tensor bundle) is read and written without TensorFlow:
+    a VGG-16 'SavedModel' directory feeds `vgg16_dir`, an FCN-8s checkpoint feeds `model_load_dir` /
+    `load_variables` including the Adam slots and global_step under their TF names."""
+    from fcn8s_tensorflow_amd import tf_bundle
+    from fcn8s_tensorflow_amd.fcn8s import FCN8s
+    m = make()
+    g = gen(2, 32, 64, 0, onehot=False)
+    m.train(g, epochs=1, steps_per_epoch=2, learning_rate_schedule=lambda s: 1e-3, record_summaries=False)
+    params = m.engine.get_params(); mom = m.engine.get_opt_state()
+    img = next(g)[0]
+    pred = m.predict(img)
+    sm_dir = tmp_path / "tf_saved_model"
+    m.export_tf_variables(str(sm_dir / "variables" / "variables"))
+    names = tf_bundle.read_index(str(sm_dir / "variables" / "variables.index"))[1]
+    assert "fc6/weights" in names and "fc6/weights/adam_optimizer_1" in names and "optimizer/global_step" in names
+    # encoder-only directory, as downloaded for `vgg16_dir`
+    vgg_dir = tmp_path / "vgg16"
+    tf_bundle.write_bundle(str(vgg_dir / "variables" / "variables"),
+                           {k: v for k, v in params.items() if k.startswith("conv") or k.startswith("fc6/") or k.startswith("fc7/")})
+    m.close()
+
+    m2 = FCN8s(model_load_dir=str(sm_dir), tags=["default"])
+    assert m2.num_classes == 20 and m2.engine.widths == SMALL and m2.engine.global_step == 2
+    for k, v in m2.engine.get_params().items():
+        np.testing.assert_array_equal(v, params[k])
+    np.testing.assert_array_equal(m2.engine.get_opt_state()[1], mom[1])
+    np.testing.assert_array_equal(m2.predict(img), pred)
+    m2.close()
+
+    m3 = FCN8s(vgg16_dir=str(vgg_dir), num_classes=20, widths=SMALL)
+    got = m3.engine.get_params()
+    np.testing.assert_array_equal(got["conv3_2/filter"], params["conv3_2/filter"])
+    np.testing.assert_array_equal(got["fc7/biases"], params["fc7/biases"])
+    assert np.abs(got["fc7_1x1/kernel"]).max() < 0.01 and m3.engine.global_step == 0     # decoder freshly initialised (:159-160)
+    m3.load_variables(str(sm_dir / "variables" / "variables"))                            # tf.train.Saver-style prefix
+    np.testing.assert_array_equal(m3.engine.get_params()["fc7_1x1/kernel"], params["fc7_1x1/kernel"])
+    assert m3.engine.global_step == 2
+    m3.close()
