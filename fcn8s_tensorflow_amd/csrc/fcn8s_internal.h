@@ -35,6 +35,7 @@ struct IgemmArgs {
     int phases_x; long long w_phase_stride;
     float alpha; int relu; float mask_scale;
     int dropout; float keep_prob; unsigned long long seed; unsigned int stream_id;
+    int batched; long long x_batch_stride, y_batch_stride;   // gridDim.z independent GEMMs (Winograd positions)
 };
 void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s);
 
@@ -96,6 +97,11 @@ void launch_pad_cin(const float* w, float* w4, int taps, int Cin, int Cinp, int 
 void launch_tconv_phase_pack(const float* w, float* wp, int K, int S, int C, hipStream_t s);
 void launch_dropout_mask(float* mask, long long n, float keep_prob, unsigned long long seed,
                          unsigned int stream_id, hipStream_t s);
+// Winograd F(2x2,3x3) transforms around 16 batched GEMMs (3x3 SAME conv, H and W even, C % 4 == 0)
+void launch_wino_filter(const float* w, float* u, int Cin, int Cout, hipStream_t s);            // w[9][Cin][Cout] -> u[16][Cin][Cout]
+void launch_wino_input(const float* x, float* v, int N, int H, int W, int C, hipStream_t s);      // x[N,H,W,C] -> v[16][T][C], T = N*(H/2)*(W/2)
+void launch_wino_output(const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
+                        int relu, float* y, int N, int H, int W, int C, hipStream_t s);          // m[16][T][C] -> y[N,H,W,C]
 void launch_init_normal(float* w, long long n, float stddev, int truncated, unsigned long long seed,
                         unsigned int stream_id, hipStream_t s);
 

@@ -68,8 +68,12 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int pz = blockIdx.z;
-    const int pzy = pz / p.phases_x, pzx = pz - pzy * p.phases_x;
+    // gridDim.z: transposed-conv sub-pixel phases (weights + output offset per phase) or, when p.batched,
+    // independent GEMMs with their own input / weight / output slabs (the 16 Winograd positions)
+    const int pzy = p.batched ? 0 : pz / p.phases_x, pzx = p.batched ? 0 : pz - pzy * p.phases_x;
     const float* __restrict__ Wp = p.w + (long long)pz * p.w_phase_stride;
+    const float* __restrict__ X = p.batched ? p.x + (long long)pz * p.x_batch_stride : p.x;
+    float* __restrict__ Y = p.batched ? p.y + (long long)pz * p.y_batch_stride : p.y;
     const int offy = p.out_offy + pzy, offx = p.out_offx + pzx;
     const unsigned ntn = (unsigned)((p.Cout + BN - 1) / BN);
     // 1-D grid of M-tiles x N-tiles, N fastest: the N-tiles of one M-tile (same A panel) and the next
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
             const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
             a_val[i] = a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             const long long pix = a_val[i] ? a_base[i] + (long long)iy * p.Wi + ix : 0;
-            a_ptr[i] = p.x + pix * p.ldx + a_c4;
+            a_ptr[i] = X + pix * p.ldx + a_c4;
         }
     };
     if (FAST) {
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
                     if (a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) mk |= 1u << t;
                 }
                 a_mask[i] = mk;
-                a_ptr[i] = p.x + (a_base[i] + (long long)a_iy[i] * p.Wi + a_ix[i]) * p.ldx + a_c4;
+                a_ptr[i] = X + (a_base[i] + (long long)a_iy[i] * p.Wi + a_ix[i]) * p.ldx + a_c4;
             }
         } else set_tap();
 #pragma unroll
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) {
                 const bool ok = (a_mask[i] >> f_tap) & 1u;
-                ra[i] = ldg4(ok ? a_ptr[i] + delta : p.x);  // zeroing of out-of-image rows is deferred to sstore so
+                ra[i] = ldg4(ok ? a_ptr[i] + delta : X);  // zeroing of out-of-image rows is deferred to sstore so
                 a_ldok[i] = ok;                              // that the wave does not wait for the load before its MFMAs
             }
 #pragma unroll
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
         for (int i = 0; i < A_LD; ++i) {
             const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
             const bool ok = a_ok[i] && kok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            ra[i] = ok ? ldg4(p.x + (a_base[i] + (long long)iy * p.Wi + ix) * p.ldx + ci)
+            ra[i] = ok ? ldg4(X + (a_base[i] + (long long)iy * p.Wi + ix) * p.ldx + ci)
                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -303,12 +307,12 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
                 const long long off = rowoff[row];
                 if (off < 0) continue;
                 float v = acc[tm][tn][r] * p.alpha + bv;
-                if (MODE == 1 && gridDim.y > 1) { unsafeAtomicAdd(p.y + off + col, v); continue; }   // split-K partial
+                if (MODE == 1 && gridDim.y > 1) { unsafeAtomicAdd(Y + off + col, v); continue; }   // split-K partial
                 if (p.addend) v += p.addend[off + col];
                 if (p.relu) v = v > 0.f ? v : 0.f;
                 if (p.mask) v = p.mask[off + col] > 0.f ? v * p.mask_scale : 0.f;
                 if (p.dropout) v = dropout_apply(v, (unsigned long long)(off + col), p.seed, p.stream_id, p.keep_prob);
-                p.y[off + col] = v;
+                Y[off + col] = v;
             }
         }
     }
@@ -318,7 +322,7 @@ template <int BM, int BN, int WM, int WN, int BKF = 16>
 static void launch_igemm_cfg(const IgemmArgs& a, int phases, hipStream_t s)
 {
     dim3 grid((unsigned)(((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN)), 1, (unsigned)phases);
-    const bool fast = phases == 1 && a.Cin % BKF == 0 && a.Cout % BN == 0 && a.Ktot % a.Cin == 0;
+    const bool fast = (phases == 1 || a.batched) && a.Cin % BKF == 0 && a.Cout % BN == 0 && a.Ktot % a.Cin == 0;
     // filter bank small enough to live in L2 / MALL -> tap-inner K order (and at most 32 taps for the bit mask)
     const bool tap_inner = fast && (double)a.Ktot * a.Cout * 4.0 <= 64e6 && a.Ktot / a.Cin <= 32;
     const int mode = !fast ? 0 : (tap_inner ? 2 : 1);

@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -52,6 +54,8 @@ struct fcn8s_model {
     float *d_params = nullptr, *d_grads = nullptr, *d_m = nullptr, *d_v = nullptr, *d_wt = nullptr;
     bool own_params = false, own_grads = false;
     float *d_w1pad = nullptr, *d_tph[3] = {nullptr, nullptr, nullptr};
+    float *d_wino_u = nullptr, *d_wino_v = nullptr, *d_wino_m = nullptr;   // Winograd scratch: filters, transformed input / output
+    int wino_min_cin = 256;                                               // 3x3 layers with Cin >= this use Winograd F(2x2,3x3); 0 = never
     hipStream_t stream = nullptr;
     int64_t step = 0;
     // workspace for the current (N,H,W)
@@ -184,11 +188,47 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
              float alpha = 1.f; int relu = 0; float mask_scale = 1.f; int dropout = 0; float keep = 1.f;
              uint32_t stream_id = 0; };
 
+// 3x3 SAME conv through Winograd F(2x2,3x3): filter transform, input transform, 16 batched GEMMs on the
+// matrix cores (2.25x fewer MFMA flops than the direct form), output transform + fused epilogue.
+// u: [16][Cin][Cout], v: [16][T][Cin], mm: [16][T][Cout] scratch, T = N*(H/2)*(W/2).
+void conv3x3_winograd(fcn8s_model* m, const char* tag, const float* x, const float* w9, float* y, float* u, float* v, float* mm,
+                      int N, int H, int W, int Cin, int Cout, const float* bias, const float* addend, const float* mask,
+                      float mask_scale, int relu, hipStream_t s, const char* layer)
+{
+    const long long T = (long long)N * (H / 2) * (W / 2);
+    IgemmArgs a{};
+    a.x = v; a.w = u; a.y = mm;
+    a.N = 1; a.Ma = (int)T; a.Mb = 1; a.M = T;
+    a.Hi = (int)T; a.Wi = 1; a.Cin = Cin; a.ldx = Cin;
+    a.KW = 1; a.in_scale = 1; a.tap_step = 1; a.tap_off = 0; a.Ktot = Cin;
+    a.Ho = (int)T; a.Wo = 1; a.Cout = Cout; a.ldy = Cout;
+    a.out_scale = 1; a.phases_x = 1; a.w_phase_stride = (long long)Cin * Cout;
+    a.alpha = 1.f; a.mask_scale = 1.f;
+    a.batched = 1; a.x_batch_stride = T * Cin; a.y_batch_stride = T * Cout;
+    const double tb = 4.0 * ((double)N * H * W * Cin + 16.0 * T * Cin), ob = 4.0 * ((double)N * H * W * Cout + 16.0 * T * Cout);
+    if (m) {
+        { ProfScope ps(m, "wino_transform", 0, tb + 25.0 * 4 * Cin * Cout); launch_wino_filter(w9, u, Cin, Cout, s); launch_wino_input(x, v, N, H, W, Cin, s); }
+        { ProfScope ps(m, tag, 2.0 * 16.0 * T * Cin * Cout, 4.0 * 16.0 * (T * (double)(Cin + Cout) + (double)Cin * Cout), layer); launch_igemm(a, 16, s); }
+        { ProfScope ps(m, "wino_transform", 0, ob); launch_wino_output(mm, bias, addend, mask, mask_scale, relu, y, N, H, W, Cout, s); }
+    } else {
+        launch_wino_filter(w9, u, Cin, Cout, s); launch_wino_input(x, v, N, H, W, Cin, s);
+        launch_igemm(a, 16, s);
+        launch_wino_output(mm, bias, addend, mask, mask_scale, relu, y, N, H, W, Cout, s);
+    }
+}
+
 // SAME conv (or its data gradient when `w` holds flipped+transposed weights)
 void conv_same(fcn8s_model* m, const char* group, const float* x, const float* w, float* y,
                int N, int H, int W, int Cin, int Cout, int K, const Epi& e, hipStream_t s, int real_cin = 0,
                const char* layer = nullptr)
 {
+    if (m && K == 3 && m->wino_min_cin > 0 && Cin >= m->wino_min_cin && m->d_wino_v && Cin % 16 == 0 && Cout % 64 == 0 &&
+        H % 2 == 0 && W % 2 == 0 && e.alpha == 1.f && !e.dropout && !real_cin) {
+        const bool dgrad = strstr(group, "dgrad") != nullptr;
+        conv3x3_winograd(m, dgrad ? "wino_gemm_dgrad" : "wino_gemm_fwd", x, w, y, m->d_wino_u, m->d_wino_v, m->d_wino_m, N, H, W, Cin, Cout,
+                         e.bias, e.addend, e.mask, e.mask_scale, e.relu, s, layer);
+        return;
+    }
     IgemmArgs a{};
     a.x = x; a.w = w; a.bias = e.bias; a.addend = e.addend; a.mask = e.mask; a.y = y;
     a.N = N; a.Ma = H; a.Mb = W; a.M = (long long)N * H * W;
@@ -321,6 +361,21 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
     items.push_back({"gbuf0", gmax, 0, 0, 0, &m->gbuf[0]});
     items.push_back({"gbuf1", gmax, 0, 0, 0, &m->gbuf[1]});
     items.push_back({"softmax", (size_t)N * H * W * C, H, W, C, &m->d_softmax});
+    {   // Winograd scratch (4x the largest qualifying 3x3 layer's input / output)
+        size_t vmax = 0;
+        if (m->wino_min_cin > 0) {
+            int cin = 3;
+            for (int b = 0, hh = H, ww = W; b < 5; ++b, hh /= 2, ww /= 2)
+                for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
+                    const int cout = m->widths[b];
+                    const size_t big = (size_t)N * hh * ww * (size_t)std::max(cin, cout) * 4;
+                    if (std::max(cin, cout) >= m->wino_min_cin && big > vmax) vmax = big;
+                    cin = cout;
+                }
+        }
+        m->d_wino_v = m->d_wino_m = nullptr;
+        if (vmax) { items.push_back({"wino_v", vmax, 0, 0, 0, &m->d_wino_v}); items.push_back({"wino_m", vmax, 0, 0, 0, &m->d_wino_m}); }
+    }
 
     size_t bytes = 0;
     std::vector<size_t> offs;
@@ -642,6 +697,12 @@ int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
     if ((e = hipMalloc((void**)&m->d_tph[0], 16 * cc * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&m->d_tph[1], 16 * cc * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&m->d_tph[2], 256 * cc * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+    {
+        const char* wm = getenv("FCN8S_WINOGRAD_MIN_CIN");          // tuning / A-B switch; 0 disables the Winograd path
+        if (wm) m->wino_min_cin = atoi(wm);
+        int cmax = 0; for (int i = 0; i < 5; ++i) cmax = std::max(cmax, m->widths[i]);
+        if ((e = hipMalloc((void**)&m->d_wino_u, 16 * (size_t)cmax * cmax * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+    }
     if ((e = hipMalloc((void**)&m->d_loss, 2 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     m->d_regsum = m->d_loss + 1;
     if ((e = hipMalloc((void**)&m->d_conf, cc * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
@@ -662,6 +723,7 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->d_v) hipFree(m->d_v);
     if (m->d_wt) hipFree(m->d_wt);
     if (m->d_w1pad) hipFree(m->d_w1pad);
+    if (m->d_wino_u) hipFree(m->d_wino_u);
     for (int i = 0; i < 3; ++i) if (m->d_tph[i]) hipFree(m->d_tph[i]);
     if (m->d_loss) hipFree(m->d_loss);
     if (m->d_conf) hipFree(m->d_conf);
@@ -1014,6 +1076,20 @@ int fcn8s_op_conv2d(void* stream, const float* x, const float* w, const float* b
     if (Cin % 4 || Cout % 4 || K % 2 == 0) return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d: Cin, Cout must be multiples of 4 and K odd");
     Epi e; e.bias = bias; e.relu = relu;
     conv_same(nullptr, "", x, w, y, N, H, W, Cin, Cout, K, e, (hipStream_t)stream);
+    OPCHK(); return FCN8S_OK;
+}
+
+int fcn8s_op_conv2d_winograd(void* stream, const float* x, const float* w, const float* bias, float* y,
+                             int N, int H, int W, int Cin, int Cout, int relu)
+{
+    if (Cin % 16 || Cout % 32 || H % 2 || W % 2) return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d_winograd: needs Cin % 16, Cout % 32, even H and W");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t T = (size_t)N * (H / 2) * (W / 2);
+    float *u = nullptr, *v = nullptr, *mm = nullptr;
+    if (hipMalloc((void**)&u, 16 * (size_t)Cin * Cout * 4) != hipSuccess || hipMalloc((void**)&v, 16 * T * Cin * 4) != hipSuccess ||
+        hipMalloc((void**)&mm, 16 * T * Cout * 4) != hipSuccess) return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc");
+    conv3x3_winograd(nullptr, "", x, w, y, u, v, mm, N, H, W, Cin, Cout, bias, nullptr, nullptr, 1.f, relu, s, nullptr);
+    hipStreamSynchronize(s); hipFree(u); hipFree(v); hipFree(mm);
     OPCHK(); return FCN8S_OK;
 }
 

@@ -158,6 +158,9 @@ int fcn8s_profile_get(fcn8s_model* m, int group, const char** name, double* tota
 int fcn8s_op_preprocess(void* stream, const void* images, int image_dtype, float* out4, int64_t npix);
 int fcn8s_op_conv2d(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,
                     int N, int H, int W, int Cin, int Cout, int K, int relu);
+/* the same 3x3 SAME conv through Winograd F(2x2,3x3) (the path the model takes for its wide 3x3 layers) */
+int fcn8s_op_conv2d_winograd(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,
+                             int N, int H, int W, int Cin, int Cout, int relu);
 int fcn8s_op_conv2d_bwd(void* stream, const float* x, const float* w_hwio, const float* dy,
                         float* dx, float* dw, float* db,
                         int N, int H, int W, int Cin, int Cout, int K);

@@ -75,6 +75,27 @@ def test_conv2d_fwd_bwd(N, H, W, Cin, Cout, K):
     assert rel_err(y_.cpu().numpy(), np.maximum(y_ref, 0)) < 2e-5
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(1, 4, 6, 16, 32), (2, 8, 16, 64, 128), (1, 16, 32, 256, 256), (3, 2, 2, 32, 64)])
+def test_conv3x3_winograd(N, H, W, Cin, Cout):
+    """Winograd F(2x2,3x3) path (filter/input transforms, 16 batched MFMA GEMMs, output transform + bias + ReLU)."""
+    L = _lib()
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = orc.conv2d_same_t(torch.tensor(x).permute(0, 3, 1, 2).double(), torch.tensor(w).double(), torch.tensor(b).double(), relu=True)
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y_ = torch.empty(N, H, W, Cout).cuda()
+    L.check(L.lib.fcn8s_op_conv2d_winograd(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), N, H, W, Cin, Cout, 1))
+    torch.cuda.synchronize()
+    assert rel_err(y_.cpu().numpy(), ref) < 1e-5
+    yd = torch.empty(N, H, W, Cout).cuda()
+    L.check(L.lib.fcn8s_op_conv2d(None, ptr(xd), ptr(wd), ptr(bd), ptr(yd), N, H, W, Cin, Cout, 3, 1))
+    torch.cuda.synchronize()
+    assert rel_err(y_.cpu().numpy(), yd.cpu().numpy()) < 1e-5      # and against the direct kernel
+
+
 @pytest.mark.parametrize("N,H,W,C", [(2, 8, 8, 64), (1, 4, 6, 8), (1, 32, 64, 128)])
 def test_maxpool(N, H, W, C):
     L = _lib()
