@@ -54,6 +54,7 @@ struct WgradArgs {
     int ldc;                           // C[tap] is [Areal][ldc]
     float alpha;
     float* colsum;                     // optional: colsum[j] += sum_p B[p,j]  (bias gradient), or nullptr
+    int batched; long long a_batch_stride, b_batch_stride;   // gridDim.z = independent GEMMs (C stride = Areal*ldc)
 };
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
 // 3x3 / 7x7 SAME conv weight (+bias) gradient, several taps per block (3x3: all nine, 7x7: one filter row);
@@ -102,6 +103,8 @@ void launch_wino_filter(const float* w, float* u, int Cin, int Cout, hipStream_t
 void launch_wino_input(const float* x, float* v, int N, int H, int W, int C, hipStream_t s);      // x[N,H,W,C] -> v[16][T][C], T = N*(H/2)*(W/2)
 void launch_wino_output(const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
                         int relu, float* y, int N, int H, int W, int C, hipStream_t s);          // m[16][T][C] -> y[N,H,W,C]
+void launch_wino_dout(const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s);      // dy[N,H,W,C] -> dm[16][T][C] = A dY A^T
+void launch_wino_dfilter(const float* du, float* dw, int Cin, int Cout, hipStream_t s);           // du[16][Cin][Cout] -> dw[9][Cin][Cout] = G^T dU G
 void launch_init_normal(float* w, long long n, float stddev, int truncated, unsigned long long seed,
                         unsigned int stream_id, hipStream_t s);
 

@@ -382,7 +382,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
     const int i0 = ti * BM, j0 = tj * BN;
     const int tap = blockIdx.z;
     const int ty = tap / p.KW, tx = tap - ty * p.KW;
-    const int dy = ty + p.tap_off, dx = tx + p.tap_off;
+    // p.batched: gridDim.z enumerates independent GEMMs (Winograd positions) with their own A / B / C slabs, no tap shift
+    const int dy = p.batched ? 0 : ty + p.tap_off, dx = p.batched ? 0 : tx + p.tap_off;
+    const float* __restrict__ Ap = p.batched ? p.A + (long long)tap * p.a_batch_stride : p.A;
+    const float* __restrict__ Bp = p.batched ? p.B + (long long)tap * p.b_batch_stride : p.B;
     const long long pbeg = (long long)blockIdx.y * chunk;
     const long long pend = (pbeg + chunk < p.P) ? pbeg + chunk : p.P;
     const int PaPb = p.Pa * p.Pb;
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
         for (int i = 0; i < B_LD; ++i) {
             const int f = tid + i * 256;
             const int pix = f / (BN / 4), c = (f - pix * (BN / 4)) * 4;
-            b_ptr[i] = p.B + (pbeg + pix) * p.ldb + j0 + c;
+            b_ptr[i] = Bp + (pbeg + pix) * p.ldb + j0 + c;
             b_left[i] = (int)(pend - (pbeg + pix));
         }
     }
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
             const int iy = s_a[i] * p.a_scale + dy, ix = s_b[i] * p.a_scale + dx;
             const bool ok = s_left[i] > 0 && (unsigned)iy < (unsigned)p.Ha && (unsigned)ix < (unsigned)p.Wa;
             const long long pixi = ok ? ((long long)s_n[i] * p.Ha + iy) * p.Wa + ix : 0;
-            ra[i] = ldg4(p.A + pixi * p.lda + i0 + c);
+            ra[i] = ldg4(Ap + pixi * p.lda + i0 + c);
             a_ldok[i] = ok;                        // select deferred to sstore
             s_left[i] -= BK;
             s_b[i] += BK;
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             const bool ok = b_left[i] > 0;
-            rb[i] = ldg4(ok ? b_ptr[i] : p.B);
+            rb[i] = ldg4(ok ? b_ptr[i] : Bp);
             b_ldok[i] = ok;
             b_ptr[i] += (long long)BK * p.ldb;
             b_left[i] -= BK;
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
                 ok = (unsigned)iy < (unsigned)p.Ha && (unsigned)ix < (unsigned)p.Wa;
                 off = (((long long)n * p.Ha + iy) * p.Wa + ix) * p.lda + i0 + c;
             }
-            ra[i] = ok ? ldg4(p.A + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[i] = ok ? ldg4(Ap + off) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
             const int pix = f / (BN / 4), c = (f - pix * (BN / 4)) * 4;
             const long long pp = pk + pix;
             const bool ok = (B_F4 % 256 == 0 || f < B_F4) && pp < pend && (j0 + c) < p.Bdim;
-            rb[i] = ok ? ldg4(p.B + pp * p.ldb + j0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = ok ? ldg4(Bp + pp * p.ldb + j0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto sstore = [&](int buf) {

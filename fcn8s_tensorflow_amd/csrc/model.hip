@@ -225,7 +225,9 @@ void conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
     if (m && K == 3 && m->wino_min_cin > 0 && Cin >= m->wino_min_cin && m->d_wino_v && Cin % 16 == 0 && Cout % 64 == 0 &&
         H % 2 == 0 && W % 2 == 0 && e.alpha == 1.f && !e.dropout && !real_cin) {
         const bool dgrad = strstr(group, "dgrad") != nullptr;
-        conv3x3_winograd(m, dgrad ? "wino_gemm_dgrad" : "wino_gemm_fwd", x, w, y, m->d_wino_u, m->d_wino_v, m->d_wino_m, N, H, W, Cin, Cout,
+        float* vbuf = m->d_wino_v;
+        if (!dgrad && layer) { auto it = m->acts.find(std::string("wv:") + layer); if (it != m->acts.end()) vbuf = it->second.p; }
+        conv3x3_winograd(m, dgrad ? "wino_gemm_dgrad" : "wino_gemm_fwd", x, w, y, m->d_wino_u, vbuf, m->d_wino_m, N, H, W, Cin, Cout,
                          e.bias, e.addend, e.mask, e.mask_scale, e.relu, s, layer);
         return;
     }
@@ -293,6 +295,26 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
     const double rc = a.Areal;
     const double flops = 2.0 * a.P * K * K * rc * Cout;
     const double bytes = 4.0 * (a.P * rc + (double)a.P * Cout + (double)K * K * rc * Cout);
+    if (m && K == 3 && layer && alpha == 1.f && !real_cin && m->train_mode) {
+        auto it = m->acts.find(std::string("wv:") + layer);
+        if (it != m->acts.end() && m->d_wino_m) {             // weight gradient in the Winograd domain (V kept by the forward pass)
+            const long long T = (long long)N * (H / 2) * (W / 2);
+            WgradArgs g{};
+            g.A = it->second.p; g.B = m->d_wino_m; g.C = m->d_wino_u;
+            g.N = 1; g.Pa = 1; g.Pb = (int)T; g.P = T;
+            g.Ha = 1; g.Wa = (int)T; g.Adim = Cin; g.lda = Cin; g.Areal = Cin;
+            g.Bdim = Cout; g.ldb = Cout; g.KW = 1; g.a_scale = 1; g.tap_off = 0; g.ntaps = 16; g.ldc = Cout; g.alpha = 1.f; g.colsum = nullptr;
+            g.batched = 1; g.a_batch_stride = T * Cin; g.b_batch_stride = T * Cout;
+            { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout + 16.0 * T * Cout));
+              launch_wino_dout(dz, m->d_wino_m, N, H, W, Cout, s);
+              hipMemsetAsync(m->d_wino_u, 0, 16 * (size_t)Cin * Cout * sizeof(float), s); }
+            { ProfScope ps(m, "wino_gemm_wgrad", 2.0 * 16.0 * T * Cin * Cout, 4.0 * 16.0 * (T * (double)(Cin + Cout) + (double)Cin * Cout), layer); launch_wgrad(g, s); }
+            { ProfScope ps(m, "wino_transform", 0, 4.0 * 25.0 * Cin * Cout + 4.0 * N * H * W * Cout);
+              launch_wino_dfilter(m->d_wino_u, dw, Cin, Cout, s);
+              if (db) launch_colsum(dz, db, (long long)N * H * W, Cout, s); }
+            return;
+        }
+    }
     const bool taps = (K == 3 || K == 7) && alpha == 1.f && !real_cin;
     const bool first = K == 3 && alpha == 1.f && real_cin == 3 && Cin == 4;
     auto run = [&]() {
@@ -375,6 +397,17 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
         }
         m->d_wino_v = m->d_wino_m = nullptr;
         if (vmax) { items.push_back({"wino_v", vmax, 0, 0, 0, &m->d_wino_v}); items.push_back({"wino_m", vmax, 0, 0, 0, &m->d_wino_m}); }
+        if (m->wino_min_cin > 0) {    // the forward pass keeps each Winograd layer's transformed input for the weight gradient
+            int cin = 3;
+            for (int b = 0, hh = H, ww = W; b < 5; ++b, hh /= 2, ww /= 2)
+                for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
+                    if (cin >= m->wino_min_cin && cin % 16 == 0 && m->widths[b] % 64 == 0 && hh % 2 == 0 && ww % 2 == 0) {
+                        char nm[40]; snprintf(nm, sizeof nm, "wv:conv%d_%d", b + 1, i);
+                        items.push_back({nm, (size_t)N * hh * ww * (size_t)cin * 4, 0, 0, 0, nullptr});
+                    }
+                    cin = m->widths[b];
+                }
+        }
     }
 
     size_t bytes = 0;

@@ -141,4 +141,67 @@ void launch_wino_output(const float* m, const float* bias, const float* addend, 
                        (const float4*)addend, (const float4*)mask, mask_scale, relu, (float4*)y, N, H, W, C / 4);
 }
 
+// ---- weight gradient in the Winograd domain --------------------------------------------------------------------
+//   Y = A^T M A  =>  dM = A dY A^T (4x4 from the 2x2 output-gradient tile);   dU[xi] = V[xi]^T dM[xi] (16 batched GEMMs
+//   over the tiles, V = the input transform kept from the forward pass);   U = G g G^T  =>  dg = G^T dU G.
+__global__ __launch_bounds__(256) void wino_dout_kernel(const float4* dy, float4* dm, int N, int H, int W, int C4)
+{
+    const int th = H / 2, tw = W / 2;
+    const long long T = (long long)N * th * tw, total = T * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const long long t = i / C4;
+        const int tx = (int)(t % tw); const long long r = t / tw;
+        const int ty = (int)(r % th); const int n = (int)(r / th);
+        const long long base = (((long long)n * H + 2 * ty) * W + 2 * tx) * C4 + c;
+        const float4 y00 = dy[base], y01 = dy[base + C4], y10 = dy[base + (long long)W * C4], y11 = dy[base + (long long)W * C4 + C4];
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 q[4][2];                            // q = A dY,  A = [1 0; 1 1; 1 -1; 0 -1]
+        q[0][0] = y00;             q[0][1] = y01;
+        q[1][0] = f4add(y00, y10); q[1][1] = f4add(y01, y11);
+        q[2][0] = f4sub(y00, y10); q[2][1] = f4sub(y01, y11);
+        q[3][0] = f4sub(z, y10);   q[3][1] = f4sub(z, y11);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {              // dM = q A^T
+            dm[((long long)(a * 4 + 0) * T + t) * C4 + c] = q[a][0];
+            dm[((long long)(a * 4 + 1) * T + t) * C4 + c] = f4add(q[a][0], q[a][1]);
+            dm[((long long)(a * 4 + 2) * T + t) * C4 + c] = f4sub(q[a][0], q[a][1]);
+            dm[((long long)(a * 4 + 3) * T + t) * C4 + c] = f4sub(z, q[a][1]);
+        }
+    }
+}
+void launch_wino_dout(const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s)
+{
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(wino_dout_kernel, dim3(wcap(total)), dim3(256), 0, s, (const float4*)dy, (float4*)dm, N, H, W, C / 4);
+}
+
+__global__ void wino_dfilter_kernel(const float* du, float* dw, int Cin, int Cout)
+{
+    const long long cc = (long long)Cin * Cout;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < cc; i += (long long)gridDim.x * blockDim.x) {
+        float u[4][4], t[3][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) u[a][b] = du[(a * 4 + b) * cc + i];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {              // t = G^T dU
+            t[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
+            t[1][b] = 0.5f * (u[1][b] - u[2][b]);
+            t[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {              // dg = t G
+            dw[(a * 3 + 0) * cc + i] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+            dw[(a * 3 + 1) * cc + i] = 0.5f * (t[a][1] - t[a][2]);
+            dw[(a * 3 + 2) * cc + i] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+        }
+    }
+}
+void launch_wino_dfilter(const float* du, float* dw, int Cin, int Cout, hipStream_t s)
+{
+    hipLaunchKernelGGL(wino_dfilter_kernel, dim3(wcap((long long)Cin * Cout)), dim3(256), 0, s, du, dw, Cin, Cout);
+}
+
 }  // namespace fcn8s
