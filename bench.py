@@ -163,8 +163,10 @@ def main():
             "config": {"workload": "FCN-8s (VGG-16, fc6 7x7, 20 classes) %s step, %dx%d, %d images/GPU, %s, keep_prob 0.5"
                                    % (args.mode, W, H, N, "TF-Adam" if args.optimizer == "adam" else "SGD+momentum"),
                        "global_batch": N * world, "parallelism": "dp%d" % world},
-            "step_tflops": round(gflop_img * N * world * args.steps / dt / 1e3, 2),
-            "step_frac_of_f32_peak": round(gflop_img * N * args.steps / dt / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+            # direct-convolution flop count per second; the Winograd layers execute 2.25-4x fewer
+            # multiplies than that count, so this "effective" rate may exceed the matrix-core peak
+            "effective_tflops_direct_conv_count": round(gflop_img * N * world * args.steps / dt / 1e3, 2),
+            "fp32_direct_conv_ceiling_images_per_sec_per_gpu": round(PEAK_F32_MFMA_TFLOPS * 1e3 / gflop_img, 1),
             "roofline": roof,
             "kernel_groups_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
             "kernel_groups_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0},

@@ -55,7 +55,8 @@ struct fcn8s_model {
     bool own_params = false, own_grads = false;
     float *d_w1pad = nullptr, *d_tph[3] = {nullptr, nullptr, nullptr};
     float *d_wino_u = nullptr, *d_wino_v = nullptr, *d_wino_m = nullptr;   // Winograd scratch: filters, transformed input / output
-    int wino_min_cin = 256;                                               // 3x3 layers with Cin >= this use Winograd F(2x2,3x3); 0 = never
+    int wino_min_cin = 64;                                              // 3x3 layers with Cin >= this use Winograd; 0 = never
+    int wino_tile = 4;                                                    // F(4x4,3x3) where H, W % 4 == 0, else F(2x2,3x3)
     hipStream_t stream = nullptr;
     int64_t step = 0;
     // workspace for the current (N,H,W)
@@ -188,14 +189,20 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
              float alpha = 1.f; int relu = 0; float mask_scale = 1.f; int dropout = 0; float keep = 1.f;
              uint32_t stream_id = 0; };
 
-// 3x3 SAME conv through Winograd F(2x2,3x3): filter transform, input transform, 16 batched GEMMs on the
-// matrix cores (2.25x fewer MFMA flops than the direct form), output transform + fused epilogue.
-// u: [16][Cin][Cout], v: [16][T][Cin], mm: [16][T][Cout] scratch, T = N*(H/2)*(W/2).
-void conv3x3_winograd(fcn8s_model* m, const char* tag, const float* x, const float* w9, float* y, float* u, float* v, float* mm,
+// 3x3 SAME conv through Winograd F(tile x tile, 3x3): filter transform, input transform, (tile+2)^2 batched GEMMs
+// on the matrix cores (2.25x / 4x fewer MFMA flops than the direct form), output transform + fused epilogue.
+// u: [P][Cin][Cout], v: [P][T][Cin], mm: [P][T][Cout] scratch, P = (tile+2)^2, T = N*(H/tile)*(W/tile).
+int wino_tile_for(const fcn8s_model* m, int H, int W)
+{
+    if (m && m->wino_tile == 4 && H % 4 == 0 && W % 4 == 0) return 4;
+    return (H % 2 == 0 && W % 2 == 0) ? 2 : 0;
+}
+void conv3x3_winograd(fcn8s_model* m, int tile, const char* tag, const float* x, const float* w9, float* y, float* u, float* v, float* mm,
                       int N, int H, int W, int Cin, int Cout, const float* bias, const float* addend, const float* mask,
                       float mask_scale, int relu, hipStream_t s, const char* layer)
 {
-    const long long T = (long long)N * (H / 2) * (W / 2);
+    const int P = (tile + 2) * (tile + 2);
+    const long long T = (long long)N * (H / tile) * (W / tile);
     IgemmArgs a{};
     a.x = v; a.w = u; a.y = mm;
     a.N = 1; a.Ma = (int)T; a.Mb = 1; a.M = T;
@@ -205,15 +212,15 @@ void conv3x3_winograd(fcn8s_model* m, const char* tag, const float* x, const flo
     a.out_scale = 1; a.phases_x = 1; a.w_phase_stride = (long long)Cin * Cout;
     a.alpha = 1.f; a.mask_scale = 1.f;
     a.batched = 1; a.x_batch_stride = T * Cin; a.y_batch_stride = T * Cout;
-    const double tb = 4.0 * ((double)N * H * W * Cin + 16.0 * T * Cin), ob = 4.0 * ((double)N * H * W * Cout + 16.0 * T * Cout);
+    const double tb = 4.0 * ((double)N * H * W * Cin + (double)P * T * Cin), ob = 4.0 * ((double)N * H * W * Cout + (double)P * T * Cout);
     if (m) {
-        { ProfScope ps(m, "wino_transform", 0, tb + 25.0 * 4 * Cin * Cout); launch_wino_filter(w9, u, Cin, Cout, s); launch_wino_input(x, v, N, H, W, Cin, s); }
-        { ProfScope ps(m, tag, 2.0 * 16.0 * T * Cin * Cout, 4.0 * 16.0 * (T * (double)(Cin + Cout) + (double)Cin * Cout), layer); launch_igemm(a, 16, s); }
-        { ProfScope ps(m, "wino_transform", 0, ob); launch_wino_output(mm, bias, addend, mask, mask_scale, relu, y, N, H, W, Cout, s); }
+        { ProfScope ps(m, "wino_transform", 0, tb + (9.0 + P) * 4 * Cin * Cout); launch_wino_filter(tile, w9, u, Cin, Cout, s); launch_wino_input(tile, x, v, N, H, W, Cin, s); }
+        { ProfScope ps(m, tag, 2.0 * P * T * Cin * Cout, 4.0 * P * (T * (double)(Cin + Cout) + (double)Cin * Cout), layer); launch_igemm(a, P, s); }
+        { ProfScope ps(m, "wino_transform", 0, ob); launch_wino_output(tile, mm, bias, addend, mask, mask_scale, relu, y, N, H, W, Cout, s); }
     } else {
-        launch_wino_filter(w9, u, Cin, Cout, s); launch_wino_input(x, v, N, H, W, Cin, s);
-        launch_igemm(a, 16, s);
-        launch_wino_output(mm, bias, addend, mask, mask_scale, relu, y, N, H, W, Cout, s);
+        launch_wino_filter(tile, w9, u, Cin, Cout, s); launch_wino_input(tile, x, v, N, H, W, Cin, s);
+        launch_igemm(a, P, s);
+        launch_wino_output(tile, mm, bias, addend, mask, mask_scale, relu, y, N, H, W, Cout, s);
     }
 }
 
@@ -223,11 +230,11 @@ void conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
                const char* layer = nullptr)
 {
     if (m && K == 3 && m->wino_min_cin > 0 && Cin >= m->wino_min_cin && m->d_wino_v && Cin % 16 == 0 && Cout % 64 == 0 &&
-        H % 2 == 0 && W % 2 == 0 && e.alpha == 1.f && !e.dropout && !real_cin) {
+        wino_tile_for(m, H, W) && e.alpha == 1.f && !e.dropout && !real_cin) {
         const bool dgrad = strstr(group, "dgrad") != nullptr;
         float* vbuf = m->d_wino_v;
         if (!dgrad && layer) { auto it = m->acts.find(std::string("wv:") + layer); if (it != m->acts.end()) vbuf = it->second.p; }
-        conv3x3_winograd(m, dgrad ? "wino_gemm_dgrad" : "wino_gemm_fwd", x, w, y, m->d_wino_u, vbuf, m->d_wino_m, N, H, W, Cin, Cout,
+        conv3x3_winograd(m, wino_tile_for(m, H, W), dgrad ? "wino_gemm_dgrad" : "wino_gemm_fwd", x, w, y, m->d_wino_u, vbuf, m->d_wino_m, N, H, W, Cin, Cout,
                          e.bias, e.addend, e.mask, e.mask_scale, e.relu, s, layer);
         return;
     }
@@ -298,19 +305,20 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
     if (m && K == 3 && layer && alpha == 1.f && !real_cin && m->train_mode) {
         auto it = m->acts.find(std::string("wv:") + layer);
         if (it != m->acts.end() && m->d_wino_m) {             // weight gradient in the Winograd domain (V kept by the forward pass)
-            const long long T = (long long)N * (H / 2) * (W / 2);
+            const int tile = wino_tile_for(m, H, W), NP = (tile + 2) * (tile + 2);
+            const long long T = (long long)N * (H / tile) * (W / tile);
             WgradArgs g{};
             g.A = it->second.p; g.B = m->d_wino_m; g.C = m->d_wino_u;
             g.N = 1; g.Pa = 1; g.Pb = (int)T; g.P = T;
             g.Ha = 1; g.Wa = (int)T; g.Adim = Cin; g.lda = Cin; g.Areal = Cin;
-            g.Bdim = Cout; g.ldb = Cout; g.KW = 1; g.a_scale = 1; g.tap_off = 0; g.ntaps = 16; g.ldc = Cout; g.alpha = 1.f; g.colsum = nullptr;
+            g.Bdim = Cout; g.ldb = Cout; g.KW = 1; g.a_scale = 1; g.tap_off = 0; g.ntaps = NP; g.ldc = Cout; g.alpha = 1.f; g.colsum = nullptr;
             g.batched = 1; g.a_batch_stride = T * Cin; g.b_batch_stride = T * Cout;
-            { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout + 16.0 * T * Cout));
-              launch_wino_dout(dz, m->d_wino_m, N, H, W, Cout, s);
-              hipMemsetAsync(m->d_wino_u, 0, 16 * (size_t)Cin * Cout * sizeof(float), s); }
-            { ProfScope ps(m, "wino_gemm_wgrad", 2.0 * 16.0 * T * Cin * Cout, 4.0 * 16.0 * (T * (double)(Cin + Cout) + (double)Cin * Cout), layer); launch_wgrad(g, s); }
-            { ProfScope ps(m, "wino_transform", 0, 4.0 * 25.0 * Cin * Cout + 4.0 * N * H * W * Cout);
-              launch_wino_dfilter(m->d_wino_u, dw, Cin, Cout, s);
+            { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout + (double)NP * T * Cout));
+              launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s);
+              hipMemsetAsync(m->d_wino_u, 0, (size_t)NP * Cin * Cout * sizeof(float), s); }
+            { ProfScope ps(m, "wino_gemm_wgrad", 2.0 * NP * T * Cin * Cout, 4.0 * NP * (T * (double)(Cin + Cout) + (double)Cin * Cout), layer); launch_wgrad(g, s); }
+            { ProfScope ps(m, "wino_transform", 0, 4.0 * (9.0 + NP) * Cin * Cout + 4.0 * N * H * W * Cout);
+              launch_wino_dfilter(tile, m->d_wino_u, dw, Cin, Cout, s);
               if (db) launch_colsum(dz, db, (long long)N * H * W, Cout, s); }
             return;
         }
@@ -734,7 +742,9 @@ int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
         const char* wm = getenv("FCN8S_WINOGRAD_MIN_CIN");          // tuning / A-B switch; 0 disables the Winograd path
         if (wm) m->wino_min_cin = atoi(wm);
         int cmax = 0; for (int i = 0; i < 5; ++i) cmax = std::max(cmax, m->widths[i]);
-        if ((e = hipMalloc((void**)&m->d_wino_u, 16 * (size_t)cmax * cmax * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+        const char* wt = getenv("FCN8S_WINOGRAD_TILE");             // 2 or 4 (A-B switch)
+        if (wt) m->wino_tile = atoi(wt) == 2 ? 2 : 4;
+        if ((e = hipMalloc((void**)&m->d_wino_u, 36 * (size_t)cmax * cmax * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     }
     if ((e = hipMalloc((void**)&m->d_loss, 2 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     m->d_regsum = m->d_loss + 1;
@@ -1113,15 +1123,16 @@ int fcn8s_op_conv2d(void* stream, const float* x, const float* w, const float* b
 }
 
 int fcn8s_op_conv2d_winograd(void* stream, const float* x, const float* w, const float* bias, float* y,
-                             int N, int H, int W, int Cin, int Cout, int relu)
+                             int N, int H, int W, int Cin, int Cout, int relu, int tile)
 {
-    if (Cin % 16 || Cout % 32 || H % 2 || W % 2) return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d_winograd: needs Cin % 16, Cout % 32, even H and W");
+    if ((tile != 2 && tile != 4) || Cin % 16 || Cout % 32 || H % tile || W % tile)
+        return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d_winograd: needs tile in {2,4}, Cin % 16, Cout % 32, H and W multiples of tile");
     hipStream_t s = (hipStream_t)stream;
-    const size_t T = (size_t)N * (H / 2) * (W / 2);
+    const size_t T = (size_t)N * (H / tile) * (W / tile), P = (size_t)(tile + 2) * (tile + 2);
     float *u = nullptr, *v = nullptr, *mm = nullptr;
-    if (hipMalloc((void**)&u, 16 * (size_t)Cin * Cout * 4) != hipSuccess || hipMalloc((void**)&v, 16 * T * Cin * 4) != hipSuccess ||
-        hipMalloc((void**)&mm, 16 * T * Cout * 4) != hipSuccess) return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc");
-    conv3x3_winograd(nullptr, "", x, w, y, u, v, mm, N, H, W, Cin, Cout, bias, nullptr, nullptr, 1.f, relu, s, nullptr);
+    if (hipMalloc((void**)&u, P * (size_t)Cin * Cout * 4) != hipSuccess || hipMalloc((void**)&v, P * T * Cin * 4) != hipSuccess ||
+        hipMalloc((void**)&mm, P * T * Cout * 4) != hipSuccess) return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc");
+    conv3x3_winograd(nullptr, tile, "", x, w, y, u, v, mm, N, H, W, Cin, Cout, bias, nullptr, nullptr, 1.f, relu, s, nullptr);
     hipStreamSynchronize(s); hipFree(u); hipFree(v); hipFree(mm);
     OPCHK(); return FCN8S_OK;
 }

@@ -1,10 +1,14 @@
-// Winograd F(2x2, 3x3) transforms (Lavin & Gray 2015, correlation form) around 16 batched GEMMs that run
-// on igemm_fwd_kernel (MFMA).
-//   Y = A^T [ (G g G^T) .* (B^T d B) ] A,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],
-//   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1].
-// 16 multiplies per 2x2 output tile and (ci, co) pair instead of 36.  The transforms are HBM-bound
-// element-wise kernels (16-byte accesses along the channel axis); they pay for themselves only where the
-// activations are small next to the arithmetic, i.e. in the deep, wide layers (conv3 .. conv5).
+// Winograd F(m x m, 3x3) transforms (Lavin & Gray 2015, correlation form), m = 2 or 4, around alpha^2 batched
+// GEMMs (alpha = m + 2) that run on igemm_fwd_kernel / wgrad_kernel (MFMA).
+//
+//   forward / data gradient : V = B^T d B,  U = G g G^T,  M[xi] = V[xi] U[xi] (GEMM over channels),  Y = A^T M A
+//   weight gradient         : dM = A dY A^T,  dU[xi] = V[xi]^T dM[xi] (GEMM over tiles),  dg = G^T dU G
+//
+// Multiplies per output pixel and (ci, co) pair: direct 9, F(2x2) 4, F(4x4) 2.25.  Bytes per transformed pixel:
+// F(2x2) 4x the tensor, F(4x4) 2.25x.  fp32 error against an fp64 direct conv (measured, ReLU data, K = 2304):
+// direct 2e-7, F(2x2) 5e-7, F(4x4) 7e-6 of the output range -- far inside the 1e-3 logit tolerance.
+// The transforms are HBM-bound element-wise kernels (16-byte accesses along the channel axis); they pay for
+// themselves where the activations are small next to the arithmetic, i.e. in the wide layers (conv3 .. conv5).
 #include "fcn8s_internal.h"
 
 namespace fcn8s {
@@ -15,113 +19,153 @@ static inline int wcap(long long work)
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
+template <int M> struct WinoMat;
+template <> struct WinoMat<2> {
+    static constexpr int A = 4;
+    static __device__ __forceinline__ float bt(int i, int j) { constexpr float m[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}}; return m[i][j]; }
+    static __device__ __forceinline__ float g(int i, int j) { constexpr float m[4][3] = {{1, 0, 0}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0, 0, 1}}; return m[i][j]; }
+    static __device__ __forceinline__ float at(int i, int j) { constexpr float m[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}}; return m[i][j]; }
+};
+template <> struct WinoMat<4> {
+    static constexpr int A = 6;
+    static __device__ __forceinline__ float bt(int i, int j)
+    {
+        constexpr float m[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                                   {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+        return m[i][j];
+    }
+    static __device__ __forceinline__ float g(int i, int j)
+    {
+        constexpr float m[6][3] = {{1.f / 4, 0, 0}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                                   {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0, 0, 1}};
+        return m[i][j];
+    }
+    static __device__ __forceinline__ float at(int i, int j)
+    {
+        constexpr float m[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+        return m[i][j];
+    }
+};
+
+static __device__ __forceinline__ float4 f4fma(float s, float4 a, float4 acc)
+{
+    return make_float4(fmaf(s, a.x, acc.x), fmaf(s, a.y, acc.y), fmaf(s, a.z, acc.z), fmaf(s, a.w, acc.w));
+}
+static __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ---- filters: u[xi][ci][co] = (G g G^T)[xi] ----------------------------------------------------------------------
+template <int M>
 __global__ void wino_filter_kernel(const float* w, float* u, int Cin, int Cout)
 {
+    constexpr int A = WinoMat<M>::A;
     const long long cc = (long long)Cin * Cout;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < cc; i += (long long)gridDim.x * blockDim.x) {
-        float g[3][3], t[4][3];
+        float g[3][3], t[A][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b) g[a][b] = w[(a * 3 + b) * cc + i];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {            // t = G g
-            t[0][b] = g[0][b];
-            t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
-            t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
-            t[3][b] = g[2][b];
-        }
+        for (int a = 0; a < A; ++a)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {            // u = t G^T
-            u[(a * 4 + 0) * cc + i] = t[a][0];
-            u[(a * 4 + 1) * cc + i] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
-            u[(a * 4 + 2) * cc + i] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
-            u[(a * 4 + 3) * cc + i] = t[a][2];
-        }
+            for (int b = 0; b < 3; ++b) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s = fmaf(WinoMat<M>::g(a, k), g[k][b], s);
+                t[a][b] = s;
+            }
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+#pragma unroll
+            for (int b = 0; b < A; ++b) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s = fmaf(t[a][k], WinoMat<M>::g(b, k), s);
+                u[(a * A + b) * cc + i] = s;
+            }
     }
 }
-void launch_wino_filter(const float* w, float* u, int Cin, int Cout, hipStream_t s)
-{
-    hipLaunchKernelGGL(wino_filter_kernel, dim3(wcap((long long)Cin * Cout)), dim3(256), 0, s, w, u, Cin, Cout);
-}
 
-static __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-static __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-
-// one thread = one 2x2 output tile x 4 channels: loads the 4x4 input patch (zero outside), V = B^T d B
+// ---- input: one thread = one m x m output tile x 4 channels; alpha x alpha patch (zero outside), V = B^T d B --------
+template <int M>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float4* x, float4* v, int N, int H, int W, int C4)
 {
-    const int th = H / 2, tw = W / 2;
+    constexpr int A = WinoMat<M>::A;
+    const int th = H / M, tw = W / M;
     const long long T = (long long)N * th * tw, total = T * C4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
         const long long t = i / C4;
         const int tx = (int)(t % tw); const long long r = t / tw;
         const int ty = (int)(r % th); const int n = (int)(r / th);
-        float4 d[4][4];
+        float4 q[A][A];                            // q = B^T d, built column by column so that d is never fully live
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int iy = 2 * ty - 1 + a;
+        for (int b = 0; b < A; ++b) {
+            const int ix = M * tx - 1 + b;
+            float4 d[A];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int ix = 2 * tx - 1 + b;
-                d[a][b] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                              ? x[(((long long)n * H + iy) * W + ix) * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int a = 0; a < A; ++a) {
+                const int iy = M * ty - 1 + a;
+                d[a] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                           ? x[(((long long)n * H + iy) * W + ix) * C4 + c] : f4zero();
+            }
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                float4 s = f4zero();
+#pragma unroll
+                for (int k = 0; k < A; ++k) if (WinoMat<M>::bt(a, k) != 0.f) s = f4fma(WinoMat<M>::bt(a, k), d[k], s);
+                q[a][b] = s;
             }
         }
-        float4 q[4][4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {            // q = B^T d
-            q[0][b] = f4sub(d[0][b], d[2][b]);
-            q[1][b] = f4add(d[1][b], d[2][b]);
-            q[2][b] = f4sub(d[2][b], d[1][b]);
-            q[3][b] = f4sub(d[1][b], d[3][b]);
-        }
+        for (int a = 0; a < A; ++a)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {            // V = q B
-            v[((long long)(a * 4 + 0) * T + t) * C4 + c] = f4sub(q[a][0], q[a][2]);
-            v[((long long)(a * 4 + 1) * T + t) * C4 + c] = f4add(q[a][1], q[a][2]);
-            v[((long long)(a * 4 + 2) * T + t) * C4 + c] = f4sub(q[a][2], q[a][1]);
-            v[((long long)(a * 4 + 3) * T + t) * C4 + c] = f4sub(q[a][1], q[a][3]);
-        }
+            for (int b = 0; b < A; ++b) {          // V = q B
+                float4 s = f4zero();
+#pragma unroll
+                for (int k = 0; k < A; ++k) if (WinoMat<M>::bt(b, k) != 0.f) s = f4fma(WinoMat<M>::bt(b, k), q[a][k], s);
+                v[((long long)(a * A + b) * T + t) * C4 + c] = s;
+            }
     }
 }
-void launch_wino_input(const float* x, float* v, int N, int H, int W, int C, hipStream_t s)
-{
-    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(wino_input_kernel, dim3(wcap(total)), dim3(256), 0, s, (const float4*)x, (float4*)v, N, H, W, C / 4);
-}
 
-// one thread = one tile x 4 channels: Y = A^T M A, then the conv epilogue (bias, skip add, ReLU / ReLU-mask)
+// ---- output: one thread = one tile x 4 channels; Y = A^T M A, then the conv epilogue --------------------------------
+template <int M>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float4* m, const float4* bias, const float4* addend, const float4* mask,
                                                           float mask_scale, int relu, float4* y, int N, int H, int W, int C4)
 {
-    const int th = H / 2, tw = W / 2;
+    constexpr int A = WinoMat<M>::A;
+    const int th = H / M, tw = W / M;
     const long long T = (long long)N * th * tw, total = T * C4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
         const long long t = i / C4;
         const int tx = (int)(t % tw); const long long r = t / tw;
         const int ty = (int)(r % th); const int n = (int)(r / th);
-        float4 q[2][4];
+        float4 q[M][A];                            // q = A^T M, column by column
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {            // q = A^T M
-            const float4 m0 = m[((long long)(0 * 4 + b) * T + t) * C4 + c], m1 = m[((long long)(1 * 4 + b) * T + t) * C4 + c];
-            const float4 m2 = m[((long long)(2 * 4 + b) * T + t) * C4 + c], m3 = m[((long long)(3 * 4 + b) * T + t) * C4 + c];
-            q[0][b] = f4add(f4add(m0, m1), m2);
-            q[1][b] = f4sub(f4sub(m1, m2), m3);
+        for (int b = 0; b < A; ++b) {
+            float4 col[A];
+#pragma unroll
+            for (int a = 0; a < A; ++a) col[a] = m[((long long)(a * A + b) * T + t) * C4 + c];
+#pragma unroll
+            for (int o = 0; o < M; ++o) {
+                float4 s = f4zero();
+#pragma unroll
+                for (int k = 0; k < A; ++k) if (WinoMat<M>::at(o, k) != 0.f) s = f4fma(WinoMat<M>::at(o, k), col[k], s);
+                q[o][b] = s;
+            }
         }
-        const float4 bv = bias ? bias[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 bv = bias ? bias[c] : f4zero();
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            float4 o[2];
-            o[0] = f4add(f4add(q[a][0], q[a][1]), q[a][2]);
-            o[1] = f4sub(f4sub(q[a][1], q[a][2]), q[a][3]);
+        for (int oy = 0; oy < M; ++oy)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const long long off = (((long long)n * H + 2 * ty + a) * W + 2 * tx + b) * C4 + c;
-                float4 v = f4add(o[b], bv);
-                if (addend) v = f4add(v, addend[off]);
+            for (int ox = 0; ox < M; ++ox) {
+                float4 v = bv;
+#pragma unroll
+                for (int k = 0; k < A; ++k) if (WinoMat<M>::at(ox, k) != 0.f) v = f4fma(WinoMat<M>::at(ox, k), q[oy][k], v);
+                const long long off = (((long long)n * H + M * ty + oy) * W + M * tx + ox) * C4 + c;
+                if (addend) { const float4 ad = addend[off]; v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w; }
                 if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (mask) {
                     const float4 k = mask[off];
@@ -130,78 +174,113 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* m, const
                 }
                 y[off] = v;
             }
-        }
     }
 }
-void launch_wino_output(const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
-                        int relu, float* y, int N, int H, int W, int C, hipStream_t s)
-{
-    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(wino_output_kernel, dim3(wcap(total)), dim3(256), 0, s, (const float4*)m, (const float4*)bias,
-                       (const float4*)addend, (const float4*)mask, mask_scale, relu, (float4*)y, N, H, W, C / 4);
-}
 
-// ---- weight gradient in the Winograd domain --------------------------------------------------------------------
-//   Y = A^T M A  =>  dM = A dY A^T (4x4 from the 2x2 output-gradient tile);   dU[xi] = V[xi]^T dM[xi] (16 batched GEMMs
-//   over the tiles, V = the input transform kept from the forward pass);   U = G g G^T  =>  dg = G^T dU G.
+// ---- weight gradient: dM = A dY A^T (alpha x alpha from the m x m output-gradient tile) ------------------------------
+template <int M>
 __global__ __launch_bounds__(256) void wino_dout_kernel(const float4* dy, float4* dm, int N, int H, int W, int C4)
 {
-    const int th = H / 2, tw = W / 2;
+    constexpr int A = WinoMat<M>::A;
+    const int th = H / M, tw = W / M;
     const long long T = (long long)N * th * tw, total = T * C4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
         const long long t = i / C4;
         const int tx = (int)(t % tw); const long long r = t / tw;
         const int ty = (int)(r % th); const int n = (int)(r / th);
-        const long long base = (((long long)n * H + 2 * ty) * W + 2 * tx) * C4 + c;
-        const float4 y00 = dy[base], y01 = dy[base + C4], y10 = dy[base + (long long)W * C4], y11 = dy[base + (long long)W * C4 + C4];
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 q[4][2];                            // q = A dY,  A = [1 0; 1 1; 1 -1; 0 -1]
-        q[0][0] = y00;             q[0][1] = y01;
-        q[1][0] = f4add(y00, y10); q[1][1] = f4add(y01, y11);
-        q[2][0] = f4sub(y00, y10); q[2][1] = f4sub(y01, y11);
-        q[3][0] = f4sub(z, y10);   q[3][1] = f4sub(z, y11);
+        float4 q[A][M];                            // q = A dY  (A = (A^T)^T)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {              // dM = q A^T
-            dm[((long long)(a * 4 + 0) * T + t) * C4 + c] = q[a][0];
-            dm[((long long)(a * 4 + 1) * T + t) * C4 + c] = f4add(q[a][0], q[a][1]);
-            dm[((long long)(a * 4 + 2) * T + t) * C4 + c] = f4sub(q[a][0], q[a][1]);
-            dm[((long long)(a * 4 + 3) * T + t) * C4 + c] = f4sub(z, q[a][1]);
+        for (int ox = 0; ox < M; ++ox) {
+            float4 col[M];
+#pragma unroll
+            for (int oy = 0; oy < M; ++oy) col[oy] = dy[(((long long)n * H + M * ty + oy) * W + M * tx + ox) * C4 + c];
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                float4 s = f4zero();
+#pragma unroll
+                for (int k = 0; k < M; ++k) if (WinoMat<M>::at(k, a) != 0.f) s = f4fma(WinoMat<M>::at(k, a), col[k], s);
+                q[a][ox] = s;
+            }
         }
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+#pragma unroll
+            for (int b = 0; b < A; ++b) {          // dM = q A^T
+                float4 s = f4zero();
+#pragma unroll
+                for (int k = 0; k < M; ++k) if (WinoMat<M>::at(k, b) != 0.f) s = f4fma(WinoMat<M>::at(k, b), q[a][k], s);
+                dm[((long long)(a * A + b) * T + t) * C4 + c] = s;
+            }
     }
-}
-void launch_wino_dout(const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s)
-{
-    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(wino_dout_kernel, dim3(wcap(total)), dim3(256), 0, s, (const float4*)dy, (float4*)dm, N, H, W, C / 4);
 }
 
+// ---- dg = G^T dU G ------------------------------------------------------------------------------------------------------
+template <int M>
 __global__ void wino_dfilter_kernel(const float* du, float* dw, int Cin, int Cout)
 {
+    constexpr int A = WinoMat<M>::A;
     const long long cc = (long long)Cin * Cout;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < cc; i += (long long)gridDim.x * blockDim.x) {
-        float u[4][4], t[3][4];
+        float t[3][A];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < A; ++b) {
+            float col[A];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) u[a][b] = du[(a * 4 + b) * cc + i];
+            for (int a = 0; a < A; ++a) col[a] = du[(a * A + b) * cc + i];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {              // t = G^T dU
-            t[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
-            t[1][b] = 0.5f * (u[1][b] - u[2][b]);
-            t[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+            for (int r = 0; r < 3; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < A; ++k) s = fmaf(WinoMat<M>::g(k, r), col[k], s);
+                t[r][b] = s;
+            }
         }
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {              // dg = t G
-            dw[(a * 3 + 0) * cc + i] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
-            dw[(a * 3 + 1) * cc + i] = 0.5f * (t[a][1] - t[a][2]);
-            dw[(a * 3 + 2) * cc + i] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
-        }
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < A; ++k) s = fmaf(t[r][k], WinoMat<M>::g(k, q), s);
+                dw[(r * 3 + q) * cc + i] = s;
+            }
     }
 }
-void launch_wino_dfilter(const float* du, float* dw, int Cin, int Cout, hipStream_t s)
+
+// ---- launchers (tile = 2 or 4) ------------------------------------------------------------------------------------------
+void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, hipStream_t s)
 {
-    hipLaunchKernelGGL(wino_dfilter_kernel, dim3(wcap((long long)Cin * Cout)), dim3(256), 0, s, du, dw, Cin, Cout);
+    const int g = wcap((long long)Cin * Cout);
+    if (tile == 4) hipLaunchKernelGGL(wino_filter_kernel<4>, dim3(g), dim3(256), 0, s, w, u, Cin, Cout);
+    else           hipLaunchKernelGGL(wino_filter_kernel<2>, dim3(g), dim3(256), 0, s, w, u, Cin, Cout);
+}
+void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, hipStream_t s)
+{
+    const int g = wcap((long long)N * (H / tile) * (W / tile) * (C / 4));
+    if (tile == 4) hipLaunchKernelGGL(wino_input_kernel<4>, dim3(g), dim3(256), 0, s, (const float4*)x, (float4*)v, N, H, W, C / 4);
+    else           hipLaunchKernelGGL(wino_input_kernel<2>, dim3(g), dim3(256), 0, s, (const float4*)x, (float4*)v, N, H, W, C / 4);
+}
+void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
+                        int relu, float* y, int N, int H, int W, int C, hipStream_t s)
+{
+    const int g = wcap((long long)N * (H / tile) * (W / tile) * (C / 4));
+    if (tile == 4) hipLaunchKernelGGL(wino_output_kernel<4>, dim3(g), dim3(256), 0, s, (const float4*)m, (const float4*)bias, (const float4*)addend,
+                                      (const float4*)mask, mask_scale, relu, (float4*)y, N, H, W, C / 4);
+    else           hipLaunchKernelGGL(wino_output_kernel<2>, dim3(g), dim3(256), 0, s, (const float4*)m, (const float4*)bias, (const float4*)addend,
+                                      (const float4*)mask, mask_scale, relu, (float4*)y, N, H, W, C / 4);
+}
+void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s)
+{
+    const int g = wcap((long long)N * (H / tile) * (W / tile) * (C / 4));
+    if (tile == 4) hipLaunchKernelGGL(wino_dout_kernel<4>, dim3(g), dim3(256), 0, s, (const float4*)dy, (float4*)dm, N, H, W, C / 4);
+    else           hipLaunchKernelGGL(wino_dout_kernel<2>, dim3(g), dim3(256), 0, s, (const float4*)dy, (float4*)dm, N, H, W, C / 4);
+}
+void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, hipStream_t s)
+{
+    const int g = wcap((long long)Cin * Cout);
+    if (tile == 4) hipLaunchKernelGGL(wino_dfilter_kernel<4>, dim3(g), dim3(256), 0, s, du, dw, Cin, Cout);
+    else           hipLaunchKernelGGL(wino_dfilter_kernel<2>, dim3(g), dim3(256), 0, s, du, dw, Cin, Cout);
 }
 
 }  // namespace fcn8s

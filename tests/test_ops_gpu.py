@@ -75,8 +75,9 @@ def test_conv2d_fwd_bwd(N, H, W, Cin, Cout, K):
     assert rel_err(y_.cpu().numpy(), np.maximum(y_ref, 0)) < 2e-5
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(1, 4, 6, 16, 32), (2, 8, 16, 64, 128), (1, 16, 32, 256, 256), (3, 2, 2, 32, 64)])
-def test_conv3x3_winograd(N, H, W, Cin, Cout):
+@pytest.mark.parametrize("N,H,W,Cin,Cout,tile", [(1, 4, 6, 16, 32, 2), (2, 8, 16, 64, 128, 2), (1, 16, 32, 256, 256, 2), (3, 2, 2, 32, 64, 2),
+                                                  (1, 4, 8, 16, 32, 4), (2, 8, 16, 64, 128, 4), (1, 16, 32, 256, 256, 4), (2, 4, 4, 512, 64, 4)])
+def test_conv3x3_winograd(N, H, W, Cin, Cout, tile):
     """Winograd F(2x2,3x3) path (filter/input transforms, 16 batched MFMA GEMMs, output transform + bias + ReLU)."""
     L = _lib()
     rng = np.random.default_rng(11)
@@ -87,13 +88,14 @@ def test_conv3x3_winograd(N, H, W, Cin, Cout):
     ref = ref.permute(0, 2, 3, 1).numpy()
     xd, wd, bd = dev(x), dev(w), dev(b)
     y_ = torch.empty(N, H, W, Cout).cuda()
-    L.check(L.lib.fcn8s_op_conv2d_winograd(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), N, H, W, Cin, Cout, 1))
+    L.check(L.lib.fcn8s_op_conv2d_winograd(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), N, H, W, Cin, Cout, 1, tile))
     torch.cuda.synchronize()
-    assert rel_err(y_.cpu().numpy(), ref) < 1e-5
+    tol = 1e-5 if tile == 2 else 1e-4          # fp32 F(4x4,3x3) carries ~1e-5 of the output range (winograd.hip header)
+    assert rel_err(y_.cpu().numpy(), ref) < tol
     yd = torch.empty(N, H, W, Cout).cuda()
     L.check(L.lib.fcn8s_op_conv2d(None, ptr(xd), ptr(wd), ptr(bd), ptr(yd), N, H, W, Cin, Cout, 3, 1))
     torch.cuda.synchronize()
-    assert rel_err(y_.cpu().numpy(), yd.cpu().numpy()) < 1e-5      # and against the direct kernel
+    assert rel_err(y_.cpu().numpy(), yd.cpu().numpy()) < tol       # and against the direct kernel
 
 
 @pytest.mark.parametrize("N,H,W,C", [(2, 8, 8, 64), (1, 4, 6, 8), (1, 32, 64, 128)])
