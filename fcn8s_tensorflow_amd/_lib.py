@@ -72,7 +72,7 @@ SIGNATURES = {
     "fcn8s_profile_get": (_i, [_p, _i, C.POINTER(C.c_char_p), _dp, _i64p, _dp, _dp]),
     "fcn8s_op_preprocess": (_i, [_p, _p, _i, _p, _i64]),
     "fcn8s_op_conv2d": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
-    "fcn8s_op_conv2d_winograd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
+    "fcn8s_op_conv2d_winograd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_conv2d_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_maxpool2x2": (_i, [_p, _p, _p, _i, _i, _i, _i]),
     "fcn8s_op_maxpool2x2_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i]),

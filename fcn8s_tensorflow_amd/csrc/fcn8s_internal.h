@@ -98,13 +98,16 @@ void launch_pad_cin(const float* w, float* w4, int taps, int Cin, int Cinp, int 
 void launch_tconv_phase_pack(const float* w, float* wp, int K, int S, int C, hipStream_t s);
 void launch_dropout_mask(float* mask, long long n, float keep_prob, unsigned long long seed,
                          unsigned int stream_id, hipStream_t s);
-// Winograd F(tile x tile, 3x3) transforms (tile = 2 or 4) around (tile+2)^2 batched GEMMs; H, W % tile == 0, C % 4 == 0
-void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, hipStream_t s);         // w[9][Cin][Cout] -> u[P][Cin][Cout]
-void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, hipStream_t s);   // x[N,H,W,C] -> v[P][T][C]
+// Winograd F(tile x tile, 3x3) transforms (tile = 2 or 4) around P = (tile+2)^2 batched GEMMs; H, W % tile == 0, C % 4 == 0.
+// KS = 3: plain 3x3 conv.  KS = 7: the filter is cut into a 3x3 grid of 3x3 sub-filters whose products add up in the
+// Winograd domain (GEMM depth 9*C); u / v rows are then [sub][channel].
+void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, int KS, hipStream_t s);         // w[KS*KS][Cin][Cout] -> u[P][nsub*Cin][Cout]
+void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, int KS, hipStream_t s);   // x[N,H,W,C] -> v[P][T][nsub*C]
 void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
-                        int relu, float* y, int N, int H, int W, int C, hipStream_t s);                 // m[P][T][C] -> y[N,H,W,C]
-void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s);  // dy -> dm[P][T][C] = A dY A^T
-void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, hipStream_t s);        // du[P][Cin][Cout] -> dw[9][Cin][Cout]
+                        int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,
+                        unsigned int stream_id, hipStream_t s);                                                 // m[P][T][C] -> y[N,H,W,C]
+void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s);          // dy -> dm[P][T][C] = A dY A^T
+void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, int KS, hipStream_t s);        // du[P][nsub*Cin][Cout] -> dw[KS*KS][Cin][Cout]
 void launch_init_normal(float* w, long long n, float stddev, int truncated, unsigned long long seed,
                         unsigned int stream_id, hipStream_t s);
 

@@ -335,7 +335,11 @@ static void launch_igemm_cfg(const IgemmArgs& a, int phases, hipStream_t s)
     if (mode == 1 && !a.relu && !a.mask && !a.dropout && !a.addend && a.out_scale == 1 && a.ldy == a.Cout &&
         grid.x < 512 && a.Ktot / BKF >= 512) {
         unsigned ks = 1024 / grid.x; if (ks > 8) ks = 8;
-        if (ks >= 2) { grid.y = ks; hipMemsetAsync(a.y, 0, (size_t)a.M * a.Cout * sizeof(float), s); }
+        if (ks >= 2) {
+            grid.y = ks;
+            const size_t nfl = a.batched ? (size_t)(phases - 1) * a.y_batch_stride + (size_t)a.M * a.Cout : (size_t)a.M * a.Cout;
+            hipMemsetAsync(a.y, 0, nfl * sizeof(float), s);        // every slab of a batched launch
+        }
     }
     if (mode == 2)      hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 2, BKF>), grid, dim3(256), 0, s, a);
     else if (mode == 1) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 1, BKF>), grid, dim3(256), 0, s, a);

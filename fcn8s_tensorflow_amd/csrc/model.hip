@@ -57,6 +57,7 @@ struct fcn8s_model {
     float *d_wino_u = nullptr, *d_wino_v = nullptr, *d_wino_m = nullptr;   // Winograd scratch: filters, transformed input / output
     int wino_min_cin = 64;                                              // 3x3 layers with Cin >= this use Winograd; 0 = never
     int wino_tile = 4;                                                    // F(4x4,3x3) where H, W % 4 == 0, else F(2x2,3x3)
+    int wino_fc6 = 1;                                                     // fc6 7x7 as nine 3x3 sub-filters in the Winograd domain
     hipStream_t stream = nullptr;
     int64_t step = 0;
     // workspace for the current (N,H,W)
@@ -197,31 +198,32 @@ int wino_tile_for(const fcn8s_model* m, int H, int W)
     if (m && m->wino_tile == 4 && H % 4 == 0 && W % 4 == 0) return 4;
     return (H % 2 == 0 && W % 2 == 0) ? 2 : 0;
 }
-void conv3x3_winograd(fcn8s_model* m, int tile, const char* tag, const float* x, const float* w9, float* y, float* u, float* v, float* mm,
-                      int N, int H, int W, int Cin, int Cout, const float* bias, const float* addend, const float* mask,
-                      float mask_scale, int relu, hipStream_t s, const char* layer)
+struct WinoEpi { const float* bias = nullptr; const float* addend = nullptr; const float* mask = nullptr; float mask_scale = 1.f;
+                 int relu = 0; int dropout = 0; float keep = 1.f; unsigned long long seed = 0; unsigned int stream_id = 0; };
+// KS = 3, or 7 (3x3 grid of 3x3 sub-filters, GEMM depth 9*Cin -- see winograd.hip)
+void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const float* x, const float* wk, float* y, float* u, float* v, float* mm,
+                   int N, int H, int W, int Cin, int Cout, const WinoEpi& e, hipStream_t s, const char* layer)
 {
-    const int P = (tile + 2) * (tile + 2);
+    const int P = (tile + 2) * (tile + 2), nsub2 = KS == 3 ? 1 : 9;
     const long long T = (long long)N * (H / tile) * (W / tile);
+    const int Kg = nsub2 * Cin;
     IgemmArgs a{};
     a.x = v; a.w = u; a.y = mm;
     a.N = 1; a.Ma = (int)T; a.Mb = 1; a.M = T;
-    a.Hi = (int)T; a.Wi = 1; a.Cin = Cin; a.ldx = Cin;
-    a.KW = 1; a.in_scale = 1; a.tap_step = 1; a.tap_off = 0; a.Ktot = Cin;
+    a.Hi = (int)T; a.Wi = 1; a.Cin = Kg; a.ldx = Kg;
+    a.KW = 1; a.in_scale = 1; a.tap_step = 1; a.tap_off = 0; a.Ktot = Kg;
     a.Ho = (int)T; a.Wo = 1; a.Cout = Cout; a.ldy = Cout;
-    a.out_scale = 1; a.phases_x = 1; a.w_phase_stride = (long long)Cin * Cout;
+    a.out_scale = 1; a.phases_x = 1; a.w_phase_stride = (long long)Kg * Cout;
     a.alpha = 1.f; a.mask_scale = 1.f;
-    a.batched = 1; a.x_batch_stride = T * Cin; a.y_batch_stride = T * Cout;
-    const double tb = 4.0 * ((double)N * H * W * Cin + (double)P * T * Cin), ob = 4.0 * ((double)N * H * W * Cout + (double)P * T * Cout);
+    a.batched = 1; a.x_batch_stride = T * Kg; a.y_batch_stride = T * Cout;
+    const double tb = 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg), ob = 4.0 * ((double)N * H * W * Cout + (double)P * T * Cout);
+    auto pre = [&]() { launch_wino_filter(tile, wk, u, Cin, Cout, KS, s); launch_wino_input(tile, x, v, N, H, W, Cin, KS, s); };
+    auto post = [&]() { launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s); };
     if (m) {
-        { ProfScope ps(m, "wino_transform", 0, tb + (9.0 + P) * 4 * Cin * Cout); launch_wino_filter(tile, w9, u, Cin, Cout, s); launch_wino_input(tile, x, v, N, H, W, Cin, s); }
-        { ProfScope ps(m, tag, 2.0 * P * T * Cin * Cout, 4.0 * P * (T * (double)(Cin + Cout) + (double)Cin * Cout), layer); launch_igemm(a, P, s); }
-        { ProfScope ps(m, "wino_transform", 0, ob); launch_wino_output(tile, mm, bias, addend, mask, mask_scale, relu, y, N, H, W, Cout, s); }
-    } else {
-        launch_wino_filter(tile, w9, u, Cin, Cout, s); launch_wino_input(tile, x, v, N, H, W, Cin, s);
-        launch_igemm(a, P, s);
-        launch_wino_output(tile, mm, bias, addend, mask, mask_scale, relu, y, N, H, W, Cout, s);
-    }
+        { ProfScope ps(m, "wino_transform", 0, tb + (double)(KS * KS + P * nsub2) * 4 * Cin * Cout); pre(); }
+        { ProfScope ps(m, tag, 2.0 * P * T * Kg * Cout, 4.0 * P * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_igemm(a, P, s); }
+        { ProfScope ps(m, "wino_transform", 0, ob); post(); }
+    } else { pre(); launch_igemm(a, P, s); post(); }
 }
 
 // SAME conv (or its data gradient when `w` holds flipped+transposed weights)
@@ -229,13 +231,16 @@ void conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
                int N, int H, int W, int Cin, int Cout, int K, const Epi& e, hipStream_t s, int real_cin = 0,
                const char* layer = nullptr)
 {
-    if (m && K == 3 && m->wino_min_cin > 0 && Cin >= m->wino_min_cin && m->d_wino_v && Cin % 16 == 0 && Cout % 64 == 0 &&
-        wino_tile_for(m, H, W) && e.alpha == 1.f && !e.dropout && !real_cin) {
+    const bool wino3 = m && K == 3 && m->wino_min_cin > 0 && Cin >= m->wino_min_cin && m->d_wino_v && wino_tile_for(m, H, W) && !e.dropout;
+    const bool wino7 = m && K == 7 && m->wino_fc6 && m->d_wino_v && wino_tile_for(m, H, W) == 4;
+    if ((wino3 || wino7) && Cin % 16 == 0 && Cout % 64 == 0 && e.alpha == 1.f && !real_cin) {
         const bool dgrad = strstr(group, "dgrad") != nullptr;
         float* vbuf = m->d_wino_v;
         if (!dgrad && layer) { auto it = m->acts.find(std::string("wv:") + layer); if (it != m->acts.end()) vbuf = it->second.p; }
-        conv3x3_winograd(m, wino_tile_for(m, H, W), dgrad ? "wino_gemm_dgrad" : "wino_gemm_fwd", x, w, y, m->d_wino_u, vbuf, m->d_wino_m, N, H, W, Cin, Cout,
-                         e.bias, e.addend, e.mask, e.mask_scale, e.relu, s, layer);
+        WinoEpi we; we.bias = e.bias; we.addend = e.addend; we.mask = e.mask; we.mask_scale = e.mask_scale; we.relu = e.relu;
+        we.dropout = e.dropout; we.keep = e.keep; we.seed = m->seed; we.stream_id = e.stream_id;
+        const char* tag = K == 7 ? (dgrad ? "wino_gemm_fc6_dgrad" : "wino_gemm_fc6_fwd") : (dgrad ? "wino_gemm_dgrad" : "wino_gemm_fwd");
+        conv_winograd(m, wino_tile_for(m, H, W), K, tag, x, w, y, m->d_wino_u, vbuf, m->d_wino_m, N, H, W, Cin, Cout, we, s, layer);
         return;
     }
     IgemmArgs a{};
@@ -302,23 +307,24 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
     const double rc = a.Areal;
     const double flops = 2.0 * a.P * K * K * rc * Cout;
     const double bytes = 4.0 * (a.P * rc + (double)a.P * Cout + (double)K * K * rc * Cout);
-    if (m && K == 3 && layer && alpha == 1.f && !real_cin && m->train_mode) {
+    if (m && (K == 3 || K == 7) && layer && alpha == 1.f && !real_cin && m->train_mode) {
         auto it = m->acts.find(std::string("wv:") + layer);
         if (it != m->acts.end() && m->d_wino_m) {             // weight gradient in the Winograd domain (V kept by the forward pass)
             const int tile = wino_tile_for(m, H, W), NP = (tile + 2) * (tile + 2);
             const long long T = (long long)N * (H / tile) * (W / tile);
+            const int Kg = (K == 3 ? 1 : 9) * Cin;                      // rows of V / dU: [sub-filter][channel]
             WgradArgs g{};
             g.A = it->second.p; g.B = m->d_wino_m; g.C = m->d_wino_u;
             g.N = 1; g.Pa = 1; g.Pb = (int)T; g.P = T;
-            g.Ha = 1; g.Wa = (int)T; g.Adim = Cin; g.lda = Cin; g.Areal = Cin;
+            g.Ha = 1; g.Wa = (int)T; g.Adim = Kg; g.lda = Kg; g.Areal = Kg;
             g.Bdim = Cout; g.ldb = Cout; g.KW = 1; g.a_scale = 1; g.tap_off = 0; g.ntaps = NP; g.ldc = Cout; g.alpha = 1.f; g.colsum = nullptr;
-            g.batched = 1; g.a_batch_stride = T * Cin; g.b_batch_stride = T * Cout;
+            g.batched = 1; g.a_batch_stride = T * Kg; g.b_batch_stride = T * Cout;
             { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout + (double)NP * T * Cout));
               launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s);
-              hipMemsetAsync(m->d_wino_u, 0, (size_t)NP * Cin * Cout * sizeof(float), s); }
-            { ProfScope ps(m, "wino_gemm_wgrad", 2.0 * NP * T * Cin * Cout, 4.0 * NP * (T * (double)(Cin + Cout) + (double)Cin * Cout), layer); launch_wgrad(g, s); }
+              hipMemsetAsync(m->d_wino_u, 0, (size_t)NP * Kg * Cout * sizeof(float), s); }
+            { ProfScope ps(m, K == 7 ? "wino_gemm_fc6_wgrad" : "wino_gemm_wgrad", 2.0 * NP * T * Kg * Cout, 4.0 * NP * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_wgrad(g, s); }
             { ProfScope ps(m, "wino_transform", 0, 4.0 * (9.0 + NP) * Cin * Cout + 4.0 * N * H * W * Cout);
-              launch_wino_dfilter(tile, m->d_wino_u, dw, Cin, Cout, s);
+              launch_wino_dfilter(tile, m->d_wino_u, dw, Cin, Cout, K, s);
               if (db) launch_colsum(dz, db, (long long)N * H * W, Cout, s); }
             return;
         }
@@ -403,6 +409,12 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
                     cin = cout;
                 }
         }
+        const int h5_ = H / 32, w5_ = W / 32;
+        const bool fc6w = m->wino_fc6 && m->wino_tile == 4 && m->fc6k == 7 && h5_ % 4 == 0 && w5_ % 4 == 0 && m->widths[4] % 16 == 0 && m->widths[5] % 64 == 0;
+        if (fc6w) {     // V: 36 * T * 9*c5 = 20.25 |pool5| ;  M: 2.25 |fc6|  (the data gradient swaps the two roles)
+            const size_t vf = (size_t)N * h5_ * w5_ * (size_t)std::max(m->widths[4], m->widths[5]) * 21;
+            if (vf > vmax) vmax = vf;
+        }
         m->d_wino_v = m->d_wino_m = nullptr;
         if (vmax) { items.push_back({"wino_v", vmax, 0, 0, 0, &m->d_wino_v}); items.push_back({"wino_m", vmax, 0, 0, 0, &m->d_wino_m}); }
         if (m->wino_min_cin > 0) {    // the forward pass keeps each Winograd layer's transformed input for the weight gradient
@@ -415,6 +427,7 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
                     }
                     cin = m->widths[b];
                 }
+            if (fc6w) items.push_back({"wv:fc6", (size_t)N * h5_ * w5_ * (size_t)m->widths[4] * 21, 0, 0, 0, nullptr});
         }
     }
 
@@ -495,7 +508,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     m->drop_stream = (uint32_t)(2 * m->step);
     {
         Epi e; e.bias = Wp(m, "fc6/biases"); e.relu = 1; e.dropout = drop; e.keep = keep_prob; e.stream_id = m->drop_stream;
-        conv_same(m, "fc6_fwd", x, Wp(m, "fc6/weights"), A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, e, s);
+        conv_same(m, "fc6_fwd", x, Wp(m, "fc6/weights"), A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, e, s, 0, "fc6");
     }
     {
         Epi e; e.bias = Wp(m, "fc7/biases"); e.relu = 1; e.dropout = drop; e.keep = keep_prob; e.stream_id = m->drop_stream + 1;
@@ -599,8 +612,8 @@ void backward_bucket0(fcn8s_model* m)
     { Epi e; e.mask = A(m, "fc6"); e.mask_scale = inv_keep;
       conv_same(m, "fc7_dgrad", m->gbuf[0], WTp(m, "fc7/weights"), m->gbuf[1], N, h5, w5, m->widths[6], m->widths[5], 1, e, s); }
     // fc6
-    conv_wgrad(m, "fc6_wgrad", A(m, "pool5"), m->gbuf[1], Gp(m, "fc6/weights"), Gp(m, "fc6/biases"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, 1.f, s);
-    { Epi e; conv_same(m, "fc6_dgrad", m->gbuf[1], WTp(m, "fc6/weights"), m->gbuf[0], N, h5, w5, m->widths[5], m->widths[4], m->fc6k, e, s); }
+    conv_wgrad(m, "fc6_wgrad", A(m, "pool5"), m->gbuf[1], Gp(m, "fc6/weights"), Gp(m, "fc6/biases"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, 1.f, s, 0, "fc6");
+    { Epi e; conv_same(m, "fc6_dgrad", m->gbuf[1], WTp(m, "fc6/weights"), m->gbuf[0], N, h5, w5, m->widths[5], m->widths[4], m->fc6k, e, s, 0, "fc6"); }
     m->gcur = 0;   // gbuf[0] holds d(pool5)
 }
 
@@ -744,7 +757,11 @@ int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
         int cmax = 0; for (int i = 0; i < 5; ++i) cmax = std::max(cmax, m->widths[i]);
         const char* wt = getenv("FCN8S_WINOGRAD_TILE");             // 2 or 4 (A-B switch)
         if (wt) m->wino_tile = atoi(wt) == 2 ? 2 : 4;
-        if ((e = hipMalloc((void**)&m->d_wino_u, 36 * (size_t)cmax * cmax * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+        const char* wf = getenv("FCN8S_WINOGRAD_FC6");
+        if (wf) m->wino_fc6 = atoi(wf) != 0;
+        size_t ufl = 36 * (size_t)cmax * cmax;
+        if (m->wino_fc6 && m->fc6k == 7) ufl = std::max(ufl, 36 * 9 * (size_t)m->widths[4] * m->widths[5]);   // fc6: 36 positions x 9 sub-filters
+        if ((e = hipMalloc((void**)&m->d_wino_u, ufl * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     }
     if ((e = hipMalloc((void**)&m->d_loss, 2 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     m->d_regsum = m->d_loss + 1;
@@ -1123,16 +1140,17 @@ int fcn8s_op_conv2d(void* stream, const float* x, const float* w, const float* b
 }
 
 int fcn8s_op_conv2d_winograd(void* stream, const float* x, const float* w, const float* bias, float* y,
-                             int N, int H, int W, int Cin, int Cout, int relu, int tile)
+                             int N, int H, int W, int Cin, int Cout, int K, int relu, int tile)
 {
-    if ((tile != 2 && tile != 4) || Cin % 16 || Cout % 32 || H % tile || W % tile)
-        return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d_winograd: needs tile in {2,4}, Cin % 16, Cout % 32, H and W multiples of tile");
+    if ((tile != 2 && tile != 4) || (K != 3 && K != 7) || Cin % 16 || Cout % 32 || H % tile || W % tile)
+        return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d_winograd: needs tile in {2,4}, K in {3,7}, Cin % 16, Cout % 32, H and W multiples of tile");
     hipStream_t s = (hipStream_t)stream;
-    const size_t T = (size_t)N * (H / tile) * (W / tile), P = (size_t)(tile + 2) * (tile + 2);
+    const size_t T = (size_t)N * (H / tile) * (W / tile), P = (size_t)(tile + 2) * (tile + 2), Kg = (size_t)(K == 3 ? 1 : 9) * Cin;
     float *u = nullptr, *v = nullptr, *mm = nullptr;
-    if (hipMalloc((void**)&u, P * (size_t)Cin * Cout * 4) != hipSuccess || hipMalloc((void**)&v, P * T * Cin * 4) != hipSuccess ||
+    if (hipMalloc((void**)&u, P * Kg * Cout * 4) != hipSuccess || hipMalloc((void**)&v, P * T * Kg * 4) != hipSuccess ||
         hipMalloc((void**)&mm, P * T * Cout * 4) != hipSuccess) return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc");
-    conv3x3_winograd(nullptr, tile, "", x, w, y, u, v, mm, N, H, W, Cin, Cout, bias, nullptr, nullptr, 1.f, relu, s, nullptr);
+    WinoEpi we; we.bias = bias; we.relu = relu;
+    conv_winograd(nullptr, tile, K, "", x, w, y, u, v, mm, N, H, W, Cin, Cout, we, s, nullptr);
     hipStreamSynchronize(s); hipFree(u); hipFree(v); hipFree(mm);
     OPCHK(); return FCN8S_OK;
 }

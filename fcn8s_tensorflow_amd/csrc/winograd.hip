@@ -7,8 +7,12 @@
 // Multiplies per output pixel and (ci, co) pair: direct 9, F(2x2) 4, F(4x4) 2.25.  Bytes per transformed pixel:
 // F(2x2) 4x the tensor, F(4x4) 2.25x.  fp32 error against an fp64 direct conv (measured, ReLU data, K = 2304):
 // direct 2e-7, F(2x2) 5e-7, F(4x4) 7e-6 of the output range -- far inside the 1e-3 logit tolerance.
-// The transforms are HBM-bound element-wise kernels (16-byte accesses along the channel axis); they pay for
-// themselves where the activations are small next to the arithmetic, i.e. in the wide layers (conv3 .. conv5).
+// The transforms are HBM-bound element-wise kernels (16-byte accesses along the channel axis).
+//
+// Large kernels (fc6, 7x7): the filter is zero-extended to 9x9 and cut into a 3x3 grid of 3x3 sub-filters; sub-filter
+// (a, b) is a 3x3 conv of the input shifted by (3a, 3b).  All nine share the OUTPUT tiling, so their products add up in
+// the Winograd domain: per position xi one GEMM with K = 9*Cin ([V_00 | V_01 | ... | V_22] x [U_00; ...; U_22]) --
+// 20.25 multiplies per output instead of 49, with F(4x4,3x3)'s numerics.
 #include "fcn8s_internal.h"
 
 namespace fcn8s {
@@ -53,18 +57,23 @@ static __device__ __forceinline__ float4 f4fma(float s, float4 a, float4 acc)
 }
 static __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// ---- filters: u[xi][ci][co] = (G g G^T)[xi] ----------------------------------------------------------------------
+// ---- filters: u[xi][sub*Cin + ci][co] = (G g_sub G^T)[xi];  g_sub = taps (3a..3a+2, 3b..3b+2) of the KS x KS filter -----
 template <int M>
-__global__ void wino_filter_kernel(const float* w, float* u, int Cin, int Cout)
+__global__ void wino_filter_kernel(const float* w, float* u, int Cin, int Cout, int KS, int nsub)
 {
     constexpr int A = WinoMat<M>::A;
-    const long long cc = (long long)Cin * Cout;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < cc; i += (long long)gridDim.x * blockDim.x) {
+    const long long cc = (long long)Cin * Cout, total = cc * nsub * nsub, ucc = cc * nsub * nsub;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int sub = (int)(i / cc); const long long e = i - sub * cc;
+        const int sa = sub / nsub, sb = sub - sa * nsub;
         float g[3][3], t[A][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = w[(a * 3 + b) * cc + i];
+            for (int b = 0; b < 3; ++b) {
+                const int ky = 3 * sa + a, kx = 3 * sb + b;
+                g[a][b] = (ky < KS && kx < KS) ? w[(long long)(ky * KS + kx) * cc + e] : 0.f;
+            }
 #pragma unroll
         for (int a = 0; a < A; ++a)
 #pragma unroll
@@ -81,18 +90,20 @@ __global__ void wino_filter_kernel(const float* w, float* u, int Cin, int Cout)
                 float s = 0.f;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) s = fmaf(t[a][k], WinoMat<M>::g(b, k), s);
-                u[(a * A + b) * cc + i] = s;
+                u[(long long)(a * A + b) * ucc + i] = s;           // row (sub*Cin + ci), column co
             }
     }
 }
 
 // ---- input: one thread = one m x m output tile x 4 channels; alpha x alpha patch (zero outside), V = B^T d B --------
 template <int M>
-__global__ __launch_bounds__(256) void wino_input_kernel(const float4* x, float4* v, int N, int H, int W, int C4)
+__global__ __launch_bounds__(256) void wino_input_kernel(const float4* x, float4* v, int N, int H, int W, int C4, int pad, int nsub)
 {
     constexpr int A = WinoMat<M>::A;
     const int th = H / M, tw = W / M;
     const long long T = (long long)N * th * tw, total = T * C4;
+    const int sub = blockIdx.y, sa = sub / nsub, sb = sub - sa * nsub;     // sub-filter: patch shifted by (3 sa, 3 sb)
+    const int oy = 3 * sa - pad, ox = 3 * sb - pad, ldv = C4 * nsub * nsub, coff = sub * C4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
         const long long t = i / C4;
@@ -101,11 +112,11 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* x, float4
         float4 q[A][A];                            // q = B^T d, built column by column so that d is never fully live
 #pragma unroll
         for (int b = 0; b < A; ++b) {
-            const int ix = M * tx - 1 + b;
+            const int ix = M * tx + ox + b;
             float4 d[A];
 #pragma unroll
             for (int a = 0; a < A; ++a) {
-                const int iy = M * ty - 1 + a;
+                const int iy = M * ty + oy + a;
                 d[a] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
                            ? x[(((long long)n * H + iy) * W + ix) * C4 + c] : f4zero();
             }
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* x, float4
                 float4 s = f4zero();
 #pragma unroll
                 for (int k = 0; k < A; ++k) if (WinoMat<M>::bt(b, k) != 0.f) s = f4fma(WinoMat<M>::bt(b, k), q[a][k], s);
-                v[((long long)(a * A + b) * T + t) * C4 + c] = s;
+                v[((long long)(a * A + b) * T + t) * ldv + coff + c] = s;
             }
     }
 }
@@ -132,7 +143,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* x, float4
 // ---- output: one thread = one tile x 4 channels; Y = A^T M A, then the conv epilogue --------------------------------
 template <int M>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float4* m, const float4* bias, const float4* addend, const float4* mask,
-                                                          float mask_scale, int relu, float4* y, int N, int H, int W, int C4)
+                                                          float mask_scale, int relu, float4* y, int N, int H, int W, int C4,
+                                                          int dropout, float keep, unsigned long long seed, unsigned int stream_id)
 {
     constexpr int A = WinoMat<M>::A;
     const int th = H / M, tw = W / M;
@@ -171,6 +183,14 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* m, const
                     const float4 k = mask[off];
                     v.x = k.x > 0.f ? v.x * mask_scale : 0.f; v.y = k.y > 0.f ? v.y * mask_scale : 0.f;
                     v.z = k.z > 0.f ? v.z * mask_scale : 0.f; v.w = k.w > 0.f ? v.w * mask_scale : 0.f;
+                }
+                if (dropout) {                     // same Philox stream as the direct kernel's epilogue: element index NHWC
+                    const unsigned long long e = (unsigned long long)off * 4;
+                    const float ik = 1.f / keep;
+                    v.x = philox_uniform(e, seed, stream_id) < keep ? v.x * ik : 0.f;
+                    v.y = philox_uniform(e + 1, seed, stream_id) < keep ? v.y * ik : 0.f;
+                    v.z = philox_uniform(e + 2, seed, stream_id) < keep ? v.z * ik : 0.f;
+                    v.w = philox_uniform(e + 3, seed, stream_id) < keep ? v.w * ik : 0.f;
                 }
                 y[off] = v;
             }
@@ -215,19 +235,21 @@ __global__ __launch_bounds__(256) void wino_dout_kernel(const float4* dy, float4
     }
 }
 
-// ---- dg = G^T dU G ------------------------------------------------------------------------------------------------------
+// ---- dg_sub = G^T dU_sub G, scattered back to the taps (3a+i, 3b+j) < KS of the KS x KS filter gradient -----------------
 template <int M>
-__global__ void wino_dfilter_kernel(const float* du, float* dw, int Cin, int Cout)
+__global__ void wino_dfilter_kernel(const float* du, float* dw, int Cin, int Cout, int KS, int nsub)
 {
     constexpr int A = WinoMat<M>::A;
-    const long long cc = (long long)Cin * Cout;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < cc; i += (long long)gridDim.x * blockDim.x) {
+    const long long cc = (long long)Cin * Cout, total = cc * nsub * nsub, ucc = total;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int sub = (int)(i / cc); const long long e = i - sub * cc;
+        const int sa = sub / nsub, sb = sub - sa * nsub;
         float t[3][A];
 #pragma unroll
         for (int b = 0; b < A; ++b) {
             float col[A];
 #pragma unroll
-            for (int a = 0; a < A; ++a) col[a] = du[(a * A + b) * cc + i];
+            for (int a = 0; a < A; ++a) col[a] = du[(long long)(a * A + b) * ucc + i];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 float s = 0.f;
@@ -243,32 +265,36 @@ __global__ void wino_dfilter_kernel(const float* du, float* dw, int Cin, int Cou
                 float s = 0.f;
 #pragma unroll
                 for (int k = 0; k < A; ++k) s = fmaf(t[r][k], WinoMat<M>::g(k, q), s);
-                dw[(r * 3 + q) * cc + i] = s;
+                const int ky = 3 * sa + r, kx = 3 * sb + q;
+                if (ky < KS && kx < KS) dw[(long long)(ky * KS + kx) * cc + e] = s;
             }
     }
 }
 
-// ---- launchers (tile = 2 or 4) ------------------------------------------------------------------------------------------
-void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, hipStream_t s)
+// ---- launchers (tile = 2 or 4; KS = 3, or 7 = 3x3 grid of 3x3 sub-filters) --------------------------------------------------
+void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, int KS, hipStream_t s)
 {
-    const int g = wcap((long long)Cin * Cout);
-    if (tile == 4) hipLaunchKernelGGL(wino_filter_kernel<4>, dim3(g), dim3(256), 0, s, w, u, Cin, Cout);
-    else           hipLaunchKernelGGL(wino_filter_kernel<2>, dim3(g), dim3(256), 0, s, w, u, Cin, Cout);
+    const int nsub = KS == 3 ? 1 : 3;
+    const int g = wcap((long long)Cin * Cout * nsub * nsub);
+    if (tile == 4) hipLaunchKernelGGL(wino_filter_kernel<4>, dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
+    else           hipLaunchKernelGGL(wino_filter_kernel<2>, dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
 }
-void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, hipStream_t s)
+void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, int KS, hipStream_t s)
 {
-    const int g = wcap((long long)N * (H / tile) * (W / tile) * (C / 4));
-    if (tile == 4) hipLaunchKernelGGL(wino_input_kernel<4>, dim3(g), dim3(256), 0, s, (const float4*)x, (float4*)v, N, H, W, C / 4);
-    else           hipLaunchKernelGGL(wino_input_kernel<2>, dim3(g), dim3(256), 0, s, (const float4*)x, (float4*)v, N, H, W, C / 4);
+    const int nsub = KS == 3 ? 1 : 3, pad = (KS - 1) / 2;
+    const dim3 g(wcap((long long)N * (H / tile) * (W / tile) * (C / 4)), nsub * nsub);
+    if (tile == 4) hipLaunchKernelGGL(wino_input_kernel<4>, g, dim3(256), 0, s, (const float4*)x, (float4*)v, N, H, W, C / 4, pad, nsub);
+    else           hipLaunchKernelGGL(wino_input_kernel<2>, g, dim3(256), 0, s, (const float4*)x, (float4*)v, N, H, W, C / 4, pad, nsub);
 }
 void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
-                        int relu, float* y, int N, int H, int W, int C, hipStream_t s)
+                        int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,
+                        unsigned int stream_id, hipStream_t s)
 {
     const int g = wcap((long long)N * (H / tile) * (W / tile) * (C / 4));
     if (tile == 4) hipLaunchKernelGGL(wino_output_kernel<4>, dim3(g), dim3(256), 0, s, (const float4*)m, (const float4*)bias, (const float4*)addend,
-                                      (const float4*)mask, mask_scale, relu, (float4*)y, N, H, W, C / 4);
+                                      (const float4*)mask, mask_scale, relu, (float4*)y, N, H, W, C / 4, dropout, keep, seed, stream_id);
     else           hipLaunchKernelGGL(wino_output_kernel<2>, dim3(g), dim3(256), 0, s, (const float4*)m, (const float4*)bias, (const float4*)addend,
-                                      (const float4*)mask, mask_scale, relu, (float4*)y, N, H, W, C / 4);
+                                      (const float4*)mask, mask_scale, relu, (float4*)y, N, H, W, C / 4, dropout, keep, seed, stream_id);
 }
 void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s)
 {
@@ -276,11 +302,12 @@ void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W,
     if (tile == 4) hipLaunchKernelGGL(wino_dout_kernel<4>, dim3(g), dim3(256), 0, s, (const float4*)dy, (float4*)dm, N, H, W, C / 4);
     else           hipLaunchKernelGGL(wino_dout_kernel<2>, dim3(g), dim3(256), 0, s, (const float4*)dy, (float4*)dm, N, H, W, C / 4);
 }
-void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, hipStream_t s)
+void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, int KS, hipStream_t s)
 {
-    const int g = wcap((long long)Cin * Cout);
-    if (tile == 4) hipLaunchKernelGGL(wino_dfilter_kernel<4>, dim3(g), dim3(256), 0, s, du, dw, Cin, Cout);
-    else           hipLaunchKernelGGL(wino_dfilter_kernel<2>, dim3(g), dim3(256), 0, s, du, dw, Cin, Cout);
+    const int nsub = KS == 3 ? 1 : 3;
+    const int g = wcap((long long)Cin * Cout * nsub * nsub);
+    if (tile == 4) hipLaunchKernelGGL(wino_dfilter_kernel<4>, dim3(g), dim3(256), 0, s, du, dw, Cin, Cout, KS, nsub);
+    else           hipLaunchKernelGGL(wino_dfilter_kernel<2>, dim3(g), dim3(256), 0, s, du, dw, Cin, Cout, KS, nsub);
 }
 
 }  // namespace fcn8s

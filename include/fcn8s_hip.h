@@ -158,10 +158,10 @@ int fcn8s_profile_get(fcn8s_model* m, int group, const char** name, double* tota
 int fcn8s_op_preprocess(void* stream, const void* images, int image_dtype, float* out4, int64_t npix);
 int fcn8s_op_conv2d(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,
                     int N, int H, int W, int Cin, int Cout, int K, int relu);
-/* the same 3x3 SAME conv through Winograd F(tile x tile, 3x3), tile = 2 or 4 (the path the model takes for its
- * wide 3x3 layers; H, W multiples of tile) */
+/* the same SAME conv through Winograd F(tile x tile, 3x3), tile = 2 or 4 (the path the model takes for its 3x3
+ * layers; K = 7 runs fc6's decomposition into nine 3x3 sub-filters; H, W multiples of tile) */
 int fcn8s_op_conv2d_winograd(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,
-                             int N, int H, int W, int Cin, int Cout, int relu, int tile);
+                             int N, int H, int W, int Cin, int Cout, int K, int relu, int tile);
 int fcn8s_op_conv2d_bwd(void* stream, const float* x, const float* w_hwio, const float* dy,
                         float* dx, float* dw, float* db,
                         int N, int H, int W, int Cin, int Cout, int K);

@@ -84,7 +84,8 @@ def test_forward_logits_and_argmax(widths, n, h, w):
 
 
 @pytest.mark.parametrize("widths,n,h,w,l2", [(SMALL, 2, 64, 64, 0.0), (SMALL, 1, 32, 96, 1e-2), (None, 1, 32, 32, 0.0),
-                                                (None, 2, 32, 64, 0.0)])   # full width, W % 64 == 0: the specialised conv1_1 / 3x3 wgrad kernels
+                                                (None, 2, 32, 64, 0.0),    # full width, W % 64 == 0: the specialised conv1_1 / 3x3 wgrad kernels
+                                                (SMALL, 1, 128, 128, 1e-3)])  # 4x4 fc6 map: fc6 through the Winograd sub-filter decomposition
 def test_gradients(widths, n, h, w, l2):
     P, img, lab = tie_free_case(widths, n, h, w, seed=2)
     e = make_engine(widths)
@@ -98,13 +99,14 @@ def test_gradients(widths, n, h, w, l2):
     e.close()
 
 
-def test_dropout_statistics_and_parity():
+@pytest.mark.parametrize("n,hw", [(2, 64), (1, 128)])      # 128: fc6 runs through the Winograd path (dropout fused in its output transform)
+def test_dropout_statistics_and_parity(n, hw):
     widths = SMALL
-    P, img, lab = tie_free_case(widths, 2, 64, 64, seed=4)
+    P, img, lab = tie_free_case(widths, n, hw, hw, seed=4)
     e = make_engine(widths, seed=1234)
     e.set_params(P)
     loss = e.forward_backward(img, lab, keep_prob=0.5)
-    m6, m7 = e.dropout_masks((2, 2, 2, widths[5]), (2, 2, 2, widths[6]))
+    m6, m7 = e.dropout_masks((n, hw // 32, hw // 32, widths[5]), (n, hw // 32, hw // 32, widths[6]))
     assert set(np.unique(m6)) <= {0.0, 1.0} and 0.3 < m6.mean() < 0.7 and 0.3 < m7.mean() < 0.7
     assert not np.array_equal(m6, m7)
     loss_ref, g_ref, _ = orc.loss_and_grads(P, img, orc.one_hot(lab, 20).astype(np.float32), keep_prob=0.5, masks=(m6, m7))

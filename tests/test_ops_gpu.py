@@ -77,25 +77,31 @@ def test_conv2d_fwd_bwd(N, H, W, Cin, Cout, K):
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,tile", [(1, 4, 6, 16, 32, 2), (2, 8, 16, 64, 128, 2), (1, 16, 32, 256, 256, 2), (3, 2, 2, 32, 64, 2),
                                                   (1, 4, 8, 16, 32, 4), (2, 8, 16, 64, 128, 4), (1, 16, 32, 256, 256, 4), (2, 4, 4, 512, 64, 4)])
-def test_conv3x3_winograd(N, H, W, Cin, Cout, tile):
+def test_conv3x3_winograd(N, H, W, Cin, Cout, tile, K=3):
     """Winograd F(2x2,3x3) path (filter/input transforms, 16 batched MFMA GEMMs, output transform + bias + ReLU)."""
     L = _lib()
     rng = np.random.default_rng(11)
     x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
-    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    w = (rng.standard_normal((K, K, Cin, Cout)) / np.sqrt(K * K * Cin)).astype(np.float32)
     b = rng.standard_normal(Cout).astype(np.float32)
     ref = orc.conv2d_same_t(torch.tensor(x).permute(0, 3, 1, 2).double(), torch.tensor(w).double(), torch.tensor(b).double(), relu=True)
     ref = ref.permute(0, 2, 3, 1).numpy()
     xd, wd, bd = dev(x), dev(w), dev(b)
     y_ = torch.empty(N, H, W, Cout).cuda()
-    L.check(L.lib.fcn8s_op_conv2d_winograd(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), N, H, W, Cin, Cout, 1, tile))
+    L.check(L.lib.fcn8s_op_conv2d_winograd(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), N, H, W, Cin, Cout, K, 1, tile))
     torch.cuda.synchronize()
     tol = 1e-5 if tile == 2 else 1e-4          # fp32 F(4x4,3x3) carries ~1e-5 of the output range (winograd.hip header)
     assert rel_err(y_.cpu().numpy(), ref) < tol
     yd = torch.empty(N, H, W, Cout).cuda()
-    L.check(L.lib.fcn8s_op_conv2d(None, ptr(xd), ptr(wd), ptr(bd), ptr(yd), N, H, W, Cin, Cout, 3, 1))
+    L.check(L.lib.fcn8s_op_conv2d(None, ptr(xd), ptr(wd), ptr(bd), ptr(yd), N, H, W, Cin, Cout, K, 1))
     torch.cuda.synchronize()
     assert rel_err(y_.cpu().numpy(), yd.cpu().numpy()) < tol       # and against the direct kernel
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(1, 4, 4, 16, 32), (2, 8, 12, 64, 128), (1, 16, 32, 32, 64)])
+def test_conv7x7_winograd_subfilter_decomposition(N, H, W, Cin, Cout):
+    """fc6's path: the 7x7 filter as a 3x3 grid of 3x3 sub-filters summed in the F(4x4,3x3) Winograd domain."""
+    test_conv3x3_winograd(N, H, W, Cin, Cout, 4, K=7)
 
 
 @pytest.mark.parametrize("N,H,W,C", [(2, 8, 8, 64), (1, 4, 6, 8), (1, 32, 64, 128)])
