@@ -155,6 +155,17 @@ def main():
                     "algorithmic_gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 3),
                     "algorithmic_mb_per_launch": round(g["bytes"] / g["launches"] / 1e6, 2),
                     "share_of_step_time": round(g["ms"] / (dt * 1e3), 3)}
+        # largest HBM-bound kernel family (Winograd transforms, pools, ...) against the HBM roof
+        hb = {k: v for k, v in prof.items() if v["flops"] == 0 and v["bytes"] > 0 and v["ms"] > 0}
+        hdom = max(hb, key=lambda k: hb[k]["ms"]) if hb else None
+        hbm_roof = None
+        if hdom:
+            g = hb[hdom]
+            gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+            hbm_roof = {"kernel_group": hdom, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(gbs / PEAK_HBM_GBS, 4), "launches": g["launches"],
+                        "algorithmic_mb_per_launch": round(g["bytes"] / g["launches"] / 1e6, 2),
+                        "share_of_step_time": round(g["ms"] / (dt * 1e3), 3)}
         out = {
             "metric": "training images/sec at 1024x512 bs16" if args.mode == "train" else "inference images/sec at 1024x512",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,6 +179,7 @@ def main():
             "effective_tflops_direct_conv_count": round(gflop_img * N * world * args.steps / dt / 1e3, 2),
             "fp32_direct_conv_ceiling_images_per_sec_per_gpu": round(PEAK_F32_MFMA_TFLOPS * 1e3 / gflop_img, 1),
             "roofline": roof,
+            "roofline_hbm": hbm_roof,
             "kernel_groups_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
             "kernel_groups_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0},
             "kernel_groups_gbs": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in prof.items() if v["flops"] == 0 and v["ms"] > 0},
