@@ -51,11 +51,21 @@ template <> struct WinoMat<4> {
     }
 };
 
-static __device__ __forceinline__ float4 f4fma(float s, float4 a, float4 acc)
+// VEC floats per lane along the channel axis.  F(2x2): 16 bytes (float4).  F(4x4): 8 bytes (float2) -- the 6x6 tile
+// of float4 needs 170-200 VGPRs (2 waves/SIMD); with float2 the same kernels fit 4+ waves/SIMD, which these
+// HBM-bound kernels need to keep enough loads in flight.
+template <int VEC> struct alignas(VEC * 4) VecF {
+    float d[VEC];
+};
+template <int VEC> static __device__ __forceinline__ VecF<VEC> vzero() { VecF<VEC> r; _Pragma("unroll") for (int i = 0; i < VEC; ++i) r.d[i] = 0.f; return r; }
+template <int VEC> static __device__ __forceinline__ VecF<VEC> vfma(float s, const VecF<VEC>& a, VecF<VEC> acc)
 {
-    return make_float4(fmaf(s, a.x, acc.x), fmaf(s, a.y, acc.y), fmaf(s, a.z, acc.z), fmaf(s, a.w, acc.w));
+    _Pragma("unroll") for (int i = 0; i < VEC; ++i) acc.d[i] = fmaf(s, a.d[i], acc.d[i]);
+    return acc;
 }
-static __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+#define f4fma vfma<VEC>
+#define f4zero vzero<VEC>
+#define float4 VecF<VEC>
 
 // ---- filters: u[xi][sub*Cin + ci][co] = (G g_sub G^T)[xi];  g_sub = taps (3a..3a+2, 3b..3b+2) of the KS x KS filter -----
 template <int M>
@@ -96,7 +106,7 @@ __global__ void wino_filter_kernel(const float* w, float* u, int Cin, int Cout, 
 }
 
 // ---- input: one thread = one m x m output tile x 4 channels; alpha x alpha patch (zero outside), V = B^T d B --------
-template <int M>
+template <int M, int VEC>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float4* x, float4* v, int N, int H, int W, int C4, int pad, int nsub)
 {
     constexpr int A = WinoMat<M>::A;
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* x, float4
 }
 
 // ---- output: one thread = one tile x 4 channels; Y = A^T M A, then the conv epilogue --------------------------------
-template <int M>
+template <int M, int VEC>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float4* m, const float4* bias, const float4* addend, const float4* mask,
                                                           float mask_scale, int relu, float4* y, int N, int H, int W, int C4,
                                                           int dropout, float keep, unsigned long long seed, unsigned int stream_id)
@@ -177,20 +187,16 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* m, const
 #pragma unroll
                 for (int k = 0; k < A; ++k) if (WinoMat<M>::at(ox, k) != 0.f) v = f4fma(WinoMat<M>::at(ox, k), q[oy][k], v);
                 const long long off = (((long long)n * H + M * ty + oy) * W + M * tx + ox) * C4 + c;
-                if (addend) { const float4 ad = addend[off]; v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w; }
-                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (addend) { const float4 ad = addend[off]; _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] += ad.d[i]; }
+                if (relu) { _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = fmaxf(v.d[i], 0.f); }
                 if (mask) {
                     const float4 k = mask[off];
-                    v.x = k.x > 0.f ? v.x * mask_scale : 0.f; v.y = k.y > 0.f ? v.y * mask_scale : 0.f;
-                    v.z = k.z > 0.f ? v.z * mask_scale : 0.f; v.w = k.w > 0.f ? v.w * mask_scale : 0.f;
+                    _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = k.d[i] > 0.f ? v.d[i] * mask_scale : 0.f;
                 }
                 if (dropout) {                     // same Philox stream as the direct kernel's epilogue: element index NHWC
-                    const unsigned long long e = (unsigned long long)off * 4;
+                    const unsigned long long e = (unsigned long long)off * VEC;
                     const float ik = 1.f / keep;
-                    v.x = philox_uniform(e, seed, stream_id) < keep ? v.x * ik : 0.f;
-                    v.y = philox_uniform(e + 1, seed, stream_id) < keep ? v.y * ik : 0.f;
-                    v.z = philox_uniform(e + 2, seed, stream_id) < keep ? v.z * ik : 0.f;
-                    v.w = philox_uniform(e + 3, seed, stream_id) < keep ? v.w * ik : 0.f;
+                    _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = philox_uniform(e + i, seed, stream_id) < keep ? v.d[i] * ik : 0.f;
                 }
                 y[off] = v;
             }
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* m, const
 }
 
 // ---- weight gradient: dM = A dY A^T (alpha x alpha from the m x m output-gradient tile) ------------------------------
-template <int M>
+template <int M, int VEC>
 __global__ __launch_bounds__(256) void wino_dout_kernel(const float4* dy, float4* dm, int N, int H, int W, int C4)
 {
     constexpr int A = WinoMat<M>::A;
@@ -271,6 +277,10 @@ __global__ void wino_dfilter_kernel(const float* du, float* dw, int Cin, int Cou
     }
 }
 
+#undef f4fma
+#undef f4zero
+#undef float4
+
 // ---- launchers (tile = 2 or 4; KS = 3, or 7 = 3x3 grid of 3x3 sub-filters) --------------------------------------------------
 void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, int KS, hipStream_t s)
 {
@@ -282,25 +292,28 @@ void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, i
 void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, int KS, hipStream_t s)
 {
     const int nsub = KS == 3 ? 1 : 3, pad = (KS - 1) / 2;
-    const dim3 g(wcap((long long)N * (H / tile) * (W / tile) * (C / 4)), nsub * nsub);
-    if (tile == 4) hipLaunchKernelGGL(wino_input_kernel<4>, g, dim3(256), 0, s, (const float4*)x, (float4*)v, N, H, W, C / 4, pad, nsub);
-    else           hipLaunchKernelGGL(wino_input_kernel<2>, g, dim3(256), 0, s, (const float4*)x, (float4*)v, N, H, W, C / 4, pad, nsub);
+    if (tile == 4) hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(wcap((long long)N * (H / 4) * (W / 4) * (C / 2)), nsub * nsub), dim3(256), 0, s,
+                                      (const VecF<2>*)x, (VecF<2>*)v, N, H, W, C / 2, pad, nsub);
+    else           hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(wcap((long long)N * (H / 2) * (W / 2) * (C / 4)), nsub * nsub), dim3(256), 0, s,
+                                      (const VecF<4>*)x, (VecF<4>*)v, N, H, W, C / 4, pad, nsub);
 }
 void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
                         int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,
                         unsigned int stream_id, hipStream_t s)
 {
-    const int g = wcap((long long)N * (H / tile) * (W / tile) * (C / 4));
-    if (tile == 4) hipLaunchKernelGGL(wino_output_kernel<4>, dim3(g), dim3(256), 0, s, (const float4*)m, (const float4*)bias, (const float4*)addend,
-                                      (const float4*)mask, mask_scale, relu, (float4*)y, N, H, W, C / 4, dropout, keep, seed, stream_id);
-    else           hipLaunchKernelGGL(wino_output_kernel<2>, dim3(g), dim3(256), 0, s, (const float4*)m, (const float4*)bias, (const float4*)addend,
-                                      (const float4*)mask, mask_scale, relu, (float4*)y, N, H, W, C / 4, dropout, keep, seed, stream_id);
+    if (tile == 4) hipLaunchKernelGGL((wino_output_kernel<4, 2>), dim3(wcap((long long)N * (H / 4) * (W / 4) * (C / 2))), dim3(256), 0, s,
+                                      (const VecF<2>*)m, (const VecF<2>*)bias, (const VecF<2>*)addend, (const VecF<2>*)mask, mask_scale, relu,
+                                      (VecF<2>*)y, N, H, W, C / 2, dropout, keep, seed, stream_id);
+    else           hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(wcap((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, s,
+                                      (const VecF<4>*)m, (const VecF<4>*)bias, (const VecF<4>*)addend, (const VecF<4>*)mask, mask_scale, relu,
+                                      (VecF<4>*)y, N, H, W, C / 4, dropout, keep, seed, stream_id);
 }
 void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s)
 {
-    const int g = wcap((long long)N * (H / tile) * (W / tile) * (C / 4));
-    if (tile == 4) hipLaunchKernelGGL(wino_dout_kernel<4>, dim3(g), dim3(256), 0, s, (const float4*)dy, (float4*)dm, N, H, W, C / 4);
-    else           hipLaunchKernelGGL(wino_dout_kernel<2>, dim3(g), dim3(256), 0, s, (const float4*)dy, (float4*)dm, N, H, W, C / 4);
+    if (tile == 4) hipLaunchKernelGGL((wino_dout_kernel<4, 2>), dim3(wcap((long long)N * (H / 4) * (W / 4) * (C / 2))), dim3(256), 0, s,
+                                      (const VecF<2>*)dy, (VecF<2>*)dm, N, H, W, C / 2);
+    else           hipLaunchKernelGGL((wino_dout_kernel<2, 4>), dim3(wcap((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, s,
+                                      (const VecF<4>*)dy, (VecF<4>*)dm, N, H, W, C / 4);
 }
 void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, int KS, hipStream_t s)
 {
