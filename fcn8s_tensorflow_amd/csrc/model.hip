@@ -188,7 +188,7 @@ struct ProfScope {
 // ---- layer launchers ------------------------------------------------------------
 struct Epi { const float* bias = nullptr; const float* addend = nullptr; const float* mask = nullptr;
              float alpha = 1.f; int relu = 0; float mask_scale = 1.f; int dropout = 0; float keep = 1.f;
-             uint32_t stream_id = 0; };
+             uint32_t stream_id = 0; int dgrad = 0; };   // dgrad: data-gradient launch (profile tag; never keeps V)
 
 // 3x3 SAME conv through Winograd F(tile x tile, 3x3): filter transform, input transform, (tile+2)^2 batched GEMMs
 // on the matrix cores (2.25x / 4x fewer MFMA flops than the direct form), output transform + fused epilogue.
@@ -234,7 +234,7 @@ void conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
     const bool wino3 = m && K == 3 && m->wino_min_cin > 0 && Cin >= m->wino_min_cin && m->d_wino_v && wino_tile_for(m, H, W) && !e.dropout;
     const bool wino7 = m && K == 7 && m->wino_fc6 && m->d_wino_v && wino_tile_for(m, H, W) == 4;
     if ((wino3 || wino7) && Cin % 16 == 0 && Cout % 64 == 0 && e.alpha == 1.f && !real_cin) {
-        const bool dgrad = strstr(group, "dgrad") != nullptr;
+        const bool dgrad = e.dgrad != 0;
         float* vbuf = m->d_wino_v;
         if (!dgrad && layer) { auto it = m->acts.find(std::string("wv:") + layer); if (it != m->acts.end()) vbuf = it->second.p; }
         WinoEpi we; we.bias = e.bias; we.addend = e.addend; we.mask = e.mask; we.mask_scale = e.mask_scale; we.relu = e.relu;
@@ -613,7 +613,7 @@ void backward_bucket0(fcn8s_model* m)
       conv_same(m, "fc7_dgrad", m->gbuf[0], WTp(m, "fc7/weights"), m->gbuf[1], N, h5, w5, m->widths[6], m->widths[5], 1, e, s); }
     // fc6
     conv_wgrad(m, "fc6_wgrad", A(m, "pool5"), m->gbuf[1], Gp(m, "fc6/weights"), Gp(m, "fc6/biases"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, 1.f, s, 0, "fc6");
-    { Epi e; conv_same(m, "fc6_dgrad", m->gbuf[1], WTp(m, "fc6/weights"), m->gbuf[0], N, h5, w5, m->widths[5], m->widths[4], m->fc6k, e, s, 0, "fc6"); }
+    { Epi e; e.dgrad = 1; conv_same(m, "fc6_dgrad", m->gbuf[1], WTp(m, "fc6/weights"), m->gbuf[0], N, h5, w5, m->widths[5], m->widths[4], m->fc6k, e, s, 0, "fc6"); }
     m->gcur = 0;   // gbuf[0] holds d(pool5)
 }
 
@@ -643,7 +643,7 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
             conv_wgrad(m, first ? "conv1_1_wgrad" : "conv3x3_wgrad", xin, dz, Gp(m, std::string(nm) + "/filter"), Gp(m, std::string(nm) + "/biases"),
                        N, h, w, cin, cw, 3, 1.f, s, real_cin, nm);
             if (first) break;
-            Epi e;
+            Epi e; e.dgrad = 1;
             if (i > 1) { e.mask = xin; e.mask_scale = 1.f; }               // ReLU of the previous conv
             else if (b == 5) e.addend = m->gskip4;                        // d(pool4) also receives the pool4_1x1 path
             else if (b == 4) e.addend = m->gskip3;                        // d(pool3) also receives the pool3_1x1 path

@@ -10,6 +10,7 @@ Sources exercised (reference file:line):
   cityscapesscripts/helpers/labels.py:62-99,185-187 (ids_to_trainIds_array)  the 35 -> 20 trainId table (exec'd up to :188; :191 overflows on NumPy 2)
   cityscapesscripts/evaluation/addToConfusionMatrix_impl.c:3-17  compiled by oracle/Makefile into oracle/_ref/
   data_generator/batch_generator.py:16-130,140-417  BatchGenerator contract (cv2 stubbed, scipy.misc.imread -> PIL)
+  cityscapesscripts/evaluation/evalPixelLevelSemanticLabeling.py:173-182,229-335  official IoU scoring functions (labels / PIL stubbed)
 """
 import ctypes
 import os
@@ -98,6 +99,28 @@ def main():
         x, y = next(g3)
         out["x_crop"] = x; out["y_crop"] = y
         np.savez_compressed(os.path.join(HERE, "batchgen_contract.npz"), **out)
+    # ---- official pixel-level scoring: the reference evaluator's own functions on a random confusion matrix --------
+    import PIL
+    if not hasattr(PIL, "PILLOW_VERSION"):
+        PIL.PILLOW_VERSION = PIL.__version__                     # csHelpers.py:16 predates Pillow 7
+    lab_mod = types.ModuleType("labels")
+    exec("\n".join(src[:188]), lab_mod.__dict__)
+    sys.modules["labels"] = lab_mod                               # labels.py:191 overflows on NumPy 2; the table above it is intact
+    sys.path.insert(0, os.path.join(REF, "cityscapesscripts", "helpers"))
+    sys.path.insert(0, os.path.join(REF, "cityscapesscripts", "evaluation"))
+    os.environ.setdefault("CITYSCAPES_DATASET", "/tmp")
+    import evalPixelLevelSemanticLabeling as ev
+    conf = ev.generateMatrix(ev.args)
+    conf[:] = rng.integers(0, 5000, conf.shape)
+    conf[:, 22] = 0; conf[22, :] = 0                             # an evaluated class that never occurs -> nan, left out of the mean
+    cls = {ev.id2label[l].name: ev.getIouScoreForLabel(l, conf, ev.args) for l in ev.args.evalLabels}
+    cat = {c: ev.getIouScoreForCategory(c, conf, ev.args) for c in ev.category2labels.keys()}
+    np.savez_compressed(os.path.join(HERE, "cityscapes_scores.npz"), conf=conf.astype(np.int64),
+                        class_names=np.array(list(cls)), class_scores=np.array(list(cls.values()), dtype=np.float64),
+                        class_avg=ev.getScoreAverage(cls, ev.args),
+                        cat_names=np.array(list(cat)), cat_scores=np.array(list(cat.values()), dtype=np.float64),
+                        cat_avg=ev.getScoreAverage(cat, ev.args),
+                        trainids_to_ids=np.array([0] + [ns["trainIds_to_ids_dict"][t] for t in range(1, 20)], dtype=np.uint8))   # labels.py:188-192 (its loop overflows uint8 on the id -1 label under NumPy 2; [0] is forced to 0 there)
     print("golden fixtures written to", HERE)
 
 
