@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--optimizer", default="adam", choices=["adam", "sgd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL); 'gloo' lets the "
+                    "multi-rank path be exercised on a single-GPU box together with --device")
+    ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     args = ap.parse_args()
 
     import torch
@@ -88,19 +91,30 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = local_rank if args.device is None else args.device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend)
     if args.gpus != world and rank == 0 and world == 1 and args.gpus > 1:
         print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus), file=sys.stderr)
         sys.exit(2)
 
+    trace = os.environ.get("FCN8S_BENCH_TRACE")
+    def mark(msg):
+        if trace:
+            print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
     N, H, W = args.batch, args.height, args.width
-    eng = Engine(20, device_id=local_rank, seed=1234 + rank)
+    mark("process group up; creating engine")
+    eng = Engine(20, device_id=dev, seed=1234 + rank)
     eng.init_params(seed=0)                       # He-normal VGG, reference decoder init (same on every rank)
+    mark("broadcast params")
     eng.broadcast_params(0)
+    mark("params broadcast")
     rng = np.random.default_rng(1234 + rank)      # SURVEY 8d synthetic inputs
     images = torch.from_numpy(rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)).cuda()
     labels = torch.from_numpy(rng.integers(0, 20, (N, H, W), dtype=np.uint8)).cuda()
@@ -117,9 +131,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        mark("warmup step %d enqueued" % i)
     fence()
+    mark("warmup done")
     eng.profile(True)
     eng.profile_reset()
     t0 = time.perf_counter()
@@ -127,6 +143,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    mark("timed region done")
     prof = eng.profile_results()
     eng.profile(False)
     if world > 1:
