@@ -55,6 +55,8 @@ struct WgradArgs {
     float alpha;
     float* colsum;                     // optional: colsum[j] += sum_p B[p,j]  (bias gradient), or nullptr
     int batched; long long a_batch_stride, b_batch_stride;   // gridDim.z = independent GEMMs (C stride = Areal*ldc)
+    int c_uninitialized;               // 0: C was zeroed by the caller (accumulate with atomics); 1: the launcher decides (plain store or memset)
+    int plain_store;                   // set by the launcher
 };
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
 // 3x3 / 7x7 SAME conv weight (+bias) gradient, several taps per block (3x3: all nine, 7x7: one filter row);

@@ -553,7 +553,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < p.Areal) unsafeAtomicAdd(Ct + (long long)row * p.ldc + col, acc[tm][tn][r] * p.alpha);
+                if (row < p.Areal) {
+                    if (p.plain_store) Ct[(long long)row * p.ldc + col] = acc[tm][tn][r] * p.alpha;     // sole writer of this tile
+                    else unsafeAtomicAdd(Ct + (long long)row * p.ldc + col, acc[tm][tn][r] * p.alpha);
+                }
             }
         if (COLSUM && do_colsum && lane < 32) unsafeAtomicAdd(p.colsum + col, accs[COLSUM ? tn : 0][0]);
     }
@@ -836,6 +839,11 @@ static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
     constexpr bool fused_colsum = BM * BN < 128 * 128;
     WgradArgs b = a;
     if (!fused_colsum && a.colsum) { launch_colsum(a.B, a.colsum, a.P, a.Bdim, s); b.colsum = nullptr; }
+    b.plain_store = 0;
+    if (a.c_uninitialized) {            // the caller did not zero C: store directly when every tile has a single writer, else zero it here
+        if (splits == 1 && WK == 1) b.plain_store = 1;
+        else hipMemsetAsync(a.C, 0, (size_t)a.ntaps * a.Areal * a.ldc * sizeof(float), s);
+    }
     static const std::string tag = "wgrad_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ">";
     g_last_kernel = tag.c_str();
     if (fast) hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK, true, fused_colsum>), grid, dim3(256), 0, s, b, (int)chunk);

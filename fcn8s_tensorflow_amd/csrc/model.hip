@@ -318,10 +318,9 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             g.N = 1; g.Pa = 1; g.Pb = (int)T; g.P = T;
             g.Ha = 1; g.Wa = (int)T; g.Adim = Kg; g.lda = Kg; g.Areal = Kg;
             g.Bdim = Cout; g.ldb = Cout; g.KW = 1; g.a_scale = 1; g.tap_off = 0; g.ntaps = NP; g.ldc = Cout; g.alpha = 1.f; g.colsum = nullptr;
-            g.batched = 1; g.a_batch_stride = T * Kg; g.b_batch_stride = T * Cout;
+            g.batched = 1; g.a_batch_stride = T * Kg; g.b_batch_stride = T * Cout; g.c_uninitialized = 1;
             { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout + (double)NP * T * Cout));
-              launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s);
-              hipMemsetAsync(m->d_wino_u, 0, (size_t)NP * Kg * Cout * sizeof(float), s); }
+              launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s); }
             { ProfScope ps(m, K == 7 ? "wino_gemm_fc6_wgrad" : "wino_gemm_wgrad", 2.0 * NP * T * Kg * Cout, 4.0 * NP * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_wgrad(g, s); }
             { ProfScope ps(m, "wino_transform", 0, 4.0 * (9.0 + NP) * Cin * Cout + 4.0 * N * H * W * Cout);
               launch_wino_dfilter(tile, m->d_wino_u, dw, Cin, Cout, K, s);
