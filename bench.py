@@ -75,7 +75,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--optimizer", default="adam", choices=["adam", "sgd"])
+    ap.add_argument("--optimizer", default="sgd", choices=["adam", "sgd"],
+                    help="sgd = SGD+momentum as BASELINE.json config 3 names; adam = TF-Adam, the reference's own optimizer "
+                         "(fcn8s_tensorflow.py:256) -- same step time to 0.1 %")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL); 'gloo' lets the "

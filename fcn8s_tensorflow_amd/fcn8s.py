@@ -53,6 +53,12 @@ from .engine import Engine
 _SAVERS = {'saved_model', 'train_saver'}
 
 
+def _check_metric_names(metrics):
+    for metric in metrics:
+        if metric not in ('loss', 'mean_iou', 'accuracy'):
+            raise ValueError("{} is not a valid metric. Valid metrics are ['loss', mean_iou', 'accuracy']".format(metric))
+
+
 class FCN8s:
 
     def __init__(self, model_load_dir=None, tags=None, vgg16_dir=None, num_classes=None, variables_load_dir=None,
@@ -153,19 +159,12 @@ class FCN8s:
 
     def _initialize_metrics(self, metrics):
         '''fcn8s_tensorflow.py:371-397'''
-        self.metric_names = []
-        self.best_metric_values = []
-        self.metric_update_ops = []
-        self.metric_value_tensors = []
-        if 'loss' in metrics:
-            self.metric_names.append('loss'); self.best_metric_values.append(99999999.9)
-            self.metric_update_ops.append('mean_loss_update_op'); self.metric_value_tensors.append('mean_loss_value')
-        if 'mean_iou' in metrics:
-            self.metric_names.append('mean_iou'); self.best_metric_values.append(0.0)
-            self.metric_update_ops.append('mean_iou_update_op'); self.metric_value_tensors.append('mean_iou_value')
-        if 'accuracy' in metrics:
-            self.metric_names.append('accuracy'); self.best_metric_values.append(0.0)
-            self.metric_update_ops.append('acc_update_op'); self.metric_value_tensors.append('acc_value')
+        table = (('loss', 99999999.9, 'mean_loss'), ('mean_iou', 0.0, 'mean_iou'), ('accuracy', 0.0, 'acc'))
+        chosen = [row for row in table if row[0] in metrics]
+        self.metric_names = [name for name, _, _ in chosen]
+        self.best_metric_values = [worst for _, worst, _ in chosen]
+        self.metric_update_ops = [stem + '_update_op' for _, _, stem in chosen]      # names only: there is no graph
+        self.metric_value_tensors = [stem + '_value' for _, _, stem in chosen]
 
     def train(self,
               train_generator,
@@ -195,121 +194,94 @@ class FCN8s:
         '''Trains the model; arguments as fcn8s_tensorflow.py:424-503.  Summaries are written as
         JSON lines (`<summaries_dir>/<summaries_name>/scalars.jsonl`) instead of TensorBoard
         event files; if `summaries_dir` is None nothing is recorded.'''
-        if not eval_dataset in ['train', 'val']:
+        _check_metric_names(metrics)
+        if eval_dataset not in ('train', 'val'):
             raise ValueError("`eval_dataset` must be one of 'train' or 'val', but is '{}'.".format(eval_dataset))
-
-        if (eval_dataset == 'val') and ((val_generator is None) or (val_steps is None)):
+        if eval_dataset == 'val' and (val_generator is None or val_steps is None):
             raise ValueError("When eval_dataset == 'val', a `val_generator` and `val_steps` must be passed.")
-
-        for metric in metrics:
-            if not metric in ['loss', 'mean_iou', 'accuracy']:
-                raise ValueError("{} is not a valid metric. Valid metrics are ['loss', mean_iou', 'accuracy']".format(metric))
-
-        if (not monitor in metrics) and (not monitor == 'loss'):
+        if monitor != 'loss' and monitor not in metrics:
             raise ValueError('You are trying to monitor {}, but it is not in `metrics` and is therefore not being computed.'.format(monitor))
 
         self.eval_dataset = eval_dataset
-
-        self.g_step = self.engine.global_step
-        learning_rate = learning_rate_schedule(self.g_step)
-
         self._initialize_metrics(metrics)
+        self.g_step = self.engine.global_step
+        self._lr = learning_rate_schedule(self.g_step)       # the schedule is called once here and once after every step (:527, :583)
 
-        training_writer = evaluation_writer = None
+        train_log = eval_log = None
         if record_summaries and summaries_dir is not None and self.engine.rank == 0:
-            training_writer = _ScalarLog(os.path.join(summaries_dir, summaries_name or 'training'))
-            if len(metrics) > 0:
-                evaluation_writer = _ScalarLog(os.path.join(summaries_dir, (summaries_name or 'training') + '_eval'))
+            run = summaries_name or 'training'
+            train_log = _ScalarLog(os.path.join(summaries_dir, run))
+            if metrics:
+                eval_log = _ScalarLog(os.path.join(summaries_dir, run + '_eval'))
+
+        eval_source = {'train': (train_generator, steps_per_epoch, 'Evaluation on training dataset'),
+                       'val': (val_generator, val_steps, 'Evaluation on validation dataset')}[eval_dataset]
 
         for epoch in range(1, epochs + 1):
+            self._run_epoch(train_generator, steps_per_epoch, learning_rate_schedule, keep_prob, l2_regularization,
+                            'Epoch {}/{}'.format(epoch, epochs), training_loss_display_averaging,
+                            train_log, summaries_frequency)
+            eval_epoch = epoch % eval_frequency == 0
 
-            loss_history = deque(maxlen=training_loss_display_averaging)
+            if metrics and eval_epoch:
+                generator, num_batches, description = eval_source
+                self._evaluate(generator, metrics, num_batches, l2_regularization, description)
+                if eval_log is not None:
+                    eval_log.add(self.g_step, **dict(zip(self.metric_names, self.metric_values)))
 
-            tr = trange(steps_per_epoch, file=sys.stdout, disable=self.engine.rank != 0)
-            tr.set_description('Epoch {}/{}'.format(epoch, epochs))
+            if save_during_training and epoch % save_frequency == 0 and self._wants_save(save_best_only, monitor):
+                self.save(model_save_dir=save_dir, saver=saver, tags=save_tags, name=save_name,
+                          include_global_step=True, include_last_training_loss=True,
+                          include_metrics=bool(self.metric_names))
 
-            for train_step in tr:
-
-                batch_images, batch_labels = next(train_generator)
-
-                current_loss, self.g_step = self.engine.train_step(batch_images, batch_labels,
-                                                                   learning_rate=learning_rate,
-                                                                   keep_prob=keep_prob,
-                                                                   l2_rate=l2_regularization)
-                if training_writer is not None and ((self.g_step - 1) % summaries_frequency == 0):
-                    training_writer.add(self.g_step, total_loss=current_loss, learning_rate=learning_rate)
-
-                self.variables_updated = True
-
-                loss_history.append(current_loss)
-                losses = np.array(loss_history)
-                self.training_loss = np.mean(losses)
-
-                tr.set_postfix(ordered_dict={'loss': self.training_loss,
-                                             'learning rate': learning_rate})
-
-                learning_rate = learning_rate_schedule(self.g_step)
-
-            if (len(metrics) > 0) and (epoch % eval_frequency == 0):
-
-                if eval_dataset == 'train':
-                    data_generator = train_generator
-                    num_batches = steps_per_epoch
-                    description = 'Evaluation on training dataset'
-                elif eval_dataset == 'val':
-                    data_generator = val_generator
-                    num_batches = val_steps
-                    description = 'Evaluation on validation dataset'
-
-                self._evaluate(data_generator=data_generator,
-                               metrics=metrics,
-                               num_batches=num_batches,
-                               l2_regularization=l2_regularization,
-                               description=description)
-
-                if evaluation_writer is not None:
-                    evaluation_writer.add(self.g_step, **dict(zip(self.metric_names, self.metric_values)))
-
-            if save_during_training and (epoch % save_frequency == 0):
-
-                save = False
-                if save_best_only:
-                    if (monitor == 'loss' and
-                        (not 'loss' in self.metric_names) and
-                        self.training_loss < self.best_training_loss):
-                        save = True
-                    else:
-                        i = self.metric_names.index(monitor)
-                        if (monitor == 'loss') and (self.metric_values[i] < self.best_metric_values[i]):
-                            save = True
-                        elif (monitor in ['accuracry', 'mean_iou']) and (self.metric_values[i] > self.best_metric_values[i]):
-                            save = True          # ('accuracry': the reference's spelling, :626 -- accuracy never triggers a save there either)
-                    if save:
-                        print('New best {} value, saving model.'.format(monitor))
-                    else:
-                        print('No improvement over previous best {} value, not saving model.'.format(monitor))
-                else:
-                    save = True
-
-                if save:
-                    self.save(model_save_dir=save_dir,
-                              saver=saver,
-                              tags=save_tags,
-                              name=save_name,
-                              include_global_step=True,
-                              include_last_training_loss=True,
-                              include_metrics=(len(self.metric_names) > 0))
-
-            if self.training_loss < self.best_training_loss:
-                self.best_training_loss = self.training_loss
-
-            if epoch % eval_frequency == 0:
-
-                for i, metric_name in enumerate(self.metric_names):
-                    if (metric_name == 'loss') and (self.metric_values[i] < self.best_metric_values[i]):
+            # Bests are updated after the save decision (fcn8s_tensorflow.py:648-658).
+            self.best_training_loss = min(self.best_training_loss, self.training_loss)
+            if eval_epoch:
+                for i, name in enumerate(self.metric_names):
+                    if self._improved(name, i):
                         self.best_metric_values[i] = self.metric_values[i]
-                    elif (metric_name in ['accuracry', 'mean_iou']) and (self.metric_values[i] > self.best_metric_values[i]):
-                        self.best_metric_values[i] = self.metric_values[i]
+
+    def _run_epoch(self, generator, steps, schedule, keep_prob, l2_rate, title, window, log, log_every):
+        '''One epoch of train steps (fcn8s_tensorflow.py:542-590): a step runs with the schedule's value
+        at the global step before it; `training_loss` is the mean over the last `window` steps.'''
+        recent = deque(maxlen=window)
+        bar = trange(steps, file=sys.stdout, disable=self.engine.rank != 0)
+        bar.set_description(title)
+        for _ in bar:
+            lr = self._lr
+            images, labels = next(generator)
+            loss, self.g_step = self.engine.train_step(images, labels, learning_rate=lr, keep_prob=keep_prob, l2_rate=l2_rate)
+            self.variables_updated = True
+            if log is not None and (self.g_step - 1) % log_every == 0:
+                log.add(self.g_step, total_loss=loss, learning_rate=lr)
+            recent.append(loss)
+            self.training_loss = float(np.mean(recent))
+            bar.set_postfix(ordered_dict={'loss': self.training_loss, 'learning rate': lr})
+            self._lr = schedule(self.g_step)
+
+    def _improved(self, name, i):
+        '''Whether metric `i` beat its best.  The reference compares the name against
+        ['accuracry', 'mean_iou'] (fcn8s_tensorflow.py:626,:656), so 'accuracy' never counts as an
+        improvement there; kept, because `best_metric_values` and save decisions depend on it.'''
+        if name == 'loss':
+            return self.metric_values[i] < self.best_metric_values[i]
+        if name == 'mean_iou':
+            return self.metric_values[i] > self.best_metric_values[i]
+        return False
+
+    def _wants_save(self, best_only, monitor):
+        '''Save decision of fcn8s_tensorflow.py:612-634.'''
+        if not best_only:
+            return True
+        if monitor == 'loss' and 'loss' not in self.metric_names:
+            better = self.training_loss < self.best_training_loss
+        else:
+            better = self._improved(monitor, self.metric_names.index(monitor))
+        if better:
+            print('New best {} value, saving model.'.format(monitor))
+        else:
+            print('No improvement over previous best {} value, not saving model.'.format(monitor))
+        return better
 
     def _evaluate(self, data_generator, metrics, num_batches, l2_regularization, description='Running evaluation'):
         '''fcn8s_tensorflow.py:660-697'''
@@ -326,29 +298,17 @@ class FCN8s:
         values = dict(zip(('loss', 'mean_iou', 'accuracy'), self.engine.metrics_get()))
         self.metric_values = [values[n] for n in self.metric_names]
 
-        evaluation_results_string = ''
-        for i, metric_name in enumerate(self.metric_names):
-            evaluation_results_string += metric_name + ': {:.4f}  '.format(self.metric_values[i])
         if self.engine.rank == 0:
-            print(evaluation_results_string)
+            print(''.join('{}: {:.4f}  '.format(n, v) for n, v in zip(self.metric_names, self.metric_values)))
 
     def evaluate(self, data_generator, num_batches, metrics={'loss', 'mean_iou', 'accuracy'}, l2_regularization=0.0, dataset='val'):
         '''fcn8s_tensorflow.py:699-741'''
-        for metric in metrics:
-            if not metric in ['loss', 'mean_iou', 'accuracy']:
-                raise ValueError("{} is not a valid metric. Valid metrics are ['loss', mean_iou', 'accuracy']".format(metric))
-
-        if not dataset in {'train', 'val'}:
+        _check_metric_names(metrics)
+        if dataset not in ('train', 'val'):
             raise ValueError("`dataset` must be either 'train' or 'val'.")
-
         self._initialize_metrics(metrics)
-
         self._evaluate(data_generator, metrics, num_batches, l2_regularization, description='Running evaluation')
-
-        if dataset == 'val':
-            self.eval_dataset = 'val'
-        else:
-            self.eval_dataset = 'train'
+        self.eval_dataset = dataset
 
     def predict(self, images, argmax=True):
         '''fcn8s_tensorflow.py:743-770.  `images`: array-like of rank 4 (a list of HWC arrays works).
