@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--optimizer", default="sgd", choices=["adam", "sgd"],
                     help="sgd = SGD+momentum as BASELINE.json config 3 names; adam = TF-Adam, the reference's own optimizer "
-                         "(fcn8s_tensorflow.py:256) -- same step time to 0.1 %")
+                         "(fcn8s_tensorflow.py:256) -- same step time to within 0.1 percent")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL); 'gloo' lets the "
