@@ -1,16 +1,53 @@
 """BASELINE.json's full-size configurations on the GPU.
 
+config 1: one 256x256 image, forward + argmax -- the CPU oracle stands where the TF1 CPU path stood.
 config 2: 1024x512 bs1 fp32 inference -- logits within 1e-3 of the CPU oracle, per-pixel argmax identical
           wherever the oracle's top-2 logit gap exceeds twice that tolerance.
 config 3: 1024x512 bs16 training step -- too large for the CPU oracle in a test, so it is checked through
           size-independent properties: closed-form loss / bias gradient at zero decoder weights, batch
-          linearity of the gradients (what data-parallel training relies on), and determinism of the forward."""
+          linearity of the gradients (what data-parallel training relies on), and determinism of the forward.
+config 5 (shape): 2048x1024, 4 images per GPU (global 32 over 8 GPUs) -- same properties at that size."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 from oracle import fcn8s_oracle as orc  # noqa: E402  (checker only)
+
+
+def _check_inference(e, P, img, tol=1e-3):
+    e.set_params(P)
+    pred = e.predict(img, argmax=True)
+    n, h, w = img.shape[:3]
+    logits = e.activation("logits", (n, h, w, 20))
+    ref = orc.forward(P, img)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert float(np.abs(logits - ref).max()) < tol * scale
+    srt = np.sort(ref, -1)
+    safe = (srt[..., -1] - srt[..., -2]) > 2 * tol * scale
+    ref_arg = np.argmax(orc.softmax(ref), -1)
+    assert pred.dtype == np.int64 and pred.shape == (n, h, w)
+    assert (pred[safe] == ref_arg[safe]).all(), int((pred[safe] != ref_arg[safe]).sum())
+    return safe.mean(), (pred != ref_arg).mean()
+
+
+def test_config1_single_256x256_image_forward_argmax():
+    from fcn8s_tensorflow_amd.engine import Engine
+    rng = np.random.default_rng(7)                                               # c1 = one 256x256 image, seed 7
+    img = rng.integers(0, 256, (1, 256, 256, 3), dtype=np.uint8)
+    e = Engine(20)
+    safe, differ = _check_inference(e, orc.init_params(20, seed=0, decoder_std_scale=30.0, bias_std=0.05), img)
+    assert safe > 0.95 and differ < 1e-3
+    # the softmax output (what predict(argmax=False) returns, fcn8s_tensorflow.py:268) against the oracle's
+    # (decoder scaled so that the logits are O(1): a saturated softmax would turn logit round-off into 0/1 flips)
+    P = orc.init_params(20, seed=1, decoder_std_scale=5.0, bias_std=0.05)
+    e.set_params(P)
+    sm = e.predict(img, argmax=False)
+    ref = orc.forward(P, img)
+    assert 0.05 < float(np.abs(ref).max()) < 50.0
+    assert sm.shape == (1, 256, 256, 20) and np.abs(sm.sum(-1) - 1).max() < 1e-5
+    assert np.abs(sm - orc.softmax(ref)).max() < 1e-3
+    e.close()
 
 
 def test_config2_inference_1024x512_bs1_vs_oracle():
@@ -98,4 +135,43 @@ def test_config3_training_step_1024x512_bs16_properties():
         ratios.append((l0 - l1) / target)
     e.flat_params.copy_(theta)
     assert any(0.75 < r < 1.25 for r in ratios[1:]), ratios
+    e.close()
+
+
+def test_config5_shape_2048x1024_bs4_properties():
+    import torch
+    from fcn8s_tensorflow_amd.engine import Engine
+    N, H, W, C = 4, 1024, 2048, 20
+    e = Engine(C, seed=5)
+    img, lab = orc.synthetic_batch(N, H, W)
+    imgd, labd = torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda()
+    e.init_params(seed=0)
+    zero = {k: np.zeros(s[0], np.float32) for k, s in e.specs.items() if "1x1" in k or "trans" in k}
+    e.set_params(zero)
+    loss = e.forward_backward(imgd, labd, keep_prob=1.0)
+    assert abs(loss - np.log(C)) < 1e-5
+    gb = e.grad_view("fc7_pool4_pool3_conv2d_trans/bias").cpu().numpy()
+    assert np.abs(gb - (1.0 / C - np.bincount(lab.ravel(), minlength=C) / lab.size)).max() < 1e-6
+
+    e.init_params(seed=2)
+    e.forward_backward(imgd, labd, keep_prob=1.0)
+    g_full = e.flat_grads.clone()
+    e.forward_backward(imgd[:2], labd[:2], keep_prob=1.0)
+    g_a = e.flat_grads.clone()
+    e.forward_backward(imgd[2:], labd[2:], keep_prob=1.0)
+    g_mean = 0.5 * (g_a + e.flat_grads)
+    for name in ("conv1_2/filter", "conv4_1/filter", "fc6/weights", "fc7/biases", "fc7_1x1/kernel", "fc7_pool4_conv2d_trans/kernel"):
+        shape, off = e.specs[name]
+        n = int(np.prod(shape))
+        a, b = g_full[off:off + n], g_mean[off:off + n]
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-12, name
+
+    # a quarter of one image equals the same crop run on its own wherever the receptive field stays inside it:
+    # not true for a conv net with SAME padding in general, so instead check translation of the batch axis --
+    # image k of the batch gives the same prediction as image k alone
+    full = e.predict(imgd, argmax=True)
+    one = e.predict(imgd[3:4], argmax=True)
+    assert float((torch.as_tensor(full[3:4]) != torch.as_tensor(one)).float().mean()) < 1e-4
+    loss, step = e.train_step(imgd, labd, 1e-4, keep_prob=0.5)
+    assert np.isfinite(loss) and step == 1
     e.close()
