@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--optimizer", default="sgd", choices=["adam", "sgd"],
                     help="sgd = SGD+momentum as BASELINE.json config 3 names; adam = TF-Adam, the reference's own optimizer "
                          "(fcn8s_tensorflow.py:256) -- same step time to within 0.1 percent")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc"],
+                    help="fp32 = the reference's arithmetic (the headline number); bf16_fc = BASELINE config 5's mode (forward "
+                         "fc6/fc7 with bf16 operands on the bf16 MFMA, fp32 accumulate) -- reported as dtype 'bf16_fc+f32'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL); 'gloo' lets the "
@@ -112,7 +115,7 @@ def main():
             print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
     N, H, W = args.batch, args.height, args.width
     mark("process group up; creating engine")
-    eng = Engine(20, device_id=dev, seed=1234 + rank)
+    eng = Engine(20, device_id=dev, seed=1234 + rank, precision=args.precision)
     eng.init_params(seed=0)                       # He-normal VGG, reference decoder init (same on every rank)
     mark("broadcast params")
     eng.broadcast_params(0)
@@ -189,7 +192,7 @@ def main():
             "metric": "training images/sec at 1024x512 bs16" if args.mode == "train" else "inference images/sec at 1024x512",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "fp32" else "bf16_fc+f32", "data": "synthetic",
             "config": {"workload": "FCN-8s (VGG-16, fc6 7x7, 20 classes) %s step, %dx%d, %d images/GPU, %s, keep_prob 0.5"
                                    % (args.mode, W, H, N, "TF-Adam" if args.optimizer == "adam" else "SGD+momentum"),
                        "global_batch": N * world, "parallelism": "dp%d" % world},

@@ -16,6 +16,7 @@ HOST, DEVICE = 0, 1
 IMG_U8, IMG_F32 = 0, 1
 OPT_TF_ADAM, OPT_SGD_MOMENTUM, OPT_NONE = 0, 1, 2
 NUM_BUCKETS = 3
+PREC_F32, PREC_BF16_FC = 0, 1
 
 
 class Config(C.Structure):
@@ -63,6 +64,8 @@ SIGNATURES = {
     "fcn8s_set_global_step": (_i, [_p, _i64]),
     "fcn8s_get_opt_state": (_i, [_p, _p, _p, _sz]),
     "fcn8s_set_opt_state": (_i, [_p, _p, _p, _sz]),
+    "fcn8s_set_precision": (_i, [_p, _i]),
+    "fcn8s_get_precision": (_i, [_p]),
     "fcn8s_get_activation": (_i, [_p, C.c_char_p, _p, _sz]),
     "fcn8s_get_dropout_masks": (_i, [_p, _p, _sz, _p, _sz]),
     "fcn8s_crc32c": (C.c_uint32, [_p, _sz, C.c_uint32]),
@@ -73,6 +76,7 @@ SIGNATURES = {
     "fcn8s_op_preprocess": (_i, [_p, _p, _i, _p, _i64]),
     "fcn8s_op_conv2d": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_conv2d_winograd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "fcn8s_op_conv2d_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_conv2d_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_maxpool2x2": (_i, [_p, _p, _p, _i, _i, _i, _i]),
     "fcn8s_op_maxpool2x2_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i]),

@@ -40,6 +40,20 @@ struct IgemmArgs {
 void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s);
 
 // ---------------------------------------------------------------------------
+// bf16-operand / fp32-accumulate SAME conv (stride 1, odd K) on v_mfma_f32_32x32x16_bf16 -- the optional fc6 / fc7
+// precision mode (gemm_bf16.hip).  x: fp32 NHWC; wt: bf16 K-tile-major blocks written by launch_w_to_bf16_tiles from the
+// fp32 HWIO kernel; y: fp32.  Needs Cin % 32 == 0, Cout % 128 == 0 (launch returns false otherwise).
+// ---------------------------------------------------------------------------
+struct Bf16ConvArgs {
+    const float* x; const unsigned short* wt; const float* bias; float* y;
+    int N, H, W, Cin, Cout, K;
+    int relu, dropout; float keep_prob; unsigned long long seed; unsigned int stream_id;
+    long long M; int m_fastest;        // filled in by the launcher
+};
+void launch_w_to_bf16_tiles(const float* w, unsigned short* wt, int K, int Cout, hipStream_t s);   // w[K][Cout] -> wt[K/32][Cout][32]
+bool launch_conv_bf16(const Bf16ConvArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------------------
 // Weight-gradient GEMM on the f32 MFMA:
 //   C[tap][i][j] += alpha * sum_p A[srcA(p, tap), i] * B[p, j]
 // p runs over the (N, Pa, Pb) pixel grid of B; srcA = (n, a_scale*a + dy, a_scale*b + dx).

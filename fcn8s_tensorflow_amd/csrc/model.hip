@@ -58,6 +58,8 @@ struct fcn8s_model {
     int wino_min_cin = 64;                                              // 3x3 layers with Cin >= this use Winograd; 0 = never
     int wino_tile = 4;                                                    // F(4x4,3x3) where H, W % 4 == 0, else F(2x2,3x3)
     int wino_fc6 = 1;                                                     // fc6 7x7 as nine 3x3 sub-filters in the Winograd domain
+    int precision = FCN8S_PREC_F32;                                       // FCN8S_PREC_BF16_FC: forward fc6 / fc7 on the bf16 MFMA
+    unsigned short* d_wbf16 = nullptr;                                    // bf16 K-tile-major copy of the fc6 / fc7 kernel (one at a time)
     hipStream_t stream = nullptr;
     int64_t step = 0;
     // workspace for the current (N,H,W)
@@ -505,13 +507,37 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     const int h5 = h, w5 = w;
     const bool drop = train && keep_prob < 1.f;
     m->drop_stream = (uint32_t)(2 * m->step);
-    {
-        Epi e; e.bias = Wp(m, "fc6/biases"); e.relu = 1; e.dropout = drop; e.keep = keep_prob; e.stream_id = m->drop_stream;
-        conv_same(m, "fc6_fwd", x, Wp(m, "fc6/weights"), A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, e, s, 0, "fc6");
-    }
-    {
-        Epi e; e.bias = Wp(m, "fc7/biases"); e.relu = 1; e.dropout = drop; e.keep = keep_prob; e.stream_id = m->drop_stream + 1;
-        conv_same(m, "fc7_fwd", A(m, "fc6"), Wp(m, "fc7/weights"), A(m, "fc7"), N, h5, w5, m->widths[5], m->widths[6], 1, e, s);
+    if (m->precision == FCN8S_PREC_BF16_FC) {
+        // config 5: bf16-rounded operands, fp32 accumulate, fp32 epilogue and output (gemm_bf16.hip)
+        auto fc = [&](const char* tag, const char* wname, const char* bname, const float* in, float* out, int cin, int cout, int k, uint32_t stream_id) {
+            const int K = k * k * cin;
+            { ProfScope ps(m, "weight_relayout", 0, 6.0 * K * cout); launch_w_to_bf16_tiles(Wp(m, wname), m->d_wbf16, K, cout, s); }
+            Bf16ConvArgs a{};
+            a.x = in; a.wt = m->d_wbf16; a.bias = Wp(m, bname); a.y = out;
+            a.N = N; a.H = h5; a.W = w5; a.Cin = cin; a.Cout = cout; a.K = k;
+            a.relu = 1; a.dropout = drop; a.keep_prob = keep_prob; a.seed = m->seed; a.stream_id = stream_id;
+            const double M = (double)N * h5 * w5;
+            ProfScope ps(m, tag, 2.0 * M * K * cout, 4.0 * M * (cin + cout) + 2.0 * K * cout);
+            launch_conv_bf16(a, s);
+        };
+        fc("fc6_fwd_bf16", "fc6/weights", "fc6/biases", x, A(m, "fc6"), m->widths[4], m->widths[5], m->fc6k, m->drop_stream);
+        if (train) {            // the fp32 weight gradient of fc6 runs in the Winograd domain and wants the transformed input
+            auto it = m->acts.find("wv:fc6");
+            if (it != m->acts.end()) {
+                ProfScope ps(m, "wino_transform", 0, 4.0 * N * h5 * w5 * m->widths[4] * (9 + 20.25));
+                launch_wino_input(4, x, it->second.p, N, h5, w5, m->widths[4], 7, s);
+            }
+        }
+        fc("fc7_fwd_bf16", "fc7/weights", "fc7/biases", A(m, "fc6"), A(m, "fc7"), m->widths[5], m->widths[6], 1, m->drop_stream + 1);
+    } else {
+        {
+            Epi e; e.bias = Wp(m, "fc6/biases"); e.relu = 1; e.dropout = drop; e.keep = keep_prob; e.stream_id = m->drop_stream;
+            conv_same(m, "fc6_fwd", x, Wp(m, "fc6/weights"), A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, e, s, 0, "fc6");
+        }
+        {
+            Epi e; e.bias = Wp(m, "fc7/biases"); e.relu = 1; e.dropout = drop; e.keep = keep_prob; e.stream_id = m->drop_stream + 1;
+            conv_same(m, "fc7_fwd", A(m, "fc6"), Wp(m, "fc7/weights"), A(m, "fc7"), N, h5, w5, m->widths[5], m->widths[6], 1, e, s);
+        }
     }
     // decoder (fcn8s_tensorflow.py:171-233)
     { Epi e; e.bias = Wp(m, "pool3_1x1/bias"); e.alpha = 0.0001f;
@@ -783,6 +809,7 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->d_wt) hipFree(m->d_wt);
     if (m->d_w1pad) hipFree(m->d_w1pad);
     if (m->d_wino_u) hipFree(m->d_wino_u);
+    if (m->d_wbf16) hipFree(m->d_wbf16);
     for (int i = 0; i < 3; ++i) if (m->d_tph[i]) hipFree(m->d_tph[i]);
     if (m->d_loss) hipFree(m->d_loss);
     if (m->d_conf) hipFree(m->d_conf);
@@ -792,6 +819,23 @@ int fcn8s_destroy(fcn8s_model* m)
 }
 
 const char* fcn8s_last_error(const fcn8s_model* m) { return m ? m->err.c_str() : g_last_error.c_str(); }
+
+int fcn8s_set_precision(fcn8s_model* m, int precision)
+{
+    if (!m) return FCN8S_ERR_BAD_ARG;
+    if (precision != FCN8S_PREC_F32 && precision != FCN8S_PREC_BF16_FC) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_precision: unknown precision");
+    if (precision == FCN8S_PREC_BF16_FC) {
+        if (m->widths[4] % 32 || m->widths[5] % 128 || m->widths[6] % 128)
+            return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_precision: BF16_FC needs conv5 width % 32 == 0 and fc6 / fc7 widths % 128 == 0");
+        if (!m->d_wbf16) {
+            const size_t n = std::max((size_t)m->fc6k * m->fc6k * m->widths[4] * m->widths[5], (size_t)m->widths[5] * m->widths[6]);
+            HIPCHK(m, hipMalloc((void**)&m->d_wbf16, n * sizeof(unsigned short)));
+        }
+    }
+    m->precision = precision;
+    return FCN8S_OK;
+}
+int fcn8s_get_precision(const fcn8s_model* m) { return m ? m->precision : -1; }
 
 int fcn8s_set_stream(fcn8s_model* m, void* s) { if (!m) return FCN8S_ERR_BAD_ARG; m->stream = (hipStream_t)s; return FCN8S_OK; }
 int fcn8s_synchronize(fcn8s_model* m) { if (!m) return FCN8S_ERR_BAD_ARG; HIPCHK(m, hipStreamSynchronize(m->stream)); return FCN8S_OK; }
@@ -1151,6 +1195,21 @@ int fcn8s_op_conv2d_winograd(void* stream, const float* x, const float* w, const
     WinoEpi we; we.bias = bias; we.relu = relu;
     conv_winograd(nullptr, tile, K, "", x, w, y, u, v, mm, N, H, W, Cin, Cout, we, s, nullptr);
     hipStreamSynchronize(s); hipFree(u); hipFree(v); hipFree(mm);
+    OPCHK(); return FCN8S_OK;
+}
+
+int fcn8s_op_conv2d_bf16(void* stream, const float* x, const float* w, const float* bias, float* y,
+                         int N, int H, int W, int Cin, int Cout, int K, int relu)
+{
+    if (Cin % 32 || Cout % 128 || K % 2 == 0) return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d_bf16: needs Cin % 32 == 0, Cout % 128 == 0, K odd");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned short* wt = nullptr;
+    if (hipMalloc((void**)&wt, (size_t)K * K * Cin * Cout * 2) != hipSuccess) return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc");
+    launch_w_to_bf16_tiles(w, wt, K * K * Cin, Cout, s);
+    Bf16ConvArgs a{};
+    a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K = K; a.relu = relu;
+    launch_conv_bf16(a, s);
+    hipStreamSynchronize(s); hipFree(wt);
     OPCHK(); return FCN8S_OK;
 }
 

@@ -28,7 +28,7 @@ def _dist():
 
 
 class Engine:
-    def __init__(self, num_classes, widths=None, fc6_ksize=7, device_id=0, seed=0, process_group=None):
+    def __init__(self, num_classes, widths=None, fc6_ksize=7, device_id=0, seed=0, process_group=None, precision='fp32'):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("fcn8s_tensorflow_amd needs an AMD GPU (gfx950); there is no CPU fallback for the hot path")
@@ -55,6 +55,7 @@ class Engine:
         L.check(L.lib.fcn8s_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self.widths = tuple(widths) if widths else (64, 128, 256, 512, 512, 4096, 4096)
+        self.set_precision(precision)
         self.specs = OrderedDict()          # name -> (shape, offset)
         for i in range(L.lib.fcn8s_num_params(self.h)):
             name = C.c_char_p(); nd = C.c_int32(); shp = (C.c_int64 * 4)(); off = C.c_int64()
@@ -246,6 +247,15 @@ class Engine:
         return (ka_i, a), pi, dt, a.ctypes.data_as(C.c_void_p), where, nhw
 
     # ---- hot path ----------------------------------------------------------------------------
+    def set_precision(self, precision):
+        """'fp32' (the reference's arithmetic) or 'bf16_fc' (BASELINE config 5: forward fc6 / fc7 with bf16-rounded
+        operands on the bf16 MFMA, fp32 accumulation; the rest of the step stays fp32)."""
+        modes = {'fp32': L.PREC_F32, 'bf16_fc': L.PREC_BF16_FC}
+        if precision not in modes:
+            raise ValueError("`precision` must be 'fp32' or 'bf16_fc', but is '{}'.".format(precision))
+        L.check(L.lib.fcn8s_set_precision(self.h, modes[precision]), self.h)
+        self.precision = precision
+
     def train_step(self, images, labels, learning_rate, keep_prob=0.5, l2_rate=0.0,
                    optimizer=L.OPT_TF_ADAM, fetch_loss=True):
         """sess.run([train_op, total_loss, global_step]) (fcn8s_tensorflow.py:554-572)."""

@@ -50,6 +50,10 @@ extern "C" {
 
 #define FCN8S_NUM_BUCKETS 3       /* gradient buckets in backward-production order */
 
+#define FCN8S_PREC_F32     0      /* everything exact fp32 (the reference's arithmetic; default) */
+#define FCN8S_PREC_BF16_FC 1      /* BASELINE.json config 5: the forward fc6 / fc7 contractions take bf16-rounded operands on the
+                                     bf16 MFMA with fp32 accumulation; everything else, and the whole backward pass, stays fp32 */
+
 typedef struct fcn8s_model fcn8s_model;
 
 typedef struct fcn8s_config {
@@ -137,6 +141,11 @@ int     fcn8s_set_opt_state(fcn8s_model* m, const float* host_m, const float* ho
 
 /* ---- introspection for parity tests ----------------------------------------- *
  * names: "pool3","pool4","fc7","logits", "conv1_1"... (post-ReLU activations)     */
+/* Arithmetic of the forward fc6 / fc7 layers (FCN8S_PREC_*); not in the reference, which is fp32 throughout.
+ * BF16_FC needs fc6/fc7 widths that are multiples of 128 and a conv5 width that is a multiple of 32 (BAD_ARG otherwise). */
+int fcn8s_set_precision(fcn8s_model* m, int precision);
+int fcn8s_get_precision(const fcn8s_model* m);
+
 int fcn8s_get_activation(fcn8s_model* m, const char* name, float* host, size_t nfloats);
 int fcn8s_get_dropout_masks(fcn8s_model* m, float* host_mask6, size_t n6, float* host_mask7, size_t n7);
 
@@ -162,6 +171,10 @@ int fcn8s_op_conv2d(void* stream, const float* x, const float* w_hwio, const flo
  * layers; K = 7 runs fc6's decomposition into nine 3x3 sub-filters; H, W multiples of tile) */
 int fcn8s_op_conv2d_winograd(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,
                              int N, int H, int W, int Cin, int Cout, int K, int relu, int tile);
+/* the same SAME conv with bf16-rounded operands and fp32 accumulation on the bf16 MFMA (FCN8S_PREC_BF16_FC's kernel);
+ * Cin % 32 == 0, Cout % 128 == 0, K odd */
+int fcn8s_op_conv2d_bf16(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,
+                         int N, int H, int W, int Cin, int Cout, int K, int relu);
 int fcn8s_op_conv2d_bwd(void* stream, const float* x, const float* w_hwio, const float* dy,
                         float* dx, float* dw, float* db,
                         int N, int H, int W, int Cin, int Cout, int K);

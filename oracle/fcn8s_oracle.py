@@ -172,9 +172,26 @@ def dropout_t(x, keep_prob, mask):
 # The graph
 # ----------------------------------------------------------------------------
 
-def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False):
+def _bf16_round(t):
+    """Round-to-nearest-even to bfloat16 and back (what v_cvt_pk_bf16_f32 does to an MFMA operand)."""
+    return t.detach().to(torch.bfloat16).to(t.dtype)
+
+
+def _fc_conv(x, w, b, bf16):
+    """fc6 / fc7: SAME conv + bias + ReLU.  bf16: the forward VALUE is the contraction of the bf16-rounded operands
+    (fp32 products and sums); the backward pass is the fp32 conv gradient taken with the unrounded operands -- the
+    mode only changes the forward arithmetic (BASELINE config 5: "bf16 fwd / fp32 accum")."""
+    if not bf16:
+        return conv2d_same_t(x, w, b, relu=True)
+    z = conv2d_same_t(x, w, b)
+    z = z + (conv2d_same_t(_bf16_round(x), _bf16_round(w), b.detach()) - z).detach()
+    return F.relu(z)
+
+
+def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False):
     """Forward pass on torch tensors.  P: name -> torch tensor (TF layouts).
     images_t: NHWC RGB float.  masks: optional (mask6, mask7) NHWC tensors.
+    bf16_fc: BASELINE config 5 -- both operands of the fc6 / fc7 contractions rounded to bfloat16, fp32 accumulate.
     Returns logits NCHW (and the activation dict when keep=True)."""
     acts = OrderedDict()
     x = _nchw(preprocess_t(images_t))
@@ -192,11 +209,11 @@ def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False):
     m6 = m7 = None
     if masks is not None:
         m6, m7 = (_nchw(m) for m in masks)
-    x = conv2d_same_t(x, P["fc6/weights"], P["fc6/biases"], relu=True)
+    x = _fc_conv(x, P["fc6/weights"], P["fc6/biases"], bf16_fc)
     x = dropout_t(x, keep_prob, m6)
     if keep:
         acts["fc6"] = x
-    x = conv2d_same_t(x, P["fc7/weights"], P["fc7/biases"], relu=True)
+    x = _fc_conv(x, P["fc7/weights"], P["fc7/biases"], bf16_fc)
     x = dropout_t(x, keep_prob, m7)
     if keep:
         acts["fc7"] = x
@@ -230,12 +247,12 @@ def _params_t(params, dtype, requires_grad=False):
     return OrderedDict((k, _t(v, dtype).requires_grad_(requires_grad)) for k, v in params.items())
 
 
-def forward(params, images, keep_prob=1.0, masks=None, dtype=torch.float32, keep=False):
+def forward(params, images, keep_prob=1.0, masks=None, dtype=torch.float32, keep=False, bf16_fc=False):
     """numpy front-end.  Returns logits NHWC (and activations NHWC if keep)."""
     with torch.no_grad():
         P = _params_t(params, dtype)
         mt = None if masks is None else tuple(_t(m, dtype) for m in masks)
-        out = forward_t(P, _t(images, dtype), keep_prob, mt, keep)
+        out = forward_t(P, _t(images, dtype), keep_prob, mt, keep, bf16_fc)
         if keep:
             logits, acts = out
             return _nhwc(logits).contiguous().numpy(), {k: _nhwc(v).contiguous().numpy() for k, v in acts.items()}
@@ -243,12 +260,12 @@ def forward(params, images, keep_prob=1.0, masks=None, dtype=torch.float32, keep
 
 
 def loss_and_grads(params, images, labels_onehot, l2_rate=0.0, keep_prob=1.0, masks=None,
-                   dtype=torch.float32):
+                   dtype=torch.float32, bf16_fc=False):
     """total_loss and d(total_loss)/d(every variable) -- what
     AdamOptimizer.minimize differentiates (var_list=None, :257)."""
     P = _params_t(params, dtype, requires_grad=True)
     mt = None if masks is None else tuple(_t(m, dtype) for m in masks)
-    logits = forward_t(P, _t(images, dtype), keep_prob, mt)
+    logits = forward_t(P, _t(images, dtype), keep_prob, mt, bf16_fc=bf16_fc)
     loss = total_loss_t(P, logits, _t(labels_onehot, dtype), l2_rate)
     grads = torch.autograd.grad(loss, list(P.values()))
     return (float(loss.detach()),

@@ -36,10 +36,10 @@ def pool_near_ties(P, img, tol=2e-5):
     return n
 
 
-def tie_free_case(widths, n, h, w, seed):
+def tie_free_case(widths, n, h, w, seed, decoder_std_scale=30.0):
     """First (params, images, labels) at or after `seed` without pool near-ties."""
     for s in range(seed, seed + 20):
-        P = orc.init_params(20, widths or orc.DEFAULT_WIDTHS, seed=s, decoder_std_scale=30.0, bias_std=0.05)
+        P = orc.init_params(20, widths or orc.DEFAULT_WIDTHS, seed=s, decoder_std_scale=decoder_std_scale, bias_std=0.05)
         img, lab = batch(n, h, w, seed=s + 100)
         if pool_near_ties(P, img) == 0:
             return P, img, lab
@@ -115,6 +115,55 @@ def test_dropout_statistics_and_parity(n, hw):
     for k in g_ref:
         assert rel(g[k], g_ref[k]) < 2e-3, k
     e.close()
+
+
+@pytest.mark.parametrize("widths,n,h,w", [(SMALL, 2, 64, 96), (SMALL, 1, 128, 128), (None, 1, 32, 64)])
+def test_bf16_fc_mode_config5(widths, n, h, w):
+    """BASELINE config 5's arithmetic: forward fc6 / fc7 on the bf16 MFMA (operands rounded to bfloat16, fp32
+    accumulate), everything else fp32.  Parity is against the oracle running the SAME rounding (logits 1e-3, gradients
+    2e-3, like the fp32 mode); the distance to the pure-fp32 oracle is what the mode costs and is only reported."""
+    # full width: a milder decoder than the fp32 tests use, so that the logits are O(1-10) -- with logits in the
+    # hundreds the softmax saturates and turns the 2e-4 bf16-boundary effect (below) into percent-level gradient changes
+    P, img, lab = tie_free_case(widths, n, h, w, seed=6, decoder_std_scale=30.0 if widths else 6.0)
+    e = make_engine(widths)
+    with pytest.raises(ValueError):
+        e.set_precision('fp16')
+    e.set_precision('bf16_fc')
+    e.set_params(P)
+    pred = e.predict(img, argmax=True)
+    logits = e.activation("logits", (n, h, w, 20))
+    ref, acts = orc.forward(P, img, keep=True, bf16_fc=True)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(logits - ref).max() < 1e-3 * scale
+    # (an input that differs from the oracle's by fp32 round-off can land on the other side of a bf16 rounding
+    #  boundary, a 2^-9 step for that operand -- hence 1e-3 here where the fp32 mode holds 1e-4)
+    assert rel(e.activation("fc7", acts["fc7"].shape), acts["fc7"]) < 1e-3
+    ok, _ = argmax_agree(pred, orc.softmax(ref))
+    assert ok
+    ref32 = orc.forward(P, img)
+    cost = float(np.abs(ref - ref32).max()) / scale
+    assert 1e-6 < cost < 5e-2, cost                      # bf16 rounding is visible, and small
+    assert np.abs(logits - ref32).max() > 0.2 * np.abs(ref - ref32).max()      # the GPU really took the bf16 path
+
+    onehot = orc.one_hot(lab, 20)
+    loss = e.forward_backward(img, onehot, keep_prob=1.0, l2_rate=1e-3)
+    loss_ref, g_ref, _ = orc.loss_and_grads(P, img, onehot.astype(np.float32), l2_rate=1e-3, bf16_fc=True)
+    assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    g = e.get_grads()
+    for k in g_ref:
+        assert rel(g[k], g_ref[k]) < 2e-3, (k, rel(g[k], g_ref[k]))
+
+    # dropout uses the same Philox stream in both precisions: the masks the library reports reproduce its loss
+    loss_d = e.forward_backward(img, lab, keep_prob=0.5)
+    m6, m7 = e.dropout_masks((n, h // 32, w // 32, e.widths[5]), (n, h // 32, w // 32, e.widths[6]))
+    loss_dref, _, _ = orc.loss_and_grads(P, img, onehot.astype(np.float32), keep_prob=0.5, masks=(m6, m7), bf16_fc=True)
+    assert abs(loss_d - loss_dref) < 1e-4 * max(1.0, abs(loss_dref))
+    # back to fp32: bit-identical to an engine that never left it
+    e.set_precision('fp32')
+    a = e.predict(img, argmax=False)
+    e2 = make_engine(widths); e2.set_params(P)
+    np.testing.assert_array_equal(a, e2.predict(img, argmax=False))
+    e.close(); e2.close()
 
 
 def test_tf_adam_training_steps():

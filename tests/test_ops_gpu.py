@@ -104,6 +104,33 @@ def test_conv7x7_winograd_subfilter_decomposition(N, H, W, Cin, Cout):
     test_conv3x3_winograd(N, H, W, Cin, Cout, 4, K=7)
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,K", [(1, 4, 8, 32, 128, 7), (2, 8, 16, 64, 256, 7), (3, 5, 7, 128, 128, 1), (1, 16, 32, 512, 384, 1),
+                                               (2, 3, 3, 32, 128, 3)])
+def test_conv_bf16_mfma(N, H, W, Cin, Cout, K):
+    """FCN8S_PREC_BF16_FC's kernel (config 5): operands rounded to bfloat16 (nearest-even), fp32 products and sums.
+    Against a float64 conv of the ROUNDED operands the only difference is fp32 summation order (1e-5); against the
+    unrounded conv it is the bf16 operand rounding, 2^-9 per operand (stated, not a parity bar)."""
+    L = _lib()
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((K, K, Cin, Cout)) / np.sqrt(K * K * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    xr = torch.tensor(x).to(torch.bfloat16).double().permute(0, 3, 1, 2)
+    wr = torch.tensor(w).to(torch.bfloat16).double()
+    ref = orc.conv2d_same_t(xr, wr, torch.tensor(b).double(), relu=True).permute(0, 2, 3, 1).numpy()
+    exact = orc.conv2d_same_t(torch.tensor(x).double().permute(0, 3, 1, 2), torch.tensor(w).double(), torch.tensor(b).double(), relu=True)
+    exact = exact.permute(0, 2, 3, 1).numpy()
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y_ = torch.empty(N, H, W, Cout).cuda()
+    L.check(L.lib.fcn8s_op_conv2d_bf16(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), N, H, W, Cin, Cout, K, 1))
+    torch.cuda.synchronize()
+    y = y_.cpu().numpy()
+    assert rel_err(y, ref) < 1e-5
+    assert rel_err(y, exact) < 2e-2 and rel_err(y, exact) > 1e-5      # it really ran in bf16
+    with pytest.raises(ValueError):
+        L.check(L.lib.fcn8s_op_conv2d_bf16(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), N, H, W, Cin, Cout + 4, K, 1))
+
+
 @pytest.mark.parametrize("N,H,W,C", [(2, 8, 8, 64), (1, 4, 6, 8), (1, 32, 64, 128)])
 def test_maxpool(N, H, W, C):
     L = _lib()

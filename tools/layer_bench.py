@@ -8,10 +8,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16); ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024); ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc"])
     args = ap.parse_args()
     import torch
     from fcn8s_tensorflow_amd.engine import Engine
-    e = Engine(20); e.init_params(0)
+    e = Engine(20, precision=args.precision); e.init_params(0)
     rng = np.random.default_rng(0)
     img = torch.from_numpy(rng.integers(0, 256, (args.batch, args.height, args.width, 3), dtype=np.uint8)).cuda()
     lab = torch.from_numpy(rng.integers(0, 20, (args.batch, args.height, args.width), dtype=np.uint8)).cuda()
