@@ -172,6 +172,24 @@ def test_config5_shape_2048x1024_bs4_properties():
     full = e.predict(imgd, argmax=True)
     one = e.predict(imgd[3:4], argmax=True)
     assert float((torch.as_tensor(full[3:4]) != torch.as_tensor(one)).float().mean()) < 1e-4
+
+    # config 5's arithmetic at config 5's size: forward fc6 / fc7 with bf16 operands (fp32 accumulate)
+    sm32 = e.predict(imgd[:1], argmax=False).clone()
+    e.set_precision('bf16_fc')
+    sm16 = e.predict(imgd[:1], argmax=False)
+    d = float((sm16 - sm32).abs().max())
+    assert 0.0 < d < 2e-2, d                                  # operand rounding is visible and small
+    e.forward_backward(imgd, labd, keep_prob=1.0)
+    g_full = e.flat_grads.clone()
+    e.forward_backward(imgd[:2], labd[:2], keep_prob=1.0)
+    g_a = e.flat_grads.clone()
+    e.forward_backward(imgd[2:], labd[2:], keep_prob=1.0)
+    g_mean = 0.5 * (g_a + e.flat_grads)
+    for name in ("conv5_3/filter", "fc6/weights", "fc7/weights", "fc7_1x1/kernel"):
+        shape, off = e.specs[name]
+        n = int(np.prod(shape))
+        a, b = g_full[off:off + n], g_mean[off:off + n]
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-12, name
     loss, step = e.train_step(imgd, labd, 1e-4, keep_prob=0.5)
     assert np.isfinite(loss) and step == 1
     e.close()
