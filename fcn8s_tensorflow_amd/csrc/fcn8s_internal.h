@@ -117,8 +117,12 @@ void launch_dropout_mask(float* mask, long long n, float keep_prob, unsigned lon
 // Winograd F(tile x tile, 3x3) transforms (tile = 2 or 4) around P = (tile+2)^2 batched GEMMs; H, W % tile == 0, C % 4 == 0.
 // KS = 3: plain 3x3 conv.  KS = 7: the filter is cut into a 3x3 grid of 3x3 sub-filters whose products add up in the
 // Winograd domain (GEMM depth 9*C); u / v rows are then [sub][channel].
+long long wino_slab(long long T, int C);   // floats between the slabs of consecutive Winograd positions of a [P][T][C] tensor (T*C + skew)
 void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, int KS, hipStream_t s);         // w[KS*KS][Cin][Cout] -> u[P][nsub*Cin][Cout]
 void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, int KS, hipStream_t s);   // x[N,H,W,C] -> v[P][T][nsub*C]
+// F(4x4,3x3) only: V = B^T dy B (input transform of the data-gradient conv) AND dM = A dy A^T (weight-gradient transform) from
+// one read of dy; returns false if the shape is not covered.
+bool launch_wino_input_dout(const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s);
 void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
                         int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,
                         unsigned int stream_id, hipStream_t s);                                                 // m[P][T][C] -> y[N,H,W,C]

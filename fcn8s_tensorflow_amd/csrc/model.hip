@@ -59,6 +59,7 @@ struct fcn8s_model {
     int wino_tile = 4;                                                    // F(4x4,3x3) where H, W % 4 == 0, else F(2x2,3x3)
     int wino_fc6 = 1;                                                     // fc6 7x7 as nine 3x3 sub-filters in the Winograd domain
     int precision = FCN8S_PREC_F32;                                       // FCN8S_PREC_BF16_FC: forward fc6 / fc7 on the bf16 MFMA
+    std::string fused_v_layer;                                            // layer whose data-gradient input transform already sits in d_wino_v
     unsigned short* d_wbf16 = nullptr;                                    // bf16 K-tile-major copy of the fc6 / fc7 kernel (one at a time)
     hipStream_t stream = nullptr;
     int64_t step = 0;
@@ -204,7 +205,7 @@ struct WinoEpi { const float* bias = nullptr; const float* addend = nullptr; con
                  int relu = 0; int dropout = 0; float keep = 1.f; unsigned long long seed = 0; unsigned int stream_id = 0; };
 // KS = 3, or 7 (3x3 grid of 3x3 sub-filters, GEMM depth 9*Cin -- see winograd.hip)
 void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const float* x, const float* wk, float* y, float* u, float* v, float* mm,
-                   int N, int H, int W, int Cin, int Cout, const WinoEpi& e, hipStream_t s, const char* layer)
+                   int N, int H, int W, int Cin, int Cout, const WinoEpi& e, hipStream_t s, const char* layer, bool v_ready = false)
 {
     const int P = (tile + 2) * (tile + 2), nsub2 = KS == 3 ? 1 : 9;
     const long long T = (long long)N * (H / tile) * (W / tile);
@@ -217,12 +218,13 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
     a.Ho = (int)T; a.Wo = 1; a.Cout = Cout; a.ldy = Cout;
     a.out_scale = 1; a.phases_x = 1; a.w_phase_stride = (long long)Kg * Cout;
     a.alpha = 1.f; a.mask_scale = 1.f;
-    a.batched = 1; a.x_batch_stride = T * Kg; a.y_batch_stride = T * Cout;
+    a.batched = 1; a.x_batch_stride = wino_slab(T, Kg); a.y_batch_stride = wino_slab(T, Cout);
     const double tb = 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg), ob = 4.0 * ((double)N * H * W * Cout + (double)P * T * Cout);
-    auto pre = [&]() { launch_wino_filter(tile, wk, u, Cin, Cout, KS, s); launch_wino_input(tile, x, v, N, H, W, Cin, KS, s); };
+    // v_ready: V was written together with the weight gradient's dM by the fused transform (launch_wino_input_dout)
+    auto pre = [&]() { launch_wino_filter(tile, wk, u, Cin, Cout, KS, s); if (!v_ready) launch_wino_input(tile, x, v, N, H, W, Cin, KS, s); };
     auto post = [&]() { launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s); };
     if (m) {
-        { ProfScope ps(m, "wino_transform", 0, tb + (double)(KS * KS + P * nsub2) * 4 * Cin * Cout); pre(); }
+        { ProfScope ps(m, "wino_transform", 0, (v_ready ? 0.0 : tb) + (double)(KS * KS + P * nsub2) * 4 * Cin * Cout); pre(); }
         { ProfScope ps(m, tag, 2.0 * P * T * Kg * Cout, 4.0 * P * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_igemm(a, P, s); }
         { ProfScope ps(m, "wino_transform", 0, ob); post(); }
     } else { pre(); launch_igemm(a, P, s); post(); }
@@ -238,13 +240,16 @@ void conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
     if ((wino3 || wino7) && Cin % 16 == 0 && Cout % 64 == 0 && e.alpha == 1.f && !real_cin) {
         const bool dgrad = e.dgrad != 0;
         float* vbuf = m->d_wino_v;
+        const bool v_ready = dgrad && layer && !m->fused_v_layer.empty() && m->fused_v_layer == layer;
+        m->fused_v_layer.clear();
         if (!dgrad && layer) { auto it = m->acts.find(std::string("wv:") + layer); if (it != m->acts.end()) vbuf = it->second.p; }
         WinoEpi we; we.bias = e.bias; we.addend = e.addend; we.mask = e.mask; we.mask_scale = e.mask_scale; we.relu = e.relu;
         we.dropout = e.dropout; we.keep = e.keep; we.seed = m->seed; we.stream_id = e.stream_id;
         const char* tag = K == 7 ? (dgrad ? "wino_gemm_fc6_dgrad" : "wino_gemm_fc6_fwd") : (dgrad ? "wino_gemm_dgrad" : "wino_gemm_fwd");
-        conv_winograd(m, wino_tile_for(m, H, W), K, tag, x, w, y, m->d_wino_u, vbuf, m->d_wino_m, N, H, W, Cin, Cout, we, s, layer);
+        conv_winograd(m, wino_tile_for(m, H, W), K, tag, x, w, y, m->d_wino_u, vbuf, m->d_wino_m, N, H, W, Cin, Cout, we, s, layer, v_ready);
         return;
     }
+    if (m) m->fused_v_layer.clear();
     IgemmArgs a{};
     a.x = x; a.w = w; a.bias = e.bias; a.addend = e.addend; a.mask = e.mask; a.y = y;
     a.N = N; a.Ma = H; a.Mb = W; a.M = (long long)N * H * W;
@@ -297,7 +302,7 @@ void tconv_dgrad(fcn8s_model* m, const float* dy, const float* w, float* dx, int
 
 void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* dz, float* dw, float* db,
                 int N, int H, int W, int Cin, int Cout, int K, float alpha, hipStream_t s, int real_cin = 0,
-                const char* layer = nullptr)
+                const char* layer = nullptr, bool fuse_dgrad_input = false)
 {
     WgradArgs a{};
     a.A = x; a.B = dz; a.C = dw;
@@ -320,9 +325,14 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             g.N = 1; g.Pa = 1; g.Pb = (int)T; g.P = T;
             g.Ha = 1; g.Wa = (int)T; g.Adim = Kg; g.lda = Kg; g.Areal = Kg;
             g.Bdim = Cout; g.ldb = Cout; g.KW = 1; g.a_scale = 1; g.tap_off = 0; g.ntaps = NP; g.ldc = Cout; g.alpha = 1.f; g.colsum = nullptr;
-            g.batched = 1; g.a_batch_stride = T * Kg; g.b_batch_stride = T * Cout; g.c_uninitialized = 1;
-            { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout + (double)NP * T * Cout));
-              launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s); }
+            g.batched = 1; g.a_batch_stride = wino_slab(T, Kg); g.b_batch_stride = wino_slab(T, Cout); g.c_uninitialized = 1;
+            // fuse_dgrad_input: the data gradient of this layer follows and runs through Winograd too -- its input
+            // transform V = B^T dz B is written into d_wino_v by the same kernel that writes dM (one read of dz)
+            bool fused = false;
+            { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout + (fuse_dgrad_input ? 2.0 : 1.0) * NP * T * Cout));
+              if (fuse_dgrad_input && tile == 4 && K == 3) fused = launch_wino_input_dout(dz, m->d_wino_v, m->d_wino_m, N, H, W, Cout, s);
+              if (!fused) launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s); }
+            m->fused_v_layer = fused ? layer : "";
             { ProfScope ps(m, K == 7 ? "wino_gemm_fc6_wgrad" : "wino_gemm_wgrad", 2.0 * NP * T * Kg * Cout, 4.0 * NP * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_wgrad(g, s); }
             { ProfScope ps(m, "wino_transform", 0, 4.0 * (9.0 + NP) * Cin * Cout + 4.0 * N * H * W * Cout);
               launch_wino_dfilter(tile, m->d_wino_u, dw, Cin, Cout, K, s);
@@ -417,18 +427,19 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
             if (vf > vmax) vmax = vf;
         }
         m->d_wino_v = m->d_wino_m = nullptr;
-        if (vmax) { items.push_back({"wino_v", vmax, 0, 0, 0, &m->d_wino_v}); items.push_back({"wino_m", vmax, 0, 0, 0, &m->d_wino_m}); }
+        const size_t skew_room = 36 * (size_t)(wino_slab(0, 0) + 4);       // the slabs of a [P][T][C] tensor are T*C + skew floats apart
+        if (vmax) { vmax += skew_room; items.push_back({"wino_v", vmax, 0, 0, 0, &m->d_wino_v}); items.push_back({"wino_m", vmax, 0, 0, 0, &m->d_wino_m}); }
         if (m->wino_min_cin > 0) {    // the forward pass keeps each Winograd layer's transformed input for the weight gradient
             int cin = 3;
             for (int b = 0, hh = H, ww = W; b < 5; ++b, hh /= 2, ww /= 2)
                 for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
                     if (cin >= m->wino_min_cin && cin % 16 == 0 && m->widths[b] % 64 == 0 && hh % 2 == 0 && ww % 2 == 0) {
                         char nm[40]; snprintf(nm, sizeof nm, "wv:conv%d_%d", b + 1, i);
-                        items.push_back({nm, (size_t)N * hh * ww * (size_t)cin * 4, 0, 0, 0, nullptr});
+                        items.push_back({nm, (size_t)N * hh * ww * (size_t)cin * 4 + skew_room, 0, 0, 0, nullptr});
                     }
                     cin = m->widths[b];
                 }
-            if (fc6w) items.push_back({"wv:fc6", (size_t)N * h5_ * w5_ * (size_t)m->widths[4] * 21, 0, 0, 0, nullptr});
+            if (fc6w) items.push_back({"wv:fc6", (size_t)N * h5_ * w5_ * (size_t)m->widths[4] * 21 + skew_room, 0, 0, 0, nullptr});
         }
     }
 
@@ -665,8 +676,11 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
             else if (b > 1) { snprintf(inname, sizeof inname, "pool%d", b - 1); xin = A(m, inname); cin = m->widths[b - 2]; }
             else { xin = A(m, "x0"); cin = 4; real_cin = 3; }
             const bool first = (b == 1 && i == 1);
+            // the data-gradient conv (cw -> cin channels) takes the Winograd path under the same conditions as conv_same()
+            const bool dgrad_wino = !first && m->wino_min_cin > 0 && cw >= m->wino_min_cin && m->d_wino_v && wino_tile_for(m, h, w) == 4 &&
+                                    cw % 16 == 0 && cin % 64 == 0;
             conv_wgrad(m, first ? "conv1_1_wgrad" : "conv3x3_wgrad", xin, dz, Gp(m, std::string(nm) + "/filter"), Gp(m, std::string(nm) + "/biases"),
-                       N, h, w, cin, cw, 3, 1.f, s, real_cin, nm);
+                       N, h, w, cin, cw, 3, 1.f, s, real_cin, nm, dgrad_wino);
             if (first) break;
             Epi e; e.dgrad = 1;
             if (i > 1) { e.mask = xin; e.mask_scale = 1.f; }               // ReLU of the previous conv
@@ -1190,8 +1204,8 @@ int fcn8s_op_conv2d_winograd(void* stream, const float* x, const float* w, const
     hipStream_t s = (hipStream_t)stream;
     const size_t T = (size_t)N * (H / tile) * (W / tile), P = (size_t)(tile + 2) * (tile + 2), Kg = (size_t)(K == 3 ? 1 : 9) * Cin;
     float *u = nullptr, *v = nullptr, *mm = nullptr;
-    if (hipMalloc((void**)&u, P * Kg * Cout * 4) != hipSuccess || hipMalloc((void**)&v, P * T * Kg * 4) != hipSuccess ||
-        hipMalloc((void**)&mm, P * T * Cout * 4) != hipSuccess) return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc");
+    if (hipMalloc((void**)&u, P * Kg * Cout * 4) != hipSuccess || hipMalloc((void**)&v, P * (size_t)wino_slab(T, (int)Kg) * 4) != hipSuccess ||
+        hipMalloc((void**)&mm, P * (size_t)wino_slab(T, Cout) * 4) != hipSuccess) return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc");
     WinoEpi we; we.bias = bias; we.relu = relu;
     conv_winograd(nullptr, tile, K, "", x, w, y, u, v, mm, N, H, W, Cin, Cout, we, s, nullptr);
     hipStreamSynchronize(s); hipFree(u); hipFree(v); hipFree(mm);

@@ -14,6 +14,7 @@
 // the Winograd domain: per position xi one GEMM with K = 9*Cin ([V_00 | V_01 | ... | V_22] x [U_00; ...; U_22]) --
 // 20.25 multiplies per output instead of 49, with F(4x4,3x3)'s numerics.
 #include "fcn8s_internal.h"
+#include <cstdlib>
 
 namespace fcn8s {
 
@@ -105,140 +106,209 @@ __global__ void wino_filter_kernel(const float* w, float* u, int Cin, int Cout, 
     }
 }
 
-// ---- input: one thread = one m x m output tile x 4 channels; alpha x alpha patch (zero outside), V = B^T d B --------
+// Work mapping shared by the tile transforms: blockIdx.y = (image, tile row), blockIdx.x * 256 + threadIdx.x = (tile column,
+// channel vector).  All tensor strides are block-uniform, so every load / store address is one per-thread base pointer
+// plus a scalar offset (the first version recomputed the full NHWC index per access: ~350 quarter-rate integer
+// multiplies per tile, more VALU time than the HBM time of the bytes it moved).
+struct TileIdx { int n, ty, tx, c; long long t; bool ok; };
+static __device__ __forceinline__ TileIdx tile_index(int th, int tw, int C4)
+{
+    TileIdx r;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    r.tx = idx / C4; r.c = idx - r.tx * C4;
+    r.n = blockIdx.y / th; r.ty = blockIdx.y - r.n * th;
+    r.ok = r.tx < tw;
+    r.t = ((long long)r.n * th + r.ty) * tw + r.tx;
+    return r;
+}
+static inline dim3 tile_grid(int N, int th, int tw, int C4, int z = 1) { return dim3((unsigned)((tw * C4 + 255) / 256), (unsigned)(N * th), (unsigned)z); }
+
+// ---- input: one thread = one m x m output tile x VEC channels; alpha x alpha patch (zero outside), V = B^T d B --------
 template <int M, int VEC>
-__global__ __launch_bounds__(256) void wino_input_kernel(const float4* x, float4* v, int N, int H, int W, int C4, int pad, int nsub)
+__global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restrict__ x, float4* __restrict__ v, int N, int H, int W, int C4, int pad, int nsub,
+                                                         long long slab)
 {
     constexpr int A = WinoMat<M>::A;
     const int th = H / M, tw = W / M;
-    const long long T = (long long)N * th * tw, total = T * C4;
-    const int sub = blockIdx.y, sa = sub / nsub, sb = sub - sa * nsub;     // sub-filter: patch shifted by (3 sa, 3 sb)
-    const int oy = 3 * sa - pad, ox = 3 * sb - pad, ldv = C4 * nsub * nsub, coff = sub * C4;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4);
-        const long long t = i / C4;
-        const int tx = (int)(t % tw); const long long r = t / tw;
-        const int ty = (int)(r % th); const int n = (int)(r / th);
-        float4 q[A][A];                            // q = B^T d, built column by column so that d is never fully live
+    const int sub = blockIdx.z, sa = sub / nsub, sb = sub - sa * nsub;     // sub-filter: patch shifted by (3 sa, 3 sb)
+    const int ldv = C4 * nsub * nsub;
+    const TileIdx ti = tile_index(th, tw, C4);
+    if (!ti.ok) return;
+    const int y0 = M * ti.ty + 3 * sa - pad, x0 = M * ti.tx + 3 * sb - pad;
+    const float4* xp = x + (((long long)ti.n * H + y0) * W + x0) * C4 + ti.c;     // dereferenced only where (row, col) lies inside the image
+    bool rok[A], cok[A];
 #pragma unroll
-        for (int b = 0; b < A; ++b) {
-            const int ix = M * tx + ox + b;
-            float4 d[A];
+    for (int a = 0; a < A; ++a) { rok[a] = (unsigned)(y0 + a) < (unsigned)H; cok[a] = (unsigned)(x0 + a) < (unsigned)W; }
+    float4 q[A][A];                            // q = B^T d, built column by column so that d is never fully live
 #pragma unroll
-            for (int a = 0; a < A; ++a) {
-                const int iy = M * ty + oy + a;
-                d[a] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                           ? x[(((long long)n * H + iy) * W + ix) * C4 + c] : f4zero();
-            }
+    for (int b = 0; b < A; ++b) {
+        float4 d[A];
 #pragma unroll
-            for (int a = 0; a < A; ++a) {
-                float4 s = f4zero();
+        for (int a = 0; a < A; ++a) d[a] = (rok[a] && cok[b]) ? xp[(a * W + b) * C4] : f4zero();
 #pragma unroll
-                for (int k = 0; k < A; ++k) if (WinoMat<M>::bt(a, k) != 0.f) s = f4fma(WinoMat<M>::bt(a, k), d[k], s);
-                q[a][b] = s;
-            }
+        for (int a = 0; a < A; ++a) {
+            float4 s = f4zero();
+#pragma unroll
+            for (int k = 0; k < A; ++k) if (WinoMat<M>::bt(a, k) != 0.f) s = f4fma(WinoMat<M>::bt(a, k), d[k], s);
+            q[a][b] = s;
         }
-#pragma unroll
-        for (int a = 0; a < A; ++a)
-#pragma unroll
-            for (int b = 0; b < A; ++b) {          // V = q B
-                float4 s = f4zero();
-#pragma unroll
-                for (int k = 0; k < A; ++k) if (WinoMat<M>::bt(b, k) != 0.f) s = f4fma(WinoMat<M>::bt(b, k), q[a][k], s);
-                v[((long long)(a * A + b) * T + t) * ldv + coff + c] = s;
-            }
     }
+    float4* vp = v + ti.t * ldv + sub * C4 + ti.c;
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int b = 0; b < A; ++b) {          // V = q B
+            float4 s = f4zero();
+#pragma unroll
+            for (int k = 0; k < A; ++k) if (WinoMat<M>::bt(b, k) != 0.f) s = f4fma(WinoMat<M>::bt(b, k), q[a][k], s);
+            vp[(a * A + b) * slab] = s;
+        }
 }
 
-// ---- output: one thread = one tile x 4 channels; Y = A^T M A, then the conv epilogue --------------------------------
-template <int M, int VEC>
-__global__ __launch_bounds__(256) void wino_output_kernel(const float4* m, const float4* bias, const float4* addend, const float4* mask,
-                                                          float mask_scale, int relu, float4* y, int N, int H, int W, int C4,
-                                                          int dropout, float keep, unsigned long long seed, unsigned int stream_id)
+// ---- F(4x4,3x3) backward pair: the data-gradient conv needs V = B^T dy B, the weight gradient dM = A dy A^T of the same
+// tensor (dM's 4x4 tile is the inside of V's 6x6 patch): both from one read of dy -------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __restrict__ x, float4* __restrict__ v, float4* __restrict__ dm,
+                                                              int N, int H, int W, int C4, long long slab)
+{
+    constexpr int M = 4, A = 6;
+    const int th = H / M, tw = W / M;
+    const TileIdx ti = tile_index(th, tw, C4);
+    if (!ti.ok) return;
+    const int y0 = M * ti.ty - 1, x0 = M * ti.tx - 1;
+    const float4* xp = x + (((long long)ti.n * H + y0) * W + x0) * C4 + ti.c;
+    bool rok[A], cok[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) { rok[a] = (unsigned)(y0 + a) < (unsigned)H; cok[a] = (unsigned)(x0 + a) < (unsigned)W; }
+    float4 q[A][A], p[A][M];
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+        float4 d[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) d[a] = (rok[a] && cok[b]) ? xp[(a * W + b) * C4] : f4zero();
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            float4 s = f4zero();
+#pragma unroll
+            for (int k = 0; k < A; ++k) if (WinoMat<M>::bt(a, k) != 0.f) s = f4fma(WinoMat<M>::bt(a, k), d[k], s);
+            q[a][b] = s;
+        }
+        if (b >= 1 && b <= M) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                float4 s = f4zero();
+#pragma unroll
+                for (int k = 0; k < M; ++k) if (WinoMat<M>::at(k, a) != 0.f) s = f4fma(WinoMat<M>::at(k, a), d[k + 1], s);
+                p[a][b - 1] = s;
+            }
+        }
+    }
+    const long long o = ti.t * C4 + ti.c;
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int b = 0; b < A; ++b) {
+            float4 s = f4zero();
+#pragma unroll
+            for (int k = 0; k < A; ++k) if (WinoMat<M>::bt(b, k) != 0.f) s = f4fma(WinoMat<M>::bt(b, k), q[a][k], s);
+            v[o + (a * A + b) * slab] = s;
+        }
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int b = 0; b < A; ++b) {
+            float4 s = f4zero();
+#pragma unroll
+            for (int k = 0; k < M; ++k) if (WinoMat<M>::at(k, b) != 0.f) s = f4fma(WinoMat<M>::at(k, b), p[a][k], s);
+            dm[o + (a * A + b) * slab] = s;
+        }
+}
+
+// ---- output: one thread = one tile x VEC channels; Y = A^T M A, then the conv epilogue --------------------------------
+// DROPOUT is a template parameter: the inlined Philox rounds (fc6 only) otherwise cost every launch their registers.
+template <int M, int VEC, bool DROPOUT>
+__global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restrict__ m, const float4* __restrict__ bias, const float4* __restrict__ addend,
+                                                          const float4* __restrict__ mask, float mask_scale, int relu, float4* __restrict__ y,
+                                                          int N, int H, int W, int C4, float keep, unsigned long long seed, unsigned int stream_id,
+                                                          long long slab)
 {
     constexpr int A = WinoMat<M>::A;
     const int th = H / M, tw = W / M;
-    const long long T = (long long)N * th * tw, total = T * C4;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4);
-        const long long t = i / C4;
-        const int tx = (int)(t % tw); const long long r = t / tw;
-        const int ty = (int)(r % th); const int n = (int)(r / th);
-        float4 q[M][A];                            // q = A^T M, column by column
+    const TileIdx ti = tile_index(th, tw, C4);
+    if (!ti.ok) return;
+    const float4* mp = m + ti.t * C4 + ti.c;
+    float4 q[M][A];                            // q = A^T M, column by column
 #pragma unroll
-        for (int b = 0; b < A; ++b) {
-            float4 col[A];
+    for (int b = 0; b < A; ++b) {
+        float4 col[A];
 #pragma unroll
-            for (int a = 0; a < A; ++a) col[a] = m[((long long)(a * A + b) * T + t) * C4 + c];
+        for (int a = 0; a < A; ++a) col[a] = mp[(a * A + b) * slab];
 #pragma unroll
-            for (int o = 0; o < M; ++o) {
-                float4 s = f4zero();
+        for (int o = 0; o < M; ++o) {
+            float4 s = f4zero();
 #pragma unroll
-                for (int k = 0; k < A; ++k) if (WinoMat<M>::at(o, k) != 0.f) s = f4fma(WinoMat<M>::at(o, k), col[k], s);
-                q[o][b] = s;
-            }
+            for (int k = 0; k < A; ++k) if (WinoMat<M>::at(o, k) != 0.f) s = f4fma(WinoMat<M>::at(o, k), col[k], s);
+            q[o][b] = s;
         }
-        const float4 bv = bias ? bias[c] : f4zero();
-#pragma unroll
-        for (int oy = 0; oy < M; ++oy)
-#pragma unroll
-            for (int ox = 0; ox < M; ++ox) {
-                float4 v = bv;
-#pragma unroll
-                for (int k = 0; k < A; ++k) if (WinoMat<M>::at(ox, k) != 0.f) v = f4fma(WinoMat<M>::at(ox, k), q[oy][k], v);
-                const long long off = (((long long)n * H + M * ty + oy) * W + M * tx + ox) * C4 + c;
-                if (addend) { const float4 ad = addend[off]; _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] += ad.d[i]; }
-                if (relu) { _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = fmaxf(v.d[i], 0.f); }
-                if (mask) {
-                    const float4 k = mask[off];
-                    _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = k.d[i] > 0.f ? v.d[i] * mask_scale : 0.f;
-                }
-                if (dropout) {                     // same Philox stream as the direct kernel's epilogue: element index NHWC
-                    const unsigned long long e = (unsigned long long)off * VEC;
-                    const float ik = 1.f / keep;
-                    _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = philox_uniform(e + i, seed, stream_id) < keep ? v.d[i] * ik : 0.f;
-                }
-                y[off] = v;
-            }
     }
+    const float4 bv = bias ? bias[ti.c] : f4zero();
+    const long long off0 = (((long long)ti.n * H + M * ti.ty) * W + M * ti.tx) * C4 + ti.c;
+#pragma unroll
+    for (int oy = 0; oy < M; ++oy)
+#pragma unroll
+        for (int ox = 0; ox < M; ++ox) {
+            float4 v = bv;
+#pragma unroll
+            for (int k = 0; k < A; ++k) if (WinoMat<M>::at(ox, k) != 0.f) v = f4fma(WinoMat<M>::at(ox, k), q[oy][k], v);
+            const long long off = off0 + (oy * W + ox) * C4;
+            if (addend) { const float4 ad = addend[off]; _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] += ad.d[i]; }
+            if (relu) { _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = fmaxf(v.d[i], 0.f); }
+            if (mask) {
+                const float4 k = mask[off];
+                _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = k.d[i] > 0.f ? v.d[i] * mask_scale : 0.f;
+            }
+            if (DROPOUT) {                     // same Philox stream as the direct kernel's epilogue: element index NHWC
+                const unsigned long long e = (unsigned long long)off * VEC;
+                const float ik = 1.f / keep;
+                _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = philox_uniform(e + i, seed, stream_id) < keep ? v.d[i] * ik : 0.f;
+            }
+            y[off] = v;
+        }
 }
 
 // ---- weight gradient: dM = A dY A^T (alpha x alpha from the m x m output-gradient tile) ------------------------------
 template <int M, int VEC>
-__global__ __launch_bounds__(256) void wino_dout_kernel(const float4* dy, float4* dm, int N, int H, int W, int C4)
+__global__ __launch_bounds__(256) void wino_dout_kernel(const float4* __restrict__ dy, float4* __restrict__ dm, int N, int H, int W, int C4, long long slab)
 {
     constexpr int A = WinoMat<M>::A;
     const int th = H / M, tw = W / M;
-    const long long T = (long long)N * th * tw, total = T * C4;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4);
-        const long long t = i / C4;
-        const int tx = (int)(t % tw); const long long r = t / tw;
-        const int ty = (int)(r % th); const int n = (int)(r / th);
-        float4 q[A][M];                            // q = A dY  (A = (A^T)^T)
+    const TileIdx ti = tile_index(th, tw, C4);
+    if (!ti.ok) return;
+    const float4* yp = dy + (((long long)ti.n * H + M * ti.ty) * W + M * ti.tx) * C4 + ti.c;
+    float4 q[A][M];                            // q = A dY  (A = (A^T)^T)
 #pragma unroll
-        for (int ox = 0; ox < M; ++ox) {
-            float4 col[M];
+    for (int ox = 0; ox < M; ++ox) {
+        float4 col[M];
 #pragma unroll
-            for (int oy = 0; oy < M; ++oy) col[oy] = dy[(((long long)n * H + M * ty + oy) * W + M * tx + ox) * C4 + c];
+        for (int oy = 0; oy < M; ++oy) col[oy] = yp[(oy * W + ox) * C4];
 #pragma unroll
-            for (int a = 0; a < A; ++a) {
-                float4 s = f4zero();
+        for (int a = 0; a < A; ++a) {
+            float4 s = f4zero();
 #pragma unroll
-                for (int k = 0; k < M; ++k) if (WinoMat<M>::at(k, a) != 0.f) s = f4fma(WinoMat<M>::at(k, a), col[k], s);
-                q[a][ox] = s;
-            }
+            for (int k = 0; k < M; ++k) if (WinoMat<M>::at(k, a) != 0.f) s = f4fma(WinoMat<M>::at(k, a), col[k], s);
+            q[a][ox] = s;
         }
-#pragma unroll
-        for (int a = 0; a < A; ++a)
-#pragma unroll
-            for (int b = 0; b < A; ++b) {          // dM = q A^T
-                float4 s = f4zero();
-#pragma unroll
-                for (int k = 0; k < M; ++k) if (WinoMat<M>::at(k, b) != 0.f) s = f4fma(WinoMat<M>::at(k, b), q[a][k], s);
-                dm[((long long)(a * A + b) * T + t) * C4 + c] = s;
-            }
     }
+    float4* dp = dm + ti.t * C4 + ti.c;
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int b = 0; b < A; ++b) {          // dM = q A^T
+            float4 s = f4zero();
+#pragma unroll
+            for (int k = 0; k < M; ++k) if (WinoMat<M>::at(k, b) != 0.f) s = f4fma(WinoMat<M>::at(k, b), q[a][k], s);
+            dp[(a * A + b) * slab] = s;
+        }
 }
 
 // ---- dg_sub = G^T dU_sub G, scattered back to the taps (3a+i, 3b+j) < KS of the KS x KS filter gradient -----------------
@@ -289,31 +359,48 @@ void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, i
     if (tile == 4) hipLaunchKernelGGL(wino_filter_kernel<4>, dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
     else           hipLaunchKernelGGL(wino_filter_kernel<2>, dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
 }
+static int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+// Distance in floats between the slabs of two Winograd positions of a [P][T][C] tensor.  T*C alone is a large power of two
+// for this network (conv1_2: 2^25 floats): the 36 stores of one tile would then hit the same HBM channel and bank at the
+// same time.  The skew (4 KiB + 256 B) staggers the slabs across channels.
+long long wino_slab(long long T, int C)
+{
+    static const int skew = env_flag("FCN8S_WINO_SKEW", 1088) / 4 * 4;
+    return T * C + skew;
+}
+bool launch_wino_input_dout(const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s)
+{
+    static const int on = env_flag("FCN8S_WINO_FUSE_DZ", 1);
+    if (!on || H % 4 || W % 4 || C % 2) return false;
+    hipLaunchKernelGGL((wino_input_dout_kernel<2>), tile_grid(N, H / 4, W / 4, C / 2), dim3(256), 0, s,
+                       (const VecF<2>*)dy, (VecF<2>*)v, (VecF<2>*)dm, N, H, W, C / 2, wino_slab((long long)N * (H / 4) * (W / 4), C) / 2);
+    return true;
+}
 void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, int KS, hipStream_t s)
 {
     const int nsub = KS == 3 ? 1 : 3, pad = (KS - 1) / 2;
-    if (tile == 4) hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(wcap((long long)N * (H / 4) * (W / 4) * (C / 2)), nsub * nsub), dim3(256), 0, s,
-                                      (const VecF<2>*)x, (VecF<2>*)v, N, H, W, C / 2, pad, nsub);
-    else           hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(wcap((long long)N * (H / 2) * (W / 2) * (C / 4)), nsub * nsub), dim3(256), 0, s,
-                                      (const VecF<4>*)x, (VecF<4>*)v, N, H, W, C / 4, pad, nsub);
+    if (tile == 4) hipLaunchKernelGGL((wino_input_kernel<4, 2>), tile_grid(N, H / 4, W / 4, C / 2, nsub * nsub), dim3(256), 0, s,
+                                      (const VecF<2>*)x, (VecF<2>*)v, N, H, W, C / 2, pad, nsub, wino_slab((long long)N * (H / 4) * (W / 4), C * nsub * nsub) / 2);
+    else           hipLaunchKernelGGL((wino_input_kernel<2, 4>), tile_grid(N, H / 2, W / 2, C / 4, nsub * nsub), dim3(256), 0, s,
+                                      (const VecF<4>*)x, (VecF<4>*)v, N, H, W, C / 4, pad, nsub, wino_slab((long long)N * (H / 2) * (W / 2), C * nsub * nsub) / 4);
 }
 void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
                         int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,
                         unsigned int stream_id, hipStream_t s)
 {
-    if (tile == 4) hipLaunchKernelGGL((wino_output_kernel<4, 2>), dim3(wcap((long long)N * (H / 4) * (W / 4) * (C / 2))), dim3(256), 0, s,
-                                      (const VecF<2>*)m, (const VecF<2>*)bias, (const VecF<2>*)addend, (const VecF<2>*)mask, mask_scale, relu,
-                                      (VecF<2>*)y, N, H, W, C / 2, dropout, keep, seed, stream_id);
-    else           hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(wcap((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, s,
-                                      (const VecF<4>*)m, (const VecF<4>*)bias, (const VecF<4>*)addend, (const VecF<4>*)mask, mask_scale, relu,
-                                      (VecF<4>*)y, N, H, W, C / 4, dropout, keep, seed, stream_id);
+#define FCN8S_WOUT(M_, V_, D_) hipLaunchKernelGGL((wino_output_kernel<M_, V_, D_>), tile_grid(N, H / M_, W / M_, C / V_), dim3(256), 0, s, \
+        (const VecF<V_>*)m, (const VecF<V_>*)bias, (const VecF<V_>*)addend, (const VecF<V_>*)mask, mask_scale, relu, (VecF<V_>*)y, N, H, W, C / V_, keep, seed, stream_id, \
+        wino_slab((long long)N * (H / M_) * (W / M_), C) / V_)
+    if (tile == 4) { if (dropout) FCN8S_WOUT(4, 2, true); else FCN8S_WOUT(4, 2, false); }
+    else           { if (dropout) FCN8S_WOUT(2, 4, true); else FCN8S_WOUT(2, 4, false); }
+#undef FCN8S_WOUT
 }
 void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s)
 {
-    if (tile == 4) hipLaunchKernelGGL((wino_dout_kernel<4, 2>), dim3(wcap((long long)N * (H / 4) * (W / 4) * (C / 2))), dim3(256), 0, s,
-                                      (const VecF<2>*)dy, (VecF<2>*)dm, N, H, W, C / 2);
-    else           hipLaunchKernelGGL((wino_dout_kernel<2, 4>), dim3(wcap((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, s,
-                                      (const VecF<4>*)dy, (VecF<4>*)dm, N, H, W, C / 4);
+    if (tile == 4) hipLaunchKernelGGL((wino_dout_kernel<4, 2>), tile_grid(N, H / 4, W / 4, C / 2), dim3(256), 0, s,
+                                      (const VecF<2>*)dy, (VecF<2>*)dm, N, H, W, C / 2, wino_slab((long long)N * (H / 4) * (W / 4), C) / 2);
+    else           hipLaunchKernelGGL((wino_dout_kernel<2, 4>), tile_grid(N, H / 2, W / 2, C / 4), dim3(256), 0, s,
+                                      (const VecF<4>*)dy, (VecF<4>*)dm, N, H, W, C / 4, wino_slab((long long)N * (H / 2) * (W / 2), C) / 4);
 }
 void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, int KS, hipStream_t s)
 {
