@@ -54,6 +54,10 @@ template <int BM, int BN, int WM, int WN, int MODE, int BK>
 __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) void igemm_fwd_kernel(const IgemmArgs p)
 {
     constexpr bool FAST = MODE != 0;
+    // MODE 3 = plain batched GEMM (the Winograd positions): row m of slab z is row m of X / Y, no taps, no epilogue
+    // ops -- the generic row -> pixel prologue (integer divisions) and the per-element epilogue branches cost a
+    // K = 256 GEMM more than a tenth of its time.
+    constexpr bool PLAIN = MODE == 3;
     constexpr int LDA = BK + 4, LDB = BN, F4R = BK / 4;     // F4R float4 per A row; LDA*4 B row stride keeps ds_read_b128 conflict-free
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_LD = BM * F4R / 256;
@@ -92,6 +96,7 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
         const int row = (tid + i * 256) / F4R;
         const long long m = m0 + row;
         a_ok[i] = m < p.M;
+        if (PLAIN) { a_iy[i] = a_ix[i] = 0; a_base[i] = a_ok[i] ? m : 0; continue; }
         const long long mm = a_ok[i] ? m : 0;
         const int n = (int)(mm / MaMb);
         const int r = (int)(mm - (long long)n * MaMb);
@@ -115,7 +120,12 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
     unsigned a_mask[A_LD];                   // MODE 2: bit t set = tap t of this row lies inside the image (<= 32 taps)
     bool a_val[A_LD], a_ldok[A_LD];          // a_ldok: validity of the rows of the tile currently held in ra[]
     const float* b_ptr[B_LD];
-    auto set_tap = [&]() {                   // MODE 1 only
+    auto set_tap = [&]() {                   // MODE 1 (and 3: one tap, pixel = row)
+        if (PLAIN) {
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) { a_val[i] = a_ok[i]; a_ptr[i] = X + a_base[i] * p.ldx + a_c4; }
+            return;
+        }
         const int dy = f_ty * p.tap_step + p.tap_off, dx = f_tx * p.tap_step + p.tap_off;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
     const int nkt_all = (p.Ktot + BK - 1) / BK;
     const int kt0 = (int)((long long)nkt_all * blockIdx.y / gridDim.y);
     const int nkt = (int)((long long)nkt_all * (blockIdx.y + 1) / gridDim.y) - kt0;
-    if (MODE == 1 && kt0 > 0) {
+    if ((MODE == 1 || MODE == 3) && kt0 > 0) {
         const int tap0 = kt0 * BK / p.Cin;
         f_ci0 = kt0 * BK - tap0 * p.Cin;
         f_ty = tap0 / p.KW; f_tx = tap0 - f_ty * p.KW;
@@ -279,6 +289,42 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
         __syncthreads();
     }
 
+    if (PLAIN) {
+        // each wave transposes its 32x32 accumulator tiles through a private LDS patch so that the global stores are
+        // 16 bytes per lane (8 rows x 128 B per instruction) instead of 64 dword stores per tile
+        if (gridDim.y > 1) {                     // split-K partials
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long long m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if (m < p.M) unsafeAtomicAdd(Y + m * p.ldy + n0 + wn * TN * 32 + tn * 32 + (lane & 31), acc[tm][tn][r]);
+                    }
+            return;
+        }
+        constexpr int LDT = 36;
+        float* patch = smem + wave * 32 * LDT;           // 4 x 4.6 KB, inside the (now idle) A buffers
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + (lane & 31)] = acc[tm][tn][r];
+                __builtin_amdgcn_wave_barrier();
+                const long long mrow = m0 + wm * TM * 32 + tm * 32;
+                float* yb = Y + n0 + wn * TN * 32 + tn * 32 + (lane & 7) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = j * 8 + (lane >> 3);
+                    const float4 v = *reinterpret_cast<const float4*>(&patch[row * LDT + (lane & 7) * 4]);
+                    if (mrow + row < p.M) *reinterpret_cast<float4*>(yb + (mrow + row) * p.ldy) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        return;
+    }
     // ---- epilogue: row -> output offset table in LDS, then fused bias/add/relu/mask/dropout
     long long* rowoff = reinterpret_cast<long long*>(smem);
     if (tid < BM) {
@@ -326,13 +372,16 @@ static void launch_igemm_cfg(const IgemmArgs& a, int phases, hipStream_t s)
     const bool fast = (phases == 1 || a.batched) && a.Cin % BKF == 0 && a.Cout % BN == 0 && a.Ktot % a.Cin == 0;
     // filter bank small enough to live in L2 / MALL -> tap-inner K order (and at most 32 taps for the bit mask)
     const bool tap_inner = fast && (double)a.Ktot * a.Cout * 4.0 <= 64e6 && a.Ktot / a.Cin <= 32;
-    const int mode = !fast ? 0 : (tap_inner ? 2 : 1);
+    const bool plain = fast && a.batched && a.Ktot == a.Cin && !a.bias && !a.addend && !a.mask && !a.relu && !a.dropout && a.alpha == 1.f &&
+                       a.out_scale == 1 && a.ldy >= a.Cout && a.ldy % 4 == 0 && a.in_scale == 1 && a.tap_off == 0;
+    const int mode = !fast ? 0 : (plain ? 3 : (tap_inner ? 2 : 1));
     static const std::string base = "igemm_fwd_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", ";
-    static const std::string tags[3] = {base + "0, 16>", base + "1, " + std::to_string(BKF) + ">", base + "2, " + std::to_string(BKF) + ">"};
+    static const std::string tags[4] = {base + "0, 16>", base + "1, " + std::to_string(BKF) + ">", base + "2, " + std::to_string(BKF) + ">",
+                                        base + "3, " + std::to_string(BKF) + ">"};
     g_last_kernel = tags[mode].c_str();
     // few output tiles but a very long reduction (fc6 data gradient: 256 tiles, K = 200704): split K over
     // gridDim.y and combine with fp32 atomics -- only when the epilogue is linear
-    if (mode == 1 && !a.relu && !a.mask && !a.dropout && !a.addend && a.out_scale == 1 && a.ldy == a.Cout &&
+    if ((mode == 1 || mode == 3) && !a.relu && !a.mask && !a.dropout && !a.addend && a.out_scale == 1 && a.ldy == a.Cout &&
         grid.x < 512 && a.Ktot / BKF >= 512) {
         unsigned ks = 1024 / grid.x; if (ks > 8) ks = 8;
         if (ks >= 2) {
@@ -341,7 +390,8 @@ static void launch_igemm_cfg(const IgemmArgs& a, int phases, hipStream_t s)
             hipMemsetAsync(a.y, 0, nfl * sizeof(float), s);        // every slab of a batched launch
         }
     }
-    if (mode == 2)      hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 2, BKF>), grid, dim3(256), 0, s, a);
+    if (mode == 3)      hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 3, BKF>), grid, dim3(256), 0, s, a);
+    else if (mode == 2) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 2, BKF>), grid, dim3(256), 0, s, a);
     else if (mode == 1) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 1, BKF>), grid, dim3(256), 0, s, a);
     else                hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 0, 16>), grid, dim3(256), 0, s, a);
 }
