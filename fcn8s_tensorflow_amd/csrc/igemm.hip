@@ -418,7 +418,7 @@ void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s)
 // FAST = (Adim % BM == 0, Bdim % BN == 0, Pb >= 16): pixel coordinates of each thread's load slots
 // are advanced incrementally (16 pixels per K-tile), loads are unconditional + select.
 template <int BM, int BN, int WM, int WN, int WK, bool FAST, bool COLSUM>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, const int chunk)
+__global__ __launch_bounds__(256, FAST ? 4 : 1) void wgrad_kernel(const WgradArgs p, const int chunk)
 {
     constexpr int BK = 16, LDA = BM, LDB = BN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
