@@ -869,6 +869,109 @@ bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, 
     return true;
 }
 
+// ===========================================================================
+// weight gradient of the stride-S, K = 2S transposed conv (the 16x16 / stride-8 upsampler):
+//   dW[ky][kx][co][ci] = sum_{n,i,j} dY[n, S*i + ky - S/2, S*j + kx - S/2, co] * X[n, i, j, ci]
+// C = 20 channels: a 20 x 20 product per tap would waste 61 % of a 32 x 32 MFMA tile, and the generic kernel
+// re-read dY once per tap (256 taps).  VALU instead: a block owns one filter row ky and a 64-pixel segment of input
+// rows; the matching dY row segment (S*64 + S pixels x C) and the X segment sit in LDS, thread (kx mod 8, co)
+// keeps the partial sums of two taps dW[ky][kx + 8q][co][:] in registers (packed fp32 FMAs; X via LDS broadcast reads).  dY is read twice in
+// total (each output row serves two ky), atomics once per block at the end.
+// ===========================================================================
+struct TconvWgradArgs { const float* X; const float* dY; float* dW; int N, Hi, Wi, rows_per_block; };
+
+template <int C, int K, int S>
+__global__ __launch_bounds__(K / 2 * C) void tconv_wgrad_kernel(const TconvWgradArgs p)
+{
+    constexpr int JSEG = 64, PAD = (K - S) / 2, SEGPIX = JSEG * S + (K - S);      // dY pixels one segment touches
+    constexpr int NT = K / 2 * C, TQ = 2, KQ = K / TQ, HALVES = NT / (KQ * C);     // thread = (kx mod KQ, co); owns the TQ taps kx + KQ*q
+    // (TQ = 4 with the segment split between two thread halves was measured: 196 VGPRs, 2x slower)
+    __shared__ __attribute__((aligned(16))) float dys[SEGPIX * C];
+    __shared__ __attribute__((aligned(16))) float xs[JSEG * C];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, half = tid / (KQ * C), tt = tid - half * (KQ * C), kx = tt / C, co = tt - kx * C;
+    const int ky = blockIdx.x, j0 = blockIdx.y * JSEG;
+    const int Ho = p.Hi * S, Wo = p.Wi * S;
+    const int ox0 = j0 * S - PAD;                                                 // first dY column of the segment (may be < 0)
+    const int jn = p.Wi - j0 < JSEG ? p.Wi - j0 : JSEG;
+    f32x2 acc[TQ][C / 2];                                                         // packed fp32 FMA: two ci per instruction
+#pragma unroll
+    for (int q = 0; q < TQ; ++q)
+#pragma unroll
+        for (int c = 0; c < C / 2; ++c) acc[q][c] = f32x2{0.f, 0.f};
+    const long long row0 = (long long)blockIdx.z * p.rows_per_block, nrows = (long long)p.N * p.Hi;
+    for (long long r = row0; r < row0 + p.rows_per_block && r < nrows; ++r) {
+        const int n = (int)(r / p.Hi), i = (int)(r - (long long)n * p.Hi);
+        const int oy = i * S + ky - PAD;
+        if ((unsigned)oy >= (unsigned)Ho) continue;                               // block-uniform
+        const float* dyrow = p.dY + ((long long)n * Ho + oy) * Wo * C;
+        const float* xrow = p.X + (((long long)n * p.Hi + i) * p.Wi + j0) * C;
+        constexpr int NF4 = SEGPIX * C / 4, FILL = (NF4 + NT - 1) / NT, XF4 = JSEG * C / 4, XFILL = (XF4 + NT - 1) / NT;
+        float4 stage[FILL], xst[XFILL];
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {                                       // all loads in flight before the first LDS store
+            const int f = tid + it * NT;
+            const int px = ox0 + (f * 4) / C;                                     // C % 4 == 0: a float4 never straddles two pixels
+            stage[it] = (f < NF4 && (unsigned)px < (unsigned)Wo) ? *reinterpret_cast<const float4*>(dyrow + (long long)ox0 * C + f * 4)
+                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < XFILL; ++it) {
+            const int f = tid + it * NT;
+            xst[it] = (f < jn * C / 4) ? *reinterpret_cast<const float4*>(xrow + f * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();                                                          // previous row's readers are done
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {
+            const int f = tid + it * NT;
+            if (f < NF4) *reinterpret_cast<float4*>(&dys[f * 4]) = stage[it];
+        }
+#pragma unroll
+        for (int it = 0; it < XFILL; ++it) {
+            const int f = tid + it * NT;
+            if (f < XF4) *reinterpret_cast<float4*>(&xs[f * 4]) = xst[it];
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int jj = 0; jj < JSEG / HALVES; ++jj) {                              // columns >= jn hold zeros
+            const int j = half * (JSEG / HALVES) + jj;
+            f32x2 d[TQ];
+#pragma unroll
+            for (int q = 0; q < TQ; ++q) { const float v = dys[(j * S + kx + KQ * q) * C + co]; d[q] = f32x2{v, v}; }   // zero outside the image
+#pragma unroll
+            for (int c4 = 0; c4 < C / 4; ++c4) {
+                const float4 xv = *reinterpret_cast<const float4*>(&xs[j * C + c4 * 4]);             // one address per half-block: LDS broadcast
+                const f32x2 xa = {xv.x, xv.y}, xb = {xv.z, xv.w};
+#pragma unroll
+                for (int q = 0; q < TQ; ++q) {
+                    acc[q][2 * c4] = __builtin_elementwise_fma(d[q], xa, acc[q][2 * c4]);
+                    acc[q][2 * c4 + 1] = __builtin_elementwise_fma(d[q], xb, acc[q][2 * c4 + 1]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) {
+        float* out = p.dW + ((long long)(ky * K + kx + KQ * q) * C + co) * C;
+#pragma unroll
+        for (int c = 0; c < C / 2; ++c) { unsafeAtomicAdd(out + 2 * c, acc[q][c][0]); unsafeAtomicAdd(out + 2 * c + 1, acc[q][c][1]); }
+    }
+}
+
+bool launch_tconv_wgrad(const float* X, const float* dY, float* dW, int N, int Hi, int Wi, int C, int K, int S, hipStream_t s)
+{
+    if (!(C == 20 && K == 16 && S == 8)) return false;
+    TconvWgradArgs a{X, dY, dW, N, Hi, Wi, 0};
+    const long long nrows = (long long)N * Hi;
+    const int jsegs = (Wi + 63) / 64;
+    long long zb = 2048 / (16 * jsegs); if (zb < 1) zb = 1; if (zb > nrows) zb = nrows;
+    a.rows_per_block = (int)((nrows + zb - 1) / zb);
+    zb = (nrows + a.rows_per_block - 1) / a.rows_per_block;
+    g_last_kernel = "tconv_wgrad_kernel<20, 16, 8>";
+    hipLaunchKernelGGL((tconv_wgrad_kernel<20, 16, 8>), dim3(16, (unsigned)jsegs, (unsigned)zb), dim3(160), 0, s, a);
+    return true;
+}
+
 template <int BM, int BN, int WM, int WN, int WK>
 static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
 {

@@ -361,8 +361,9 @@ void tconv_wgrad(fcn8s_model* m, const float* x, const float* dy, float* dw, int
     a.Bdim = C; a.ldb = C;
     a.KW = K; a.a_scale = S; a.tap_off = -(K - S) / 2; a.ntaps = K * K;
     a.ldc = C; a.alpha = 1.f; a.colsum = nullptr;
-    if (m) { ProfScope ps(m, "tconv_wgrad", 2.0 * a.P * K * K * C * C, 4.0 * ((double)N * Hi * S * Wi * S * C + (double)a.P * C)); launch_wgrad(a, s); }
-    else launch_wgrad(a, s);
+    auto run = [&]() { if (!launch_tconv_wgrad(x, dy, dw, N, Hi, Wi, C, K, S, s)) launch_wgrad(a, s); };
+    if (m) { ProfScope ps(m, "tconv_wgrad", 2.0 * a.P * K * K * C * C, 4.0 * ((double)N * Hi * S * Wi * S * C + (double)a.P * C)); run(); }
+    else run();
 }
 
 // ---- workspace --------------------------------------------------------------------

@@ -11,4 +11,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> $OUT/bench.err
 python tools/pmc_summary.py $OUT/pmc_fetch/bench_counter_collection.csv $OUT/pmc_write/bench_counter_collection.csv $OUT/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline ($TAG)" > $OUT/pmc_summary.txt
 python bench.py --steps 10 --warmup 3 --mode infer --batch 1 --no-cpu-baseline > $OUT/bench_infer_bs1.json 2>> $OUT/bench.err
+python bench.py --steps 10 --warmup 3 --precision bf16_fc --no-cpu-baseline > $OUT/bench_train_bs16_bf16_fc.json 2>> $OUT/bench.err
+python bench.py --steps 10 --warmup 3 --optimizer adam --no-cpu-baseline > $OUT/bench_train_bs16_tf_adam.json 2>> $OUT/bench.err
 cat $OUT/bench_train_bs16.json
