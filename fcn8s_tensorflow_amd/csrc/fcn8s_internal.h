@@ -126,10 +126,15 @@ void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, i
 void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, int KS, hipStream_t s);   // x[N,H,W,C] -> v[P][T][nsub*C]
 // F(4x4,3x3) only: V = B^T dy B (input transform of the data-gradient conv) AND dM = A dy A^T (weight-gradient transform) from
 // one read of dy; returns false if the shape is not covered.
-bool launch_wino_input_dout(const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s);
+// pidx != nullptr: `dy` is instead the gradient of the 2x2/2 max-pool output, [N,H/2,W/2,C], and pidx the per-window argmax bytes
+// written by launch_wino_output -- the max-pool backward (with the ReLU mask) is applied on the fly and dy never exists in HBM.
+bool launch_wino_input_dout(const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s, const unsigned char* pidx = nullptr);
+bool wino_fuse_dz_enabled();
 void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
                         int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,
-                        unsigned int stream_id, hipStream_t s);                                                 // m[P][T][C] -> y[N,H,W,C]
+                        unsigned int stream_id, hipStream_t s, float* pool = nullptr, unsigned char* pidx = nullptr);   // m[P][T][C] -> y[N,H,W,C]
+// (pool != nullptr: also writes the 2x2/2 max-pool of y, [N,H/2,W/2,C] -- the tiles are aligned with the pool windows -- and,
+//  if pidx != nullptr, one byte per pooled element: index 0..3 of the window's first maximum, 4 if that maximum is not > 0)
 void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s);          // dy -> dm[P][T][C] = A dY A^T
 void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, int KS, hipStream_t s);        // du[P][nsub*Cin][Cout] -> dw[KS*KS][Cin][Cout]
 void launch_init_normal(float* w, long long n, float stddev, int truncated, unsigned long long seed,

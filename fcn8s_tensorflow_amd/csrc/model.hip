@@ -59,6 +59,7 @@ struct fcn8s_model {
     int wino_tile = 4;                                                    // F(4x4,3x3) where H, W % 4 == 0, else F(2x2,3x3)
     int wino_fc6 = 1;                                                     // fc6 7x7 as nine 3x3 sub-filters in the Winograd domain
     int precision = FCN8S_PREC_F32;                                       // FCN8S_PREC_BF16_FC: forward fc6 / fc7 on the bf16 MFMA
+    bool pool_fused[5] = {false, false, false, false, false};            // forward wrote pool_b + argmax bytes from conv_b_last's output transform
     std::string fused_v_layer;                                            // layer whose data-gradient input transform already sits in d_wino_v
     unsigned short* d_wbf16 = nullptr;                                    // bf16 K-tile-major copy of the fc6 / fc7 kernel (one at a time)
     hipStream_t stream = nullptr;
@@ -191,7 +192,9 @@ struct ProfScope {
 // ---- layer launchers ------------------------------------------------------------
 struct Epi { const float* bias = nullptr; const float* addend = nullptr; const float* mask = nullptr;
              float alpha = 1.f; int relu = 0; float mask_scale = 1.f; int dropout = 0; float keep = 1.f;
-             uint32_t stream_id = 0; int dgrad = 0; };   // dgrad: data-gradient launch (profile tag; never keeps V)
+             uint32_t stream_id = 0; int dgrad = 0;      // dgrad: data-gradient launch (profile tag; never keeps V)
+             float* pool_out = nullptr;                  // 2x2/2 max-pool of the output, written by the Winograd output transform if that path runs
+             unsigned char* pool_idx = nullptr; };       // ... with the per-window argmax bytes the backward pass routes the pool gradient by
 
 // 3x3 SAME conv through Winograd F(tile x tile, 3x3): filter transform, input transform, (tile+2)^2 batched GEMMs
 // on the matrix cores (2.25x / 4x fewer MFMA flops than the direct form), output transform + fused epilogue.
@@ -202,7 +205,7 @@ int wino_tile_for(const fcn8s_model* m, int H, int W)
     return (H % 2 == 0 && W % 2 == 0) ? 2 : 0;
 }
 struct WinoEpi { const float* bias = nullptr; const float* addend = nullptr; const float* mask = nullptr; float mask_scale = 1.f;
-                 int relu = 0; int dropout = 0; float keep = 1.f; unsigned long long seed = 0; unsigned int stream_id = 0; };
+                 int relu = 0; int dropout = 0; float keep = 1.f; unsigned long long seed = 0; unsigned int stream_id = 0; float* pool = nullptr; unsigned char* pidx = nullptr; };
 // KS = 3, or 7 (3x3 grid of 3x3 sub-filters, GEMM depth 9*Cin -- see winograd.hip)
 void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const float* x, const float* wk, float* y, float* u, float* v, float* mm,
                    int N, int H, int W, int Cin, int Cout, const WinoEpi& e, hipStream_t s, const char* layer, bool v_ready = false)
@@ -219,10 +222,10 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
     a.out_scale = 1; a.phases_x = 1; a.w_phase_stride = (long long)Kg * Cout;
     a.alpha = 1.f; a.mask_scale = 1.f;
     a.batched = 1; a.x_batch_stride = wino_slab(T, Kg); a.y_batch_stride = wino_slab(T, Cout);
-    const double tb = 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg), ob = 4.0 * ((double)N * H * W * Cout + (double)P * T * Cout);
+    const double tb = 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg), ob = 4.0 * ((double)N * H * W * Cout * (e.pool ? 1.25 : 1.0) + (double)P * T * Cout);
     // v_ready: V was written together with the weight gradient's dM by the fused transform (launch_wino_input_dout)
     auto pre = [&]() { launch_wino_filter(tile, wk, u, Cin, Cout, KS, s); if (!v_ready) launch_wino_input(tile, x, v, N, H, W, Cin, KS, s); };
-    auto post = [&]() { launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s); };
+    auto post = [&]() { launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s, e.pool, e.pidx); };
     if (m) {
         { ProfScope ps(m, "wino_transform", 0, (v_ready ? 0.0 : tb) + (double)(KS * KS + P * nsub2) * 4 * Cin * Cout); pre(); }
         { ProfScope ps(m, tag, 2.0 * P * T * Kg * Cout, 4.0 * P * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_igemm(a, P, s); }
@@ -230,8 +233,8 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
     } else { pre(); launch_igemm(a, P, s); post(); }
 }
 
-// SAME conv (or its data gradient when `w` holds flipped+transposed weights)
-void conv_same(fcn8s_model* m, const char* group, const float* x, const float* w, float* y,
+// SAME conv (or its data gradient when `w` holds flipped+transposed weights).  Returns true if e.pool_out was written.
+bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w, float* y,
                int N, int H, int W, int Cin, int Cout, int K, const Epi& e, hipStream_t s, int real_cin = 0,
                const char* layer = nullptr)
 {
@@ -244,10 +247,10 @@ void conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
         m->fused_v_layer.clear();
         if (!dgrad && layer) { auto it = m->acts.find(std::string("wv:") + layer); if (it != m->acts.end()) vbuf = it->second.p; }
         WinoEpi we; we.bias = e.bias; we.addend = e.addend; we.mask = e.mask; we.mask_scale = e.mask_scale; we.relu = e.relu;
-        we.dropout = e.dropout; we.keep = e.keep; we.seed = m->seed; we.stream_id = e.stream_id;
+        we.dropout = e.dropout; we.keep = e.keep; we.seed = m->seed; we.stream_id = e.stream_id; we.pool = e.pool_out; we.pidx = e.pool_idx;
         const char* tag = K == 7 ? (dgrad ? "wino_gemm_fc6_dgrad" : "wino_gemm_fc6_fwd") : (dgrad ? "wino_gemm_dgrad" : "wino_gemm_fwd");
         conv_winograd(m, wino_tile_for(m, H, W), K, tag, x, w, y, m->d_wino_u, vbuf, m->d_wino_m, N, H, W, Cin, Cout, we, s, layer, v_ready);
-        return;
+        return e.pool_out != nullptr;
     }
     if (m) m->fused_v_layer.clear();
     IgemmArgs a{};
@@ -264,6 +267,7 @@ void conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
     const double bytes = 4.0 * (a.M * rc + (double)a.M * Cout + (double)K * K * rc * Cout);
     if (m) { ProfScope ps(m, group, flops, bytes, layer); launch_igemm(a, 1, s); }
     else launch_igemm(a, 1, s);
+    return false;
 }
 
 // transposed conv forward (k = 2s) as s*s phase-specific 2x2 convs; wp = phase-packed weights
@@ -302,7 +306,7 @@ void tconv_dgrad(fcn8s_model* m, const float* dy, const float* w, float* dx, int
 
 void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* dz, float* dw, float* db,
                 int N, int H, int W, int Cin, int Cout, int K, float alpha, hipStream_t s, int real_cin = 0,
-                const char* layer = nullptr, bool fuse_dgrad_input = false)
+                const char* layer = nullptr, bool fuse_dgrad_input = false, const unsigned char* pool_idx = nullptr)
 {
     WgradArgs a{};
     a.A = x; a.B = dz; a.C = dw;
@@ -329,14 +333,20 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             // fuse_dgrad_input: the data gradient of this layer follows and runs through Winograd too -- its input
             // transform V = B^T dz B is written into d_wino_v by the same kernel that writes dM (one read of dz)
             bool fused = false;
-            { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout + (fuse_dgrad_input ? 2.0 : 1.0) * NP * T * Cout));
-              if (fuse_dgrad_input && tile == 4 && K == 3) fused = launch_wino_input_dout(dz, m->d_wino_v, m->d_wino_m, N, H, W, Cout, s);
+            { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout * (pool_idx ? 0.3125 : 1.0) + (fuse_dgrad_input ? 2.0 : 1.0) * NP * T * Cout));
+              // pool_idx: dz is d(pool) [N,H/2,W/2,Cout]; the max-pool backward happens inside the transform (the caller checked eligibility)
+              if (fuse_dgrad_input && tile == 4 && K == 3) fused = launch_wino_input_dout(dz, m->d_wino_v, m->d_wino_m, N, H, W, Cout, s, pool_idx);
               if (!fused) launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s); }
             m->fused_v_layer = fused ? layer : "";
             { ProfScope ps(m, K == 7 ? "wino_gemm_fc6_wgrad" : "wino_gemm_wgrad", 2.0 * NP * T * Kg * Cout, 4.0 * NP * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_wgrad(g, s); }
-            { ProfScope ps(m, "wino_transform", 0, 4.0 * (9.0 + NP) * Cin * Cout + 4.0 * N * H * W * Cout);
+            { ProfScope ps(m, "wino_transform", 0, 4.0 * (9.0 + NP) * Cin * Cout + 4.0 * N * H * W * Cout * ((tile == 4 && (pool_idx || fused)) ? 1.0 / 16 : 1.0));
               launch_wino_dfilter(tile, m->d_wino_u, dw, Cin, Cout, K, s);
-              if (db) launch_colsum(dz, db, (long long)N * H * W, Cout, s); }
+              // bias gradient = sum of dz over all pixels.  dM[(1,1)] = sum_kl A^T(k,1) dz[k][l] A^T(l,1) and column 1 of A^T is all ones:
+              // the slab of position (1,1) holds the per-tile sums -- 16x fewer bytes than dz, and dz need not exist
+              if (db) {
+                  if (tile == 4 && (pool_idx || fused)) launch_colsum(m->d_wino_m + 7 * wino_slab(T, Cout), db, T, Cout, s);
+                  else launch_colsum(dz, db, (long long)N * H * W, Cout, s);
+              } }
             return;
         }
     }
@@ -394,6 +404,10 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
         add(nm, h, w, m->widths[b]);
     }
     const int h5 = H / 32, w5 = W / 32, h4 = H / 16, w4 = W / 16, h3 = H / 8, w3 = W / 8;
+    for (int b = 0; b < 5; ++b) {      // argmax bytes of pool_b (one per pooled element), see launch_wino_output
+        char nm[16]; snprintf(nm, sizeof nm, "pidx%d", b + 1);
+        items.push_back({nm, ((size_t)N * (H >> (b + 1)) * (W >> (b + 1)) * (size_t)m->widths[b] + 3) / 4, 0, 0, 0, nullptr});
+    }
     add("fc6", h5, w5, m->widths[5]);
     add("fc7", h5, w5, m->widths[6]);
     add("s7", h5, w5, C); add("p4", h4, w4, C); add("p3", h3, w3, C);
@@ -504,16 +518,22 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     const float* x = A(m, "x0");
     int h = H, w = W, cin = 4;
     for (int b = 0; b < 5; ++b) {
+        char pn[32]; bool pooled = false;
         for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
             char nm[32]; snprintf(nm, sizeof nm, "conv%d_%d", b + 1, i);
             const bool first = (b == 0 && i == 1);
             Epi e; e.bias = Wp(m, std::string(nm) + "/biases"); e.relu = 1;
             const float* wt = first ? m->d_w1pad : Wp(m, std::string(nm) + "/filter");
-            conv_same(m, first ? "conv1_1_fwd" : "conv3x3_fwd", x, wt, A(m, nm), N, h, w, cin, m->widths[b], 3, e, s, first ? 3 : 0, nm);
+            if (i == kConvsPerBlock[b]) {                                                                    // last conv of the block
+                snprintf(pn, sizeof pn, "pool%d", b + 1); e.pool_out = A(m, pn);
+                if (train) { char ix[16]; snprintf(ix, sizeof ix, "pidx%d", b + 1); e.pool_idx = (unsigned char*)A(m, ix); }
+            }
+            pooled = conv_same(m, first ? "conv1_1_fwd" : "conv3x3_fwd", x, wt, A(m, nm), N, h, w, cin, m->widths[b], 3, e, s, first ? 3 : 0, nm);
             x = A(m, nm); cin = m->widths[b];
         }
-        char pn[32]; snprintf(pn, sizeof pn, "pool%d", b + 1);
-        { ProfScope ps(m, "maxpool_fwd", 0, 4.0 * N * h * w * cin * 1.25); launch_maxpool_fwd(x, A(m, pn), N, h, w, cin, s); }
+        snprintf(pn, sizeof pn, "pool%d", b + 1);
+        m->pool_fused[b] = pooled && train;
+        if (!pooled) { ProfScope ps(m, "maxpool_fwd", 0, 4.0 * N * h * w * cin * 1.25); launch_maxpool_fwd(x, A(m, pn), N, h, w, cin, s); }
         x = A(m, pn); h /= 2; w /= 2;
     }
     const int h5 = h, w5 = w;
@@ -664,10 +684,20 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
         const int cw = m->widths[b - 1];
         const int nconv = kConvsPerBlock[b - 1];
         char last[32]; snprintf(last, sizeof last, "conv%d_%d", b, nconv);
-        // d(pool_b) in gbuf[gcur] -> dZ of the last conv (ReLU mask fused)
-        { ProfScope ps(m, "maxpool_bwd", 0, 4.0 * N * h * w * cw * 2.25);
-          launch_maxpool_bwd(A(m, last), m->gbuf[m->gcur], m->gbuf[m->gcur ^ 1], N, h, w, cw, 1, s); }
-        m->gcur ^= 1;
+        // d(pool_b) in gbuf[gcur] -> dZ of the last conv (ReLU mask fused).  If the forward pass kept the argmax bytes and both
+        // gradients of that conv run through Winograd, the routing happens inside their shared transform and dZ is never written.
+        const unsigned char* pidx = nullptr;
+        {
+            char ix[16]; snprintf(ix, sizeof ix, "pidx%d", b);
+            const bool wino_both = m->pool_fused[b - 1] && wino_fuse_dz_enabled() && m->wino_min_cin > 0 && cw >= m->wino_min_cin && m->d_wino_v &&
+                                   wino_tile_for(m, h, w) == 4 && cw % 64 == 0 && nconv > 1 && m->acts.count(std::string("wv:") + last);
+            if (wino_both) pidx = (const unsigned char*)A(m, ix);
+        }
+        if (!pidx) {
+            ProfScope ps(m, "maxpool_bwd", 0, 4.0 * N * h * w * cw * 2.25);
+            launch_maxpool_bwd(A(m, last), m->gbuf[m->gcur], m->gbuf[m->gcur ^ 1], N, h, w, cw, 1, s);
+            m->gcur ^= 1;
+        }
         for (int i = nconv; i >= 1; --i) {
             char nm[32]; snprintf(nm, sizeof nm, "conv%d_%d", b, i);
             const float* dz = m->gbuf[m->gcur];
@@ -681,7 +711,7 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
             const bool dgrad_wino = !first && m->wino_min_cin > 0 && cw >= m->wino_min_cin && m->d_wino_v && wino_tile_for(m, h, w) == 4 &&
                                     cw % 16 == 0 && cin % 64 == 0;
             conv_wgrad(m, first ? "conv1_1_wgrad" : "conv3x3_wgrad", xin, dz, Gp(m, std::string(nm) + "/filter"), Gp(m, std::string(nm) + "/biases"),
-                       N, h, w, cin, cw, 3, 1.f, s, real_cin, nm, dgrad_wino);
+                       N, h, w, cin, cw, 3, 1.f, s, real_cin, nm, dgrad_wino, i == nconv ? pidx : nullptr);
             if (first) break;
             Epi e; e.dgrad = 1;
             if (i > 1) { e.mask = xin; e.mask_scale = 1.f; }               // ReLU of the previous conv

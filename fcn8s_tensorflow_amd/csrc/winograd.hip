@@ -167,9 +167,11 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restric
 
 // ---- F(4x4,3x3) backward pair: the data-gradient conv needs V = B^T dy B, the weight gradient dM = A dy A^T of the same
 // tensor (dM's 4x4 tile is the inside of V's 6x6 patch): both from one read of dy -------------------------------------------
-template <int VEC>
+// POOL: dy is not materialised -- it is the max-pool backward of dpool [N,H/2,W/2,C] routed by the argmax bytes the forward
+// output transform kept (dy[pixel] = dpool[window] if the pixel is the window's first maximum and that maximum is > 0).
+template <int VEC, bool POOL>
 __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __restrict__ x, float4* __restrict__ v, float4* __restrict__ dm,
-                                                              int N, int H, int W, int C4, long long slab)
+                                                              int N, int H, int W, int C4, long long slab, const unsigned char* __restrict__ pidx)
 {
     constexpr int M = 4, A = 6;
     const int th = H / M, tw = W / M;
@@ -181,11 +183,33 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
 #pragma unroll
     for (int a = 0; a < A; ++a) { rok[a] = (unsigned)(y0 + a) < (unsigned)H; cok[a] = (unsigned)(x0 + a) < (unsigned)W; }
     float4 q[A][A], p[A][M];
+    // POOL: the patch rows y0..y0+5 = 4ty-1..4ty+4 touch window rows 2ty-1..2ty+2 (4 of them); same for columns
+    const int Hp = H / 2, Wp = W / 2;
+    const long long wbase = (((long long)ti.n * Hp + (2 * ti.ty - 1)) * Wp + (2 * ti.tx - 1)) * C4 + ti.c;
 #pragma unroll
     for (int b = 0; b < A; ++b) {
         float4 d[A];
+        if (POOL) {
+            const int wc = (b + 1) >> 1;                                   // window column 0..3 of patch column b; (x0 + b) & 1 == (b + 1) & 1
 #pragma unroll
-        for (int a = 0; a < A; ++a) d[a] = (rok[a] && cok[b]) ? xp[(a * W + b) * C4] : f4zero();
+            for (int wr = 0; wr < 4; ++wr) {                               // window rows; patch rows 2wr-1, 2wr
+                const bool wok = (unsigned)(2 * ti.ty - 1 + wr) < (unsigned)Hp && (unsigned)(2 * ti.tx - 1 + wc) < (unsigned)Wp;
+                const long long wo = wbase + ((long long)wr * Wp + wc) * C4;
+                float4 g = f4zero();
+                unsigned char id[VEC];
+                _Pragma("unroll") for (int i = 0; i < VEC; ++i) id[i] = 4;
+                if (wok) { g = x[wo]; _Pragma("unroll") for (int i = 0; i < VEC; ++i) id[i] = pidx[wo * VEC + i]; }
+                _Pragma("unroll") for (int half = 0; half < 2; ++half) {
+                    const int a = 2 * wr - 1 + half;                       // patch row; its parity inside the window is (a + 1) & 1 == half ^ 1 ... see pos
+                    if (a < 0 || a >= A) continue;
+                    const int pos = ((a + 1) & 1) * 2 + ((b + 1) & 1);     // (row parity, column parity) of the pixel inside its window
+                    _Pragma("unroll") for (int i = 0; i < VEC; ++i) d[a].d[i] = id[i] == pos ? g.d[i] : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < A; ++a) d[a] = (rok[a] && cok[b]) ? xp[(a * W + b) * C4] : f4zero();
+        }
 #pragma unroll
         for (int a = 0; a < A; ++a) {
             float4 s = f4zero();
@@ -230,7 +254,7 @@ template <int M, int VEC, bool DROPOUT>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restrict__ m, const float4* __restrict__ bias, const float4* __restrict__ addend,
                                                           const float4* __restrict__ mask, float mask_scale, int relu, float4* __restrict__ y,
                                                           int N, int H, int W, int C4, float keep, unsigned long long seed, unsigned int stream_id,
-                                                          long long slab)
+                                                          long long slab, float4* __restrict__ pool, unsigned char* __restrict__ pidx)
 {
     constexpr int A = WinoMat<M>::A;
     const int th = H / M, tw = W / M;
@@ -253,6 +277,9 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restri
     }
     const float4 bv = bias ? bias[ti.c] : f4zero();
     const long long off0 = (((long long)ti.n * H + M * ti.ty) * W + M * ti.tx) * C4 + ti.c;
+    float4 pmax[M / 2][M / 2];                 // pool != nullptr: the 2x2/2 max-pool of this tile (tile origins are even), written below
+    unsigned char parg[M / 2][M / 2][VEC];     // pidx != nullptr: which window element is the FIRST maximum (0..3; 4 = max not > 0, i.e. no
+                                               // gradient through the ReLU) -- the routing rule of maxpool_bwd_kernel, kept for the backward pass
 #pragma unroll
     for (int oy = 0; oy < M; ++oy)
 #pragma unroll
@@ -273,7 +300,26 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restri
                 _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = philox_uniform(e + i, seed, stream_id) < keep ? v.d[i] * ik : 0.f;
             }
             y[off] = v;
+            if ((oy & 1) == 0 && (ox & 1) == 0) {
+                pmax[oy / 2][ox / 2] = v;
+                _Pragma("unroll") for (int i = 0; i < VEC; ++i) parg[oy / 2][ox / 2][i] = 0;
+            } else {
+                _Pragma("unroll") for (int i = 0; i < VEC; ++i)
+                    if (v.d[i] > pmax[oy / 2][ox / 2].d[i]) { pmax[oy / 2][ox / 2].d[i] = v.d[i]; parg[oy / 2][ox / 2][i] = (unsigned char)((oy & 1) * 2 + (ox & 1)); }
+            }
         }
+    if (pool) {
+        const int Hp = H / 2, Wp = W / 2;
+#pragma unroll
+        for (int py = 0; py < M / 2; ++py)
+#pragma unroll
+            for (int px = 0; px < M / 2; ++px)
+            {
+                const long long po = (((long long)ti.n * Hp + (M / 2) * ti.ty + py) * Wp + (M / 2) * ti.tx + px) * C4 + ti.c;
+                pool[po] = pmax[py][px];
+                if (pidx) { _Pragma("unroll") for (int i = 0; i < VEC; ++i) pidx[po * VEC + i] = pmax[py][px].d[i] > 0.f ? parg[py][px][i] : (unsigned char)4; }
+            }
+    }
 }
 
 // ---- weight gradient: dM = A dY A^T (alpha x alpha from the m x m output-gradient tile) ------------------------------
@@ -368,12 +414,15 @@ long long wino_slab(long long T, int C)
     static const int skew = env_flag("FCN8S_WINO_SKEW", 1088) / 4 * 4;
     return T * C + skew;
 }
-bool launch_wino_input_dout(const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s)
+bool wino_fuse_dz_enabled() { static const int on = env_flag("FCN8S_WINO_FUSE_DZ", 1); return on != 0; }
+bool launch_wino_input_dout(const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s, const unsigned char* pidx)
 {
-    static const int on = env_flag("FCN8S_WINO_FUSE_DZ", 1);
-    if (!on || H % 4 || W % 4 || C % 2) return false;
-    hipLaunchKernelGGL((wino_input_dout_kernel<2>), tile_grid(N, H / 4, W / 4, C / 2), dim3(256), 0, s,
-                       (const VecF<2>*)dy, (VecF<2>*)v, (VecF<2>*)dm, N, H, W, C / 2, wino_slab((long long)N * (H / 4) * (W / 4), C) / 2);
+    if (!wino_fuse_dz_enabled() || H % 4 || W % 4 || C % 2) return false;
+    const long long slab = wino_slab((long long)N * (H / 4) * (W / 4), C) / 2;
+    if (pidx) hipLaunchKernelGGL((wino_input_dout_kernel<2, true>), tile_grid(N, H / 4, W / 4, C / 2), dim3(256), 0, s,
+                                 (const VecF<2>*)dy, (VecF<2>*)v, (VecF<2>*)dm, N, H, W, C / 2, slab, pidx);
+    else      hipLaunchKernelGGL((wino_input_dout_kernel<2, false>), tile_grid(N, H / 4, W / 4, C / 2), dim3(256), 0, s,
+                                 (const VecF<2>*)dy, (VecF<2>*)v, (VecF<2>*)dm, N, H, W, C / 2, slab, pidx);
     return true;
 }
 void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, int KS, hipStream_t s)
@@ -386,11 +435,11 @@ void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, 
 }
 void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
                         int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,
-                        unsigned int stream_id, hipStream_t s)
+                        unsigned int stream_id, hipStream_t s, float* pool, unsigned char* pidx)
 {
 #define FCN8S_WOUT(M_, V_, D_) hipLaunchKernelGGL((wino_output_kernel<M_, V_, D_>), tile_grid(N, H / M_, W / M_, C / V_), dim3(256), 0, s, \
         (const VecF<V_>*)m, (const VecF<V_>*)bias, (const VecF<V_>*)addend, (const VecF<V_>*)mask, mask_scale, relu, (VecF<V_>*)y, N, H, W, C / V_, keep, seed, stream_id, \
-        wino_slab((long long)N * (H / M_) * (W / M_), C) / V_)
+        wino_slab((long long)N * (H / M_) * (W / M_), C) / V_, (VecF<V_>*)pool, pidx)
     if (tile == 4) { if (dropout) FCN8S_WOUT(4, 2, true); else FCN8S_WOUT(4, 2, false); }
     else           { if (dropout) FCN8S_WOUT(2, 4, true); else FCN8S_WOUT(2, 4, false); }
 #undef FCN8S_WOUT
