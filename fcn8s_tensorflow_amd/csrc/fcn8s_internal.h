@@ -121,6 +121,9 @@ void launch_dropout_mask(float* mask, long long n, float keep_prob, unsigned lon
 // Winograd F(tile x tile, 3x3) transforms (tile = 2 or 4) around P = (tile+2)^2 batched GEMMs; H, W % tile == 0, C % 4 == 0.
 // KS = 3: plain 3x3 conv.  KS = 7: the filter is cut into a 3x3 grid of 3x3 sub-filters whose products add up in the
 // Winograd domain (GEMM depth 9*C); u / v rows are then [sub][channel].
+int wino_r(int KS);                 // sub-filter size: 3 for 3x3 kernels; 7x7 (fc6): 4 by default (FCN8S_WINOGRAD_FC6_R=3 selects 3)
+int wino_nsub(int KS);              // sub-filters per dimension: ceil(KS / r)
+int wino_alpha(int tile, int KS);   // tile + r - 1; the number of Winograd positions is alpha^2
 long long wino_slab(long long T, int C);   // floats between the slabs of consecutive Winograd positions of a [P][T][C] tensor (T*C + skew)
 void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, int KS, hipStream_t s);         // w[KS*KS][Cin][Cout] -> u[P][nsub*Cin][Cout]
 void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, int KS, hipStream_t s);   // x[N,H,W,C] -> v[P][T][nsub*C]
@@ -132,10 +135,10 @@ bool launch_wino_input_dout(const float* dy, float* v, float* dm, int N, int H, 
 bool wino_fuse_dz_enabled();
 void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
                         int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,
-                        unsigned int stream_id, hipStream_t s, float* pool = nullptr, unsigned char* pidx = nullptr);   // m[P][T][C] -> y[N,H,W,C]
+                        unsigned int stream_id, hipStream_t s, float* pool = nullptr, unsigned char* pidx = nullptr, int KS = 3);   // m[P][T][C] -> y[N,H,W,C]
 // (pool != nullptr: also writes the 2x2/2 max-pool of y, [N,H/2,W/2,C] -- the tiles are aligned with the pool windows -- and,
 //  if pidx != nullptr, one byte per pooled element: index 0..3 of the window's first maximum, 4 if that maximum is not > 0)
-void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s);          // dy -> dm[P][T][C] = A dY A^T
+void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s, int KS = 3);   // dy -> dm[P][T][C] = A dY A^T
 void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, int KS, hipStream_t s);        // du[P][nsub*Cin][Cout] -> dw[KS*KS][Cin][Cout]
 void launch_init_normal(float* w, long long n, float stddev, int truncated, unsigned long long seed,
                         unsigned int stream_id, hipStream_t s);

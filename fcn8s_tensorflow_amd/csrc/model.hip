@@ -210,7 +210,7 @@ struct WinoEpi { const float* bias = nullptr; const float* addend = nullptr; con
 void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const float* x, const float* wk, float* y, float* u, float* v, float* mm,
                    int N, int H, int W, int Cin, int Cout, const WinoEpi& e, hipStream_t s, const char* layer, bool v_ready = false)
 {
-    const int P = (tile + 2) * (tile + 2), nsub2 = KS == 3 ? 1 : 9;
+    const int P = wino_alpha(tile, KS) * wino_alpha(tile, KS), nsub2 = wino_nsub(KS) * wino_nsub(KS);
     const long long T = (long long)N * (H / tile) * (W / tile);
     const int Kg = nsub2 * Cin;
     IgemmArgs a{};
@@ -225,7 +225,7 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
     const double tb = 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg), ob = 4.0 * ((double)N * H * W * Cout * (e.pool ? 1.25 : 1.0) + (double)P * T * Cout);
     // v_ready: V was written together with the weight gradient's dM by the fused transform (launch_wino_input_dout)
     auto pre = [&]() { launch_wino_filter(tile, wk, u, Cin, Cout, KS, s); if (!v_ready) launch_wino_input(tile, x, v, N, H, W, Cin, KS, s); };
-    auto post = [&]() { launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s, e.pool, e.pidx); };
+    auto post = [&]() { launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s, e.pool, e.pidx, KS); };
     if (m) {
         { ProfScope ps(m, "wino_transform", 0, (v_ready ? 0.0 : tb) + (double)(KS * KS + P * nsub2) * 4 * Cin * Cout); pre(); }
         { ProfScope ps(m, tag, 2.0 * P * T * Kg * Cout, 4.0 * P * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_igemm(a, P, s); }
@@ -321,9 +321,9 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
     if (m && (K == 3 || K == 7) && layer && alpha == 1.f && !real_cin && m->train_mode) {
         auto it = m->acts.find(std::string("wv:") + layer);
         if (it != m->acts.end() && m->d_wino_m) {             // weight gradient in the Winograd domain (V kept by the forward pass)
-            const int tile = wino_tile_for(m, H, W), NP = (tile + 2) * (tile + 2);
+            const int tile = wino_tile_for(m, H, W), NP = wino_alpha(tile, K) * wino_alpha(tile, K);
             const long long T = (long long)N * (H / tile) * (W / tile);
-            const int Kg = (K == 3 ? 1 : 9) * Cin;                      // rows of V / dU: [sub-filter][channel]
+            const int Kg = wino_nsub(K) * wino_nsub(K) * Cin;           // rows of V / dU: [sub-filter][channel]
             WgradArgs g{};
             g.A = it->second.p; g.B = m->d_wino_m; g.C = m->d_wino_u;
             g.N = 1; g.Pa = 1; g.Pb = (int)T; g.P = T;
@@ -336,7 +336,7 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout * (pool_idx ? 0.3125 : 1.0) + (fuse_dgrad_input ? 2.0 : 1.0) * NP * T * Cout));
               // pool_idx: dz is d(pool) [N,H/2,W/2,Cout]; the max-pool backward happens inside the transform (the caller checked eligibility)
               if (fuse_dgrad_input && tile == 4 && K == 3) fused = launch_wino_input_dout(dz, m->d_wino_v, m->d_wino_m, N, H, W, Cout, s, pool_idx);
-              if (!fused) launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s); }
+              if (!fused) launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s, K); }
             m->fused_v_layer = fused ? layer : "";
             { ProfScope ps(m, K == 7 ? "wino_gemm_fc6_wgrad" : "wino_gemm_wgrad", 2.0 * NP * T * Kg * Cout, 4.0 * NP * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_wgrad(g, s); }
             { ProfScope ps(m, "wino_transform", 0, 4.0 * (9.0 + NP) * Cin * Cout + 4.0 * N * H * W * Cout * ((tile == 4 && (pool_idx || fused)) ? 1.0 / 16 : 1.0));
@@ -437,7 +437,7 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
         }
         const int h5_ = H / 32, w5_ = W / 32;
         const bool fc6w = m->wino_fc6 && m->wino_tile == 4 && m->fc6k == 7 && h5_ % 4 == 0 && w5_ % 4 == 0 && m->widths[4] % 16 == 0 && m->widths[5] % 64 == 0;
-        if (fc6w) {     // V: 36 * T * 9*c5 = 20.25 |pool5| ;  M: 2.25 |fc6|  (the data gradient swaps the two roles)
+        if (fc6w) {     // V: P * T * nsub^2 * c5 = 20.25 |pool5| (r = 3) or 12.25 (r = 4);  M: 2.25 / 3.06 |fc6|  (the data gradient swaps the two roles)
             const size_t vf = (size_t)N * h5_ * w5_ * (size_t)std::max(m->widths[4], m->widths[5]) * 21;
             if (vf > vmax) vmax = vf;
         }
@@ -1233,7 +1233,7 @@ int fcn8s_op_conv2d_winograd(void* stream, const float* x, const float* w, const
     if ((tile != 2 && tile != 4) || (K != 3 && K != 7) || Cin % 16 || Cout % 32 || H % tile || W % tile)
         return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d_winograd: needs tile in {2,4}, K in {3,7}, Cin % 16, Cout % 32, H and W multiples of tile");
     hipStream_t s = (hipStream_t)stream;
-    const size_t T = (size_t)N * (H / tile) * (W / tile), P = (size_t)(tile + 2) * (tile + 2), Kg = (size_t)(K == 3 ? 1 : 9) * Cin;
+    const size_t T = (size_t)N * (H / tile) * (W / tile), P = (size_t)wino_alpha(tile, K) * wino_alpha(tile, K), Kg = (size_t)wino_nsub(K) * wino_nsub(K) * Cin;
     float *u = nullptr, *v = nullptr, *mm = nullptr;
     if (hipMalloc((void**)&u, P * Kg * Cout * 4) != hipSuccess || hipMalloc((void**)&v, P * (size_t)wino_slab(T, (int)Kg) * 4) != hipSuccess ||
         hipMalloc((void**)&mm, P * (size_t)wino_slab(T, Cout) * 4) != hipSuccess) return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc");

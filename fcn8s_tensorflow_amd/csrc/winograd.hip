@@ -9,10 +9,13 @@
 // direct 2e-7, F(2x2) 5e-7, F(4x4) 7e-6 of the output range -- far inside the 1e-3 logit tolerance.
 // The transforms are HBM-bound element-wise kernels (16-byte accesses along the channel axis).
 //
-// Large kernels (fc6, 7x7): the filter is zero-extended to 9x9 and cut into a 3x3 grid of 3x3 sub-filters; sub-filter
-// (a, b) is a 3x3 conv of the input shifted by (3a, 3b).  All nine share the OUTPUT tiling, so their products add up in
-// the Winograd domain: per position xi one GEMM with K = 9*Cin ([V_00 | V_01 | ... | V_22] x [U_00; ...; U_22]) --
-// 20.25 multiplies per output instead of 49, with F(4x4,3x3)'s numerics.
+// Large kernels (fc6, 7x7): the filter is zero-extended and cut into a grid of r x r sub-filters; sub-filter (a, b) is an
+// r x r conv of the input shifted by (r a, r b).  All of them share the OUTPUT tiling, so their products add up in the
+// Winograd domain: per position xi one GEMM with K = nsub^2 * Cin ([V_00 | V_01 | ...] x [U_00; U_01; ...]).
+//   r = 3: 9x9 extension, 3x3 grid, F(4x4,3x3): 36 positions, 20.25 multiplies per output instead of 49;
+//   r = 4: 8x8 extension, 2x2 grid, F(4x4,4x4): 49 positions, 12.25 multiplies per output (default for fc6).
+// F(4x4,4x4) uses the points {0, 1, -1, 1/2, -1/2, -2, inf} (Cook-Toom; matrices derived and checked symbolically): fp32
+// error 1e-5 of the output range at K = 2048 against 5e-6 for F(4x4,3x3).
 #include "fcn8s_internal.h"
 #include <cstdlib>
 
@@ -24,14 +27,14 @@ static inline int wcap(long long work)
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
-template <int M> struct WinoMat;
-template <> struct WinoMat<2> {
+template <int M, int R = 3> struct WinoMat;
+template <> struct WinoMat<2, 3> {
     static constexpr int A = 4;
     static __device__ __forceinline__ float bt(int i, int j) { constexpr float m[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}}; return m[i][j]; }
     static __device__ __forceinline__ float g(int i, int j) { constexpr float m[4][3] = {{1, 0, 0}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0, 0, 1}}; return m[i][j]; }
     static __device__ __forceinline__ float at(int i, int j) { constexpr float m[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}}; return m[i][j]; }
 };
-template <> struct WinoMat<4> {
+template <> struct WinoMat<4, 3> {
     static constexpr int A = 6;
     static __device__ __forceinline__ float bt(int i, int j)
     {
@@ -48,6 +51,29 @@ template <> struct WinoMat<4> {
     static __device__ __forceinline__ float at(int i, int j)
     {
         constexpr float m[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+        return m[i][j];
+    }
+};
+
+template <> struct WinoMat<4, 4> {                  // F(4,4), points 0, 1, -1, 1/2, -1/2, -2, inf
+    static constexpr int A = 7;
+    static __device__ __forceinline__ float bt(int i, int j)
+    {
+        constexpr float m[7][7] = {{2, 1, -10, -5, 8, 4, 0}, {0, -2, -3, 7, 12, 4, 0}, {0, 2, -1, -9, 4, 4, 0}, {0, 2, 5, 0, -5, -2, 0},
+                                   {0, -2, 3, 4, -3, -2, 0}, {0, -1, 0, 5, 0, -4, 0}, {0, 2, 1, -10, -5, 8, 4}};
+        return m[i][j];
+    }
+    static __device__ __forceinline__ float g(int i, int j)
+    {
+        constexpr float m[7][4] = {{1.f / 2, 0, 0, 0}, {1.f / 18, 1.f / 18, 1.f / 18, 1.f / 18}, {1.f / 6, -1.f / 6, 1.f / 6, -1.f / 6},
+                                   {8.f / 15, 4.f / 15, 2.f / 15, 1.f / 15}, {8.f / 9, -4.f / 9, 2.f / 9, -1.f / 9},
+                                   {1.f / 90, -1.f / 45, 2.f / 45, -4.f / 45}, {0, 0, 0, 1.f / 4}};
+        return m[i][j];
+    }
+    static __device__ __forceinline__ float at(int i, int j)
+    {
+        constexpr float m[4][7] = {{1, 1, 1, 1, 1, 1, 0}, {0, 1, -1, 1.f / 2, -1.f / 2, -2, 0}, {0, 1, 1, 1.f / 4, 1.f / 4, 4, 0},
+                                   {0, 1, -1, 1.f / 8, -1.f / 8, -8, 1}};
         return m[i][j];
     }
 };
@@ -69,29 +95,29 @@ template <int VEC> static __device__ __forceinline__ VecF<VEC> vfma(float s, con
 #define float4 VecF<VEC>
 
 // ---- filters: u[xi][sub*Cin + ci][co] = (G g_sub G^T)[xi];  g_sub = taps (3a..3a+2, 3b..3b+2) of the KS x KS filter -----
-template <int M>
+template <int M, int R>
 __global__ void wino_filter_kernel(const float* w, float* u, int Cin, int Cout, int KS, int nsub)
 {
-    constexpr int A = WinoMat<M>::A;
+    constexpr int A = WinoMat<M, R>::A;
     const long long cc = (long long)Cin * Cout, total = cc * nsub * nsub, ucc = cc * nsub * nsub;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int sub = (int)(i / cc); const long long e = i - sub * cc;
         const int sa = sub / nsub, sb = sub - sa * nsub;
-        float g[3][3], t[A][3];
+        float g[R][R], t[A][R];
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int a = 0; a < R; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const int ky = 3 * sa + a, kx = 3 * sb + b;
+            for (int b = 0; b < R; ++b) {
+                const int ky = R * sa + a, kx = R * sb + b;
                 g[a][b] = (ky < KS && kx < KS) ? w[(long long)(ky * KS + kx) * cc + e] : 0.f;
             }
 #pragma unroll
         for (int a = 0; a < A; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
+            for (int b = 0; b < R; ++b) {
                 float s = 0.f;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) s = fmaf(WinoMat<M>::g(a, k), g[k][b], s);
+                for (int k = 0; k < R; ++k) s = fmaf(WinoMat<M, R>::g(a, k), g[k][b], s);
                 t[a][b] = s;
             }
 #pragma unroll
@@ -100,7 +126,7 @@ __global__ void wino_filter_kernel(const float* w, float* u, int Cin, int Cout, 
             for (int b = 0; b < A; ++b) {
                 float s = 0.f;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) s = fmaf(t[a][k], WinoMat<M>::g(b, k), s);
+                for (int k = 0; k < R; ++k) s = fmaf(t[a][k], WinoMat<M, R>::g(b, k), s);
                 u[(long long)(a * A + b) * ucc + i] = s;           // row (sub*Cin + ci), column co
             }
     }
@@ -124,17 +150,17 @@ static __device__ __forceinline__ TileIdx tile_index(int th, int tw, int C4)
 static inline dim3 tile_grid(int N, int th, int tw, int C4, int z = 1) { return dim3((unsigned)((tw * C4 + 255) / 256), (unsigned)(N * th), (unsigned)z); }
 
 // ---- input: one thread = one m x m output tile x VEC channels; alpha x alpha patch (zero outside), V = B^T d B --------
-template <int M, int VEC>
+template <int M, int VEC, int R>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restrict__ x, float4* __restrict__ v, int N, int H, int W, int C4, int pad, int nsub,
                                                          long long slab)
 {
-    constexpr int A = WinoMat<M>::A;
+    constexpr int A = WinoMat<M, R>::A;
     const int th = H / M, tw = W / M;
-    const int sub = blockIdx.z, sa = sub / nsub, sb = sub - sa * nsub;     // sub-filter: patch shifted by (3 sa, 3 sb)
+    const int sub = blockIdx.z, sa = sub / nsub, sb = sub - sa * nsub;     // sub-filter: patch shifted by (R sa, R sb)
     const int ldv = C4 * nsub * nsub;
     const TileIdx ti = tile_index(th, tw, C4);
     if (!ti.ok) return;
-    const int y0 = M * ti.ty + 3 * sa - pad, x0 = M * ti.tx + 3 * sb - pad;
+    const int y0 = M * ti.ty + R * sa - pad, x0 = M * ti.tx + R * sb - pad;
     const float4* xp = x + (((long long)ti.n * H + y0) * W + x0) * C4 + ti.c;     // dereferenced only where (row, col) lies inside the image
     bool rok[A], cok[A];
 #pragma unroll
@@ -149,7 +175,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restric
         for (int a = 0; a < A; ++a) {
             float4 s = f4zero();
 #pragma unroll
-            for (int k = 0; k < A; ++k) if (WinoMat<M>::bt(a, k) != 0.f) s = f4fma(WinoMat<M>::bt(a, k), d[k], s);
+            for (int k = 0; k < A; ++k) if (WinoMat<M, R>::bt(a, k) != 0.f) s = f4fma(WinoMat<M, R>::bt(a, k), d[k], s);
             q[a][b] = s;
         }
     }
@@ -160,7 +186,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restric
         for (int b = 0; b < A; ++b) {          // V = q B
             float4 s = f4zero();
 #pragma unroll
-            for (int k = 0; k < A; ++k) if (WinoMat<M>::bt(b, k) != 0.f) s = f4fma(WinoMat<M>::bt(b, k), q[a][k], s);
+            for (int k = 0; k < A; ++k) if (WinoMat<M, R>::bt(b, k) != 0.f) s = f4fma(WinoMat<M, R>::bt(b, k), q[a][k], s);
             vp[(a * A + b) * slab] = s;
         }
 }
@@ -214,7 +240,7 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
         for (int a = 0; a < A; ++a) {
             float4 s = f4zero();
 #pragma unroll
-            for (int k = 0; k < A; ++k) if (WinoMat<M>::bt(a, k) != 0.f) s = f4fma(WinoMat<M>::bt(a, k), d[k], s);
+            for (int k = 0; k < A; ++k) if (WinoMat<4, 3>::bt(a, k) != 0.f) s = f4fma(WinoMat<4, 3>::bt(a, k), d[k], s);
             q[a][b] = s;
         }
         if (b >= 1 && b <= M) {
@@ -222,7 +248,7 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
             for (int a = 0; a < A; ++a) {
                 float4 s = f4zero();
 #pragma unroll
-                for (int k = 0; k < M; ++k) if (WinoMat<M>::at(k, a) != 0.f) s = f4fma(WinoMat<M>::at(k, a), d[k + 1], s);
+                for (int k = 0; k < M; ++k) if (WinoMat<4, 3>::at(k, a) != 0.f) s = f4fma(WinoMat<4, 3>::at(k, a), d[k + 1], s);
                 p[a][b - 1] = s;
             }
         }
@@ -234,7 +260,7 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
         for (int b = 0; b < A; ++b) {
             float4 s = f4zero();
 #pragma unroll
-            for (int k = 0; k < A; ++k) if (WinoMat<M>::bt(b, k) != 0.f) s = f4fma(WinoMat<M>::bt(b, k), q[a][k], s);
+            for (int k = 0; k < A; ++k) if (WinoMat<4, 3>::bt(b, k) != 0.f) s = f4fma(WinoMat<4, 3>::bt(b, k), q[a][k], s);
             v[o + (a * A + b) * slab] = s;
         }
 #pragma unroll
@@ -243,20 +269,20 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
         for (int b = 0; b < A; ++b) {
             float4 s = f4zero();
 #pragma unroll
-            for (int k = 0; k < M; ++k) if (WinoMat<M>::at(k, b) != 0.f) s = f4fma(WinoMat<M>::at(k, b), p[a][k], s);
+            for (int k = 0; k < M; ++k) if (WinoMat<4, 3>::at(k, b) != 0.f) s = f4fma(WinoMat<4, 3>::at(k, b), p[a][k], s);
             dm[o + (a * A + b) * slab] = s;
         }
 }
 
 // ---- output: one thread = one tile x VEC channels; Y = A^T M A, then the conv epilogue --------------------------------
 // DROPOUT is a template parameter: the inlined Philox rounds (fc6 only) otherwise cost every launch their registers.
-template <int M, int VEC, bool DROPOUT>
+template <int M, int VEC, bool DROPOUT, int R>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restrict__ m, const float4* __restrict__ bias, const float4* __restrict__ addend,
                                                           const float4* __restrict__ mask, float mask_scale, int relu, float4* __restrict__ y,
                                                           int N, int H, int W, int C4, float keep, unsigned long long seed, unsigned int stream_id,
                                                           long long slab, float4* __restrict__ pool, unsigned char* __restrict__ pidx)
 {
-    constexpr int A = WinoMat<M>::A;
+    constexpr int A = WinoMat<M, R>::A;
     const int th = H / M, tw = W / M;
     const TileIdx ti = tile_index(th, tw, C4);
     if (!ti.ok) return;
@@ -271,7 +297,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restri
         for (int o = 0; o < M; ++o) {
             float4 s = f4zero();
 #pragma unroll
-            for (int k = 0; k < A; ++k) if (WinoMat<M>::at(o, k) != 0.f) s = f4fma(WinoMat<M>::at(o, k), col[k], s);
+            for (int k = 0; k < A; ++k) if (WinoMat<M, R>::at(o, k) != 0.f) s = f4fma(WinoMat<M, R>::at(o, k), col[k], s);
             q[o][b] = s;
         }
     }
@@ -286,7 +312,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restri
         for (int ox = 0; ox < M; ++ox) {
             float4 v = bv;
 #pragma unroll
-            for (int k = 0; k < A; ++k) if (WinoMat<M>::at(ox, k) != 0.f) v = f4fma(WinoMat<M>::at(ox, k), q[oy][k], v);
+            for (int k = 0; k < A; ++k) if (WinoMat<M, R>::at(ox, k) != 0.f) v = f4fma(WinoMat<M, R>::at(ox, k), q[oy][k], v);
             const long long off = off0 + (oy * W + ox) * C4;
             if (addend) { const float4 ad = addend[off]; _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] += ad.d[i]; }
             if (relu) { _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = fmaxf(v.d[i], 0.f); }
@@ -323,10 +349,10 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restri
 }
 
 // ---- weight gradient: dM = A dY A^T (alpha x alpha from the m x m output-gradient tile) ------------------------------
-template <int M, int VEC>
+template <int M, int VEC, int R>
 __global__ __launch_bounds__(256) void wino_dout_kernel(const float4* __restrict__ dy, float4* __restrict__ dm, int N, int H, int W, int C4, long long slab)
 {
-    constexpr int A = WinoMat<M>::A;
+    constexpr int A = WinoMat<M, R>::A;
     const int th = H / M, tw = W / M;
     const TileIdx ti = tile_index(th, tw, C4);
     if (!ti.ok) return;
@@ -341,7 +367,7 @@ __global__ __launch_bounds__(256) void wino_dout_kernel(const float4* __restrict
         for (int a = 0; a < A; ++a) {
             float4 s = f4zero();
 #pragma unroll
-            for (int k = 0; k < M; ++k) if (WinoMat<M>::at(k, a) != 0.f) s = f4fma(WinoMat<M>::at(k, a), col[k], s);
+            for (int k = 0; k < M; ++k) if (WinoMat<M, R>::at(k, a) != 0.f) s = f4fma(WinoMat<M, R>::at(k, a), col[k], s);
             q[a][ox] = s;
         }
     }
@@ -352,42 +378,42 @@ __global__ __launch_bounds__(256) void wino_dout_kernel(const float4* __restrict
         for (int b = 0; b < A; ++b) {          // dM = q A^T
             float4 s = f4zero();
 #pragma unroll
-            for (int k = 0; k < M; ++k) if (WinoMat<M>::at(k, b) != 0.f) s = f4fma(WinoMat<M>::at(k, b), q[a][k], s);
+            for (int k = 0; k < M; ++k) if (WinoMat<M, R>::at(k, b) != 0.f) s = f4fma(WinoMat<M, R>::at(k, b), q[a][k], s);
             dp[(a * A + b) * slab] = s;
         }
 }
 
 // ---- dg_sub = G^T dU_sub G, scattered back to the taps (3a+i, 3b+j) < KS of the KS x KS filter gradient -----------------
-template <int M>
+template <int M, int R>
 __global__ void wino_dfilter_kernel(const float* du, float* dw, int Cin, int Cout, int KS, int nsub)
 {
-    constexpr int A = WinoMat<M>::A;
+    constexpr int A = WinoMat<M, R>::A;
     const long long cc = (long long)Cin * Cout, total = cc * nsub * nsub, ucc = total;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int sub = (int)(i / cc); const long long e = i - sub * cc;
         const int sa = sub / nsub, sb = sub - sa * nsub;
-        float t[3][A];
+        float t[R][A];
 #pragma unroll
         for (int b = 0; b < A; ++b) {
             float col[A];
 #pragma unroll
             for (int a = 0; a < A; ++a) col[a] = du[(long long)(a * A + b) * ucc + i];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
+            for (int r = 0; r < R; ++r) {
                 float s = 0.f;
 #pragma unroll
-                for (int k = 0; k < A; ++k) s = fmaf(WinoMat<M>::g(k, r), col[k], s);
+                for (int k = 0; k < A; ++k) s = fmaf(WinoMat<M, R>::g(k, r), col[k], s);
                 t[r][b] = s;
             }
         }
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < R; ++q) {
                 float s = 0.f;
 #pragma unroll
-                for (int k = 0; k < A; ++k) s = fmaf(t[r][k], WinoMat<M>::g(k, q), s);
-                const int ky = 3 * sa + r, kx = 3 * sb + q;
+                for (int k = 0; k < A; ++k) s = fmaf(t[r][k], WinoMat<M, R>::g(k, q), s);
+                const int ky = R * sa + r, kx = R * sb + q;
                 if (ky < KS && kx < KS) dw[(long long)(ky * KS + kx) * cc + e] = s;
             }
     }
@@ -397,15 +423,16 @@ __global__ void wino_dfilter_kernel(const float* du, float* dw, int Cin, int Cou
 #undef f4zero
 #undef float4
 
-// ---- launchers (tile = 2 or 4; KS = 3, or 7 = 3x3 grid of 3x3 sub-filters) --------------------------------------------------
-void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, int KS, hipStream_t s)
-{
-    const int nsub = KS == 3 ? 1 : 3;
-    const int g = wcap((long long)Cin * Cout * nsub * nsub);
-    if (tile == 4) hipLaunchKernelGGL(wino_filter_kernel<4>, dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
-    else           hipLaunchKernelGGL(wino_filter_kernel<2>, dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
-}
+// ---- launchers (tile = 2 or 4; KS = 3, or 7 = grid of r x r sub-filters, r = wino_r(7)) ------------------------------------
 static int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+// sub-filter size used for a KS x KS kernel: 3 for the 3x3 layers; fc6 (7x7): 4 (2x2 grid, F(4x4,4x4)) unless FCN8S_WINOGRAD_FC6_R=3
+int wino_r(int KS)
+{
+    static const int r7 = env_flag("FCN8S_WINOGRAD_FC6_R", 4) == 3 ? 3 : 4;
+    return KS == 3 ? 3 : r7;
+}
+int wino_nsub(int KS) { const int r = wino_r(KS); return (KS + r - 1) / r; }
+int wino_alpha(int tile, int KS) { return tile + wino_r(KS) - 1; }
 // Distance in floats between the slabs of two Winograd positions of a [P][T][C] tensor.  T*C alone is a large power of two
 // for this network (conv1_2: 2^25 floats): the 36 stores of one tile would then hit the same HBM channel and bank at the
 // same time.  The skew (4 KiB + 256 B) staggers the slabs across channels.
@@ -413,6 +440,14 @@ long long wino_slab(long long T, int C)
 {
     static const int skew = env_flag("FCN8S_WINO_SKEW", 1088) / 4 * 4;
     return T * C + skew;
+}
+void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, int KS, hipStream_t s)
+{
+    const int nsub = wino_nsub(KS);
+    const int g = wcap((long long)Cin * Cout * nsub * nsub);
+    if (tile == 4 && wino_r(KS) == 4) hipLaunchKernelGGL((wino_filter_kernel<4, 4>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
+    else if (tile == 4)               hipLaunchKernelGGL((wino_filter_kernel<4, 3>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
+    else                              hipLaunchKernelGGL((wino_filter_kernel<2, 3>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
 }
 bool wino_fuse_dz_enabled() { static const int on = env_flag("FCN8S_WINO_FUSE_DZ", 1); return on != 0; }
 bool launch_wino_input_dout(const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s, const unsigned char* pidx)
@@ -427,36 +462,42 @@ bool launch_wino_input_dout(const float* dy, float* v, float* dm, int N, int H, 
 }
 void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, int KS, hipStream_t s)
 {
-    const int nsub = KS == 3 ? 1 : 3, pad = (KS - 1) / 2;
-    if (tile == 4) hipLaunchKernelGGL((wino_input_kernel<4, 2>), tile_grid(N, H / 4, W / 4, C / 2, nsub * nsub), dim3(256), 0, s,
-                                      (const VecF<2>*)x, (VecF<2>*)v, N, H, W, C / 2, pad, nsub, wino_slab((long long)N * (H / 4) * (W / 4), C * nsub * nsub) / 2);
-    else           hipLaunchKernelGGL((wino_input_kernel<2, 4>), tile_grid(N, H / 2, W / 2, C / 4, nsub * nsub), dim3(256), 0, s,
-                                      (const VecF<4>*)x, (VecF<4>*)v, N, H, W, C / 4, pad, nsub, wino_slab((long long)N * (H / 2) * (W / 2), C * nsub * nsub) / 4);
+    const int nsub = wino_nsub(KS), pad = (KS - 1) / 2, n2 = nsub * nsub;
+#define FCN8S_WIN(M_, V_, R_) hipLaunchKernelGGL((wino_input_kernel<M_, V_, R_>), tile_grid(N, H / M_, W / M_, C / V_, n2), dim3(256), 0, s, \
+        (const VecF<V_>*)x, (VecF<V_>*)v, N, H, W, C / V_, pad, nsub, wino_slab((long long)N * (H / M_) * (W / M_), C * n2) / V_)
+    if (tile == 4 && wino_r(KS) == 4) FCN8S_WIN(4, 2, 4);
+    else if (tile == 4)               FCN8S_WIN(4, 2, 3);
+    else                              FCN8S_WIN(2, 4, 3);
+#undef FCN8S_WIN
 }
 void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
                         int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,
-                        unsigned int stream_id, hipStream_t s, float* pool, unsigned char* pidx)
+                        unsigned int stream_id, hipStream_t s, float* pool, unsigned char* pidx, int KS)
 {
-#define FCN8S_WOUT(M_, V_, D_) hipLaunchKernelGGL((wino_output_kernel<M_, V_, D_>), tile_grid(N, H / M_, W / M_, C / V_), dim3(256), 0, s, \
+#define FCN8S_WOUT(M_, V_, D_, R_) hipLaunchKernelGGL((wino_output_kernel<M_, V_, D_, R_>), tile_grid(N, H / M_, W / M_, C / V_), dim3(256), 0, s, \
         (const VecF<V_>*)m, (const VecF<V_>*)bias, (const VecF<V_>*)addend, (const VecF<V_>*)mask, mask_scale, relu, (VecF<V_>*)y, N, H, W, C / V_, keep, seed, stream_id, \
         wino_slab((long long)N * (H / M_) * (W / M_), C) / V_, (VecF<V_>*)pool, pidx)
-    if (tile == 4) { if (dropout) FCN8S_WOUT(4, 2, true); else FCN8S_WOUT(4, 2, false); }
-    else           { if (dropout) FCN8S_WOUT(2, 4, true); else FCN8S_WOUT(2, 4, false); }
+    if (tile == 4 && wino_r(KS) == 4) { if (dropout) FCN8S_WOUT(4, 2, true, 4); else FCN8S_WOUT(4, 2, false, 4); }
+    else if (tile == 4)               { if (dropout) FCN8S_WOUT(4, 2, true, 3); else FCN8S_WOUT(4, 2, false, 3); }
+    else                              { if (dropout) FCN8S_WOUT(2, 4, true, 3); else FCN8S_WOUT(2, 4, false, 3); }
 #undef FCN8S_WOUT
 }
-void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s)
+void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s, int KS)
 {
-    if (tile == 4) hipLaunchKernelGGL((wino_dout_kernel<4, 2>), tile_grid(N, H / 4, W / 4, C / 2), dim3(256), 0, s,
-                                      (const VecF<2>*)dy, (VecF<2>*)dm, N, H, W, C / 2, wino_slab((long long)N * (H / 4) * (W / 4), C) / 2);
-    else           hipLaunchKernelGGL((wino_dout_kernel<2, 4>), tile_grid(N, H / 2, W / 2, C / 4), dim3(256), 0, s,
-                                      (const VecF<4>*)dy, (VecF<4>*)dm, N, H, W, C / 4, wino_slab((long long)N * (H / 2) * (W / 2), C) / 4);
+#define FCN8S_WDOUT(M_, V_, R_) hipLaunchKernelGGL((wino_dout_kernel<M_, V_, R_>), tile_grid(N, H / M_, W / M_, C / V_), dim3(256), 0, s, \
+        (const VecF<V_>*)dy, (VecF<V_>*)dm, N, H, W, C / V_, wino_slab((long long)N * (H / M_) * (W / M_), C) / V_)
+    if (tile == 4 && wino_r(KS) == 4) FCN8S_WDOUT(4, 2, 4);
+    else if (tile == 4)               FCN8S_WDOUT(4, 2, 3);
+    else                              FCN8S_WDOUT(2, 4, 3);
+#undef FCN8S_WDOUT
 }
 void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, int KS, hipStream_t s)
 {
-    const int nsub = KS == 3 ? 1 : 3;
+    const int nsub = wino_nsub(KS);
     const int g = wcap((long long)Cin * Cout * nsub * nsub);
-    if (tile == 4) hipLaunchKernelGGL(wino_dfilter_kernel<4>, dim3(g), dim3(256), 0, s, du, dw, Cin, Cout, KS, nsub);
-    else           hipLaunchKernelGGL(wino_dfilter_kernel<2>, dim3(g), dim3(256), 0, s, du, dw, Cin, Cout, KS, nsub);
+    if (tile == 4 && wino_r(KS) == 4) hipLaunchKernelGGL((wino_dfilter_kernel<4, 4>), dim3(g), dim3(256), 0, s, du, dw, Cin, Cout, KS, nsub);
+    else if (tile == 4)               hipLaunchKernelGGL((wino_dfilter_kernel<4, 3>), dim3(g), dim3(256), 0, s, du, dw, Cin, Cout, KS, nsub);
+    else                              hipLaunchKernelGGL((wino_dfilter_kernel<2, 3>), dim3(g), dim3(256), 0, s, du, dw, Cin, Cout, KS, nsub);
 }
 
 }  // namespace fcn8s
