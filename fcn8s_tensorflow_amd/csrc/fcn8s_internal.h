@@ -118,7 +118,8 @@ void launch_pad_cin(const float* w, float* w4, int taps, int Cin, int Cinp, int 
 void launch_tconv_phase_pack(const float* w, float* wp, int K, int S, int C, hipStream_t s);
 void launch_dropout_mask(float* mask, long long n, float keep_prob, unsigned long long seed,
                          unsigned int stream_id, hipStream_t s);
-// Winograd F(tile x tile, 3x3) transforms (tile = 2 or 4) around P = (tile+2)^2 batched GEMMs; H, W % tile == 0, C % 4 == 0.
+// Winograd F(tile x tile, 3x3) transforms (tile = 2, 4 or 6) around P = (tile+2)^2 batched GEMMs; C % 4 == 0; H, W % tile == 0 for
+// tile 2 (tiles 4 and 6 handle partial edge tiles; T = N * ceil(H/tile) * ceil(W/tile)).
 // KS = 3: plain 3x3 conv.  KS = 7: the filter is cut into a 3x3 grid of 3x3 sub-filters whose products add up in the
 // Winograd domain (GEMM depth 9*C); u / v rows are then [sub][channel].
 int wino_r(int KS);                 // sub-filter size: 3 for 3x3 kernels; 7x7 (fc6): 4 by default (FCN8S_WINOGRAD_FC6_R=3 selects 3)
@@ -131,7 +132,7 @@ void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, 
 // one read of dy; returns false if the shape is not covered.
 // pidx != nullptr: `dy` is instead the gradient of the 2x2/2 max-pool output, [N,H/2,W/2,C], and pidx the per-window argmax bytes
 // written by launch_wino_output -- the max-pool backward (with the ReLU mask) is applied on the fly and dy never exists in HBM.
-bool launch_wino_input_dout(const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s, const unsigned char* pidx = nullptr);
+bool launch_wino_input_dout(int tile, const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s, const unsigned char* pidx = nullptr);
 bool wino_fuse_dz_enabled();
 void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
                         int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,

@@ -56,7 +56,7 @@ struct fcn8s_model {
     float *d_w1pad = nullptr, *d_tph[3] = {nullptr, nullptr, nullptr};
     float *d_wino_u = nullptr, *d_wino_v = nullptr, *d_wino_m = nullptr;   // Winograd scratch: filters, transformed input / output
     int wino_min_cin = 64;                                              // 3x3 layers with Cin >= this use Winograd; 0 = never
-    int wino_tile = 4;                                                    // F(4x4,3x3) where H, W % 4 == 0, else F(2x2,3x3)
+    int wino_tile = 6;                                                    // largest 3x3 output tile: F(6x6,3x3) / F(4x4,3x3) per layer by cost, F(2x2,3x3) fallback
     int wino_fc6 = 1;                                                     // fc6 7x7 as nine 3x3 sub-filters in the Winograd domain
     int precision = FCN8S_PREC_F32;                                       // FCN8S_PREC_BF16_FC: forward fc6 / fc7 on the bf16 MFMA
     bool pool_fused[5] = {false, false, false, false, false};            // forward wrote pool_b + argmax bytes from conv_b_last's output transform
@@ -199,11 +199,21 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
 // 3x3 SAME conv through Winograd F(tile x tile, 3x3): filter transform, input transform, (tile+2)^2 batched GEMMs
 // on the matrix cores (2.25x / 4x fewer MFMA flops than the direct form), output transform + fused epilogue.
 // u: [P][Cin][Cout], v: [P][T][Cin], mm: [P][T][Cout] scratch, P = (tile+2)^2, T = N*(H/tile)*(W/tile).
-int wino_tile_for(const fcn8s_model* m, int H, int W)
+// Output tile of the Winograd path for a K x K SAME conv on an H x W map (0 = none).  K = 7 (fc6): 4 (sub-filter decomposition).
+// K = 3: F(6x6) [64 positions per 36 outputs, partial edge tiles] or F(4x4) [36 per 16, needs H, W % 4 == 0], whichever multiplies
+// less on this map (small maps lose more to F(6x6)'s partial tiles than they gain); F(2x2) as the fallback.
+int wino_tile_for(const fcn8s_model* m, int H, int W, int K = 3)
 {
-    if (m && m->wino_tile == 4 && H % 4 == 0 && W % 4 == 0) return 4;
-    return (H % 2 == 0 && W % 2 == 0) ? 2 : 0;
+    if (!m || H % 2 || W % 2) return 0;
+    const bool t4 = m->wino_tile >= 4 && H % 4 == 0 && W % 4 == 0;
+    if (K == 7) return t4 ? 4 : 0;
+    if (m->wino_tile == 6) {
+        const long long c6 = 64LL * ((H + 5) / 6) * ((W + 5) / 6), c4 = t4 ? 36LL * (H / 4) * (W / 4) : 16LL * (H / 2) * (W / 2);
+        if (c6 < c4) return 6;
+    }
+    return t4 ? 4 : 2;
 }
+long long wino_tiles(int tile, int N, int H, int W) { return (long long)N * ((H + tile - 1) / tile) * ((W + tile - 1) / tile); }
 struct WinoEpi { const float* bias = nullptr; const float* addend = nullptr; const float* mask = nullptr; float mask_scale = 1.f;
                  int relu = 0; int dropout = 0; float keep = 1.f; unsigned long long seed = 0; unsigned int stream_id = 0; float* pool = nullptr; unsigned char* pidx = nullptr; };
 // KS = 3, or 7 (3x3 grid of 3x3 sub-filters, GEMM depth 9*Cin -- see winograd.hip)
@@ -211,7 +221,7 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
                    int N, int H, int W, int Cin, int Cout, const WinoEpi& e, hipStream_t s, const char* layer, bool v_ready = false)
 {
     const int P = wino_alpha(tile, KS) * wino_alpha(tile, KS), nsub2 = wino_nsub(KS) * wino_nsub(KS);
-    const long long T = (long long)N * (H / tile) * (W / tile);
+    const long long T = wino_tiles(tile, N, H, W);
     const int Kg = nsub2 * Cin;
     IgemmArgs a{};
     a.x = v; a.w = u; a.y = mm;
@@ -238,8 +248,8 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
                int N, int H, int W, int Cin, int Cout, int K, const Epi& e, hipStream_t s, int real_cin = 0,
                const char* layer = nullptr)
 {
-    const bool wino3 = m && K == 3 && m->wino_min_cin > 0 && Cin >= m->wino_min_cin && m->d_wino_v && wino_tile_for(m, H, W) && !e.dropout;
-    const bool wino7 = m && K == 7 && m->wino_fc6 && m->d_wino_v && wino_tile_for(m, H, W) == 4;
+    const bool wino3 = m && K == 3 && m->wino_min_cin > 0 && Cin >= m->wino_min_cin && m->d_wino_v && wino_tile_for(m, H, W, 3) && !e.dropout;
+    const bool wino7 = m && K == 7 && m->wino_fc6 && m->d_wino_v && wino_tile_for(m, H, W, 7) == 4;
     if ((wino3 || wino7) && Cin % 16 == 0 && Cout % 64 == 0 && e.alpha == 1.f && !real_cin) {
         const bool dgrad = e.dgrad != 0;
         float* vbuf = m->d_wino_v;
@@ -249,7 +259,7 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
         WinoEpi we; we.bias = e.bias; we.addend = e.addend; we.mask = e.mask; we.mask_scale = e.mask_scale; we.relu = e.relu;
         we.dropout = e.dropout; we.keep = e.keep; we.seed = m->seed; we.stream_id = e.stream_id; we.pool = e.pool_out; we.pidx = e.pool_idx;
         const char* tag = K == 7 ? (dgrad ? "wino_gemm_fc6_dgrad" : "wino_gemm_fc6_fwd") : (dgrad ? "wino_gemm_dgrad" : "wino_gemm_fwd");
-        conv_winograd(m, wino_tile_for(m, H, W), K, tag, x, w, y, m->d_wino_u, vbuf, m->d_wino_m, N, H, W, Cin, Cout, we, s, layer, v_ready);
+        conv_winograd(m, wino_tile_for(m, H, W, K), K, tag, x, w, y, m->d_wino_u, vbuf, m->d_wino_m, N, H, W, Cin, Cout, we, s, layer, v_ready);
         return e.pool_out != nullptr;
     }
     if (m) m->fused_v_layer.clear();
@@ -321,8 +331,8 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
     if (m && (K == 3 || K == 7) && layer && alpha == 1.f && !real_cin && m->train_mode) {
         auto it = m->acts.find(std::string("wv:") + layer);
         if (it != m->acts.end() && m->d_wino_m) {             // weight gradient in the Winograd domain (V kept by the forward pass)
-            const int tile = wino_tile_for(m, H, W), NP = wino_alpha(tile, K) * wino_alpha(tile, K);
-            const long long T = (long long)N * (H / tile) * (W / tile);
+            const int tile = wino_tile_for(m, H, W, K), NP = wino_alpha(tile, K) * wino_alpha(tile, K);
+            const long long T = wino_tiles(tile, N, H, W);
             const int Kg = wino_nsub(K) * wino_nsub(K) * Cin;           // rows of V / dU: [sub-filter][channel]
             WgradArgs g{};
             g.A = it->second.p; g.B = m->d_wino_m; g.C = m->d_wino_u;
@@ -335,16 +345,16 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             bool fused = false;
             { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout * (pool_idx ? 0.3125 : 1.0) + (fuse_dgrad_input ? 2.0 : 1.0) * NP * T * Cout));
               // pool_idx: dz is d(pool) [N,H/2,W/2,Cout]; the max-pool backward happens inside the transform (the caller checked eligibility)
-              if (fuse_dgrad_input && tile == 4 && K == 3) fused = launch_wino_input_dout(dz, m->d_wino_v, m->d_wino_m, N, H, W, Cout, s, pool_idx);
+              if (fuse_dgrad_input && tile >= 4 && K == 3) fused = launch_wino_input_dout(tile, dz, m->d_wino_v, m->d_wino_m, N, H, W, Cout, s, pool_idx);
               if (!fused) launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s, K); }
             m->fused_v_layer = fused ? layer : "";
             { ProfScope ps(m, K == 7 ? "wino_gemm_fc6_wgrad" : "wino_gemm_wgrad", 2.0 * NP * T * Kg * Cout, 4.0 * NP * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_wgrad(g, s); }
-            { ProfScope ps(m, "wino_transform", 0, 4.0 * (9.0 + NP) * Cin * Cout + 4.0 * N * H * W * Cout * ((tile == 4 && (pool_idx || fused)) ? 1.0 / 16 : 1.0));
+            { ProfScope ps(m, "wino_transform", 0, 4.0 * (9.0 + NP) * Cin * Cout + 4.0 * N * H * W * Cout * ((tile >= 4 && (pool_idx || fused)) ? 1.0 / (tile * tile) : 1.0));
               launch_wino_dfilter(tile, m->d_wino_u, dw, Cin, Cout, K, s);
               // bias gradient = sum of dz over all pixels.  dM[(1,1)] = sum_kl A^T(k,1) dz[k][l] A^T(l,1) and column 1 of A^T is all ones:
               // the slab of position (1,1) holds the per-tile sums -- 16x fewer bytes than dz, and dz need not exist
               if (db) {
-                  if (tile == 4 && (pool_idx || fused)) launch_colsum(m->d_wino_m + 7 * wino_slab(T, Cout), db, T, Cout, s);
+                  if (tile >= 4 && (pool_idx || fused)) launch_colsum(m->d_wino_m + (wino_alpha(tile, K) + 1) * wino_slab(T, Cout), db, T, Cout, s);
                   else launch_colsum(dz, db, (long long)N * H * W, Cout, s);
               } }
             return;
@@ -423,38 +433,43 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
     items.push_back({"gbuf0", gmax, 0, 0, 0, &m->gbuf[0]});
     items.push_back({"gbuf1", gmax, 0, 0, 0, &m->gbuf[1]});
     items.push_back({"softmax", (size_t)N * H * W * C, H, W, C, &m->d_softmax});
-    {   // Winograd scratch (4x the largest qualifying 3x3 layer's input / output)
+    {   // Winograd scratch: the largest [P][T][C] tensor any layer needs (V and M of the forward and of the data-gradient conv)
+        auto slab_floats = [&](int hh, int ww, int c, int K) -> size_t {      // P slabs of wino_slab(T, nsub^2 c) floats
+            const int tile = wino_tile_for(m, hh, ww, K);
+            if (!tile) return 0;
+            const int al = wino_alpha(tile, K), ns = wino_nsub(K);
+            return (size_t)al * al * (size_t)wino_slab(wino_tiles(tile, N, hh, ww), ns * ns * c);
+        };
         size_t vmax = 0;
         if (m->wino_min_cin > 0) {
             int cin = 3;
             for (int b = 0, hh = H, ww = W; b < 5; ++b, hh /= 2, ww /= 2)
                 for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
                     const int cout = m->widths[b];
-                    const size_t big = (size_t)N * hh * ww * (size_t)std::max(cin, cout) * 4;
-                    if (std::max(cin, cout) >= m->wino_min_cin && big > vmax) vmax = big;
+                    if (std::max(cin, cout) >= m->wino_min_cin) vmax = std::max(vmax, slab_floats(hh, ww, std::max(cin, cout), 3));
                     cin = cout;
                 }
         }
         const int h5_ = H / 32, w5_ = W / 32;
-        const bool fc6w = m->wino_fc6 && m->wino_tile == 4 && m->fc6k == 7 && h5_ % 4 == 0 && w5_ % 4 == 0 && m->widths[4] % 16 == 0 && m->widths[5] % 64 == 0;
-        if (fc6w) {     // V: P * T * nsub^2 * c5 = 20.25 |pool5| (r = 3) or 12.25 (r = 4);  M: 2.25 / 3.06 |fc6|  (the data gradient swaps the two roles)
-            const size_t vf = (size_t)N * h5_ * w5_ * (size_t)std::max(m->widths[4], m->widths[5]) * 21;
-            if (vf > vmax) vmax = vf;
+        const bool fc6w = m->wino_fc6 && m->fc6k == 7 && wino_tile_for(m, h5_, w5_, 7) == 4 && m->widths[4] % 16 == 0 && m->widths[5] % 64 == 0;
+        if (fc6w) {     // V: P * T * nsub^2 * c5;  M: P * T * c6  (the data gradient swaps the two roles; M has nsub = 1)
+            const int al = wino_alpha(4, 7);
+            vmax = std::max(vmax, slab_floats(h5_, w5_, std::max(m->widths[4], m->widths[5]), 7));
+            vmax = std::max(vmax, (size_t)al * al * (size_t)wino_slab(wino_tiles(4, N, h5_, w5_), std::max(m->widths[4], m->widths[5])));
         }
         m->d_wino_v = m->d_wino_m = nullptr;
-        const size_t skew_room = 36 * (size_t)(wino_slab(0, 0) + 4);       // the slabs of a [P][T][C] tensor are T*C + skew floats apart
-        if (vmax) { vmax += skew_room; items.push_back({"wino_v", vmax, 0, 0, 0, &m->d_wino_v}); items.push_back({"wino_m", vmax, 0, 0, 0, &m->d_wino_m}); }
+        if (vmax) { items.push_back({"wino_v", vmax, 0, 0, 0, &m->d_wino_v}); items.push_back({"wino_m", vmax, 0, 0, 0, &m->d_wino_m}); }
         if (m->wino_min_cin > 0) {    // the forward pass keeps each Winograd layer's transformed input for the weight gradient
             int cin = 3;
             for (int b = 0, hh = H, ww = W; b < 5; ++b, hh /= 2, ww /= 2)
                 for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
-                    if (cin >= m->wino_min_cin && cin % 16 == 0 && m->widths[b] % 64 == 0 && hh % 2 == 0 && ww % 2 == 0) {
+                    if (cin >= m->wino_min_cin && cin % 16 == 0 && m->widths[b] % 64 == 0 && wino_tile_for(m, hh, ww, 3)) {
                         char nm[40]; snprintf(nm, sizeof nm, "wv:conv%d_%d", b + 1, i);
-                        items.push_back({nm, (size_t)N * hh * ww * (size_t)cin * 4 + skew_room, 0, 0, 0, nullptr});
+                        items.push_back({nm, slab_floats(hh, ww, cin, 3), 0, 0, 0, nullptr});
                     }
                     cin = m->widths[b];
                 }
-            if (fc6w) items.push_back({"wv:fc6", (size_t)N * h5_ * w5_ * (size_t)m->widths[4] * 21 + skew_room, 0, 0, 0, nullptr});
+            if (fc6w) items.push_back({"wv:fc6", slab_floats(h5_, w5_, m->widths[4], 7), 0, 0, 0, nullptr});
         }
     }
 
@@ -690,7 +705,7 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
         {
             char ix[16]; snprintf(ix, sizeof ix, "pidx%d", b);
             const bool wino_both = m->pool_fused[b - 1] && wino_fuse_dz_enabled() && m->wino_min_cin > 0 && cw >= m->wino_min_cin && m->d_wino_v &&
-                                   wino_tile_for(m, h, w) == 4 && cw % 64 == 0 && nconv > 1 && m->acts.count(std::string("wv:") + last);
+                                   wino_tile_for(m, h, w) >= 4 && cw % 64 == 0 && nconv > 1 && m->acts.count(std::string("wv:") + last);
             if (wino_both) pidx = (const unsigned char*)A(m, ix);
         }
         if (!pidx) {
@@ -708,7 +723,7 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
             else { xin = A(m, "x0"); cin = 4; real_cin = 3; }
             const bool first = (b == 1 && i == 1);
             // the data-gradient conv (cw -> cin channels) takes the Winograd path under the same conditions as conv_same()
-            const bool dgrad_wino = !first && m->wino_min_cin > 0 && cw >= m->wino_min_cin && m->d_wino_v && wino_tile_for(m, h, w) == 4 &&
+            const bool dgrad_wino = !first && m->wino_min_cin > 0 && cw >= m->wino_min_cin && m->d_wino_v && wino_tile_for(m, h, w) >= 4 &&
                                     cw % 16 == 0 && cin % 64 == 0;
             conv_wgrad(m, first ? "conv1_1_wgrad" : "conv3x3_wgrad", xin, dz, Gp(m, std::string(nm) + "/filter"), Gp(m, std::string(nm) + "/biases"),
                        N, h, w, cin, cw, 3, 1.f, s, real_cin, nm, dgrad_wino, i == nconv ? pidx : nullptr);
@@ -826,10 +841,10 @@ int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
         if (wm) m->wino_min_cin = atoi(wm);
         int cmax = 0; for (int i = 0; i < 5; ++i) cmax = std::max(cmax, m->widths[i]);
         const char* wt = getenv("FCN8S_WINOGRAD_TILE");             // 2 or 4 (A-B switch)
-        if (wt) m->wino_tile = atoi(wt) == 2 ? 2 : 4;
+        if (wt) { const int t = atoi(wt); m->wino_tile = t == 2 ? 2 : (t == 4 ? 4 : 6); }
         const char* wf = getenv("FCN8S_WINOGRAD_FC6");
         if (wf) m->wino_fc6 = atoi(wf) != 0;
-        size_t ufl = 36 * (size_t)cmax * cmax;
+        size_t ufl = 64 * (size_t)cmax * cmax;                        // F(6x6,3x3): 64 positions
         if (m->wino_fc6 && m->fc6k == 7) ufl = std::max(ufl, 36 * 9 * (size_t)m->widths[4] * m->widths[5]);   // fc6: 36 positions x 9 sub-filters
         if ((e = hipMalloc((void**)&m->d_wino_u, ufl * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     }
@@ -1230,10 +1245,10 @@ int fcn8s_op_conv2d(void* stream, const float* x, const float* w, const float* b
 int fcn8s_op_conv2d_winograd(void* stream, const float* x, const float* w, const float* bias, float* y,
                              int N, int H, int W, int Cin, int Cout, int K, int relu, int tile)
 {
-    if ((tile != 2 && tile != 4) || (K != 3 && K != 7) || Cin % 16 || Cout % 32 || H % tile || W % tile)
-        return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d_winograd: needs tile in {2,4}, K in {3,7}, Cin % 16, Cout % 32, H and W multiples of tile");
+    if ((tile != 2 && tile != 4 && tile != 6) || (K != 3 && K != 7) || (K == 7 && tile != 4) || Cin % 16 || Cout % 32 || (tile != 6 && (H % tile || W % tile)) || H % 2 || W % 2)
+        return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d_winograd: needs tile in {2,4,6} (4 for K = 7), K in {3,7}, Cin % 16, Cout % 32, even H and W (multiples of tile for tile 2 and 4)");
     hipStream_t s = (hipStream_t)stream;
-    const size_t T = (size_t)N * (H / tile) * (W / tile), P = (size_t)wino_alpha(tile, K) * wino_alpha(tile, K), Kg = (size_t)wino_nsub(K) * wino_nsub(K) * Cin;
+    const size_t T = (size_t)wino_tiles(tile, N, H, W), P = (size_t)wino_alpha(tile, K) * wino_alpha(tile, K), Kg = (size_t)wino_nsub(K) * wino_nsub(K) * Cin;
     float *u = nullptr, *v = nullptr, *mm = nullptr;
     if (hipMalloc((void**)&u, P * Kg * Cout * 4) != hipSuccess || hipMalloc((void**)&v, P * (size_t)wino_slab(T, (int)Kg) * 4) != hipSuccess ||
         hipMalloc((void**)&mm, P * (size_t)wino_slab(T, Cout) * 4) != hipSuccess) return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc");

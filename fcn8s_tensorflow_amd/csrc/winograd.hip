@@ -55,6 +55,27 @@ template <> struct WinoMat<4, 3> {
     }
 };
 
+template <> struct WinoMat<6, 3> {                  // F(6,3), points 0, 1, -1, 2, -2, 1/2, -1/2, inf
+    static constexpr int A = 8;
+    static __device__ __forceinline__ float bt(int i, int j)
+    {
+        constexpr float m[8][8] = {{4, 0, -21, 0, 21, 0, -4, 0}, {0, -4, -4, 17, 17, -4, -4, 0}, {0, 4, -4, -17, 17, 4, -4, 0}, {0, 2, 1, -10, -5, 8, 4, 0},
+                                   {0, -2, 1, 10, -5, -8, 4, 0}, {0, 4, 8, -5, -10, 1, 2, 0}, {0, -4, 8, 5, -10, -1, 2, 0}, {0, -4, 0, 21, 0, -21, 0, 4}};
+        return m[i][j];
+    }
+    static __device__ __forceinline__ float g(int i, int j)
+    {
+        constexpr float m[8][3] = {{1.f / 4, 0, 0}, {1.f / 18, 1.f / 18, 1.f / 18}, {1.f / 18, -1.f / 18, 1.f / 18}, {1.f / 360, 1.f / 180, 1.f / 90},
+                                   {1.f / 360, -1.f / 180, 1.f / 90}, {16.f / 45, 8.f / 45, 4.f / 45}, {16.f / 45, -8.f / 45, 4.f / 45}, {0, 0, 1.f / 4}};
+        return m[i][j];
+    }
+    static __device__ __forceinline__ float at(int i, int j)
+    {
+        constexpr float m[6][8] = {{1, 1, 1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 1.f / 2, -1.f / 2, 0}, {0, 1, 1, 4, 4, 1.f / 4, 1.f / 4, 0},
+                                   {0, 1, -1, 8, -8, 1.f / 8, -1.f / 8, 0}, {0, 1, 1, 16, 16, 1.f / 16, 1.f / 16, 0}, {0, 1, -1, 32, -32, 1.f / 32, -1.f / 32, 1}};
+        return m[i][j];
+    }
+};
 template <> struct WinoMat<4, 4> {                  // F(4,4), points 0, 1, -1, 1/2, -1/2, -2, inf
     static constexpr int A = 7;
     static __device__ __forceinline__ float bt(int i, int j)
@@ -155,7 +176,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restric
                                                          long long slab)
 {
     constexpr int A = WinoMat<M, R>::A;
-    const int th = H / M, tw = W / M;
+    const int th = (H + M - 1) / M, tw = (W + M - 1) / M;      // partial tiles at the bottom / right edge (F(6x6): 512 = 85 * 6 + 2)
     const int sub = blockIdx.z, sa = sub / nsub, sb = sub - sa * nsub;     // sub-filter: patch shifted by (R sa, R sb)
     const int ldv = C4 * nsub * nsub;
     const TileIdx ti = tile_index(th, tw, C4);
@@ -195,12 +216,12 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restric
 // tensor (dM's 4x4 tile is the inside of V's 6x6 patch): both from one read of dy -------------------------------------------
 // POOL: dy is not materialised -- it is the max-pool backward of dpool [N,H/2,W/2,C] routed by the argmax bytes the forward
 // output transform kept (dy[pixel] = dpool[window] if the pixel is the window's first maximum and that maximum is > 0).
-template <int VEC, bool POOL>
+template <int M, int VEC, bool POOL>
 __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __restrict__ x, float4* __restrict__ v, float4* __restrict__ dm,
                                                               int N, int H, int W, int C4, long long slab, const unsigned char* __restrict__ pidx)
 {
-    constexpr int M = 4, A = 6;
-    const int th = H / M, tw = W / M;
+    constexpr int A = M + 2, NW = M / 2 + 2;           // NW: pool windows one patch row / column touches
+    const int th = (H + M - 1) / M, tw = (W + M - 1) / M;      // partial tiles at the bottom / right edge (F(6x6): 512 = 85 * 6 + 2)
     const TileIdx ti = tile_index(th, tw, C4);
     if (!ti.ok) return;
     const int y0 = M * ti.ty - 1, x0 = M * ti.tx - 1;
@@ -209,17 +230,17 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
 #pragma unroll
     for (int a = 0; a < A; ++a) { rok[a] = (unsigned)(y0 + a) < (unsigned)H; cok[a] = (unsigned)(x0 + a) < (unsigned)W; }
     float4 q[A][A], p[A][M];
-    // POOL: the patch rows y0..y0+5 = 4ty-1..4ty+4 touch window rows 2ty-1..2ty+2 (4 of them); same for columns
+    // POOL: the patch rows y0..y0+M+1 = M ty - 1 .. M ty + M touch window rows (M/2) ty - 1 .. (M/2) ty + M/2 (NW of them); same for columns
     const int Hp = H / 2, Wp = W / 2;
-    const long long wbase = (((long long)ti.n * Hp + (2 * ti.ty - 1)) * Wp + (2 * ti.tx - 1)) * C4 + ti.c;
+    const long long wbase = (((long long)ti.n * Hp + ((M / 2) * ti.ty - 1)) * Wp + ((M / 2) * ti.tx - 1)) * C4 + ti.c;
 #pragma unroll
     for (int b = 0; b < A; ++b) {
         float4 d[A];
         if (POOL) {
             const int wc = (b + 1) >> 1;                                   // window column 0..3 of patch column b; (x0 + b) & 1 == (b + 1) & 1
 #pragma unroll
-            for (int wr = 0; wr < 4; ++wr) {                               // window rows; patch rows 2wr-1, 2wr
-                const bool wok = (unsigned)(2 * ti.ty - 1 + wr) < (unsigned)Hp && (unsigned)(2 * ti.tx - 1 + wc) < (unsigned)Wp;
+            for (int wr = 0; wr < NW; ++wr) {                              // window rows; patch rows 2wr-1, 2wr
+                const bool wok = (unsigned)((M / 2) * ti.ty - 1 + wr) < (unsigned)Hp && (unsigned)((M / 2) * ti.tx - 1 + wc) < (unsigned)Wp;
                 const long long wo = wbase + ((long long)wr * Wp + wc) * C4;
                 float4 g = f4zero();
                 unsigned char id[VEC];
@@ -240,7 +261,7 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
         for (int a = 0; a < A; ++a) {
             float4 s = f4zero();
 #pragma unroll
-            for (int k = 0; k < A; ++k) if (WinoMat<4, 3>::bt(a, k) != 0.f) s = f4fma(WinoMat<4, 3>::bt(a, k), d[k], s);
+            for (int k = 0; k < A; ++k) if (WinoMat<M, 3>::bt(a, k) != 0.f) s = f4fma(WinoMat<M, 3>::bt(a, k), d[k], s);
             q[a][b] = s;
         }
         if (b >= 1 && b <= M) {
@@ -248,7 +269,7 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
             for (int a = 0; a < A; ++a) {
                 float4 s = f4zero();
 #pragma unroll
-                for (int k = 0; k < M; ++k) if (WinoMat<4, 3>::at(k, a) != 0.f) s = f4fma(WinoMat<4, 3>::at(k, a), d[k + 1], s);
+                for (int k = 0; k < M; ++k) if (WinoMat<M, 3>::at(k, a) != 0.f) s = f4fma(WinoMat<M, 3>::at(k, a), d[k + 1], s);
                 p[a][b - 1] = s;
             }
         }
@@ -260,7 +281,7 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
         for (int b = 0; b < A; ++b) {
             float4 s = f4zero();
 #pragma unroll
-            for (int k = 0; k < A; ++k) if (WinoMat<4, 3>::bt(b, k) != 0.f) s = f4fma(WinoMat<4, 3>::bt(b, k), q[a][k], s);
+            for (int k = 0; k < A; ++k) if (WinoMat<M, 3>::bt(b, k) != 0.f) s = f4fma(WinoMat<M, 3>::bt(b, k), q[a][k], s);
             v[o + (a * A + b) * slab] = s;
         }
 #pragma unroll
@@ -269,7 +290,7 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
         for (int b = 0; b < A; ++b) {
             float4 s = f4zero();
 #pragma unroll
-            for (int k = 0; k < M; ++k) if (WinoMat<4, 3>::at(k, b) != 0.f) s = f4fma(WinoMat<4, 3>::at(k, b), p[a][k], s);
+            for (int k = 0; k < M; ++k) if (WinoMat<M, 3>::at(k, b) != 0.f) s = f4fma(WinoMat<M, 3>::at(k, b), p[a][k], s);
             dm[o + (a * A + b) * slab] = s;
         }
 }
@@ -283,7 +304,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restri
                                                           long long slab, float4* __restrict__ pool, unsigned char* __restrict__ pidx)
 {
     constexpr int A = WinoMat<M, R>::A;
-    const int th = H / M, tw = W / M;
+    const int th = (H + M - 1) / M, tw = (W + M - 1) / M;      // partial tiles at the bottom / right edge (F(6x6): 512 = 85 * 6 + 2)
     const TileIdx ti = tile_index(th, tw, C4);
     if (!ti.ok) return;
     const float4* mp = m + ti.t * C4 + ti.c;
@@ -314,6 +335,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restri
 #pragma unroll
             for (int k = 0; k < A; ++k) if (WinoMat<M, R>::at(ox, k) != 0.f) v = f4fma(WinoMat<M, R>::at(ox, k), q[oy][k], v);
             const long long off = off0 + (oy * W + ox) * C4;
+            const bool inside = M * ti.ty + oy < H && M * ti.tx + ox < W;              // false only in partial edge tiles
+            if (!inside) { if ((oy & 1) == 0 && (ox & 1) == 0) { pmax[oy / 2][ox / 2] = v; _Pragma("unroll") for (int i = 0; i < VEC; ++i) parg[oy / 2][ox / 2][i] = 0; } continue; }
             if (addend) { const float4 ad = addend[off]; _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] += ad.d[i]; }
             if (relu) { _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = fmaxf(v.d[i], 0.f); }
             if (mask) {
@@ -340,7 +363,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restri
         for (int py = 0; py < M / 2; ++py)
 #pragma unroll
             for (int px = 0; px < M / 2; ++px)
-            {
+            if ((M / 2) * ti.ty + py < Hp && (M / 2) * ti.tx + px < Wp) {                // H, W even: a window is inside or outside as a whole
                 const long long po = (((long long)ti.n * Hp + (M / 2) * ti.ty + py) * Wp + (M / 2) * ti.tx + px) * C4 + ti.c;
                 pool[po] = pmax[py][px];
                 if (pidx) { _Pragma("unroll") for (int i = 0; i < VEC; ++i) pidx[po * VEC + i] = pmax[py][px].d[i] > 0.f ? parg[py][px][i] : (unsigned char)4; }
@@ -353,7 +376,7 @@ template <int M, int VEC, int R>
 __global__ __launch_bounds__(256) void wino_dout_kernel(const float4* __restrict__ dy, float4* __restrict__ dm, int N, int H, int W, int C4, long long slab)
 {
     constexpr int A = WinoMat<M, R>::A;
-    const int th = H / M, tw = W / M;
+    const int th = (H + M - 1) / M, tw = (W + M - 1) / M;      // partial tiles at the bottom / right edge (F(6x6): 512 = 85 * 6 + 2)
     const TileIdx ti = tile_index(th, tw, C4);
     if (!ti.ok) return;
     const float4* yp = dy + (((long long)ti.n * H + M * ti.ty) * W + M * ti.tx) * C4 + ti.c;
@@ -362,7 +385,7 @@ __global__ __launch_bounds__(256) void wino_dout_kernel(const float4* __restrict
     for (int ox = 0; ox < M; ++ox) {
         float4 col[M];
 #pragma unroll
-        for (int oy = 0; oy < M; ++oy) col[oy] = yp[(oy * W + ox) * C4];
+        for (int oy = 0; oy < M; ++oy) col[oy] = (M * ti.ty + oy < H && M * ti.tx + ox < W) ? yp[(oy * W + ox) * C4] : f4zero();
 #pragma unroll
         for (int a = 0; a < A; ++a) {
             float4 s = f4zero();
@@ -432,7 +455,7 @@ int wino_r(int KS)
     return KS == 3 ? 3 : r7;
 }
 int wino_nsub(int KS) { const int r = wino_r(KS); return (KS + r - 1) / r; }
-int wino_alpha(int tile, int KS) { return tile + wino_r(KS) - 1; }
+int wino_alpha(int tile, int KS) { return tile + (tile == 6 ? 3 : wino_r(KS)) - 1; }
 // Distance in floats between the slabs of two Winograd positions of a [P][T][C] tensor.  T*C alone is a large power of two
 // for this network (conv1_2: 2^25 floats): the 36 stores of one tile would then hit the same HBM channel and bank at the
 // same time.  The skew (4 KiB + 256 B) staggers the slabs across channels.
@@ -445,27 +468,30 @@ void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, i
 {
     const int nsub = wino_nsub(KS);
     const int g = wcap((long long)Cin * Cout * nsub * nsub);
-    if (tile == 4 && wino_r(KS) == 4) hipLaunchKernelGGL((wino_filter_kernel<4, 4>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
+    if (tile == 6)                    hipLaunchKernelGGL((wino_filter_kernel<6, 3>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
+    else if (tile == 4 && wino_r(KS) == 4) hipLaunchKernelGGL((wino_filter_kernel<4, 4>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
     else if (tile == 4)               hipLaunchKernelGGL((wino_filter_kernel<4, 3>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
     else                              hipLaunchKernelGGL((wino_filter_kernel<2, 3>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
 }
 bool wino_fuse_dz_enabled() { static const int on = env_flag("FCN8S_WINO_FUSE_DZ", 1); return on != 0; }
-bool launch_wino_input_dout(const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s, const unsigned char* pidx)
+bool launch_wino_input_dout(int tile, const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s, const unsigned char* pidx)
 {
-    if (!wino_fuse_dz_enabled() || H % 4 || W % 4 || C % 2) return false;
-    const long long slab = wino_slab((long long)N * (H / 4) * (W / 4), C) / 2;
-    if (pidx) hipLaunchKernelGGL((wino_input_dout_kernel<2, true>), tile_grid(N, H / 4, W / 4, C / 2), dim3(256), 0, s,
-                                 (const VecF<2>*)dy, (VecF<2>*)v, (VecF<2>*)dm, N, H, W, C / 2, slab, pidx);
-    else      hipLaunchKernelGGL((wino_input_dout_kernel<2, false>), tile_grid(N, H / 4, W / 4, C / 2), dim3(256), 0, s,
-                                 (const VecF<2>*)dy, (VecF<2>*)v, (VecF<2>*)dm, N, H, W, C / 2, slab, pidx);
+    if (!wino_fuse_dz_enabled() || (tile != 4 && tile != 6) || H % 2 || W % 2 || C % 2) return false;
+    const int th = (H + tile - 1) / tile, tw = (W + tile - 1) / tile;
+#define FCN8S_WFUSE(M_, V_, P_) hipLaunchKernelGGL((wino_input_dout_kernel<M_, V_, P_>), tile_grid(N, th, tw, C / V_), dim3(256), 0, s, \
+        (const VecF<V_>*)dy, (VecF<V_>*)v, (VecF<V_>*)dm, N, H, W, C / V_, wino_slab((long long)N * th * tw, C) / V_, pidx)
+    if (tile == 4) { if (pidx) FCN8S_WFUSE(4, 2, true); else FCN8S_WFUSE(4, 2, false); }
+    else           { if (pidx) FCN8S_WFUSE(6, 1, true); else FCN8S_WFUSE(6, 1, false); }      // 8x8 + 8x6 values per lane: one channel per lane
+#undef FCN8S_WFUSE
     return true;
 }
 void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, int KS, hipStream_t s)
 {
     const int nsub = wino_nsub(KS), pad = (KS - 1) / 2, n2 = nsub * nsub;
-#define FCN8S_WIN(M_, V_, R_) hipLaunchKernelGGL((wino_input_kernel<M_, V_, R_>), tile_grid(N, H / M_, W / M_, C / V_, n2), dim3(256), 0, s, \
-        (const VecF<V_>*)x, (VecF<V_>*)v, N, H, W, C / V_, pad, nsub, wino_slab((long long)N * (H / M_) * (W / M_), C * n2) / V_)
-    if (tile == 4 && wino_r(KS) == 4) FCN8S_WIN(4, 2, 4);
+#define FCN8S_WIN(M_, V_, R_) hipLaunchKernelGGL((wino_input_kernel<M_, V_, R_>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / V_, n2), dim3(256), 0, s, \
+        (const VecF<V_>*)x, (VecF<V_>*)v, N, H, W, C / V_, pad, nsub, wino_slab((long long)N * ((H + M_ - 1) / M_) * ((W + M_ - 1) / M_), C * n2) / V_)
+    if (tile == 6)                    FCN8S_WIN(6, 2, 3);
+    else if (tile == 4 && wino_r(KS) == 4) FCN8S_WIN(4, 2, 4);
     else if (tile == 4)               FCN8S_WIN(4, 2, 3);
     else                              FCN8S_WIN(2, 4, 3);
 #undef FCN8S_WIN
@@ -474,19 +500,21 @@ void launch_wino_output(int tile, const float* m, const float* bias, const float
                         int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,
                         unsigned int stream_id, hipStream_t s, float* pool, unsigned char* pidx, int KS)
 {
-#define FCN8S_WOUT(M_, V_, D_, R_) hipLaunchKernelGGL((wino_output_kernel<M_, V_, D_, R_>), tile_grid(N, H / M_, W / M_, C / V_), dim3(256), 0, s, \
+#define FCN8S_WOUT(M_, V_, D_, R_) hipLaunchKernelGGL((wino_output_kernel<M_, V_, D_, R_>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / V_), dim3(256), 0, s, \
         (const VecF<V_>*)m, (const VecF<V_>*)bias, (const VecF<V_>*)addend, (const VecF<V_>*)mask, mask_scale, relu, (VecF<V_>*)y, N, H, W, C / V_, keep, seed, stream_id, \
-        wino_slab((long long)N * (H / M_) * (W / M_), C) / V_, (VecF<V_>*)pool, pidx)
-    if (tile == 4 && wino_r(KS) == 4) { if (dropout) FCN8S_WOUT(4, 2, true, 4); else FCN8S_WOUT(4, 2, false, 4); }
+        wino_slab((long long)N * ((H + M_ - 1) / M_) * ((W + M_ - 1) / M_), C) / V_, (VecF<V_>*)pool, pidx)
+    if (tile == 6)                    { if (dropout) FCN8S_WOUT(6, 2, true, 3); else FCN8S_WOUT(6, 2, false, 3); }
+    else if (tile == 4 && wino_r(KS) == 4) { if (dropout) FCN8S_WOUT(4, 2, true, 4); else FCN8S_WOUT(4, 2, false, 4); }
     else if (tile == 4)               { if (dropout) FCN8S_WOUT(4, 2, true, 3); else FCN8S_WOUT(4, 2, false, 3); }
     else                              { if (dropout) FCN8S_WOUT(2, 4, true, 3); else FCN8S_WOUT(2, 4, false, 3); }
 #undef FCN8S_WOUT
 }
 void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s, int KS)
 {
-#define FCN8S_WDOUT(M_, V_, R_) hipLaunchKernelGGL((wino_dout_kernel<M_, V_, R_>), tile_grid(N, H / M_, W / M_, C / V_), dim3(256), 0, s, \
-        (const VecF<V_>*)dy, (VecF<V_>*)dm, N, H, W, C / V_, wino_slab((long long)N * (H / M_) * (W / M_), C) / V_)
-    if (tile == 4 && wino_r(KS) == 4) FCN8S_WDOUT(4, 2, 4);
+#define FCN8S_WDOUT(M_, V_, R_) hipLaunchKernelGGL((wino_dout_kernel<M_, V_, R_>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / V_), dim3(256), 0, s, \
+        (const VecF<V_>*)dy, (VecF<V_>*)dm, N, H, W, C / V_, wino_slab((long long)N * ((H + M_ - 1) / M_) * ((W + M_ - 1) / M_), C) / V_)
+    if (tile == 6)                    FCN8S_WDOUT(6, 2, 3);
+    else if (tile == 4 && wino_r(KS) == 4) FCN8S_WDOUT(4, 2, 4);
     else if (tile == 4)               FCN8S_WDOUT(4, 2, 3);
     else                              FCN8S_WDOUT(2, 4, 3);
 #undef FCN8S_WDOUT
@@ -495,7 +523,8 @@ void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout
 {
     const int nsub = wino_nsub(KS);
     const int g = wcap((long long)Cin * Cout * nsub * nsub);
-    if (tile == 4 && wino_r(KS) == 4) hipLaunchKernelGGL((wino_dfilter_kernel<4, 4>), dim3(g), dim3(256), 0, s, du, dw, Cin, Cout, KS, nsub);
+    if (tile == 6)                    hipLaunchKernelGGL((wino_dfilter_kernel<6, 3>), dim3(g), dim3(256), 0, s, du, dw, Cin, Cout, KS, nsub);
+    else if (tile == 4 && wino_r(KS) == 4) hipLaunchKernelGGL((wino_dfilter_kernel<4, 4>), dim3(g), dim3(256), 0, s, du, dw, Cin, Cout, KS, nsub);
     else if (tile == 4)               hipLaunchKernelGGL((wino_dfilter_kernel<4, 3>), dim3(g), dim3(256), 0, s, du, dw, Cin, Cout, KS, nsub);
     else                              hipLaunchKernelGGL((wino_dfilter_kernel<2, 3>), dim3(g), dim3(256), 0, s, du, dw, Cin, Cout, KS, nsub);
 }

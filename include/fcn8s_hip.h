@@ -167,8 +167,9 @@ int fcn8s_profile_get(fcn8s_model* m, int group, const char** name, double* tota
 int fcn8s_op_preprocess(void* stream, const void* images, int image_dtype, float* out4, int64_t npix);
 int fcn8s_op_conv2d(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,
                     int N, int H, int W, int Cin, int Cout, int K, int relu);
-/* the same SAME conv through Winograd F(tile x tile, 3x3), tile = 2 or 4 (the path the model takes for its 3x3
- * layers; K = 7 runs fc6's decomposition into nine 3x3 sub-filters; H, W multiples of tile) */
+/* the same SAME conv through Winograd F(tile x tile, 3x3), tile = 2, 4 or 6 (the path the model takes for its 3x3
+ * layers; tile 6 handles partial edge tiles, tiles 2 and 4 need H, W multiples of tile; K = 7 with tile 4 runs fc6's
+ * decomposition into 4x4 sub-filters, F(4x4,4x4)) */
 int fcn8s_op_conv2d_winograd(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,
                              int N, int H, int W, int Cin, int Cout, int K, int relu, int tile);
 /* the same SAME conv with bf16-rounded operands and fp32 accumulation on the bf16 MFMA (FCN8S_PREC_BF16_FC's kernel);

@@ -76,7 +76,8 @@ def test_conv2d_fwd_bwd(N, H, W, Cin, Cout, K):
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,tile", [(1, 4, 6, 16, 32, 2), (2, 8, 16, 64, 128, 2), (1, 16, 32, 256, 256, 2), (3, 2, 2, 32, 64, 2),
-                                                  (1, 4, 8, 16, 32, 4), (2, 8, 16, 64, 128, 4), (1, 16, 32, 256, 256, 4), (2, 4, 4, 512, 64, 4)])
+                                                  (1, 4, 8, 16, 32, 4), (2, 8, 16, 64, 128, 4), (1, 16, 32, 256, 256, 4), (2, 4, 4, 512, 64, 4),
+                                                  (1, 6, 12, 16, 32, 6), (2, 8, 16, 64, 128, 6), (1, 32, 64, 256, 256, 6), (3, 2, 4, 32, 64, 6), (1, 34, 22, 64, 64, 6)])
 def test_conv3x3_winograd(N, H, W, Cin, Cout, tile, K=3):
     """Winograd F(2x2,3x3) path (filter/input transforms, 16 batched MFMA GEMMs, output transform + bias + ReLU)."""
     L = _lib()
@@ -90,7 +91,7 @@ def test_conv3x3_winograd(N, H, W, Cin, Cout, tile, K=3):
     y_ = torch.empty(N, H, W, Cout).cuda()
     L.check(L.lib.fcn8s_op_conv2d_winograd(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), N, H, W, Cin, Cout, K, 1, tile))
     torch.cuda.synchronize()
-    tol = 1e-5 if tile == 2 else 1e-4          # fp32 F(4x4,3x3) carries ~1e-5 of the output range (winograd.hip header)
+    tol = 1e-5 if tile == 2 else 1e-4          # fp32 F(4x4,3x3) / F(6x6,3x3) carry ~1e-5 / 2e-5 of the output range (winograd.hip header)
     assert rel_err(y_.cpu().numpy(), ref) < tol
     yd = torch.empty(N, H, W, Cout).cuda()
     L.check(L.lib.fcn8s_op_conv2d(None, ptr(xd), ptr(wd), ptr(bd), ptr(yd), N, H, W, Cin, Cout, K, 1))
