@@ -36,6 +36,7 @@ struct IgemmArgs {
     float alpha; int relu; float mask_scale;
     int dropout; float keep_prob; unsigned long long seed; unsigned int stream_id;
     int batched; long long x_batch_stride, y_batch_stride;   // gridDim.z independent GEMMs (Winograd positions)
+    int m_fastest;                                           // tile order, set by the launcher (see igemm.hip)
 };
 void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s);
 

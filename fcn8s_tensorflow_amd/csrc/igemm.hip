@@ -84,8 +84,12 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
     // M-tiles (overlapping halos) are neighbours in the XCD's contiguous run of logical ids.  (M-fastest and
     // 32-M-tile panels were measured for the streamed fc6 filter bank: same time, same fabric traffic.)
     const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);
-    const long long m0 = (long long)(lid / ntn) * BM;
-    const int n0 = (int)(lid % ntn) * BN;
+    // p.m_fastest (launcher): when the B operand is the big one (fc6: a 33 MB filter slab per Winograd position against 4 MB of
+    // activations), neighbouring ids share the B panel instead, so that each panel is fetched by ONE XCD's L2 and not by every
+    // XCD that holds one of its M-tiles (rocprof FETCH_SIZE of the fc6 GEMMs was 2-3x their algorithmic bytes with N fastest).
+    const unsigned ntm = gridDim.x / ntn;
+    const long long m0 = (long long)(p.m_fastest ? lid % ntm : lid / ntn) * BM;
+    const int n0 = (int)(p.m_fastest ? lid / ntm : lid % ntn) * BN;
     const int MaMb = p.Ma * p.Mb;
 
     long long a_base[A_LD];
@@ -366,8 +370,10 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
 }
 
 template <int BM, int BN, int WM, int WN, int BKF = 16>
-static void launch_igemm_cfg(const IgemmArgs& a, int phases, hipStream_t s)
+static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
 {
+    IgemmArgs a = a0;
+    a.m_fastest = (double)a.Ktot * a.Cout > (double)a.M * a.Cin;         // B (filters) larger than A (activations)
     dim3 grid((unsigned)(((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN)), 1, (unsigned)phases);
     const bool fast = (phases == 1 || a.batched) && a.Cin % BKF == 0 && a.Cout % BN == 0 && a.Ktot % a.Cin == 0;
     // filter bank small enough to live in L2 / MALL -> tap-inner K order (and at most 32 taps for the bit mask)
