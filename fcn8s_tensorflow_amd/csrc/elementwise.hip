@@ -133,9 +133,14 @@ int softmax_xent_blocks(long long npix)
 template <int C>   // C % 4 == 0: registers hold the pixel's logits
 __global__ __launch_bounds__(256) void softmax_xent_kernel_c(const float* logits, const uint8_t* labels,
                                                              float* dlogits, double* partials,
-                                                             long long npix, float gscale)
+                                                             long long npix, float gscale, float* colsum)
 {
     __shared__ double sh[4];
+    __shared__ float cs[C];
+    float csum[C];                             // colsum != nullptr: column sums of dlogits (= the last bias gradient), saves a pass over dlogits
+#pragma unroll
+    for (int i = 0; i < C; ++i) csum[i] = 0.f;
+    if (threadIdx.x < C) cs[threadIdx.x] = 0.f;
     double lsum = 0;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix;
          p += (long long)gridDim.x * blockDim.x) {
@@ -165,11 +170,23 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel_c(const float* logits
                 t.z = e[4*i+2] * inv - ((4*i+2) == lab ? gscale : 0.f);
                 t.w = e[4*i+3] * inv - ((4*i+3) == lab ? gscale : 0.f);
                 dst[i] = t;
+                csum[4*i] += t.x; csum[4*i+1] += t.y; csum[4*i+2] += t.z; csum[4*i+3] += t.w;
             }
         }
     }
     const double t = block_sum(lsum, sh);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    if (colsum && dlogits) {
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            float v = csum[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&cs[i], v);
+        }
+        __syncthreads();
+        if (threadIdx.x < C) unsafeAtomicAdd(colsum + threadIdx.x, cs[threadIdx.x]);
+    }
 }
 __global__ __launch_bounds__(256) void softmax_xent_kernel_any(const float* logits, const uint8_t* labels,
                                                                float* dlogits, double* partials,
@@ -195,15 +212,17 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel_any(const float* logi
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 void launch_softmax_xent(const float* logits, const uint8_t* labels, float* dlogits, double* partials,
-                         long long npix, int C, float grad_scale, hipStream_t s)
+                         long long npix, int C, float grad_scale, hipStream_t s, float* colsum)
 {
     const int blocks = softmax_xent_blocks(npix);
     if (C == 20)
-        hipLaunchKernelGGL(softmax_xent_kernel_c<20>, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, npix, grad_scale);
+        hipLaunchKernelGGL(softmax_xent_kernel_c<20>, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, npix, grad_scale, colsum);
     else if (C == 4)
-        hipLaunchKernelGGL(softmax_xent_kernel_c<4>, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, npix, grad_scale);
-    else
+        hipLaunchKernelGGL(softmax_xent_kernel_c<4>, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, npix, grad_scale, colsum);
+    else {
         hipLaunchKernelGGL(softmax_xent_kernel_any, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, npix, C, grad_scale);
+        if (colsum && dlogits) launch_colsum(dlogits, colsum, npix, C, s);
+    }
 }
 
 __global__ void finalize_loss_kernel(const double* partials, int nparts, long long npix, const float* regsum,

@@ -97,7 +97,7 @@ void launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H
 // partials: double[>= softmax_xent_blocks(npix)]
 int  softmax_xent_blocks(long long npix);
 void launch_softmax_xent(const float* logits, const uint8_t* labels, float* dlogits, double* partials,
-                         long long npix, int C, float grad_scale, hipStream_t s);
+                         long long npix, int C, float grad_scale, hipStream_t s, float* colsum = nullptr)   /* colsum[c] += sum_p dlogits[p,c] (zero-initialised by the caller) */;
 // loss_out[0] = sum(partials)/npix + 0.5*rate*regsum[0]
 void launch_finalize_loss(const double* partials, int nparts, long long npix, const float* regsum,
                           float rate, float* loss_out, hipStream_t s);

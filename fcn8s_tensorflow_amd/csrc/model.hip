@@ -73,6 +73,7 @@ struct fcn8s_model {
     int gcur = 0;
     void* d_images = nullptr; uint8_t* d_labels = nullptr;
     float *d_loss = nullptr, *d_regsum = nullptr, *d_softmax = nullptr;
+    float* d_lastbias = nullptr;       // column sums of dlogits (gradient of the last transposed conv's bias), produced by the loss kernel
     double* d_partials = nullptr; long long* d_pred = nullptr;
     unsigned long long* d_conf = nullptr;
     double loss_sum = 0; int64_t loss_cnt = 0;
@@ -609,7 +610,9 @@ int compute_loss(fcn8s_model* m, const uint8_t* lab_dev, float l2_rate, bool wit
     const long long npix = (long long)m->N * m->H * m->W;
     const int nb = softmax_xent_blocks(npix);
     { ProfScope ps(m, "softmax_xent", 0, (double)npix * (m->C * 4 * (with_grad ? 2 : 1) + 1));
-      launch_softmax_xent(A(m, "logits"), lab_dev, with_grad ? m->dlogits : nullptr, m->d_partials, npix, m->C, 1.0f / (float)npix, s); }
+      if (with_grad) hipMemsetAsync(m->d_lastbias, 0, 64 * sizeof(float), s);
+      launch_softmax_xent(A(m, "logits"), lab_dev, with_grad ? m->dlogits : nullptr, m->d_partials, npix, m->C, 1.0f / (float)npix, s,
+                          with_grad ? m->d_lastbias : nullptr); }
     const float* reg = nullptr;
     if (l2_rate != 0.f) {
         hipMemsetAsync(m->d_regsum, 0, sizeof(float), s);
@@ -655,7 +658,7 @@ void backward_bucket0(fcn8s_model* m)
     prepare_backward_weights(m);
     // logits = tconv16x16s8(a3)
     tconv_wgrad(m, A(m, "a3"), m->dlogits, Gp(m, "fc7_pool4_pool3_conv2d_trans/kernel"), N, h3, w3, C, 16, 8, s);
-    { ProfScope ps(m, "bias_grad", 0, 4.0 * N * H * W * C); launch_colsum(m->dlogits, Gp(m, "fc7_pool4_pool3_conv2d_trans/bias"), (long long)N * H * W, C, s); }
+    launch_axpy(Gp(m, "fc7_pool4_pool3_conv2d_trans/bias"), m->d_lastbias, 1.f, C, s);      // column sums of dlogits, from the loss kernel
     tconv_dgrad(m, m->dlogits, Wp(m, "fc7_pool4_pool3_conv2d_trans/kernel"), m->da3, N, h3, w3, C, 16, 8, s);
     l2_grad(m, "fc7_pool4_pool3_conv2d_trans/kernel");
     // a3 = tconv4x4s2(a4) + p3 ; p3 = conv1x1(pool3 * 1e-4)
@@ -848,8 +851,8 @@ int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
         if (m->wino_fc6 && m->fc6k == 7) ufl = std::max(ufl, 36 * 9 * (size_t)m->widths[4] * m->widths[5]);   // fc6: 36 positions x 9 sub-filters
         if ((e = hipMalloc((void**)&m->d_wino_u, ufl * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     }
-    if ((e = hipMalloc((void**)&m->d_loss, 2 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
-    m->d_regsum = m->d_loss + 1;
+    if ((e = hipMalloc((void**)&m->d_loss, (2 + 64) * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+    m->d_regsum = m->d_loss + 1; m->d_lastbias = m->d_loss + 2;
     if ((e = hipMalloc((void**)&m->d_conf, cc * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     hipMemset(m->d_conf, 0, cc * sizeof(unsigned long long));
     hipMemset(m->d_loss, 0, 2 * sizeof(float));
