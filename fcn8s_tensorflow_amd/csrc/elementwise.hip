@@ -510,4 +510,34 @@ void launch_init_normal(float* w, long long n, float stddev, int truncated, unsi
     hipLaunchKernelGGL(init_normal_kernel, dim3(cap_blocks(n, 256)), dim3(256), 0, s, w, n, stddev, truncated, seed, stream_id);
 }
 
+// ---- GPU-side augmentation of a uint8 batch: per-image crop window / canvas placement, horizontal flip and
+// brightness gain, the three geometric + photometric augmentations of data_generator/batch_generator.py:293-379 that do
+// not resample.  out[n, y, x] = in[n, y + oy[n], flip ? (Wo-1-x) + ox[n] : x + ox[n]] (outside the source: image 0, label void).
+__global__ void augment_u8_kernel(const unsigned char* img, const unsigned char* lab, unsigned char* oimg, unsigned char* olab,
+                                  const int* params, int N, int H, int W, int Ho, int Wo, int void_id)
+{
+    const long long total = (long long)N * Ho * Wo;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo); const long long r = i / Wo;
+        const int y = (int)(r % Ho), n = (int)(r / Ho);
+        const int oy = params[4 * n], ox = params[4 * n + 1], flip = params[4 * n + 2];
+        const float gain = __int_as_float(params[4 * n + 3]);
+        const int sy = y + oy, sx = (flip ? Wo - 1 - x : x) + ox;
+        const bool in = (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+        const long long src = ((long long)n * H + sy) * W + sx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = in ? (float)img[src * 3 + c] * gain : 0.f;
+            v = fminf(fmaxf(v, 0.f), 255.f);
+            oimg[i * 3 + c] = (unsigned char)(v + 0.5f);
+        }
+        if (lab) olab[i] = in ? lab[src] : (unsigned char)void_id;
+    }
+}
+void launch_augment_u8(const unsigned char* img, const unsigned char* lab, unsigned char* oimg, unsigned char* olab, const int* params,
+                       int N, int H, int W, int Ho, int Wo, int void_id, hipStream_t s)
+{
+    hipLaunchKernelGGL(augment_u8_kernel, dim3(cap_blocks((long long)N * Ho * Wo, 256)), dim3(256), 0, s, img, lab, oimg, olab, params, N, H, W, Ho, Wo, void_id);
+}
+
 }  // namespace fcn8s

@@ -142,6 +142,9 @@ void launch_wino_output(int tile, const float* m, const float* bias, const float
 //  if pidx != nullptr, one byte per pooled element: index 0..3 of the window's first maximum, 4 if that maximum is not > 0)
 void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s, int KS = 3);   // dy -> dm[P][T][C] = A dY A^T
 void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, int KS, hipStream_t s);        // du[P][nsub*Cin][Cout] -> dw[KS*KS][Cin][Cout]
+// params: int[4] per image = {y offset, x offset, flip, float bits of the brightness gain}
+void launch_augment_u8(const unsigned char* img, const unsigned char* lab, unsigned char* oimg, unsigned char* olab, const int* params,
+                       int N, int H, int W, int Ho, int Wo, int void_id, hipStream_t s);
 void launch_init_normal(float* w, long long n, float stddev, int truncated, unsigned long long seed,
                         unsigned int stream_id, hipStream_t s);
 

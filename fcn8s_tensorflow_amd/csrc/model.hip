@@ -1236,6 +1236,15 @@ int fcn8s_onehot_to_ids(void* stream, const void* onehot, int elem_bytes, int64_
 int fcn8s_op_preprocess(void* stream, const void* images, int dtype, float* out4, int64_t npix)
 { launch_preprocess(images, dtype, out4, npix, (hipStream_t)stream); OPCHK(); return FCN8S_OK; }
 
+int fcn8s_op_augment_u8(void* stream, const uint8_t* images, const uint8_t* labels, uint8_t* out_images, uint8_t* out_labels,
+                        const int32_t* params, int N, int H, int W, int Ho, int Wo, int void_id)
+{
+    if (!images || !out_images || !params || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || (labels && !out_labels))
+        return fail(nullptr, FCN8S_ERR_BAD_ARG, "augment_u8: bad argument");
+    launch_augment_u8(images, labels, out_images, out_labels, params, N, H, W, Ho, Wo, void_id, (hipStream_t)stream);
+    OPCHK(); return FCN8S_OK;
+}
+
 int fcn8s_op_conv2d(void* stream, const float* x, const float* w, const float* bias, float* y,
                     int N, int H, int W, int Cin, int Cout, int K, int relu)
 {

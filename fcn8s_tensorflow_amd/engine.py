@@ -332,6 +332,39 @@ class Engine:
         L.check(L.lib.fcn8s_metrics_get(self.h, C.byref(a), C.byref(b), C.byref(c)), self.h)
         return float(a.value), float(b.value), float(c.value)
 
+    def augment(self, images, labels=None, out_hw=None, offsets=None, flips=None, gains=None, void_class_id=0):
+        """GPU-side augmentation of a uint8 batch already on the device (not in the reference, whose BatchGenerator augments on
+        the host: batch_generator.py:293-379).  images: uint8 cuda tensor [N,H,W,3]; labels: uint8 cuda tensor [N,H,W] or None.
+        Per image: `offsets[n] = (y, x)` top-left corner of the output window in the source (negative = place the source inside a
+        larger canvas, like `random_crop` does), `flips[n]` horizontal flip, `gains[n]` brightness factor.  Returns the
+        augmented (images, labels) as new cuda tensors of size `out_hw` (default: unchanged)."""
+        torch = self.torch
+        self._sync_stream()
+        if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3 or not images.is_cuda:
+            raise ValueError("`images` must be a uint8 cuda tensor of shape (N, H, W, 3)")
+        N, H, W = (int(x) for x in images.shape[:3])
+        Ho, Wo = (int(x) for x in (out_hw or (H, W)))
+        par = np.zeros((N, 4), np.int32)
+        if offsets is not None:
+            par[:, :2] = np.asarray(offsets, np.int32).reshape(N, 2)
+        if flips is not None:
+            par[:, 2] = np.asarray(flips).astype(np.int32).reshape(N)
+        par[:, 3] = np.asarray(gains if gains is not None else np.ones(N), np.float32).reshape(N).view(np.int32)
+        pd = torch.from_numpy(par).to(self.device)
+        images = images.contiguous()
+        out = torch.empty((N, Ho, Wo, 3), dtype=torch.uint8, device=self.device)
+        lab_out = None; lp = lo = None
+        if labels is not None:
+            if labels.dtype != torch.uint8 or tuple(labels.shape) != (N, H, W) or not labels.is_cuda:
+                raise ValueError("`labels` must be a uint8 cuda tensor of shape (N, H, W)")
+            labels = labels.contiguous()
+            lab_out = torch.empty((N, Ho, Wo), dtype=torch.uint8, device=self.device)
+            lp, lo = C.c_void_p(labels.data_ptr()), C.c_void_p(lab_out.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(L.lib.fcn8s_op_augment_u8(stream, C.c_void_p(images.data_ptr()), lp, C.c_void_p(out.data_ptr()), lo,
+                                          C.c_void_p(pd.data_ptr()), N, H, W, Ho, Wo, int(void_class_id)))
+        return out, lab_out
+
     def predict(self, images, argmax=True):
         """sess.run(predictions_argmax | softmax_output) (fcn8s_tensorflow.py:764-770)."""
         self._sync_stream()

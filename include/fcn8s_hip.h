@@ -165,6 +165,12 @@ int fcn8s_profile_get(fcn8s_model* m, int group, const char** name, double* tota
 /* ---- single ops on DEVICE pointers (unit parity tests; same kernels the model
  * uses).  `stream` may be NULL (default stream).                                 */
 int fcn8s_op_preprocess(void* stream, const void* images, int image_dtype, float* out4, int64_t npix);
+/* GPU-side augmentation of a uint8 batch on DEVICE pointers (the crop / canvas placement, horizontal flip and
+ * brightness steps of data_generator/batch_generator.py:293-379, which do not resample).  params: int32[4] per image =
+ * {y offset, x offset, flip (0|1), IEEE-754 bits of the float brightness gain}; out[n,y,x] = in[n, y+oy, (flip ? Wo-1-x : x) + ox]
+ * * gain (clamped to 0..255, rounded), zero / void_id outside the source.  labels / out_labels may be NULL. */
+int fcn8s_op_augment_u8(void* stream, const uint8_t* images, const uint8_t* labels, uint8_t* out_images, uint8_t* out_labels,
+                        const int32_t* params, int N, int H, int W, int Ho, int Wo, int void_id);
 int fcn8s_op_conv2d(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,
                     int N, int H, int W, int Cin, int Cout, int K, int relu);
 /* the same SAME conv through Winograd F(tile x tile, 3x3), tile = 2, 4 or 6 (the path the model takes for its 3x3

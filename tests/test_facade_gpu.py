@@ -247,3 +247,31 @@ def test_tensorflow_checkpoint_files_round_trip(tmp_path):
     np.testing.assert_array_equal(m3.engine.get_params()["fc7_1x1/kernel"], params["fc7_1x1/kernel"])
     assert m3.engine.global_step == 2
     m3.close()
+
+
+def test_gpu_augmentation_matches_host_crop_flip_brightness():
+    """crop / canvas placement, horizontal flip and brightness on the GPU, against NumPy doing what
+    data_generator/batch_generator.py:293-379 does on the host for those (non-resampling) steps."""
+    import torch
+    from fcn8s_tensorflow_amd.engine import Engine
+    rng = np.random.default_rng(3)
+    N, H, W, Ho, Wo = 3, 20, 28, 16, 24
+    img = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8); lab = rng.integers(0, 20, (N, H, W), dtype=np.uint8)
+    offs = np.array([[2, 3], [-3, -5], [4, 0]]); flips = np.array([0, 1, 1]); gains = np.array([1.0, 1.5, 0.5], np.float32)
+    e = Engine(20, widths=(8, 8, 8, 8, 8, 16, 16))
+    out, lo = e.augment(torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda(), out_hw=(Ho, Wo), offsets=offs, flips=flips, gains=gains,
+                        void_class_id=0)
+    out, lo = out.cpu().numpy(), lo.cpu().numpy()
+    for n in range(N):
+        ref = np.zeros((Ho, Wo, 3), np.float32); rl = np.zeros((Ho, Wo), np.uint8)
+        for y in range(Ho):
+            for x in range(Wo):
+                sy, sx = y + offs[n, 0], (Wo - 1 - x if flips[n] else x) + offs[n, 1]
+                if 0 <= sy < H and 0 <= sx < W:
+                    ref[y, x] = img[n, sy, sx].astype(np.float32) * gains[n]; rl[y, x] = lab[n, sy, sx]
+        ref = np.floor(np.clip(ref, 0, 255) + 0.5).astype(np.uint8)
+        np.testing.assert_array_equal(out[n], ref)
+        np.testing.assert_array_equal(lo[n], rl)
+    with pytest.raises(ValueError):
+        e.augment(torch.zeros(1, 4, 4, 3).cuda())
+    e.close()
