@@ -319,36 +319,46 @@ void launch_confusion(const uint8_t* labels, const long long* pred, long long np
 }
 
 // ---- column sums (bias gradients): out[c] += sum_r x[r, c] --------------------
-__global__ __launch_bounds__(256) void colsum_kernel(const float* x, float* out, long long rows, int C,
-                                                     long long rows_per_block)
+// 16-byte loads, four independent rows in flight per thread; a block covers `rpb` rows x up to 1024 columns, reduces its
+// row groups through LDS and adds C partial sums to `out` (the first version read one float per thread per step: 89 us
+// per call on average, 1.9 ms per training step).
+__global__ __launch_bounds__(256) void colsum_kernel(const float4* __restrict__ x, float* __restrict__ out, long long rows, int C4, int tpr,
+                                                     long long rpb)
 {
-    __shared__ float sh[256];
-    const int CT = C < 64 ? 32 : 64;              // column tile handled by this block
-    const int rgroups = 256 / CT;
-    const int c = blockIdx.y * CT + (threadIdx.x % CT);
-    const int rg = threadIdx.x / CT;
-    const long long r0 = blockIdx.x * rows_per_block;
-    const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
-    float acc = 0.f;
-    if (c < C)
-        for (long long r = r0 + rg; r < r1; r += rgroups) acc += x[r * C + c];
+    __shared__ float4 sh[256];
+    const int rgroups = 256 / tpr;
+    const int lc = threadIdx.x % tpr, rg = threadIdx.x / tpr;
+    const int c = blockIdx.y * tpr + lc;
+    const long long r0 = blockIdx.x * rpb, r1 = (r0 + rpb < rows) ? r0 + rpb : rows;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C4 && rg < rgroups) {
+        long long r = r0 + rg;
+        for (; r + 3LL * rgroups < r1; r += 4LL * rgroups) {
+            const float4 a = x[r * C4 + c], b = x[(r + rgroups) * C4 + c], d = x[(r + 2LL * rgroups) * C4 + c], e = x[(r + 3LL * rgroups) * C4 + c];
+            acc.x += (a.x + b.x) + (d.x + e.x); acc.y += (a.y + b.y) + (d.y + e.y);
+            acc.z += (a.z + b.z) + (d.z + e.z); acc.w += (a.w + b.w) + (d.w + e.w);
+        }
+        for (; r < r1; r += rgroups) { const float4 a = x[r * C4 + c]; acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+    }
     sh[threadIdx.x] = acc;
     __syncthreads();
-    if (rg == 0 && c < C) {
-        for (int g = 1; g < rgroups; ++g) acc += sh[g * CT + (threadIdx.x % CT)];
-        unsafeAtomicAdd(out + c, acc);
+    if (rg == 0 && c < C4) {
+        for (int g = 1; g < rgroups; ++g) { const float4 t = sh[g * tpr + lc]; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+        unsafeAtomicAdd(out + 4 * c, acc.x); unsafeAtomicAdd(out + 4 * c + 1, acc.y);
+        unsafeAtomicAdd(out + 4 * c + 2, acc.z); unsafeAtomicAdd(out + 4 * c + 3, acc.w);
     }
 }
-void launch_colsum(const float* x, float* out, long long rows, int C, hipStream_t s)
+void launch_colsum(const float* x, float* out, long long rows, int C, hipStream_t s)   // C % 4 == 0 (all channel counts here are)
 {
-    const int CT = C < 64 ? 32 : 64;
-    const int ctiles = (C + CT - 1) / CT;
-    long long rblocks = (rows + 1023) / 1024;
-    const long long maxb = 2048 / ctiles > 0 ? 2048 / ctiles : 1;
+    const int C4 = C / 4;
+    int tpr = 1; while (tpr < C4 && tpr < 256) tpr *= 2;          // threads per row slice (power of two >= C4, at most 256)
+    const int ctiles = (C4 + tpr - 1) / tpr, rgroups = 256 / tpr;
+    long long rblocks = (rows + 16LL * rgroups - 1) / (16LL * rgroups);      // >= 16 rows per thread
+    const long long maxb = 4096 / ctiles > 0 ? 4096 / ctiles : 1;
     if (rblocks > maxb) rblocks = maxb;
     if (rblocks < 1) rblocks = 1;
     const long long rpb = (rows + rblocks - 1) / rblocks;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)rblocks, ctiles), dim3(256), 0, s, x, out, rows, C, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + rpb - 1) / rpb), ctiles), dim3(256), 0, s, (const float4*)x, out, rows, C4, tpr, rpb);
 }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, float* out, long long n)
