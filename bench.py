@@ -33,8 +33,11 @@ def pmc_traffic(kernel):
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         for name, v in d.get("kernels", {}).items():
             if name.replace(" ", "").startswith("voidfcn8s::" + kernel.replace(" ", "")) or name.replace(" ", "").startswith("fcn8s::" + kernel.replace(" ", "")):
-                return {"hbm_mb_per_launch": v["hbm_mb_per_launch"], "fetch_mb": v["fetch_mb_per_launch"],
-                        "write_mb": v["write_mb_per_launch"], "source": d.get("source")}
+                out = {"hbm_mb_per_launch": v["hbm_mb_per_launch"], "fetch_mb": v["fetch_mb_per_launch"],
+                       "write_mb": v["write_mb_per_launch"], "source": d.get("source")}
+                if "fetch_mb_per_launch_uncorrected" in v:      # the x2 FETCH_SIZE correction is an upper bound for 64-byte row-segment loads
+                    out["hbm_mb_per_launch_lower_bound"] = round(v["fetch_mb_per_launch_uncorrected"] + v["write_mb_per_launch"], 3)
+                return out
     except Exception:
         pass
     return None

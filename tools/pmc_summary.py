@@ -5,6 +5,9 @@
 Units / corrections follow /opt/skills/guides (MI355X_MICROARCH.md, HBM section):
   * FETCH_SIZE / WRITE_SIZE are reported in KiB (bytes = value * 1024);
   * on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads -> the fetch side is DOUBLED.
+    (The doubling is exact for streaming kernels -- it reproduces the optimizer's 4 x 538 MB -- but an UPPER BOUND for kernels
+    whose loads are 64-byte row segments, such as the A operand of the GEMM kernels (16 floats per row and K-tile); the
+    uncorrected figure is kept next to it as the lower bound.)
 
 usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [source note]
 """
@@ -30,7 +33,7 @@ def main():
         f, nf = fetch.get(k, [0.0, 0]); w, nw = write.get(k, [0.0, 0])
         fm = 2.0 * f * 1024 / max(nf, 1) / 1e6; wm = w * 1024 / max(nw, 1) / 1e6
         out["kernels"][k] = {"launches": max(nf, nw), "fetch_mb_per_launch": round(fm, 3), "write_mb_per_launch": round(wm, 3),
-                             "hbm_mb_per_launch": round(fm + wm, 3)}
+                             "hbm_mb_per_launch": round(fm + wm, 3), "fetch_mb_per_launch_uncorrected": round(fm / 2, 3)}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in sorted(out["kernels"].items(), key=lambda kv: -kv[1]["hbm_mb_per_launch"] * kv[1]["launches"])[:14]:
         print("%-100s n=%4d fetch %9.1f MB write %9.1f MB" % (k[:100], v["launches"], v["fetch_mb_per_launch"], v["write_mb_per_launch"]))
