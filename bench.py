@@ -174,8 +174,12 @@ def main():
         if dom:
             g = kern[dom]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+            tr = pmc_traffic(dom)
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom),
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    # HBM-side bytes per launch from the PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE); compare with
+                    # algorithmic_mb_per_launch * 1e6.  Details (and the uncorrected lower bound) in traffic_detail.
+                    "traffic": (round(tr["hbm_mb_per_launch"] * 1e6) if tr else None), "traffic_unit": "bytes/launch", "traffic_detail": tr,
                     "launches": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                     "algorithmic_gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 3),
                     "algorithmic_mb_per_launch": round(g["bytes"] / g["launches"] / 1e6, 2),
