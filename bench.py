@@ -128,6 +128,9 @@ def main():
     labels = torch.from_numpy(rng.integers(0, 20, (N, H, W), dtype=np.uint8)).cuda()
     opt = L.OPT_TF_ADAM if args.optimizer == "adam" else L.OPT_SGD_MOMENTUM
 
+    if args.mode == "infer":
+        eng.freeze(True)                          # a serving loop: constant weights, transformed filters built once (fcn8s_freeze_params)
+
     def step():
         if args.mode == "train":
             eng.train_step(images, labels, 1e-4, keep_prob=0.5, l2_rate=0.0, optimizer=opt, fetch_loss=False)

@@ -64,6 +64,7 @@ SIGNATURES = {
     "fcn8s_set_global_step": (_i, [_p, _i64]),
     "fcn8s_get_opt_state": (_i, [_p, _p, _p, _sz]),
     "fcn8s_set_opt_state": (_i, [_p, _p, _p, _sz]),
+    "fcn8s_freeze_params": (_i, [_p, _i]),
     "fcn8s_set_precision": (_i, [_p, _i]),
     "fcn8s_get_precision": (_i, [_p]),
     "fcn8s_get_activation": (_i, [_p, C.c_char_p, _p, _sz]),

@@ -60,6 +60,9 @@ struct fcn8s_model {
     int wino_fc6 = 1;                                                     // fc6 7x7 as nine 3x3 sub-filters in the Winograd domain
     int precision = FCN8S_PREC_F32;                                       // FCN8S_PREC_BF16_FC: forward fc6 / fc7 on the bf16 MFMA
     bool pool_fused[5] = {false, false, false, false, false};            // forward wrote pool_b + argmax bytes from conv_b_last's output transform
+    // fcn8s_freeze_params: the caller promises constant parameters; Winograd-transformed filters are then kept per layer
+    bool frozen = false;
+    std::map<std::string, float*> u_cache;                               // layer -> transformed filter bank (hipMalloc'ed), valid while frozen
     std::string fused_v_layer;                                            // layer whose data-gradient input transform already sits in d_wino_v
     unsigned short* d_wbf16 = nullptr;                                    // bf16 K-tile-major copy of the fc6 / fc7 kernel (one at a time)
     hipStream_t stream = nullptr;
@@ -234,11 +237,20 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
     a.alpha = 1.f; a.mask_scale = 1.f;
     a.batched = 1; a.x_batch_stride = wino_slab(T, Kg); a.y_batch_stride = wino_slab(T, Cout);
     const double tb = 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg), ob = 4.0 * ((double)N * H * W * Cout * (e.pool ? 1.25 : 1.0) + (double)P * T * Cout);
+    // frozen parameters (evaluate / predict loops): the transformed filter bank of each forward layer is computed once and kept
+    bool u_cached = false;
+    if (m && m->frozen && layer && !v_ready && std::string(tag).find("dgrad") == std::string::npos) {
+        float*& cu = m->u_cache[std::string(layer) + "#" + std::to_string(tile)];       // (the tile, hence the bank's shape, depends on the image size)
+        if (cu) { u = cu; u_cached = true; }
+        else if (hipMalloc((void**)&cu, (size_t)P * Kg * Cout * sizeof(float)) == hipSuccess) u = cu;       // filled below, reused from the next call on
+        else { cu = nullptr; (void)hipGetLastError(); }
+        a.w = u;
+    }
     // v_ready: V was written together with the weight gradient's dM by the fused transform (launch_wino_input_dout)
-    auto pre = [&]() { launch_wino_filter(tile, wk, u, Cin, Cout, KS, s); if (!v_ready) launch_wino_input(tile, x, v, N, H, W, Cin, KS, s); };
+    auto pre = [&]() { if (!u_cached) launch_wino_filter(tile, wk, u, Cin, Cout, KS, s); if (!v_ready) launch_wino_input(tile, x, v, N, H, W, Cin, KS, s); };
     auto post = [&]() { launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s, e.pool, e.pidx, KS); };
     if (m) {
-        { ProfScope ps(m, "wino_transform", 0, (v_ready ? 0.0 : tb) + (double)(KS * KS + P * nsub2) * 4 * Cin * Cout); pre(); }
+        { ProfScope ps(m, "wino_transform", 0, (v_ready ? 0.0 : tb) + (u_cached ? 0.0 : (double)(KS * KS + P * nsub2) * 4 * Cin * Cout)); pre(); }
         { ProfScope ps(m, tag, 2.0 * P * T * Kg * Cout, 4.0 * P * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_igemm(a, P, s); }
         { ProfScope ps(m, "wino_transform", 0, ob); post(); }
     } else { pre(); launch_igemm(a, P, s); post(); }
@@ -872,6 +884,7 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->d_wt) hipFree(m->d_wt);
     if (m->d_w1pad) hipFree(m->d_w1pad);
     if (m->d_wino_u) hipFree(m->d_wino_u);
+    for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
     if (m->d_wbf16) hipFree(m->d_wbf16);
     for (int i = 0; i < 3; ++i) if (m->d_tph[i]) hipFree(m->d_tph[i]);
     if (m->d_loss) hipFree(m->d_loss);
@@ -882,6 +895,21 @@ int fcn8s_destroy(fcn8s_model* m)
 }
 
 const char* fcn8s_last_error(const fcn8s_model* m) { return m ? m->err.c_str() : g_last_error.c_str(); }
+
+static void drop_u_cache(fcn8s_model* m)
+{
+    if (m->u_cache.empty()) return;
+    hipStreamSynchronize(m->stream);
+    for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
+    m->u_cache.clear();
+}
+int fcn8s_freeze_params(fcn8s_model* m, int frozen)
+{
+    if (!m) return FCN8S_ERR_BAD_ARG;
+    if (!frozen || !m->frozen) drop_u_cache(m);          // entering or leaving: start from an empty cache
+    m->frozen = frozen != 0;
+    return FCN8S_OK;
+}
 
 int fcn8s_set_precision(fcn8s_model* m, int precision)
 {
@@ -932,7 +960,11 @@ static int xfer_named(fcn8s_model* m, float* base, const char* name, void* host,
     else HIPCHK(m, hipMemcpy(host, base + p.offset, n * sizeof(float), hipMemcpyDeviceToHost));
     return FCN8S_OK;
 }
-int fcn8s_set_param(fcn8s_model* m, const char* name, const float* host, size_t n) { return xfer_named(m, m ? m->d_params : nullptr, name, (void*)host, n, true); }
+int fcn8s_set_param(fcn8s_model* m, const char* name, const float* host, size_t n)
+{
+    if (m && m->frozen) fcn8s_freeze_params(m, 0);      // parameters are about to change: leave the frozen state
+    return xfer_named(m, m ? m->d_params : nullptr, name, (void*)host, n, true);
+}
 int fcn8s_get_param(fcn8s_model* m, const char* name, float* host, size_t n) { return xfer_named(m, m ? m->d_params : nullptr, name, host, n, false); }
 int fcn8s_get_grad(fcn8s_model* m, const char* name, float* host, size_t n) { return xfer_named(m, m ? m->d_grads : nullptr, name, host, n, false); }
 void* fcn8s_param_buffer(fcn8s_model* m, size_t* n) { if (!m) return nullptr; if (n) *n = m->total; return m->d_params; }
@@ -947,6 +979,7 @@ int fcn8s_bucket_range(const fcn8s_model* m, int b, size_t* off, size_t* n)
 
 int fcn8s_init_params(fcn8s_model* m, uint64_t seed)
 {
+    if (m && m->frozen) fcn8s_freeze_params(m, 0);      // parameters are about to change (or a training pass starts): leave the frozen state
     if (!m) return FCN8S_ERR_BAD_ARG;
     HIPCHK(m, hipMemsetAsync(m->d_params, 0, m->total * sizeof(float), m->stream));
     uint32_t sid = 1000;
@@ -967,6 +1000,7 @@ int fcn8s_init_params(fcn8s_model* m, uint64_t seed)
 int fcn8s_forward_loss(fcn8s_model* m, const void* images, int dtype, const uint8_t* labels, int N, int H, int W,
                        float keep_prob, float l2_rate, int where)
 {
+    if (m && m->frozen) fcn8s_freeze_params(m, 0);      // parameters are about to change (or a training pass starts): leave the frozen state
     if (!m || !images || !labels) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_forward_loss: null argument");
     if (!(keep_prob > 0.f && keep_prob <= 1.f)) return fail(m, FCN8S_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
     int rc = ensure_workspace(m, N, H, W); if (rc) return rc;
@@ -987,6 +1021,7 @@ int fcn8s_backward_bucket(fcn8s_model* m, int bucket)
 
 int fcn8s_apply_update(fcn8s_model* m, int optimizer, float lr, float grad_scale)
 {
+    if (m && m->frozen) fcn8s_freeze_params(m, 0);      // parameters are about to change (or a training pass starts): leave the frozen state
     if (!m) return FCN8S_ERR_BAD_ARG;
     const int64_t t = m->step + 1;
     if (optimizer == FCN8S_OPT_TF_ADAM) {
@@ -1016,6 +1051,7 @@ int fcn8s_read_loss(fcn8s_model* m, float* loss_out)
 int fcn8s_train_step(fcn8s_model* m, const void* images, int dtype, const uint8_t* labels, int N, int H, int W,
                      float lr, float keep_prob, float l2_rate, int where, float* loss_out, int64_t* step_out)
 {
+    if (m && m->frozen) fcn8s_freeze_params(m, 0);      // parameters are about to change (or a training pass starts): leave the frozen state
     int rc = fcn8s_forward_loss(m, images, dtype, labels, N, H, W, keep_prob, l2_rate, where); if (rc) return rc;
     for (int b = 0; b < FCN8S_NUM_BUCKETS; ++b) { rc = do_backward_bucket(m, b); if (rc) return rc; }
     rc = fcn8s_apply_update(m, FCN8S_OPT_TF_ADAM, lr, 1.f); if (rc) return rc;

@@ -136,6 +136,7 @@ class Engine:
     def broadcast_params(self, src=0):
         d = _dist()
         if d and self.world_size > 1:
+            self.freeze(False)
             d.broadcast(self.flat_params, src=src, group=self.pg)
 
     @property
@@ -247,6 +248,12 @@ class Engine:
         return (ka_i, a), pi, dt, a.ctypes.data_as(C.c_void_p), where, nhw
 
     # ---- hot path ----------------------------------------------------------------------------
+    def freeze(self, frozen=True):
+        """Promise (or withdraw the promise) that the parameters stay constant: inside evaluate() / predict loops the library then
+        keeps the Winograd-transformed filter banks across calls.  Library calls that change parameters unfreeze on their own;
+        code that writes into `flat_params` through torch must call `freeze(False)` first."""
+        L.check(L.lib.fcn8s_freeze_params(self.h, 1 if frozen else 0), self.h)
+
     def set_precision(self, precision):
         """'fp32' (the reference's arithmetic) or 'bf16_fc' (BASELINE config 5: forward fc6 / fc7 with bf16-rounded
         operands on the bf16 MFMA, fp32 accumulation; the rest of the step stays fp32)."""

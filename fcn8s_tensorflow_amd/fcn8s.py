@@ -290,9 +290,13 @@ class FCN8s:
         tr = trange(num_batches, file=sys.stdout, disable=self.engine.rank != 0)
         tr.set_description(description)
 
-        for step in tr:
-            batch_images, batch_labels = next(data_generator)
-            self.engine.eval_step(batch_images, batch_labels, l2_rate=l2_regularization)
+        self.engine.freeze(True)            # no training inside an evaluation loop: transformed filters are built once
+        try:
+            for step in tr:
+                batch_images, batch_labels = next(data_generator)
+                self.engine.eval_step(batch_images, batch_labels, l2_rate=l2_regularization)
+        finally:
+            self.engine.freeze(False)
 
         self.engine.metrics_allreduce()
         values = dict(zip(('loss', 'mean_iou', 'accuracy'), self.engine.metrics_get()))
@@ -341,6 +345,7 @@ class FCN8s:
         tr = trange(num_images, file=sys.stdout)
         tr.set_description('Processing images')
 
+        self.engine.freeze(True)            # constant weights for the whole directory
         for i in tr:
             filepath = image_paths[i]
             pil = Image.open(filepath).convert('RGB')
@@ -362,6 +367,7 @@ class FCN8s:
                 processed = canvas
 
             processed.save(os.path.join(results_dir, os.path.basename(filepath)))
+        self.engine.freeze(False)
 
     def save(self,
              model_save_dir,

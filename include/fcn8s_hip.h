@@ -141,6 +141,12 @@ int     fcn8s_set_opt_state(fcn8s_model* m, const float* host_m, const float* ho
 
 /* ---- introspection for parity tests ----------------------------------------- *
  * names: "pool3","pool4","fc7","logits", "conv1_1"... (post-ReLU activations)     */
+/* frozen = 1: the caller promises that the parameters stay constant (an evaluate() / predict loop, the reference's sessions never
+ * train inside one, fcn8s_tensorflow.py:660-697, :743-770); the library then keeps derived tensors (Winograd-transformed filter
+ * banks) across calls instead of rebuilding them per forward pass.  Any library call that changes parameters or starts a training
+ * pass unfreezes; whoever writes into an external parameter buffer (fcn8s_config.ext_params) must call this with 0 first. */
+int fcn8s_freeze_params(fcn8s_model* m, int frozen);
+
 /* Arithmetic of the forward fc6 / fc7 layers (FCN8S_PREC_*); not in the reference, which is fp32 throughout.
  * BF16_FC needs fc6/fc7 widths that are multiples of 128 and a conv5 width that is a multiple of 32 (BAD_ARG otherwise). */
 int fcn8s_set_precision(fcn8s_model* m, int precision);

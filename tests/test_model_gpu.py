@@ -246,3 +246,29 @@ def test_errors_are_python_exceptions():
     with pytest.raises(ValueError):
         e.train_step(batch(1, 32, 32)[0], np.zeros((1, 32, 16), np.uint8), 1e-3)
     e.close()
+
+
+def test_frozen_parameters_cache_and_invalidation():
+    """fcn8s_freeze_params: identical predictions with the cached transformed filters, across image sizes (the Winograd tile
+    and with it the bank's shape depends on the size), and every parameter change leaves the frozen state."""
+    widths = SMALL
+    P = orc.init_params(20, widths, seed=3, decoder_std_scale=30.0, bias_std=0.05)
+    img, _ = batch(2, 128, 160)
+    small, _ = batch(1, 32, 64, seed=5)
+    e = make_engine(widths); e.set_params(P)
+    ref = e.predict(img, argmax=False); ref_small = e.predict(small, argmax=False)
+    e.freeze(True)
+    for _ in range(2):                                   # first call fills the cache, second uses it
+        np.testing.assert_array_equal(e.predict(img, argmax=False), ref)
+        np.testing.assert_array_equal(e.predict(small, argmax=False), ref_small)
+    P2 = orc.init_params(20, widths, seed=4, decoder_std_scale=30.0, bias_std=0.05)
+    e.set_params(P2)                                     # unfreezes: no stale filters
+    e2 = make_engine(widths); e2.set_params(P2)
+    np.testing.assert_array_equal(e.predict(img, argmax=False), e2.predict(img, argmax=False))
+    e.freeze(True); e.predict(img)
+    e.train_step(img, batch(2, 128, 160)[1], 1e-3, keep_prob=1.0)      # a training step unfreezes as well ...
+    after = e.predict(img, argmax=False)                               # ... so this must not see the filters cached before it
+    e.freeze(False)
+    np.testing.assert_array_equal(after, e.predict(img, argmax=False))
+    assert np.abs(after - e2.predict(img, argmax=False)).max() > 0     # and the step did change the weights
+    e.close(); e2.close()
