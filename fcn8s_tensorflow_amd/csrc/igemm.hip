@@ -389,9 +389,14 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
     g_last_kernel = tags[mode].c_str();
     // few output tiles but a very long reduction (fc6 data gradient: 256 tiles, K = 200704): split K over
     // gridDim.y and combine with fp32 atomics -- only when the epilogue is linear
-    if ((mode == 1 || mode == 3) && !a.relu && !a.mask && !a.dropout && !a.addend && a.out_scale == 1 && a.ldy == a.Cout &&
-        grid.x < 512 && a.Ktot / BKF >= 512) {
-        unsigned ks = 1024 / grid.x; if (ks > 8) ks = 8;
+    // ... or few blocks altogether (batch-1 inference: fc6 has 32 tiles per Winograd position and must still stream a 1.6 GB
+    // filter bank at HBM speed)
+    const bool linear = (mode == 1 || mode == 3) && !a.relu && !a.mask && !a.dropout && !a.addend && a.out_scale == 1 && a.ldy == a.Cout;
+    const unsigned nblocks = grid.x * (unsigned)phases, nkt_all = (unsigned)(a.Ktot / BKF);
+    if (linear && ((grid.x < 512 && nkt_all >= 512) || (nblocks < 2048 && nkt_all >= 64))) {
+        unsigned ks = nkt_all >= 512 && grid.x < 512 ? 1024 / grid.x : 4096 / nblocks;
+        if (ks > 8) ks = 8;
+        if (ks > nkt_all / 16) ks = nkt_all / 16;
         if (ks >= 2) {
             grid.y = ks;
             const size_t nfl = a.batched ? (size_t)(phases - 1) * a.y_batch_stride + (size_t)a.M * a.Cout : (size_t)a.M * a.Cout;
