@@ -85,7 +85,8 @@ def test_forward_logits_and_argmax(widths, n, h, w):
 
 @pytest.mark.parametrize("widths,n,h,w,l2", [(SMALL, 2, 64, 64, 0.0), (SMALL, 1, 32, 96, 1e-2), (None, 1, 32, 32, 0.0),
                                                 (None, 2, 32, 64, 0.0),    # full width, W % 64 == 0: the specialised conv1_1 / 3x3 wgrad kernels
-                                                (SMALL, 1, 128, 128, 1e-3)])  # 4x4 fc6 map: fc6 through the Winograd sub-filter decomposition
+                                                (SMALL, 1, 128, 128, 1e-3),   # 4x4 fc6 map: fc6 through the Winograd sub-filter decomposition
+                                                (SMALL, 1, 96, 160, 1e-3), (SMALL, 2, 64, 224, 0.0)])   # sizes that are not multiples of the 6x6 tile in any block
 def test_gradients(widths, n, h, w, l2):
     P, img, lab = tie_free_case(widths, n, h, w, seed=2)
     e = make_engine(widths)
