@@ -236,7 +236,7 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
     a.out_scale = 1; a.phases_x = 1; a.w_phase_stride = (long long)Kg * Cout;
     a.alpha = 1.f; a.mask_scale = 1.f;
     a.batched = 1; a.x_batch_stride = wino_slab(T, Kg); a.y_batch_stride = wino_slab(T, Cout);
-    const double tb = 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg), ob = 4.0 * ((double)N * H * W * Cout * (e.pool ? 1.25 : 1.0) + (double)P * T * Cout);
+    const double tb = 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg), ob = 4.0 * ((double)N * H * W * Cout * ((e.pool ? 1.25 : 1.0) + (e.mask ? 1.0 : 0.0) + (e.addend ? 1.0 : 0.0)) + (double)P * T * Cout);   // y (+ pool) written, ReLU mask / skip addend read
     // frozen parameters (evaluate / predict loops): the transformed filter bank of each forward layer is computed once and kept
     bool u_cached = false;
     if (m && m->frozen && layer && !v_ready && std::string(tag).find("dgrad") == std::string::npos) {
