@@ -137,7 +137,10 @@ bool launch_wino_input_dout(int tile, const float* dy, float* v, float* dm, int 
 bool wino_fuse_dz_enabled();
 void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
                         int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,
-                        unsigned int stream_id, hipStream_t s, float* pool = nullptr, unsigned char* pidx = nullptr, int KS = 3);   // m[P][T][C] -> y[N,H,W,C]
+                        unsigned int stream_id, hipStream_t s, float* pool = nullptr, unsigned char* pidx = nullptr, int KS = 3,
+                        unsigned* rbits_out = nullptr, const unsigned* rbits_in = nullptr);                      // m[P][T][C] -> y[N,H,W,C]
+// rbits_out: also record (y > 0) as one bit per element (wino_rbits_words() words); rbits_in: use such a record instead of `mask`
+size_t wino_rbits_words(int tile, int N, int H, int W, int C);
 // (pool != nullptr: also writes the 2x2/2 max-pool of y, [N,H/2,W/2,C] -- the tiles are aligned with the pool windows -- and,
 //  if pidx != nullptr, one byte per pooled element: index 0..3 of the window's first maximum, 4 if that maximum is not > 0)
 void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s, int KS = 3);   // dy -> dm[P][T][C] = A dY A^T

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -63,6 +64,7 @@ struct fcn8s_model {
     // fcn8s_freeze_params: the caller promises constant parameters; Winograd-transformed filters are then kept per layer
     bool frozen = false;
     std::map<std::string, float*> u_cache;                               // layer -> transformed filter bank (hipMalloc'ed), valid while frozen
+    std::set<std::string> rbits_ok;                                       // layers whose forward pass wrote a ReLU bit mask ("rb:<layer>") this step
     std::string fused_v_layer;                                            // layer whose data-gradient input transform already sits in d_wino_v
     unsigned short* d_wbf16 = nullptr;                                    // bf16 K-tile-major copy of the fc6 / fc7 kernel (one at a time)
     hipStream_t stream = nullptr;
@@ -198,7 +200,9 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
              float alpha = 1.f; int relu = 0; float mask_scale = 1.f; int dropout = 0; float keep = 1.f;
              uint32_t stream_id = 0; int dgrad = 0;      // dgrad: data-gradient launch (profile tag; never keeps V)
              float* pool_out = nullptr;                  // 2x2/2 max-pool of the output, written by the Winograd output transform if that path runs
-             unsigned char* pool_idx = nullptr; };       // ... with the per-window argmax bytes the backward pass routes the pool gradient by
+             unsigned char* pool_idx = nullptr;          // ... with the per-window argmax bytes the backward pass routes the pool gradient by
+             unsigned* relu_bits_out = nullptr;          // forward, Winograd path: also record (y > 0), one bit per element
+             const unsigned* relu_bits_in = nullptr; };  // data gradient, Winograd path: such a record of `mask` (read instead of the tensor)
 
 // 3x3 SAME conv through Winograd F(tile x tile, 3x3): filter transform, input transform, (tile+2)^2 batched GEMMs
 // on the matrix cores (2.25x / 4x fewer MFMA flops than the direct form), output transform + fused epilogue.
@@ -219,7 +223,8 @@ int wino_tile_for(const fcn8s_model* m, int H, int W, int K = 3)
 }
 long long wino_tiles(int tile, int N, int H, int W) { return (long long)N * ((H + tile - 1) / tile) * ((W + tile - 1) / tile); }
 struct WinoEpi { const float* bias = nullptr; const float* addend = nullptr; const float* mask = nullptr; float mask_scale = 1.f;
-                 int relu = 0; int dropout = 0; float keep = 1.f; unsigned long long seed = 0; unsigned int stream_id = 0; float* pool = nullptr; unsigned char* pidx = nullptr; };
+                 int relu = 0; int dropout = 0; float keep = 1.f; unsigned long long seed = 0; unsigned int stream_id = 0; float* pool = nullptr; unsigned char* pidx = nullptr;
+                 unsigned* rbits_out = nullptr; const unsigned* rbits_in = nullptr; };
 // KS = 3, or 7 (3x3 grid of 3x3 sub-filters, GEMM depth 9*Cin -- see winograd.hip)
 void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const float* x, const float* wk, float* y, float* u, float* v, float* mm,
                    int N, int H, int W, int Cin, int Cout, const WinoEpi& e, hipStream_t s, const char* layer, bool v_ready = false)
@@ -236,7 +241,7 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
     a.out_scale = 1; a.phases_x = 1; a.w_phase_stride = (long long)Kg * Cout;
     a.alpha = 1.f; a.mask_scale = 1.f;
     a.batched = 1; a.x_batch_stride = wino_slab(T, Kg); a.y_batch_stride = wino_slab(T, Cout);
-    const double tb = 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg), ob = 4.0 * ((double)N * H * W * Cout * ((e.pool ? 1.25 : 1.0) + (e.mask ? 1.0 : 0.0) + (e.addend ? 1.0 : 0.0)) + (double)P * T * Cout);   // y (+ pool) written, ReLU mask / skip addend read
+    const double tb = 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg), ob = 4.0 * ((double)N * H * W * Cout * ((e.pool ? 1.25 : 1.0) + (e.rbits_in ? 1.0 / 32 : (e.mask ? 1.0 : 0.0)) + (e.addend ? 1.0 : 0.0) + (e.rbits_out ? 1.0 / 32 : 0.0)) + (double)P * T * Cout);   // y (+ pool) written, ReLU mask / skip addend read
     // frozen parameters (evaluate / predict loops): the transformed filter bank of each forward layer is computed once and kept
     bool u_cached = false;
     if (m && m->frozen && layer && !v_ready && std::string(tag).find("dgrad") == std::string::npos) {
@@ -248,7 +253,7 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
     }
     // v_ready: V was written together with the weight gradient's dM by the fused transform (launch_wino_input_dout)
     auto pre = [&]() { if (!u_cached) launch_wino_filter(tile, wk, u, Cin, Cout, KS, s); if (!v_ready) launch_wino_input(tile, x, v, N, H, W, Cin, KS, s); };
-    auto post = [&]() { launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s, e.pool, e.pidx, KS); };
+    auto post = [&]() { launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s, e.pool, e.pidx, KS, e.rbits_out, e.rbits_in); };
     if (m) {
         { ProfScope ps(m, "wino_transform", 0, (v_ready ? 0.0 : tb) + (u_cached ? 0.0 : (double)(KS * KS + P * nsub2) * 4 * Cin * Cout)); pre(); }
         { ProfScope ps(m, tag, 2.0 * P * T * Kg * Cout, 4.0 * P * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_igemm(a, P, s); }
@@ -271,6 +276,8 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
         if (!dgrad && layer) { auto it = m->acts.find(std::string("wv:") + layer); if (it != m->acts.end()) vbuf = it->second.p; }
         WinoEpi we; we.bias = e.bias; we.addend = e.addend; we.mask = e.mask; we.mask_scale = e.mask_scale; we.relu = e.relu;
         we.dropout = e.dropout; we.keep = e.keep; we.seed = m->seed; we.stream_id = e.stream_id; we.pool = e.pool_out; we.pidx = e.pool_idx;
+        we.rbits_out = e.relu_bits_out; we.rbits_in = e.relu_bits_in;
+        if (e.relu_bits_out && layer) m->rbits_ok.insert(layer);
         const char* tag = K == 7 ? (dgrad ? "wino_gemm_fc6_dgrad" : "wino_gemm_fc6_fwd") : (dgrad ? "wino_gemm_dgrad" : "wino_gemm_fwd");
         conv_winograd(m, wino_tile_for(m, H, W, K), K, tag, x, w, y, m->d_wino_u, vbuf, m->d_wino_m, N, H, W, Cin, Cout, we, s, layer, v_ready);
         return e.pool_out != nullptr;
@@ -427,6 +434,18 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
         add(nm, h, w, m->widths[b]);
     }
     const int h5 = H / 32, w5 = W / 32, h4 = H / 16, w4 = W / 16, h3 = H / 8, w3 = W / 8;
+    {   // ReLU bit masks of the convs whose output is another conv's input (read back by that conv's data gradient)
+        int cin = 3;
+        for (int b = 0, hh = H, ww = W; b < 5; ++b, hh /= 2, ww /= 2)
+            for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
+                const int tile = wino_tile_for(m, hh, ww, 3);
+                if (i < kConvsPerBlock[b] && m->wino_min_cin > 0 && cin >= m->wino_min_cin && cin % 16 == 0 && m->widths[b] % 64 == 0 && tile) {
+                    char nm[40]; snprintf(nm, sizeof nm, "rb:conv%d_%d", b + 1, i);
+                    items.push_back({nm, wino_rbits_words(tile, N, hh, ww, m->widths[b]), 0, 0, 0, nullptr});
+                }
+                cin = m->widths[b];
+            }
+    }
     for (int b = 0; b < 5; ++b) {      // argmax bytes of pool_b (one per pooled element), see launch_wino_output
         char nm[16]; snprintf(nm, sizeof nm, "pidx%d", b + 1);
         items.push_back({nm, ((size_t)N * (H >> (b + 1)) * (W >> (b + 1)) * (size_t)m->widths[b] + 3) / 4, 0, 0, 0, nullptr});
@@ -542,6 +561,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     hipStream_t s = m->stream;
     const int N = m->N, H = m->H, W = m->W, C = m->C;
     prepare_forward_weights(m);
+    m->rbits_ok.clear();
     { ProfScope ps(m, "preprocess", 0, (double)N * H * W * (16 + (dtype ? 12 : 3))); launch_preprocess(img_dev, dtype, A(m, "x0"), (long long)N * H * W, s); }
     const float* x = A(m, "x0");
     int h = H, w = W, cin = 4;
@@ -552,6 +572,10 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
             const bool first = (b == 0 && i == 1);
             Epi e; e.bias = Wp(m, std::string(nm) + "/biases"); e.relu = 1;
             const float* wt = first ? m->d_w1pad : Wp(m, std::string(nm) + "/filter");
+            if (train && i < kConvsPerBlock[b]) {                                                            // its output is the next conv's input
+                auto it = m->acts.find(std::string("rb:") + nm);
+                if (it != m->acts.end()) e.relu_bits_out = (unsigned*)it->second.p;
+            }
             if (i == kConvsPerBlock[b]) {                                                                    // last conv of the block
                 snprintf(pn, sizeof pn, "pool%d", b + 1); e.pool_out = A(m, pn);
                 if (train) { char ix[16]; snprintf(ix, sizeof ix, "pidx%d", b + 1); e.pool_idx = (unsigned char*)A(m, ix); }
@@ -744,7 +768,10 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
                        N, h, w, cin, cw, 3, 1.f, s, real_cin, nm, dgrad_wino, i == nconv ? pidx : nullptr);
             if (first) break;
             Epi e; e.dgrad = 1;
-            if (i > 1) { e.mask = xin; e.mask_scale = 1.f; }               // ReLU of the previous conv
+            if (i > 1) {                                                   // ReLU of the previous conv
+                e.mask = xin; e.mask_scale = 1.f;
+                if (m->rbits_ok.count(inname)) e.relu_bits_in = (const unsigned*)A(m, (std::string("rb:") + inname).c_str());
+            }
             else if (b == 5) e.addend = m->gskip4;                        // d(pool4) also receives the pool4_1x1 path
             else if (b == 4) e.addend = m->gskip3;                        // d(pool3) also receives the pool3_1x1 path
             conv_same(m, "conv3x3_dgrad", dz, WTp(m, std::string(nm) + "/filter"), m->gbuf[m->gcur ^ 1], N, h, w, cw, cin, 3, e, s, 0, nm);

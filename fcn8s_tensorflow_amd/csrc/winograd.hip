@@ -297,16 +297,23 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
 
 // ---- output: one thread = one tile x VEC channels; Y = A^T M A, then the conv epilogue --------------------------------
 // DROPOUT is a template parameter: the inlined Philox rounds (fc6 only) otherwise cost every launch their registers.
-template <int M, int VEC, bool DROPOUT, int R>
-__global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restrict__ m, const float4* __restrict__ bias, const float4* __restrict__ addend,
+template <int M, int VEC, bool DROPOUT, int R, bool POOL>
+__global__ __launch_bounds__(256, 3) void wino_output_kernel(const float4* __restrict__ m, const float4* __restrict__ bias, const float4* __restrict__ addend,
                                                           const float4* __restrict__ mask, float mask_scale, int relu, float4* __restrict__ y,
                                                           int N, int H, int W, int C4, float keep, unsigned long long seed, unsigned int stream_id,
-                                                          long long slab, float4* __restrict__ pool, unsigned char* __restrict__ pidx)
+                                                          long long slab, float4* __restrict__ pool, unsigned char* __restrict__ pidx,
+                                                          unsigned* __restrict__ rbits_out, const unsigned* __restrict__ rbits_in)
 {
     constexpr int A = WinoMat<M, R>::A;
+    // ReLU bit masks: a forward launch can record (y > 0) as one bit per element, RW words per (tile, channel vector); the data-
+    // gradient launch that would read y back as its mask (same geometry, same thread mapping) reads those words instead (1/32 of the bytes)
+    constexpr int RW = (M * M * VEC + 31) / 32;
     const int th = (H + M - 1) / M, tw = (W + M - 1) / M;      // partial tiles at the bottom / right edge (F(6x6): 512 = 85 * 6 + 2)
     const TileIdx ti = tile_index(th, tw, C4);
     if (!ti.ok) return;
+    unsigned rb[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) rb[j] = rbits_in ? rbits_in[(ti.t * C4 + ti.c) * RW + j] : 0u;
     const float4* mp = m + ti.t * C4 + ti.c;
     float4 q[M][A];                            // q = A^T M, column by column
 #pragma unroll
@@ -324,8 +331,9 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restri
     }
     const float4 bv = bias ? bias[ti.c] : f4zero();
     const long long off0 = (((long long)ti.n * H + M * ti.ty) * W + M * ti.tx) * C4 + ti.c;
-    float4 pmax[M / 2][M / 2];                 // pool != nullptr: the 2x2/2 max-pool of this tile (tile origins are even), written below
-    unsigned char parg[M / 2][M / 2][VEC];     // pidx != nullptr: which window element is the FIRST maximum (0..3; 4 = max not > 0, i.e. no
+    constexpr int PW = POOL ? M / 2 : 1;       // POOL: the launch also writes the 2x2/2 max-pool (a template flag keeps the other 80 % of the launches lean)
+    float4 pmax[PW][PW];                       // the 2x2/2 max-pool of this tile (tile origins are even), written below
+    unsigned char parg[PW][PW][VEC];           // pidx != nullptr: which window element is the FIRST maximum (0..3; 4 = max not > 0, i.e. no
                                                // gradient through the ReLU) -- the routing rule of maxpool_bwd_kernel, kept for the backward pass
 #pragma unroll
     for (int oy = 0; oy < M; ++oy)
@@ -336,10 +344,16 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restri
             for (int k = 0; k < A; ++k) if (WinoMat<M, R>::at(ox, k) != 0.f) v = f4fma(WinoMat<M, R>::at(ox, k), q[oy][k], v);
             const long long off = off0 + (oy * W + ox) * C4;
             const bool inside = M * ti.ty + oy < H && M * ti.tx + ox < W;              // false only in partial edge tiles
-            if (!inside) { if ((oy & 1) == 0 && (ox & 1) == 0) { pmax[oy / 2][ox / 2] = v; _Pragma("unroll") for (int i = 0; i < VEC; ++i) parg[oy / 2][ox / 2][i] = 0; } continue; }
+            if (!inside) { if (POOL && (oy & 1) == 0 && (ox & 1) == 0) { pmax[POOL ? oy / 2 : 0][POOL ? ox / 2 : 0] = v; _Pragma("unroll") for (int i = 0; i < VEC; ++i) parg[POOL ? oy / 2 : 0][POOL ? ox / 2 : 0][i] = 0; } continue; }
             if (addend) { const float4 ad = addend[off]; _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] += ad.d[i]; }
             if (relu) { _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = fmaxf(v.d[i], 0.f); }
-            if (mask) {
+            if (rbits_in) {
+                _Pragma("unroll") for (int i = 0; i < VEC; ++i) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int bit = (oy * M + ox) * VEC + i;
+                    v.d[i] = ((rb[bit >> 5] >> (bit & 31)) & 1u) ? v.d[i] * mask_scale : 0.f;
+                }
+            } else if (mask) {
                 const float4 k = mask[off];
                 _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = k.d[i] > 0.f ? v.d[i] * mask_scale : 0.f;
             }
@@ -349,25 +363,39 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float4* __restri
                 _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = philox_uniform(e + i, seed, stream_id) < keep ? v.d[i] * ik : 0.f;
             }
             y[off] = v;
-            if ((oy & 1) == 0 && (ox & 1) == 0) {
-                pmax[oy / 2][ox / 2] = v;
-                _Pragma("unroll") for (int i = 0; i < VEC; ++i) parg[oy / 2][ox / 2][i] = 0;
-            } else {
-                _Pragma("unroll") for (int i = 0; i < VEC; ++i)
-                    if (v.d[i] > pmax[oy / 2][ox / 2].d[i]) { pmax[oy / 2][ox / 2].d[i] = v.d[i]; parg[oy / 2][ox / 2][i] = (unsigned char)((oy & 1) * 2 + (ox & 1)); }
+            if (rbits_out) {
+                _Pragma("unroll") for (int i = 0; i < VEC; ++i) {
+                    const int bit = (oy * M + ox) * VEC + i;
+                    if (v.d[i] > 0.f) rb[bit >> 5] |= 1u << (bit & 31);
+                }
+            }
+            if (POOL) {
+                constexpr int dummy = 0; (void)dummy;
+                const int py = POOL ? oy / 2 : 0, px = POOL ? ox / 2 : 0;
+                if ((oy & 1) == 0 && (ox & 1) == 0) {
+                    pmax[py][px] = v;
+                    _Pragma("unroll") for (int i = 0; i < VEC; ++i) parg[py][px][i] = 0;
+                } else {
+                    _Pragma("unroll") for (int i = 0; i < VEC; ++i)
+                        if (v.d[i] > pmax[py][px].d[i]) { pmax[py][px].d[i] = v.d[i]; parg[py][px][i] = (unsigned char)((oy & 1) * 2 + (ox & 1)); }
+                }
             }
         }
-    if (pool) {
+    if (POOL && pool) {
         const int Hp = H / 2, Wp = W / 2;
 #pragma unroll
-        for (int py = 0; py < M / 2; ++py)
+        for (int py = 0; py < PW; ++py)
 #pragma unroll
-            for (int px = 0; px < M / 2; ++px)
+            for (int px = 0; px < PW; ++px)
             if ((M / 2) * ti.ty + py < Hp && (M / 2) * ti.tx + px < Wp) {                // H, W even: a window is inside or outside as a whole
                 const long long po = (((long long)ti.n * Hp + (M / 2) * ti.ty + py) * Wp + (M / 2) * ti.tx + px) * C4 + ti.c;
                 pool[po] = pmax[py][px];
                 if (pidx) { _Pragma("unroll") for (int i = 0; i < VEC; ++i) pidx[po * VEC + i] = pmax[py][px].d[i] > 0.f ? parg[py][px][i] : (unsigned char)4; }
             }
+    }
+    if (rbits_out) {
+#pragma unroll
+        for (int j = 0; j < RW; ++j) rbits_out[(ti.t * C4 + ti.c) * RW + j] = rb[j];
     }
 }
 
@@ -455,6 +483,13 @@ int wino_r(int KS)
     return KS == 3 ? 3 : r7;
 }
 int wino_nsub(int KS) { const int r = wino_r(KS); return (KS + r - 1) / r; }
+// 32-bit words of the ReLU bit mask a [N,H,W,C] output of tile size `tile` needs (launch_wino_output's rbits_out / rbits_in)
+size_t wino_rbits_words(int tile, int N, int H, int W, int C)
+{
+    const int vec = tile == 2 ? 4 : 2;
+    const size_t T = (size_t)N * ((H + tile - 1) / tile) * ((W + tile - 1) / tile);
+    return T * (size_t)(C / vec) * (size_t)((tile * tile * vec + 31) / 32);
+}
 int wino_alpha(int tile, int KS) { return tile + (tile == 6 ? 3 : wino_r(KS)) - 1; }
 // Distance in floats between the slabs of two Winograd positions of a [P][T][C] tensor.  T*C alone is a large power of two
 // for this network (conv1_2: 2^25 floats): the 36 stores of one tile would then hit the same HBM channel and bank at the
@@ -498,16 +533,18 @@ void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, 
 }
 void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
                         int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,
-                        unsigned int stream_id, hipStream_t s, float* pool, unsigned char* pidx, int KS)
+                        unsigned int stream_id, hipStream_t s, float* pool, unsigned char* pidx, int KS, unsigned* rbits_out, const unsigned* rbits_in)
 {
-#define FCN8S_WOUT(M_, V_, D_, R_) hipLaunchKernelGGL((wino_output_kernel<M_, V_, D_, R_>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / V_), dim3(256), 0, s, \
+#define FCN8S_WOUT(M_, V_, D_, R_) if (pool) FCN8S_WOUT2(M_, V_, D_, R_, true); else FCN8S_WOUT2(M_, V_, D_, R_, false)
+#define FCN8S_WOUT2(M_, V_, D_, R_, P_) hipLaunchKernelGGL((wino_output_kernel<M_, V_, D_, R_, P_>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / V_), dim3(256), 0, s, \
         (const VecF<V_>*)m, (const VecF<V_>*)bias, (const VecF<V_>*)addend, (const VecF<V_>*)mask, mask_scale, relu, (VecF<V_>*)y, N, H, W, C / V_, keep, seed, stream_id, \
-        wino_slab((long long)N * ((H + M_ - 1) / M_) * ((W + M_ - 1) / M_), C) / V_, (VecF<V_>*)pool, pidx)
+        wino_slab((long long)N * ((H + M_ - 1) / M_) * ((W + M_ - 1) / M_), C) / V_, (VecF<V_>*)pool, pidx, rbits_out, rbits_in)
     if (tile == 6)                    { if (dropout) FCN8S_WOUT(6, 2, true, 3); else FCN8S_WOUT(6, 2, false, 3); }
     else if (tile == 4 && wino_r(KS) == 4) { if (dropout) FCN8S_WOUT(4, 2, true, 4); else FCN8S_WOUT(4, 2, false, 4); }
     else if (tile == 4)               { if (dropout) FCN8S_WOUT(4, 2, true, 3); else FCN8S_WOUT(4, 2, false, 3); }
     else                              { if (dropout) FCN8S_WOUT(2, 4, true, 3); else FCN8S_WOUT(2, 4, false, 3); }
 #undef FCN8S_WOUT
+#undef FCN8S_WOUT2
 }
 void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s, int KS)
 {
