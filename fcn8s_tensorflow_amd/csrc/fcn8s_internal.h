@@ -46,13 +46,15 @@ void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s);
 // fp32 HWIO kernel; y: fp32.  Needs Cin % 32 == 0, Cout % 128 == 0 (launch returns false otherwise).
 // ---------------------------------------------------------------------------
 struct Bf16ConvArgs {
-    const float* x; const unsigned short* wt; const float* bias; float* y;
+    const float* x; const unsigned short* xh;   // activations: fp32, or (xh != nullptr) already converted by launch_f32_to_bf16
+    const unsigned short* wt; const float* bias; float* y;
     int N, H, W, Cin, Cout, K;
     int relu, dropout; float keep_prob; unsigned long long seed; unsigned int stream_id;
     long long M; int m_fastest;        // filled in by the launcher
 };
 void launch_w_to_bf16_tiles(const float* w, unsigned short* wt, int K, int Cout, hipStream_t s);   // w[K][Cout] -> wt[K/32][Cout][32]
 bool launch_conv_bf16(const Bf16ConvArgs& a, hipStream_t s);
+void launch_f32_to_bf16(const float* x, unsigned short* y, long long n, hipStream_t s);                // n % 8 == 0
 
 // ---------------------------------------------------------------------------
 // Weight-gradient GEMM on the f32 MFMA:

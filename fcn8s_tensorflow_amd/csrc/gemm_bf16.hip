@@ -6,8 +6,8 @@
 // products and sums are fp32, bias / ReLU / dropout are applied in fp32, the output tensor is fp32.
 //
 // Data layout:
-//   activations  fp32 NHWC in HBM, converted to bf16 on the way into LDS ([row][k], 80-byte rows -> conflict-free
-//                ds_read_b128 of one lane's 8 consecutive k);
+//   activations  fp32 NHWC in HBM; converted to a bf16 copy once per layer (f32_to_bf16_kernel) or, without that copy, on the
+//                way into LDS ([row][k], 80-byte rows -> conflict-free ds_read_b128 of one lane's 8 consecutive k);
 //   weights      re-laid out once per forward pass by w_to_bf16_tiles_kernel into bf16 K-tile-major blocks
 //                wt[k / 32][cout][k % 32]: the B tile of a block (128 couts x 32 k) is one contiguous 8 KB run.
 // Block = 256 threads (4 wave64) -> 128 pixels x 128 couts, wave tile 64 x 64 = 2 x 2 MFMA tiles, 8 MFMAs per wave
@@ -50,18 +50,38 @@ void launch_w_to_bf16_tiles(const float* w, unsigned short* wt, int K, int Cout,
     hipLaunchKernelGGL(w_to_bf16_tiles_kernel, grid, dim3(256), 0, s, w, wt, K, Cout);
 }
 
+// activations fp32 -> bf16 (RNE), 8 elements per thread: the GEMM then fetches half the bytes per A tile from L2 (with fp32 A tiles
+// the 128 x 128 kernel was L2-bandwidth-bound: 24 KB per K-tile and block)
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float4* __restrict__ x, bf16x8* __restrict__ y, long long n8)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const float4 a = x[2 * i], b = x[2 * i + 1];
+        bf16x8 o;
+        o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+        o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+        y[i] = o;
+    }
+}
+void launch_f32_to_bf16(const float* x, unsigned short* y, long long n, hipStream_t s)       // n % 8 == 0
+{
+    long long b = (n / 8 + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)b), dim3(256), 0, s, (const float4*)x, (bf16x8*)y, n / 8);
+}
+
 static __device__ __forceinline__ unsigned xcd_run(unsigned p, unsigned total)
 {
     const unsigned q = total >> 3, r = total & 7u, xcd = p & 7u, i = p >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
-template <int BM, int BN>
+// ABF16: p.xh holds the activations already converted to bf16 (launch_f32_to_bf16); else fp32 p.x is converted on the way into LDS
+template <int BM, int BN, bool ABF16>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const Bf16ConvArgs p)
 {
     constexpr int LDK = BFK + 8;                   // bf16 elements per LDS row (80 B)
     constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;
-    constexpr int A_LD = BM * (BFK / 4) / 256;     // float4 global loads of A per thread and K-tile
+    constexpr int AEL = ABF16 ? 8 : 4;             // A elements per 16-byte global load
+    constexpr int A_LD = BM * (BFK / AEL) / 256;   // 16-byte global loads of A per thread and K-tile
     constexpr int B_LD = BN * (BFK / 8) / 256;     // 16-byte global loads of B per thread and K-tile
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (BM + BN) * LDK];
     unsigned short* As = smem;
@@ -82,11 +102,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const Bf16ConvArgs p)
     int a_y[A_LD], a_x[A_LD];
     long long a_img[A_LD];
     bool a_ok[A_LD], a_val[A_LD], a_ldok[A_LD];
-    const float* a_ptr[A_LD];
-    const int a_c4 = (tid % (BFK / 4)) * 4;
+    const void* a_ptr[A_LD];
+    const int a_c4 = (tid % (BFK / AEL)) * AEL;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-        const int row = (tid + i * 256) / (BFK / 4);
+        const int row = (tid + i * 256) / (BFK / AEL);
         const long long m = m0 + row;
         a_ok[i] = m < p.M;
         const long long mm = a_ok[i] ? m : 0;
@@ -101,18 +121,19 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const Bf16ConvArgs p)
             const int iy = a_y[i] + f_ty - pad, ix = a_x[i] + f_tx - pad;
             a_val[i] = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const long long pix = a_val[i] ? a_img[i] + (long long)iy * p.W + ix : 0;
-            a_ptr[i] = p.x + pix * p.Cin + a_c4;
+            a_ptr[i] = ABF16 ? (const void*)(p.xh + pix * p.Cin + a_c4) : (const void*)(p.x + pix * p.Cin + a_c4);
         }
     };
     set_tap();
     const unsigned short* b_ptr = p.wt + (long long)n0 * BFK + tid * 8;     // + kt * Cout * 32 per K-tile, + i * 2048 per slot
 
-    f32x4 ra[A_LD];
+    f32x4 ra[A_LD];                                // ABF16: the same 16 bytes hold 8 bf16
     bf16x8 rb[B_LD];
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + f_ci0);
+            ra[i] = ABF16 ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(a_ptr[i]) + f_ci0)
+                          : *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a_ptr[i]) + f_ci0);
             a_ldok[i] = a_val[i];
         }
         const unsigned short* bp = b_ptr + (long long)kt * p.Cout * BFK;
@@ -128,12 +149,15 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const Bf16ConvArgs p)
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            const int row = (tid + i * 256) / (BFK / 4);
+            const int row = (tid + i * 256) / (BFK / AEL);
             f32x4 v = ra[i];
-            if (!a_ldok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            bf16x4 h;
-            h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-            *reinterpret_cast<bf16x4*>(&As[(buf * BM + row) * LDK + a_c4]) = h;
+            if (!a_ldok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};          // (all-zero bits are +0 in bf16 too)
+            if (ABF16) *reinterpret_cast<f32x4*>(&As[(buf * BM + row) * LDK + a_c4]) = v;
+            else {
+                bf16x4 h;
+                h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+                *reinterpret_cast<bf16x4*>(&As[(buf * BM + row) * LDK + a_c4]) = h;
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
@@ -212,9 +236,10 @@ bool launch_conv_bf16(const Bf16ConvArgs& a0, hipStream_t s)
     const double n_fast = abytes + bbytes * ntm / (R / ntn > 1.0 ? R / ntn : 1.0);
     const double m_fast = bbytes + abytes * ntn / (R / ntm > 1.0 ? R / ntm : 1.0);
     a.m_fastest = m_fast < n_fast;
-    g_last_kernel = "conv_bf16_kernel<128, 128>";
+    g_last_kernel = a.xh ? "conv_bf16_kernel<128, 128, true>" : "conv_bf16_kernel<128, 128, false>";
     dim3 grid((unsigned)(ntm * ntn));
-    hipLaunchKernelGGL((conv_bf16_kernel<128, 128>), grid, dim3(256), 0, s, a);
+    if (a.xh) hipLaunchKernelGGL((conv_bf16_kernel<128, 128, true>), grid, dim3(256), 0, s, a);
+    else      hipLaunchKernelGGL((conv_bf16_kernel<128, 128, false>), grid, dim3(256), 0, s, a);
     return true;
 }
 

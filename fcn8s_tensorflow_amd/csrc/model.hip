@@ -67,6 +67,7 @@ struct fcn8s_model {
     std::set<std::string> rbits_ok;                                       // layers whose forward pass wrote a ReLU bit mask ("rb:<layer>") this step
     std::string fused_v_layer;                                            // layer whose data-gradient input transform already sits in d_wino_v
     unsigned short* d_wbf16 = nullptr;                                    // bf16 K-tile-major copy of the fc6 / fc7 kernel (one at a time)
+    unsigned short* d_abf16 = nullptr; size_t abf16_elems = 0;            // bf16 copy of the layer's input activations
     hipStream_t stream = nullptr;
     int64_t step = 0;
     // workspace for the current (N,H,W)
@@ -598,6 +599,14 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
             { ProfScope ps(m, "weight_relayout", 0, 6.0 * K * cout); launch_w_to_bf16_tiles(Wp(m, wname), m->d_wbf16, K, cout, s); }
             Bf16ConvArgs a{};
             a.x = in; a.wt = m->d_wbf16; a.bias = Wp(m, bname); a.y = out;
+            const size_t nin = (size_t)N * h5 * w5 * cin;
+            if (nin % 8 == 0) {         // activations to bf16 once: the GEMM re-reads each A tile Cout/128 times
+                if (m->abf16_elems < nin) {
+                    if (m->d_abf16) { hipStreamSynchronize(s); hipFree(m->d_abf16); m->d_abf16 = nullptr; m->abf16_elems = 0; }
+                    if (hipMalloc((void**)&m->d_abf16, nin * sizeof(unsigned short)) == hipSuccess) m->abf16_elems = nin; else (void)hipGetLastError();
+                }
+                if (m->d_abf16) { ProfScope ps(m, "weight_relayout", 0, 6.0 * nin); launch_f32_to_bf16(in, m->d_abf16, (long long)nin, s); a.xh = m->d_abf16; }
+            }
             a.N = N; a.H = h5; a.W = w5; a.Cin = cin; a.Cout = cout; a.K = k;
             a.relu = 1; a.dropout = drop; a.keep_prob = keep_prob; a.seed = m->seed; a.stream_id = stream_id;
             const double M = (double)N * h5 * w5;
@@ -913,6 +922,7 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->d_wino_u) hipFree(m->d_wino_u);
     for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
     if (m->d_wbf16) hipFree(m->d_wbf16);
+    if (m->d_abf16) hipFree(m->d_abf16);
     for (int i = 0; i < 3; ++i) if (m->d_tph[i]) hipFree(m->d_tph[i]);
     if (m->d_loss) hipFree(m->d_loss);
     if (m->d_conf) hipFree(m->d_conf);
