@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The suites load libfcn8s_hip.so / libfcn8s_oracle.so from the tree; build them if a fresh checkout has not yet
+    # (hipcc cross-compiles for gfx950 without a GPU; a no-op when the libraries exist).
+    lib = os.path.join(ROOT, "fcn8s_tensorflow_amd", "libfcn8s_hip.so")
+    orc = os.path.join(ROOT, "oracle", "libfcn8s_oracle.so")
+    if not (os.path.exists(lib) and os.path.exists(orc)):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "fcn8s_tensorflow_amd", "csrc")], check=False, capture_output=True)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=False, capture_output=True)
 
 
 def _has_gpu():
