@@ -43,10 +43,10 @@ def pmc_traffic(kernel):
     return None
 
 
-def cpu_baseline(h, w, seconds_budget=30.0):
+def cpu_baseline(h, w, seconds_budget=30.0, optimizer="sgd"):
     """CPU restatement of the reference graph (oracle, kind 'port'), timed on this
-    host's cores on a bounded sample: bs1 training steps (fwd + bwd + TF-Adam) at
-    the bench resolution.  TF1 itself is not installable here."""
+    host's cores on a bounded sample: bs1 training steps (fwd + bwd + the same optimizer
+    as the GPU run) at the bench resolution.  TF1 itself is not installable here."""
     import torch
     from oracle import fcn8s_oracle as orc
     cores = os.cpu_count() or 1
@@ -61,13 +61,17 @@ def cpu_baseline(h, w, seconds_budget=30.0):
         _, g, _ = orc.loss_and_grads(P, img, onehot)
         t += 1
         for k in P:
-            P[k], m[k], v_[k] = orc.tf_adam_step(P[k], g[k], m[k], v_[k], t, 1e-4)
+            if optimizer == "adam":
+                P[k], m[k], v_[k] = orc.tf_adam_step(P[k], g[k], m[k], v_[k], t, 1e-4)
+            else:
+                P[k], m[k] = orc.sgd_momentum_step(P[k], g[k], m[k], 1e-4)
         n += 1
         el = time.perf_counter() - t0
         if el > seconds_budget * 0.5 or n >= 3:
             break
     return {"value": round(n / el, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d training step(s) (fwd+bwd+TF-Adam) of 1 image %dx%d on torch-CPU fp32, %.1f s" % (n, w, h, el)}
+            "sample": "%d training step(s) (fwd+bwd+%s) of 1 image %dx%d on torch-CPU fp32, %.1f s"
+                      % (n, "TF-Adam" if optimizer == "adam" else "SGD+momentum", w, h, el)}
 
 
 def main():
@@ -219,7 +223,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(H, W)
+                out["cpu_baseline"] = cpu_baseline(H, W, optimizer=args.optimizer)
             except Exception as ex:  # the oracle is only a reported baseline
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out), flush=True)
