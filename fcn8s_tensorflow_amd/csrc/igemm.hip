@@ -371,6 +371,199 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
     }
 }
 
+// ===========================================================================
+// plain GEMM rows (the Winograd positions, 1x1 convs): LDS-DMA main loop
+// ===========================================================================
+// Y[z] (M x Cout) = epilogue( X[z] (M x K, row stride ldx) * W[z] (K x Cout) ), the MODE 3 / 1x1 cases of igemm_fwd_kernel with a
+// different way of filling LDS: global_load_lds_dwordx4 moves 64 lanes x 16 B from global memory straight into LDS (no VGPR
+// staging, no ds_write, no vmcnt wait in front of a store pass), S = 3 stages, and one K-tile stays in flight ACROSS the K-tile
+// barrier (counted vmcnt + raw s_barrier).  Measured on the bare batched GEMM (tools/gemm_lab.hip, random data, MI355X):
+// 125-129 / 132-134 / 138-141 TFLOP/s at K = 256 / 512 / 2048 against 116-122 / 121-125 / 126-129 for the register-staged loop.
+//   * the LDS destination of one instruction is M0 + lane * 16 B (wave-uniform base, lane-linear): the A image therefore has
+//     unpadded 64-byte rows, and ds_read_b128 stays conflict-free through an XOR swizzle of the 16-byte chunk index with
+//     (row / 4) & 3 -- applied to the per-lane SOURCE address when loading and to the LDS address when reading (guide 5.4 rule 21);
+//   * inline asm, because hipcc's waitcnt pass makes every ds_read wait vmcnt(0) for any LDS-DMA it knows about, which would
+//     drain the pipeline once per K-tile; the asm loads are invisible to it and the counted waits are written by hand;
+//   * saddr form (block-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset): no 64-bit VALU address math in the loop.
+// Rows >= M read row M - 1 (their products land in accumulator rows that are never stored).
+static __device__ __forceinline__ void glds16(const float* sbase, unsigned voff, unsigned lds_byte_off)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte_off) : "memory", "m0");
+}
+template <int N> static __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WM, int WN, int S, bool EPI>
+__global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void gemm_glds_kernel(const IgemmArgs p)
+{
+    constexpr int BK = 16, CH = 4, RPI = 16;             // 16-byte chunks per A row; A rows per wave-instruction (1 KiB)
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_PW = BM / RPI / 4, B_PW = BK * BN / 256 / 4;   // LDS-DMA instructions per wave and K-tile
+    static_assert(WM * WN == 4 && A_PW >= 1 && B_PW >= 1, "tile / wave split");
+    constexpr int L = A_PW + B_PW;
+    constexpr int STAGE = BM * BK + BK * BN;             // floats per stage
+    __shared__ __attribute__((aligned(16))) float smem[S * STAGE];
+    static_assert(S * STAGE >= 4 * 32 * 36, "epilogue patches");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int pz = blockIdx.z;
+    const float* __restrict__ Wp = p.w + (long long)pz * p.w_phase_stride;
+    const float* __restrict__ X = p.batched ? p.x + (long long)pz * p.x_batch_stride : p.x;
+    float* __restrict__ Y = p.batched ? p.y + (long long)pz * p.y_batch_stride : p.y;
+    const unsigned ntn = (unsigned)(p.Cout / BN);
+    const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const unsigned ntm = gridDim.x / ntn;
+    const long long m0 = (long long)(p.m_fastest ? lid % ntm : lid / ntn) * BM;
+    const int n0 = (int)(p.m_fastest ? lid / ntm : lid % ntn) * BN;
+
+    unsigned a_voff[A_PW], b_voff[B_PW];
+#pragma unroll
+    for (int i = 0; i < A_PW; ++i) {
+        const int row = (wave * A_PW + i) * RPI + lane / CH, pc = lane % CH;
+        const int c = pc ^ ((row >> 2) & 3);             // logical chunk held by physical chunk pc of this row
+        long long m = m0 + row; if (m >= p.M) m = p.M - 1;
+        a_voff[i] = (unsigned)((m - m0) * p.ldx + c * 4) * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PW; ++i) {
+        const int f = (wave * B_PW + i) * 64 + lane;
+        const int k = f / (BN / 4), j = (f % (BN / 4)) * 4;
+        b_voff[i] = (unsigned)(k * p.Cout + j) * 4u;
+    }
+    // split-K (gridDim.y > 1, linear epilogue only): this block reduces K-tiles [kt0, kt0 + nkt)
+    const int nkt_all = p.Ktot / BK;
+    const int kt0 = (int)((long long)nkt_all * blockIdx.y / gridDim.y);
+    const int nkt = (int)((long long)nkt_all * (blockIdx.y + 1) / gridDim.y) - kt0;
+    const float* a_base = X + m0 * p.ldx + (long long)kt0 * BK;
+    const float* b_base = Wp + n0 + (long long)kt0 * BK * p.Cout;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    auto issue = [&](int kt, int stage) {
+        const float* ga = a_base + (long long)kt * BK;
+        const float* gb = b_base + (long long)kt * BK * p.Cout;
+        const unsigned la = lds0 + (unsigned)(stage * STAGE + wave * A_PW * 256) * 4u;
+        const unsigned lb = lds0 + (unsigned)(stage * STAGE + BM * BK + wave * B_PW * 256) * 4u;
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) glds16(ga, a_voff[i], la + i * 1024);
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) glds16(gb, b_voff[i], lb + i * 1024);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int a_off[TM], a_sw[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int row = wm * TM * 32 + tm * 32 + (lane & 31);
+        a_off[tm] = row * BK;
+        a_sw[tm] = (row >> 2) & 3;
+    }
+    const int b_off = ((lane >> 5) * 4) * BN + wn * TN * 32 + (lane & 31);
+    auto compute = [&](int stage) {
+        const float* sa = smem + stage * STAGE;
+        const float* sb = sa + BM * BK;
+#pragma unroll
+        for (int kk2 = 0; kk2 < BK / 8; ++kk2) {
+            float4 af[TM];
+            float bf[TN][4];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                af[tm] = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((kk2 * 2 + (lane >> 5)) ^ a_sw[tm]) * 4));
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[tn][j] = sb[b_off + (kk2 * 8 + j) * BN + tn * 32];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const float av = j == 0 ? af[tm].x : j == 1 ? af[tm].y : j == 2 ? af[tm].z : af[tm].w;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[tn][j], acc[tm][tn], 0, 0, 0);
+                }
+        }
+    };
+
+    // Iteration kt: wait until this wave's pieces of tile kt have landed (the S - 2 newer tiles may stay in flight), barrier (every
+    // wave's pieces have landed AND every wave is done reading the stage of tile kt - 1), refill that stage with tile kt + S - 1, compute.
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t)
+        if (t < nkt) issue(t, t);
+    int stage = 0, pre = S - 1;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + S - 2 < nkt) wait_vmcnt<(S - 2) * L>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + S - 1 < nkt) issue(kt + S - 1, pre);
+        compute(stage);
+        stage = stage + 1 == S ? 0 : stage + 1;
+        pre = pre + 1 == S ? 0 : pre + 1;
+    }
+
+    if (gridDim.y > 1) {                         // split-K partials (Y zeroed by the launcher)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < p.M) unsafeAtomicAdd(Y + m * p.ldy + n0 + wn * TN * 32 + tn * 32 + (lane & 31), acc[tm][tn][r]);
+                }
+        return;
+    }
+    if (!EPI) {
+        // each wave transposes its 32x32 accumulator tiles through a private LDS patch: 16-byte global stores
+        __builtin_amdgcn_s_barrier();            // every wave is done reading the last stage
+        constexpr int LDT = 36;
+        float* patch = smem + wave * 32 * LDT;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + (lane & 31)] = acc[tm][tn][r];
+                __builtin_amdgcn_wave_barrier();
+                const long long mrow = m0 + wm * TM * 32 + tm * 32;
+                float* yb = Y + n0 + wn * TN * 32 + tn * 32 + (lane & 7) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = j * 8 + (lane >> 3);
+                    const float4 v = *reinterpret_cast<const float4*>(&patch[row * LDT + (lane & 7) * 4]);
+                    if (mrow + row < p.M) *reinterpret_cast<float4*>(yb + (mrow + row) * p.ldy) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        return;
+    }
+    // fused 1x1-conv epilogue (row m = output pixel m)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                const long long off = m * p.ldy;
+                float v = acc[tm][tn][r] * p.alpha + bv;
+                if (p.addend) v += p.addend[off + col];
+                if (p.relu) v = v > 0.f ? v : 0.f;
+                if (p.mask) v = p.mask[off + col] > 0.f ? v * p.mask_scale : 0.f;
+                if (p.dropout) v = dropout_apply(v, (unsigned long long)(off + col), p.seed, p.stream_id, p.keep_prob);
+                Y[off + col] = v;
+            }
+    }
+}
+
+static bool glds_enabled() { static const int on = [] { const char* e = getenv("FCN8S_GEMM_LDSDMA"); return e ? atoi(e) : 1; }(); return on != 0; }
+
 template <int BM, int BN, int WM, int WN, int BKF = 16>
 static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
 {
@@ -401,6 +594,20 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
             grid.y = ks;
             const size_t nfl = a.batched ? (size_t)(phases - 1) * a.y_batch_stride + (size_t)a.M * a.Cout : (size_t)a.M * a.Cout;
             hipMemsetAsync(a.y, 0, nfl * sizeof(float), s);        // every slab of a batched launch
+        }
+    }
+    // plain-GEMM rows with K % 16 == 0 and whole N tiles: the LDS-DMA main loop (gemm_glds_kernel)
+    const bool rows1x1 = fast && a.Ktot == a.Cin && a.in_scale == 1 && a.tap_off == 0 && a.out_scale == 1 && a.out_offy == 0 && a.out_offx == 0 &&
+                         (a.batched || (phases == 1 && a.Hi == a.Ma && a.Wi == a.Mb && a.Ho == a.Ma && a.Wo == a.Mb)) && a.ldy >= a.Cout;
+    if constexpr (BN >= 64 && BKF == 16) {
+        if (glds_enabled() && rows1x1 && (mode == 3 || grid.y == 1) && (long long)(BM - 1) * a.ldx < (1LL << 29) && (long long)16 * a.Cout < (1LL << 29)) {
+            static const std::string gt[2] = {"gemm_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", plain>",
+                                              "gemm_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", epilogue>"};
+            const bool epi = mode != 3;
+            g_last_kernel = gt[epi ? 1 : 0].c_str();
+            if (epi) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, 3, true>), grid, dim3(256), 0, s, a);
+            else     hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(256), 0, s, a);
+            return;
         }
     }
     if (mode == 3)      hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 3, BKF>), grid, dim3(256), 0, s, a);
@@ -985,6 +1192,137 @@ bool launch_tconv_wgrad(const float* X, const float* dY, float* dW, int N, int H
     return true;
 }
 
+// ===========================================================================
+// weight gradient over plain rows (Winograd positions, 1x1 convs): LDS-DMA main loop
+// ===========================================================================
+// C[z][i][j] (+)= alpha * sum_{rows of this block's chunk} A[z][row][i0 + i] * B[z][row][j0 + j].  Both operands are [row][channel],
+// so both LDS images ([k][column]) are lane-linear as they come (no swizzle); same S = 3 stage pipeline as gemm_glds_kernel.  A
+// chunk's last, partial K-tile (rows % 16, only when the row count is not a multiple of 16) goes through registers with zero fill.
+// 1-D grid, XCD-aware: the (ci, co) tiles of one (position, row chunk) share their A / B row panels and are neighbours in the id
+// order, i.e. run behind the same L2 (the 3-D grid of wgrad_kernel deals them round-robin over all eight).
+template <int BM, int BN, int WM, int WN, int S>
+__global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void wgrad_glds_kernel(const WgradArgs p, const int chunk, const int nsplit)
+{
+    constexpr int BK = 16;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_PW = BK * BM / 256 / 4, B_PW = BK * BN / 256 / 4;
+    static_assert(WM * WN == 4 && A_PW >= 1 && B_PW >= 1, "tile / wave split");
+    constexpr int L = A_PW + B_PW;
+    constexpr int STAGE = BK * (BM + BN);
+    __shared__ __attribute__((aligned(16))) float smem[S * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const unsigned ntj = (unsigned)(p.Bdim / BN), ntiles = (unsigned)(p.Adim / BM) * ntj;
+    const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const unsigned tile = lid % ntiles, rest = lid / ntiles;
+    const unsigned ys = rest % (unsigned)nsplit, z = rest / (unsigned)nsplit;
+    const int i0 = (int)(tile / ntj) * BM, j0 = (int)(tile % ntj) * BN;
+    const float* __restrict__ Ap = p.batched ? p.A + (long long)z * p.a_batch_stride : p.A;
+    const float* __restrict__ Bp = p.batched ? p.B + (long long)z * p.b_batch_stride : p.B;
+    const long long pbeg = (long long)ys * chunk;
+    const long long pend = (pbeg + chunk < p.P) ? pbeg + chunk : p.P;
+    const int nkt = (int)((pend - pbeg) / BK), rem = (int)((pend - pbeg) % BK);
+
+    unsigned a_voff[A_PW], b_voff[B_PW];
+#pragma unroll
+    for (int i = 0; i < A_PW; ++i) {
+        const int f = (wave * A_PW + i) * 64 + lane;
+        a_voff[i] = (unsigned)((f / (BM / 4)) * p.lda + (f % (BM / 4)) * 4) * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PW; ++i) {
+        const int f = (wave * B_PW + i) * 64 + lane;
+        b_voff[i] = (unsigned)((f / (BN / 4)) * p.ldb + (f % (BN / 4)) * 4) * 4u;
+    }
+    const float* a_base = Ap + pbeg * p.lda + i0;
+    const float* b_base = Bp + pbeg * p.ldb + j0;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    auto issue = [&](int kt, int stage) {
+        const float* ga = a_base + (long long)kt * BK * p.lda;
+        const float* gb = b_base + (long long)kt * BK * p.ldb;
+        const unsigned la = lds0 + (unsigned)(stage * STAGE + wave * A_PW * 256) * 4u;
+        const unsigned lb = lds0 + (unsigned)(stage * STAGE + BK * BM + wave * B_PW * 256) * 4u;
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) glds16(ga, a_voff[i], la + i * 1024);
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) glds16(gb, b_voff[i], lb + i * 1024);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int a_off = (lane >> 5) * BM + wm * TM * 32 + (lane & 31);
+    const int b_off = (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
+    auto compute = [&](int stage) {
+        const float* sa = smem + stage * STAGE + a_off;
+        const float* sb = smem + stage * STAGE + BK * BM + b_off;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) af[tm] = sa[kk * 2 * BM + tm * 32];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bf[tn] = sb[kk * 2 * BN + tn * 32];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
+        }
+    };
+
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t)
+        if (t < nkt) issue(t, t);
+    int stage = 0, pre = S - 1;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + S - 2 < nkt) wait_vmcnt<(S - 2) * L>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + S - 1 < nkt) issue(kt + S - 1, pre);
+        compute(stage);
+        stage = stage + 1 == S ? 0 : stage + 1;
+        pre = pre + 1 == S ? 0 : pre + 1;
+    }
+    if (rem > 0) {                               // partial last K-tile: through registers, rows >= rem are zeros
+        __syncthreads();
+        const float* ga = a_base + (long long)nkt * BK * p.lda;
+        const float* gb = b_base + (long long)nkt * BK * p.ldb;
+#pragma unroll
+        for (int i = 0; i < BK * BM / 4 / 256; ++i) {
+            const int f = tid + i * 256, k = f / (BM / 4), c = (f % (BM / 4)) * 4;
+            *reinterpret_cast<float4*>(&smem[k * BM + c]) = k < rem ? ldg4(ga + (long long)k * p.lda + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < BK * BN / 4 / 256; ++i) {
+            const int f = tid + i * 256, k = f / (BN / 4), c = (f % (BN / 4)) * 4;
+            *reinterpret_cast<float4*>(&smem[BK * BM + k * BN + c]) = k < rem ? ldg4(gb + (long long)k * p.ldb + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        compute(0);
+    }
+
+    float* Ct = p.C + (long long)z * p.Areal * p.ldc;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = j0 + wn * TN * 32 + tn * 32 + (lane & 31);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < p.Areal) {
+                    if (p.plain_store) Ct[(long long)row * p.ldc + col] = acc[tm][tn][r] * p.alpha;     // sole writer of this tile
+                    else unsafeAtomicAdd(Ct + (long long)row * p.ldc + col, acc[tm][tn][r] * p.alpha);
+                }
+            }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int WK>
 static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
 {
@@ -1012,6 +1350,15 @@ static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
     }
     static const std::string tag = "wgrad_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ">";
     g_last_kernel = tag.c_str();
+    if constexpr (WK == 1 && BM >= 64 && BN >= 64) {
+        const bool rows = a.batched || (a.ntaps == 1 && a.KW == 1 && a.a_scale == 1 && a.tap_off == 0 && a.Ha == a.Pa && a.Wa == a.Pb);
+        if (glds_enabled() && full_tiles && a.Adim % BM == 0 && a.Bdim % BN == 0 && rows && !b.colsum && a.lda <= (1 << 20) && a.ldb <= (1 << 20)) {
+            static const std::string gtag = "wgrad_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ">";
+            g_last_kernel = gtag.c_str();
+            hipLaunchKernelGGL((wgrad_glds_kernel<BM, BN, WM, WN, 3>), dim3((unsigned)(nti * ntj) * (unsigned)splits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)chunk, splits);
+            return;
+        }
+    }
     if (fast) hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK, true, fused_colsum>), grid, dim3(256), 0, s, b, (int)chunk);
     else      hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK, false, fused_colsum>), grid, dim3(256), 0, s, b, (int)chunk);
 }

@@ -264,8 +264,9 @@ class Engine:
         self.precision = precision
 
     def train_step(self, images, labels, learning_rate, keep_prob=0.5, l2_rate=0.0,
-                   optimizer=L.OPT_TF_ADAM, fetch_loss=True):
-        """sess.run([train_op, total_loss, global_step]) (fcn8s_tensorflow.py:554-572)."""
+                   optimizer=L.OPT_TF_ADAM, fetch_loss=True, reduce=True):
+        """sess.run([train_op, total_loss, global_step]) (fcn8s_tensorflow.py:554-572).
+        `reduce=False` skips the gradient exchange of a data-parallel run (measurement only: bench.py's local-only leg)."""
         self._sync_stream()
         ka, pi, dt, pl, where, nhw = self._inputs(images, labels)
         N, H, W = (int(x) for x in nhw)
@@ -281,9 +282,10 @@ class Engine:
         red = BucketReducer(self.flat_grads, self.buckets, self.pg)
         for b in range(L.NUM_BUCKETS):
             L.check(L.lib.fcn8s_backward_bucket(self.h, b), self.h)
-            red.reduce_bucket(b)          # RCCL moves bucket b while the next bucket's backward runs
+            if reduce:
+                red.reduce_bucket(b)      # RCCL moves bucket b while the next bucket's backward runs
         red.wait()
-        L.check(L.lib.fcn8s_apply_update(self.h, optimizer, float(learning_rate), red.grad_scale()), self.h)
+        L.check(L.lib.fcn8s_apply_update(self.h, optimizer, float(learning_rate), red.grad_scale() if reduce else 1.0), self.h)
         if fetch_loss:
             L.check(L.lib.fcn8s_read_loss(self.h, C.byref(loss)), self.h)
         return (float(loss.value) if fetch_loss else None), self.global_step

@@ -1,0 +1,376 @@
+// Main-loop laboratory for the batched fp32 MFMA GEMM behind the Winograd positions (igemm_fwd_kernel MODE 3):
+//   C[p] (T x N) = A[p] (T x K, k contiguous) * B[p] (K x N, n contiguous),  p = 0 .. P-1.
+// Every variant is checked against a float64 reference on a small problem before it is timed on random data.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_lab.hip -o gemm_lab && ./gemm_lab
+// Variants:
+//   REG  : global -> VGPR -> LDS (padded A rows), 2 LDS buffers, loads issued mid-tile, one __syncthreads per K-tile (round-1 kernel)
+//   GLDS : global_load_lds_dwordx4 straight into an XOR-swizzled LDS image (no VGPR staging, no ds_write), S stages, counted vmcnt,
+//          raw s_barrier: S-2 K-tiles stay in flight across the barrier
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include <algorithm>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+struct Args { const float* A; const float* B; float* C; long long T; int K, N; long long sa, sb, sc; int noload; };
+
+static __device__ __forceinline__ unsigned xcd_swizzle(unsigned p, unsigned total)
+{
+    const unsigned q = total >> 3, r = total & 7u, xcd = p & 7u, i = p >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+// one LDS-DMA piece: 64 lanes x 16 B from (sbase + voff) to LDS byte offset m0 + lane * 16.  Inline asm so that hipcc's waitcnt
+// pass does not see an LDS write: it would otherwise wait vmcnt(0) before the next ds_read and drain the pipeline every K-tile.
+static __device__ __forceinline__ void glds16(const float* sbase, unsigned voff, unsigned lds_byte_off)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte_off) : "memory", "m0");
+}
+template <int N> static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// GLDS kernel
+// ------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int BK, int S, int OCC>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
+{
+    constexpr int NW = WM * WN, NT = NW * 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int CH = BK / 4;                       // 16-byte chunks per A row
+    constexpr int RPI = 64 / CH;                     // A rows per wave-instruction (1 KiB)
+    constexpr int A_I = BM / RPI;                    // A wave-instructions per tile
+    constexpr int B_I = BK * BN / 256;               // B wave-instructions per tile
+    constexpr int A_PW = A_I / NW, B_PW = B_I / NW;  // per wave
+    static_assert(A_I % NW == 0 && B_I % NW == 0, "tile / wave split");
+    constexpr int L = A_PW + B_PW;                   // glds instructions per wave per K-tile
+    constexpr int STAGE = BM * BK + BK * BN;         // floats per stage
+    __shared__ __attribute__((aligned(16))) float smem[S * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int pz = blockIdx.z;
+    const float* __restrict__ A = p.A + pz * p.sa;
+    const float* __restrict__ B = p.B + pz * p.sb;
+    float* __restrict__ C = p.C + pz * p.sc;
+    const unsigned ntn = (unsigned)(p.N / BN);
+    const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const long long m0 = (long long)(lid / ntn) * BM;
+    const int n0 = (int)(lid % ntn) * BN;
+
+    // per-lane 32-bit byte offsets from block-uniform 64-bit bases (global_load_lds saddr form: no 64-bit VALU address math in
+    // the loop); LDS destinations are wave-uniform byte offsets (M0) + lane * 16 B
+    unsigned a_voff[A_PW], b_voff[B_PW];
+#pragma unroll
+    for (int i = 0; i < A_PW; ++i) {
+        const int inst = wave * A_PW + i;
+        const int row = inst * RPI + lane / CH, pc = lane % CH;
+        const int c = pc ^ ((row / (16 / CH)) & (CH - 1));      // logical chunk stored at physical chunk pc of this row
+        long long m = m0 + row; if (m >= p.T) m = p.T - 1;
+        a_voff[i] = (unsigned)((m - m0) * p.K + c * 4) * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PW; ++i) {
+        const int f = (wave * B_PW + i) * 64 + lane;
+        const int k = f / (BN / 4), j = (f % (BN / 4)) * 4;
+        b_voff[i] = (unsigned)(k * p.N + j) * 4u;
+    }
+    const float* a_base = A + m0 * p.K;              // block-uniform, advanced by BK floats per K-tile
+    const float* b_base = B + n0;                    // ... by BK rows
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    auto issue = [&](int kt, int stage) {
+        const float* ga = a_base + (long long)kt * BK;
+        const float* gb = b_base + (long long)kt * BK * p.N;
+        const unsigned la = lds0 + (unsigned)(stage * STAGE + wave * A_PW * 256) * 4u;
+        const unsigned lb = lds0 + (unsigned)(stage * STAGE + BM * BK + wave * B_PW * 256) * 4u;
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) glds16(ga, a_voff[i], la + i * 1024);
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) glds16(gb, b_voff[i], lb + i * 1024);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addressing: A row = wm*TM*32 + tm*32 + (lane & 31); logical chunk = kk2*2 + (lane >> 5)
+    int a_off[TM];
+    int a_sw[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int row = wm * TM * 32 + tm * 32 + (lane & 31);
+        a_off[tm] = row * BK;
+        a_sw[tm] = (row / (16 / CH)) & (CH - 1);
+    }
+    const int b_off = ((lane >> 5) * 4) * BN + wn * TN * 32 + (lane & 31);
+
+    auto compute = [&](int stage) {
+        const float* sa = smem + stage * STAGE;
+        const float* sb = sa + BM * BK;
+#pragma unroll
+        for (int kk2 = 0; kk2 < BK / 8; ++kk2) {
+            float4 af[TM];
+            float bf[TN][4];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                af[tm] = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((kk2 * 2 + (lane >> 5)) ^ a_sw[tm]) * 4));
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[tn][j] = sb[b_off + (kk2 * 8 + j) * BN + tn * 32];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const float av = j == 0 ? af[tm].x : j == 1 ? af[tm].y : j == 2 ? af[tm].z : af[tm].w;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[tn][j], acc[tm][tn], 0, 0, 0);
+                }
+        }
+    };
+
+    const int nkt = p.K / BK;
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t)
+        if (t < nkt) issue(t, t);
+    int stage = 0, pre = S - 1;               // stage of tile kt; stage tile kt+S-1 goes to
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + S - 2 < nkt) wait_vm<(S - 2) * L>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + S - 1 < nkt && !p.noload) issue(kt + S - 1, pre);
+        compute(stage);
+        stage = stage + 1 == S ? 0 : stage + 1;
+        pre = pre + 1 == S ? 0 : pre + 1;
+    }
+    __builtin_amdgcn_s_barrier();
+
+    // epilogue: 32x32 accumulator tiles transposed through a wave-private LDS patch, 16-byte stores
+    constexpr int LDT = 36;
+    float* patch = smem + wave * 32 * LDT;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + (lane & 31)] = acc[tm][tn][r];
+            __builtin_amdgcn_wave_barrier();
+            const long long mrow = m0 + wm * TM * 32 + tm * 32;
+            float* yb = C + n0 + wn * TN * 32 + tn * 32 + (lane & 7) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = j * 8 + (lane >> 3);
+                const float4 v = *reinterpret_cast<const float4*>(&patch[row * LDT + (lane & 7) * 4]);
+                if (mrow + row < p.T) *reinterpret_cast<float4*>(yb + (mrow + row) * p.N) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// REG kernel (round-1 structure)
+// ------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int OCC>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_reg(const Args p)
+{
+    constexpr int BK = 16, NT = WM * WN * 64, LDA = BK + 4, LDB = BN, F4R = BK / 4;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_LD = BM * F4R / NT, B_LD = BK * BN / 4 / NT;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDA + 2 * BK * LDB];
+    float* As = smem; float* Bs = smem + 2 * BM * LDA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int pz = blockIdx.z;
+    const float* __restrict__ A = p.A + pz * p.sa;
+    const float* __restrict__ B = p.B + pz * p.sb;
+    float* __restrict__ C = p.C + pz * p.sc;
+    const unsigned ntn = (unsigned)(p.N / BN);
+    const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const long long m0 = (long long)(lid / ntn) * BM;
+    const int n0 = (int)(lid % ntn) * BN;
+    const float* ap[A_LD]; const float* bp[B_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) { const int f = tid + i * NT; long long m = m0 + f / F4R; if (m >= p.T) m = p.T - 1; ap[i] = A + m * p.K + (f % F4R) * 4; }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) { const int f = tid + i * NT; bp[i] = B + (long long)(f / (BN / 4)) * p.N + n0 + (f % (BN / 4)) * 4; }
+    float4 ra[A_LD], rb[B_LD];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) ra[i] = *(const float4*)(ap[i] + kt * BK);
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) rb[i] = *(const float4*)(bp[i] + (long long)kt * BK * p.N);
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) { const int f = tid + i * NT; *(float4*)&As[buf * BM * LDA + (f / F4R) * LDA + (f % F4R) * 4] = ra[i]; }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) { const int f = tid + i * NT; *(float4*)&Bs[buf * BK * LDB + (f / (BN / 4)) * LDB + (f % (BN / 4)) * 4] = rb[i]; }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nkt = p.K / BK;
+    gload(0); sstore(0); __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        const float* As_ = As + buf * BM * LDA + (wm * TM * 32 + (lane & 31)) * LDA + (lane >> 5) * 4;
+        const float* Bs_ = Bs + buf * BK * LDB + ((lane >> 5) * 4) * LDB + wn * TN * 32 + (lane & 31);
+#pragma unroll
+        for (int kk2 = 0; kk2 < 2; ++kk2) {
+            if (kk2 == 1 && kt + 1 < nkt) gload(kt + 1);
+            float4 af[TM]; float bf[TN][4];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) af[tm] = *(const float4*)(As_ + tm * 32 * LDA + kk2 * 8);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[tn][j] = Bs_[(kk2 * 8 + j) * LDB + tn * 32];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const float av = j == 0 ? af[tm].x : j == 1 ? af[tm].y : j == 2 ? af[tm].z : af[tm].w;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[tn][j], acc[tm][tn], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nkt) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    constexpr int LDT = 36;
+    float* patch = smem + wave * 32 * LDT;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + (lane & 31)] = acc[tm][tn][r];
+            __builtin_amdgcn_wave_barrier();
+            const long long mrow = m0 + wm * TM * 32 + tm * 32;
+            float* yb = C + n0 + wn * TN * 32 + tn * 32 + (lane & 7) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = j * 8 + (lane >> 3);
+                const float4 v = *reinterpret_cast<const float4*>(&patch[row * LDT + (lane & 7) * 4]);
+                if (mrow + row < p.T) *reinterpret_cast<float4*>(yb + (mrow + row) * p.N) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
+__global__ void fill(float* p, size_t n, unsigned seed)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        p[i] = ((h & 0xffffff) / 16777216.0f - 0.5f) * 2.f;
+    }
+}
+__global__ void ref_gemm(const Args p, double* out, int P)          // one thread per output element (small problems only)
+{
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long per = p.T * p.N;
+    if (i >= per * P) return;
+    const int z = (int)(i / per); const long long r = (i - z * per) / p.N; const int c = (int)(i % p.N);
+    double s = 0;
+    for (int k = 0; k < p.K; ++k) s += (double)p.A[z * p.sa + r * p.K + k] * (double)p.B[z * p.sb + (long long)k * p.N + c];
+    out[i] = s;
+}
+
+struct Shape { const char* name; long long T; int K, N, P; };
+static float *dA, *dB, *dC; static double* dRef; static int g_noload = 0;
+static size_t capA, capB, capC;
+
+template <typename F> static void run(const char* tag, F launch, int BM, int BN, const Shape& s, bool check)
+{
+    Args a{dA, dB, dC, s.T, s.K, s.N, s.T * s.K + 1088, (long long)s.K * s.N, s.T * s.N + 1088, check ? 0 : g_noload};
+    dim3 grid((unsigned)(((s.T + BM - 1) / BM) * (s.N / BN)), 1, (unsigned)s.P);
+    if (check) {
+        hipMemset(dC, 0xff, (size_t)s.P * a.sc * 4);
+        launch(grid, a);
+        hipLaunchKernelGGL(ref_gemm, dim3((unsigned)((s.T * s.N * s.P + 255) / 256)), dim3(256), 0, 0, a, dRef, s.P);
+        std::vector<float> hc((size_t)s.P * a.sc); std::vector<double> hr((size_t)s.T * s.N * s.P);
+        hipMemcpy(hc.data(), dC, hc.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(hr.data(), dRef, hr.size() * 8, hipMemcpyDeviceToHost);
+        double worst = 0; long long bad = 0;
+        for (int z = 0; z < s.P; ++z) for (long long r = 0; r < s.T; ++r) for (int c = 0; c < s.N; ++c) {
+            const double d = std::fabs((double)hc[z * a.sc + r * s.N + c] - hr[(z * s.T + r) * s.N + c]);
+            if (!(d < 1e-3)) ++bad; if (d > worst) worst = d;
+        }
+        printf("  check %-28s T=%lld K=%d N=%d P=%d: max err %.2e, bad %lld %s\n", tag, s.T, s.K, s.N, s.P, worst, bad, bad ? "FAIL" : "ok");
+        return;
+    }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    launch(grid, a); hipDeviceSynchronize();
+    float best = 1e30f, tot = 0;
+    const int reps = 6;
+    for (int i = 0; i < reps; ++i) {
+        hipEventRecord(e0, 0); launch(grid, a); hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); tot += ms; if (ms < best) best = ms;
+    }
+    const double fl = 2.0 * s.T * s.K * (double)s.N * s.P;
+    printf("  %-28s %-10s avg %.3f ms %.1f TF/s   best %.3f ms %.1f TF/s\n", tag, s.name, tot / reps, fl / (tot / reps) / 1e9, best, fl / best / 1e9);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
+#define GLDS(BM, BN, WM, WN, BK, S, OCC) [&](dim3 g, const Args& a) { hipLaunchKernelGGL((gemm_glds<BM, BN, WM, WN, BK, S, OCC>), g, dim3(WM * WN * 64), 0, 0, a); }
+#define REG(BM, BN, WM, WN, OCC) [&](dim3 g, const Args& a) { hipLaunchKernelGGL((gemm_reg<BM, BN, WM, WN, OCC>), g, dim3(WM * WN * 64), 0, 0, a); }
+
+int main(int argc, char** argv)
+{
+    const Shape shapes[] = {{"conv3", 15136, 256, 256, 64}, {"conv4", 3872, 512, 512, 64}, {"conv2_2", 58996, 128, 128, 64}, {"fc6", 512, 2048, 4096, 49}};
+    capA = capB = capC = 0;
+    for (auto& s : shapes) {
+        capA = std::max<size_t>(capA, (size_t)s.P * (s.T * s.K + 1088)); capB = std::max<size_t>(capB, (size_t)s.P * s.K * s.N); capC = std::max<size_t>(capC, (size_t)s.P * (s.T * s.N + 1088));
+    }
+    hipMalloc(&dA, capA * 4 + 65536); hipMalloc(&dB, capB * 4); hipMalloc(&dC, capC * 4); hipMalloc(&dRef, (size_t)300 * 512 * 4 * 8);
+    hipLaunchKernelGGL(fill, dim3(8192), dim3(256), 0, 0, dA, capA, 1u);
+    hipLaunchKernelGGL(fill, dim3(8192), dim3(256), 0, 0, dB, capB, 7u);
+    hipDeviceSynchronize();
+    const Shape chk{"check", 300, 128, 256, 3};          // T not a multiple of any tile, K = 8 / 4 K-tiles
+    const Shape chk2{"check2", 300, 32, 512, 2};         // fewer K-tiles than stages
+#define BOTH(tag, L, BM, BN) do { run(tag, L, BM, BN, chk, true); run(tag, L, BM, BN, chk2, true); } while (0)
+    BOTH("reg 128x128 occ4", REG(128, 128, 2, 2, 4), 128, 128);
+    BOTH("glds 128x128 bk16 s2 occ4", GLDS(128, 128, 2, 2, 16, 2, 4), 128, 128);
+    BOTH("glds 128x128 bk16 s3 occ3", GLDS(128, 128, 2, 2, 16, 3, 3), 128, 128);
+    BOTH("glds 128x128 bk16 s4 occ2", GLDS(128, 128, 2, 2, 16, 4, 2), 128, 128);
+    BOTH("glds 128x128 bk32 s2 occ2", GLDS(128, 128, 2, 2, 32, 2, 2), 128, 128);
+    BOTH("glds 128x128 bk32 s3 occ1", GLDS(128, 128, 2, 2, 32, 3, 1), 128, 128);
+    BOTH("glds 256x128 bk16 s3 occ4", GLDS(256, 128, 4, 2, 16, 3, 4), 256, 128);
+    BOTH("glds 256x128 bk16 s4 occ2", GLDS(256, 128, 4, 2, 16, 4, 2), 256, 128);
+    BOTH("glds 256x256 bk16 s3 occ2", GLDS(256, 256, 2, 4, 16, 3, 2), 256, 256);
+    BOTH("glds 256x256 bk16 s4 occ2", GLDS(256, 256, 2, 4, 16, 4, 2), 256, 256);
+    BOTH("glds 128x256 bk16 s3 occ2", GLDS(128, 256, 1, 4, 16, 3, 2), 128, 256);
+    for (int rep = 0; rep < 2; ++rep)
+        for (auto& s : shapes) {
+            printf("%s: T=%lld K=%d N=%d P=%d (%.1f GFLOP)\n", s.name, s.T, s.K, s.N, s.P, 2.0 * s.T * s.K * s.N * s.P / 1e9);
+            g_noload = 1;
+            run("NOLOAD 128x128 bk16 s3 occ3", GLDS(128, 128, 2, 2, 16, 3, 3), 128, 128, s, false);
+            run("NOLOAD 128x128 bk16 s2 occ4", GLDS(128, 128, 2, 2, 16, 2, 4), 128, 128, s, false);
+            run("NOLOAD 256x128 bk16 s3 occ4", GLDS(256, 128, 4, 2, 16, 3, 4), 256, 128, s, false);
+            g_noload = 0;
+            run("reg 128x128 occ4", REG(128, 128, 2, 2, 4), 128, 128, s, false);
+            run("glds 128x128 bk16 s2 occ4", GLDS(128, 128, 2, 2, 16, 2, 4), 128, 128, s, false);
+            run("glds 128x128 bk16 s3 occ3", GLDS(128, 128, 2, 2, 16, 3, 3), 128, 128, s, false);
+            run("glds 128x128 bk16 s4 occ2", GLDS(128, 128, 2, 2, 16, 4, 2), 128, 128, s, false);
+            run("glds 128x128 bk32 s2 occ2", GLDS(128, 128, 2, 2, 32, 2, 2), 128, 128, s, false);
+            run("glds 128x128 bk32 s3 occ1", GLDS(128, 128, 2, 2, 32, 3, 1), 128, 128, s, false);
+            run("glds 256x128 bk16 s3 occ4", GLDS(256, 128, 4, 2, 16, 3, 4), 256, 128, s, false);
+            run("glds 256x128 bk16 s4 occ2", GLDS(256, 128, 4, 2, 16, 4, 2), 256, 128, s, false);
+            if (s.N % 256 == 0) {
+                run("glds 256x256 bk16 s3 occ2", GLDS(256, 256, 2, 4, 16, 3, 2), 256, 256, s, false);
+                run("glds 256x256 bk16 s4 occ2", GLDS(256, 256, 2, 4, 16, 4, 2), 256, 256, s, false);
+                run("glds 128x256 bk16 s3 occ2", GLDS(128, 256, 1, 4, 16, 3, 2), 128, 256, s, false);
+            }
+        }
+    return 0;
+}
