@@ -12,6 +12,7 @@
 // Block = 256 threads = 4 wave64; K is consumed 16 at a time (8 MFMA k-steps),
 // global->register->LDS double-buffered with one barrier per K-tile.
 #include "fcn8s_internal.h"
+#include <cmath>
 #include <cstdlib>
 #include <string>
 
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void ge
         const float* sa = smem + stage * STAGE;
         const float* sb = sa + BM * BK;
 #pragma unroll
-        for (int kk2 = 0; kk2 < BK / 8; ++kk2) {
+        for (int kk2 = 0; kk2 < BK / 8; ++kk2) {       // (loading all fragments of the K-tile ahead of its MFMAs measured 7 % slower here)
             float4 af[TM];
             float bf[TN][4];
 #pragma unroll
@@ -1200,7 +1201,7 @@ bool launch_tconv_wgrad(const float* X, const float* dY, float* dW, int N, int H
 // chunk's last, partial K-tile (rows % 16, only when the row count is not a multiple of 16) goes through registers with zero fill.
 // 1-D grid, XCD-aware: the (ci, co) tiles of one (position, row chunk) share their A / B row panels and are neighbours in the id
 // order, i.e. run behind the same L2 (the 3-D grid of wgrad_kernel deals them round-robin over all eight).
-template <int BM, int BN, int WM, int WN, int S>
+template <int BM, int BN, int WM, int WN, int S, bool PRELOAD>
 __global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void wgrad_glds_kernel(const WgradArgs p, const int chunk, const int nsplit)
 {
     constexpr int BK = 16;
@@ -1262,18 +1263,23 @@ __global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void wg
     auto compute = [&](int stage) {
         const float* sa = smem + stage * STAGE + a_off;
         const float* sb = smem + stage * STAGE + BK * BM + b_off;
+        // all fragments of the K-tile first (8 x (TM + TN) VGPRs), then the MFMAs back to back: with the reads interleaved one
+        // k-step at a time the wave sat at lgkmcnt(0) in front of every group of TM * TN MFMAs
+        float af[BK / 2][TM], bf[BK / 2][TN];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float af[TM], bf[TN];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) af[tm] = sa[kk * 2 * BM + tm * 32];
+            for (int tm = 0; tm < TM; ++tm) af[kk][tm] = sa[kk * 2 * BM + tm * 32];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) bf[tn] = sb[kk * 2 * BN + tn * 32];
+            for (int tn = 0; tn < TN; ++tn) bf[kk][tn] = sb[kk * 2 * BN + tn * 32];
+        }
+        if (PRELOAD) __builtin_amdgcn_sched_barrier(0);         // (the machine scheduler otherwise sinks the reads back between the MFMAs)
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
-        }
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][tm], bf[kk][tn], acc[tm][tn], 0, 0, 0);
     };
 
 #pragma unroll
@@ -1353,9 +1359,28 @@ static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
     if constexpr (WK == 1 && BM >= 64 && BN >= 64) {
         const bool rows = a.batched || (a.ntaps == 1 && a.KW == 1 && a.a_scale == 1 && a.tap_off == 0 && a.Ha == a.Pa && a.Wa == a.Pb);
         if (glds_enabled() && full_tiles && a.Adim % BM == 0 && a.Bdim % BN == 0 && rows && !b.colsum && a.lda <= (1 << 20) && a.ldb <= (1 << 20)) {
+            // All blocks of a launch do the same work, so the launch runs in whole rounds of (256 CUs x resident blocks): pick the row
+            // split that wastes least of the last round (2048 blocks on 768 slots = 2.67 rounds idle a ninth of the chip), then the fewest splits
+            // (every split adds one pass of atomics over C).
+            constexpr int slots = 256 * ((3 * (BM + BN) * 64 <= 40960) ? 4 : 3);
+            static const int min_rounds = [] { const char* e = getenv("FCN8S_WGRAD_MIN_ROUNDS"); return e ? atoi(e) : 1; }();
+            long long best = 1; double best_score = -1e9;
+            for (long long w = 1; w <= maxsplit && (w == 1 || tiles * w <= 8LL * slots); ++w) {
+                const double r = (double)tiles * w / slots;
+                double score = r / std::ceil(r) - 0.004 * (double)w;
+                if (r < (double)min_rounds) score -= 1.0;
+                if (score > best_score) { best_score = score; best = w; }
+            }
+            long long gchunk = ((a.P + best - 1) / best + 15) / 16 * 16;
+            const int gsplits = (int)((a.P + gchunk - 1) / gchunk);
+            b.plain_store = 0;
+            if (a.c_uninitialized && gsplits == 1) b.plain_store = 1;
+            else if (a.c_uninitialized && splits == 1) hipMemsetAsync(a.C, 0, (size_t)a.ntaps * a.Areal * a.ldc * sizeof(float), s);   // (zeroed above otherwise)
             static const std::string gtag = "wgrad_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ">";
             g_last_kernel = gtag.c_str();
-            hipLaunchKernelGGL((wgrad_glds_kernel<BM, BN, WM, WN, 3>), dim3((unsigned)(nti * ntj) * (unsigned)splits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)chunk, splits);
+            static const int preload = [] { const char* e = getenv("FCN8S_WGRAD_PRELOAD"); return e ? atoi(e) : 1; }();
+            if (preload) hipLaunchKernelGGL((wgrad_glds_kernel<BM, BN, WM, WN, 3, true>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits);
+            else         hipLaunchKernelGGL((wgrad_glds_kernel<BM, BN, WM, WN, 3, false>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits);
             return;
         }
     }
