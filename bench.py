@@ -119,6 +119,89 @@ def self_launch(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+def make_png_dataset(root, n, h, w, num_classes=20, seed=0):
+    """n (image, label) PNG pairs in the Cityscapes directory convention the reference's BatchGenerator pairs by
+    (data_generator/batch_generator.py:101-119): <root>/images/<city>/<name>_leftImg8bit.png, <root>/gt/<city>/<name>_gtFine_labelIds.png.
+    Smooth structure + noise so that the PNGs compress (and decode) like photographs rather than like white noise."""
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    img_dir, gt_dir = os.path.join(root, "images", "city"), os.path.join(root, "gt", "city")
+    os.makedirs(img_dir, exist_ok=True); os.makedirs(gt_dir, exist_ok=True)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for i in range(n):
+        base = [127 + 90 * np.sin(xx / rng.uniform(20, 120) + rng.uniform(0, 6)) * np.cos(yy / rng.uniform(20, 120) + rng.uniform(0, 6)) for _ in range(3)]
+        img = np.clip(np.stack(base, -1) + rng.normal(0, 6, (h, w, 3)), 0, 255).astype(np.uint8)
+        lab = ((yy // 64) * 7 + (xx // 64) * 3 + i) % num_classes
+        Image.fromarray(img).save(os.path.join(img_dir, "s%04d_leftImg8bit.png" % i))
+        Image.fromarray(lab.astype(np.uint8)).save(os.path.join(gt_dir, "s%04d_gtFine_labelIds.png" % i))
+    return os.path.join(root, "images"), os.path.join(root, "gt")
+
+
+def e2e(args):
+    """FCN8s.train() end to end: PNG files -> BatchGenerator (decode, flip augmentation, `workers` processes) -> staging slots
+    (pinned copy + H2D on the copy stream, one batch ahead) -> the training step, loss fetched every step as the reference does
+    (fcn8s_tensorflow.py:551-578).  Prints one JSON line with the end-to-end rate next to the resident-input rate of the same
+    process."""
+    import tempfile
+    import torch
+    from fcn8s_tensorflow_amd.fcn8s import FCN8s
+    from fcn8s_tensorflow_amd.batch_generator import BatchGenerator
+    N, H, W = args.batch, args.height, args.width
+    root = tempfile.mkdtemp(prefix="fcn8s_e2e_")
+    t0 = time.perf_counter()
+    img_root, gt_root = make_png_dataset(root, 4 * N, H, W)
+    t_data = time.perf_counter() - t0
+    gen = BatchGenerator(image_dirs=[img_root], image_file_extension='png', ground_truth_dirs=[gt_root],
+                         image_name_split_separator='_leftImg8bit', ground_truth_suffix='_gtFine_labelIds',
+                         check_existence=True, num_classes=20)
+    train_gen = gen.generate(batch_size=N, convert_to_one_hot=True, flip=0.5, shuffle=True, workers=args.workers)
+    # feeder alone: batches per second the host side can deliver (class-id form, what FCN8s.train pulls)
+    train_gen.next_ids()
+    tf0 = time.perf_counter()
+    for _ in range(4):
+        train_gen.next_ids()
+    feeder_ips = 4 * N / (time.perf_counter() - tf0)
+    model = FCN8s(vgg16_dir='synthetic:0', num_classes=20, device_id=args.device or 0)
+    sched = lambda step: 1e-4
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model.train(train_gen, epochs=1, steps_per_epoch=args.warmup, learning_rate_schedule=sched, record_summaries=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        model.train(train_gen, epochs=1, steps_per_epoch=args.steps, learning_rate_schedule=sched, record_summaries=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+    # the same step on device-resident inputs (what `--mode train` times), TF-Adam like FCN8s.train
+    rng = np.random.default_rng(0)
+    images = torch.from_numpy(rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)).cuda()
+    labels = torch.from_numpy(rng.integers(0, 20, (N, H, W), dtype=np.uint8)).cuda()
+    eng = model.engine
+    for _ in range(2):
+        eng.train_step(images, labels, 1e-4, fetch_loss=False)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.train_step(images, labels, 1e-4, fetch_loss=False)
+    torch.cuda.synchronize()
+    dres = time.perf_counter() - t2
+    value, resident = N * args.steps / dt, N * args.steps / dres
+    out = {"metric": "training images/sec at 1024x512 bs16, end to end (PNG decode + augmentation + H2D + FCN8s.train)",
+           "value": round(value, 3), "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic PNG files (%d pairs, generated in %.1f s)" % (4 * N, t_data),
+           "config": {"workload": "FCN8s.train() from BatchGenerator(workers=%d, flip 0.5, one-hot contract) over %dx%d PNG pairs, %d images/step, TF-Adam, loss fetched every step"
+                                  % (args.workers, W, H, N), "global_batch": N, "parallelism": "dp1"},
+           "resident_input_images_per_sec": round(resident, 3), "e2e_over_resident": round(value / resident, 4),
+           "feeder_alone_images_per_sec": round(feeder_ips, 1), "host_cores": os.cpu_count()}
+    train_gen.close()
+    with contextlib.redirect_stdout(io.StringIO()):
+        model.close()
+    print(json.dumps(out), flush=True)
+    import shutil
+    shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

@@ -16,6 +16,7 @@ HOST, DEVICE = 0, 1
 IMG_U8, IMG_F32 = 0, 1
 OPT_TF_ADAM, OPT_SGD_MOMENTUM, OPT_NONE = 0, 1, 2
 NUM_BUCKETS = 3
+NUM_STAGE_SLOTS = 3
 PREC_F32, PREC_BF16_FC = 0, 1
 
 
@@ -57,6 +58,10 @@ SIGNATURES = {
     "fcn8s_eval_step": (_i, [_p, _p, _i, _p, _i, _i, _i, _f, _i]),
     "fcn8s_metrics_reset": (_i, [_p]),
     "fcn8s_metrics_get": (_i, [_p, _dp, _dp, _dp]),
+    "fcn8s_metrics_get_ex": (_i, [_p, _dp, _dp, _dp, _i]),
+    "fcn8s_stage_inputs": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, C.POINTER(_p), C.POINTER(_p)]),
+    "fcn8s_stage_wait": (_i, [_p, _i]),
+    "fcn8s_stage_release": (_i, [_p, _i]),
     "fcn8s_metrics_raw": (_i, [_p, _p, _dp, _i64p]),
     "fcn8s_metrics_set_raw": (_i, [_p, _p, C.c_double, _i64]),
     "fcn8s_predict": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _i]),

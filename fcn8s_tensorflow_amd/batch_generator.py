@@ -72,9 +72,8 @@ def _shift(array, x_shift, y_shift, fill):
     return out
 
 
-def _brightness(image, min=0.5, max=2.0):
-    """Scale the HSV value channel by a random factor, saturating at 255 (:473-488)."""
-    factor = np.random.uniform(min, max)
+def _brightness(image, factor):
+    """Scale the HSV value channel by `factor`, saturating at 255 (:473-488)."""
     img = image.astype(np.float32)
     v = img.max(axis=2, keepdims=True)
     scaled = np.where(v * factor > 255, 255.0 / np.maximum(v, 1.0), factor)
@@ -116,6 +115,98 @@ def prefetch(generator, depth=2):
         if isinstance(item, BaseException):
             raise item
         yield item
+
+
+def _image_size(path):
+    from PIL import Image
+    with Image.open(path) as im:
+        return im.height, im.width
+
+
+def _process_sample(task):
+    """Decode + convert + augment one sample (runs in a worker process when `workers` > 0)."""
+    image_path, gt_path, draw, conv = task
+    image = _imread(image_path)
+    gt = None
+    if gt_path is not None:
+        gt = _imread(gt_path)
+        c2i, i2i = conv['convert_colors_to_ids'], conv['convert_ids_to_ids']
+        if c2i is not False:
+            gt = convert_between_IDs_and_colors(gt, c2i, gt_dtype=gt.dtype)
+        if i2i is not False:
+            if isinstance(i2i, np.ndarray):
+                gt = convert_IDs_to_IDs(gt, i2i)
+            if isinstance(i2i, dict):
+                gt = convert_IDs_to_IDs_partial(gt, i2i)
+    return BatchGenerator._apply(image, gt, draw, conv['void_class_id'], conv['random_crop'], conv['crop'], conv['resize'], conv['gray'])
+
+
+class _BatchIterator:
+    """What `BatchGenerator.generate()` returns: the reference's infinite generator (`next()` / `for`) plus `next_ids()`, which
+    yields the same batch with uint8 class-id maps (n,H,W) instead of the bool one-hot rows (n,H,W,C) -- 1/20 of the bytes; the
+    FCN8s facade uses it to feed the GPU, which consumes class ids anyway."""
+
+    def __init__(self, owner, batch_size, conv, aug, one_hot, to_disk, shuffle, workers):
+        self.o, self.batch_size, self.conv, self.aug = owner, batch_size, conv, aug
+        self.one_hot, self.to_disk, self.shuffle = one_hot, to_disk, shuffle
+        self.current = 0
+        self.pool = None
+        if workers and workers > 0:
+            import multiprocessing as mp
+            self.pool = mp.get_context('forkserver').Pool(int(workers))    # forkserver: the workers never inherit a HIP context
+        if shuffle:
+            random.shuffle(owner.image_paths)
+
+    def __iter__(self):
+        return self
+
+    def _batch(self):
+        o = self.o
+        if self.current >= len(o.image_paths):
+            if self.shuffle:
+                random.shuffle(o.image_paths)
+            self.current = 0
+        paths = o.image_paths[self.current:self.current + self.batch_size]       # short at the end of a pass
+        self.current += self.batch_size
+        needs_size = bool(self.aug['random_crop'] or self.aug['scale'])
+        tasks = []
+        for image_path in paths:
+            h, w = _image_size(image_path) if needs_size else (0, 0)
+            draw = BatchGenerator._draw(h, w, **self.aug)
+            gt_path = o.ground_truth_paths[os.path.basename(image_path)] if o.ground_truth else None
+            tasks.append((image_path, gt_path, draw, self.conv))
+        results = self.pool.map(_process_sample, tasks) if self.pool is not None else [_process_sample(t) for t in tasks]
+        return paths, [r[0] for r in results], [r[1] for r in results]
+
+    def _finish(self, paths, images, gts, one_hot):
+        o = self.o
+        if one_hot:
+            gts = [convert_IDs_to_one_hot(gt, o.num_classes) for gt in gts]
+        if self.to_disk:
+            for path, image, gt in zip(paths, images, gts):
+                o._export(path, image, gt)
+        if o.ground_truth:
+            return np.array(images), np.array(gts)
+        return np.array(images)
+
+    def __next__(self):
+        paths, images, gts = self._batch()
+        return self._finish(paths, images, gts, self.one_hot)
+
+    def next_ids(self):
+        paths, images, gts = self._batch()
+        return self._finish(paths, images, gts, False)
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.terminate()
+            self.pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class BatchGenerator:
@@ -194,57 +285,75 @@ class BatchGenerator:
                     gt = convert_IDs_to_IDs_partial(gt, convert_ids_to_ids)
         return image, gt
 
-    def _augment(self, image, gt, void_class_id, random_crop, crop, resize, brightness, flip, translate, scale, gray):
+    @staticmethod
+    def _draw(h, w, random_crop, crop, resize, brightness, flip, translate, scale):
+        """The random decisions of one sample, drawn in the reference's order (crop y, crop x, brightness, flip, translate,
+        scale; data_generator/batch_generator.py:268-384) from the global `np.random` / `random` state.  Separated from the
+        pixel work so that the latter can run in worker processes without changing what a seeded run produces."""
+        d = {}
+        if random_crop:
+            d['ymin'] = np.random.randint(0, abs(h - random_crop[0]) + 1)
+            d['xmin'] = np.random.randint(0, abs(w - random_crop[1]) + 1)
+            h, w = random_crop
+        if crop:
+            h, w = h - crop[0] - crop[1], w - crop[2] - crop[3]
+        if resize:
+            h, w = resize
+        if brightness and np.random.uniform(0, 1) >= (1 - brightness[2]):
+            d['gain'] = np.random.uniform(brightness[0], brightness[1])
+        if flip and np.random.uniform(0, 1) >= (1 - flip):
+            d['flip'] = True
+        if translate and np.random.uniform(0, 1) >= (1 - translate[2]):
+            x = np.random.randint(translate[0][0], translate[0][1] + 1)
+            y = np.random.randint(translate[1][0], translate[1][1] + 1)
+            d['shift'] = (random.choice([-x, x]), random.choice([-y, y]))
+        if scale and np.random.uniform(0, 1) >= (1 - scale[2]):
+            d['factor'] = np.random.uniform(scale[0], scale[1])
+        return d
+
+    @staticmethod
+    def _apply(image, gt, d, void_class_id, random_crop, crop, resize, gray):
         h, w, ch = image.shape
         if random_crop:
-            y_range, x_range = h - random_crop[0], w - random_crop[1]
-            ymin = np.random.randint(0, abs(y_range) + 1)
-            xmin = np.random.randint(0, abs(x_range) + 1)
-            image = _place_or_crop(image, random_crop[0], random_crop[1], ymin, xmin, 0)
+            image = _place_or_crop(image, random_crop[0], random_crop[1], d['ymin'], d['xmin'], 0)
             if gt is not None:
-                gt = _place_or_crop(gt, random_crop[0], random_crop[1], ymin, xmin, void_class_id)
+                gt = _place_or_crop(gt, random_crop[0], random_crop[1], d['ymin'], d['xmin'], void_class_id)
             h, w = random_crop
         if crop:
             image = np.copy(image[crop[0]:h - crop[1], crop[2]:w - crop[3]])
             gt = np.copy(gt[crop[0]:h - crop[1], crop[2]:w - crop[3]])       # unconditional in the reference too (:326)
+            h, w = image.shape[:2]
         if resize:
             image = _resize(image, resize[0], resize[1], nearest=False)
             if gt is not None:
                 gt = _resize(gt, resize[0], resize[1], nearest=True)
             h, w = resize
-        if brightness:
-            if np.random.uniform(0, 1) >= (1 - brightness[2]):
-                image = _brightness(image, min=brightness[0], max=brightness[1])
-        if flip:
-            if np.random.uniform(0, 1) >= (1 - flip):
-                image = np.ascontiguousarray(image[:, ::-1])
-                if gt is not None:
-                    gt = np.ascontiguousarray(gt[:, ::-1])
-        if translate:
-            if np.random.uniform(0, 1) >= (1 - translate[2]):
-                x = np.random.randint(translate[0][0], translate[0][1] + 1)
-                y = np.random.randint(translate[1][0], translate[1][1] + 1)
-                x_shift = random.choice([-x, x])
-                y_shift = random.choice([-y, y])
-                image = _shift(image, x_shift, y_shift, 0)
-                if gt is not None:
-                    gt = _shift(gt, x_shift, y_shift, void_class_id)
-        if scale:
-            if np.random.uniform(0, 1) >= (1 - scale[2]):
-                factor = np.random.uniform(scale[0], scale[1])
-                sh, sw = int(h * factor), int(w * factor)
-                yo, xo = abs(int((h - sh) / 2)), abs(int((w - sw) / 2))
+        if 'gain' in d:
+            image = _brightness(image, d['gain'])
+        if d.get('flip'):
+            image = np.ascontiguousarray(image[:, ::-1])
+            if gt is not None:
+                gt = np.ascontiguousarray(gt[:, ::-1])
+        if 'shift' in d:
+            x_shift, y_shift = d['shift']
+            image = _shift(image, x_shift, y_shift, 0)
+            if gt is not None:
+                gt = _shift(gt, x_shift, y_shift, void_class_id)
+        if 'factor' in d:
+            factor = d['factor']
+            sh, sw = int(h * factor), int(w * factor)
+            yo, xo = abs(int((h - sh) / 2)), abs(int((w - sw) / 2))
 
-                def rescale(a, nearest, fill):
-                    patch = _resize(a, sh, sw, nearest)
-                    if factor <= 1:
-                        canvas = np.full((h, w) + a.shape[2:], 0 if fill is None else fill, dtype=a.dtype)
-                        canvas[yo:yo + sh, xo:xo + sw] = patch
-                        return canvas
-                    return np.copy(patch[yo:h + yo, xo:w + xo])
-                image = rescale(image, False, 0)
-                if gt is not None:
-                    gt = rescale(gt, True, void_class_id)
+            def rescale(a, nearest, fill):
+                patch = _resize(a, sh, sw, nearest)
+                if factor <= 1:
+                    canvas = np.full((h, w) + a.shape[2:], 0 if fill is None else fill, dtype=a.dtype)
+                    canvas[yo:yo + sh, xo:xo + sw] = patch
+                    return canvas
+                return np.copy(patch[yo:h + yo, xo:w + xo])
+            image = rescale(image, False, 0)
+            if gt is not None:
+                gt = rescale(gt, True, void_class_id)
         if gray:
             lum = image[..., 0] * 0.299 + image[..., 1] * 0.587 + image[..., 2] * 0.114
             image = np.expand_dims(np.clip(np.rint(lum), 0, 255).astype(np.uint8), axis=2)
@@ -265,38 +374,21 @@ class BatchGenerator:
                  scale=False,
                  gray=False,
                  to_disk=False,
-                 shuffle=True):
-        '''Arguments and yields as data_generator/batch_generator.py:156-219.'''
+                 shuffle=True,
+                 workers=0):
+        '''Arguments and yields as data_generator/batch_generator.py:156-219.  `workers` (not in the reference): number of
+        processes that decode and augment the samples of a batch in parallel (0 = in this thread, as the reference does); the
+        random decisions are still drawn here, in the reference's order, so seeded runs do not depend on it.  The returned object
+        is an iterator like the reference's generator and additionally offers `next_ids()`.'''
         if (convert_to_one_hot or (convert_colors_to_ids is not False) or (convert_ids_to_ids is not False)) and not self.ground_truth:
             raise ValueError("Cannot convert ground truth data: No ground truth data given.")
         if convert_to_one_hot and self.num_classes is None:
             raise ValueError("One-hot conversion requires that you pass an integer value for `num_classes` in the constructor, but `num_classes` is `None`.")
-
-        if shuffle:
-            random.shuffle(self.image_paths)
-        current = 0
-        while True:
-            if current >= len(self.image_paths):
-                if shuffle:
-                    random.shuffle(self.image_paths)
-                current = 0
-            images, gt_images = [], []
-            for image_path in self.image_paths[current:current + batch_size]:      # short at the end of a pass
-                image, gt = self._load(image_path, convert_colors_to_ids, convert_ids_to_ids)
-                image, gt = self._augment(image, gt, void_class_id, random_crop, crop, resize, brightness, flip,
-                                          translate, scale, gray)
-                if convert_to_one_hot:
-                    gt = convert_IDs_to_one_hot(gt, self.num_classes)
-                if to_disk:
-                    self._export(image_path, image, gt)
-                images.append(image)
-                if self.ground_truth:
-                    gt_images.append(gt)
-            current += batch_size
-            if self.ground_truth:
-                yield np.array(images), np.array(gt_images)
-            else:
-                yield np.array(images)
+        return _BatchIterator(self, batch_size, dict(convert_colors_to_ids=convert_colors_to_ids, convert_ids_to_ids=convert_ids_to_ids,
+                                                     void_class_id=void_class_id, random_crop=random_crop, crop=crop, resize=resize, gray=gray),
+                              dict(random_crop=random_crop, crop=crop, resize=resize, brightness=brightness, flip=flip,
+                                   translate=translate, scale=scale),
+                              convert_to_one_hot, to_disk, shuffle, workers)
 
     def _export(self, image_path, image, gt):
         target = os.path.join(self.export_dir, os.path.relpath(image_path, start=self.root_dir))

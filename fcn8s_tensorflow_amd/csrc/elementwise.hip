@@ -155,12 +155,13 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel_c(const float* logits
 #pragma unroll
         for (int i = 0; i < C; ++i) { e[i] = expf(v[i] - m); s += e[i]; }
         const int lab = labels[p];
+        const bool ign = lab >= C;                 // ids outside [0, C) (e.g. a 255 "ignore" id, an all-zero one-hot row): no loss, no gradient
         float vl = 0.f;
 #pragma unroll
         for (int i = 0; i < C; ++i) vl = (i == lab) ? v[i] : vl;
-        lsum += (double)(m + logf(s) - vl);
+        if (!ign) lsum += (double)(m + logf(s) - vl);
         if (dlogits) {
-            const float inv = gscale / s;
+            const float inv = ign ? 0.f : gscale / s;
             float4* dst = reinterpret_cast<float4*>(dlogits + p * C);
 #pragma unroll
             for (int i = 0; i < C / 4; ++i) {
@@ -202,9 +203,10 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel_any(const float* logi
         float s = 0.f;
         for (int i = 0; i < C; ++i) s += expf(l[i] - m);
         const int lab = labels[p];
-        lsum += (double)(m + logf(s) - l[lab]);
+        const bool ign = lab >= C;                 // see softmax_xent_kernel_c
+        if (!ign) lsum += (double)(m + logf(s) - l[lab]);
         if (dlogits) {
-            const float inv = gscale / s;
+            const float inv = ign ? 0.f : gscale / s;
             for (int i = 0; i < C; ++i) dlogits[p * C + i] = expf(l[i] - m) * inv - (i == lab ? gscale : 0.f);
         }
     }
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256) void onehot_to_ids_kernel(const T* oh, long lo
         const T* row = oh + p * C;
         int first = -1, cnt = 0;
         for (int c = 0; c < C; ++c) if (row[c] != 0) { if (first < 0) first = c; ++cnt; }
-        ids[p] = (uint8_t)(first < 0 ? 0 : first);
+        ids[p] = (uint8_t)(first < 0 ? 255 : first);      // all-zero row: the 'ignore' id (zero loss and gradient in the loss kernel)
         nbad += cnt != 1;
     }
     if (bad && nbad) atomicAdd(bad, nbad);
@@ -548,6 +550,22 @@ void launch_augment_u8(const unsigned char* img, const unsigned char* lab, unsig
                        int N, int H, int W, int Ho, int Wo, int void_id, hipStream_t s)
 {
     hipLaunchKernelGGL(augment_u8_kernel, dim3(cap_blocks((long long)N * Ho * Wo, 256)), dim3(256), 0, s, img, lab, oimg, olab, params, N, H, W, Ho, Wo, void_id);
+}
+
+
+// ---- strided fingerprint of a float buffer (frozen-parameter guard): wrapping sum of the bit patterns of every 61st element ----
+__global__ __launch_bounds__(256) void fingerprint_kernel(const unsigned* __restrict__ x, long long n, unsigned long long* out)
+{
+    unsigned long long acc = 0;
+    for (long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * 61; i < n; i += (long long)gridDim.x * blockDim.x * 61)
+        acc += (unsigned long long)x[i] * (unsigned long long)((i & 1023) + 1);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+void launch_fingerprint(const float* x, long long n, unsigned long long* out, hipStream_t s)
+{
+    hipMemsetAsync(out, 0, sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(fingerprint_kernel, dim3(256), dim3(256), 0, s, (const unsigned*)x, n, out);
 }
 
 }  // namespace fcn8s

@@ -63,6 +63,7 @@ struct fcn8s_model {
     bool pool_fused[5] = {false, false, false, false, false};            // forward wrote pool_b + argmax bytes from conv_b_last's output transform
     // fcn8s_freeze_params: the caller promises constant parameters; Winograd-transformed filters are then kept per layer
     bool frozen = false;
+    unsigned long long frozen_fp = 0; unsigned long long* d_fp = nullptr;   // fingerprint of the parameter buffer the cached banks were built from
     std::map<std::string, float*> u_cache;                               // layer -> transformed filter bank (hipMalloc'ed), valid while frozen
     std::set<std::string> rbits_ok;                                       // layers whose forward pass wrote a ReLU bit mask ("rb:<layer>") this step
     std::string fused_v_layer;                                            // layer whose data-gradient input transform already sits in d_wino_v
@@ -89,6 +90,11 @@ struct fcn8s_model {
     int next_bucket = 0;
     const uint8_t* cur_labels = nullptr;
     bool profile = false, profile_detail = false;
+    // pinned host staging + device slots filled on a copy stream (fcn8s_stage_inputs): the next batch's H2D overlaps this step's kernels
+    struct StageSlot { void* h_img = nullptr; uint8_t* h_lab = nullptr; void* d_img = nullptr; uint8_t* d_lab = nullptr;
+                       size_t cap_img = 0, cap_lab = 0; hipEvent_t ready = nullptr, consumed = nullptr; bool used = false; };
+    StageSlot slots[FCN8S_NUM_STAGE_SLOTS];
+    hipStream_t copy_stream = nullptr;
     std::vector<ProfGroup> groups;
     std::string err;
 };
@@ -561,6 +567,16 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
 {
     hipStream_t s = m->stream;
     const int N = m->N, H = m->H, W = m->W, C = m->C;
+    if (m->frozen && !m->u_cache.empty()) {
+        // the caller promised constant parameters; a cheap strided fingerprint catches the promise being broken through a side
+        // door (a torch optimizer or copy_ over views of ext_params): the cached filter banks are then rebuilt instead of reused
+        launch_fingerprint(m->d_params, (long long)m->total, m->d_fp, s);
+        unsigned long long fp = 0;
+        hipMemcpyAsync(&fp, m->d_fp, sizeof fp, hipMemcpyDeviceToHost, s);
+        hipStreamSynchronize(s);
+        if (fp != m->frozen_fp) { for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second); m->u_cache.clear(); }
+    }
+    const bool fill_fp = m->frozen && m->u_cache.empty();
     prepare_forward_weights(m);
     m->rbits_ok.clear();
     { ProfScope ps(m, "preprocess", 0, (double)N * H * W * (16 + (dtype ? 12 : 3))); launch_preprocess(img_dev, dtype, A(m, "x0"), (long long)N * H * W, s); }
@@ -642,6 +658,11 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     tconv_fwd(m, A(m, "s7"), m->d_tph[0], Wp(m, "fc7_conv2d_trans/bias"), A(m, "p4"), A(m, "a4"), N, h5, w5, C, 4, 2, s);
     tconv_fwd(m, A(m, "a4"), m->d_tph[1], Wp(m, "fc7_pool4_conv2d_trans/bias"), A(m, "p3"), A(m, "a3"), N, H / 16, W / 16, C, 4, 2, s);
     tconv_fwd(m, A(m, "a3"), m->d_tph[2], Wp(m, "fc7_pool4_pool3_conv2d_trans/bias"), nullptr, A(m, "logits"), N, H / 8, W / 8, C, 16, 8, s);
+    if (fill_fp) {                        // this pass (re)built the cache: remember what it was built from
+        launch_fingerprint(m->d_params, (long long)m->total, m->d_fp, s);
+        hipMemcpyAsync(&m->frozen_fp, m->d_fp, sizeof m->frozen_fp, hipMemcpyDeviceToHost, s);
+        hipStreamSynchronize(s);
+    }
     m->have_forward = true; m->train_mode = train; m->keep_prob = keep_prob;
     return FCN8S_OK;
 }
@@ -864,7 +885,7 @@ int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
 {
     if (!cfg || !out) return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_create: null argument");
     if (cfg->num_classes <= 0 || cfg->num_classes % 4 != 0 || cfg->num_classes > 64)
-        return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_create: num_classes must be a positive multiple of 4, at most 64");
+        return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_create: num_classes must be a positive multiple of 4, at most 64 (the Python facade pads other class counts)");
     fcn8s_model* m = new fcn8s_model();
     resolve_cfg(cfg, m->C, m->widths, m->fc6k);
     for (int i = 0; i < 7; ++i)
@@ -902,6 +923,7 @@ int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
     if ((e = hipMalloc((void**)&m->d_loss, (2 + 64) * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     m->d_regsum = m->d_loss + 1; m->d_lastbias = m->d_loss + 2;
     if ((e = hipMalloc((void**)&m->d_conf, cc * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&m->d_fp, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     hipMemset(m->d_conf, 0, cc * sizeof(unsigned long long));
     hipMemset(m->d_loss, 0, 2 * sizeof(float));
     *out = m;
@@ -926,6 +948,16 @@ int fcn8s_destroy(fcn8s_model* m)
     for (int i = 0; i < 3; ++i) if (m->d_tph[i]) hipFree(m->d_tph[i]);
     if (m->d_loss) hipFree(m->d_loss);
     if (m->d_conf) hipFree(m->d_conf);
+    if (m->d_fp) hipFree(m->d_fp);
+    for (auto& sl : m->slots) {
+        if (sl.h_img) hipHostFree(sl.h_img);
+        if (sl.h_lab) hipHostFree(sl.h_lab);
+        if (sl.d_img) hipFree(sl.d_img);
+        if (sl.d_lab) hipFree(sl.d_lab);
+        if (sl.ready) hipEventDestroy(sl.ready);
+        if (sl.consumed) hipEventDestroy(sl.consumed);
+    }
+    if (m->copy_stream) hipStreamDestroy(m->copy_stream);
     if (m->arena) hipFree(m->arena);
     delete m;
     return FCN8S_OK;
@@ -1146,11 +1178,17 @@ int fcn8s_metrics_set_raw(fcn8s_model* m, const int64_t* conf, double loss_sum, 
 
 int fcn8s_metrics_get(fcn8s_model* m, double* mean_loss, double* mean_iou, double* accuracy)
 {
+    return fcn8s_metrics_get_ex(m, mean_loss, mean_iou, accuracy, 0);
+}
+
+int fcn8s_metrics_get_ex(fcn8s_model* m, double* mean_loss, double* mean_iou, double* accuracy, int all_classes)
+{
     if (!m) return FCN8S_ERR_BAD_ARG;
     const int C = m->C;
     std::vector<int64_t> cm((size_t)C * C);
     int rc = fcn8s_metrics_raw(m, cm.data(), nullptr, nullptr); if (rc) return rc;
-    // tf.metrics.mean_iou: iou_c = diag/(row+col-diag), mean over classes with a non-zero denominator
+    // tf.metrics.mean_iou: iou_c = diag/(row+col-diag) with zero denominators replaced by 1; mean over the classes with a non-zero
+    // denominator (later TF 1.x), or -- all_classes, the TF 1.3.0 of fcn8s_tutorial.ipynb:311 -- over all C classes (an absent class counts as IoU 0)
     double iou_sum = 0, tot = 0, diag = 0; int valid = 0;
     for (int c = 0; c < C; ++c) {
         double row = 0, col = 0;
@@ -1161,7 +1199,7 @@ int fcn8s_metrics_get(fcn8s_model* m, double* mean_loss, double* mean_iou, doubl
         tot += row; diag += d;
     }
     if (mean_loss) *mean_loss = m->loss_cnt > 0 ? m->loss_sum / (double)m->loss_cnt : 0.0;
-    if (mean_iou) *mean_iou = valid > 0 ? iou_sum / valid : 0.0;
+    if (mean_iou) *mean_iou = all_classes ? iou_sum / C : (valid > 0 ? iou_sum / valid : 0.0);
     if (accuracy) *accuracy = tot > 0 ? diag / tot : 0.0;
     return FCN8S_OK;
 }
@@ -1189,6 +1227,59 @@ int fcn8s_predict(fcn8s_model* m, const void* images, int dtype, int N, int H, i
         HIPCHK(m, hipMemcpyAsync(out, m->d_softmax, npix * m->C * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     }
     HIPCHK(m, hipStreamSynchronize(m->stream));
+    return FCN8S_OK;
+}
+
+// ---- asynchronous host boundary ------------------------------------------------------------------
+int fcn8s_stage_inputs(fcn8s_model* m, int slot, const void* images, int dtype, const uint8_t* label_ids, int N, int H, int W,
+                       void** images_dev, uint8_t** labels_dev)
+{
+    if (!m || !images || slot < 0 || slot >= FCN8S_NUM_STAGE_SLOTS || N <= 0 || H <= 0 || W <= 0) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_stage_inputs: bad argument");
+    HIPCHK(m, hipSetDevice(m->device));                  // may be called from a feeder thread
+    if (!m->copy_stream) HIPCHK(m, hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+    fcn8s_model::StageSlot& sl = m->slots[slot];
+    const size_t npix = (size_t)N * H * W, ib = npix * 3 * (dtype == FCN8S_IMG_U8 ? 1 : 4), lb = label_ids ? npix : 0;
+    if (!sl.ready) { HIPCHK(m, hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming)); HIPCHK(m, hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming)); }
+    if (sl.used) HIPCHK(m, hipEventSynchronize(sl.ready));        // the previous copy out of this slot's pinned buffers has finished
+    if (sl.cap_img < ib) {
+        if (sl.used) HIPCHK(m, hipEventSynchronize(sl.consumed));
+        if (sl.h_img) hipHostFree(sl.h_img);
+        if (sl.d_img) hipFree(sl.d_img);
+        sl.h_img = nullptr; sl.d_img = nullptr; sl.cap_img = 0;
+        HIPCHK(m, hipHostMalloc(&sl.h_img, ib, hipHostMallocDefault));
+        HIPCHK(m, hipMalloc(&sl.d_img, ib));
+        sl.cap_img = ib;
+    }
+    if (lb && sl.cap_lab < lb) {
+        if (sl.used) HIPCHK(m, hipEventSynchronize(sl.consumed));
+        if (sl.h_lab) hipHostFree(sl.h_lab);
+        if (sl.d_lab) hipFree(sl.d_lab);
+        sl.h_lab = nullptr; sl.d_lab = nullptr; sl.cap_lab = 0;
+        HIPCHK(m, hipHostMalloc((void**)&sl.h_lab, lb, hipHostMallocDefault));
+        HIPCHK(m, hipMalloc((void**)&sl.d_lab, lb));
+        sl.cap_lab = lb;
+    }
+    memcpy(sl.h_img, images, ib);                         // pageable -> pinned on this (feeder) thread
+    if (lb) memcpy(sl.h_lab, label_ids, lb);
+    if (sl.used) HIPCHK(m, hipStreamWaitEvent(m->copy_stream, sl.consumed, 0));   // the step that last read this slot's device buffers
+    HIPCHK(m, hipMemcpyAsync(sl.d_img, sl.h_img, ib, hipMemcpyHostToDevice, m->copy_stream));
+    if (lb) HIPCHK(m, hipMemcpyAsync(sl.d_lab, sl.h_lab, lb, hipMemcpyHostToDevice, m->copy_stream));
+    HIPCHK(m, hipEventRecord(sl.ready, m->copy_stream));
+    sl.used = true;
+    if (images_dev) *images_dev = sl.d_img;
+    if (labels_dev) *labels_dev = lb ? sl.d_lab : nullptr;
+    return FCN8S_OK;
+}
+int fcn8s_stage_wait(fcn8s_model* m, int slot)
+{
+    if (!m || slot < 0 || slot >= FCN8S_NUM_STAGE_SLOTS || !m->slots[slot].used) return fail(m, FCN8S_ERR_STATE, "fcn8s_stage_wait: nothing staged in this slot");
+    HIPCHK(m, hipStreamWaitEvent(m->stream, m->slots[slot].ready, 0));
+    return FCN8S_OK;
+}
+int fcn8s_stage_release(fcn8s_model* m, int slot)
+{
+    if (!m || slot < 0 || slot >= FCN8S_NUM_STAGE_SLOTS || !m->slots[slot].used) return fail(m, FCN8S_ERR_STATE, "fcn8s_stage_release: nothing staged in this slot");
+    HIPCHK(m, hipEventRecord(m->slots[slot].consumed, m->stream));
     return FCN8S_OK;
 }
 

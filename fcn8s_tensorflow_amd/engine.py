@@ -27,6 +27,15 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized()) else None
 
 
+class Staged:
+    """One host batch on its way to the GPU through a staging slot (Engine.stage): pinned copy + H2D on the library's copy
+    stream, started by whoever called stage() -- typically the feeder thread, while the compute stream runs the previous step."""
+    __slots__ = ("slot", "img_ptr", "lab_ptr", "dtype", "nhw")
+
+    def __init__(self, slot, img_ptr, lab_ptr, dtype, nhw):
+        self.slot, self.img_ptr, self.lab_ptr, self.dtype, self.nhw = slot, img_ptr, lab_ptr, dtype, nhw
+
+
 class Engine:
     def __init__(self, num_classes, widths=None, fc6_ksize=7, device_id=0, seed=0, process_group=None, precision='fp32'):
         import torch
@@ -67,6 +76,8 @@ class Engine:
             L.check(L.lib.fcn8s_bucket_range(self.h, b, C.byref(o), C.byref(m)), self.h)
             self.buckets.append((o.value, m.value))
         self._label_checks_left = 2
+        self._label_calls = 0
+        self._bad = None
         self._sync_stream()
 
     # ---- plumbing ---------------------------------------------------------------------
@@ -201,17 +212,21 @@ class Engine:
         t = t.to(self.device).contiguous()
         npix = int(nhw[0]) * int(nhw[1]) * int(nhw[2])
         ids = torch.empty(tuple(int(x) for x in nhw), dtype=torch.uint8, device=self.device)
-        check = self._label_checks_left > 0
-        bad = torch.zeros(1, dtype=torch.int32, device=self.device) if check else None
+        # every batch adds its count of rows that are not one-hot to a device counter (no sync); the host looks at it on the first
+        # two batches and then every 64th (all-zero rows train as "ignore", multi-hot rows as their first class -- see include/fcn8s_hip.h)
+        if self._bad is None:
+            self._bad = torch.zeros(1, dtype=torch.int32, device=self.device)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         L.check(L.lib.fcn8s_onehot_to_ids(stream, C.c_void_p(t.data_ptr()), eb, npix, self.num_classes,
-                                          C.c_void_p(ids.data_ptr()), C.c_void_p(bad.data_ptr()) if check else None))
-        if check:
-            self._label_checks_left -= 1
-            nbad = int(bad.item())
+                                          C.c_void_p(ids.data_ptr()), C.c_void_p(self._bad.data_ptr())))
+        self._label_calls += 1
+        if self._label_checks_left > 0 or self._label_calls % 64 == 0:
+            self._label_checks_left = max(0, self._label_checks_left - 1)
+            nbad = int(self._bad.item())
             if nbad:
-                raise ValueError("labels must be one-hot along the last axis (%d of %d rows are not); "
-                                 "soft labels are not supported" % (nbad, npix))
+                self._bad.zero_()
+                raise ValueError("labels must be one-hot along the last axis (%d rows of the last %s were not); "
+                                 "soft labels are not supported" % (nbad, "batch" if self._label_calls <= 2 else "64 batches"))
         return ids
 
     def _inputs(self, images, labels):
@@ -219,6 +234,10 @@ class Engine:
         429-433) are shipped to the GPU and reduced to uint8 class ids there -- an np.argmax over the
         168 MB one-hot batch on the host would cost more than the whole training step."""
         torch = self.torch
+        if isinstance(images, Staged):
+            st = images
+            L.check(L.lib.fcn8s_stage_wait(self.h, st.slot), self.h)
+            return st, C.c_void_p(st.img_ptr), st.dtype, C.c_void_p(st.lab_ptr) if st.lab_ptr else None, L.DEVICE, st.nhw
         lab_is_tensor = isinstance(labels, torch.Tensor)
         lab_rank = labels.dim() if lab_is_tensor else np.ndim(labels)
         onehot = lab_rank == 4
@@ -246,6 +265,33 @@ class Engine:
             t = torch.from_numpy(a).to(self.device)
             return (ka_i, t), pi, dt, C.c_void_p(t.data_ptr()), where, nhw
         return (ka_i, a), pi, dt, a.ctypes.data_as(C.c_void_p), where, nhw
+
+    def stage(self, images, label_ids=None, slot=0):
+        """Start moving one host batch to the GPU (include/fcn8s_hip.h: fcn8s_stage_inputs) and return a `Staged` handle that
+        train_step / eval_step / predict accept in place of the arrays.  images: uint8 or float32 array (N,H,W,3); label_ids:
+        uint8 class ids (N,H,W) or None.  Thread-safe against the compute calls of this engine (it only touches the staging slot
+        and the copy stream), so a feeder thread can stage batch k+1 while step k runs."""
+        a = np.asarray(images)
+        if a.ndim != 4 or a.shape[-1] != 3:
+            raise ValueError("images must be an array-like of rank 4 with shape (batch, height, width, 3)")
+        if a.dtype != np.uint8:
+            a = a.astype(np.float32, copy=False)
+        a = np.ascontiguousarray(a)
+        lab = None
+        if label_ids is not None:
+            lab = np.ascontiguousarray(label_ids, dtype=np.uint8)
+            if tuple(lab.shape) != tuple(a.shape[:3]):
+                raise ValueError("labels shape %s does not match images %s" % (tuple(lab.shape), tuple(a.shape[:3])))
+        pi, pl = C.c_void_p(), C.c_void_p()
+        N, H, W = (int(x) for x in a.shape[:3])
+        dt = L.IMG_U8 if a.dtype == np.uint8 else L.IMG_F32
+        L.check(L.lib.fcn8s_stage_inputs(self.h, int(slot), a.ctypes.data_as(C.c_void_p), dt,
+                                         lab.ctypes.data_as(C.c_void_p) if lab is not None else None, N, H, W, C.byref(pi), C.byref(pl)), self.h)
+        return Staged(int(slot), pi.value, pl.value, dt, (N, H, W))
+
+    def _release(self, ka):
+        if isinstance(ka, Staged):
+            L.check(L.lib.fcn8s_stage_release(self.h, ka.slot), self.h)
 
     # ---- hot path ----------------------------------------------------------------------------
     def freeze(self, frozen=True):
@@ -275,10 +321,13 @@ class Engine:
         if ws == 1 and optimizer == L.OPT_TF_ADAM:
             step = C.c_int64(0)
             L.check(L.lib.fcn8s_train_step(self.h, pi, dt, pl, N, H, W, float(learning_rate), float(keep_prob),
-                                           float(l2_rate), where, C.byref(loss) if fetch_loss else None,
-                                           C.byref(step)), self.h)
+                                           float(l2_rate), where, None, C.byref(step)), self.h)
+            self._release(ka)
+            if fetch_loss:
+                L.check(L.lib.fcn8s_read_loss(self.h, C.byref(loss)), self.h)
             return (float(loss.value) if fetch_loss else None), int(step.value)
         L.check(L.lib.fcn8s_forward_loss(self.h, pi, dt, pl, N, H, W, float(keep_prob), float(l2_rate), where), self.h)
+        self._release(ka)
         red = BucketReducer(self.flat_grads, self.buckets, self.pg)
         for b in range(L.NUM_BUCKETS):
             L.check(L.lib.fcn8s_backward_bucket(self.h, b), self.h)
@@ -296,6 +345,7 @@ class Engine:
         ka, pi, dt, pl, where, nhw = self._inputs(images, labels)
         N, H, W = (int(x) for x in nhw)
         L.check(L.lib.fcn8s_forward_loss(self.h, pi, dt, pl, N, H, W, float(keep_prob), float(l2_rate), where), self.h)
+        self._release(ka)
         for b in range(L.NUM_BUCKETS):
             L.check(L.lib.fcn8s_backward_bucket(self.h, b), self.h)
         loss = C.c_float(0.0)
@@ -312,6 +362,7 @@ class Engine:
         ka, pi, dt, pl, where, nhw = self._inputs(images, labels)
         N, H, W = (int(x) for x in nhw)
         L.check(L.lib.fcn8s_eval_step(self.h, pi, dt, pl, N, H, W, float(l2_rate), where), self.h)
+        self._release(ka)
 
     def metrics_reset(self):
         self._sync_stream()
@@ -336,9 +387,11 @@ class Engine:
         cm = t[:-2].round().long().numpy().reshape(cm.shape).astype(np.int64)
         L.check(L.lib.fcn8s_metrics_set_raw(self.h, np.ascontiguousarray(cm).ctypes.data_as(C.c_void_p), float(t[-2]), int(round(float(t[-1])))), self.h)
 
-    def metrics_get(self):
+    def metrics_get(self, all_classes=False):
+        """(mean loss, mean IoU, accuracy).  all_classes: average the IoU over all classes, absent ones counting 0 (what the
+        tutorial's TF 1.3.0 tf.metrics.mean_iou does) instead of over the classes that occur (later TF 1.x)."""
         a, b, c = C.c_double(), C.c_double(), C.c_double()
-        L.check(L.lib.fcn8s_metrics_get(self.h, C.byref(a), C.byref(b), C.byref(c)), self.h)
+        L.check(L.lib.fcn8s_metrics_get_ex(self.h, C.byref(a), C.byref(b), C.byref(c), 1 if all_classes else 0), self.h)
         return float(a.value), float(b.value), float(c.value)
 
     def augment(self, images, labels=None, out_hw=None, offsets=None, flips=None, gains=None, void_class_id=0):
@@ -377,13 +430,17 @@ class Engine:
     def predict(self, images, argmax=True):
         """sess.run(predictions_argmax | softmax_output) (fcn8s_tensorflow.py:764-770)."""
         self._sync_stream()
-        ka_i, pi, dt, where, nhw = self._images(images)
+        if isinstance(images, Staged):
+            ka_i, pi, dt, _, where, nhw = self._inputs(images, None)
+        else:
+            ka_i, pi, dt, where, nhw = self._images(images)
         N, H, W = (int(x) for x in nhw)
         torch = self.torch
         if where == L.DEVICE:
             out = torch.empty((N, H, W), dtype=torch.int64, device=self.device) if argmax else \
                 torch.empty((N, H, W, self.num_classes), dtype=torch.float32, device=self.device)
             L.check(L.lib.fcn8s_predict(self.h, pi, dt, N, H, W, int(bool(argmax)), C.c_void_p(out.data_ptr()), where), self.h)
+            self._release(ka_i)
             return out
         out = np.empty((N, H, W), np.int64) if argmax else np.empty((N, H, W, self.num_classes), np.float32)
         L.check(L.lib.fcn8s_predict(self.h, pi, dt, N, H, W, int(bool(argmax)), out.ctypes.data_as(C.c_void_p), where), self.h)

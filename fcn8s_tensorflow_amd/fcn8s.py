@@ -87,6 +87,9 @@ class FCN8s:
 
         self.variables_updated = False
         self.eval_dataset = None
+        # False: mean IoU over the classes that occur (tf.metrics.mean_iou of later TF 1.x); True: over all classes, absent ones
+        # counting 0 -- the TF 1.3.0 the tutorial ran on (fcn8s_tutorial.ipynb:311).  Not a reference argument; set it on the instance.
+        self.mean_iou_over_all_classes = False
 
         self.metric_names = []
         self.metric_values = []
@@ -247,9 +250,10 @@ class FCN8s:
         recent = deque(maxlen=window)
         bar = trange(steps, file=sys.stdout, disable=self.engine.rank != 0)
         bar.set_description(title)
+        feed = _Feeder(self.engine, generator, steps)        # batch k+1 is decoded / staged / copied while step k runs
         for _ in bar:
             lr = self._lr
-            images, labels = next(generator)
+            images, labels = feed.next()
             loss, self.g_step = self.engine.train_step(images, labels, learning_rate=lr, keep_prob=keep_prob, l2_rate=l2_rate)
             self.variables_updated = True
             if log is not None and (self.g_step - 1) % log_every == 0:
@@ -292,14 +296,15 @@ class FCN8s:
 
         self.engine.freeze(True)            # no training inside an evaluation loop: transformed filters are built once
         try:
+            feed = _Feeder(self.engine, data_generator, num_batches)
             for step in tr:
-                batch_images, batch_labels = next(data_generator)
+                batch_images, batch_labels = feed.next()
                 self.engine.eval_step(batch_images, batch_labels, l2_rate=l2_regularization)
         finally:
             self.engine.freeze(False)
 
         self.engine.metrics_allreduce()
-        values = dict(zip(('loss', 'mean_iou', 'accuracy'), self.engine.metrics_get()))
+        values = dict(zip(('loss', 'mean_iou', 'accuracy'), self.engine.metrics_get(all_classes=self.mean_iou_over_all_classes)))
         self.metric_values = [values[n] for n in self.metric_names]
 
         if self.engine.rank == 0:
@@ -346,28 +351,34 @@ class FCN8s:
         tr.set_description('Processing images')
 
         self.engine.freeze(True)            # constant weights for the whole directory
-        for i in tr:
-            filepath = image_paths[i]
-            pil = Image.open(filepath).convert('RGB')
-            if resize and not np.array_equal((pil.height, pil.width), resize):
-                pil = pil.resize((resize[1], resize[0]), Image.BILINEAR)
-            image = np.asarray(pil)
-            img_height, img_width, img_ch = image.shape
+        try:
+            for i in tr:
+                self._segment_file(image_paths[i], results_dir, color_map, resize, include_unprocessed_image, arrangement)
+        finally:
+            self.engine.freeze(False)
 
-            prediction = self.predict([image], argmax=False)
-            processed = print_segmentation_onto_image(image=image, prediction=prediction, color_map=color_map)
+    def _segment_file(self, filepath, results_dir, color_map, resize, include_unprocessed_image, arrangement):
+        '''Loop body of predict_and_save (fcn8s_tensorflow.py:829-855).'''
+        from PIL import Image
+        pil = Image.open(filepath).convert('RGB')
+        if resize and not np.array_equal((pil.height, pil.width), resize):
+            pil = pil.resize((resize[1], resize[0]), Image.BILINEAR)
+        image = np.asarray(pil)
+        img_height, img_width, img_ch = image.shape
 
-            if include_unprocessed_image:
-                if arrangement == 'vertical':
-                    canvas = Image.new('RGB', (img_width, 2 * img_height))
-                    canvas.paste(processed, (0, 0)); canvas.paste(pil, (0, img_height))
-                else:
-                    canvas = Image.new('RGB', (2 * img_width, img_height))
-                    canvas.paste(processed, (0, 0)); canvas.paste(pil, (img_width, 0))
-                processed = canvas
+        prediction = self.predict([image], argmax=False)
+        processed = print_segmentation_onto_image(image=image, prediction=prediction, color_map=color_map)
 
-            processed.save(os.path.join(results_dir, os.path.basename(filepath)))
-        self.engine.freeze(False)
+        if include_unprocessed_image:
+            if arrangement == 'vertical':
+                canvas = Image.new('RGB', (img_width, 2 * img_height))
+                canvas.paste(processed, (0, 0)); canvas.paste(pil, (0, img_height))
+            else:
+                canvas = Image.new('RGB', (2 * img_width, img_height))
+                canvas.paste(processed, (0, 0)); canvas.paste(pil, (img_width, 0))
+            processed = canvas
+
+        processed.save(os.path.join(results_dir, os.path.basename(filepath)))
 
     def save(self,
              model_save_dir,
@@ -418,8 +429,8 @@ class FCN8s:
             else:
                 os.makedirs(target, exist_ok=True)
                 _save_checkpoint(self.engine, os.path.join(target, 'variables.npz'))
-                _write_meta(target, self.engine, tags)
-                _prune_checkpoints(model_save_dir, keep=5)          # Saver(max_to_keep=5), :927-930
+                _write_meta(target, self.engine, tags)      # (the reference builds a fresh Saver per save() call, :927-934, so its
+                                                            #  max_to_keep=5 never deletes an earlier checkpoint: nothing is pruned here either)
         self.last_saved_model_name = model_name
 
         self.variables_updated = False
@@ -446,7 +457,12 @@ class FCN8s:
                 n = int(np.prod(shape))
                 tensors[k + tf_bundle.ADAM_M_SUFFIX] = m[off:off + n].reshape(shape)
                 tensors[k + tf_bundle.ADAM_V_SUFFIX] = v[off:off + n].reshape(shape)
-            tensors['optimizer/global_step'] = np.asarray(self.engine.global_step, dtype=np.int32)
+            step = self.engine.global_step
+            tensors['optimizer/global_step'] = np.asarray(step, dtype=np.int32)
+            # AdamOptimizer's non-slot variables (initialised to beta, multiplied by beta in every apply): a Saver over all
+            # saveable variables (load_variables, :943) would not restore without them
+            tensors['optimizer/beta1_power'] = np.asarray(0.9 ** (step + 1), dtype=np.float32)
+            tensors['optimizer/beta2_power'] = np.asarray(0.999 ** (step + 1), dtype=np.float32)
         tf_bundle.write_bundle(prefix, tensors)
 
     def close(self):
@@ -516,11 +532,42 @@ def _read_meta(model_dir):
         return json.load(fh)
 
 
-def _prune_checkpoints(save_dir, keep):
-    dirs = [d for d in glob(os.path.join(save_dir, 'saved_model*')) if os.path.isfile(os.path.join(d, 'variables.npz'))]
-    dirs.sort(key=os.path.getmtime)
-    for d in dirs[:-keep]:
-        shutil.rmtree(d, ignore_errors=True)
+class _Feeder:
+    """Pulls exactly `count` batches from a generator on a helper thread, one batch ahead of the consumer, and -- when the batch is
+    (uint8 images, uint8 class ids) -- already starts its host-to-device copy through a staging slot (Engine.stage), so that PNG
+    decoding, the pinned-memory copy and the DMA of batch k+1 overlap the GPU work of step k.  The reference pulls and feeds
+    serially inside the step loop (fcn8s_tensorflow.py:551-572).  Generators made by this package's BatchGenerator offer
+    `next_ids()` (the same batch with class ids instead of the 20x larger one-hot rows); any other generator is consumed through
+    next() and its arrays are fed as they are.  Exactly `count` batches are consumed, as in the reference's loops."""
+
+    def __init__(self, engine, generator, count):
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=1)
+        self.err = None
+
+        def work():
+            try:
+                pull = getattr(generator, 'next_ids', None)
+                for i in range(count):
+                    images, labels = pull() if pull is not None else next(generator)
+                    if (isinstance(images, np.ndarray) and images.dtype == np.uint8 and isinstance(labels, np.ndarray)
+                            and labels.dtype == np.uint8 and labels.ndim == 3 and images.ndim == 4):
+                        self.q.put((engine.stage(images, labels, slot=i % L.NUM_STAGE_SLOTS), None))
+                    else:
+                        self.q.put((images, labels))
+            except BaseException as e:          # surfaces in the consumer
+                self.err = e
+                self.q.put(None)
+
+        self.t = threading.Thread(target=work, daemon=True)
+        self.t.start()
+
+    def next(self):
+        item = self.q.get()
+        if item is None:
+            raise self.err
+        return item
 
 
 class _ScalarLog:

@@ -49,6 +49,7 @@ extern "C" {
 #define FCN8S_OPT_NONE         2  /* caller updates the parameter buffer itself (torch optimizer over views) */
 
 #define FCN8S_NUM_BUCKETS 3       /* gradient buckets in backward-production order */
+#define FCN8S_NUM_STAGE_SLOTS 3   /* host-input staging slots (fcn8s_stage_inputs) */
 
 #define FCN8S_PREC_F32     0      /* everything exact fp32 (the reference's arithmetic; default) */
 #define FCN8S_PREC_BF16_FC 1      /* BASELINE.json config 5: the forward fc6 / fc7 contractions take bf16-rounded operands on the
@@ -96,8 +97,9 @@ int    fcn8s_init_params(fcn8s_model* m, uint64_t seed);              /* synthet
 /* ---- labels: the reference feeds one-hot rows [N,H,W,C] (placeholder int32 :110, bool from the generator,
  * helpers/ground_truth_conversion_utils.py:84-88).  The kernels consume uint8 class ids; this converts a
  * DEVICE one-hot tensor (elem_bytes 1 = bool/uint8, 4 = int32/float32 bit patterns, non-zero = set) into
- * ids on the device: ids[p] = first c with onehot[p,c] != 0 (= np.argmax of a one-hot row).  `bad_count`
- * (device, may be NULL) receives the number of rows that are not one-hot.                                */
+ * ids on the device: ids[p] = first c with onehot[p,c] != 0 (= np.argmax of a one-hot row); an all-zero row becomes
+ * id 255.  Ids outside [0, C) contribute neither loss nor gradient (softmax_cross_entropy_with_logits of an all-zero
+ * row is 0, :253).  `bad_count` (device, may be NULL) is incremented by the number of rows that are not one-hot.       */
 int fcn8s_onehot_to_ids(void* stream, const void* onehot_dev, int elem_bytes, int64_t npix, int C,
                         uint8_t* ids_dev, int32_t* bad_count_dev);
 
@@ -119,11 +121,27 @@ int fcn8s_backward_bucket(fcn8s_model* m, int bucket);
 int fcn8s_apply_update(fcn8s_model* m, int optimizer, float learning_rate, float grad_scale);
 int fcn8s_read_loss(fcn8s_model* m, float* loss_out);                /* synchronises */
 
+/* ---- asynchronous host boundary (the reference's feed_dict copies, :558-560, are synchronous inside sess.run) ----------------
+ * fcn8s_stage_inputs copies one host batch (images [N,H,W,3] uint8/float32, optional uint8 class ids [N,H,W]) into pinned
+ * staging memory and starts the host-to-device copy on the model's own copy stream; it returns as soon as the copy is queued and
+ * may be called from a feeder thread while the model's stream is busy with the previous step.  The device pointers it returns
+ * are then fed to fcn8s_train_step / fcn8s_eval_step / fcn8s_predict with where = FCN8S_DEVICE, bracketed by fcn8s_stage_wait
+ * (the model's stream waits for the copy) and fcn8s_stage_release (marks the point after which the slot may be refilled).
+ * FCN8S_NUM_STAGE_SLOTS slots; refilling a slot waits for its previous release.                                              */
+int fcn8s_stage_inputs(fcn8s_model* m, int slot, const void* images, int image_dtype, const uint8_t* label_ids,
+                       int N, int H, int W, void** images_dev, uint8_t** labels_dev);
+int fcn8s_stage_wait(fcn8s_model* m, int slot);
+int fcn8s_stage_release(fcn8s_model* m, int slot);
+
 /* ---- evaluation: sess.run(metric_update_ops) :685-689; reset :674; values :692 */
 int fcn8s_eval_step(fcn8s_model* m, const void* images, int image_dtype, const uint8_t* label_ids,
                     int N, int H, int W, float l2_rate, int where);
 int fcn8s_metrics_reset(fcn8s_model* m);
 int fcn8s_metrics_get(fcn8s_model* m, double* mean_loss, double* mean_iou, double* accuracy);
+/* all_classes != 0: mean IoU over ALL classes, an absent class counting as IoU 0 -- what tf.metrics.mean_iou of the tutorial's
+ * TensorFlow 1.3.0 computes (fcn8s_tensorflow.py:291-293, fcn8s_tutorial.ipynb:311); 0: mean over the classes that occur in the
+ * labels or the predictions (later TF 1.x; = fcn8s_metrics_get).  Identical whenever every class occurs.                        */
+int fcn8s_metrics_get_ex(fcn8s_model* m, double* mean_loss, double* mean_iou, double* accuracy, int all_classes);
 /* raw accumulators (for cross-rank reduction): confusion[C*C] row = label, col = prediction */
 int fcn8s_metrics_raw(fcn8s_model* m, int64_t* confusion, double* loss_sum, int64_t* loss_count);
 int fcn8s_metrics_set_raw(fcn8s_model* m, const int64_t* confusion, double loss_sum, int64_t loss_count);

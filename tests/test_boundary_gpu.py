@@ -1,0 +1,139 @@
+"""The boundary around the hot path on the GPU: asynchronous host staging, the frozen-parameter guard, bench.py as the
+driver calls it (self-launching ranks, end-to-end mode), and the LDS-DMA GEMM kernels at every tile configuration."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fcn8s_oracle as orc  # noqa: E402  (checker only)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = (8, 16, 32, 64, 64, 128, 128)
+
+
+def _engine(widths=SMALL, seed=0):
+    from fcn8s_tensorflow_amd.engine import Engine
+    return Engine(20, widths=widths, device_id=0, seed=seed)
+
+
+def _batch(n, h, w, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8), rng.integers(0, 20, (n, h, w), dtype=np.uint8)
+
+
+def test_staged_inputs_equal_direct_inputs():
+    """fcn8s_stage_inputs / stage_wait / stage_release: a batch that travels through a pinned staging slot and the copy stream
+    gives bit-identical results to the same batch passed as host arrays, slots can be refilled while earlier steps are queued,
+    and staging from another thread works (what the facade's feeder does)."""
+    import threading
+    P = orc.init_params(20, SMALL, seed=1, decoder_std_scale=30.0, bias_std=0.05)
+    a, b = _engine(), _engine()
+    a.set_params(P); b.set_params(P)
+    batches = [_batch(2, 32, 64, s) for s in range(5)]
+    staged = [None] * len(batches)
+
+    def feeder():
+        for i, (img, lab) in enumerate(batches[:3]):
+            staged[i] = b.stage(img, lab, slot=i % 3)
+    t = threading.Thread(target=feeder); t.start(); t.join()
+    for i, (img, lab) in enumerate(batches):
+        la, sa = a.train_step(img, lab, 1e-3, keep_prob=1.0)
+        if staged[i] is None:
+            staged[i] = b.stage(img, lab, slot=i % 3)          # refills a slot whose previous batch has been consumed
+        lb, sb = b.train_step(staged[i], None, 1e-3, keep_prob=1.0)
+        assert la == lb and sa == sb
+    np.testing.assert_array_equal(a.flat_params.cpu().numpy(), b.flat_params.cpu().numpy())
+    img, lab = batches[0]
+    st = b.stage(img, None, slot=0)                              # images only: predict
+    np.testing.assert_array_equal(a.predict(img), b.predict(st).cpu().numpy())
+    a.metrics_reset(); b.metrics_reset()
+    a.eval_step(img, lab); b.eval_step(b.stage(img, lab, slot=1), None)
+    np.testing.assert_array_equal(a.metrics_raw()[0], b.metrics_raw()[0])
+    with pytest.raises(Exception):
+        b.stage(img, lab[:, :16], slot=0)
+    a.close(); b.close()
+
+
+def test_frozen_parameters_survive_a_write_through_the_side_door():
+    """A torch write into the external parameter buffer while frozen (what a torch optimizer over views would do) is caught by the
+    fingerprint guard: the next forward pass rebuilds the cached Winograd filter banks instead of using stale ones."""
+    P = orc.init_params(20, SMALL, seed=3, decoder_std_scale=30.0, bias_std=0.05)
+    img, _ = _batch(1, 128, 160, 0)
+    e = _engine(); e.set_params(P)
+    e.freeze(True)
+    before = e.predict(img, argmax=False)
+    np.testing.assert_array_equal(e.predict(img, argmax=False), before)      # cached banks in use
+    e.flat_params.mul_(1.01)                                                 # the side door: no library call, no freeze(False)
+    after = e.predict(img, argmax=False)
+    e2 = _engine(); e2.flat_params.copy_(e.flat_params)
+    np.testing.assert_array_equal(after, e2.predict(img, argmax=False))      # = a model that never cached anything
+    assert np.abs(after - before).max() > 0
+    e.close(); e2.close()
+
+
+def _run_bench(*args, timeout=600):
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` without torchrun, exactly as the driver calls it for N > 1 (the ranks share this box's one GPU and
+    exchange over gloo; on the 8-GPU node the same path runs one rank per GPU over RCCL)."""
+    out = _run_bench("--gpus", "2", "--backend", "gloo", "--device", "0", "--steps", "2", "--warmup", "1", "--batch", "2",
+                     "--height", "64", "--width", "64", "--no-cpu-baseline")
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert out["comm"]["rccl_ranks"] == 2 and len(out["comm"]["allreduce_ms_per_bucket_standalone"]) == 3
+    assert out["value"] > 0 and np.isfinite(out["final_loss"])
+
+
+def test_bench_single_gpu_line_and_end_to_end_mode():
+    out = _run_bench("--steps", "2", "--warmup", "1", "--batch", "2", "--height", "64", "--width", "64", "--no-cpu-baseline")
+    assert out["n_gpus"] == 1 and out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
+    out = _run_bench("--mode", "e2e", "--steps", "2", "--warmup", "1", "--batch", "2", "--height", "64", "--width", "64", "--workers", "2")
+    assert out["value"] > 0 and out["resident_input_images_per_sec"] > 0 and "end to end" in out["metric"]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [
+    (1, 15, 20, 256, 128),      # M = 300: <64,64> tiles, rows clamped in the last tile
+    (1, 160, 161, 64, 128),     # M = 25 760: <128,128> tiles (>= 200 blocks), last tile partial
+    (1, 160, 161, 128, 64),     # Cout = 64: <128,64> tiles
+    (2, 40, 41, 512, 128),      # <64,128> tiles (between 200 blocks of 64x128 and 200 of 128x128)
+    (1, 7, 9, 4096, 256),       # long K (256 K-tiles), few rows
+])
+def test_plain_row_gemm_kernels(N, H, W, Cin, Cout):
+    """1x1 convolutions are the plain-row GEMMs of the LDS-DMA kernels (gemm_glds_kernel forward / data gradient with the fused
+    bias + ReLU epilogue, wgrad_glds_kernel for the weight gradient, including its register-path K tail when the row count is
+    not a multiple of 16): against a float64 oracle, fp32 summation-order tolerance."""
+    from fcn8s_tensorflow_amd import _lib as L
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((1, 1, Cin, Cout)) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    dy = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    x64, w64 = x.reshape(-1, Cin).astype(np.float64), w.reshape(Cin, Cout).astype(np.float64)
+    y_ref = x64 @ w64 + b
+    dx_ref = dy.reshape(-1, Cout).astype(np.float64) @ w64.T
+    dw_ref = x64.T @ dy.reshape(-1, Cout).astype(np.float64)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    y_, dx_, dw_, db_ = torch.empty(N, H, W, Cout).cuda(), torch.empty(N, H, W, Cin).cuda(), torch.empty(1, 1, Cin, Cout).cuda(), torch.empty(Cout).cuda()
+    L.check(L.lib.fcn8s_op_conv2d(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), N, H, W, Cin, Cout, 1, 1))
+    L.check(L.lib.fcn8s_op_conv2d_bwd(None, ptr(xd), ptr(wd), ptr(dyd), ptr(dx_), ptr(dw_), ptr(db_), N, H, W, Cin, Cout, 1))
+    torch.cuda.synchronize()
+    rel = lambda a, r: float(np.abs(a.astype(np.float64) - r).max() / (np.abs(r).max() + 1e-30))
+    assert rel(y_.cpu().numpy().reshape(-1, Cout), np.maximum(y_ref, 0)) < 2e-5
+    assert rel(dx_.cpu().numpy().reshape(-1, Cin), dx_ref) < 2e-5
+    assert rel(dw_.cpu().numpy().reshape(Cin, Cout), dw_ref) < 2e-5
+    assert rel(db_.cpu().numpy(), dy.reshape(-1, Cout).astype(np.float64).sum(0)) < 2e-5

@@ -110,3 +110,39 @@ def test_prefetch_wrapper_preserves_order_and_errors(dataset):
     assert next(p) == 1
     with pytest.raises(KeyError):
         next(p)
+
+
+def _png_tree(tmp_path, n=5, h=16, w=24, C=20):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    (tmp_path / 'img' / 'a').mkdir(parents=True); (tmp_path / 'gt' / 'a').mkdir(parents=True)
+    for i in range(n):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(tmp_path / 'img' / 'a' / ('f%d_x.png' % i))
+        Image.fromarray(rng.integers(0, C, (h, w), dtype=np.uint8)).save(tmp_path / 'gt' / 'a' / ('f%d_gt.png' % i))
+    from fcn8s_tensorflow_amd.batch_generator import BatchGenerator
+    return lambda: BatchGenerator([str(tmp_path / 'img')], 'png', [str(tmp_path / 'gt')], '_x', '_gt', True, C)
+
+
+def test_worker_processes_and_class_id_batches_do_not_change_what_a_seeded_run_yields(tmp_path):
+    """`workers` moves decoding / augmentation into processes, `next_ids()` skips the one-hot expansion: with the same seeds both
+    give the batches the serial, one-hot generator gives (the random decisions are drawn in the parent, in the reference's order)."""
+    import random
+    make = _png_tree(tmp_path)
+    kw = dict(batch_size=2, random_crop=(12, 20), brightness=(0.5, 2.0, 0.5), flip=0.5, translate=((0, 3), (0, 3), 0.5),
+              scale=(0.7, 1.3, 0.5), void_class_id=0, shuffle=True)
+
+    def run(workers, ids):
+        random.seed(5); np.random.seed(5)
+        g = make().generate(workers=workers, **kw)
+        out = [g.next_ids() if ids else next(g) for _ in range(4)]         # wraps around once (5 files, batches of 2: 2, 2, 1, 2)
+        g.close()
+        return out
+    serial = run(0, False)
+    assert [b[0].shape[0] for b in serial] == [2, 2, 1, 2]
+    assert serial[0][1].dtype == bool and serial[0][1].shape == (2, 12, 20, 20)
+    for other, ids in ((run(2, False), False), (run(0, True), True), (run(2, True), True)):
+        for (i0, g0), (i1, g1) in zip(serial, other):
+            np.testing.assert_array_equal(i0, i1)
+            np.testing.assert_array_equal(np.argmax(g0, -1).astype(np.uint8), g1 if ids else np.argmax(g1, -1).astype(np.uint8))
+            if ids:
+                assert g1.dtype == np.uint8 and g1.ndim == 3

@@ -211,29 +211,73 @@ def test_tf_adam_training_steps():
 
 
 def test_eval_metrics():
+    """Streaming metrics (fcn8s_tensorflow.py:273-322).  Integer work is exact: the confusion matrix the library accumulates equals
+    the one built from its own per-pixel predictions; those predictions equal the oracle's wherever the oracle's top-2 softmax
+    margin exceeds 1e-4 and are one of the oracle's two best classes elsewhere; mean IoU / accuracy follow the reference's
+    formulas exactly on that matrix and differ from the oracle's values by no more than the near-tie pixels can move them."""
     widths = SMALL
     P = orc.init_params(20, widths, seed=7, decoder_std_scale=30.0, bias_std=0.05)
     e = make_engine(widths)
     e.set_params(P)
     sm = orc.StreamingMetrics(20)
     e.metrics_reset()
+    cm_own = np.zeros((20, 20), np.int64)
+    n_unsafe = 0
     for i, n in enumerate((2, 1, 2)):            # ragged batches: the per-batch loss mean weighs them equally
         img, lab = batch(n, 32, 64, seed=20 + i)
         lab[:, :, :16] = 3                        # leave some classes absent from the ground truth
         e.eval_step(img, orc.one_hot(lab, 20))
         loss, l, p = orc.eval_step(P, img, orc.one_hot(lab, 20).astype(np.float32))
         sm.update(loss, l, p)
+        pred = e.predict(img, argmax=True)        # the same forward pass, per pixel
+        soft = orc.softmax(orc.forward(P, img))
+        order = np.argsort(soft, -1)
+        safe = (np.take_along_axis(soft, order[..., -1:], -1) - np.take_along_axis(soft, order[..., -2:-1], -1))[..., 0] > 1e-4
+        assert (pred[safe] == p[safe]).all()
+        assert ((pred == order[..., -1]) | (pred == order[..., -2]))[~safe].all()
+        n_unsafe += int((~safe).sum())
+        cm_own += orc.confusion_matrix(lab, pred, 20)
     loss, miou, acc = e.metrics_get()
     rl, rm, ra = sm.values()
     cm, _, cnt = e.metrics_raw()
-    assert cnt == 3 and cm.sum() == 5 * 32 * 64
+    total = 5 * 32 * 64
+    assert cnt == 3 and cm.sum() == total
     assert abs(loss - rl) < 1e-4 * max(1, abs(rl))
-    mism = np.abs(cm - sm.cm).sum()
-    assert mism <= 0.002 * cm.sum()               # only near-tie pixels may differ
-    if mism == 0:
-        assert abs(miou - rm) < 1e-12 and abs(acc - ra) < 1e-12
+    np.testing.assert_array_equal(cm, cm_own)                                       # bit-exact counting
+    assert abs(miou - orc.mean_iou_from_confusion(cm)) < 1e-12                      # the reference's formulas on that matrix
+    assert abs(acc - orc.accuracy_from_confusion(cm)) < 1e-12
+    assert n_unsafe <= 0.002 * total
+    assert abs(acc - ra) <= n_unsafe / total + 1e-12                                # a near-tie pixel moves accuracy by at most 1/total
+    assert abs(miou - rm) <= 1e-12 if n_unsafe == 0 else abs(miou - rm) < 5e-3
+    # TF 1.3.0's variant (SURVEY a5): absent classes count as IoU 0 in the mean
+    _, miou_all, _ = e.metrics_get(all_classes=True)
+    assert abs(miou_all - orc.mean_iou_from_confusion(cm, valid_only=False)) < 1e-12
+    assert miou_all < miou                                                           # some classes are absent here
     e.metrics_reset()
     assert e.metrics_raw()[0].sum() == 0
+    e.close()
+
+
+def test_out_of_range_label_ids_are_ignored():
+    """Ids outside [0, C) -- a 255 'ignore' id, or the id an all-zero one-hot row is given -- contribute neither loss nor
+    gradient (TF's softmax_cross_entropy_with_logits of an all-zero row is 0, fcn8s_tensorflow.py:253)."""
+    widths = SMALL
+    P = orc.init_params(20, widths, seed=2, decoder_std_scale=30.0, bias_std=0.05)
+    img, lab = batch(2, 32, 64, seed=9)
+    onehot = orc.one_hot(lab, 20).astype(np.float32)
+    hole = np.zeros(lab.shape, bool); hole[:, 5:20, 10:40] = True
+    onehot[hole] = 0.0                            # all-zero rows
+    lab_ign = lab.copy(); lab_ign[hole] = 255
+    e = make_engine(widths)
+    e.set_params(P)
+    loss_ids = e.forward_backward(img, lab_ign, keep_prob=1.0)
+    g_ids = e.get_grads()
+    loss_ref, g_ref, _ = orc.loss_and_grads(P, img, onehot)
+    assert abs(loss_ids - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    # TF's fused kernel returns softmax - labels as the gradient even for an all-zero row (it assumes rows sum to 1); the true
+    # derivative of -sum(labels * log_softmax) is zero there, which is what autograd (the oracle) and the library compute
+    for k in g_ref:
+        assert rel(g_ids[k], g_ref[k]) < 2e-3, k
     e.close()
 
 
