@@ -30,8 +30,9 @@ def _batch(n, h, w, seed):
 
 def test_staged_inputs_equal_direct_inputs():
     """fcn8s_stage_inputs / stage_wait / stage_release: a batch that travels through a pinned staging slot and the copy stream
-    gives bit-identical results to the same batch passed as host arrays, slots can be refilled while earlier steps are queued,
-    and staging from another thread works (what the facade's feeder does)."""
+    gives the results of the same batch passed as host arrays (bit-identical on the deterministic forward path; to round-off
+    for the gradients, whose weight-gradient atomics commute only up to fp32 summation order), slots can be refilled
+    while earlier steps are queued, and staging from another thread works (what the facade's feeder does)."""
     import threading
     P = orc.init_params(20, SMALL, seed=1, decoder_std_scale=30.0, bias_std=0.05)
     a, b = _engine(), _engine()
@@ -44,12 +45,17 @@ def test_staged_inputs_equal_direct_inputs():
             staged[i] = b.stage(img, lab, slot=i % 3)
     t = threading.Thread(target=feeder); t.start(); t.join()
     for i, (img, lab) in enumerate(batches):
-        la, sa = a.train_step(img, lab, 1e-3, keep_prob=1.0)
         if staged[i] is None:
             staged[i] = b.stage(img, lab, slot=i % 3)          # refills a slot whose previous batch has been consumed
-        lb, sb = b.train_step(staged[i], None, 1e-3, keep_prob=1.0)
-        assert la == lb and sa == sb
-    np.testing.assert_array_equal(a.flat_params.cpu().numpy(), b.flat_params.cpu().numpy())
+        la = a.forward_backward(img, lab, keep_prob=1.0)
+        lb = b.forward_backward(staged[i], None, keep_prob=1.0)
+        assert la == lb, (i, la, lb)                           # same weights, same batch: the forward pass is deterministic
+        ga, gb = a.flat_grads, b.flat_grads
+        assert float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max())      # (weight-gradient atomics: summation order only)
+    la, sa = a.train_step(batches[0][0], batches[0][1], 1e-3, keep_prob=1.0)
+    lb, sb = b.train_step(b.stage(batches[0][0], batches[0][1], slot=2), None, 1e-3, keep_prob=1.0)
+    assert la == lb and sa == sb == 1
+    b.flat_params.copy_(a.flat_params)
     img, lab = batches[0]
     st = b.stage(img, None, slot=0)                              # images only: predict
     np.testing.assert_array_equal(a.predict(img), b.predict(st).cpu().numpy())

@@ -163,20 +163,20 @@ def test_config3_training_step_1024x512_bs16_properties():
     assert torch.equal(p1, p2)
 
     # (4) full-size directional-derivative check of the whole backward pass through a 4-image batch: a CENTRAL difference
-    #     along g, (L(theta - eps g) - L(theta + eps g)) / (2 eps |g|^2), equals 1 up to the third-order term, so the step can be
+    #     along g, (L(theta + eps g) - L(theta - eps g)) / (2 eps |g|^2), equals 1 up to the third-order term, so the step can be
     #     large enough for the fp32 loss resolution (2.4e-7) not to matter
     e.forward_backward(imgd[:4], labd[:4], keep_prob=1.0)
     g = e.flat_grads.clone()
     theta = e.flat_params.clone()                       # torch view of the library's parameter buffer
     norm2 = float((g.double() ** 2).sum())
     ratios = []
-    for target in (1e-4, 3e-4, 1e-3):                   # intended first-order loss change
+    for target in (2e-5, 4e-5, 6e-5):                   # intended first-order loss change (at 1e-4 the third-order term is already 3 %)
         eps = target / norm2
         e.flat_params.copy_(theta - eps * g)
         lm = e.forward_backward(imgd[:4], labd[:4], keep_prob=1.0)
         e.flat_params.copy_(theta + eps * g)
         lp = e.forward_backward(imgd[:4], labd[:4], keep_prob=1.0)
-        ratios.append((lm - lp) / (2 * target))
+        ratios.append((lp - lm) / (2 * target))
     e.flat_params.copy_(theta)
     print("config 3 directional derivative ratios:", ratios)
     assert any(0.97 < r < 1.03 for r in ratios), ratios

@@ -252,7 +252,17 @@ def test_eval_metrics():
     # TF 1.3.0's variant: absent classes count as IoU 0 in the mean
     _, miou_all, _ = e.metrics_get(all_classes=True)
     assert abs(miou_all - orc.mean_iou_from_confusion(cm, valid_only=False)) < 1e-12
-    assert miou_all < miou                                                           # some classes are absent here
+    # ... which differs from the valid-class mean as soon as a class occurs neither in the labels nor in the predictions
+    import ctypes as C
+    from fcn8s_tensorflow_amd import _lib as L
+    cm2 = cm.copy(); cm2[7, :] = 0; cm2[:, 7] = 0; cm2[12, :] = 0; cm2[:, 12] = 0
+    L.check(L.lib.fcn8s_metrics_set_raw(e.h, np.ascontiguousarray(cm2).ctypes.data_as(C.c_void_p), 1.5, 3), e.h)
+    l2, miou_valid, acc2 = e.metrics_get()
+    _, miou_all, _ = e.metrics_get(all_classes=True)
+    assert l2 == 0.5
+    assert abs(miou_valid - orc.mean_iou_from_confusion(cm2, valid_only=True)) < 1e-12
+    assert abs(miou_all - orc.mean_iou_from_confusion(cm2, valid_only=False)) < 1e-12
+    assert abs(miou_all - miou_valid * 18 / 20) < 1e-12
     e.metrics_reset()
     assert e.metrics_raw()[0].sum() == 0
     e.close()
