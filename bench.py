@@ -54,17 +54,31 @@ def _median(xs):
     return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
 
 
-def cpu_baseline(h, w, seconds_budget=150.0, optimizer="sgd"):
+def cpu_baseline(h, w, seconds_budget=200.0, optimizer="sgd"):
     """CPU restatement of the reference graph (oracle, kind 'port'), timed on this host's cores as BASELINE.md section 3 /
     SURVEY 8d prescribe: (c1) one 256x256 image forward + argmax, (c2) one 1024x512 image forward, (c3) bs1 training steps
     (fwd + bwd + the same optimizer as the GPU run) at the bench resolution -- each leg 1 warm-up + up to 3 timed runs,
     median reported; `value` is the training leg.  TF1 itself is not installable here."""
     import torch
     from oracle import fcn8s_oracle as orc
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     P = orc.init_params(20, seed=0)
     t_start = time.perf_counter()
+    img1 = np.random.default_rng(7).integers(0, 256, (1, 256, 256, 3), dtype=np.uint8)      # SURVEY 8d: c1 = one 256x256 image, seed 7
+    # thread count: torch-CPU on one image does not scale to every hardware thread of a large host (256 threads made the 256x256
+    # forward pass take 10 s); pick the fastest of a few counts on the small leg and use it for all legs -- `cores` reports it
+    cands = sorted({c for c in (ncpu, ncpu // 2, ncpu // 4, 64, 32, 16) if 1 <= c <= ncpu}, reverse=True)
+    best = (None, 1e30)
+    for c in cands:
+        torch.set_num_threads(c)
+        orc.forward(P, img1)
+        a = time.perf_counter(); orc.forward(P, img1); d = time.perf_counter() - a
+        if d < best[1]:
+            best = (c, d)
+        if time.perf_counter() - t_start > 40.0:
+            break
+    cores = best[0]
+    torch.set_num_threads(cores)
 
     def timed(fn, max_runs=3, leg_budget=30.0):
         fn()                                   # warm-up (thread pool, oneDNN primitive caches, page faults)
@@ -73,7 +87,6 @@ def cpu_baseline(h, w, seconds_budget=150.0, optimizer="sgd"):
             a = time.perf_counter(); fn(); ts.append(time.perf_counter() - a)
         return ts
 
-    img1 = np.random.default_rng(7).integers(0, 256, (1, 256, 256, 3), dtype=np.uint8)      # c1 = one 256x256 image, seed 7
     t_c1 = timed(lambda: np.argmax(orc.softmax(orc.forward(P, img1)), -1), leg_budget=10.0)
     img, lab = orc.synthetic_batch(1, h, w)
     t_c2 = timed(lambda: orc.forward(P, img), leg_budget=25.0)
@@ -91,9 +104,9 @@ def cpu_baseline(h, w, seconds_budget=150.0, optimizer="sgd"):
                 Pc[k], m[k] = orc.sgd_momentum_step(Pc[k], g[k], m[k], 1e-4)
 
     left = seconds_budget - (time.perf_counter() - t_start)
-    t_c3 = timed(train_step, leg_budget=max(left * 0.7, 1.0))
+    t_c3 = timed(train_step, leg_budget=max(left * 0.78, 1.0))
     med = _median(t_c3)
-    return {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+    return {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": cores, "host_threads_available": ncpu, "kind": "port",
             "sample": "bs1 training step (fwd+bwd+%s) of one %dx%d image on torch-CPU fp32: 1 warm-up + %d timed, median %.1f s "
                       "(CPU restatement of the reference graph; TF1 unavailable)"
                       % ("TF-Adam" if optimizer == "adam" else "SGD+momentum", w, h, len(t_c3), med),

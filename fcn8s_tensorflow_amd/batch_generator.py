@@ -141,6 +141,81 @@ def _process_sample(task):
     return BatchGenerator._apply(image, gt, draw, conv['void_class_id'], conv['random_crop'], conv['crop'], conv['resize'], conv['gray'])
 
 
+class _WorkerPool:
+    """N decode subprocesses (fcn8s_tensorflow_amd._feed_worker) + /dev/shm batch buffers they fill in place."""
+
+    def __init__(self, n):
+        import subprocess
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ)
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        env["OMP_NUM_THREADS"] = "1"
+        self.procs = [subprocess.Popen([sys.executable, "-m", "fcn8s_tensorflow_amd._feed_worker"], stdin=subprocess.PIPE,
+                                       stdout=subprocess.PIPE, env=env) for _ in range(int(n))]
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+        import tempfile
+        self.dir = tempfile.mkdtemp(prefix="fcn8s_feed_%d_" % os.getpid(), dir=shm)
+        self.shapes = None            # (image shape, gt shape or None) of one sample, learnt from the first batch
+        self.slot = 0
+        self.maps = {}
+
+    def _buffer(self, slot, nbytes):
+        key = (slot, nbytes)
+        if key not in self.maps:
+            path = os.path.join(self.dir, "slot%d_%d" % (slot, nbytes))
+            with open(path, "wb") as f:
+                f.truncate(nbytes)
+            self.maps[key] = (path, np.memmap(path, dtype=np.uint8, mode="r+"))
+        return self.maps[key]
+
+    def run(self, tasks):
+        from ._feed_worker import _read, _write
+        n = len(tasks)
+        dests = [None] * n
+        buf = None
+        if self.shapes is not None and n:
+            ishape, gshape = self.shapes
+            isz = int(np.prod(ishape)); gsz = int(np.prod(gshape)) if gshape is not None else 0
+            self.slot = (self.slot + 1) % 2
+            path, buf = self._buffer(self.slot, max(1, n * (isz + gsz)))
+            dests = [(path, i * isz, ishape, n * isz + i * gsz, gshape) for i in range(n)]
+        # deal the samples round-robin, then collect in order (each worker answers its tasks in the order it got them)
+        for i, t in enumerate(tasks):
+            _write(self.procs[i % len(self.procs)].stdin, (t, dests[i]))
+        images, gts = [None] * n, [None] * n
+        for i in range(n):
+            r = _read(self.procs[i % len(self.procs)].stdout)
+            if r is None:
+                raise RuntimeError("a BatchGenerator decode worker died")
+            if r[0] == "err":
+                raise RuntimeError("BatchGenerator decode worker: " + r[1])
+            if r[0] == "arr":
+                images[i], gts[i] = r[1], r[2]
+            else:
+                _, ioff, ishape, goff, gshape = dests[i]
+                images[i] = buf[ioff:ioff + int(np.prod(ishape))].reshape(ishape)
+                gts[i] = buf[goff:goff + int(np.prod(gshape))].reshape(gshape) if gshape is not None else None
+        if n and images[0] is not None:
+            self.shapes = (tuple(images[0].shape), tuple(gts[0].shape) if gts[0] is not None else None)
+        return images, gts
+
+    def close(self):
+        for p in self.procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=2)
+            except Exception:
+                p.kill()
+        self.procs = []
+        self.maps = {}
+        import shutil
+        shutil.rmtree(self.dir, ignore_errors=True)
+
+
 class _BatchIterator:
     """What `BatchGenerator.generate()` returns: the reference's infinite generator (`next()` / `for`) plus `next_ids()`, which
     yields the same batch with uint8 class-id maps (n,H,W) instead of the bool one-hot rows (n,H,W,C) -- 1/20 of the bytes; the
@@ -152,8 +227,7 @@ class _BatchIterator:
         self.current = 0
         self.pool = None
         if workers and workers > 0:
-            import multiprocessing as mp
-            self.pool = mp.get_context('forkserver').Pool(int(workers))    # forkserver: the workers never inherit a HIP context
+            self.pool = _WorkerPool(workers)
         if shuffle:
             random.shuffle(owner.image_paths)
 
@@ -168,14 +242,17 @@ class _BatchIterator:
             self.current = 0
         paths = o.image_paths[self.current:self.current + self.batch_size]       # short at the end of a pass
         self.current += self.batch_size
-        needs_size = bool(self.aug['random_crop'] or self.aug['scale'])
+        needs_size = bool(self.aug['random_crop'])
         tasks = []
         for image_path in paths:
             h, w = _image_size(image_path) if needs_size else (0, 0)
             draw = BatchGenerator._draw(h, w, **self.aug)
             gt_path = o.ground_truth_paths[os.path.basename(image_path)] if o.ground_truth else None
             tasks.append((image_path, gt_path, draw, self.conv))
-        results = self.pool.map(_process_sample, tasks) if self.pool is not None else [_process_sample(t) for t in tasks]
+        if self.pool is not None:
+            images, gts = self.pool.run(tasks)
+            return paths, images, gts
+        results = [_process_sample(t) for t in tasks]
         return paths, [r[0] for r in results], [r[1] for r in results]
 
     def _finish(self, paths, images, gts, one_hot):
@@ -199,7 +276,7 @@ class _BatchIterator:
 
     def close(self):
         if self.pool is not None:
-            self.pool.terminate()
+            self.pool.close()
             self.pool = None
 
     def __del__(self):
