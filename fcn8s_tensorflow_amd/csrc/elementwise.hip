@@ -553,6 +553,84 @@ void launch_augment_u8(const unsigned char* img, const unsigned char* lab, unsig
 }
 
 
+// ---- GPU-side resampling augmentations of a uint8 batch: resize, random scale, translate of
+// data_generator/batch_generator.py:328-384 in one kernel.  Per image n: the source [H,W] is (virtually) resized to [rh,rw] --
+// images with the triangle filter whose support grows with the shrink factor (what Pillow's BILINEAR resize, the repo's host
+// path, computes: horizontal pass rounded to 8 bits, then the vertical pass), labels by nearest neighbour -- and placed with its
+// top-left corner at (oy,ox) of the [Ho,Wo] output (negative = crop); pixels not covered get 0 / void_id.
+//   resize to (h',w')        : rh = Ho = h', rw = Wo = w', offset 0
+//   scale by f <= 1 / f > 1  : rh = int(H f), rw = int(W f), offset = +/- |int((H - rh) / 2)| ...
+//   translate by (dx,dy)     : rh = H, rw = W (exact copy), offset = (dy,dx)
+// ytab / xtab (optional, [N][tab_stride]): source row / column of each resized row / column for the nearest-neighbour path, as the
+// host computes them (a running double sum, so that exact .0 boundaries fall as they do there); NULL = floor((r + 0.5) * H / rh).
+__global__ __launch_bounds__(256) void resample_u8_kernel(const unsigned char* __restrict__ img, const unsigned char* __restrict__ lab,
+                                                          unsigned char* __restrict__ oimg, unsigned char* __restrict__ olab,
+                                                          const int* __restrict__ params, const int* __restrict__ ytab, const int* __restrict__ xtab,
+                                                          int tab_stride, int N, int H, int W, int Ho, int Wo, int void_id)
+{
+    const long long total = (long long)N * Ho * Wo;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo); const long long r = i / Wo;
+        const int y = (int)(r % Ho), n = (int)(r / Ho);
+        const int rh = params[4 * n], rw = params[4 * n + 1], oy = params[4 * n + 2], ox = params[4 * n + 3];
+        const int ry = y - oy, rx = x - ox;
+        if ((unsigned)ry >= (unsigned)rh || (unsigned)rx >= (unsigned)rw) {
+            if (oimg) { oimg[i * 3] = 0; oimg[i * 3 + 1] = 0; oimg[i * 3 + 2] = 0; }
+            if (olab) olab[i] = (unsigned char)void_id;
+            continue;
+        }
+        if (olab) {
+            const float sy = (float)H / (float)rh, sx = (float)W / (float)rw;
+            int ly = ytab ? ytab[(long long)n * tab_stride + ry] : (int)(((float)ry + 0.5f) * sy);
+            int lx = xtab ? xtab[(long long)n * tab_stride + rx] : (int)(((float)rx + 0.5f) * sx);
+            ly = ly < 0 ? 0 : (ly >= H ? H - 1 : ly); lx = lx < 0 ? 0 : (lx >= W ? W - 1 : lx);
+            olab[i] = lab[((long long)n * H + ly) * W + lx];
+        }
+        if (!oimg) continue;
+        if (rh == H && rw == W) {
+            const long long src = (((long long)n * H + ry) * W + rx) * 3;
+            oimg[i * 3] = img[src]; oimg[i * 3 + 1] = img[src + 1]; oimg[i * 3 + 2] = img[src + 2];
+            continue;
+        }
+        // Pillow's two-pass resampler restated in its own arithmetic: double-precision triangle weights, normalised, rounded to 22-bit
+        // fixed point; horizontal pass accumulated in integers and stored as 8 bits, then the vertical pass likewise
+        const double dsy = (double)H / (double)rh, dsx = (double)W / (double)rw;
+        const double fy = dsy < 1.0 ? 1.0 : dsy, fx = dsx < 1.0 ? 1.0 : dsx;
+        const double cy = ((double)ry + 0.5) * dsy, cx = ((double)rx + 0.5) * dsx;
+        int y0 = (int)(cy - fy + 0.5), y1 = (int)(cy + fy + 0.5), x0 = (int)(cx - fx + 0.5), x1 = (int)(cx + fx + 0.5);
+        y0 = y0 < 0 ? 0 : y0; y1 = y1 > H ? H : y1; x0 = x0 < 0 ? 0 : x0; x1 = x1 > W ? W : x1;
+        auto tri = [](double t) { t = t < 0.0 ? -t : t; return t < 1.0 ? 1.0 - t : 0.0; };
+        double wxs = 0.0, wys = 0.0;
+        for (int k = x0; k < x1; ++k) wxs += tri(((double)k - cx + 0.5) / fx);
+        for (int k = y0; k < y1; ++k) wys += tri(((double)k - cy + 0.5) / fy);
+        auto fix = [](double w) { return w < 0.0 ? (int)(-0.5 + w * 4194304.0) : (int)(0.5 + w * 4194304.0); };     // 1 << 22
+        auto clip8 = [](int v) { v >>= 22; return v < 0 ? 0 : (v > 255 ? 255 : v); };
+        int acc0 = 1 << 21, acc1 = 1 << 21, acc2 = 1 << 21;
+        for (int ky = y0; ky < y1; ++ky) {
+            double wy = tri(((double)ky - cy + 0.5) / fy); if (wys != 0.0) wy /= wys;
+            const int ky_c = fix(wy);
+            const unsigned char* row = img + (((long long)n * H + ky) * W) * 3;
+            int h0 = 1 << 21, h1 = 1 << 21, h2 = 1 << 21;
+            for (int kx = x0; kx < x1; ++kx) {
+                double wx = tri(((double)kx - cx + 0.5) / fx); if (wxs != 0.0) wx /= wxs;
+                const int kx_c = fix(wx);
+                h0 += (int)row[kx * 3] * kx_c; h1 += (int)row[kx * 3 + 1] * kx_c; h2 += (int)row[kx * 3 + 2] * kx_c;
+            }
+            acc0 += clip8(h0) * ky_c; acc1 += clip8(h1) * ky_c; acc2 += clip8(h2) * ky_c;
+        }
+        oimg[i * 3] = (unsigned char)clip8(acc0);
+        oimg[i * 3 + 1] = (unsigned char)clip8(acc1);
+        oimg[i * 3 + 2] = (unsigned char)clip8(acc2);
+    }
+}
+void launch_resample_u8(const unsigned char* img, const unsigned char* lab, unsigned char* oimg, unsigned char* olab, const int* params,
+                        const int* ytab, const int* xtab, int tab_stride, int N, int H, int W, int Ho, int Wo, int void_id, hipStream_t s)
+{
+    hipLaunchKernelGGL(resample_u8_kernel, dim3(cap_blocks((long long)N * Ho * Wo, 256)), dim3(256), 0, s, img, lab, oimg, olab, params,
+                       ytab, xtab, tab_stride, N, H, W, Ho, Wo, void_id);
+}
+
+
 // ---- strided fingerprint of a float buffer (frozen-parameter guard): wrapping sum of the bit patterns of every 61st element ----
 __global__ __launch_bounds__(256) void fingerprint_kernel(const unsigned* __restrict__ x, long long n, unsigned long long* out)
 {

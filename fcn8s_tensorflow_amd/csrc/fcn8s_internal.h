@@ -150,6 +150,9 @@ void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout
 // params: int[4] per image = {y offset, x offset, flip, float bits of the brightness gain}
 void launch_augment_u8(const unsigned char* img, const unsigned char* lab, unsigned char* oimg, unsigned char* olab, const int* params,
                        int N, int H, int W, int Ho, int Wo, int void_id, hipStream_t s);
+// params: int[4] per image = {resized height, resized width, y offset, x offset}; ytab / xtab: optional nearest-neighbour source tables
+void launch_resample_u8(const unsigned char* img, const unsigned char* lab, unsigned char* oimg, unsigned char* olab, const int* params,
+                        const int* ytab, const int* xtab, int tab_stride, int N, int H, int W, int Ho, int Wo, int void_id, hipStream_t s);
 // wrapping sum over every 61st element's bit pattern (weighted by position): changes whenever an optimizer step or a bulk copy touches the buffer
 void launch_fingerprint(const float* x, long long n, unsigned long long* out, hipStream_t s);
 void launch_init_normal(float* w, long long n, float stddev, int truncated, unsigned long long seed,

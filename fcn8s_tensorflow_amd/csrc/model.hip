@@ -1409,6 +1409,17 @@ int fcn8s_op_augment_u8(void* stream, const uint8_t* images, const uint8_t* labe
     OPCHK(); return FCN8S_OK;
 }
 
+int fcn8s_op_resample_u8(void* stream, const uint8_t* images, const uint8_t* labels, uint8_t* out_images, uint8_t* out_labels,
+                         const int32_t* params, const int32_t* ytab, const int32_t* xtab, int tab_stride,
+                         int N, int H, int W, int Ho, int Wo, int void_id)
+{
+    if ((!images && !labels) || (images && !out_images) || (labels && !out_labels) || !params || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 ||
+        ((ytab || xtab) && tab_stride <= 0))
+        return fail(nullptr, FCN8S_ERR_BAD_ARG, "resample_u8: bad argument");
+    launch_resample_u8(images, labels, images ? out_images : nullptr, labels ? out_labels : nullptr, params, ytab, xtab, tab_stride, N, H, W, Ho, Wo, void_id, (hipStream_t)stream);
+    OPCHK(); return FCN8S_OK;
+}
+
 int fcn8s_op_conv2d(void* stream, const float* x, const float* w, const float* bias, float* y,
                     int N, int H, int W, int Cin, int Cout, int K, int relu)
 {

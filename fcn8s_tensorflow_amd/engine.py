@@ -427,6 +427,51 @@ class Engine:
                                           C.c_void_p(pd.data_ptr()), N, H, W, Ho, Wo, int(void_class_id)))
         return out, lab_out
 
+    @staticmethod
+    def nearest_table(in_size, out_size):
+        """Source index of every output index of a nearest-neighbour resize in_size -> out_size, computed the way the host path
+        (Pillow's affine NEAREST) does: a running double-precision sum 0.5 s, 1.5 s, ... truncated -- so that positions which are
+        exact integers in real arithmetic fall on the same side as there."""
+        s = float(in_size) / float(out_size)
+        steps = np.full(out_size, s, np.float64); steps[0] = 0.5 * s
+        return np.minimum(np.cumsum(steps).astype(np.int64), in_size - 1).astype(np.int32)
+
+    def resample(self, images, labels=None, out_hw=None, sizes=None, offsets=None, void_class_id=0):
+        """GPU-side resize / scale / translate of a uint8 batch already on the device (fcn8s_op_resample_u8; the reference's
+        BatchGenerator does these on the host, batch_generator.py:328-384).  images: uint8 cuda tensor [N,H,W,3]; labels: uint8 cuda
+        tensor [N,H,W] or None.  Per image: `sizes[n] = (rh, rw)` size the source is resized to (default: out_hw), `offsets[n] =
+        (oy, ox)` where its top-left corner lands in the output (negative = crop).  Returns new (images, labels) of size out_hw."""
+        torch = self.torch
+        self._sync_stream()
+        if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3 or not images.is_cuda:
+            raise ValueError("`images` must be a uint8 cuda tensor of shape (N, H, W, 3)")
+        N, H, W = (int(x) for x in images.shape[:3])
+        Ho, Wo = (int(x) for x in (out_hw or (H, W)))
+        par = np.zeros((N, 4), np.int32)
+        par[:, :2] = np.asarray(sizes, np.int32).reshape(N, 2) if sizes is not None else (Ho, Wo)
+        if offsets is not None:
+            par[:, 2:] = np.asarray(offsets, np.int32).reshape(N, 2)
+        stride = int(max(par[:, 0].max(), par[:, 1].max()))
+        ytab = np.zeros((N, stride), np.int32); xtab = np.zeros((N, stride), np.int32)
+        for n in range(N):
+            ytab[n, :par[n, 0]] = self.nearest_table(H, int(par[n, 0]))
+            xtab[n, :par[n, 1]] = self.nearest_table(W, int(par[n, 1]))
+        pd, yd, xd = (torch.from_numpy(a).to(self.device) for a in (par, ytab, xtab))
+        images = images.contiguous()
+        out = torch.empty((N, Ho, Wo, 3), dtype=torch.uint8, device=self.device)
+        lab_out = None; lp = lo = None
+        if labels is not None:
+            if labels.dtype != torch.uint8 or tuple(labels.shape) != (N, H, W) or not labels.is_cuda:
+                raise ValueError("`labels` must be a uint8 cuda tensor of shape (N, H, W)")
+            labels = labels.contiguous()
+            lab_out = torch.empty((N, Ho, Wo), dtype=torch.uint8, device=self.device)
+            lp, lo = C.c_void_p(labels.data_ptr()), C.c_void_p(lab_out.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(L.lib.fcn8s_op_resample_u8(stream, C.c_void_p(images.data_ptr()), lp, C.c_void_p(out.data_ptr()), lo,
+                                           C.c_void_p(pd.data_ptr()), C.c_void_p(yd.data_ptr()), C.c_void_p(xd.data_ptr()), stride,
+                                           N, H, W, Ho, Wo, int(void_class_id)))
+        return out, lab_out
+
     def predict(self, images, argmax=True):
         """sess.run(predictions_argmax | softmax_output) (fcn8s_tensorflow.py:764-770)."""
         self._sync_stream()

@@ -195,6 +195,14 @@ int fcn8s_op_preprocess(void* stream, const void* images, int image_dtype, float
  * * gain (clamped to 0..255, rounded), zero / void_id outside the source.  labels / out_labels may be NULL. */
 int fcn8s_op_augment_u8(void* stream, const uint8_t* images, const uint8_t* labels, uint8_t* out_images, uint8_t* out_labels,
                         const int32_t* params, int N, int H, int W, int Ho, int Wo, int void_id);
+/* the resampling augmentations of data_generator/batch_generator.py:328-384 (resize :328-331, translate :344-356, scale :358-384) on
+ * DEVICE uint8 batches: image n is resized to params[4n+0] x params[4n+1] (images: triangle filter with shrink-proportional
+ * support, the BILINEAR resize of the repo's host path; labels: nearest neighbour) and placed at offset (params[4n+2],
+ * params[4n+3]) of the [Ho,Wo] output, uncovered pixels 0 / void_id.  ytab / xtab: optional [N][tab_stride] source-index tables
+ * of the nearest path (NULL: floor((r + 0.5) * H / rh)).  images / labels may each be NULL.                                   */
+int fcn8s_op_resample_u8(void* stream, const uint8_t* images, const uint8_t* labels, uint8_t* out_images, uint8_t* out_labels,
+                         const int32_t* params, const int32_t* ytab, const int32_t* xtab, int tab_stride,
+                         int N, int H, int W, int Ho, int Wo, int void_id);
 int fcn8s_op_conv2d(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,
                     int N, int H, int W, int Cin, int Cout, int K, int relu);
 /* the same SAME conv through Winograd F(tile x tile, 3x3), tile = 2, 4 or 6 (the path the model takes for its 3x3

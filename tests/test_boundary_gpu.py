@@ -143,3 +143,54 @@ def test_plain_row_gemm_kernels(N, H, W, Cin, Cout):
     assert rel(dx_.cpu().numpy().reshape(-1, Cin), dx_ref) < 2e-5
     assert rel(dw_.cpu().numpy().reshape(Cin, Cout), dw_ref) < 2e-5
     assert rel(db_.cpu().numpy(), dy.reshape(-1, Cout).astype(np.float64).sum(0)) < 2e-5
+
+
+def test_gpu_resize_scale_translate_match_the_host_generator():
+    """fcn8s_op_resample_u8 against the host path of this repo's BatchGenerator (`_apply`: Pillow BILINEAR / NEAREST resize, NumPy
+    shifts; reference data_generator/batch_generator.py:328-384) on the same parameters: labels bit-exact, images within 1 LSB."""
+    from fcn8s_tensorflow_amd.batch_generator import BatchGenerator
+    e = _engine()
+    rng = np.random.default_rng(11)
+    N, H, W, void = 4, 64, 96, 7
+    img = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+    lab = rng.integers(0, 20, (N, H, W), dtype=np.uint8)
+    imgd, labd = torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda()
+
+    def host(i, draw, resize=False):
+        return BatchGenerator._apply(img[i], lab[i], draw, void, False, False, resize, False)
+
+    def check(gi, gl, hi, hl, what):
+        np.testing.assert_array_equal(gl, hl, err_msg=what)
+        assert np.abs(gi.astype(int) - hi.astype(int)).max() <= 1, what       # (measured: identical -- the kernel restates the host
+        assert (gi != hi).mean() < 1e-3, what                                  #  resampler's fixed-point arithmetic)
+
+    # resize (:328-331): every image to the same size, down and up
+    for rs in ((45, 67), (83, 125), (32, 48), (64, 96)):
+        gi, gl = e.resample(imgd, labd, out_hw=rs)
+        for i in range(N):
+            hi, hl = host(i, {}, resize=rs)
+            check(gi[i].cpu().numpy(), gl[i].cpu().numpy(), hi, hl, "resize %s" % (rs,))
+    # scale (:358-384): per-image factor, canvas placement for f <= 1, centre crop for f > 1
+    factors = [0.61, 0.93, 1.27, 1.9]
+    sizes = [(int(H * f), int(W * f)) for f in factors]
+    offs = []
+    for f, (sh, sw) in zip(factors, sizes):
+        yo, xo = abs(int((H - sh) / 2)), abs(int((W - sw) / 2))
+        offs.append((yo, xo) if f <= 1 else (-yo, -xo))
+    gi, gl = e.resample(imgd, labd, out_hw=(H, W), sizes=sizes, offsets=offs, void_class_id=void)
+    for i, f in enumerate(factors):
+        hi, hl = host(i, {'factor': f})
+        check(gi[i].cpu().numpy(), gl[i].cpu().numpy(), hi, hl, "scale %.2f" % f)
+    # translate (:344-356): integer shifts, exact copy inside, void / zero outside
+    shifts = [(5, -3), (-17, 0), (0, 11), (40, 30)]          # (x_shift, y_shift)
+    gi, gl = e.resample(imgd, labd, out_hw=(H, W), sizes=[(H, W)] * N, offsets=[(dy, dx) for dx, dy in shifts], void_class_id=void)
+    for i, sh in enumerate(shifts):
+        hi, hl = host(i, {'shift': sh})
+        np.testing.assert_array_equal(gi[i].cpu().numpy(), hi)
+        np.testing.assert_array_equal(gl[i].cpu().numpy(), hl)
+    # labels only / images only
+    _, gl2 = e.resample(imgd, labd, out_hw=(45, 67))
+    assert gl2.shape == (N, 45, 67)
+    gi3, gl3 = e.resample(imgd, None, out_hw=(45, 67))
+    assert gl3 is None and gi3.shape == (N, 45, 67, 3)
+    e.close()
