@@ -15,7 +15,10 @@ the library's HIP kernel when the inputs live on the GPU, by NumPy otherwise.
 from __future__ import annotations
 
 import ctypes as C
+import fnmatch
+import glob
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -169,3 +172,89 @@ class PixelLevelEvaluator:
         cs, cat = self.class_scores(), self.category_scores()
         return {"classScores": cs, "averageScoreClasses": score_average(cs),
                 "categoryScores": cat, "averageScoreCategories": score_average(cat)}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# files either side of the scoring: label-id PNG export and the evaluator's prediction / ground-truth file loop
+# ---------------------------------------------------------------------------------------------------------
+def save_label_id_png(path, pred_train_ids):
+    """Write one prediction (train ids, (H,W), as `FCN8s.predict` returns them) as the single-channel uint8 label-id PNG the
+    official evaluator reads (evalPixelLevelSemanticLabeling.py:553-555; ids via labels.py:188-192)."""
+    from PIL import Image
+    a = np.asarray(pred_train_ids)
+    if a.ndim != 2:
+        raise ValueError("expected one (H, W) map of train ids, got shape {}".format(a.shape))
+    Image.fromarray(TRAINIDS_TO_IDS_ARRAY[a.astype(np.int64)]).save(path)
+
+
+def cs_file_info(file_name):
+    """csHelpers.getCsFileInfo: (city, sequenceNb, frameNb) of `<city>_<seq>_<frame>_<type>[_<type2>].<ext>`."""
+    parts = os.path.basename(file_name).split('_')
+    if len(parts) < 4:
+        raise ValueError("Cannot parse given filename ({}). Does not seem to be a valid Cityscapes file.".format(file_name))
+    return parts[0], parts[1], parts[2]
+
+
+def walk_predictions(prediction_path):
+    return [(root, files) for root, _, files in os.walk(prediction_path)]
+
+
+def find_prediction(prediction_path, ground_truth_file, walk=None):
+    """evalPixelLevelSemanticLabeling.py:72-106: the one file `<city>_<seq>_<frame>*.png` anywhere below `prediction_path`
+    (`walk`: a walk_predictions() result to reuse, as the evaluator walks the tree once)."""
+    if walk is None:
+        walk = walk_predictions(prediction_path)
+    city, seq, frame = cs_file_info(ground_truth_file)
+    pattern = "{}_{}_{}*.png".format(city, seq, frame)
+    found = None
+    for root, files in walk:
+        for f in fnmatch.filter(files, pattern):
+            if found is not None:
+                raise ValueError("Found multiple predictions for ground truth {}".format(ground_truth_file))
+            found = os.path.join(root, f)
+    if found is None:
+        raise ValueError("Found no prediction for ground truth {}".format(ground_truth_file))
+    return found
+
+
+def evaluate_file_pairs(prediction_files, ground_truth_files, device=None):
+    """evaluateImgLists / evaluatePair (evalPixelLevelSemanticLabeling.py:454-498, 550-595): accumulate conf[gt, pred] over
+    pairs of label-id PNGs with the evaluator's checks, then the class / category scores.  `device`: a torch cuda device
+    to count on the GPU (the library's confusion kernel), None = NumPy."""
+    from PIL import Image
+    if len(prediction_files) != len(ground_truth_files):
+        raise ValueError("List of images for prediction and groundtruth are not of equal size.")
+    ev = PixelLevelEvaluator()
+    pixels = 0
+    for pf, gf in zip(prediction_files, ground_truth_files):
+        pred, gt = np.array(Image.open(pf)), np.array(Image.open(gf))
+        if pred.ndim != 2:
+            raise ValueError("Predicted image has multiple channels.")
+        if pred.shape[1] != gt.shape[1]:
+            raise ValueError("Image widths of " + pf + " and " + gf + " are not equal.")
+        if pred.shape[0] != gt.shape[0]:
+            raise ValueError("Image heights of " + pf + " and " + gf + " are not equal.")
+        if gt.max() >= NUM_IDS:
+            raise ValueError("Unknown label with id {:}".format(int(gt.max())))
+        if device is not None:
+            import torch
+            confusion_add(ev.conf, torch.from_numpy(gt.astype(np.uint8)).to(device), torch.from_numpy(pred.astype(np.int64)).to(device))
+        else:
+            confusion_add(ev.conf, gt, pred)
+        pixels += pred.size
+        if int(ev.conf.sum()) != pixels:
+            raise ValueError("Number of analyzed pixels and entries in confusion matrix disagree: contMatrix {}, pixels {}".format(int(ev.conf.sum()), pixels))
+    res = ev.results()
+    res["confMatrix"] = ev.conf
+    res["nbPixels"] = pixels
+    return res
+
+
+def evaluate_directory(ground_truth_search, prediction_path, device=None):
+    """The evaluator's no-argument mode (:667-676): every ground-truth file matching the glob (the official one is
+    `<cityscapes>/gtFine/val/*/*_gtFine_labelIds.png`) against its prediction below `prediction_path`."""
+    gts = sorted(glob.glob(ground_truth_search))
+    if not gts:
+        raise ValueError("Cannot find any ground truth images to use for evaluation. Searched for: {}".format(ground_truth_search))
+    walk = walk_predictions(prediction_path)
+    return evaluate_file_pairs([find_prediction(prediction_path, g, walk) for g in gts], gts, device)

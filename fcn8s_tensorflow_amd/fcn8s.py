@@ -357,6 +357,38 @@ class FCN8s:
         finally:
             self.engine.freeze(False)
 
+    def predict_and_export_label_ids(self, results_dir, images_dir, resize=False, image_file_extension='png', overwrite_existing=True):
+        '''Not in the reference: runs every `*.png` below `images_dir` (sub-directories = cities, as in leftImg8bit/val) through the
+        model and writes the argmax as single-channel label-id PNGs under the same file names into `results_dir` -- the input of the
+        official scorer (cityscapesscripts/evaluation/evalPixelLevelSemanticLabeling.py:72-106, 553-555; cityscapes_eval.evaluate_directory
+        here).  Predictions are train ids 0..19 (0 = void) mapped through labels.py:188-192; `resize=(h, w)` feeds the network a
+        resized image and writes the prediction back at the file's own size (nearest neighbour).'''
+        from PIL import Image
+        from . import cityscapes_eval as ce
+        if self.num_classes != 20:
+            raise ValueError("label-id export uses the 20 Cityscapes train ids; this model has {} classes.".format(self.num_classes))
+        if overwrite_existing and os.path.exists(results_dir):
+            shutil.rmtree(results_dir)
+        os.makedirs(results_dir, exist_ok=True)
+        paths = sorted(glob(os.path.join(images_dir, '**', '*.' + image_file_extension), recursive=True))
+        tr = trange(len(paths), file=sys.stdout)
+        tr.set_description('Exporting label ids')
+        self.engine.freeze(True)
+        try:
+            for i in tr:
+                pil = Image.open(paths[i]).convert('RGB')
+                size = pil.size
+                if resize and not np.array_equal((pil.height, pil.width), resize):
+                    pil = pil.resize((resize[1], resize[0]), Image.BILINEAR)
+                pred = np.asarray(self.predict([np.asarray(pil)], argmax=True))[0]
+                ids = Image.fromarray(ce.TRAINIDS_TO_IDS_ARRAY[pred])
+                if ids.size != size:
+                    ids = ids.resize(size, Image.NEAREST)
+                ids.save(os.path.join(results_dir, os.path.basename(paths[i])))
+        finally:
+            self.engine.freeze(False)
+        return len(paths)
+
     def _segment_file(self, filepath, results_dir, color_map, resize, include_unprocessed_image, arrangement):
         '''Loop body of predict_and_save (fcn8s_tensorflow.py:829-855).'''
         from PIL import Image

@@ -11,6 +11,7 @@ Sources exercised (reference file:line):
   cityscapesscripts/evaluation/addToConfusionMatrix_impl.c:3-17  compiled by oracle/Makefile into oracle/_ref/
   data_generator/batch_generator.py:16-130,140-417  BatchGenerator contract (cv2 stubbed, scipy.misc.imread -> PIL)
   cityscapesscripts/evaluation/evalPixelLevelSemanticLabeling.py:173-182,229-335  official IoU scoring functions (labels / PIL stubbed)
+  cityscapesscripts/evaluation/evalPixelLevelSemanticLabeling.py:72-106,454-498,550-595  prediction lookup + the file-pair evaluation loop on PNG pairs
 """
 import ctypes
 import os
@@ -121,6 +122,35 @@ def main():
                         cat_names=np.array(list(cat)), cat_scores=np.array(list(cat.values()), dtype=np.float64),
                         cat_avg=ev.getScoreAverage(cat, ev.args),
                         trainids_to_ids=np.array([0] + [ns["trainIds_to_ids_dict"][t] for t in range(1, 20)], dtype=np.uint8))   # labels.py:188-192 (its loop overflows uint8 on the id -1 label under NumPy 2; [0] is forced to 0 there)
+    # ---- the evaluator's file loop: getPrediction (:72-106) and evaluateImgLists / evaluatePair (:454-498, :550-595) on PNG pairs ----
+    ev.CSUPPORT = False                                            # its python loop (the compiled loop is pinned through confmat.npz)
+    ev.args.evalInstLevelScore = False; ev.args.evalPixelAccuracy = False; ev.args.quiet = True; ev.args.JSONOutput = False
+    names = ["frankfurt_000000_000294", "frankfurt_000001_007973", "munster_000005_000019"]
+    gts = rng.integers(0, 34, (3, 12, 20), dtype=np.uint8)
+    preds = ce_like = None
+    tid = lut[gts]                                                 # the perfect train-id map, then damaged
+    preds = np.array([ns["trainIds_to_ids_dict"].get(int(t), 0) if t > 0 else 0 for t in tid.ravel()], np.uint8).reshape(tid.shape)
+    flip = rng.random(preds.shape) < 0.3
+    preds[flip] = np.array([7, 8, 11, 21, 23, 24, 26, 33], np.uint8)[rng.integers(0, 8, int(flip.sum()))]
+    with tempfile.TemporaryDirectory() as d:
+        gdir, pdir = os.path.join(d, "gtFine", "val"), os.path.join(d, "results")
+        gt_files = []
+        for i, nm in enumerate(names):
+            city = nm.split("_")[0]
+            os.makedirs(os.path.join(gdir, city), exist_ok=True); os.makedirs(os.path.join(pdir, "sub"), exist_ok=True)
+            gf = os.path.join(gdir, city, nm + "_gtFine_labelIds.png"); gt_files.append(gf)
+            Image.fromarray(gts[i]).save(gf)
+            Image.fromarray(preds[i]).save(os.path.join(pdir, "sub", nm + "_leftImg8bit.png"))
+        ev.args.predictionPath = pdir; ev.args.predictionWalk = None
+        pred_files = [ev.getPrediction(ev.args, g) for g in gt_files]
+        res = ev.evaluateImgLists(pred_files, gt_files, ev.args)
+        np.savez_compressed(os.path.join(HERE, "cityscapes_filepairs.npz"), names=np.array(names), gts=gts, preds=preds,
+                            matched=np.array([os.path.relpath(p, pdir) for p in pred_files]),
+                            conf=np.asarray(res["confMatrix"], dtype=np.int64),
+                            class_names=np.array(list(res["classScores"])), class_scores=np.array(list(res["classScores"].values()), dtype=np.float64),
+                            class_avg=res["averageScoreClasses"],
+                            cat_names=np.array(list(res["categoryScores"])), cat_scores=np.array(list(res["categoryScores"].values()), dtype=np.float64),
+                            cat_avg=res["averageScoreCategories"])
     print("golden fixtures written to", HERE)
 
 

@@ -70,3 +70,49 @@ def test_gpu_accumulation_equals_host():
     b.add(torch.from_numpy(pred).cuda(), torch.from_numpy(gt).cuda())
     np.testing.assert_array_equal(a.conf, b.conf)
     assert a.results()["averageScoreClasses"] == b.results()["averageScoreClasses"]
+
+
+def test_file_pair_loop_matches_reference_evaluator(tmp_path):
+    """Label-id PNG pairs on disk -> prediction lookup by `<city>_<seq>_<frame>*.png` -> confusion matrix -> scores, against what the
+    reference's evaluateImgLists / getPrediction produced on the same files (tests/golden/make_golden.py)."""
+    from PIL import Image
+    d = np.load(os.path.join(GOLD, "cityscapes_filepairs.npz"))
+    gdir, pdir = tmp_path / "gtFine" / "val", tmp_path / "results"
+    gts = []
+    for i, nm in enumerate(d["names"]):
+        city = str(nm).split("_")[0]
+        (gdir / city).mkdir(parents=True, exist_ok=True); (pdir / "sub").mkdir(parents=True, exist_ok=True)
+        Image.fromarray(d["gts"][i]).save(gdir / city / (str(nm) + "_gtFine_labelIds.png"))
+        Image.fromarray(d["preds"][i]).save(pdir / "sub" / (str(nm) + "_leftImg8bit.png"))
+        gts.append(str(gdir / city / (str(nm) + "_gtFine_labelIds.png")))
+    matched = [ce.find_prediction(str(pdir), g) for g in gts]
+    assert [os.path.relpath(m, str(pdir)) for m in matched] == list(d["matched"])
+    res = ce.evaluate_directory(str(gdir / "*" / "*_gtFine_labelIds.png"), str(pdir))
+    np.testing.assert_array_equal(res["confMatrix"], d["conf"])
+    got = np.array([res["classScores"][n] for n in d["class_names"]])
+    np.testing.assert_allclose(got, d["class_scores"], rtol=0, atol=1e-15, equal_nan=True)
+    assert abs(res["averageScoreClasses"] - float(d["class_avg"])) < 1e-15
+    gotc = np.array([res["categoryScores"][n] for n in d["cat_names"]])
+    np.testing.assert_allclose(gotc, d["cat_scores"], rtol=0, atol=1e-15, equal_nan=True)
+    assert abs(res["averageScoreCategories"] - float(d["cat_avg"])) < 1e-15
+    assert res["nbPixels"] == d["gts"].size
+    # the evaluator's error cases
+    Image.fromarray(d["preds"][0]).save(pdir / (str(d["names"][0]) + "_dup.png"))
+    with pytest.raises(ValueError, match="multiple predictions"):
+        ce.find_prediction(str(pdir), gts[0])
+    with pytest.raises(ValueError, match="no prediction"):
+        ce.find_prediction(str(pdir), str(gdir / "x" / "bonn_000000_000001_gtFine_labelIds.png"))
+    bad = tmp_path / "bad.png"; Image.fromarray(d["preds"][0][:, :10]).save(bad)
+    with pytest.raises(ValueError, match="widths"):
+        ce.evaluate_file_pairs([str(bad)], [gts[0]])
+
+
+def test_label_id_png_export_round_trip(tmp_path):
+    rng = np.random.default_rng(3)
+    tid = rng.integers(0, 20, (9, 13))
+    ce.save_label_id_png(str(tmp_path / "a_000000_000001_pred.png"), tid)
+    from PIL import Image
+    back = np.array(Image.open(tmp_path / "a_000000_000001_pred.png"))
+    assert back.dtype == np.uint8 and back.ndim == 2
+    np.testing.assert_array_equal(back, ce.TRAINIDS_TO_IDS_ARRAY[tid])
+    np.testing.assert_array_equal(ce.IDS_TO_TRAINIDS_ARRAY[back], tid)          # void (0) maps to id 0 and back

@@ -275,3 +275,31 @@ def test_gpu_augmentation_matches_host_crop_flip_brightness():
     with pytest.raises(ValueError):
         e.augment(torch.zeros(1, 4, 4, 3).cuda())
     e.close()
+
+
+def test_label_id_export_feeds_the_official_scorer(tmp_path):
+    """predict_and_export_label_ids -> label-id PNGs under the Cityscapes file names -> cityscapes_eval.evaluate_directory (the
+    restated evalPixelLevelSemanticLabeling file loop): the scores equal those accumulated directly from predict()."""
+    from PIL import Image
+    from fcn8s_tensorflow_amd import cityscapes_eval as ce
+    m = make()
+    rng = np.random.default_rng(5)
+    names = ["aachen_000000_000019", "aachen_000001_000019", "bonn_000002_000019"]
+    direct = ce.PixelLevelEvaluator()
+    for nm in names:
+        city = nm.split("_")[0]
+        (tmp_path / "leftImg8bit" / city).mkdir(parents=True, exist_ok=True); (tmp_path / "gtFine" / city).mkdir(parents=True, exist_ok=True)
+        img = rng.integers(0, 256, (32, 64, 3), dtype=np.uint8)
+        gt = rng.integers(0, 34, (32, 64)).astype(np.uint8)
+        Image.fromarray(img).save(tmp_path / "leftImg8bit" / city / (nm + "_leftImg8bit.png"))
+        Image.fromarray(gt).save(tmp_path / "gtFine" / city / (nm + "_gtFine_labelIds.png"))
+        direct.add(m.predict([img])[0], gt)
+    n = m.predict_and_export_label_ids(str(tmp_path / "results"), str(tmp_path / "leftImg8bit"))
+    assert n == 3 and sorted(os.listdir(tmp_path / "results")) == sorted(nm + "_leftImg8bit.png" for nm in names)
+    res = ce.evaluate_directory(str(tmp_path / "gtFine" / "*" / "*_gtFine_labelIds.png"), str(tmp_path / "results"))
+    np.testing.assert_array_equal(res["confMatrix"], direct.conf)
+    assert res["averageScoreClasses"] == direct.results()["averageScoreClasses"] or (np.isnan(res["averageScoreClasses"]) and np.isnan(direct.results()["averageScoreClasses"]))
+    import torch
+    res_gpu = ce.evaluate_directory(str(tmp_path / "gtFine" / "*" / "*_gtFine_labelIds.png"), str(tmp_path / "results"), device=torch.device("cuda", 0))
+    np.testing.assert_array_equal(res_gpu["confMatrix"], direct.conf)
+    m.close()
