@@ -129,7 +129,7 @@ int wino_r(int KS);                 // sub-filter size: 3 for 3x3 kernels; 7x7 (
 int wino_nsub(int KS);              // sub-filters per dimension: ceil(KS / r)
 int wino_alpha(int tile, int KS);   // tile + r - 1; the number of Winograd positions is alpha^2
 long long wino_slab(long long T, int C);   // floats between the slabs of consecutive Winograd positions of a [P][T][C] tensor (T*C + skew)
-void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, int KS, hipStream_t s);         // w[KS*KS][Cin][Cout] -> u[P][nsub*Cin][Cout]
+void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, int KS, hipStream_t s, int transpose_out = 0);   // w[KS*KS][Cin][Cout] -> u[P][nsub*Cin][Cout]  (transpose_out: u[P][Cout][Cin], KS = 3 only)
 void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, int KS, hipStream_t s);   // x[N,H,W,C] -> v[P][T][nsub*C]
 // F(4x4,3x3) only: V = B^T dy B (input transform of the data-gradient conv) AND dM = A dy A^T (weight-gradient transform) from
 // one read of dy; returns false if the shape is not covered.
@@ -145,7 +145,11 @@ void launch_wino_output(int tile, const float* m, const float* bias, const float
 size_t wino_rbits_words(int tile, int N, int H, int W, int C);
 // (pool != nullptr: also writes the 2x2/2 max-pool of y, [N,H/2,W/2,C] -- the tiles are aligned with the pool windows -- and,
 //  if pidx != nullptr, one byte per pooled element: index 0..3 of the window's first maximum, 4 if that maximum is not > 0)
-void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s, int KS = 3);   // dy -> dm[P][T][C] = A dY A^T
+void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s, int KS = 3, const unsigned char* pidx = nullptr);   // dy -> dm[P][T][C] = A dY A^T  (tile 6 with pidx: dy is d(pool), routed through the argmax bytes)
+// F(6x6,3x3) data gradient as the adjoint of the forward algorithm: dv[P][T][C] = dM U^T -> dx = overlap-added B dv B^T (+ skip addend, ReLU mask)
+bool wino_dgrad_adjoint_enabled();
+void launch_wino_dgrad_output(const float* dv, const float* addend, const float* mask, float mask_scale, const unsigned* rbits_in, float* y,
+                              int N, int H, int W, int C, hipStream_t s);
 void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, int KS, hipStream_t s);        // du[P][nsub*Cin][Cout] -> dw[KS*KS][Cin][Cout]
 // params: int[4] per image = {y offset, x offset, flip, float bits of the brightness gain}
 void launch_augment_u8(const unsigned char* img, const unsigned char* lab, unsigned char* oimg, unsigned char* olab, const int* params,

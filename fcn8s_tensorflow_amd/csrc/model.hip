@@ -67,6 +67,7 @@ struct fcn8s_model {
     std::map<std::string, float*> u_cache;                               // layer -> transformed filter bank (hipMalloc'ed), valid while frozen
     std::set<std::string> rbits_ok;                                       // layers whose forward pass wrote a ReLU bit mask ("rb:<layer>") this step
     std::string fused_v_layer;                                            // layer whose data-gradient input transform already sits in d_wino_v
+    std::string dm_layer;                                                 // layer whose dM = A dY A^T sits in d_wino_m, ready for the adjoint data gradient
     unsigned short* d_wbf16 = nullptr;                                    // bf16 K-tile-major copy of the fc6 / fc7 kernel (one at a time)
     unsigned short* d_abf16 = nullptr; size_t abf16_elems = 0;            // bf16 copy of the layer's input activations
     hipStream_t stream = nullptr;
@@ -209,7 +210,8 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
              float* pool_out = nullptr;                  // 2x2/2 max-pool of the output, written by the Winograd output transform if that path runs
              unsigned char* pool_idx = nullptr;          // ... with the per-window argmax bytes the backward pass routes the pool gradient by
              unsigned* relu_bits_out = nullptr;          // forward, Winograd path: also record (y > 0), one bit per element
-             const unsigned* relu_bits_in = nullptr; };  // data gradient, Winograd path: such a record of `mask` (read instead of the tensor)
+             const unsigned* relu_bits_in = nullptr;     // data gradient, Winograd path: such a record of `mask` (read instead of the tensor)
+             const float* w_fwd = nullptr; };            // data gradient: the layer's forward kernel [3,3,Cout_of_this_conv... = Cin here][...] (adjoint Winograd path)
 
 // 3x3 SAME conv through Winograd F(tile x tile, 3x3): filter transform, input transform, (tile+2)^2 batched GEMMs
 // on the matrix cores (2.25x / 4x fewer MFMA flops than the direct form), output transform + fused epilogue.
@@ -275,6 +277,30 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
 {
     const bool wino3 = m && K == 3 && m->wino_min_cin > 0 && Cin >= m->wino_min_cin && m->d_wino_v && wino_tile_for(m, H, W, 3) && !e.dropout;
     const bool wino7 = m && K == 7 && m->wino_fc6 && m->d_wino_v && wino_tile_for(m, H, W, 7) == 4;
+    if (m && wino3 && e.dgrad && layer && e.w_fwd && !m->dm_layer.empty() && m->dm_layer == layer && wino_tile_for(m, H, W, 3) == 6 &&
+        Cin % 64 == 0 && Cout % 64 == 0 && e.alpha == 1.f && !real_cin && !e.bias && !e.relu) {
+        // Data gradient as the adjoint of the forward Winograd algorithm: dV[xi] = dM[xi] U[xi]^T with the dM = A dY A^T the weight
+        // gradient just built (d_wino_m) and the FORWARD filter bank, then dx = overlap-added B dV B^T.  (Here Cin = channels of dY,
+        // Cout = channels of dx; w_fwd is [3,3,Cout,Cin].)
+        m->dm_layer.clear(); m->fused_v_layer.clear();
+        const int P = 64;
+        const long long T = wino_tiles(6, N, H, W);
+        IgemmArgs a{};
+        a.x = m->d_wino_m; a.w = m->d_wino_u; a.y = m->d_wino_v;
+        a.N = 1; a.Ma = (int)T; a.Mb = 1; a.M = T;
+        a.Hi = (int)T; a.Wi = 1; a.Cin = Cin; a.ldx = Cin;
+        a.KW = 1; a.in_scale = 1; a.tap_step = 1; a.tap_off = 0; a.Ktot = Cin;
+        a.Ho = (int)T; a.Wo = 1; a.Cout = Cout; a.ldy = Cout;
+        a.out_scale = 1; a.phases_x = 1; a.w_phase_stride = (long long)Cin * Cout;
+        a.alpha = 1.f; a.mask_scale = 1.f;
+        a.batched = 1; a.x_batch_stride = wino_slab(T, Cin); a.y_batch_stride = wino_slab(T, Cout);
+        { ProfScope ps(m, "wino_transform", 0, (double)(9 + P) * 4 * Cin * Cout); launch_wino_filter(6, e.w_fwd, m->d_wino_u, Cout, Cin, 3, s, 1); }
+        { ProfScope ps(m, "wino_gemm_dgrad", 2.0 * P * T * Cin * Cout, 4.0 * P * (T * (double)(Cin + Cout) + (double)Cin * Cout), layer); launch_igemm(a, P, s); }
+        { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout * (1.0 + (e.relu_bits_in ? 1.0 / 32 : (e.mask ? 1.0 : 0.0)) + (e.addend ? 1.0 : 0.0)) + (double)P * T * Cout));
+          launch_wino_dgrad_output(m->d_wino_v, e.addend, e.mask, e.mask_scale, e.relu_bits_in, y, N, H, W, Cout, s); }
+        return false;
+    }
+    if (m) m->dm_layer.clear();
     if ((wino3 || wino7) && Cin % 16 == 0 && Cout % 64 == 0 && e.alpha == 1.f && !real_cin) {
         const bool dgrad = e.dgrad != 0;
         float* vbuf = m->d_wino_v;
@@ -369,19 +395,26 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             g.batched = 1; g.a_batch_stride = wino_slab(T, Kg); g.b_batch_stride = wino_slab(T, Cout); g.c_uninitialized = 1;
             // fuse_dgrad_input: the data gradient of this layer follows and runs through Winograd too -- its input
             // transform V = B^T dz B is written into d_wino_v by the same kernel that writes dM (one read of dz)
-            bool fused = false;
-            { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout * (pool_idx ? 0.3125 : 1.0) + (fuse_dgrad_input ? 2.0 : 1.0) * NP * T * Cout));
+            bool fused = false, dm_ready = false;
+            const bool adj_bytes = fuse_dgrad_input && tile == 6 && K == 3 && wino_dgrad_adjoint_enabled() && Cin % 64 == 0 && Cout % 64 == 0;
+            { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout * (pool_idx ? 0.3125 : 1.0) + ((fuse_dgrad_input && !adj_bytes) ? 2.0 : 1.0) * NP * T * Cout));
               // pool_idx: dz is d(pool) [N,H/2,W/2,Cout]; the max-pool backward happens inside the transform (the caller checked eligibility)
-              if (fuse_dgrad_input && tile >= 4 && K == 3) fused = launch_wino_input_dout(tile, dz, m->d_wino_v, m->d_wino_m, N, H, W, Cout, s, pool_idx);
-              if (!fused) launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s, K); }
+              // adjoint data gradient (tile 6): it consumes dM itself, no second transform of dz
+              const bool adjoint = fuse_dgrad_input && tile == 6 && K == 3 && wino_dgrad_adjoint_enabled() && Cin % 64 == 0 && Cout % 64 == 0;
+              if (adjoint) { launch_wino_dout(6, dz, m->d_wino_m, N, H, W, Cout, s, 3, pool_idx); dm_ready = true; }
+              else {
+                  if (fuse_dgrad_input && tile >= 4 && K == 3) fused = launch_wino_input_dout(tile, dz, m->d_wino_v, m->d_wino_m, N, H, W, Cout, s, pool_idx);
+                  if (!fused) launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s, K);
+              } }
             m->fused_v_layer = fused ? layer : "";
+            m->dm_layer = dm_ready ? layer : "";
             { ProfScope ps(m, K == 7 ? "wino_gemm_fc6_wgrad" : "wino_gemm_wgrad", 2.0 * NP * T * Kg * Cout, 4.0 * NP * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_wgrad(g, s); }
-            { ProfScope ps(m, "wino_transform", 0, 4.0 * (9.0 + NP) * Cin * Cout + 4.0 * N * H * W * Cout * ((tile >= 4 && (pool_idx || fused)) ? 1.0 / (tile * tile) : 1.0));
+            { ProfScope ps(m, "wino_transform", 0, 4.0 * (9.0 + NP) * Cin * Cout + 4.0 * N * H * W * Cout * (tile >= 4 ? 1.0 / (tile * tile) : 1.0));
               launch_wino_dfilter(tile, m->d_wino_u, dw, Cin, Cout, K, s);
               // bias gradient = sum of dz over all pixels.  dM[(1,1)] = sum_kl A^T(k,1) dz[k][l] A^T(l,1) and column 1 of A^T is all ones:
               // the slab of position (1,1) holds the per-tile sums -- 16x fewer bytes than dz, and dz need not exist
               if (db) {
-                  if (tile >= 4 && (pool_idx || fused)) launch_colsum(m->d_wino_m + (wino_alpha(tile, K) + 1) * wino_slab(T, Cout), db, T, Cout, s);
+                  if (tile >= 4) launch_colsum(m->d_wino_m + (wino_alpha(tile, K) + 1) * wino_slab(T, Cout), db, T, Cout, s);
                   else launch_colsum(dz, db, (long long)N * H * W, Cout, s);
               } }
             return;
@@ -797,7 +830,7 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
             conv_wgrad(m, first ? "conv1_1_wgrad" : "conv3x3_wgrad", xin, dz, Gp(m, std::string(nm) + "/filter"), Gp(m, std::string(nm) + "/biases"),
                        N, h, w, cin, cw, 3, 1.f, s, real_cin, nm, dgrad_wino, i == nconv ? pidx : nullptr);
             if (first) break;
-            Epi e; e.dgrad = 1;
+            Epi e; e.dgrad = 1; e.w_fwd = Wp(m, std::string(nm) + "/filter");
             if (i > 1) {                                                   // ReLU of the previous conv
                 e.mask = xin; e.mask_scale = 1.f;
                 if (m->rbits_ok.count(inname)) e.relu_bits_in = (const unsigned*)A(m, (std::string("rb:") + inname).c_str());

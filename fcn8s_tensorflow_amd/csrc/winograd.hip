@@ -116,12 +116,16 @@ template <int VEC> static __device__ __forceinline__ VecF<VEC> vfma(float s, con
 #define float4 VecF<VEC>
 
 // ---- filters: u[xi][sub*Cin + ci][co] = (G g_sub G^T)[xi];  g_sub = taps (3a..3a+2, 3b..3b+2) of the KS x KS filter -----
+// transpose_out (nsub == 1 only): u[xi][co][ci] instead of u[xi][ci][co] -- the B operand of the data gradient computed as the
+// adjoint of the forward algorithm (launch_wino_dgrad_output), dV[xi] = dM[xi] U[xi]^T
 template <int M, int R>
-__global__ void wino_filter_kernel(const float* w, float* u, int Cin, int Cout, int KS, int nsub)
+__global__ void wino_filter_kernel(const float* w, float* u, int Cin, int Cout, int KS, int nsub, int transpose_out)
 {
     constexpr int A = WinoMat<M, R>::A;
     const long long cc = (long long)Cin * Cout, total = cc * nsub * nsub, ucc = cc * nsub * nsub;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x; i0 < total; i0 += (long long)gridDim.x * blockDim.x) {
+        // transposed output: consecutive threads walk ci for a fixed co (coalesced stores; the loads of w are strided instead and hit L2)
+        const long long i = transpose_out ? (i0 % Cin) * Cout + i0 / Cin : i0;
         const int sub = (int)(i / cc); const long long e = i - sub * cc;
         const int sa = sub / nsub, sb = sub - sa * nsub;
         float g[R][R], t[A][R];
@@ -148,7 +152,7 @@ __global__ void wino_filter_kernel(const float* w, float* u, int Cin, int Cout, 
                 float s = 0.f;
 #pragma unroll
                 for (int k = 0; k < R; ++k) s = fmaf(t[a][k], WinoMat<M, R>::g(b, k), s);
-                u[(long long)(a * A + b) * ucc + i] = s;           // row (sub*Cin + ci), column co
+                u[(long long)(a * A + b) * ucc + (transpose_out ? i0 : i)] = s;           // row (sub*Cin + ci), column co
             }
     }
 }
@@ -400,20 +404,41 @@ __global__ __launch_bounds__(256, 3) void wino_output_kernel(const float4* __res
 }
 
 // ---- weight gradient: dM = A dY A^T (alpha x alpha from the m x m output-gradient tile) ------------------------------
-template <int M, int VEC, int R>
-__global__ __launch_bounds__(256) void wino_dout_kernel(const float4* __restrict__ dy, float4* __restrict__ dm, int N, int H, int W, int C4, long long slab)
+// POOL: dy is not materialised -- it is the max-pool backward of dpool [N,H/2,W/2,C] routed by the argmax bytes the forward output
+// transform kept (see wino_input_dout_kernel); tile origins are even, so a tile covers whole windows.
+template <int M, int VEC, int R, bool POOL>
+__global__ __launch_bounds__(256) void wino_dout_kernel(const float4* __restrict__ dy, float4* __restrict__ dm, int N, int H, int W, int C4, long long slab,
+                                                        const unsigned char* __restrict__ pidx)
 {
     constexpr int A = WinoMat<M, R>::A;
     const int th = (H + M - 1) / M, tw = (W + M - 1) / M;      // partial tiles at the bottom / right edge (F(6x6): 512 = 85 * 6 + 2)
     const TileIdx ti = tile_index(th, tw, C4);
     if (!ti.ok) return;
     const float4* yp = dy + (((long long)ti.n * H + M * ti.ty) * W + M * ti.tx) * C4 + ti.c;
+    const int Hp = H / 2, Wp = W / 2;
     float4 q[A][M];                            // q = A dY  (A = (A^T)^T)
 #pragma unroll
     for (int ox = 0; ox < M; ++ox) {
         float4 col[M];
+        if (POOL) {
+#pragma unroll
+            for (int wr = 0; wr < M / 2; ++wr) {
+                const int py = (M / 2) * ti.ty + wr, px = (M / 2) * ti.tx + ox / 2;
+                const bool wok = py < Hp && px < Wp;
+                const long long wo = (((long long)ti.n * Hp + py) * Wp + px) * C4 + ti.c;
+                float4 g = f4zero();
+                unsigned char id[VEC];
+                _Pragma("unroll") for (int i = 0; i < VEC; ++i) id[i] = 4;
+                if (wok) { g = dy[wo]; _Pragma("unroll") for (int i = 0; i < VEC; ++i) id[i] = pidx[wo * VEC + i]; }
+                _Pragma("unroll") for (int half = 0; half < 2; ++half) {
+                    const int pos = half * 2 + (ox & 1);
+                    _Pragma("unroll") for (int i = 0; i < VEC; ++i) col[2 * wr + half].d[i] = id[i] == pos ? g.d[i] : 0.f;
+                }
+            }
+        } else {
 #pragma unroll
         for (int oy = 0; oy < M; ++oy) col[oy] = (M * ti.ty + oy < H && M * ti.tx + ox < W) ? yp[(oy * W + ox) * C4] : f4zero();
+        }
 #pragma unroll
         for (int a = 0; a < A; ++a) {
             float4 s = f4zero();
@@ -431,6 +456,102 @@ __global__ __launch_bounds__(256) void wino_dout_kernel(const float4* __restrict
 #pragma unroll
             for (int k = 0; k < M; ++k) if (WinoMat<M, R>::at(k, b) != 0.f) s = f4fma(WinoMat<M, R>::at(k, b), q[a][k], s);
             dp[(a * A + b) * slab] = s;
+        }
+}
+
+// ---- data gradient as the adjoint of the forward algorithm (F(6x6,3x3)): dx = sum over tiles of B dV B^T, overlap-added ----------
+// Forward: V = B^T d B per tile (8x8 patches, stride 6).  Its adjoint maps dV = dM U^T (dM = A dY A^T, the tensor the weight gradient
+// needs anyway) back to the input: every tile contributes the 8x8 patch B dV B^T, and neighbouring patches overlap by two pixels.
+// One thread = one 6x6 output region x VEC channels, computed as a gather: the inner 6x6 of its own patch plus the border rows /
+// columns / corners of the eight neighbouring patches.  Row 0 and row 7 of B have a single non-zero (B^T(0,0), B^T(7,7)), so a
+// neighbour's border row needs only its eight values of position row 7 (or 0): 100 loads per thread instead of 64, the extra ones
+// from slabs other threads of the same wave stream anyway.  Compared with transforming dY a second time (V' = B^T dY_patch B) this
+// removes one [P][T][C] write per layer from the backward pass.
+template <int VEC>
+__global__ __launch_bounds__(256, 2) void wino_dgrad_output_kernel(const float4* __restrict__ dv, const float4* __restrict__ addend,
+                                                                   const float4* __restrict__ mask, float mask_scale, const unsigned* __restrict__ rbits_in,
+                                                                   float4* __restrict__ y, int N, int H, int W, int C4, long long slab)
+{
+    constexpr int M = 6, A = 8;
+    typedef WinoMat<6, 3> WM;
+    constexpr int RW = (M * M * VEC + 31) / 32;
+    const int th = (H + M - 1) / M, tw = (W + M - 1) / M;
+    const TileIdx ti = tile_index(th, tw, C4);
+    if (!ti.ok) return;
+    const long long o = ti.t * C4 + ti.c;
+    unsigned rb[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) rb[j] = rbits_in ? rbits_in[o * RW + j] : 0u;
+    float4 tt[M][A];                           // tt[i][b] = sum_a B^T(a, i+1) dV[a][b]   (patch rows 1..6)
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+        float4 col[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) col[a] = dv[(a * A + b) * slab + o];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            float4 s = f4zero();
+#pragma unroll
+            for (int a = 0; a < A; ++a) if (WM::bt(a, i + 1) != 0.f) s = f4fma(WM::bt(a, i + 1), col[a], s);
+            tt[i][b] = s;
+        }
+    }
+    // neighbours' border contributions
+    const bool up = ti.ty > 0, down = ti.ty + 1 < th, left = ti.tx > 0, right = ti.tx + 1 < tw;
+    float4 nrow[2][M], ncol[2][M], corner[2][2];      // [0] = top / left, [1] = bottom / right
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const bool okr = e == 0 ? up : down, okc = e == 0 ? left : right;
+        const long long orow = o + (e == 0 ? -(long long)tw : (long long)tw) * C4, ocol = o + (e == 0 ? -1 : 1) * (long long)C4;
+        const int pa = e == 0 ? 7 : 0;                 // the neighbour's position row / column that reaches into this region
+        const float edge = WM::bt(pa, pa);             // the single non-zero of B's row `pa`
+        float4 r[A], c[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k) { r[k] = okr ? dv[(pa * A + k) * slab + orow] : f4zero(); c[k] = okc ? dv[(k * A + pa) * slab + ocol] : f4zero(); }
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            float4 sr = f4zero(), sc = f4zero();
+#pragma unroll
+            for (int k = 0; k < A; ++k) if (WM::bt(k, j + 1) != 0.f) { sr = f4fma(WM::bt(k, j + 1), r[k], sr); sc = f4fma(WM::bt(k, j + 1), c[k], sc); }
+            _Pragma("unroll") for (int v = 0; v < VEC; ++v) { sr.d[v] *= edge; sc.d[v] *= edge; }
+            nrow[e][j] = sr; ncol[e][j] = sc;
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {                  // corners: (row neighbour e, column neighbour f)
+            const bool okf = f == 0 ? left : right;
+            const int pb = f == 0 ? 7 : 0;
+            const long long oc = orow + (f == 0 ? -1 : 1) * (long long)C4;
+            float4 v = (okr && okf) ? dv[(pa * A + pb) * slab + oc] : f4zero();
+            _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] *= edge * WM::bt(pb, pb);
+            corner[e][f] = v;
+        }
+    }
+    const long long off0 = (((long long)ti.n * H + M * ti.ty) * W + M * ti.tx) * C4 + ti.c;
+#pragma unroll
+    for (int oy = 0; oy < M; ++oy)
+#pragma unroll
+        for (int ox = 0; ox < M; ++ox) {
+            float4 v = f4zero();
+#pragma unroll
+            for (int b = 0; b < A; ++b) if (WM::bt(b, ox + 1) != 0.f) v = f4fma(WM::bt(b, ox + 1), tt[oy][b], v);
+            if (oy == 0)     { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += nrow[0][ox].d[k]; }
+            if (oy == M - 1) { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += nrow[1][ox].d[k]; }
+            if (ox == 0)     { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += ncol[0][oy].d[k]; }
+            if (ox == M - 1) { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += ncol[1][oy].d[k]; }
+            if ((oy == 0 || oy == M - 1) && (ox == 0 || ox == M - 1)) { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += corner[oy == 0 ? 0 : 1][ox == 0 ? 0 : 1].d[k]; }
+            if (!(M * ti.ty + oy < H && M * ti.tx + ox < W)) continue;                   // partial edge tiles
+            const long long off = off0 + (oy * W + ox) * C4;
+            if (addend) { const float4 ad = addend[off]; _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += ad.d[k]; }
+            if (rbits_in) {
+                _Pragma("unroll") for (int k = 0; k < VEC; ++k) {
+                    const int bit = (oy * M + ox) * VEC + k;
+                    v.d[k] = ((rb[bit >> 5] >> (bit & 31)) & 1u) ? v.d[k] * mask_scale : 0.f;
+                }
+            } else if (mask) {
+                const float4 mk = mask[off];
+                _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] = mk.d[k] > 0.f ? v.d[k] * mask_scale : 0.f;
+            }
+            y[off] = v;
         }
 }
 
@@ -499,14 +620,30 @@ long long wino_slab(long long T, int C)
     static const int skew = env_flag("FCN8S_WINO_SKEW", 1088) / 4 * 4;
     return T * C + skew;
 }
-void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, int KS, hipStream_t s)
+void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, int KS, hipStream_t s, int transpose_out)
 {
     const int nsub = wino_nsub(KS);
     const int g = wcap((long long)Cin * Cout * nsub * nsub);
-    if (tile == 6)                    hipLaunchKernelGGL((wino_filter_kernel<6, 3>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
-    else if (tile == 4 && wino_r(KS) == 4) hipLaunchKernelGGL((wino_filter_kernel<4, 4>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
-    else if (tile == 4)               hipLaunchKernelGGL((wino_filter_kernel<4, 3>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
-    else                              hipLaunchKernelGGL((wino_filter_kernel<2, 3>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub);
+    if (nsub != 1) transpose_out = 0;
+    if (tile == 6)                    hipLaunchKernelGGL((wino_filter_kernel<6, 3>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub, transpose_out);
+    else if (tile == 4 && wino_r(KS) == 4) hipLaunchKernelGGL((wino_filter_kernel<4, 4>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub, transpose_out);
+    else if (tile == 4)               hipLaunchKernelGGL((wino_filter_kernel<4, 3>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub, transpose_out);
+    else                              hipLaunchKernelGGL((wino_filter_kernel<2, 3>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub, transpose_out);
+}
+bool wino_dgrad_adjoint_enabled() { static const int on = env_flag("FCN8S_WINO_DGRAD_ADJOINT", 1); return on != 0; }
+void launch_wino_dgrad_output(const float* dv, const float* addend, const float* mask, float mask_scale, const unsigned* rbits_in, float* y,
+                              int N, int H, int W, int C, hipStream_t s)
+{
+    constexpr int M_ = 6;
+    static const int vec = env_flag("FCN8S_WINO_DGRAD_VEC", 2);
+    const long long T = (long long)N * ((H + M_ - 1) / M_) * ((W + M_ - 1) / M_);
+    // (the ReLU bit words are laid out per (tile, channel pair): the one-channel-per-lane variant is only used without them)
+    if (vec == 1 && !rbits_in)
+        hipLaunchKernelGGL((wino_dgrad_output_kernel<1>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C), dim3(256), 0, s,
+                           (const VecF<1>*)dv, (const VecF<1>*)addend, (const VecF<1>*)mask, mask_scale, rbits_in, (VecF<1>*)y, N, H, W, C, wino_slab(T, C));
+    else
+        hipLaunchKernelGGL((wino_dgrad_output_kernel<2>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / 2), dim3(256), 0, s,
+                           (const VecF<2>*)dv, (const VecF<2>*)addend, (const VecF<2>*)mask, mask_scale, rbits_in, (VecF<2>*)y, N, H, W, C / 2, wino_slab(T, C) / 2);
 }
 bool wino_fuse_dz_enabled() { static const int on = env_flag("FCN8S_WINO_FUSE_DZ", 1); return on != 0; }
 bool launch_wino_input_dout(int tile, const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s, const unsigned char* pidx)
@@ -546,11 +683,13 @@ void launch_wino_output(int tile, const float* m, const float* bias, const float
 #undef FCN8S_WOUT
 #undef FCN8S_WOUT2
 }
-void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s, int KS)
+void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s, int KS, const unsigned char* pidx)
 {
-#define FCN8S_WDOUT(M_, V_, R_) hipLaunchKernelGGL((wino_dout_kernel<M_, V_, R_>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / V_), dim3(256), 0, s, \
-        (const VecF<V_>*)dy, (VecF<V_>*)dm, N, H, W, C / V_, wino_slab((long long)N * ((H + M_ - 1) / M_) * ((W + M_ - 1) / M_), C) / V_)
-    if (tile == 6)                    FCN8S_WDOUT(6, 2, 3);
+#define FCN8S_WDOUT(M_, V_, R_) hipLaunchKernelGGL((wino_dout_kernel<M_, V_, R_, false>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / V_), dim3(256), 0, s, \
+        (const VecF<V_>*)dy, (VecF<V_>*)dm, N, H, W, C / V_, wino_slab((long long)N * ((H + M_ - 1) / M_) * ((W + M_ - 1) / M_), C) / V_, nullptr)
+    if (tile == 6 && pidx)            hipLaunchKernelGGL((wino_dout_kernel<6, 2, 3, true>), tile_grid(N, (H + 5) / 6, (W + 5) / 6, C / 2), dim3(256), 0, s,
+                                                         (const VecF<2>*)dy, (VecF<2>*)dm, N, H, W, C / 2, wino_slab((long long)N * ((H + 5) / 6) * ((W + 5) / 6), C) / 2, pidx);
+    else if (tile == 6)               FCN8S_WDOUT(6, 2, 3);
     else if (tile == 4 && wino_r(KS) == 4) FCN8S_WDOUT(4, 2, 4);
     else if (tile == 4)               FCN8S_WDOUT(4, 2, 3);
     else                              FCN8S_WDOUT(2, 4, 3);

@@ -5,7 +5,7 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-python bench.py --steps 10 --warmup 3 > $OUT/bench_train_bs16.json 2> $OUT/bench.err
+python bench.py --steps 20 --warmup 5 > $OUT/bench_train_bs16.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2>> $OUT/bench.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> $OUT/bench.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> $OUT/bench.err
