@@ -211,7 +211,8 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
              unsigned char* pool_idx = nullptr;          // ... with the per-window argmax bytes the backward pass routes the pool gradient by
              unsigned* relu_bits_out = nullptr;          // forward, Winograd path: also record (y > 0), one bit per element
              const unsigned* relu_bits_in = nullptr;     // data gradient, Winograd path: such a record of `mask` (read instead of the tensor)
-             const float* w_fwd = nullptr; };            // data gradient: the layer's forward kernel [3,3,Cout_of_this_conv... = Cin here][...] (adjoint Winograd path)
+             const float* w_fwd = nullptr;
+             int skip_y = 0; };                          // Winograd path with pool_out: do not write the full-resolution output (only its pool is consumed)            // data gradient: the layer's forward kernel [3,3,Cout_of_this_conv... = Cin here][...] (adjoint Winograd path)
 
 // 3x3 SAME conv through Winograd F(tile x tile, 3x3): filter transform, input transform, (tile+2)^2 batched GEMMs
 // on the matrix cores (2.25x / 4x fewer MFMA flops than the direct form), output transform + fused epilogue.
@@ -233,7 +234,7 @@ int wino_tile_for(const fcn8s_model* m, int H, int W, int K = 3)
 long long wino_tiles(int tile, int N, int H, int W) { return (long long)N * ((H + tile - 1) / tile) * ((W + tile - 1) / tile); }
 struct WinoEpi { const float* bias = nullptr; const float* addend = nullptr; const float* mask = nullptr; float mask_scale = 1.f;
                  int relu = 0; int dropout = 0; float keep = 1.f; unsigned long long seed = 0; unsigned int stream_id = 0; float* pool = nullptr; unsigned char* pidx = nullptr;
-                 unsigned* rbits_out = nullptr; const unsigned* rbits_in = nullptr; };
+                 unsigned* rbits_out = nullptr; const unsigned* rbits_in = nullptr; int skip_y = 0; };
 // KS = 3, or 7 (3x3 grid of 3x3 sub-filters, GEMM depth 9*Cin -- see winograd.hip)
 void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const float* x, const float* wk, float* y, float* u, float* v, float* mm,
                    int N, int H, int W, int Cin, int Cout, const WinoEpi& e, hipStream_t s, const char* layer, bool v_ready = false)
@@ -250,7 +251,7 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
     a.out_scale = 1; a.phases_x = 1; a.w_phase_stride = (long long)Kg * Cout;
     a.alpha = 1.f; a.mask_scale = 1.f;
     a.batched = 1; a.x_batch_stride = wino_slab(T, Kg); a.y_batch_stride = wino_slab(T, Cout);
-    const double tb = 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg), ob = 4.0 * ((double)N * H * W * Cout * ((e.pool ? 1.25 : 1.0) + (e.rbits_in ? 1.0 / 32 : (e.mask ? 1.0 : 0.0)) + (e.addend ? 1.0 : 0.0) + (e.rbits_out ? 1.0 / 32 : 0.0)) + (double)P * T * Cout);   // y (+ pool) written, ReLU mask / skip addend read
+    const double tb = 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg), ob = 4.0 * ((double)N * H * W * Cout * ((e.pool ? (e.skip_y ? 0.25 : 1.25) : 1.0) + (e.rbits_in ? 1.0 / 32 : (e.mask ? 1.0 : 0.0)) + (e.addend ? 1.0 : 0.0) + (e.rbits_out ? 1.0 / 32 : 0.0)) + (double)P * T * Cout);   // y (+ pool) written, ReLU mask / skip addend read
     // frozen parameters (evaluate / predict loops): the transformed filter bank of each forward layer is computed once and kept
     bool u_cached = false;
     if (m && m->frozen && layer && !v_ready && std::string(tag).find("dgrad") == std::string::npos) {
@@ -262,7 +263,7 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
     }
     // v_ready: V was written together with the weight gradient's dM by the fused transform (launch_wino_input_dout)
     auto pre = [&]() { if (!u_cached) launch_wino_filter(tile, wk, u, Cin, Cout, KS, s); if (!v_ready) launch_wino_input(tile, x, v, N, H, W, Cin, KS, s); };
-    auto post = [&]() { launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s, e.pool, e.pidx, KS, e.rbits_out, e.rbits_in); };
+    auto post = [&]() { launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, (e.skip_y && e.pool) ? nullptr : y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s, e.pool, e.pidx, KS, e.rbits_out, e.rbits_in); };
     if (m) {
         { ProfScope ps(m, "wino_transform", 0, (v_ready ? 0.0 : tb) + (u_cached ? 0.0 : (double)(KS * KS + P * nsub2) * 4 * Cin * Cout)); pre(); }
         { ProfScope ps(m, tag, 2.0 * P * T * Kg * Cout, 4.0 * P * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_igemm(a, P, s); }
@@ -309,7 +310,7 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
         if (!dgrad && layer) { auto it = m->acts.find(std::string("wv:") + layer); if (it != m->acts.end()) vbuf = it->second.p; }
         WinoEpi we; we.bias = e.bias; we.addend = e.addend; we.mask = e.mask; we.mask_scale = e.mask_scale; we.relu = e.relu;
         we.dropout = e.dropout; we.keep = e.keep; we.seed = m->seed; we.stream_id = e.stream_id; we.pool = e.pool_out; we.pidx = e.pool_idx;
-        we.rbits_out = e.relu_bits_out; we.rbits_in = e.relu_bits_in;
+        we.rbits_out = e.relu_bits_out; we.rbits_in = e.relu_bits_in; we.skip_y = e.skip_y && e.pool_out;
         if (e.relu_bits_out && layer) m->rbits_ok.insert(layer);
         const char* tag = K == 7 ? (dgrad ? "wino_gemm_fc6_dgrad" : "wino_gemm_fc6_fwd") : (dgrad ? "wino_gemm_dgrad" : "wino_gemm_fwd");
         conv_winograd(m, wino_tile_for(m, H, W, K), K, tag, x, w, y, m->d_wino_u, vbuf, m->d_wino_m, N, H, W, Cin, Cout, we, s, layer, v_ready);
@@ -596,6 +597,16 @@ void prepare_forward_weights(fcn8s_model* m)
     launch_tconv_phase_pack(Wp(m, "fc7_pool4_pool3_conv2d_trans/kernel"), m->d_tph[2], 16, 8, m->C, s);
 }
 
+// Whether the backward pass routes d(pool_b) through the argmax bytes inside the Winograd transform of conv_b_last (then neither dZ
+// nor the conv's full-resolution output is ever read again); b is the 1-based block number.  Same test as backward_blocks().
+bool pool_backward_fused(const fcn8s_model* m, int b, bool pooled_by_transform)
+{
+    const int h = m->H >> (b - 1), w = m->W >> (b - 1), cw = m->widths[b - 1], nconv = kConvsPerBlock[b - 1];
+    char last[32]; snprintf(last, sizeof last, "wv:conv%d_%d", b, nconv);
+    return pooled_by_transform && wino_fuse_dz_enabled() && m->wino_min_cin > 0 && cw >= m->wino_min_cin && m->d_wino_v &&
+           wino_tile_for(m, h, w) >= 4 && cw % 64 == 0 && nconv > 1 && m->acts.count(last);
+}
+
 int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, bool train)
 {
     hipStream_t s = m->stream;
@@ -629,6 +640,10 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
             if (i == kConvsPerBlock[b]) {                                                                    // last conv of the block
                 snprintf(pn, sizeof pn, "pool%d", b + 1); e.pool_out = A(m, pn);
                 if (train) { char ix[16]; snprintf(ix, sizeof ix, "pidx%d", b + 1); e.pool_idx = (unsigned char*)A(m, ix); }
+                // The block's last conv output feeds only the pool.  If the output transform writes the pool (and, for training, the backward
+                // pass routes through the argmax bytes), the full-resolution tensor is never read again and is not written at all
+                // (2.15 GB for conv1_2 at 16 x 1024x512); fcn8s_get_activation of such a layer then returns stale data.
+                e.skip_y = !train || pool_backward_fused(m, b + 1, true);
             }
             pooled = conv_same(m, first ? "conv1_1_fwd" : "conv3x3_fwd", x, wt, A(m, nm), N, h, w, cin, m->widths[b], 3, e, s, first ? 3 : 0, nm);
             x = A(m, nm); cin = m->widths[b];
@@ -806,8 +821,7 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
         const unsigned char* pidx = nullptr;
         {
             char ix[16]; snprintf(ix, sizeof ix, "pidx%d", b);
-            const bool wino_both = m->pool_fused[b - 1] && wino_fuse_dz_enabled() && m->wino_min_cin > 0 && cw >= m->wino_min_cin && m->d_wino_v &&
-                                   wino_tile_for(m, h, w) >= 4 && cw % 64 == 0 && nconv > 1 && m->acts.count(std::string("wv:") + last);
+            const bool wino_both = pool_backward_fused(m, b, m->pool_fused[b - 1]);
             if (wino_both) pidx = (const unsigned char*)A(m, ix);
         }
         if (!pidx) {

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 3) void wino_output_kernel(const float4* __res
                 const float ik = 1.f / keep;
                 _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = philox_uniform(e + i, seed, stream_id) < keep ? v.d[i] * ik : 0.f;
             }
-            y[off] = v;
+            if (!POOL || y) y[off] = v;          // POOL launches may skip the full-resolution tensor (nobody reads it: see model.hip forward())
             if (rbits_out) {
                 _Pragma("unroll") for (int i = 0; i < VEC; ++i) {
                     const int bit = (oy * M + ox) * VEC + i;
