@@ -27,6 +27,41 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized()) else None
 
 
+_CLASS_AXES = {   # axes of the decoder variables that run over classes (fcn8s_tensorflow.py:173-233)
+    'pool3_1x1/kernel': (3,), 'pool3_1x1/bias': (0,), 'pool4_1x1/kernel': (3,), 'pool4_1x1/bias': (0,),
+    'fc7_1x1/kernel': (3,), 'fc7_1x1/bias': (0,),
+    'fc7_conv2d_trans/kernel': (2, 3), 'fc7_conv2d_trans/bias': (0,),
+    'fc7_pool4_conv2d_trans/kernel': (2, 3), 'fc7_pool4_conv2d_trans/bias': (0,),
+    'fc7_pool4_pool3_conv2d_trans/kernel': (2, 3), 'fc7_pool4_pool3_conv2d_trans/bias': (0,)}
+_PAD_LOGIT = -1e30   # bias of a padding class in the last layer: its softmax probability is exactly 0, so is every gradient that touches it
+
+
+def padded_classes(num_classes):
+    """The library's class dimension: the next multiple of 4 (its C-channel tensors are accessed 16 bytes at a time)."""
+    return (int(num_classes) + 3) // 4 * 4
+
+
+def _pad_classes(name, a, c, cpad, slot=False):
+    """Embed a decoder variable with `c` classes into the `cpad`-class shape: padding weights 0 (a padding channel then carries
+    exactly 0 through the decoder and receives exactly 0 gradient -- the subspace is invariant under training), padding entries of
+    the last bias _PAD_LOGIT."""
+    axes = _CLASS_AXES.get(name)
+    if axes is None or c == cpad:
+        return a
+    a = np.asarray(a)
+    pad = [(0, cpad - c) if i in axes else (0, 0) for i in range(a.ndim)]
+    fill = _PAD_LOGIT if (name == 'fc7_pool4_pool3_conv2d_trans/bias' and not slot) else 0.0
+    return np.pad(a, pad, constant_values=fill)
+
+
+def _unpad_classes(name, a, c, cpad):
+    axes = _CLASS_AXES.get(name)
+    if axes is None or c == cpad:
+        return a
+    sl = tuple(slice(0, c) if i in axes else slice(None) for i in range(np.ndim(a)))
+    return np.ascontiguousarray(np.asarray(a)[sl])
+
+
 class Staged:
     """One host batch on its way to the GPU through a staging slot (Engine.stage): pinned copy + H2D on the library's copy
     stream, started by whoever called stage() -- typically the feeder thread, while the compute stream runs the previous step."""
@@ -37,7 +72,7 @@ class Staged:
 
 
 class Engine:
-    def __init__(self, num_classes, widths=None, fc6_ksize=7, device_id=0, seed=0, process_group=None, precision='fp32'):
+    def __init__(self, num_classes, widths=None, fc6_ksize=7, device_id=0, seed=0, process_group=None, precision='fp32', logical_classes=None):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("fcn8s_tensorflow_amd needs an AMD GPU (gfx950); there is no CPU fallback for the hot path")
@@ -45,6 +80,8 @@ class Engine:
         self.device = torch.device("cuda", device_id)
         torch.cuda.set_device(self.device)
         self.num_classes = int(num_classes)
+        # classes the caller sees when `num_classes` was padded to the library's multiple of 4 (FCN8s facade): one-hot labels carry this many channels
+        self.logical_classes = int(logical_classes) if logical_classes else int(num_classes)
         self.pg = process_group
         cfg = L.Config()
         cfg.num_classes = int(num_classes)
@@ -119,7 +156,7 @@ class Engine:
         for k, v in params.items():
             if k not in self.specs:
                 raise ValueError("unknown variable '%s'" % k)
-            a = np.ascontiguousarray(v, dtype=np.float32)
+            a = np.ascontiguousarray(self.pad(k, np.asarray(v, dtype=np.float32)), dtype=np.float32)
             if tuple(a.shape) != self.specs[k][0]:
                 raise ValueError("variable '%s' has shape %s, expected %s" % (k, a.shape, self.specs[k][0]))
             L.check(L.lib.fcn8s_set_param(self.h, k.encode(), a.ctypes.data_as(C.c_void_p), a.size), self.h)
@@ -129,7 +166,7 @@ class Engine:
         for k, (shape, _) in self.specs.items():
             a = np.empty(shape, np.float32)
             L.check(L.lib.fcn8s_get_param(self.h, k.encode(), a.ctypes.data_as(C.c_void_p), a.size), self.h)
-            out[k] = a
+            out[k] = self.unpad(k, a)
         return out
 
     def get_grads(self):
@@ -137,12 +174,26 @@ class Engine:
         for k, (shape, _) in self.specs.items():
             a = np.empty(shape, np.float32)
             L.check(L.lib.fcn8s_get_grad(self.h, k.encode(), a.ctypes.data_as(C.c_void_p), a.size), self.h)
-            out[k] = a
+            out[k] = self.unpad(k, a)
         return out
+
+    def pad(self, name, a, slot=False):
+        """A variable (or, slot=True, one of its optimizer slots) with `logical_classes` classes in the library's padded shape."""
+        return _pad_classes(name, a, self.logical_classes, self.num_classes, slot)
+
+    def unpad(self, name, a):
+        return _unpad_classes(name, a, self.logical_classes, self.num_classes)
 
     def init_params(self, seed=0):
         self._sync_stream()
         L.check(L.lib.fcn8s_init_params(self.h, int(seed)), self.h)
+        if self.logical_classes != self.num_classes:           # padding classes: zero weights, probability-0 bias in the last layer
+            c = self.logical_classes
+            for name, axes in _CLASS_AXES.items():
+                v = self.param_view(name)
+                fill = _PAD_LOGIT if name == 'fc7_pool4_pool3_conv2d_trans/bias' else 0.0
+                for ax in axes:
+                    v.narrow(ax, c, self.num_classes - c).fill_(fill)
 
     def broadcast_params(self, src=0):
         d = _dist()
@@ -199,8 +250,8 @@ class Engine:
         """One-hot rows (N,H,W,C) on the device -> uint8 class ids on the device (library kernel).
         The first batches are also checked for being one-hot (costs one host sync each)."""
         torch = self.torch
-        if t.shape[-1] != self.num_classes:
-            raise ValueError("one-hot labels must have %d channels, got %d" % (self.num_classes, t.shape[-1]))
+        if t.shape[-1] != self.logical_classes:
+            raise ValueError("one-hot labels must have %d channels, got %d" % (self.logical_classes, t.shape[-1]))
         if tuple(t.shape[:3]) != tuple(nhw):
             raise ValueError("labels shape %s does not match images %s" % (tuple(t.shape), tuple(nhw)))
         if t.dtype in (torch.bool, torch.uint8, torch.int8):
@@ -217,7 +268,7 @@ class Engine:
         if self._bad is None:
             self._bad = torch.zeros(1, dtype=torch.int32, device=self.device)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        L.check(L.lib.fcn8s_onehot_to_ids(stream, C.c_void_p(t.data_ptr()), eb, npix, self.num_classes,
+        L.check(L.lib.fcn8s_onehot_to_ids(stream, C.c_void_p(t.data_ptr()), eb, npix, self.logical_classes,
                                           C.c_void_p(ids.data_ptr()), C.c_void_p(self._bad.data_ptr())))
         self._label_calls += 1
         if self._label_checks_left > 0 or self._label_calls % 64 == 0:
@@ -368,11 +419,17 @@ class Engine:
         self._sync_stream()
         L.check(L.lib.fcn8s_metrics_reset(self.h), self.h)
 
-    def metrics_raw(self):
+    def _metrics_raw_padded(self):
         Cn = self.num_classes
         cm = np.zeros((Cn, Cn), np.int64); ls = C.c_double(); lc = C.c_int64()
         L.check(L.lib.fcn8s_metrics_raw(self.h, cm.ctypes.data_as(C.c_void_p), C.byref(ls), C.byref(lc)), self.h)
         return cm, float(ls.value), int(lc.value)
+
+    def metrics_raw(self):
+        """(confusion matrix [label, prediction] over the caller's classes, sum of the per-batch losses, number of batches)"""
+        cm, ls, lc = self._metrics_raw_padded()
+        c = self.logical_classes
+        return np.ascontiguousarray(cm[:c, :c]), ls, lc
 
     def metrics_allreduce(self):
         """Sum the confusion matrix and the per-batch loss samples over ranks."""
@@ -380,7 +437,7 @@ class Engine:
         if not d or self.world_size == 1:
             return
         torch = self.torch
-        cm, ls, lc = self.metrics_raw()
+        cm, ls, lc = self._metrics_raw_padded()
         t = torch.cat([torch.from_numpy(cm.reshape(-1)).double(), torch.tensor([ls, float(lc)], dtype=torch.float64)]).to(self.device)
         d.all_reduce(t, group=self.pg)
         t = t.cpu()
@@ -392,6 +449,8 @@ class Engine:
         tutorial's TF 1.3.0 tf.metrics.mean_iou does) instead of over the classes that occur (later TF 1.x)."""
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         L.check(L.lib.fcn8s_metrics_get_ex(self.h, C.byref(a), C.byref(b), C.byref(c), 1 if all_classes else 0), self.h)
+        if all_classes and self.logical_classes != self.num_classes:      # the padding classes never occur: they must not count as absent ones
+            b = C.c_double(b.value * self.num_classes / self.logical_classes)
         return float(a.value), float(b.value), float(c.value)
 
     def augment(self, images, labels=None, out_hw=None, offsets=None, flips=None, gains=None, void_class_id=0):
@@ -486,10 +545,10 @@ class Engine:
                 torch.empty((N, H, W, self.num_classes), dtype=torch.float32, device=self.device)
             L.check(L.lib.fcn8s_predict(self.h, pi, dt, N, H, W, int(bool(argmax)), C.c_void_p(out.data_ptr()), where), self.h)
             self._release(ka_i)
-            return out
+            return out if argmax or self.logical_classes == self.num_classes else out[..., :self.logical_classes].contiguous()
         out = np.empty((N, H, W), np.int64) if argmax else np.empty((N, H, W, self.num_classes), np.float32)
         L.check(L.lib.fcn8s_predict(self.h, pi, dt, N, H, W, int(bool(argmax)), out.ctypes.data_as(C.c_void_p), where), self.h)
-        return out
+        return out if argmax or self.logical_classes == self.num_classes else np.ascontiguousarray(out[..., :self.logical_classes])
 
     # ---- introspection (tests, bench) -----------------------------------------------------------
     def activation(self, name, shape):

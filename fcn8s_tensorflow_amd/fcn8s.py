@@ -48,7 +48,7 @@ except Exception:  # pragma: no cover
 
 from . import _lib as L
 from . import tf_bundle
-from .engine import Engine
+from .engine import Engine, padded_classes
 
 _SAVERS = {'saved_model', 'train_saver'}
 
@@ -70,7 +70,8 @@ class FCN8s:
             tags (list, optional): kept for signature parity; checked against the saved tags if given.
             vgg16_dir (string, optional): the VGG-16 SavedModel directory (variables bundle), a directory with
                 `vgg16_weights.npz`, or 'synthetic[:seed]'.
-            num_classes (int, optional): number of segmentation classes (multiple of 4).
+            num_classes (int, optional): number of segmentation classes (any count up to 64; counts that are not a multiple of 4
+                are padded inside the engine with classes of probability 0).
             variables_load_dir (string, optional): path prefix written by `save(saver='train_saver')`.
             device_id (int, optional): HIP device; defaults to LOCAL_RANK or 0.
             seed (int): dropout seed (rank is added in data-parallel runs).
@@ -113,18 +114,20 @@ class FCN8s:
                 raise ValueError("'{}' does not hold an FCN-8s checkpoint (no variable 'fc7_1x1/bias').".format(model_load_dir))
             self.num_classes = int(tensors['fc7_1x1/bias'].shape[0])
             w = tuple(int(tensors[k].shape[-1]) for k in ('conv1_2/filter', 'conv2_2/filter', 'conv3_3/filter', 'conv4_3/filter', 'conv5_3/filter', 'fc6/weights', 'fc7/weights'))
-            self.engine = Engine(self.num_classes, widths=w, fc6_ksize=int(tensors['fc6/weights'].shape[0]), device_id=device_id, seed=seed + rank)
+            self.engine = Engine(padded_classes(self.num_classes), widths=w, fc6_ksize=int(tensors['fc6/weights'].shape[0]), device_id=device_id, seed=seed + rank,
+                                 logical_classes=self.num_classes)
             _load_tf_tensors(self.engine, tensors, with_state=True)
         elif model_load_dir is not None:
             meta = _read_meta(model_load_dir)
             if tags is not None and meta.get("tags") is not None and not set(tags) <= set(meta["tags"]):
                 raise RuntimeError("MetaGraphDef associated with tags {} could not be found in SavedModel (available: {}).".format(tags, meta["tags"]))
             self.num_classes = int(meta["num_classes"])
-            self.engine = Engine(self.num_classes, widths=meta.get("widths"), fc6_ksize=meta.get("fc6_ksize", 7),
-                                 device_id=device_id, seed=seed + rank)
+            self.engine = Engine(padded_classes(self.num_classes), widths=meta.get("widths"), fc6_ksize=meta.get("fc6_ksize", 7),
+                                 device_id=device_id, seed=seed + rank, logical_classes=self.num_classes)
             _load_checkpoint(self.engine, os.path.join(model_load_dir, "variables", "variables.npz"), with_state=True)
         else:
-            self.engine = Engine(num_classes, widths=widths, fc6_ksize=fc6_ksize, device_id=device_id, seed=seed + rank)
+            self.engine = Engine(padded_classes(num_classes), widths=widths, fc6_ksize=fc6_ksize, device_id=device_id, seed=seed + rank,
+                                 logical_classes=num_classes)
             self._load_vgg16()
             if variables_load_dir is not None:
                 self.load_variables(variables_load_dir)
@@ -487,8 +490,8 @@ class FCN8s:
             m, v = self.engine.get_opt_state()
             for k, (shape, off) in self.engine.specs.items():
                 n = int(np.prod(shape))
-                tensors[k + tf_bundle.ADAM_M_SUFFIX] = m[off:off + n].reshape(shape)
-                tensors[k + tf_bundle.ADAM_V_SUFFIX] = v[off:off + n].reshape(shape)
+                tensors[k + tf_bundle.ADAM_M_SUFFIX] = self.engine.unpad(k, m[off:off + n].reshape(shape))
+                tensors[k + tf_bundle.ADAM_V_SUFFIX] = self.engine.unpad(k, v[off:off + n].reshape(shape))
             step = self.engine.global_step
             tensors['optimizer/global_step'] = np.asarray(step, dtype=np.int32)
             # AdamOptimizer's non-slot variables (initialised to beta, multiplied by beta in every apply): a Saver over all
@@ -536,8 +539,8 @@ def _load_tf_tensors(engine, tensors, with_state=True):
     for k, (shape, off) in engine.specs.items():
         cnt = int(np.prod(shape))
         if k + tf_bundle.ADAM_M_SUFFIX in tensors and k + tf_bundle.ADAM_V_SUFFIX in tensors:
-            m[off:off + cnt] = tensors[k + tf_bundle.ADAM_M_SUFFIX].reshape(-1)
-            v[off:off + cnt] = tensors[k + tf_bundle.ADAM_V_SUFFIX].reshape(-1)
+            m[off:off + cnt] = engine.pad(k, tensors[k + tf_bundle.ADAM_M_SUFFIX], slot=True).reshape(-1)
+            v[off:off + cnt] = engine.pad(k, tensors[k + tf_bundle.ADAM_V_SUFFIX], slot=True).reshape(-1)
             found = True
     if found:
         engine.set_opt_state(m, v)
@@ -549,7 +552,7 @@ def _load_tf_tensors(engine, tensors, with_state=True):
 
 def _write_meta(target, engine, tags):
     with open(os.path.join(target, 'fcn8s_meta.json'), 'w') as f:
-        json.dump({'format': 'fcn8s_tensorflow_amd/1', 'num_classes': engine.num_classes, 'widths': list(engine.widths),
+        json.dump({'format': 'fcn8s_tensorflow_amd/1', 'num_classes': engine.logical_classes, 'widths': list(engine.widths),
                    'fc6_ksize': engine.specs['fc6/weights'][0][0], 'tags': list(tags) if tags else None,
                    'global_step': engine.global_step}, f)
 

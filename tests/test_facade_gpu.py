@@ -303,3 +303,52 @@ def test_label_id_export_feeds_the_official_scorer(tmp_path):
     res_gpu = ce.evaluate_directory(str(tmp_path / "gtFine" / "*" / "*_gtFine_labelIds.png"), str(tmp_path / "results"), device=torch.device("cuda", 0))
     np.testing.assert_array_equal(res_gpu["confMatrix"], direct.conf)
     m.close()
+
+
+@pytest.mark.parametrize("C", [2, 19])
+def test_class_counts_that_are_not_multiples_of_four(C, tmp_path):
+    """The reference takes any `num_classes` (e.g. its 2-class KITTI road setup); the library's C-channel tensors are 16-byte
+    vectors, so the facade pads the class dimension with classes of probability 0.  Everything the caller sees has C classes and
+    equals the oracle evaluated with C classes; the padding subspace stays exactly zero through training."""
+    from fcn8s_tensorflow_amd.fcn8s import FCN8s
+    m = FCN8s(vgg16_dir='synthetic:1', num_classes=C, widths=SMALL)
+    e = m.engine
+    assert e.logical_classes == C and e.num_classes % 4 == 0
+    P = orc.init_params(C, SMALL, seed=2, decoder_std_scale=30.0, bias_std=0.05)
+    e.set_params(P)
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (2, 32, 64, 3), dtype=np.uint8)
+    lab = rng.integers(0, C, (2, 32, 64), dtype=np.uint8)
+    sm = m.predict(img, argmax=False)
+    ref = orc.forward(P, img)
+    assert sm.shape == (2, 32, 64, C) and np.abs(sm.sum(-1) - 1).max() < 1e-5
+    assert np.abs(sm - orc.softmax(ref)).max() < 1e-3
+    assert m.predict(img).max() < C
+    onehot = orc.one_hot(lab, C)
+    loss = e.forward_backward(img, onehot, keep_prob=1.0, l2_rate=1e-3)
+    loss_ref, g_ref, _ = orc.loss_and_grads(P, img, onehot.astype(np.float32), l2_rate=1e-3)
+    assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    g = e.get_grads()
+    for k in g_ref:
+        assert g[k].shape == g_ref[k].shape
+        assert np.abs(g[k] - g_ref[k]).max() <= 2e-3 * (np.abs(g_ref[k]).max() + 1e-30), k
+    # training keeps the padding exactly where it was
+    def gen2():
+        while True:
+            yield img, onehot
+    m.train(gen2(), 1, 3, lambda s: 1e-3, metrics={'mean_iou'}, eval_frequency=1)
+    pad_w = e.param_view('fc7_1x1/kernel')[..., C:]
+    assert float(pad_w.abs().max()) == 0.0 and float(e.param_view('fc7_pool4_pool3_conv2d_trans/bias')[C:].max()) < -1e29
+    cm, _, _ = e.metrics_raw()
+    assert cm.shape == (C, C) and cm.sum() == 3 * lab.size          # evaluation on the training generator: 3 batches
+    m.save(str(tmp_path), 'saved_model', force_save=True)
+    d = [x for x in os.listdir(tmp_path) if x.startswith('saved_model')][0]
+    m2 = FCN8s(model_load_dir=str(tmp_path / d))
+    assert m2.num_classes == C
+    np.testing.assert_array_equal(m2.predict(img), m.predict(img))
+    m.export_tf_variables(str(tmp_path / 'tfvars'))
+    from fcn8s_tensorflow_amd import tf_bundle
+    t = tf_bundle.read_bundle(str(tmp_path / 'tfvars'))
+    assert t['fc7_conv2d_trans/kernel'].shape == (4, 4, C, C) and t['fc7_1x1/bias/adam_optimizer'].shape == (C,)
+    assert 'optimizer/beta1_power' in t and abs(float(np.asarray(t['optimizer/beta1_power']).reshape(-1)[0]) - 0.9 ** (e.global_step + 1)) < 1e-6
+    m.close(); m2.close()
