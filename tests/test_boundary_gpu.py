@@ -103,6 +103,16 @@ def test_bench_self_launches_two_ranks():
     assert out["value"] > 0 and np.isfinite(out["final_loss"])
 
 
+def test_run_dp_launches_two_ranks_and_trains():
+    """run_dp.py (the launcher INTEGRATION.md names): self-launches 2 ranks, each runs FCN8s.train() on its shard of a generated PNG
+    tree, gradients exchanged over gloo on this one-GPU box (RCCL on the 8-GPU node)."""
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_dp.py"), "--gpus", "2", "--backend", "gloo", "--device", "0", "--batch", "2",
+                        "--height", "64", "--width", "64", "--steps-per-epoch", "2", "--workers", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rank 0: 2 ranks x 2 images/step, global step 2" in r.stdout, r.stdout[-1000:]
+
+
 def test_bench_single_gpu_line_and_end_to_end_mode():
     out = _run_bench("--steps", "2", "--warmup", "1", "--batch", "2", "--height", "64", "--width", "64", "--no-cpu-baseline")
     assert out["n_gpus"] == 1 and out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
