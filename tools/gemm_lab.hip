@@ -12,6 +12,7 @@
 #include <vector>
 #include <cmath>
 #include <algorithm>
+#include <string>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -322,6 +323,52 @@ template <typename F> static void run(const char* tag, F launch, int BM, int BN,
     hipEventDestroy(e0); hipEventDestroy(e1);
 }
 
+
+// ---- co-scheduling probe: an MFMA-bound GEMM and an HBM-bound streaming kernel on two streams ---------------------------------
+template <int REGS>
+__global__ __launch_bounds__(256) void stream_kernel(const float4* __restrict__ in, float4* __restrict__ out, size_t n4)
+{
+    // REGS float4 loads in flight per thread, like a transform kernel that holds an 8x8 tile
+    float4 v[REGS];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i + (REGS - 1) * stride < n4; i += REGS * stride) {
+#pragma unroll
+        for (int r = 0; r < REGS; ++r) v[r] = in[i + r * stride];
+#pragma unroll
+        for (int r = 0; r < REGS; ++r) { v[r].x = v[r].x * 1.0001f + v[r].y; out[i + r * stride] = v[r]; }
+    }
+}
+static void corun_probe()
+{
+    const Shape s{"conv4", 3872, 512, 512, 64};
+    Args a{dA, dB, dC, s.T, s.K, s.N, s.T * s.K + 1088, (long long)s.K * s.N, s.T * s.N + 1088, 0};
+    dim3 grid((unsigned)(((s.T + 127) / 128) * (s.N / 128)), 1, (unsigned)s.P);
+    const size_t n4 = (size_t)256 << 20 >> 4 << 2;          // 1 GiB in, 1 GiB out
+    float4 *si, *so; hipMalloc(&si, n4 * 16); hipMalloc(&so, n4 * 16);
+    hipStream_t s1, s2; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto timeit = [&](bool g, int m, int reps) {
+        hipDeviceSynchronize();
+        hipEventRecord(e0, 0); hipStreamWaitEvent(s1, e0, 0); hipStreamWaitEvent(s2, e0, 0);
+        for (int r = 0; r < reps; ++r) {
+            if (g) hipLaunchKernelGGL((gemm_glds<128, 128, 2, 2, 16, 3, 3>), grid, dim3(256), 0, s1, a);
+            if (m == 8) hipLaunchKernelGGL((stream_kernel<8>), dim3(2048), dim3(256), 0, s2, si, so, n4);
+            if (m == 32) hipLaunchKernelGGL((stream_kernel<32>), dim3(2048), dim3(256), 0, s2, si, so, n4);
+            if (m == 48) hipLaunchKernelGGL((stream_kernel<48>), dim3(2048), dim3(256), 0, s2, si, so, n4);
+        }
+        hipEvent_t d1, d2; hipEventCreate(&d1); hipEventCreate(&d2);
+        hipEventRecord(d1, s1); hipEventRecord(d2, s2); hipStreamWaitEvent(0, d1, 0); hipStreamWaitEvent(0, d2, 0);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); return ms / reps;
+    };
+    for (int regs : {8, 32, 48}) {
+        timeit(true, regs, 2);
+        const float tg = timeit(true, 0, 8), tm = timeit(false, regs, 8), tb = timeit(true, regs, 8);
+        printf("co-run probe (%3d float4 in flight per streaming thread): GEMM alone %.3f ms (%.1f TF/s), stream alone %.3f ms (%.2f TB/s), both %.3f ms per pair (sum %.3f, max %.3f)\n",
+               regs, tg, 2.0 * s.T * s.K * s.N * s.P / tg / 1e9, tm, 2.0 * n4 * 16 / tm / 1e9, tb, tg + tm, tg > tm ? tg : tm);
+    }
+}
+
 #define GLDS(BM, BN, WM, WN, BK, S, OCC) [&](dim3 g, const Args& a) { hipLaunchKernelGGL((gemm_glds<BM, BN, WM, WN, BK, S, OCC>), g, dim3(WM * WN * 64), 0, 0, a); }
 #define REG(BM, BN, WM, WN, OCC) [&](dim3 g, const Args& a) { hipLaunchKernelGGL((gemm_reg<BM, BN, WM, WN, OCC>), g, dim3(WM * WN * 64), 0, 0, a); }
 
@@ -336,6 +383,7 @@ int main(int argc, char** argv)
     hipLaunchKernelGGL(fill, dim3(8192), dim3(256), 0, 0, dA, capA, 1u);
     hipLaunchKernelGGL(fill, dim3(8192), dim3(256), 0, 0, dB, capB, 7u);
     hipDeviceSynchronize();
+    if (argc > 1 && std::string(argv[1]) == "corun") { corun_probe(); return 0; }
     const Shape chk{"check", 300, 128, 256, 3};          // T not a multiple of any tile, K = 8 / 4 K-tiles
     const Shape chk2{"check2", 300, 32, 512, 2};         // fewer K-tiles than stages
 #define BOTH(tag, L, BM, BN) do { run(tag, L, BM, BN, chk, true); run(tag, L, BM, BN, chk2, true); } while (0)
