@@ -602,8 +602,9 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
                          (a.batched || (phases == 1 && a.Hi == a.Ma && a.Wi == a.Mb && a.Ho == a.Ma && a.Wo == a.Mb)) && a.ldy >= a.Cout;
     if constexpr (BN >= 64 && BKF == 16) {
         if (glds_enabled() && rows1x1 && (mode == 3 || grid.y == 1) && (long long)(BM - 1) * a.ldx < (1LL << 29) && (long long)16 * a.Cout < (1LL << 29)) {
-            static const std::string gt[2] = {"gemm_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", plain>",
-                                              "gemm_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", epilogue>"};
+            // (the kernel symbols as rocprofv3 prints them, so that bench.py can look the PMC traffic of the dominant kernel up by name)
+            static const std::string gbase = "gemm_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3, ";
+            static const std::string gt[2] = {gbase + "false>", gbase + "true>"};
             const bool epi = mode != 3;
             g_last_kernel = gt[epi ? 1 : 0].c_str();
             if (epi) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, 3, true>), grid, dim3(256), 0, s, a);
@@ -1376,9 +1377,10 @@ static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
             b.plain_store = 0;
             if (a.c_uninitialized && gsplits == 1) b.plain_store = 1;
             else if (a.c_uninitialized && splits == 1) hipMemsetAsync(a.C, 0, (size_t)a.ntaps * a.Areal * a.ldc * sizeof(float), s);   // (zeroed above otherwise)
-            static const std::string gtag = "wgrad_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ">";
-            g_last_kernel = gtag.c_str();
             static const int preload = [] { const char* e = getenv("FCN8S_WGRAD_PRELOAD"); return e ? atoi(e) : 1; }();
+            static const std::string gbase = "wgrad_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3, ";
+            static const std::string gtag[2] = {gbase + "false>", gbase + "true>"};
+            g_last_kernel = gtag[preload ? 1 : 0].c_str();
             if (preload) hipLaunchKernelGGL((wgrad_glds_kernel<BM, BN, WM, WN, 3, true>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits);
             else         hipLaunchKernelGGL((wgrad_glds_kernel<BM, BN, WM, WN, 3, false>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits);
             return;

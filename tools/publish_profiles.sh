@@ -1,20 +1,25 @@
 #!/bin/bash
-# Copies the judged summaries of one tools/collect_profiles.sh run (gpurun_out/prof_<tag>/) into profiles/ under round-1 names.
-TAG=${1:?usage: publish_profiles.sh <tag>}
+# Copies the judged summaries of one tools/collect_profiles.sh run (gpurun_out/prof_<tag>/) into profiles/ under round names.
+TAG=${1:?usage: publish_profiles.sh <tag> [round prefix, default r02]}
+R=${2:-r02}
 SRC=gpurun_out/prof_$TAG
 DST=profiles
 set -e
-cp $SRC/bench_train_bs16.json            $DST/r01_bench_train_bs16.json
-cp $SRC/bench_train_bs16_tf_adam.json    $DST/r01_bench_train_bs16_tf_adam.json
-cp $SRC/bench_train_bs16_bf16_fc.json    $DST/r01_bench_train_bs16_bf16_fc.json
-cp $SRC/bench_infer_bs1.json             $DST/r01_bench_infer_bs1.json
-cp $SRC/bench_under_rocprof.json         $DST/r01_bench_under_rocprof.json
-cp $SRC/stats/bench_kernel_stats.csv     $DST/r01_bench_train_kernel_stats.csv
-cp $SRC/pmc_fetch/bench_counter_collection.csv $DST/r01_pmc_fetch_counter_collection.csv
-cp $SRC/pmc_write/bench_counter_collection.csv $DST/r01_pmc_write_counter_collection.csv
-cp $SRC/pmc_clock/bench_counter_collection.csv $DST/r01_pmc_clock_counter_collection.csv
-cp $SRC/pmc_summary.txt                  $DST/r01_pmc_summary.txt
-cp $SRC/pmc_clock_summary.txt            $DST/r01_pmc_clock_summary.txt
-cp $SRC/pmc_clock.json                   $DST/r01_pmc_clock.json
+cp $SRC/bench_train_bs16.json            $DST/${R}_bench_train_bs16.json
+cp $SRC/bench_train_bs16_tf_adam.json    $DST/${R}_bench_train_bs16_tf_adam.json
+cp $SRC/bench_train_bs16_bf16_fc.json    $DST/${R}_bench_train_bs16_bf16_fc.json
+cp $SRC/bench_infer_bs1.json             $DST/${R}_bench_infer_bs1.json
+cp $SRC/bench_under_rocprof.json         $DST/${R}_bench_under_rocprof.json
+cp $SRC/stats/bench_kernel_stats.csv     $DST/${R}_bench_train_kernel_stats.csv
+cp $SRC/pmc_fetch/bench_counter_collection.csv $DST/${R}_pmc_fetch_counter_collection.csv
+cp $SRC/pmc_write/bench_counter_collection.csv $DST/${R}_pmc_write_counter_collection.csv
+cp $SRC/pmc_clock/bench_counter_collection.csv $DST/${R}_pmc_clock_counter_collection.csv
+cp $SRC/pmc_summary.txt                  $DST/${R}_pmc_summary.txt
+cp $SRC/pmc_clock_summary.txt            $DST/${R}_pmc_clock_summary.txt
+cp $SRC/pmc_clock.json                   $DST/${R}_pmc_clock.json
 cp $SRC/pmc_traffic.json                 $DST/pmc_traffic.json
-echo "published $TAG"
+for f in bench_c5_2048x1024_bs4_bf16_fc bench_c5_2048x1024_bs4_fp32 bench_e2e_train_bs16 bench_2ranks_one_gpu_gloo; do
+    [ -f $SRC/$f.json ] && cp $SRC/$f.json $DST/${R}_$f.json
+done
+[ -f $SRC/layer_bench.txt ] && cp $SRC/layer_bench.txt $DST/${R}_layer_bench.txt
+echo "published $TAG as $R"
