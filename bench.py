@@ -129,7 +129,12 @@ def self_launch(args, argv):
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
-    return subprocess.call(cmd, env=env)
+    # only the JSON line goes to stdout; whatever else the ranks print there (gloo's connection banner, ...) is moved to stderr
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout:
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return p.wait()
 
 
 def make_png_dataset(root, n, h, w, num_classes=20, seed=0):

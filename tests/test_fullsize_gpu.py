@@ -110,14 +110,13 @@ def test_config3_gradients_1024x512_bs1_vs_oracle():
     e.close()
     loss_ref, g_ref, _ = orc.loss_and_grads(P, img, orc.one_hot(lab, 20).astype(np.float32), l2_rate=1e-3)
     assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref)), (loss, loss_ref)
-    worst = ("", 0.0)
     assert len(g_ref) == 42
-    for k in g_ref:
-        err = float(np.abs(np.asarray(g[k], np.float64) - g_ref[k]).max() / (np.abs(g_ref[k]).max() + 1e-30))
-        if err > worst[1]:
-            worst = (k, err)
+    errs = {k: float(np.abs(np.asarray(g[k], np.float64) - g_ref[k]).max() / (np.abs(g_ref[k]).max() + 1e-30)) for k in g_ref}
+    ranked = sorted(errs.items(), key=lambda kv: -kv[1])
+    print("config 3 gradients at 1024x512, error / max per tensor, worst five:", ", ".join("%s %.2e" % kv for kv in ranked[:5]),
+          "; median %.2e" % float(np.median(list(errs.values()))))
+    for k, err in ranked:
         assert err < 2e-3, (k, err)
-    print("config 3 gradients at 1024x512: worst tensor %s, %.2e of its max" % worst)
 
 
 def test_config3_training_step_1024x512_bs16_properties():
