@@ -5,13 +5,14 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-python bench.py --steps 20 --warmup 5 > $OUT/bench_train_bs16.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2>> $OUT/bench.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> $OUT/bench.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> $OUT/bench.err
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_clock -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> $OUT/bench.err
 python tools/pmc_clock_summary.py $OUT/pmc_clock/bench_counter_collection.csv $OUT/pmc_clock.json > $OUT/pmc_clock_summary.txt
 python tools/pmc_summary.py $OUT/pmc_fetch/bench_counter_collection.csv $OUT/pmc_write/bench_counter_collection.csv $OUT/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline ($TAG)" > $OUT/pmc_summary.txt
+cp $OUT/pmc_traffic.json profiles/pmc_traffic.json      # the bench line below reads roofline.traffic from it (same box, same build, same command)
+python bench.py --steps 20 --warmup 5 > $OUT/bench_train_bs16.json 2> $OUT/bench.err
 python bench.py --steps 10 --warmup 3 --mode infer --batch 1 --no-cpu-baseline > $OUT/bench_infer_bs1.json 2>> $OUT/bench.err
 python bench.py --steps 10 --warmup 3 --precision bf16_fc --no-cpu-baseline > $OUT/bench_train_bs16_bf16_fc.json 2>> $OUT/bench.err
 python bench.py --steps 10 --warmup 3 --optimizer adam --no-cpu-baseline > $OUT/bench_train_bs16_tf_adam.json 2>> $OUT/bench.err
