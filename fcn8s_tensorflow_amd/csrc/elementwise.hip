@@ -123,6 +123,20 @@ static __device__ __forceinline__ double block_sum(double v, double* sh)
     return t;   // valid in thread 0
 }
 
+// slot -> pixel index of a (possibly blocked, see PixMap) logits tensor; -1 = the slot lies outside the image
+static __device__ __forceinline__ long long slot_pixel(long long slot, const PixMap& m)
+{
+    if (!m.blocked) return slot;
+    const int S = m.S;
+    const int rx = (int)(slot % S); long long t = slot / S;
+    const int r = (int)(t % S); t /= S;
+    const int qx = (int)(t % m.QW); t /= m.QW;
+    const int q = (int)(t % m.QH); const long long n = t / m.QH;
+    const int oy = q * S - S / 2 + r, ox = qx * S - S / 2 + rx;
+    if ((unsigned)oy >= (unsigned)m.H || (unsigned)ox >= (unsigned)m.W) return -1;
+    return (n * m.H + oy) * m.W + ox;
+}
+
 // ---- K10: fused softmax cross-entropy (loss partial sums + dlogits) ---------
 constexpr int XENT_PIX_PER_BLOCK = 1024;
 int softmax_xent_blocks(long long npix)
@@ -133,7 +147,7 @@ int softmax_xent_blocks(long long npix)
 template <int C>   // C % 4 == 0: registers hold the pixel's logits
 __global__ __launch_bounds__(256) void softmax_xent_kernel_c(const float* logits, const uint8_t* labels,
                                                              float* dlogits, double* partials,
-                                                             long long npix, float gscale, float* colsum)
+                                                             long long npix, float gscale, float* colsum, const PixMap map)
 {
     __shared__ double sh[4];
     __shared__ float cs[C];
@@ -145,6 +159,15 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel_c(const float* logits
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix;
          p += (long long)gridDim.x * blockDim.x) {
         float v[C];
+        const long long pix = slot_pixel(p, map);          // npix counts slots here; labels are indexed by pixel
+        if (pix < 0) {                                     // a slot outside the image: its gradient is defined as 0
+            if (dlogits) {
+                float4* dst = reinterpret_cast<float4*>(dlogits + p * C);
+#pragma unroll
+                for (int i = 0; i < C / 4; ++i) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            continue;
+        }
         const float4* src = reinterpret_cast<const float4*>(logits + p * C);
 #pragma unroll
         for (int i = 0; i < C / 4; ++i) { const float4 t = src[i]; v[4*i] = t.x; v[4*i+1] = t.y; v[4*i+2] = t.z; v[4*i+3] = t.w; }
@@ -154,7 +177,7 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel_c(const float* logits
         float e[C]; float s = 0.f;
 #pragma unroll
         for (int i = 0; i < C; ++i) { e[i] = expf(v[i] - m); s += e[i]; }
-        const int lab = labels[p];
+        const int lab = labels[pix];
         const bool ign = lab >= C;                 // ids outside [0, C) (e.g. a 255 "ignore" id, an all-zero one-hot row): no loss, no gradient
         float vl = 0.f;
 #pragma unroll
@@ -191,18 +214,20 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel_c(const float* logits
 }
 __global__ __launch_bounds__(256) void softmax_xent_kernel_any(const float* logits, const uint8_t* labels,
                                                                float* dlogits, double* partials,
-                                                               long long npix, int C, float gscale)
+                                                               long long npix, int C, float gscale, const PixMap map)
 {
     __shared__ double sh[4];
     double lsum = 0;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix;
          p += (long long)gridDim.x * blockDim.x) {
+        const long long pix = slot_pixel(p, map);
+        if (pix < 0) { if (dlogits) for (int i = 0; i < C; ++i) dlogits[p * C + i] = 0.f; continue; }
         const float* l = logits + p * C;
         float m = l[0];
         for (int i = 1; i < C; ++i) m = fmaxf(m, l[i]);
         float s = 0.f;
         for (int i = 0; i < C; ++i) s += expf(l[i] - m);
-        const int lab = labels[p];
+        const int lab = labels[pix];
         const bool ign = lab >= C;                 // see softmax_xent_kernel_c
         if (!ign) lsum += (double)(m + logf(s) - l[lab]);
         if (dlogits) {
@@ -214,16 +239,18 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel_any(const float* logi
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 void launch_softmax_xent(const float* logits, const uint8_t* labels, float* dlogits, double* partials,
-                         long long npix, int C, float grad_scale, hipStream_t s, float* colsum)
+                         long long npix, int C, float grad_scale, hipStream_t s, float* colsum, const PixMap* map, int N)
 {
-    const int blocks = softmax_xent_blocks(npix);
+    const PixMap pm = map ? *map : PixMap{0, 0, 0, 0, 0, 0};
+    const long long nslot = pixmap_slots(pm, npix, N);
+    const int blocks = softmax_xent_blocks(npix);          // (the partial-sum count finalize_loss expects)
     if (C == 20)
-        hipLaunchKernelGGL(softmax_xent_kernel_c<20>, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, npix, grad_scale, colsum);
+        hipLaunchKernelGGL(softmax_xent_kernel_c<20>, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, nslot, grad_scale, colsum, pm);
     else if (C == 4)
-        hipLaunchKernelGGL(softmax_xent_kernel_c<4>, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, npix, grad_scale, colsum);
+        hipLaunchKernelGGL(softmax_xent_kernel_c<4>, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, nslot, grad_scale, colsum, pm);
     else {
-        hipLaunchKernelGGL(softmax_xent_kernel_any, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, npix, C, grad_scale);
-        if (colsum && dlogits) launch_colsum(dlogits, colsum, npix, C, s);
+        hipLaunchKernelGGL(softmax_xent_kernel_any, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, nslot, C, grad_scale, pm);
+        if (colsum && dlogits) launch_colsum(dlogits, colsum, nslot, C, s);
     }
 }
 
@@ -248,10 +275,12 @@ void launch_finalize_loss(const double* partials, int nparts, long long npix, co
 
 // ---- K13: softmax -> argmax (of the softmax output, lowest index on ties) ----
 __global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* logits, float* sm, long long* am,
-                                                             long long npix, int C)
+                                                             long long npix, int C, const PixMap map)
 {
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix;
          p += (long long)gridDim.x * blockDim.x) {
+        const long long pix = slot_pixel(p, map);          // outputs are always NHWC / per pixel
+        if (pix < 0) continue;
         const float* l = logits + p * C;
         float m = l[0];
         for (int i = 1; i < C; ++i) m = fmaxf(m, l[i]);
@@ -260,17 +289,125 @@ __global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* logits
         int best = 0; float bv = -1.f;
         for (int i = 0; i < C; ++i) {
             const float v = expf(l[i] - m) / s;
-            if (sm) sm[p * C + i] = v;
+            if (sm) sm[pix * C + i] = v;
             if (v > bv) { bv = v; best = i; }
         }
-        if (am) am[p] = best;
+        if (am) am[pix] = best;
     }
 }
 void launch_softmax_argmax(const float* logits, float* softmax_out, long long* argmax_out,
-                           long long npix, int C, hipStream_t s)
+                           long long npix, int C, hipStream_t s, const PixMap* map, int N)
 {
-    hipLaunchKernelGGL(softmax_argmax_kernel, dim3(cap_blocks(npix, 256)), dim3(256), 0, s, logits,
-                       softmax_out, argmax_out, npix, C);
+    const PixMap pm = map ? *map : PixMap{0, 0, 0, 0, 0, 0};
+    const long long nslot = pixmap_slots(pm, npix, N);
+    hipLaunchKernelGGL(softmax_argmax_kernel, dim3(cap_blocks(nslot, 256)), dim3(256), 0, s, logits,
+                       softmax_out, argmax_out, nslot, C, pm);
+}
+
+// ---- the k = 2s transposed conv as one GEMM: re-layouts (PixMap in fcn8s_internal.h) --------------------------------------------
+// Output pixel oy = s q - s/2 + r receives input row i = q (filter row ky = r) and i = q - 1 (ky = r + s): with rows = output
+// blocks (n, q, qx), K = (a, b, ci) over the 2 x 2 input cells (q-1+a, qx-1+b) and columns = (r, rx, co), the whole layer is
+// Y[rows][s*s*C] = A[rows][4C] * B2[4C][s*s*C] with B2[(a,b,ci)][(r,rx,co)] = w[r + s(1-a)][rx + s(1-b)][co][ci] -- no sub-pixel
+// phases, no 20-of-32 column waste, and its two gradients are plain GEMMs over the same rows.
+__global__ void tconv_im2col_kernel(const float4* __restrict__ x, float4* __restrict__ A, int N, int Hi, int Wi, int C4, int KP4)
+{
+    const int QH = Hi + 1, QW = Wi + 1;
+    const long long total = (long long)N * QH * QW * KP4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % KP4); const long long row = i / KP4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < 4 * C4) {
+            const int t = c / C4, c4 = c - t * C4, a = t >> 1, b = t & 1;
+            const int qx = (int)(row % QW); const long long r2 = row / QW;
+            const int q = (int)(r2 % QH); const long long n = r2 / QH;
+            const int iy = q - 1 + a, ix = qx - 1 + b;
+            if ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) v = x[((n * Hi + iy) * Wi + ix) * C4 + c4];
+        }
+        A[i] = v;
+    }
+}
+void launch_tconv_im2col(const float* x, float* A, int N, int Hi, int Wi, int C, int KP, hipStream_t s)
+{
+    hipLaunchKernelGGL(tconv_im2col_kernel, dim3(cap_blocks((long long)N * (Hi + 1) * (Wi + 1) * (KP / 4), 256)), dim3(256), 0, s,
+                       (const float4*)x, (float4*)A, N, Hi, Wi, C / 4, KP / 4);
+}
+__global__ void tconv_col2im_kernel(const float4* __restrict__ dA, float4* __restrict__ dx, int N, int Hi, int Wi, int C4, int KP4)
+{
+    const int QH = Hi + 1, QW = Wi + 1;
+    const long long total = (long long)N * Hi * Wi * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4); long long t = i / C4;
+        const int ix = (int)(t % Wi); t /= Wi;
+        const int iy = (int)(t % Hi); const long long n = t / Hi;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const long long row = (n * QH + (iy + 1 - a)) * QW + (ix + 1 - b);       // always inside the (Hi+1) x (Wi+1) grid
+                const float4 v = dA[row * KP4 + (a * 2 + b) * C4 + c4];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        dx[i] = acc;
+    }
+}
+void launch_tconv_col2im(const float* dA, float* dx, int N, int Hi, int Wi, int C, int KP, hipStream_t s)
+{
+    hipLaunchKernelGGL(tconv_col2im_kernel, dim3(cap_blocks((long long)N * Hi * Wi * (C / 4), 256)), dim3(256), 0, s,
+                       (const float4*)dA, (float4*)dx, N, Hi, Wi, C / 4, KP / 4);
+}
+__global__ void tconv_pack_gemm_kernel(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ b2, float* __restrict__ b2t,
+                                       float* __restrict__ bias_tiled, int C, int S, int KP)
+{
+    const int K = 2 * S, NC = S * S * C, K4 = 4 * C;
+    const long long total = (long long)NC * KP;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % KP), col = (int)(i / KP);          // b2t[col][k]
+        float v = 0.f;
+        if (k < K4) {
+            const int t = k / C, ci = k - t * C, a = t >> 1, b = t & 1;
+            const int co = col % C, rr = col / C, rx = rr % S, r = rr / S;
+            const int ky = r + S * (1 - a), kx = rx + S * (1 - b);
+            v = w[((long long)(ky * K + kx) * C + co) * C + ci];
+            b2[(long long)k * NC + col] = v;
+        }
+        b2t[i] = v;
+        if (k == 0) bias_tiled[col] = bias ? bias[col % C] : 0.f;
+    }
+}
+void launch_tconv_pack_gemm(const float* w, const float* bias, float* b2, float* b2t, float* bias_tiled, int C, int S, int KP, hipStream_t s)
+{
+    hipLaunchKernelGGL(tconv_pack_gemm_kernel, dim3(cap_blocks((long long)S * S * C * KP, 256)), dim3(256), 0, s, w, bias, b2, b2t, bias_tiled, C, S, KP);
+}
+__global__ void tconv_unpack_dw_kernel(const float* __restrict__ db2, float* __restrict__ dw, int C, int S)
+{
+    const int K = 2 * S, NC = S * S * C;
+    const long long total = (long long)K * K * C * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % C); long long t = i / C;
+        const int co = (int)(t % C); t /= C;
+        const int kx = (int)(t % K), ky = (int)(t / K);
+        const int a = ky >= S ? 0 : 1, b = kx >= S ? 0 : 1;             // ky = r + S(1 - a)
+        const int r = ky - S * (1 - a), rx = kx - S * (1 - b);
+        dw[i] += db2[(long long)((a * 2 + b) * C + ci) * NC + (r * S + rx) * C + co];
+    }
+}
+void launch_tconv_unpack_dw(const float* db2, float* dw, int C, int S, hipStream_t s)
+{
+    hipLaunchKernelGGL(tconv_unpack_dw_kernel, dim3(cap_blocks(4LL * S * S * C * C, 256)), dim3(256), 0, s, db2, dw, C, S);
+}
+__global__ void unblock_logits_kernel(const float* __restrict__ blocked, float* __restrict__ nhwc, const PixMap map, long long nslot, int C)
+{
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < nslot; p += (long long)gridDim.x * blockDim.x) {
+        const long long pix = slot_pixel(p, map);
+        if (pix < 0) continue;
+        for (int c = 0; c < C; ++c) nhwc[pix * C + c] = blocked[p * C + c];
+    }
+}
+void launch_unblock_logits(const float* blocked, float* nhwc, const PixMap& map, int N, int C, hipStream_t s)
+{
+    const long long nslot = pixmap_slots(map, 0, N);
+    hipLaunchKernelGGL(unblock_logits_kernel, dim3(cap_blocks(nslot, 256)), dim3(256), 0, s, blocked, nhwc, map, nslot, C);
 }
 
 // ---- one-hot rows -> uint8 class ids (first non-zero entry; counts rows that are not one-hot) ------------

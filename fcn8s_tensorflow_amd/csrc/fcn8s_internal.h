@@ -96,15 +96,32 @@ void launch_preprocess(const void* img, int dtype, float* out4, long long npix, 
 void launch_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t s);
 void launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C,
                         int relu_mask, hipStream_t s);
+// Where the logits of pixel slot p live.  blocked == 0: slot = pixel, NHWC.  blocked != 0: the layout the last transposed conv
+// (k = 2s, stride s, pad s/2) produces when it runs as ONE GEMM (model.hip: tconv_gemm_*): rows = (n, q, qx) over an (H/s + 1) x (W/s + 1)
+// grid of s x s output blocks that start at pixel (s q - s/2, s qx - s/2), columns = (r, rx, class); slots of the half blocks that
+// stick out of the image exist but are invalid (their gradient is written as 0).
+struct PixMap { int blocked, H, W, QH, QW, S; };
+static __host__ __device__ inline long long pixmap_slots(const PixMap& m, long long npix, int N) { return m.blocked ? (long long)N * m.QH * m.QW * m.S * m.S : npix; }
 // partials: double[>= softmax_xent_blocks(npix)]
 int  softmax_xent_blocks(long long npix);
 void launch_softmax_xent(const float* logits, const uint8_t* labels, float* dlogits, double* partials,
-                         long long npix, int C, float grad_scale, hipStream_t s, float* colsum = nullptr)   /* colsum[c] += sum_p dlogits[p,c] (zero-initialised by the caller) */;
+                         long long npix, int C, float grad_scale, hipStream_t s, float* colsum = nullptr,   /* colsum[c] += sum_p dlogits[p,c] (zero-initialised by the caller) */
+                         const PixMap* map = nullptr, int N = 0);
 // loss_out[0] = sum(partials)/npix + 0.5*rate*regsum[0]
 void launch_finalize_loss(const double* partials, int nparts, long long npix, const float* regsum,
                           float rate, float* loss_out, hipStream_t s);
 void launch_softmax_argmax(const float* logits, float* softmax_out, long long* argmax_out,
-                           long long npix, int C, hipStream_t s);
+                           long long npix, int C, hipStream_t s, const PixMap* map = nullptr, int N = 0);
+// ---- the k = 2s transposed conv as one GEMM (see PixMap): operand / result re-layouts, all tiny next to the GEMMs -------------
+// A[(n,q,qx)][(a,b,ci)] = x[n, q-1+a, qx-1+b, ci] (0 outside), row stride KP >= 4C (columns >= 4C zero)
+void launch_tconv_im2col(const float* x, float* A, int N, int Hi, int Wi, int C, int KP, hipStream_t s);
+// dx[n,i,j,ci] = sum_{a,b} dA[(n, i+1-a, j+1-b)][(a,b,ci)]
+void launch_tconv_col2im(const float* dA, float* dx, int N, int Hi, int Wi, int C, int KP, hipStream_t s);
+// w[K,K,Cout,Cin] (K = 2S) -> b2[4C][S*S*C] (forward B operand), b2t[S*S*C][KP] (data-gradient B operand, columns >= 4C zero), bias tiled to S*S*C
+void launch_tconv_pack_gemm(const float* w, const float* bias, float* b2, float* b2t, float* bias_tiled, int C, int S, int KP, hipStream_t s);
+// dw[K,K,Cout,Cin] += from db2[KP][S*S*C] (rows >= 4C ignored)
+void launch_tconv_unpack_dw(const float* db2, float* dw, int C, int S, hipStream_t s);
+void launch_unblock_logits(const float* blocked, float* nhwc, const PixMap& map, int N, int C, hipStream_t s);
 void launch_onehot_to_ids(const void* oh, int elem_bytes, long long npix, int C, uint8_t* ids, int* bad, hipStream_t s);
 void launch_confusion(const uint8_t* labels, const long long* pred, long long npix,
                       unsigned long long* conf, int C, hipStream_t s);

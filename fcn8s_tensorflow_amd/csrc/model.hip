@@ -76,6 +76,11 @@ struct fcn8s_model {
     int N = 0, H = 0, W = 0;
     char* arena = nullptr; size_t arena_bytes = 0;
     std::map<std::string, Act> acts;
+    // the last transposed conv (k = 2s = 16) as one GEMM over output blocks (PixMap, elementwise.hip): logits / dlogits live in that blocked layout
+    int tconv_gemm = 1; PixMap pm{0, 0, 0, 0, 0, 0}; int tg_kp = 0;
+    float *logits_b = nullptr, *dlogits_b = nullptr, *tg_A = nullptr, *tg_dA = nullptr;      // arena
+    float *tg_b2 = nullptr, *tg_b2t = nullptr, *tg_bias = nullptr, *tg_db2 = nullptr;         // per model
+    bool logits_nhwc_valid = false;
     float *dlogits = nullptr, *da3 = nullptr, *da4 = nullptr, *ds7 = nullptr, *gskip3 = nullptr, *gskip4 = nullptr;
     float *gbuf[2] = {nullptr, nullptr};
     int gcur = 0;
@@ -496,6 +501,16 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
     add("s7", h5, w5, C); add("p4", h4, w4, C); add("p3", h3, w3, C);
     add("a4", h4, w4, C); add("a3", h3, w3, C); add("logits", H, W, C);
     add("dlogits", H, W, C, &m->dlogits);
+    m->pm = PixMap{0, H, W, H / 8 + 1, W / 8 + 1, 8};
+    m->logits_b = m->dlogits_b = m->tg_A = m->tg_dA = nullptr;
+    if (m->tconv_gemm) {
+        const size_t rows = (size_t)N * m->pm.QH * m->pm.QW;
+        m->pm.blocked = 1;
+        items.push_back({"logits_b", rows * 64 * C, 0, 0, 0, &m->logits_b});
+        items.push_back({"dlogits_b", rows * 64 * C, 0, 0, 0, &m->dlogits_b});
+        items.push_back({"tg_A", rows * m->tg_kp, 0, 0, 0, &m->tg_A});
+        items.push_back({"tg_dA", rows * m->tg_kp, 0, 0, 0, &m->tg_dA});
+    }
     add("da3", h3, w3, C, &m->da3); add("da4", h4, w4, C, &m->da4); add("ds7", h5, w5, C, &m->ds7);
     add("gskip3", h3, w3, m->widths[2], &m->gskip3); add("gskip4", h4, w4, m->widths[3], &m->gskip4);
     size_t gmax = (size_t)N * H * W * m->widths[0];
@@ -570,6 +585,62 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
 }
 
 float* A(fcn8s_model* m, const char* n) { return m->acts.at(n).p; }
+
+// ---- the last transposed conv (16x16, stride 8) as one GEMM over output blocks -----------------------------------------------
+// (layout and algebra: PixMap in fcn8s_internal.h, tconv_*_kernel in elementwise.hip).  The s*s sub-pixel phases of tconv_fwd give every
+// phase a 20-column GEMM on a 32-wide MFMA tile through the generic predicated kernel (37 TFLOP/s); as ONE GEMM with rows = output
+// blocks, K = 4C and 64C columns it runs on the LDS-DMA kernels, and so do its two gradients.
+const float* LG(fcn8s_model* m) { return (m->tconv_gemm && m->logits_b) ? m->logits_b : m->acts.at("logits").p; }
+const PixMap* LGM(fcn8s_model* m) { return (m->tconv_gemm && m->logits_b) ? &m->pm : nullptr; }
+IgemmArgs tg_rows_gemm(const float* x, int ldx, int K, const float* w, float* y, int ncols, long long rows)
+{
+    IgemmArgs a{};
+    a.x = x; a.w = w; a.y = y;
+    a.N = 1; a.Ma = (int)rows; a.Mb = 1; a.M = rows;
+    a.Hi = (int)rows; a.Wi = 1; a.Cin = K; a.ldx = ldx;
+    a.KW = 1; a.in_scale = 1; a.tap_step = 1; a.tap_off = 0; a.Ktot = K;
+    a.Ho = (int)rows; a.Wo = 1; a.Cout = ncols; a.ldy = ncols;
+    a.out_scale = 1; a.phases_x = 1; a.alpha = 1.f; a.mask_scale = 1.f;
+    return a;
+}
+void tconv_gemm_fwd(fcn8s_model* m)
+{
+    hipStream_t s = m->stream;
+    const int C = m->C, NC = 64 * C, KP = m->tg_kp;
+    const long long rows = (long long)m->N * m->pm.QH * m->pm.QW;
+    ProfScope ps(m, "tconv_fwd", 2.0 * rows * 4 * C * NC, 4.0 * rows * (4.0 * C + NC));
+    launch_tconv_pack_gemm(Wp(m, "fc7_pool4_pool3_conv2d_trans/kernel"), Wp(m, "fc7_pool4_pool3_conv2d_trans/bias"), m->tg_b2, m->tg_b2t, m->tg_bias, C, 8, KP, s);
+    launch_tconv_im2col(m->acts.at("a3").p, m->tg_A, m->N, m->H / 8, m->W / 8, C, KP, s);
+    IgemmArgs a = tg_rows_gemm(m->tg_A, KP, 4 * C, m->tg_b2, m->logits_b, NC, rows);
+    a.bias = m->tg_bias;
+    launch_igemm(a, 1, s);
+}
+void tconv_gemm_dgrad(fcn8s_model* m)
+{
+    hipStream_t s = m->stream;
+    const int C = m->C, NC = 64 * C, KP = m->tg_kp;
+    const long long rows = (long long)m->N * m->pm.QH * m->pm.QW;
+    ProfScope ps(m, "tconv_dgrad", 2.0 * rows * NC * KP, 4.0 * rows * (NC + KP));
+    IgemmArgs a = tg_rows_gemm(m->dlogits_b, NC, NC, m->tg_b2t, m->tg_dA, KP, rows);
+    a.batched = 1;                                   // one slab: takes the plain (16-byte store) epilogue
+    launch_igemm(a, 1, s);
+    launch_tconv_col2im(m->tg_dA, m->da3, m->N, m->H / 8, m->W / 8, C, KP, s);
+}
+void tconv_gemm_wgrad(fcn8s_model* m)
+{
+    hipStream_t s = m->stream;
+    const int C = m->C, NC = 64 * C, KP = m->tg_kp;
+    const long long rows = (long long)m->N * m->pm.QH * m->pm.QW;
+    ProfScope ps(m, "tconv_wgrad", 2.0 * rows * KP * NC, 4.0 * rows * (NC + KP));
+    WgradArgs g{};
+    g.A = m->tg_A; g.B = m->dlogits_b; g.C = m->tg_db2;
+    g.N = 1; g.Pa = 1; g.Pb = (int)rows; g.P = rows;
+    g.Ha = 1; g.Wa = (int)rows; g.Adim = KP; g.lda = KP; g.Areal = KP;
+    g.Bdim = NC; g.ldb = NC; g.KW = 1; g.a_scale = 1; g.tap_off = 0; g.ntaps = 1; g.ldc = NC; g.alpha = 1.f; g.colsum = nullptr;
+    g.c_uninitialized = 1;
+    launch_wgrad(g, s);
+    launch_tconv_unpack_dw(m->tg_db2, m->d_grads + m->params[m->index.at("fc7_pool4_pool3_conv2d_trans/kernel")].offset, C, 8, s);
+}
 
 // ---- forward ------------------------------------------------------------------------
 int stage_inputs(fcn8s_model* m, const void* images, int dtype, const uint8_t* labels, int where,
@@ -705,7 +776,9 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
       conv_same(m, "score1x1_fwd", A(m, "fc7"), Wp(m, "fc7_1x1/kernel"), A(m, "s7"), N, h5, w5, m->widths[6], C, 1, e, s); }
     tconv_fwd(m, A(m, "s7"), m->d_tph[0], Wp(m, "fc7_conv2d_trans/bias"), A(m, "p4"), A(m, "a4"), N, h5, w5, C, 4, 2, s);
     tconv_fwd(m, A(m, "a4"), m->d_tph[1], Wp(m, "fc7_pool4_conv2d_trans/bias"), A(m, "p3"), A(m, "a3"), N, H / 16, W / 16, C, 4, 2, s);
-    tconv_fwd(m, A(m, "a3"), m->d_tph[2], Wp(m, "fc7_pool4_pool3_conv2d_trans/bias"), nullptr, A(m, "logits"), N, H / 8, W / 8, C, 16, 8, s);
+    if (m->tconv_gemm && m->logits_b) tconv_gemm_fwd(m);
+    else tconv_fwd(m, A(m, "a3"), m->d_tph[2], Wp(m, "fc7_pool4_pool3_conv2d_trans/bias"), nullptr, A(m, "logits"), N, H / 8, W / 8, C, 16, 8, s);
+    m->logits_nhwc_valid = !(m->tconv_gemm && m->logits_b);
     if (fill_fp) {                        // this pass (re)built the cache: remember what it was built from
         launch_fingerprint(m->d_params, (long long)m->total, m->d_fp, s);
         hipMemcpyAsync(&m->frozen_fp, m->d_fp, sizeof m->frozen_fp, hipMemcpyDeviceToHost, s);
@@ -725,8 +798,9 @@ int compute_loss(fcn8s_model* m, const uint8_t* lab_dev, float l2_rate, bool wit
     const int nb = softmax_xent_blocks(npix);
     { ProfScope ps(m, "softmax_xent", 0, (double)npix * (m->C * 4 * (with_grad ? 2 : 1) + 1));
       if (with_grad) hipMemsetAsync(m->d_lastbias, 0, 64 * sizeof(float), s);
-      launch_softmax_xent(A(m, "logits"), lab_dev, with_grad ? m->dlogits : nullptr, m->d_partials, npix, m->C, 1.0f / (float)npix, s,
-                          with_grad ? m->d_lastbias : nullptr); }
+      const bool blk = m->tconv_gemm && m->logits_b;
+      launch_softmax_xent(blk ? m->logits_b : A(m, "logits"), lab_dev, with_grad ? (blk ? m->dlogits_b : m->dlogits) : nullptr, m->d_partials, npix, m->C,
+                          1.0f / (float)npix, s, with_grad ? m->d_lastbias : nullptr, blk ? &m->pm : nullptr, m->N); }
     const float* reg = nullptr;
     if (l2_rate != 0.f) {
         hipMemsetAsync(m->d_regsum, 0, sizeof(float), s);
@@ -771,9 +845,10 @@ void backward_bucket0(fcn8s_model* m)
     hipMemsetAsync(m->d_grads, 0, m->total * sizeof(float), s);
     prepare_backward_weights(m);
     // logits = tconv16x16s8(a3)
-    tconv_wgrad(m, A(m, "a3"), m->dlogits, Gp(m, "fc7_pool4_pool3_conv2d_trans/kernel"), N, h3, w3, C, 16, 8, s);
+    const bool blk = m->tconv_gemm && m->logits_b;
+    if (blk) tconv_gemm_wgrad(m); else tconv_wgrad(m, A(m, "a3"), m->dlogits, Gp(m, "fc7_pool4_pool3_conv2d_trans/kernel"), N, h3, w3, C, 16, 8, s);
     launch_axpy(Gp(m, "fc7_pool4_pool3_conv2d_trans/bias"), m->d_lastbias, 1.f, C, s);      // column sums of dlogits, from the loss kernel
-    tconv_dgrad(m, m->dlogits, Wp(m, "fc7_pool4_pool3_conv2d_trans/kernel"), m->da3, N, h3, w3, C, 16, 8, s);
+    if (blk) tconv_gemm_dgrad(m); else tconv_dgrad(m, m->dlogits, Wp(m, "fc7_pool4_pool3_conv2d_trans/kernel"), m->da3, N, h3, w3, C, 16, 8, s);
     l2_grad(m, "fc7_pool4_pool3_conv2d_trans/kernel");
     // a3 = tconv4x4s2(a4) + p3 ; p3 = conv1x1(pool3 * 1e-4)
     conv_wgrad(m, "score1x1_wgrad", A(m, "pool3"), m->da3, Gp(m, "pool3_1x1/kernel"), Gp(m, "pool3_1x1/bias"), N, h3, w3, m->widths[2], C, 1, 0.0001f, s);
@@ -971,6 +1046,15 @@ int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
     m->d_regsum = m->d_loss + 1; m->d_lastbias = m->d_loss + 2;
     if ((e = hipMalloc((void**)&m->d_conf, cc * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&m->d_fp, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    { const char* tg = getenv("FCN8S_TCONV_GEMM"); if (tg) m->tconv_gemm = atoi(tg) != 0; }
+    m->tg_kp = (4 * m->C + 63) / 64 * 64;
+    if (m->tconv_gemm) {
+        const size_t NC = 64 * (size_t)m->C, KP = (size_t)m->tg_kp;
+        if ((e = hipMalloc((void**)&m->tg_b2, 4 * (size_t)m->C * NC * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+        if ((e = hipMalloc((void**)&m->tg_b2t, NC * KP * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+        if ((e = hipMalloc((void**)&m->tg_db2, KP * NC * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+        if ((e = hipMalloc((void**)&m->tg_bias, NC * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+    }
     hipMemset(m->d_conf, 0, cc * sizeof(unsigned long long));
     hipMemset(m->d_loss, 0, 2 * sizeof(float));
     *out = m;
@@ -996,6 +1080,10 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->d_loss) hipFree(m->d_loss);
     if (m->d_conf) hipFree(m->d_conf);
     if (m->d_fp) hipFree(m->d_fp);
+    if (m->tg_b2) hipFree(m->tg_b2);
+    if (m->tg_b2t) hipFree(m->tg_b2t);
+    if (m->tg_db2) hipFree(m->tg_db2);
+    if (m->tg_bias) hipFree(m->tg_bias);
     for (auto& sl : m->slots) {
         if (sl.h_img) hipHostFree(sl.h_img);
         if (sl.h_lab) hipHostFree(sl.h_lab);
@@ -1186,7 +1274,7 @@ int fcn8s_eval_step(fcn8s_model* m, const void* images, int dtype, const uint8_t
     rc = forward(m, img, dtype, 1.0f, false); if (rc) return rc;
     rc = compute_loss(m, lab, l2_rate, false); if (rc) return rc;
     const long long npix = (long long)N * H * W;
-    { ProfScope ps(m, "softmax_argmax", 0, (double)npix * (m->C * 4 + 8)); launch_softmax_argmax(A(m, "logits"), nullptr, m->d_pred, npix, m->C, m->stream); }
+    { ProfScope ps(m, "softmax_argmax", 0, (double)npix * (m->C * 4 + 8)); launch_softmax_argmax(LG(m), nullptr, m->d_pred, npix, m->C, m->stream, LGM(m), m->N); }
     launch_confusion(lab, m->d_pred, npix, m->d_conf, m->C, m->stream);
     float loss = 0.f;
     rc = fcn8s_read_loss(m, &loss); if (rc) return rc;          // tf.metrics.mean(total_loss): one sample per batch
@@ -1261,16 +1349,16 @@ int fcn8s_predict(fcn8s_model* m, const void* images, int dtype, int N, int H, i
     const long long npix = (long long)N * H * W;
     if (where == FCN8S_DEVICE) {
         ProfScope ps(m, "softmax_argmax", 0, (double)npix * (m->C * 4 + 8));
-        if (argmax) launch_softmax_argmax(A(m, "logits"), nullptr, (long long*)out, npix, m->C, m->stream);
-        else launch_softmax_argmax(A(m, "logits"), (float*)out, nullptr, npix, m->C, m->stream);
+        if (argmax) launch_softmax_argmax(LG(m), nullptr, (long long*)out, npix, m->C, m->stream, LGM(m), m->N);
+        else launch_softmax_argmax(LG(m), (float*)out, nullptr, npix, m->C, m->stream, LGM(m), m->N);
         HIPCHK(m, hipGetLastError());
         return FCN8S_OK;
     }
     if (argmax) {
-        launch_softmax_argmax(A(m, "logits"), nullptr, m->d_pred, npix, m->C, m->stream);
+        launch_softmax_argmax(LG(m), nullptr, m->d_pred, npix, m->C, m->stream, LGM(m), m->N);
         HIPCHK(m, hipMemcpyAsync(out, m->d_pred, npix * sizeof(long long), hipMemcpyDeviceToHost, m->stream));
     } else {
-        launch_softmax_argmax(A(m, "logits"), m->d_softmax, nullptr, npix, m->C, m->stream);
+        launch_softmax_argmax(LG(m), m->d_softmax, nullptr, npix, m->C, m->stream, LGM(m), m->N);
         HIPCHK(m, hipMemcpyAsync(out, m->d_softmax, npix * m->C * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     }
     HIPCHK(m, hipStreamSynchronize(m->stream));
@@ -1358,6 +1446,10 @@ int fcn8s_get_activation(fcn8s_model* m, const char* name, float* host, size_t n
     if (!m->have_forward) return fail(m, FCN8S_ERR_STATE, "no forward pass has been run");
     auto it = m->acts.find(name);
     if (it == m->acts.end()) return fail(m, FCN8S_ERR_NOT_FOUND, std::string("unknown activation '") + name + "'");
+    if (std::string(name) == "logits" && !m->logits_nhwc_valid && m->logits_b) {      // kept in the blocked GEMM layout: convert for the caller
+        launch_unblock_logits(m->logits_b, it->second.p, m->pm, m->N, m->C, m->stream);
+        m->logits_nhwc_valid = true;
+    }
     if (n != it->second.n) return fail(m, FCN8S_ERR_SHAPE, std::string("activation '") + name + "' has " + std::to_string(it->second.n) + " elements");
     HIPCHK(m, hipStreamSynchronize(m->stream));
     HIPCHK(m, hipMemcpy(host, it->second.p, n * sizeof(float), hipMemcpyDeviceToHost));
