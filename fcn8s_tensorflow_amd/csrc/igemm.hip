@@ -565,6 +565,115 @@ __global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void ge
     }
 }
 
+// ===========================================================================
+// conv1_1 forward (3 -> 64 channels on the 4-channel padded input): a write-bound layer (2.15 GB out, 0.13 GB in at 16 x 1024x512)
+// ===========================================================================
+// One 16-byte LDS-DMA chunk of the A image is exactly one tap of one pixel (b, g, r, 0), so the implicit-GEMM A tile
+// [128 pixels][taps 4kt .. 4kt+3] is gathered straight from the image by per-lane addresses (taps outside the image read a zero
+// pixel); K = 9 taps x 4 = 36, padded to 48 = three K-tiles, all in flight at once; bias + ReLU in the 16-byte-store epilogue.
+// The generic predicated kernel needed 0.98 ms for this layer, this one is bound by the output stream.
+static __device__ __forceinline__ void glds16v(const float* vaddr, unsigned lds_byte_off)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds_byte_off) : "memory", "m0");
+}
+struct Conv1Args { const float* x4; const float* w48; const float* bias; float* y; const float* zero16; int N, H, W; long long M; };
+
+__global__ __launch_bounds__(256, 4) void conv1_glds_kernel(const Conv1Args p)
+{
+    constexpr int BM = 128, BN = 64, BK = 16, NKT = 3, WN = 2, TM = 2, TN = 1, CH = 4, RPI = 16;
+    constexpr int A_PW = BM / RPI / 4;               // 2 LDS-DMA instructions per wave and K-tile for A, 1 for B
+    constexpr int STAGE = BM * BK + BK * BN;
+    __shared__ __attribute__((aligned(16))) float smem[NKT * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+#pragma unroll
+    for (int i = 0; i < A_PW; ++i) {
+        const int row = (wave * A_PW + i) * RPI + lane / CH, pc = lane % CH;
+        const int c = pc ^ ((row >> 2) & 3);          // logical chunk (= tap within the K-tile) held by physical chunk pc
+        long long m = m0 + row; if (m >= p.M) m = p.M - 1;
+        const int x = (int)(m % p.W); const long long r = m / p.W; const int y = (int)(r % p.H);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const int t = kt * 4 + c, dy = t / 3 - 1, dx = t % 3 - 1;
+            const bool ok = t < 9 && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
+            const float* src = ok ? p.x4 + (m + (long long)dy * p.W + dx) * 4 : p.zero16;
+            glds16v(src, lds0 + (unsigned)(kt * STAGE + (wave * A_PW + i) * 256) * 4u);
+        }
+    }
+    {
+        const int f = wave * 64 + lane;               // B: one instruction per wave and K-tile (16 x 64 floats = 4 KB)
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+            glds16v(p.w48 + (kt * BK + f / (BN / 4)) * BN + (f % (BN / 4)) * 4, lds0 + (unsigned)(kt * STAGE + BM * BK + wave * 256) * 4u);
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    int a_off[TM], a_sw[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int row = wm * TM * 32 + tm * 32 + (lane & 31);
+        a_off[tm] = row * BK; a_sw[tm] = (row >> 2) & 3;
+    }
+    const int b_off = ((lane >> 5) * 4) * BN + wn * TN * 32 + (lane & 31);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const float* sa = smem + kt * STAGE;
+        const float* sb = sa + BM * BK;
+#pragma unroll
+        for (int kk2 = 0; kk2 < BK / 8; ++kk2) {
+            float4 af[TM]; float bf[4];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) af[tm] = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((kk2 * 2 + (lane >> 5)) ^ a_sw[tm]) * 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = sb[b_off + (kk2 * 8 + j) * BN];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const float av = j == 0 ? af[tm].x : j == 1 ? af[tm].y : j == 2 ? af[tm].z : af[tm].w;
+                    acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[j], acc[tm][0], 0, 0, 0);
+                }
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    constexpr int LDT = 36;
+    float* patch = smem + wave * 32 * LDT;
+    const float4 bv = ldg4(p.bias + wn * 32 + (lane & 7) * 4);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + (lane & 31)] = acc[tm][0][r];
+        __builtin_amdgcn_wave_barrier();
+        const long long mrow = m0 + wm * TM * 32 + tm * 32;
+        float* yb = p.y + wn * 32 + (lane & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = j * 8 + (lane >> 3);
+            float4 v = *reinterpret_cast<const float4*>(&patch[row * LDT + (lane & 7) * 4]);
+            v.x = fmaxf(v.x + bv.x, 0.f); v.y = fmaxf(v.y + bv.y, 0.f); v.z = fmaxf(v.z + bv.z, 0.f); v.w = fmaxf(v.w + bv.w, 0.f);
+            if (mrow + row < p.M) *reinterpret_cast<float4*>(yb + (mrow + row) * BN) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+bool conv1_ldsdma_enabled() { static const int on = [] { const char* e = getenv("FCN8S_CONV1_LDSDMA"); return e ? atoi(e) : 1; }(); return on != 0; }
+// x4: [N,H,W,4] (b, g, r, 0); w48: [48][64] = taps 0..8 x 4 channels, rows 36..47 zero; y = relu(conv + bias), [N,H,W,64]
+bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, hipStream_t s)
+{
+    if (!conv1_ldsdma_enabled() || Cout != 64 || !bias || !zero16) return false;
+    Conv1Args a{x4, w48, bias, y, zero16, N, H, W, (long long)N * H * W};
+    g_last_kernel = "conv1_glds_kernel";
+    hipLaunchKernelGGL(conv1_glds_kernel, dim3((unsigned)((a.M + 127) / 128)), dim3(256), 0, s, a);
+    return true;
+}
+
 static bool glds_enabled() { static const int on = [] { const char* e = getenv("FCN8S_GEMM_LDSDMA"); return e ? atoi(e) : 1; }(); return on != 0; }
 
 template <int BM, int BN, int WM, int WN, int BKF = 16>

@@ -716,7 +716,12 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 // (2.15 GB for conv1_2 at 16 x 1024x512); fcn8s_get_activation of such a layer then returns stale data.
                 e.skip_y = !train || pool_backward_fused(m, b + 1, true);
             }
-            pooled = conv_same(m, first ? "conv1_1_fwd" : "conv3x3_fwd", x, wt, A(m, nm), N, h, w, cin, m->widths[b], 3, e, s, first ? 3 : 0, nm);
+            bool done = false;
+            if (first && m->widths[0] == 64 && conv1_ldsdma_enabled()) {            // conv1_1: write-bound gather kernel (igemm.hip: conv1_glds_kernel)
+                ProfScope ps(m, "conv1_1_fwd", 2.0 * N * h * w * 27.0 * m->widths[0], 4.0 * N * h * w * (3.0 + m->widths[0]), nm);
+                done = launch_conv1_fwd(x, m->d_w1pad, e.bias, A(m, nm), m->d_w1pad + 12 * 4 * (size_t)m->widths[0], N, h, w, m->widths[0], s);
+            }
+            if (!done) pooled = conv_same(m, first ? "conv1_1_fwd" : "conv3x3_fwd", x, wt, A(m, nm), N, h, w, cin, m->widths[b], 3, e, s, first ? 3 : 0, nm);
             x = A(m, nm); cin = m->widths[b];
         }
         snprintf(pn, sizeof pn, "pool%d", b + 1);
@@ -1025,7 +1030,9 @@ int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
     if (cfg->ext_grads) m->d_grads = (float*)cfg->ext_grads;
     else { if ((e = hipMalloc((void**)&m->d_grads, bytes)) != hipSuccess) return bail("hipMalloc(grads)", e); m->own_grads = true; hipMemset(m->d_grads, 0, bytes); }
     if ((e = hipMalloc((void**)&m->d_wt, bytes)) != hipSuccess) return bail("hipMalloc(wt)", e);
-    if ((e = hipMalloc((void**)&m->d_w1pad, 9 * 4 * (size_t)m->widths[0] * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+    // 12 taps x 4 channels: rows 36..47 (three padding taps of the LDS-DMA conv1_1 kernel) and the 64 floats behind them stay zero
+    if ((e = hipMalloc((void**)&m->d_w1pad, (12 * 4 * (size_t)m->widths[0] + 64) * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+    hipMemset(m->d_w1pad, 0, (12 * 4 * (size_t)m->widths[0] + 64) * sizeof(float));
     const size_t cc = (size_t)m->C * m->C;
     if ((e = hipMalloc((void**)&m->d_tph[0], 16 * cc * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&m->d_tph[1], 16 * cc * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
