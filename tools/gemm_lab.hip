@@ -37,7 +37,8 @@ template <int N> static __device__ __forceinline__ void wait_vm() { asm volatile
 // ------------------------------------------------------------------------------------------------------------------
 // GLDS kernel
 // ------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int BK, int S, int OCC>
+// BI: B stored k-interleaved in global memory, [K/4][N][4], so that the four k-steps a lane feeds from one column are one ds_read_b128
+template <int BM, int BN, int WM, int WN, int BK, int S, int OCC, bool BI = false>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
 {
     constexpr int NW = WM * WN, NT = NW * 64;
@@ -78,14 +79,15 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
     for (int i = 0; i < B_PW; ++i) {
         const int f = (wave * B_PW + i) * 64 + lane;
         const int k = f / (BN / 4), j = (f % (BN / 4)) * 4;
-        b_voff[i] = (unsigned)(k * p.N + j) * 4u;
+        b_voff[i] = BI ? (unsigned)((f / BN) * p.N * 4 + (f % BN) * 4) * 4u      // k-group f / BN, column f % BN, 4 k values
+                       : (unsigned)(k * p.N + j) * 4u;
     }
     const float* a_base = A + m0 * p.K;              // block-uniform, advanced by BK floats per K-tile
-    const float* b_base = B + n0;                    // ... by BK rows
+    const float* b_base = B + (BI ? n0 * 4 : n0);    // ... by BK rows
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
     auto issue = [&](int kt, int stage) {
         const float* ga = a_base + (long long)kt * BK;
-        const float* gb = b_base + (long long)kt * BK * p.N;
+        const float* gb = b_base + (long long)kt * BK * p.N;       // (same advance in both layouts: BK rows = BK / 4 k-groups of 4 N floats)
         const unsigned la = lds0 + (unsigned)(stage * STAGE + wave * A_PW * 256) * 4u;
         const unsigned lb = lds0 + (unsigned)(stage * STAGE + BM * BK + wave * B_PW * 256) * 4u;
 #pragma unroll
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
         a_off[tm] = row * BK;
         a_sw[tm] = (row / (16 / CH)) & (CH - 1);
     }
-    const int b_off = ((lane >> 5) * 4) * BN + wn * TN * 32 + (lane & 31);
+    const int b_off = BI ? ((lane >> 5) * BN + wn * TN * 32 + (lane & 31)) * 4 : ((lane >> 5) * 4) * BN + wn * TN * 32 + (lane & 31);
 
     auto compute = [&](int stage) {
         const float* sa = smem + stage * STAGE;
@@ -124,9 +126,15 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
             for (int tm = 0; tm < TM; ++tm)
                 af[tm] = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((kk2 * 2 + (lane >> 5)) ^ a_sw[tm]) * 4));
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
+            for (int tn = 0; tn < TN; ++tn) {
+                if (BI) {
+                    const float4 t = *reinterpret_cast<const float4*>(sb + b_off + (kk2 * 2 * BN + tn * 32) * 4);
+                    bf[tn][0] = t.x; bf[tn][1] = t.y; bf[tn][2] = t.z; bf[tn][3] = t.w;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bf[tn][j] = sb[b_off + (kk2 * 8 + j) * BN + tn * 32];
+                    for (int j = 0; j < 4; ++j) bf[tn][j] = sb[b_off + (kk2 * 8 + j) * BN + tn * 32];
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -384,6 +392,30 @@ int main(int argc, char** argv)
     hipLaunchKernelGGL(fill, dim3(8192), dim3(256), 0, 0, dB, capB, 7u);
     hipDeviceSynchronize();
     if (argc > 1 && std::string(argv[1]) == "corun") { corun_probe(); return 0; }
+    if (argc > 1 && std::string(argv[1]) == "bi") {
+        // correctness: B filled so that the interleaved reading of the SAME buffer is a valid matrix; compare BI kernel on buffer X with the
+        // plain kernel on the de-interleaved copy
+        const Shape c{"check", 300, 128, 256, 2};
+        Args a{dA, dB, dC, c.T, c.K, c.N, c.T * c.K + 1088, (long long)c.K * c.N, c.T * c.N + 1088, 0};
+        std::vector<float> hb((size_t)c.P * c.K * c.N), hi(hb.size());
+        hipMemcpy(hb.data(), dB, hb.size() * 4, hipMemcpyDeviceToHost);
+        for (int z = 0; z < c.P; ++z) for (int k = 0; k < c.K; ++k) for (int n = 0; n < c.N; ++n)
+            hi[(size_t)z * c.K * c.N + ((size_t)(k / 4) * c.N + n) * 4 + k % 4] = hb[(size_t)z * c.K * c.N + (size_t)k * c.N + n];
+        float* dBi; hipMalloc(&dBi, hi.size() * 4); hipMemcpy(dBi, hi.data(), hi.size() * 4, hipMemcpyHostToDevice);
+        dim3 grid((unsigned)(((c.T + 127) / 128) * (c.N / 128)), 1, (unsigned)c.P);
+        std::vector<float> r0((size_t)c.P * a.sc), r1(r0.size());
+        hipLaunchKernelGGL((gemm_glds<128, 128, 2, 2, 16, 3, 3, false>), grid, dim3(256), 0, 0, a); hipMemcpy(r0.data(), dC, r0.size() * 4, hipMemcpyDeviceToHost);
+        Args b = a; b.B = dBi;
+        hipLaunchKernelGGL((gemm_glds<128, 128, 2, 2, 16, 3, 3, true>), grid, dim3(256), 0, 0, b); hipMemcpy(r1.data(), dC, r1.size() * 4, hipMemcpyDeviceToHost);
+        double worst = 0; for (int z = 0; z < c.P; ++z) for (long long r = 0; r < c.T; ++r) for (int n = 0; n < c.N; ++n) worst = std::max(worst, (double)std::fabs(r0[z * a.sc + r * c.N + n] - r1[z * a.sc + r * c.N + n]));
+        printf("B-interleaved vs plain: max abs difference %.3e\n", worst);
+        for (int rep = 0; rep < 2; ++rep)
+            for (auto& s : shapes) {
+                run("glds 128x128 s3 plain B", GLDS(128, 128, 2, 2, 16, 3, 3), 128, 128, s, false);
+                run("glds 128x128 s3 interleaved B", [&](dim3 g, const Args& a) { hipLaunchKernelGGL((gemm_glds<128, 128, 2, 2, 16, 3, 3, true>), g, dim3(256), 0, 0, a); }, 128, 128, s, false);
+            }
+        return 0;
+    }
     const Shape chk{"check", 300, 128, 256, 3};          // T not a multiple of any tile, K = 8 / 4 K-tiles
     const Shape chk2{"check2", 300, 32, 512, 2};         // fewer K-tiles than stages
 #define BOTH(tag, L, BM, BN) do { run(tag, L, BM, BN, chk, true); run(tag, L, BM, BN, chk2, true); } while (0)
