@@ -5,6 +5,10 @@
 // re-layouts.  16-byte vector accesses, grid-stride loops capped at 2048 blocks.
 #include "fcn8s_internal.h"
 #include <math.h>
+#include <map>
+#include <mutex>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace fcn8s {
 
@@ -295,13 +299,44 @@ __global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* logits
         if (am) am[pix] = best;
     }
 }
+// C % 4 == 0 in registers: 16-byte loads / stores, one expf per class (same values as the generic kernel: v_i = expf(l_i - max) / sum)
+template <int C>
+__global__ __launch_bounds__(256) void softmax_argmax_kernel_c(const float* __restrict__ logits, float* __restrict__ sm, long long* __restrict__ am,
+                                                               long long npix, const PixMap map)
+{
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+        const long long pix = slot_pixel(p, map);
+        if (pix < 0) continue;
+        float v[C];
+        const float4* src = reinterpret_cast<const float4*>(logits + p * C);
+#pragma unroll
+        for (int i = 0; i < C / 4; ++i) { const float4 t = src[i]; v[4*i] = t.x; v[4*i+1] = t.y; v[4*i+2] = t.z; v[4*i+3] = t.w; }
+        float m = v[0];
+#pragma unroll
+        for (int i = 1; i < C; ++i) m = fmaxf(m, v[i]);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < C; ++i) { v[i] = expf(v[i] - m); s += v[i]; }
+        int best = 0; float bv = -1.f;
+#pragma unroll
+        for (int i = 0; i < C; ++i) { v[i] = v[i] / s; if (v[i] > bv) { bv = v[i]; best = i; } }
+        if (sm) {
+            float4* dst = reinterpret_cast<float4*>(sm + pix * C);
+#pragma unroll
+            for (int i = 0; i < C / 4; ++i) dst[i] = make_float4(v[4*i], v[4*i+1], v[4*i+2], v[4*i+3]);
+        }
+        if (am) am[pix] = best;
+    }
+}
 void launch_softmax_argmax(const float* logits, float* softmax_out, long long* argmax_out,
                            long long npix, int C, hipStream_t s, const PixMap* map, int N)
 {
     const PixMap pm = map ? *map : PixMap{0, 0, 0, 0, 0, 0};
     const long long nslot = pixmap_slots(pm, npix, N);
-    hipLaunchKernelGGL(softmax_argmax_kernel, dim3(cap_blocks(nslot, 256)), dim3(256), 0, s, logits,
-                       softmax_out, argmax_out, nslot, C, pm);
+    const int blocks = cap_blocks(nslot, 256);
+    if (C == 20) hipLaunchKernelGGL(softmax_argmax_kernel_c<20>, dim3(blocks), dim3(256), 0, s, logits, softmax_out, argmax_out, nslot, pm);
+    else if (C == 4) hipLaunchKernelGGL(softmax_argmax_kernel_c<4>, dim3(blocks), dim3(256), 0, s, logits, softmax_out, argmax_out, nslot, pm);
+    else hipLaunchKernelGGL(softmax_argmax_kernel, dim3(blocks), dim3(256), 0, s, logits, softmax_out, argmax_out, nslot, C, pm);
 }
 
 // ---- the k = 2s transposed conv as one GEMM: re-layouts (PixMap in fcn8s_internal.h) --------------------------------------------
@@ -458,11 +493,14 @@ void launch_confusion(const uint8_t* labels, const long long* pred, long long np
 }
 
 // ---- column sums (bias gradients): out[c] += sum_r x[r, c] --------------------
-// 16-byte loads, four independent rows in flight per thread; a block covers `rpb` rows x up to 1024 columns, reduces its
-// row groups through LDS and adds C partial sums to `out` (the first version read one float per thread per step: 89 us
-// per call on average, 1.9 ms per training step).
+// 16-byte loads, four independent rows in flight per thread; a block covers `rpb` rows x up to 1024 columns and reduces its
+// row groups through LDS.  Blocks do NOT meet in atomics: device-scope atomics on one cache line (and equally a ticket counter
+// with a fence) serialise at ~100 ns per block, so the one-kernel versions took time proportional to their block count (919
+// blocks on a 60 MB slab: 125 us = 0.5 TB/s).  Each block stores its partial row; a second, one-block-per-column-tile kernel
+// adds the rows up in block order (reproducible) and does the single read-modify-write of `out`.  A launch that fits one
+// block per column tile writes `out` directly.
 __global__ __launch_bounds__(256) void colsum_kernel(const float4* __restrict__ x, float* __restrict__ out, long long rows, int C4, int tpr,
-                                                     long long rpb)
+                                                     long long rpb, float4* __restrict__ partial)
 {
     __shared__ float4 sh[256];
     const int rgroups = 256 / tpr;
@@ -483,9 +521,54 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float4* __restrict__ 
     __syncthreads();
     if (rg == 0 && c < C4) {
         for (int g = 1; g < rgroups; ++g) { const float4 t = sh[g * tpr + lc]; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
-        unsafeAtomicAdd(out + 4 * c, acc.x); unsafeAtomicAdd(out + 4 * c + 1, acc.y);
-        unsafeAtomicAdd(out + 4 * c + 2, acc.z); unsafeAtomicAdd(out + 4 * c + 3, acc.w);
+        if (partial) partial[(long long)blockIdx.x * C4 + c] = acc;
+        else { float* o = out + 4 * c; o[0] += acc.x; o[1] += acc.y; o[2] += acc.z; o[3] += acc.w; }
     }
+}
+// 16 float4 columns x 16 row groups per block, eight independent loads in flight per thread (the rows are L2-resident)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float4* __restrict__ partial, float* __restrict__ out, int nrows, int C4)
+{
+    __shared__ float4 sh[256];
+    const int lc = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + lc;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C4) {
+        int b = rg;
+        for (; b + 7 * 16 < nrows; b += 8 * 16) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(long long)(b + 16 * u) * C4 + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w; }
+        }
+        for (; b < nrows; b += 16) { const float4 v = partial[(long long)b * C4 + c]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    }
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    if (rg == 0 && c < C4) {
+        for (int g = 1; g < 16; ++g) { const float4 v = sh[g * 16 + lc]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        float* o = out + 4 * c;
+        o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+    }
+}
+namespace {
+struct ColsumScratch { float* partial = nullptr; size_t cap = 0; };
+// per stream: two streams may run column sums at the same time, launches on one stream are ordered
+ColsumScratch* colsum_scratch(hipStream_t s, size_t floats)
+{
+    static std::mutex mu;
+    static std::map<hipStream_t, ColsumScratch> pool;
+    std::lock_guard<std::mutex> lk(mu);
+    ColsumScratch& e = pool[s];
+    if (e.cap < floats) {
+        if (e.partial) hipFree(e.partial);                  // (synchronises the device: nothing still reads the old buffer)
+        e.partial = nullptr; e.cap = 0;
+        const size_t want = floats < (1u << 18) ? (1u << 18) : floats;
+        if (hipMalloc((void**)&e.partial, want * sizeof(float)) != hipSuccess) return nullptr;
+        e.cap = want;
+    }
+    return &e;
+}
 }
 void launch_colsum(const float* x, float* out, long long rows, int C, hipStream_t s)   // C % 4 == 0 (all channel counts here are)
 {
@@ -493,11 +576,20 @@ void launch_colsum(const float* x, float* out, long long rows, int C, hipStream_
     int tpr = 1; while (tpr < C4 && tpr < 256) tpr *= 2;          // threads per row slice (power of two >= C4, at most 256)
     const int ctiles = (C4 + tpr - 1) / tpr, rgroups = 256 / tpr;
     long long rblocks = (rows + 16LL * rgroups - 1) / (16LL * rgroups);      // >= 16 rows per thread
-    const long long maxb = 4096 / ctiles > 0 ? 4096 / ctiles : 1;
+    static const int maxb_total = [] { const char* e = getenv("FCN8S_COLSUM_MAXB"); return e ? atoi(e) : 512; }();
+    const long long maxb = maxb_total / ctiles > 0 ? maxb_total / ctiles : 1;
     if (rblocks > maxb) rblocks = maxb;
     if (rblocks < 1) rblocks = 1;
     const long long rpb = (rows + rblocks - 1) / rblocks;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + rpb - 1) / rpb), ctiles), dim3(256), 0, s, (const float4*)x, out, rows, C4, tpr, rpb);
+    const unsigned gx = (unsigned)((rows + rpb - 1) / rpb);
+    float4* partial = nullptr;
+    if (gx > 1) {
+        ColsumScratch* sc = colsum_scratch(s, (size_t)gx * C);
+        if (!sc) { fprintf(stderr, "fcn8s: column-sum scratch allocation failed\n"); abort(); }
+        partial = (float4*)sc->partial;
+    }
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, ctiles), dim3(256), 0, s, (const float4*)x, out, rows, C4, tpr, rpb, partial);
+    if (gx > 1) hipLaunchKernelGGL(colsum_final_kernel, dim3((C4 + 15) / 16), dim3(256), 0, s, (const float4*)partial, out, (int)gx, C4);
 }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, float* out, long long n)

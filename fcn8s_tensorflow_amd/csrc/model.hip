@@ -334,8 +334,16 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
     const double rc = real_cin ? real_cin : Cin;
     const double flops = 2.0 * a.M * K * K * rc * Cout;
     const double bytes = 4.0 * (a.M * rc + (double)a.M * Cout + (double)K * K * rc * Cout);
-    if (m) { ProfScope ps(m, group, flops, bytes, layer); launch_igemm(a, 1, s); }
-    else launch_igemm(a, 1, s);
+    // 1x1 score heads: one skinny dimension (skinny.hip); everything else goes through the general tile kernels
+    auto run = [&]() {
+        if (K == 1 && !real_cin && !e.addend && !e.relu && !e.dropout) {
+            if (Cout <= 32 && !e.mask && launch_head_fwd(x, w, e.bias, y, a.M, Cin, Cout, e.alpha, s)) return;
+            if (Cin <= 32 && !e.bias && launch_head_dgrad(x, w, e.mask, e.mask_scale, y, a.M, Cout, Cin, e.alpha, s)) return;
+        }
+        launch_igemm(a, 1, s);
+    };
+    if (m) { ProfScope ps(m, group, flops, bytes, layer); run(); }
+    else run();
     return false;
 }
 
@@ -429,6 +437,10 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
     const bool taps = (K == 3 || K == 7) && alpha == 1.f && !real_cin;
     const bool first = K == 3 && alpha == 1.f && real_cin == 3 && Cin == 4;
     auto run = [&]() {
+        if (K == 1 && !real_cin && Cout <= 32 && launch_head_wgrad(x, dz, dw, a.P, Cin, Cout, alpha, s)) {
+            if (db) launch_colsum(dz, db, a.P, Cout, s);
+            return;
+        }
         if (taps && launch_wgrad_taps(x, dz, dw, db, N, H, W, Cin, Cout, K, s)) return;
         if (first && launch_conv1_wgrad(x, dz, dw, db, N, H, W, Cout, s)) return;
         launch_wgrad(a, s);

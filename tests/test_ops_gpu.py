@@ -42,6 +42,13 @@ CONV_CASES = [
     (1, 3, 5, 8, 20, 3),
     (2, 4, 16, 64, 128, 7),     # 7x7 with W % 16 == 0, C % 64 == 0: the one-filter-row-per-block wgrad kernel
     (2, 8, 32, 128, 64, 3),     # 3x3, all-nine-taps wgrad kernel, two ci tiles
+    # 1x1 score heads (skinny.hip): ragged row counts, the 8-wave K split, the K % 32 tail, and the 4-class build
+    (1, 5, 7, 256, 20, 1),
+    (2, 8, 8, 4096, 20, 1),
+    (3, 11, 3, 512, 20, 1),
+    (1, 9, 5, 96, 4, 1),
+    (1, 4, 8, 2112, 20, 1),
+    (1, 64, 128, 256, 20, 1),
 ]
 
 
