@@ -217,6 +217,7 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
              unsigned* relu_bits_out = nullptr;          // forward, Winograd path: also record (y > 0), one bit per element
              const unsigned* relu_bits_in = nullptr;     // data gradient, Winograd path: such a record of `mask` (read instead of the tensor)
              const float* w_fwd = nullptr;
+             int lazy_wt = 0;                            // data gradient: `w` is still to be filled from w_fwd (flip + transpose) if the adjoint path is not taken
              int skip_y = 0; };                          // Winograd path with pool_out: do not write the full-resolution output (only its pool is consumed)            // data gradient: the layer's forward kernel [3,3,Cout_of_this_conv... = Cin here][...] (adjoint Winograd path)
 
 // 3x3 SAME conv through Winograd F(tile x tile, 3x3): filter transform, input transform, (tile+2)^2 batched GEMMs
@@ -307,6 +308,10 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
         return false;
     }
     if (m) m->dm_layer.clear();
+    if (e.lazy_wt && e.w_fwd) {
+        if (m) { ProfScope ps(m, "weight_relayout", 0, 8.0 * K * K * Cin * Cout); launch_flip_transpose(e.w_fwd, const_cast<float*>(w), K * K, Cout, Cin, s); }
+        else launch_flip_transpose(e.w_fwd, const_cast<float*>(w), K * K, Cout, Cin, s);
+    }
     if ((wino3 || wino7) && Cin % 16 == 0 && Cout % 64 == 0 && e.alpha == 1.f && !real_cin) {
         const bool dgrad = e.dgrad != 0;
         float* vbuf = m->d_wino_v;
@@ -833,14 +838,10 @@ int compute_loss(fcn8s_model* m, const uint8_t* lab_dev, float l2_rate, bool wit
 void prepare_backward_weights(fcn8s_model* m)
 {
     hipStream_t s = m->stream;
-    ProfScope ps(m, "weight_relayout", 0, 8.0 * m->total);
-    int cin = 3;
-    for (int b = 0; b < 5; ++b)
-        for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
-            char nm[32]; snprintf(nm, sizeof nm, "conv%d_%d/filter", b + 1, i);
-            if (!(b == 0 && i == 1)) launch_flip_transpose(Wp(m, nm), WTp(m, nm), 9, cin, m->widths[b], s);
-            cin = m->widths[b];
-        }
+    ProfScope ps(m, "weight_relayout", 0, 8.0 * ((double)m->fc6k * m->fc6k * m->widths[4] * m->widths[5] + (double)m->widths[5] * m->widths[6] +
+                                                 (double)m->C * (m->widths[2] + m->widths[3] + m->widths[6])));
+    // (the 3x3 layers' flipped + transposed kernels are made on demand in conv_same: the adjoint Winograd data gradient, which the
+    // wide layers take, reads the forward kernel)
     launch_flip_transpose(Wp(m, "fc6/weights"), WTp(m, "fc6/weights"), m->fc6k * m->fc6k, m->widths[4], m->widths[5], s);
     launch_flip_transpose(Wp(m, "fc7/weights"), WTp(m, "fc7/weights"), 1, m->widths[5], m->widths[6], s);
     launch_flip_transpose(Wp(m, "pool3_1x1/kernel"), WTp(m, "pool3_1x1/kernel"), 1, m->widths[2], m->C, s);
@@ -936,7 +937,7 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
             conv_wgrad(m, first ? "conv1_1_wgrad" : "conv3x3_wgrad", xin, dz, Gp(m, std::string(nm) + "/filter"), Gp(m, std::string(nm) + "/biases"),
                        N, h, w, cin, cw, 3, 1.f, s, real_cin, nm, dgrad_wino, i == nconv ? pidx : nullptr);
             if (first) break;
-            Epi e; e.dgrad = 1; e.w_fwd = Wp(m, std::string(nm) + "/filter");
+            Epi e; e.dgrad = 1; e.w_fwd = Wp(m, std::string(nm) + "/filter"); e.lazy_wt = 1;
             if (i > 1) {                                                   // ReLU of the previous conv
                 e.mask = xin; e.mask_scale = 1.f;
                 if (m->rbits_ok.count(inname)) e.relu_bits_in = (const unsigned*)A(m, (std::string("rb:") + inname).c_str());
