@@ -741,7 +741,9 @@ void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s)
         if (blocks(128, 64) >= 200) launch_igemm_cfg<128, 64, 2, 2>(a, phases, s);
         else                        launch_igemm_cfg<64, 64, 2, 2>(a, phases, s);
     } else {
-        if (blocks(128, 128) >= 200)     launch_igemm_cfg<128, 128, 2, 2>(a, phases, s);   // (K-tile depth 32 and 256x64 tiles measured slower: fewer resident waves)
+        // (at most 64 rows -- fc6 at batch 1 has 32 tiles per Winograd position: a 128-row tile would spend 3/4 of its MFMAs on padding)
+        if (a.M <= 64 && blocks(64, 128) >= 200) launch_igemm_cfg<64, 128, 2, 2>(a, phases, s);
+        else if (blocks(128, 128) >= 200) launch_igemm_cfg<128, 128, 2, 2>(a, phases, s);   // (K-tile depth 32 and 256x64 tiles measured slower: fewer resident waves)
         else if (blocks(64, 128) >= 200) launch_igemm_cfg<64, 128, 2, 2>(a, phases, s);
         else                             launch_igemm_cfg<64, 64, 2, 2>(a, phases, s);
     }

@@ -9,6 +9,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16); ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024); ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc"])
+    ap.add_argument("--infer", action="store_true", help="predict() (frozen parameters, argmax) instead of a training step")
     args = ap.parse_args()
     import torch
     from fcn8s_tensorflow_amd.engine import Engine
@@ -16,10 +17,15 @@ def main():
     rng = np.random.default_rng(0)
     img = torch.from_numpy(rng.integers(0, 256, (args.batch, args.height, args.width, 3), dtype=np.uint8)).cuda()
     lab = torch.from_numpy(rng.integers(0, 20, (args.batch, args.height, args.width), dtype=np.uint8)).cuda()
-    e.train_step(img, lab, 1e-4, fetch_loss=False); torch.cuda.synchronize()
+    if args.infer:
+        e.freeze(True)
+        step = lambda: e.predict(img, argmax=True)
+    else:
+        step = lambda: e.train_step(img, lab, 1e-4, fetch_loss=False)
+    step(); step(); torch.cuda.synchronize()
     e.profile(2); e.profile_reset()
     for _ in range(args.steps):
-        e.train_step(img, lab, 1e-4, fetch_loss=False)
+        step()
     torch.cuda.synchronize()
     tot = 0
     for k, v in e.profile_results().items():
