@@ -217,6 +217,8 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
              unsigned* relu_bits_out = nullptr;          // forward, Winograd path: also record (y > 0), one bit per element
              const unsigned* relu_bits_in = nullptr;     // data gradient, Winograd path: such a record of `mask` (read instead of the tensor)
              const float* w_fwd = nullptr;
+             unsigned* in_relu_bits_out = nullptr;       // forward, Winograd path: record (x > 0) of the input too (see wino_input_kernel) ...
+             const char* in_layer = nullptr;              // ... under this producer's name in rbits_ok
              int lazy_wt = 0;                            // data gradient: `w` is still to be filled from w_fwd (flip + transpose) if the adjoint path is not taken
              int skip_y = 0; };                          // Winograd path with pool_out: do not write the full-resolution output (only its pool is consumed)            // data gradient: the layer's forward kernel [3,3,Cout_of_this_conv... = Cin here][...] (adjoint Winograd path)
 
@@ -240,7 +242,8 @@ int wino_tile_for(const fcn8s_model* m, int H, int W, int K = 3)
 long long wino_tiles(int tile, int N, int H, int W) { return (long long)N * ((H + tile - 1) / tile) * ((W + tile - 1) / tile); }
 struct WinoEpi { const float* bias = nullptr; const float* addend = nullptr; const float* mask = nullptr; float mask_scale = 1.f;
                  int relu = 0; int dropout = 0; float keep = 1.f; unsigned long long seed = 0; unsigned int stream_id = 0; float* pool = nullptr; unsigned char* pidx = nullptr;
-                 unsigned* rbits_out = nullptr; const unsigned* rbits_in = nullptr; int skip_y = 0; };
+                 unsigned* rbits_out = nullptr; const unsigned* rbits_in = nullptr; int skip_y = 0;
+                 unsigned* in_rbits_out = nullptr; };     // ReLU bit record of the INPUT, written by the input transform
 // KS = 3, or 7 (3x3 grid of 3x3 sub-filters, GEMM depth 9*Cin -- see winograd.hip)
 void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const float* x, const float* wk, float* y, float* u, float* v, float* mm,
                    int N, int H, int W, int Cin, int Cout, const WinoEpi& e, hipStream_t s, const char* layer, bool v_ready = false)
@@ -268,7 +271,7 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
         a.w = u;
     }
     // v_ready: V was written together with the weight gradient's dM by the fused transform (launch_wino_input_dout)
-    auto pre = [&]() { if (!u_cached) launch_wino_filter(tile, wk, u, Cin, Cout, KS, s); if (!v_ready) launch_wino_input(tile, x, v, N, H, W, Cin, KS, s); };
+    auto pre = [&]() { if (!u_cached) launch_wino_filter(tile, wk, u, Cin, Cout, KS, s); if (!v_ready) launch_wino_input(tile, x, v, N, H, W, Cin, KS, s, e.in_rbits_out); };
     auto post = [&]() { launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, (e.skip_y && e.pool) ? nullptr : y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s, e.pool, e.pidx, KS, e.rbits_out, e.rbits_in); };
     if (m) {
         { ProfScope ps(m, "wino_transform", 0, (v_ready ? 0.0 : tb) + (u_cached ? 0.0 : (double)(KS * KS + P * nsub2) * 4 * Cin * Cout)); pre(); }
@@ -322,6 +325,7 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
         we.dropout = e.dropout; we.keep = e.keep; we.seed = m->seed; we.stream_id = e.stream_id; we.pool = e.pool_out; we.pidx = e.pool_idx;
         we.rbits_out = e.relu_bits_out; we.rbits_in = e.relu_bits_in; we.skip_y = e.skip_y && e.pool_out;
         if (e.relu_bits_out && layer) m->rbits_ok.insert(layer);
+        if (e.in_relu_bits_out && e.in_layer && K == 3 && !dgrad) { we.in_rbits_out = e.in_relu_bits_out; m->rbits_ok.insert(e.in_layer); }
         const char* tag = K == 7 ? (dgrad ? "wino_gemm_fc6_dgrad" : "wino_gemm_fc6_fwd") : (dgrad ? "wino_gemm_dgrad" : "wino_gemm_fwd");
         conv_winograd(m, wino_tile_for(m, H, W, K), K, tag, x, w, y, m->d_wino_u, vbuf, m->d_wino_m, N, H, W, Cin, Cout, we, s, layer, v_ready);
         return e.pool_out != nullptr;
@@ -502,7 +506,9 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
         for (int b = 0, hh = H, ww = W; b < 5; ++b, hh /= 2, ww /= 2)
             for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
                 const int tile = wino_tile_for(m, hh, ww, 3);
-                if (i < kConvsPerBlock[b] && m->wino_min_cin > 0 && cin >= m->wino_min_cin && cin % 16 == 0 && m->widths[b] % 64 == 0 && tile) {
+                // (conv1_1 is not a Winograd layer: its record is written by conv1_2's input transform, if that is one)
+                const bool by_consumer = b == 0 && i == 1 && kConvsPerBlock[0] > 1 && m->wino_min_cin > 0 && m->widths[0] >= m->wino_min_cin && m->widths[0] % 64 == 0 && tile;
+                if (by_consumer || (i < kConvsPerBlock[b] && m->wino_min_cin > 0 && cin >= m->wino_min_cin && cin % 16 == 0 && m->widths[b] % 64 == 0 && tile)) {
                     char nm[40]; snprintf(nm, sizeof nm, "rb:conv%d_%d", b + 1, i);
                     items.push_back({nm, wino_rbits_words(tile, N, hh, ww, m->widths[b]), 0, 0, 0, nullptr});
                 }
@@ -724,6 +730,10 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
             if (train && i < kConvsPerBlock[b]) {                                                            // its output is the next conv's input
                 auto it = m->acts.find(std::string("rb:") + nm);
                 if (it != m->acts.end()) e.relu_bits_out = (unsigned*)it->second.p;
+            }
+            if (train && b == 0 && i == 2) {                                                                 // input = conv1_1, made by the gather kernel
+                auto it = m->acts.find("rb:conv1_1");
+                if (it != m->acts.end()) { e.in_relu_bits_out = (unsigned*)it->second.p; e.in_layer = "conv1_1"; }
             }
             if (i == kConvsPerBlock[b]) {                                                                    // last conv of the block
                 snprintf(pn, sizeof pn, "pool%d", b + 1); e.pool_out = A(m, pn);

@@ -162,28 +162,59 @@ __global__ void wino_filter_kernel(const float* w, float* u, int Cin, int Cout, 
 // plus a scalar offset (the first version recomputed the full NHWC index per access: ~350 quarter-rate integer
 // multiplies per tile, more VALU time than the HBM time of the bytes it moved).
 struct TileIdx { int n, ty, tx, c; long long t; bool ok; };
-static __device__ __forceinline__ TileIdx tile_index(int th, int tw, int C4)
+// Optional XCD-banded order (FCN8S_WINO_XCD_BAND=1).  The hardware deals consecutive workgroups round-robin to the 8 XCDs (each
+// with its own L2), so with the plain (x fastest, tile row next) order vertically adjacent tile rows -- which share two input
+// rows (input transform) or the neighbours' border positions (gather form of the adjoint data gradient) -- land on different
+// L2s and the shared rows are fetched twice over the fabric (+22 % / +28 % FETCH_SIZE in the PMC pass).  Banded, XCD k takes the
+// k-th contiguous band of tile rows: workgroup L is the (L / 8)-th of XCD L % 8 and gets logical index (L % 8) * (B / 8) + L / 8
+// (tile_grid pads the row count to a multiple of 8 so that B % 8 == 0; rows >= N * th do nothing).  Measured: no change in any
+// transform kernel's duration (the second fetch is served by the memory-side cache, not HBM), so the plain order stays the default.
+__device__ int g_wino_xcd_band = 0;
+static __device__ __forceinline__ TileIdx tile_index(int th, int tw, int C4, int N)
 {
     TileIdx r;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (g_wino_xcd_band) {
+        const unsigned L = by * gridDim.x + bx, per = gridDim.x * gridDim.y / 8;
+        const unsigned Lp = (L & 7) * per + (L >> 3);
+        by = Lp / gridDim.x; bx = Lp - by * gridDim.x;
+    }
+    const int idx = bx * 256 + threadIdx.x;
     r.tx = idx / C4; r.c = idx - r.tx * C4;
-    r.n = blockIdx.y / th; r.ty = blockIdx.y - r.n * th;
-    r.ok = r.tx < tw;
+    r.n = by / th; r.ty = by - r.n * th;
+    r.ok = r.tx < tw && r.n < N;
     r.t = ((long long)r.n * th + r.ty) * tw + r.tx;
     return r;
 }
-static inline dim3 tile_grid(int N, int th, int tw, int C4, int z = 1) { return dim3((unsigned)((tw * C4 + 255) / 256), (unsigned)(N * th), (unsigned)z); }
+static inline dim3 tile_grid(int N, int th, int tw, int C4, int z = 1)
+{
+    static const bool once = [] {
+        const char* e = getenv("FCN8S_WINO_XCD_BAND");
+        const int v = e ? atoi(e) : 0;
+        if (v != 0) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_xcd_band), &v, sizeof v);
+        return true;
+    }();
+    (void)once;
+    return dim3((unsigned)((tw * C4 + 255) / 256), (unsigned)((N * th + 7) / 8 * 8), (unsigned)z);
+}
 
 // ---- input: one thread = one m x m output tile x VEC channels; alpha x alpha patch (zero outside), V = B^T d B --------
 template <int M, int VEC, int R>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restrict__ x, float4* __restrict__ v, int N, int H, int W, int C4, int pad, int nsub,
-                                                         long long slab)
+                                                         long long slab, unsigned* __restrict__ rbits_out)
 {
     constexpr int A = WinoMat<M, R>::A;
+    // rbits_out (3x3 layers, pad = 1): also record (x > 0) of the tile's own M x M pixels (patch rows / columns 1..M), in the layout
+    // of wino_output_kernel's rbits_out -- for an input that a non-Winograd kernel produced (conv1_1), so that the data gradient
+    // of this layer reads 1/32 of that tensor instead of all of it
+    constexpr int RW = (M * M * VEC + 31) / 32;
+    unsigned rb[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) rb[j] = 0u;
     const int th = (H + M - 1) / M, tw = (W + M - 1) / M;      // partial tiles at the bottom / right edge (F(6x6): 512 = 85 * 6 + 2)
     const int sub = blockIdx.z, sa = sub / nsub, sb = sub - sa * nsub;     // sub-filter: patch shifted by (R sa, R sb)
     const int ldv = C4 * nsub * nsub;
-    const TileIdx ti = tile_index(th, tw, C4);
+    const TileIdx ti = tile_index(th, tw, C4, N);
     if (!ti.ok) return;
     const int y0 = M * ti.ty + R * sa - pad, x0 = M * ti.tx + R * sb - pad;
     const float4* xp = x + (((long long)ti.n * H + y0) * W + x0) * C4 + ti.c;     // dereferenced only where (row, col) lies inside the image
@@ -196,6 +227,15 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restric
         float4 d[A];
 #pragma unroll
         for (int a = 0; a < A; ++a) d[a] = (rok[a] && cok[b]) ? xp[(a * W + b) * C4] : f4zero();
+        if (rbits_out && b >= 1 && b <= M) {
+#pragma unroll
+            for (int a = 1; a <= M; ++a)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const int bit = ((a - 1) * M + (b - 1)) * VEC + i;
+                    if (d[a].d[i] > 0.f) rb[bit >> 5] |= 1u << (bit & 31);
+                }
+        }
 #pragma unroll
         for (int a = 0; a < A; ++a) {
             float4 s = f4zero();
@@ -203,6 +243,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restric
             for (int k = 0; k < A; ++k) if (WinoMat<M, R>::bt(a, k) != 0.f) s = f4fma(WinoMat<M, R>::bt(a, k), d[k], s);
             q[a][b] = s;
         }
+    }
+    if (rbits_out) {
+#pragma unroll
+        for (int j = 0; j < RW; ++j) rbits_out[(ti.t * C4 + ti.c) * RW + j] = rb[j];
     }
     float4* vp = v + ti.t * ldv + sub * C4 + ti.c;
 #pragma unroll
@@ -226,7 +270,7 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
 {
     constexpr int A = M + 2, NW = M / 2 + 2;           // NW: pool windows one patch row / column touches
     const int th = (H + M - 1) / M, tw = (W + M - 1) / M;      // partial tiles at the bottom / right edge (F(6x6): 512 = 85 * 6 + 2)
-    const TileIdx ti = tile_index(th, tw, C4);
+    const TileIdx ti = tile_index(th, tw, C4, N);
     if (!ti.ok) return;
     const int y0 = M * ti.ty - 1, x0 = M * ti.tx - 1;
     const float4* xp = x + (((long long)ti.n * H + y0) * W + x0) * C4 + ti.c;
@@ -313,7 +357,7 @@ __global__ __launch_bounds__(256, 3) void wino_output_kernel(const float4* __res
     // gradient launch that would read y back as its mask (same geometry, same thread mapping) reads those words instead (1/32 of the bytes)
     constexpr int RW = (M * M * VEC + 31) / 32;
     const int th = (H + M - 1) / M, tw = (W + M - 1) / M;      // partial tiles at the bottom / right edge (F(6x6): 512 = 85 * 6 + 2)
-    const TileIdx ti = tile_index(th, tw, C4);
+    const TileIdx ti = tile_index(th, tw, C4, N);
     if (!ti.ok) return;
     unsigned rb[RW];
 #pragma unroll
@@ -412,7 +456,7 @@ __global__ __launch_bounds__(256) void wino_dout_kernel(const float4* __restrict
 {
     constexpr int A = WinoMat<M, R>::A;
     const int th = (H + M - 1) / M, tw = (W + M - 1) / M;      // partial tiles at the bottom / right edge (F(6x6): 512 = 85 * 6 + 2)
-    const TileIdx ti = tile_index(th, tw, C4);
+    const TileIdx ti = tile_index(th, tw, C4, N);
     if (!ti.ok) return;
     const float4* yp = dy + (((long long)ti.n * H + M * ti.ty) * W + M * ti.tx) * C4 + ti.c;
     const int Hp = H / 2, Wp = W / 2;
@@ -476,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void wino_dgrad_output_kernel(const float4*
     typedef WinoMat<6, 3> WM;
     constexpr int RW = (M * M * VEC + 31) / 32;
     const int th = (H + M - 1) / M, tw = (W + M - 1) / M;
-    const TileIdx ti = tile_index(th, tw, C4);
+    const TileIdx ti = tile_index(th, tw, C4, N);
     if (!ti.ok) return;
     const long long o = ti.t * C4 + ti.c;
     unsigned rb[RW];
@@ -657,11 +701,12 @@ bool launch_wino_input_dout(int tile, const float* dy, float* v, float* dm, int 
 #undef FCN8S_WFUSE
     return true;
 }
-void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, int KS, hipStream_t s)
+void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, int KS, hipStream_t s, unsigned* rbits_out)
 {
+    if (KS != 3) rbits_out = nullptr;
     const int nsub = wino_nsub(KS), pad = (KS - 1) / 2, n2 = nsub * nsub;
 #define FCN8S_WIN(M_, V_, R_) hipLaunchKernelGGL((wino_input_kernel<M_, V_, R_>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / V_, n2), dim3(256), 0, s, \
-        (const VecF<V_>*)x, (VecF<V_>*)v, N, H, W, C / V_, pad, nsub, wino_slab((long long)N * ((H + M_ - 1) / M_) * ((W + M_ - 1) / M_), C * n2) / V_)
+        (const VecF<V_>*)x, (VecF<V_>*)v, N, H, W, C / V_, pad, nsub, wino_slab((long long)N * ((H + M_ - 1) / M_) * ((W + M_ - 1) / M_), C * n2) / V_, rbits_out)
     if (tile == 6)                    FCN8S_WIN(6, 2, 3);
     else if (tile == 4 && wino_r(KS) == 4) FCN8S_WIN(4, 2, 4);
     else if (tile == 4)               FCN8S_WIN(4, 2, 3);
