@@ -86,6 +86,7 @@ struct fcn8s_model {
     int gcur = 0;
     void* d_images = nullptr; uint8_t* d_labels = nullptr;
     float *d_loss = nullptr, *d_regsum = nullptr, *d_softmax = nullptr;
+    float* h_loss = nullptr; hipEvent_t loss_ev = nullptr; bool loss_copied = false;   // pinned copy of d_loss, queued right after the loss kernels
     float* d_lastbias = nullptr;       // column sums of dlogits (gradient of the last transposed conv's bias), produced by the loss kernel
     double* d_partials = nullptr; long long* d_pred = nullptr;
     unsigned long long* d_conf = nullptr;
@@ -840,6 +841,11 @@ int compute_loss(fcn8s_model* m, const uint8_t* lab_dev, float l2_rate, bool wit
         reg = m->d_regsum;
     }
     launch_finalize_loss(m->d_partials, nb, npix, reg, l2_rate, m->d_loss, s);
+    // The loss is final here, a third of the way into a training step: queue its copy now, so that fcn8s_read_loss waits for this
+    // point of the stream only and the host can go on queueing the next step while the backward pass runs (the reference fetches
+    // the loss every step, fcn8s_tensorflow.py:554-578; waiting for the whole stream left the GPU idle for ~2 ms per step).
+    m->loss_copied = m->h_loss && m->loss_ev && hipMemcpyAsync(m->h_loss, m->d_loss, sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess &&
+                     hipEventRecord(m->loss_ev, s) == hipSuccess;
     m->l2_rate = l2_rate; m->have_loss = true;
     return FCN8S_OK;
 }
@@ -1087,6 +1093,8 @@ int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
     }
     hipMemset(m->d_conf, 0, cc * sizeof(unsigned long long));
     hipMemset(m->d_loss, 0, 2 * sizeof(float));
+    if (hipHostMalloc((void**)&m->h_loss, 64, hipHostMallocDefault) != hipSuccess) { m->h_loss = nullptr; (void)hipGetLastError(); }
+    if (hipEventCreateWithFlags(&m->loss_ev, hipEventDisableTiming) != hipSuccess) { m->loss_ev = nullptr; (void)hipGetLastError(); }
     *out = m;
     return FCN8S_OK;
 }
@@ -1108,6 +1116,8 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->d_abf16) hipFree(m->d_abf16);
     for (int i = 0; i < 3; ++i) if (m->d_tph[i]) hipFree(m->d_tph[i]);
     if (m->d_loss) hipFree(m->d_loss);
+    if (m->h_loss) hipHostFree(m->h_loss);
+    if (m->loss_ev) hipEventDestroy(m->loss_ev);
     if (m->d_conf) hipFree(m->d_conf);
     if (m->d_fp) hipFree(m->d_fp);
     if (m->tg_b2) hipFree(m->tg_b2);
@@ -1277,6 +1287,11 @@ int fcn8s_apply_update(fcn8s_model* m, int optimizer, float lr, float grad_scale
 int fcn8s_read_loss(fcn8s_model* m, float* loss_out)
 {
     if (!m || !loss_out) return FCN8S_ERR_BAD_ARG;
+    if (m->loss_copied) {
+        HIPCHK(m, hipEventSynchronize(m->loss_ev));
+        *loss_out = *m->h_loss;
+        return FCN8S_OK;
+    }
     HIPCHK(m, hipMemcpyAsync(loss_out, m->d_loss, sizeof(float), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     return FCN8S_OK;
