@@ -536,8 +536,15 @@ __global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void ge
                 for (int j = 0; j < 4; ++j) {
                     const int row = j * 8 + (lane >> 3);
                     float4 v = *reinterpret_cast<const float4*>(&patch[row * LDT + (lane & 7) * 4]);
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;           // (the only epilogue op this path knows: a per-column bias)
-                    if (mrow + row < p.M) *reinterpret_cast<float4*>(yb + (mrow + row) * p.ldy) = v;
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;           // (the epilogue ops this path knows: a per-column bias, or a ReLU/dropout mask)
+                    if (mrow + row < p.M) {
+                        if (p.mask) {
+                            const float4 mk = ldg4(p.mask + (mrow + row) * p.ldy + n0 + wn * TN * 32 + tn * 32 + (lane & 7) * 4);
+                            v.x = mk.x > 0.f ? v.x * p.mask_scale : 0.f; v.y = mk.y > 0.f ? v.y * p.mask_scale : 0.f;
+                            v.z = mk.z > 0.f ? v.z * p.mask_scale : 0.f; v.w = mk.w > 0.f ? v.w * p.mask_scale : 0.f;
+                        }
+                        *reinterpret_cast<float4*>(yb + (mrow + row) * p.ldy) = v;
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -718,7 +725,9 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
             // (the kernel symbols as rocprofv3 prints them, so that bench.py can look the PMC traffic of the dominant kernel up by name)
             static const std::string gbase = "gemm_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3, ";
             static const std::string gt[2] = {gbase + "false>", gbase + "true>"};
-            const bool epi = mode != 3 && !bias_only;
+            // ... or nothing but a mask (the fc7 data gradient: ReLU + dropout of fc6)
+            const bool mask_only = fast && a.mask && !a.bias && !a.addend && !a.relu && !a.dropout && a.alpha == 1.f && a.ldy % 4 == 0 && a.Cout % 4 == 0 && grid.y == 1;
+            const bool epi = mode != 3 && !bias_only && !mask_only;
             g_last_kernel = gt[epi ? 1 : 0].c_str();
             if (epi) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, 3, true>), grid, dim3(256), 0, s, a);
             else     hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(256), 0, s, a);
