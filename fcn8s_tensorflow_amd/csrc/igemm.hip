@@ -635,16 +635,17 @@ __global__ __launch_bounds__(256, 4) void conv1_glds_kernel(const Conv1Args p)
         const float* sb = sa + BM * BK;
 #pragma unroll
         for (int kk2 = 0; kk2 < BK / 8; ++kk2) {
-            float4 af[TM]; float bf[4];
+            if (kt == NKT - 1 && kk2 == 1) continue;        // taps 10, 11: padding (all-zero rows of w48)
+            float4 af[TM]; float bf[3];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) af[tm] = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((kk2 * 2 + (lane >> 5)) ^ a_sw[tm]) * 4));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = sb[b_off + (kk2 * 8 + j) * BN];
+            for (int j = 0; j < 3; ++j) bf[j] = sb[b_off + (kk2 * 8 + j) * BN];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 3; ++j)                     // (the fourth channel of every tap is the zero pad of the 4-channel image: 15 MFMA steps instead of 24)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
-                    const float av = j == 0 ? af[tm].x : j == 1 ? af[tm].y : j == 2 ? af[tm].z : af[tm].w;
+                    const float av = j == 0 ? af[tm].x : j == 1 ? af[tm].y : af[tm].z;
                     acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[j], acc[tm][0], 0, 0, 0);
                 }
         }
@@ -1207,7 +1208,10 @@ bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, 
 {
     if (Cout != 64 || W % 64) return false;
     Conv1WgradArgs a{(const float4*)X4, dZ, dW, db, N, H, W, (long long)N * H * (W / 64), 0};
-    long long blocks = a.nseg < 2048 ? a.nseg : 2048;
+    // 512 blocks: every block ends in 1792 atomics on the same addresses, and those serialise (2048 blocks: 0.67 ms, 512: 0.60 ms;
+    // a register-staged prefetch of the next segment needed 256 VGPRs and was slower)
+    static const int maxb = [] { const char* e = getenv("FCN8S_CONV1_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+    long long blocks = a.nseg < maxb ? a.nseg : maxb;
     a.segs_per_block = (int)((a.nseg + blocks - 1) / blocks);
     blocks = (a.nseg + a.segs_per_block - 1) / a.segs_per_block;
     g_last_kernel = "conv1_wgrad_kernel";
