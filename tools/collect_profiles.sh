@@ -22,4 +22,5 @@ python bench.py --steps 10 --warmup 3 --height 1024 --width 2048 --batch 4 --no-
 python bench.py --mode e2e --steps 10 --warmup 3 --workers 32 > $OUT/bench_e2e_train_bs16.json 2>> $OUT/bench.err
 python bench.py --gpus 2 --backend gloo --device 0 --steps 5 --warmup 2 --batch 8 --no-cpu-baseline > $OUT/bench_2ranks_one_gpu_gloo.json 2>> $OUT/bench.err
 python tools/layer_bench.py > $OUT/layer_bench.txt 2>> $OUT/bench.err
+python tools/layer_bench.py --infer --batch 1 --steps 10 > $OUT/layer_bench_infer_bs1.txt 2>> $OUT/bench.err
 cat $OUT/bench_train_bs16.json

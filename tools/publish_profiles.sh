@@ -22,4 +22,5 @@ for f in bench_c5_2048x1024_bs4_bf16_fc bench_c5_2048x1024_bs4_fp32 bench_e2e_tr
     [ -f $SRC/$f.json ] && cp $SRC/$f.json $DST/${R}_$f.json
 done
 [ -f $SRC/layer_bench.txt ] && cp $SRC/layer_bench.txt $DST/${R}_layer_bench.txt
+[ -f $SRC/layer_bench_infer_bs1.txt ] && cp $SRC/layer_bench_infer_bs1.txt $DST/${R}_layer_bench_infer_bs1.txt
 echo "published $TAG as $R"
