@@ -746,15 +746,16 @@ void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s)
     // largest tile that still yields about one block per CU (small batches / deep layers have few pixels:
     // 1024x512 bs1 gives conv5 only 2048 pixels = 64 tiles of 128x128 on 256 CUs)
     auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn) * phases; };
+    static const long long minb = [] { const char* e = getenv("FCN8S_GEMM_MIN_BLOCKS"); return e ? atoll(e) : 200LL; }();
     if (a.Cout <= 32)      launch_igemm_cfg<128, 32, 4, 1>(a, phases, s);
     else if (a.Cout <= 64) {
-        if (blocks(128, 64) >= 200) launch_igemm_cfg<128, 64, 2, 2>(a, phases, s);
+        if (blocks(128, 64) >= minb) launch_igemm_cfg<128, 64, 2, 2>(a, phases, s);
         else                        launch_igemm_cfg<64, 64, 2, 2>(a, phases, s);
     } else {
         // (at most 64 rows -- fc6 at batch 1 has 32 tiles per Winograd position: a 128-row tile would spend 3/4 of its MFMAs on padding)
-        if (a.M <= 64 && blocks(64, 128) >= 200) launch_igemm_cfg<64, 128, 2, 2>(a, phases, s);
-        else if (blocks(128, 128) >= 200) launch_igemm_cfg<128, 128, 2, 2>(a, phases, s);   // (K-tile depth 32 and 256x64 tiles measured slower: fewer resident waves)
-        else if (blocks(64, 128) >= 200) launch_igemm_cfg<64, 128, 2, 2>(a, phases, s);
+        if (a.M <= 64 && blocks(64, 128) >= minb) launch_igemm_cfg<64, 128, 2, 2>(a, phases, s);
+        else if (blocks(128, 128) >= minb) launch_igemm_cfg<128, 128, 2, 2>(a, phases, s);   // (K-tile depth 32 and 256x64 tiles measured slower: fewer resident waves)
+        else if (blocks(64, 128) >= minb) launch_igemm_cfg<64, 128, 2, 2>(a, phases, s);
         else                             launch_igemm_cfg<64, 64, 2, 2>(a, phases, s);
     }
 }
