@@ -6,6 +6,7 @@
 //   REG  : global -> VGPR -> LDS (padded A rows), 2 LDS buffers, loads issued mid-tile, one __syncthreads per K-tile (round-1 kernel)
 //   GLDS : global_load_lds_dwordx4 straight into an XOR-swizzled LDS image (no VGPR staging, no ds_write), S stages, counted vmcnt,
 //          raw s_barrier: S-2 K-tiles stay in flight across the barrier
+//   persist (./gemm_lab persist): GLDS with a block walking a range of output tiles, pipeline kept full across tile boundaries
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -181,6 +182,151 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
             }
             __builtin_amdgcn_wave_barrier();
         }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent GLDS kernel: a block walks a contiguous range of output tiles; the (tile, K-tile) pairs form one flattened
+// sequence, so the LDS-DMA pipeline never drains at a tile boundary (the first K-tiles of the next tile are in flight while the
+// last ones of this tile are multiplied).  Epilogue = direct dword stores from the accumulators (two full 128-byte lines per
+// instruction); stores and loads complete out of order with respect to each other on gfx9, so the wait that follows an
+// epilogue is vmcnt(0).
+// ------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int S, int OCC>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds_persist(const Args p, const int P, const int tiles_per_block)
+{
+    constexpr int BK = 16, NW = WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int CH = 4, RPI = 16;
+    constexpr int A_PW = BM / RPI / NW, B_PW = BK * BN / 256 / NW;
+    constexpr int L = A_PW + B_PW;
+    constexpr int STAGE = BM * BK + BK * BN;
+    __shared__ __attribute__((aligned(16))) float smem[S * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const unsigned ntn = (unsigned)(p.N / BN), ntm = (unsigned)((p.T + BM - 1) / BM);
+    const unsigned per_pos = ntn * ntm;
+    const long long total = (long long)per_pos * P;
+    const unsigned r = xcd_swizzle(blockIdx.x, gridDim.x);          // consecutive ranges on one XCD
+    const long long t_begin = (long long)r * tiles_per_block;
+    long long t_end = t_begin + tiles_per_block; if (t_end > total) t_end = total;
+    if (t_begin >= t_end) return;
+    const int nkt = p.K / BK;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+
+    // ---- load side: tile whose K-tiles are being issued
+    const float* a_base = nullptr; const float* b_base = nullptr;
+    unsigned a_voff[A_PW], b_voff[B_PW];
+#pragma unroll
+    for (int i = 0; i < B_PW; ++i) {
+        const int f = (wave * B_PW + i) * 64 + lane;
+        const int k = f / (BN / 4), j = (f % (BN / 4)) * 4;
+        b_voff[i] = (unsigned)(k * p.N + j) * 4u;
+    }
+    auto set_load_tile = [&](long long t) {
+        const int z = (int)(t / per_pos); const unsigned lid = (unsigned)(t - (long long)z * per_pos);
+        const long long m0 = (long long)(lid / ntn) * BM; const int n0 = (int)(lid % ntn) * BN;
+        a_base = p.A + z * p.sa + m0 * p.K;
+        b_base = p.B + z * p.sb + n0;
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) {
+            const int row = (wave * A_PW + i) * RPI + lane / CH, pc = lane % CH;
+            const int c = pc ^ ((row >> 2) & 3);
+            long long m = m0 + row; if (m >= p.T) m = p.T - 1;
+            a_voff[i] = (unsigned)((m - m0) * p.K + c * 4) * 4u;
+        }
+    };
+    auto issue = [&](int kt, int stage) {
+        const float* ga = a_base + (long long)kt * BK;
+        const float* gb = b_base + (long long)kt * BK * p.N;
+        const unsigned la = lds0 + (unsigned)(stage * STAGE + wave * A_PW * 256) * 4u;
+        const unsigned lb = lds0 + (unsigned)(stage * STAGE + BM * BK + wave * B_PW * 256) * 4u;
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) glds16(ga, a_voff[i], la + i * 1024);
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) glds16(gb, b_voff[i], lb + i * 1024);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    int a_off[TM], a_sw[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int row = wm * TM * 32 + tm * 32 + (lane & 31);
+        a_off[tm] = row * BK; a_sw[tm] = (row >> 2) & 3;
+    }
+    const int b_off = ((lane >> 5) * 4) * BN + wn * TN * 32 + (lane & 31);
+    auto compute = [&](int stage) {
+        const float* sa = smem + stage * STAGE;
+        const float* sb = sa + BM * BK;
+#pragma unroll
+        for (int kk2 = 0; kk2 < BK / 8; ++kk2) {
+            float4 af[TM]; float bf[TN][4];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) af[tm] = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((kk2 * 2 + (lane >> 5)) ^ a_sw[tm]) * 4));
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[tn][j] = sb[b_off + (kk2 * 8 + j) * BN + tn * 32];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const float av = j == 0 ? af[tm].x : j == 1 ? af[tm].y : j == 2 ? af[tm].z : af[tm].w;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[tn][j], acc[tm][tn], 0, 0, 0);
+                }
+        }
+    };
+
+    // nkt >= S - 1 (checked by the launcher).  Per tile: the main part issues this tile's remaining K-tiles, the last S - 1
+    // iterations issue the first S - 1 K-tiles of the next tile.
+    set_load_tile(t_begin);
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t) issue(t, t);
+    int stage = 0, pre = S - 1;
+    for (long long tc = t_begin; tc < t_end; ++tc) {
+        const int nmain = nkt - (S - 1);
+        for (int kt = 0; kt < nmain; ++kt) {
+            if (kt == 0 && tc != t_begin) wait_vm<0>(); else wait_vm<(S - 2) * L>();     // (after an epilogue: its stores complete out of order with the loads)
+            __builtin_amdgcn_s_barrier();
+            if (!p.noload) issue(kt + S - 1, pre);
+            compute(stage);
+            stage = stage + 1 == S ? 0 : stage + 1;
+            pre = pre + 1 == S ? 0 : pre + 1;
+        }
+        const bool more = tc + 1 < t_end;
+        if (more) set_load_tile(tc + 1);
+#pragma unroll
+        for (int j = 0; j < S - 1; ++j) {
+            if (more) { if (nmain == 0 && j == 0 && tc != t_begin) wait_vm<0>(); else wait_vm<(S - 2) * L>(); }
+            else { if (j + S - 2 < S - 1 && !(nmain == 0 && j == 0 && tc != t_begin)) wait_vm<(S - 2) * L>(); else wait_vm<0>(); }
+            __builtin_amdgcn_s_barrier();
+            if (more && !p.noload) issue(j, pre);
+            compute(stage);
+            stage = stage + 1 == S ? 0 : stage + 1;
+            pre = pre + 1 == S ? 0 : pre + 1;
+        }
+        {
+            const int z = (int)(tc / per_pos); const unsigned lid = (unsigned)(tc - (long long)z * per_pos);
+            const long long m0 = (long long)(lid / ntn) * BM; const int n0 = (int)(lid % ntn) * BN;
+            float* C = p.C + z * p.sc;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int q2 = 0; q2 < 16; ++q2) {
+                        const long long m = m0 + wm * TM * 32 + tm * 32 + (q2 & 3) + 8 * (q2 >> 2) + 4 * (lane >> 5);
+                        if (m < p.T) C[m * p.N + n0 + wn * TN * 32 + tn * 32 + (lane & 31)] = acc[tm][tn][q2];
+                        acc[tm][tn][q2] = 0.f;
+                    }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -392,6 +538,29 @@ int main(int argc, char** argv)
     hipLaunchKernelGGL(fill, dim3(8192), dim3(256), 0, 0, dB, capB, 7u);
     hipDeviceSynchronize();
     if (argc > 1 && std::string(argv[1]) == "corun") { corun_probe(); return 0; }
+    if (argc > 1 && std::string(argv[1]) == "persist") {
+        const Shape more[] = {{"conv3", 15136, 256, 256, 64}, {"conv4", 3872, 512, 512, 64}, {"conv5", 1056, 512, 512, 64}, {"conv2_2", 58996, 128, 128, 64}, {"fc6", 512, 2048, 4096, 49}};
+        auto persist = [&](int occ_blocks) {
+            return [=](dim3 g, const Args& a) {
+                const long long total = (long long)g.x * g.z;
+                long long nb = 256LL * occ_blocks; if (nb > total) nb = total;
+                const int tpb = (int)((total + nb - 1) / nb);
+                nb = (total + tpb - 1) / tpb;
+                hipLaunchKernelGGL((gemm_glds_persist<128, 128, 2, 2, 3, 3>), dim3((unsigned)nb), dim3(256), 0, 0, a, (int)g.z, tpb);
+            };
+        };
+        const Shape chk{"check", 300, 128, 256, 3}, chk2{"check2", 300, 32, 512, 2};
+        run("persist 128x128 s3 x3", persist(3), 128, 128, chk, true); run("persist 128x128 s3 x3", persist(3), 128, 128, chk2, true);
+        for (int rep = 0; rep < 2; ++rep)
+            for (auto& s : more) {
+                printf("%s: T=%lld K=%d N=%d P=%d\n", s.name, s.T, s.K, s.N, s.P);
+                run("glds 128x128 bk16 s3 occ3", GLDS(128, 128, 2, 2, 16, 3, 3), 128, 128, s, false);
+                run("persist x3 (768 blocks)", persist(3), 128, 128, s, false);
+                run("persist x6 (1536 blocks)", persist(6), 128, 128, s, false);
+                run("persist x12", persist(12), 128, 128, s, false);
+            }
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "bi") {
         // correctness: B filled so that the interleaved reading of the SAME buffer is a valid matrix; compare BI kernel on buffer X with the
         // plain kernel on the de-interleaved copy
