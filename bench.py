@@ -29,6 +29,7 @@ FWD_GFLOP_PER_IMG_512x1024 = 445.04
 TRAIN_GFLOP_PER_IMG_512x1024 = 1333.3
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0           # dense bf16 MFMA peak (same guide); the f32x3 mode's roof is a sixth of it
 
 
 def pmc_traffic(kernel):
@@ -231,7 +232,7 @@ def main():
     ap.add_argument("--optimizer", default="sgd", choices=["adam", "sgd"],
                     help="sgd = SGD+momentum as BASELINE.json config 3 names; adam = TF-Adam, the reference's own optimizer "
                          "(fcn8s_tensorflow.py:256) -- same step time to within 0.1 percent")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc", "f32x3"],
                     help="fp32 = the reference's arithmetic (the headline number); bf16_fc = BASELINE config 5's mode (forward "
                          "fc6/fc7 with bf16 operands on the bf16 MFMA, fp32 accumulate) -- reported as dtype 'bf16_fc+f32'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -371,8 +372,10 @@ def main():
             g = kern[dom]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
             tr = pmc_traffic(dom)
-            roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            # f32x3 mode: six bf16 MFMA products per fp32-equivalent multiply-add -> peak = bf16 dense peak / 6
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if args.precision == "f32x3" and "_x3_" in dom else PEAK_F32_MFMA_TFLOPS
+            roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     # HBM-side bytes per launch from the PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE); compare with
                     # algorithmic_mb_per_launch * 1e6.  Details (and the uncorrected lower bound) in traffic_detail.
                     "traffic": (round(tr["hbm_mb_per_launch"] * 1e6) if tr else None), "traffic_unit": "bytes/launch", "traffic_detail": tr,
@@ -395,7 +398,7 @@ def main():
             "metric": "training images/sec at 1024x512 bs16" if args.mode == "train" else "inference images/sec at 1024x512",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16_fc+f32", "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16_fc": "bf16_fc+f32", "f32x3": "f32x3 (fp32 operands as three bf16 pieces on the bf16 MFMA, fp32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {"workload": "FCN-8s (VGG-16, fc6 7x7, 20 classes) %s step, %dx%d, %d images/GPU, %s, keep_prob 0.5"
                                    % (args.mode, W, H, N, "TF-Adam" if args.optimizer == "adam" else "SGD+momentum"),
                        "global_batch": N * world, "parallelism": "dp%d" % world},

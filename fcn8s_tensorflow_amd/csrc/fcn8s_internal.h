@@ -130,6 +130,7 @@ void launch_unblock_logits(const float* blocked, float* nhwc, const PixMap& map,
 void launch_onehot_to_ids(const void* oh, int elem_bytes, long long npix, int C, uint8_t* ids, int* bad, hipStream_t s);
 void launch_confusion(const uint8_t* labels, const long long* pred, long long npix,
                       unsigned long long* conf, int C, hipStream_t s);
+void set_mfma_split(int nsplit);      // igemm.hip: 3 = the LDS-DMA GEMM kernels run in f32x3 mode (fp32 operands split into three bf16 pieces), 0 = f32 MFMA
 // skinny.hip: 1x1 convs with <= 32 output (forward, weight gradient) or input (data gradient) channels; false = shape not covered
 bool launch_head_fwd(const float* x, const float* w, const float* bias, float* y, long long M, int K, int C, float alpha, hipStream_t s);
 bool launch_head_dgrad(const float* dy, const float* wt, const float* mask, float mask_scale, float* dx, long long M, int K, int C, float alpha,

@@ -393,8 +393,45 @@ static __device__ __forceinline__ void glds16(const float* sbase, unsigned voff,
 }
 template <int N> static __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// ---- f32x3: fp32-accurate products on the bf16 matrix pipe (optional precision mode FCN8S_PREC_F32X3) --------------------------
+// Every fp32 operand x is split exactly into three bf16 pieces x = hi + mid + lo (each residual is representable, so the split has
+// no error) and a*b is taken as hi*hi + hi*mid + mid*hi + hi*lo + mid*mid + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation; the three dropped terms are below 2^-23 |a b|, i.e. below the rounding of one fp32 multiply.  Against a float64
+// reference the result is as close as the f32 MFMA's (tools/gemm_lab.hip x3: max error 6.4e-6 vs 7.5e-6 on K = 128).  Six bf16 MFMAs
+// (32 cycles, K = 16) replace eight f32 MFMAs (64 cycles, K = 2): 2.7x less matrix-pipe time, of which the ~190 VALU instructions
+// of the split take half back -- VALU and MFMA issue did not overlap in any arrangement tried (interleaved by hand or by
+// sched_group_barrier, or software-pipelined over K-tiles): 155-170 "TFLOP/s" against 122-136.  Not the default: the headline
+// number is measured on the exact f32 MFMA.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+static int g_mfma_split = [] { const char* e = getenv("FCN8S_F32X3"); return e && atoi(e) ? 3 : 0; }();     // (the environment switch serves the op-level entry points, which have no model)
+void set_mfma_split(int nsplit) { g_mfma_split = nsplit == 3 ? 3 : 0; }
+static __device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo)
+{
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { hi[i] = (__bf16)x[i]; r[i] = x[i] - (float)hi[i]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { mid[i] = (__bf16)r[i]; r[i] = r[i] - (float)mid[i]; lo[i] = (__bf16)r[i]; }
+}
+static __device__ __forceinline__ f32x16 mfma_x3(const bf16x8& ah, const bf16x8& am, const bf16x8& al, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl, f32x16 acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);          // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN, int S, bool EPI, int NSPLIT>
+static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p);
+// (two entry points instead of one more template parameter, so that the f32 kernels keep the symbols the profiles are keyed by)
 template <int BM, int BN, int WM, int WN, int S, bool EPI>
-__global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void gemm_glds_kernel(const IgemmArgs p)
+__global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void gemm_glds_kernel(const IgemmArgs p) { gemm_glds_body<BM, BN, WM, WN, S, EPI, 0>(p); }
+template <int BM, int BN, int WM, int WN, int S, bool EPI>
+__global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void gemm_glds_x3_kernel(const IgemmArgs p) { gemm_glds_body<BM, BN, WM, WN, S, EPI, 3>(p); }
+template <int BM, int BN, int WM, int WN, int S, bool EPI, int NSPLIT>
+static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p)
 {
     constexpr int BK = 16, CH = 4, RPI = 16;             // 16-byte chunks per A row; A rows per wave-instruction (1 KiB)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -468,6 +505,28 @@ __global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void ge
     auto compute = [&](int stage) {
         const float* sa = smem + stage * STAGE;
         const float* sb = sa + BM * BK;
+        if constexpr (NSPLIT == 3) {                   // one K = 16 step of the bf16 MFMA per K-tile: lane half h holds k = 8h .. 8h + 7
+            bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const float4 u = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((2 * (lane >> 5)) ^ a_sw[tm]) * 4));
+                const float4 v = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((2 * (lane >> 5) + 1) ^ a_sw[tm]) * 4));
+                const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+                split3_bf16(x, ah[tm], am[tm], al[tm]);
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = sb[((lane >> 5) * 8 + j) * BN + wn * TN * 32 + tn * 32 + (lane & 31)];
+                split3_bf16(x, bh[tn], bm[tn], bl[tn]);
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_x3(ah[tm], am[tm], al[tm], bh[tn], bm[tn], bl[tn], acc[tm][tn]);
+            return;
+        }
 #pragma unroll
         for (int kk2 = 0; kk2 < BK / 8; ++kk2) {       // (loading all fragments of the K-tile ahead of its MFMAs measured 7 % slower here)
             float4 af[TM];
@@ -725,11 +784,17 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
         if (glds_enabled() && rows1x1 && (mode == 3 || grid.y == 1) && (long long)(BM - 1) * a.ldx < (1LL << 29) && (long long)16 * a.Cout < (1LL << 29)) {
             // (the kernel symbols as rocprofv3 prints them, so that bench.py can look the PMC traffic of the dominant kernel up by name)
             static const std::string gbase = "gemm_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3, ";
-            static const std::string gt[2] = {gbase + "false>", gbase + "true>"};
+            static const std::string xbase = "gemm_glds_x3_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3, ";
+            static const std::string gt[4] = {gbase + "false>", gbase + "true>", xbase + "false>", xbase + "true>"};
             // ... or nothing but a mask (the fc7 data gradient: ReLU + dropout of fc6)
             const bool mask_only = fast && a.mask && !a.bias && !a.addend && !a.relu && !a.dropout && a.alpha == 1.f && a.ldy % 4 == 0 && a.Cout % 4 == 0 && grid.y == 1;
             const bool epi = mode != 3 && !bias_only && !mask_only;
-            g_last_kernel = gt[epi ? 1 : 0].c_str();
+            g_last_kernel = gt[(epi ? 1 : 0) + (g_mfma_split == 3 ? 2 : 0)].c_str();
+            if (g_mfma_split == 3) {
+                if (epi) hipLaunchKernelGGL((gemm_glds_x3_kernel<BM, BN, WM, WN, 3, true>), grid, dim3(256), 0, s, a);
+                else     hipLaunchKernelGGL((gemm_glds_x3_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(256), 0, s, a);
+                return;
+            }
             if (epi) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, 3, true>), grid, dim3(256), 0, s, a);
             else     hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(256), 0, s, a);
             return;
@@ -1331,8 +1396,14 @@ bool launch_tconv_wgrad(const float* X, const float* dY, float* dW, int N, int H
 // chunk's last, partial K-tile (rows % 16, only when the row count is not a multiple of 16) goes through registers with zero fill.
 // 1-D grid, XCD-aware: the (ci, co) tiles of one (position, row chunk) share their A / B row panels and are neighbours in the id
 // order, i.e. run behind the same L2 (the 3-D grid of wgrad_kernel deals them round-robin over all eight).
+template <int BM, int BN, int WM, int WN, int S, bool PRELOAD, int NSPLIT>
+static __device__ __forceinline__ void wgrad_glds_body(const WgradArgs& p, const int chunk, const int nsplit);
 template <int BM, int BN, int WM, int WN, int S, bool PRELOAD>
-__global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void wgrad_glds_kernel(const WgradArgs p, const int chunk, const int nsplit)
+__global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void wgrad_glds_kernel(const WgradArgs p, const int chunk, const int nsplit) { wgrad_glds_body<BM, BN, WM, WN, S, PRELOAD, 0>(p, chunk, nsplit); }
+template <int BM, int BN, int WM, int WN, int S>
+__global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void wgrad_glds_x3_kernel(const WgradArgs p, const int chunk, const int nsplit) { wgrad_glds_body<BM, BN, WM, WN, S, true, 3>(p, chunk, nsplit); }
+template <int BM, int BN, int WM, int WN, int S, bool PRELOAD, int NSPLIT>
+static __device__ __forceinline__ void wgrad_glds_body(const WgradArgs& p, const int chunk, const int nsplit)
 {
     constexpr int BK = 16;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -1391,6 +1462,30 @@ __global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void wg
     const int a_off = (lane >> 5) * BM + wm * TM * 32 + (lane & 31);
     const int b_off = (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
     auto compute = [&](int stage) {
+        if constexpr (NSPLIT == 3) {                   // f32x3 (see split3_bf16): lane half h holds rows k = 8h .. 8h + 7 of the K-tile
+            const float* sa3 = smem + stage * STAGE + (lane >> 5) * 8 * BM + wm * TM * 32 + (lane & 31);
+            const float* sb3 = smem + stage * STAGE + BK * BM + (lane >> 5) * 8 * BN + wn * TN * 32 + (lane & 31);
+            bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = sa3[j * BM + tm * 32];
+                split3_bf16(x, ah[tm], am[tm], al[tm]);
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = sb3[j * BN + tn * 32];
+                split3_bf16(x, bh[tn], bm[tn], bl[tn]);
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_x3(ah[tm], am[tm], al[tm], bh[tn], bm[tn], bl[tn], acc[tm][tn]);
+            return;
+        }
         const float* sa = smem + stage * STAGE + a_off;
         const float* sb = smem + stage * STAGE + BK * BM + b_off;
         // all fragments of the K-tile first (8 x (TM + TN) VGPRs), then the MFMAs back to back: with the reads interleaved one
@@ -1510,6 +1605,8 @@ static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
             static const std::string gbase = "wgrad_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3, ";
             static const std::string gtag[2] = {gbase + "false>", gbase + "true>"};
             g_last_kernel = gtag[preload ? 1 : 0].c_str();
+            if (g_mfma_split == 3) { static const std::string xtag = "wgrad_glds_x3_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>"; g_last_kernel = xtag.c_str();
+                                     hipLaunchKernelGGL((wgrad_glds_x3_kernel<BM, BN, WM, WN, 3>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits); return; }
             if (preload) hipLaunchKernelGGL((wgrad_glds_kernel<BM, BN, WM, WN, 3, true>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits);
             else         hipLaunchKernelGGL((wgrad_glds_kernel<BM, BN, WM, WN, 3, false>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits);
             return;

@@ -477,6 +477,7 @@ void tconv_wgrad(fcn8s_model* m, const float* x, const float* dy, float* dw, int
 // ---- workspace --------------------------------------------------------------------
 int ensure_workspace(fcn8s_model* m, int N, int H, int W)
 {
+    set_mfma_split(m->precision == FCN8S_PREC_F32X3 ? 3 : 0);     // (process-wide launcher switch: re-asserted at every model entry point)
     if (N <= 0) return fail(m, FCN8S_ERR_SHAPE, "batch size must be positive");
     if (H <= 0 || W <= 0 || H % 32 || W % 32)
         return fail(m, FCN8S_ERR_SHAPE, "image height and width must be positive multiples of 32 (five 2x2 pools, then x2, x2, x8 upsampling must line up with the skip connections)");
@@ -970,6 +971,7 @@ int do_backward_bucket(fcn8s_model* m, int bucket)
 {
     if (!m->have_loss || !m->train_mode) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: call fcn8s_forward_loss first");
     if (bucket != m->next_bucket) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: buckets must be run in order 0,1,2");
+    set_mfma_split(m->precision == FCN8S_PREC_F32X3 ? 3 : 0);
     if (bucket == 0) backward_bucket0(m);
     else if (bucket == 1) backward_blocks(m, 5, 4);
     else backward_blocks(m, 3, 1);
@@ -1158,7 +1160,7 @@ int fcn8s_freeze_params(fcn8s_model* m, int frozen)
 int fcn8s_set_precision(fcn8s_model* m, int precision)
 {
     if (!m) return FCN8S_ERR_BAD_ARG;
-    if (precision != FCN8S_PREC_F32 && precision != FCN8S_PREC_BF16_FC) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_precision: unknown precision");
+    if (precision != FCN8S_PREC_F32 && precision != FCN8S_PREC_BF16_FC && precision != FCN8S_PREC_F32X3) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_precision: unknown precision");
     if (precision == FCN8S_PREC_BF16_FC) {
         if (m->widths[4] % 32 || m->widths[5] % 128 || m->widths[6] % 128)
             return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_precision: BF16_FC needs conv5 width % 32 == 0 and fc6 / fc7 widths % 128 == 0");
@@ -1168,6 +1170,7 @@ int fcn8s_set_precision(fcn8s_model* m, int precision)
         }
     }
     m->precision = precision;
+    set_mfma_split(precision == FCN8S_PREC_F32X3 ? 3 : 0);
     return FCN8S_OK;
 }
 int fcn8s_get_precision(const fcn8s_model* m) { return m ? m->precision : -1; }

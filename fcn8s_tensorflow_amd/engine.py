@@ -352,11 +352,12 @@ class Engine:
         L.check(L.lib.fcn8s_freeze_params(self.h, 1 if frozen else 0), self.h)
 
     def set_precision(self, precision):
-        """'fp32' (the reference's arithmetic) or 'bf16_fc' (BASELINE config 5: forward fc6 / fc7 with bf16-rounded
-        operands on the bf16 MFMA, fp32 accumulation; the rest of the step stays fp32)."""
-        modes = {'fp32': L.PREC_F32, 'bf16_fc': L.PREC_BF16_FC}
+        """'fp32' (the reference's arithmetic), 'bf16_fc' (BASELINE config 5: forward fc6 / fc7 with bf16-rounded
+        operands on the bf16 MFMA, fp32 accumulation; the rest of the step stays fp32) or 'f32x3' (every large GEMM on the
+        bf16 MFMA with each fp32 operand split exactly into three bf16 pieces: fp32 accuracy, not bit-identical to fp32)."""
+        modes = {'fp32': L.PREC_F32, 'bf16_fc': L.PREC_BF16_FC, 'f32x3': L.PREC_F32X3}
         if precision not in modes:
-            raise ValueError("`precision` must be 'fp32' or 'bf16_fc', but is '{}'.".format(precision))
+            raise ValueError("`precision` must be 'fp32', 'bf16_fc' or 'f32x3', but is '{}'.".format(precision))
         L.check(L.lib.fcn8s_set_precision(self.h, modes[precision]), self.h)
         self.precision = precision
 

@@ -54,6 +54,10 @@ extern "C" {
 #define FCN8S_PREC_F32     0      /* everything exact fp32 (the reference's arithmetic; default) */
 #define FCN8S_PREC_BF16_FC 1      /* BASELINE.json config 5: the forward fc6 / fc7 contractions take bf16-rounded operands on the
                                      bf16 MFMA with fp32 accumulation; everything else, and the whole backward pass, stays fp32 */
+#define FCN8S_PREC_F32X3   2      /* fp32-accurate products on the bf16 MFMA: in every LDS-DMA GEMM (Winograd positions, fc6, fc7, the last
+                                     transposed conv; forward, data and weight gradients) each fp32 operand is split exactly into three
+                                     bf16 pieces and six of the nine piece products are accumulated in fp32 -- error below one fp32
+                                     rounding per product, not bit-identical to an fmaf chain; 1.25x faster GEMMs.  Not the default. */
 
 typedef struct fcn8s_model fcn8s_model;
 
@@ -165,7 +169,7 @@ int     fcn8s_set_opt_state(fcn8s_model* m, const float* host_m, const float* ho
  * pass unfreezes; whoever writes into an external parameter buffer (fcn8s_config.ext_params) must call this with 0 first. */
 int fcn8s_freeze_params(fcn8s_model* m, int frozen);
 
-/* Arithmetic of the forward fc6 / fc7 layers (FCN8S_PREC_*); not in the reference, which is fp32 throughout.
+/* Arithmetic mode (FCN8S_PREC_*); not in the reference, which is fp32 throughout.
  * BF16_FC needs fc6/fc7 widths that are multiples of 128 and a conv5 width that is a multiple of 32 (BAD_ARG otherwise). */
 int fcn8s_set_precision(fcn8s_model* m, int precision);
 int fcn8s_get_precision(const fcn8s_model* m);

@@ -267,3 +267,13 @@ def test_preprocess():
     o = out.cpu().numpy()
     np.testing.assert_allclose(o[..., :3], ref, rtol=0, atol=1e-5)
     assert (o[..., 3] == 0).all()
+
+
+def test_conv_ops_in_f32x3_mode_hold_the_fp32_tolerances():
+    """FCN8S_F32X3=1 routes every LDS-DMA GEMM of the op-level entry points through the split-bf16 kernels (the model-level switch
+    is fcn8s_set_precision): the convolution cases above must hold their fp32 tolerances (2e-5) unchanged."""
+    import os, subprocess, sys
+    env = dict(os.environ, FCN8S_F32X3="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "conv and not f32x3"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -16,6 +16,7 @@
 #include <string>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -39,7 +40,7 @@ template <int N> static __device__ __forceinline__ void wait_vm() { asm volatile
 // GLDS kernel
 // ------------------------------------------------------------------------------------------------------------------
 // BI: B stored k-interleaved in global memory, [K/4][N][4], so that the four k-steps a lane feeds from one column are one ds_read_b128
-template <int BM, int BN, int WM, int WN, int BK, int S, int OCC, bool BI = false>
+template <int BM, int BN, int WM, int WN, int BK, int S, int OCC, bool BI = false, int NSPLIT = 0, bool PIPE = false>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
 {
     constexpr int NW = WM * WN, NT = NW * 64;
@@ -116,7 +117,55 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
     }
     const int b_off = BI ? ((lane >> 5) * BN + wn * TN * 32 + (lane & 31)) * 4 : ((lane >> 5) * 4) * BN + wn * TN * 32 + (lane & 31);
 
+    // NSPLIT = 3: fp32-accurate products on the bf16 matrix pipe.  x = hi + mid + lo with three bf16 pieces (exact: each residual is
+    // representable), a b ~= hi hi + hi mid + mid hi + hi lo + mid mid + lo hi (the three dropped terms are < 2^-23 |a b|), fp32
+    // accumulation in the MFMA: six v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles
+    // each).  NSPLIT = 1: operands rounded to bf16 once (one MFMA).
+    auto split3 = [&](const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+        float r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { hi[i] = (__bf16)x[i]; r[i] = x[i] - (float)hi[i]; }
+        if (NSPLIT == 3) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { mid[i] = (__bf16)r[i]; r[i] = r[i] - (float)mid[i]; lo[i] = (__bf16)r[i]; }
+        }
+    };
+    auto compute_bf16 = [&](int stage) {
+        static_assert(NSPLIT == 0 || BK == 16, "one bf16 MFMA K-step per K-tile");
+        const float* sa = smem + stage * STAGE;
+        const float* sb = sa + BM * BK;
+        bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            float x[8];
+            const float4 u = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((2 * (lane >> 5)) ^ a_sw[tm]) * 4));
+            const float4 v = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((2 * (lane >> 5) + 1) ^ a_sw[tm]) * 4));
+            x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+            split3(x, ah[tm], am[tm], al[tm]);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = sb[((lane >> 5) * 8 + j) * BN + wn * TN * 32 + tn * 32 + (lane & 31)];
+            split3(x, bh[tn], bm[tn], bl[tn]);
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                if (NSPLIT == 3) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[tm], bm[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bm[tn], acc[tm][tn], 0, 0, 0);
+                }
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            }
+    };
     auto compute = [&](int stage) {
+        if (NSPLIT != 0) { compute_bf16(stage); return; }
         const float* sa = smem + stage * STAGE;
         const float* sb = sa + BM * BK;
 #pragma unroll
@@ -148,6 +197,67 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
     };
 
     const int nkt = p.K / BK;
+    if constexpr (PIPE && NSPLIT == 3) {
+        // software pipeline over K-tiles: the LDS reads + three-way split of tile kt (VALU) are interleaved with the 24 MFMAs of
+        // tile kt - 1 (matrix pipe); two register sets of split fragments
+        struct Frag { bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN]; };
+        auto load_split = [&](int stage, Frag& f) {
+            const float* sa = smem + stage * STAGE;
+            const float* sb = sa + BM * BK;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                float x[8];
+                const float4 u = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((2 * (lane >> 5)) ^ a_sw[tm]) * 4));
+                const float4 v = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((2 * (lane >> 5) + 1) ^ a_sw[tm]) * 4));
+                x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+                split3(x, f.ah[tm], f.am[tm], f.al[tm]);
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = sb[((lane >> 5) * 8 + j) * BN + wn * TN * 32 + tn * 32 + (lane & 31)];
+                split3(x, f.bh[tn], f.bm[tn], f.bl[tn]);
+            }
+        };
+        auto mfmas = [&](const Frag& f) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[tm], f.bh[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[tm], f.bl[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am[tm], f.bm[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am[tm], f.bh[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[tm], f.bm[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[tm], f.bh[tn], acc[tm][tn], 0, 0, 0);
+                }
+        };
+        auto interleave = [&]() {               // scheduling hint for the region since the last barrier: LDS reads first, then 1 MFMA : 8 VALU
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+            for (int i = 0; i < 6 * TM * TN; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); }
+        };
+        Frag f0, f1;
+#pragma unroll
+        for (int t = 0; t < S - 1; ++t)
+            if (t < nkt) issue(t, t);
+        int stage = 0, pre = S - 1;
+        auto head = [&](int kt) {               // wait for tile kt, refill the stage of tile kt - 1
+            if (kt + S - 2 < nkt) wait_vm<(S - 2) * L>(); else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + S - 1 < nkt && !p.noload) issue(kt + S - 1, pre);
+        };
+        auto adv = [&]() { stage = stage + 1 == S ? 0 : stage + 1; pre = pre + 1 == S ? 0 : pre + 1; };
+        head(0); load_split(stage, f0); adv();
+        int kt = 1;
+        for (; kt + 1 < nkt; kt += 2) {
+            head(kt); load_split(stage, f1); mfmas(f0); interleave(); adv();
+            head(kt + 1); load_split(stage, f0); mfmas(f1); interleave(); adv();
+        }
+        if (kt < nkt) { head(kt); load_split(stage, f1); mfmas(f0); interleave(); adv(); mfmas(f1); }
+        else mfmas(f0);
+    } else {
 #pragma unroll
     for (int t = 0; t < S - 1; ++t)
         if (t < nkt) issue(t, t);
@@ -159,6 +269,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
         compute(stage);
         stage = stage + 1 == S ? 0 : stage + 1;
         pre = pre + 1 == S ? 0 : pre + 1;
+    }
     }
     __builtin_amdgcn_s_barrier();
 
@@ -538,6 +649,27 @@ int main(int argc, char** argv)
     hipLaunchKernelGGL(fill, dim3(8192), dim3(256), 0, 0, dB, capB, 7u);
     hipDeviceSynchronize();
     if (argc > 1 && std::string(argv[1]) == "corun") { corun_probe(); return 0; }
+    if (argc > 1 && std::string(argv[1]) == "x3") {
+        const Shape more[] = {{"conv3", 15136, 256, 256, 64}, {"conv4", 3872, 512, 512, 64}, {"conv5", 1056, 512, 512, 64}, {"conv2_2", 58996, 128, 128, 64}, {"fc6", 512, 2048, 4096, 49}};
+        const Shape chk{"check", 300, 128, 256, 3}, chk2{"check2", 300, 32, 512, 2};
+#define GX(NS, OCC) [&](dim3 g, const Args& a) { hipLaunchKernelGGL((gemm_glds<128, 128, 2, 2, 16, 3, OCC, false, NS>), g, dim3(256), 0, 0, a); }
+#define GXP(OCC) [&](dim3 g, const Args& a) { hipLaunchKernelGGL((gemm_glds<128, 128, 2, 2, 16, 3, OCC, false, 3, true>), g, dim3(256), 0, 0, a); }
+        run("bf16 x3 pipelined", GXP(2), 128, 128, chk, true); run("bf16 x3 pipelined", GXP(2), 128, 128, chk2, true);
+        run("fp32 mfma", GLDS(128, 128, 2, 2, 16, 3, 3), 128, 128, chk, true);
+        run("bf16 x3", GX(3, 3), 128, 128, chk, true); run("bf16 x3", GX(3, 3), 128, 128, chk2, true);
+        run("bf16 x1", GX(1, 3), 128, 128, chk, true);
+        for (int rep = 0; rep < 2; ++rep)
+            for (auto& s : more) {
+                printf("%s: T=%lld K=%d N=%d P=%d\n", s.name, s.T, s.K, s.N, s.P);
+                run("fp32 mfma s3 occ3", GLDS(128, 128, 2, 2, 16, 3, 3), 128, 128, s, false);
+                run("bf16 x3 s3 occ3", GX(3, 3), 128, 128, s, false);
+                run("bf16 x3 s3 occ2", GX(3, 2), 128, 128, s, false);
+                run("bf16 x3 PIPELINED occ2", GXP(2), 128, 128, s, false);
+                run("bf16 x3 PIPELINED occ3", GXP(3), 128, 128, s, false);
+                run("bf16 x1 s3 occ3", GX(1, 3), 128, 128, s, false);
+            }
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "persist") {
         const Shape more[] = {{"conv3", 15136, 256, 256, 64}, {"conv4", 3872, 512, 512, 64}, {"conv5", 1056, 512, 512, 64}, {"conv2_2", 58996, 128, 128, 64}, {"fc6", 512, 2048, 4096, 49}};
         auto persist = [&](int occ_blocks) {
