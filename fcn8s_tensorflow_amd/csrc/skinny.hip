@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
     __shared__ float red[4][4 * 32 * C];                        // [wave][t][(i * 2 + h) * C + class]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31, h = lane >> 5;
-    // channel group = blockIdx.x (fastest): the blocks in flight together read whole rows of x; with the pixel range fastest they
-    // would all hit the same 512-byte window of every 4K-float row (a 16 KB stride -- a handful of HBM channels)
+    // channel group = blockIdx.x (fastest): the blocks in flight together read whole rows of x rather than the same 512-byte
+    // window of every row (measured: the same time either way)
     const int ch0 = blockIdx.x * 128;
     const int half = ppb / 8;                                   // pixels per (wave, lane half); a multiple of 8 (launcher)
     const long long p0 = (long long)blockIdx.y * ppb + (wave * 2 + h) * half;
