@@ -37,6 +37,7 @@ struct IgemmArgs {
     int dropout; float keep_prob; unsigned long long seed; unsigned int stream_id;
     int batched; long long x_batch_stride, y_batch_stride;   // gridDim.z independent GEMMs (Winograd positions)
     int m_fastest;                                           // tile order, set by the launcher (see igemm.hip)
+    int bt, ldw;                                             // bt: the B operand is stored transposed, w[z][n][k] with row stride ldw (plain batched GEMMs on the LDS-DMA kernel only)
 };
 void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s);
 
@@ -176,6 +177,7 @@ size_t wino_rbits_words(int tile, int N, int H, int W, int C);
 void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s, int KS = 3, const unsigned char* pidx = nullptr);   // dy -> dm[P][T][C] = A dY A^T  (tile 6 with pidx: dy is d(pool), routed through the argmax bytes)
 // F(6x6,3x3) data gradient as the adjoint of the forward algorithm: dv[P][T][C] = dM U^T -> dx = overlap-added B dv B^T (+ skip addend, ReLU mask)
 bool wino_dgrad_adjoint_enabled();
+void launch_wino_dgrad_output_sub44(const float* dv, float* dx, int N, int H, int W, int C, hipStream_t s);   // fc6: see winograd.hip
 void launch_wino_dgrad_output(const float* dv, const float* addend, const float* mask, float mask_scale, const unsigned* rbits_in, float* y,
                               int N, int H, int W, int C, hipStream_t s);
 void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, int KS, hipStream_t s);        // du[P][nsub*Cin][Cout] -> dw[KS*KS][Cin][Cout]

@@ -423,19 +423,26 @@ static __device__ __forceinline__ f32x16 mfma_x3(const bf16x8& ah, const bf16x8&
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int S, bool EPI, int NSPLIT>
+template <int BM, int BN, int WM, int WN, int S, bool EPI, int NSPLIT, bool BT = false>
 static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p);
 // (two entry points instead of one more template parameter, so that the f32 kernels keep the symbols the profiles are keyed by)
 template <int BM, int BN, int WM, int WN, int S, bool EPI>
 __global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void gemm_glds_kernel(const IgemmArgs p) { gemm_glds_body<BM, BN, WM, WN, S, EPI, 0>(p); }
 template <int BM, int BN, int WM, int WN, int S, bool EPI>
 __global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void gemm_glds_x3_kernel(const IgemmArgs p) { gemm_glds_body<BM, BN, WM, WN, S, EPI, 3>(p); }
-template <int BM, int BN, int WM, int WN, int S, bool EPI, int NSPLIT>
+// BT: B stored transposed (w[z][n][k], row stride p.ldw) -- the forward Winograd filter bank U[ci][co] read as the B operand of the
+// adjoint data gradient dV = dM U^T.  Its tile is then an image like A's ([BN rows][16 k], 64-byte rows, same XOR swizzle, same
+// 16-byte fragment reads), so no transposed copy of the bank is ever made.
+template <int BM, int BN, int WM, int WN, int S>
+__global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void gemm_glds_nt_kernel(const IgemmArgs p) { gemm_glds_body<BM, BN, WM, WN, S, false, 0, true>(p); }
+template <int BM, int BN, int WM, int WN, int S>
+__global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void gemm_glds_nt_x3_kernel(const IgemmArgs p) { gemm_glds_body<BM, BN, WM, WN, S, false, 3, true>(p); }
+template <int BM, int BN, int WM, int WN, int S, bool EPI, int NSPLIT, bool BT>
 static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p)
 {
     constexpr int BK = 16, CH = 4, RPI = 16;             // 16-byte chunks per A row; A rows per wave-instruction (1 KiB)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_PW = BM / RPI / 4, B_PW = BK * BN / 256 / 4;   // LDS-DMA instructions per wave and K-tile
+    constexpr int A_PW = BM / RPI / 4, B_PW = BT ? BN / RPI / 4 : BK * BN / 256 / 4;   // LDS-DMA instructions per wave and K-tile
     static_assert(WM * WN == 4 && A_PW >= 1 && B_PW >= 1, "tile / wave split");
     constexpr int L = A_PW + B_PW;
     constexpr int STAGE = BM * BK + BK * BN;             // floats per stage
@@ -464,20 +471,26 @@ static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p)
     }
 #pragma unroll
     for (int i = 0; i < B_PW; ++i) {
-        const int f = (wave * B_PW + i) * 64 + lane;
-        const int k = f / (BN / 4), j = (f % (BN / 4)) * 4;
-        b_voff[i] = (unsigned)(k * p.Cout + j) * 4u;
+        if (BT) {
+            const int row = (wave * B_PW + i) * RPI + lane / CH, pc = lane % CH;
+            const int c = pc ^ ((row >> 2) & 3);
+            b_voff[i] = (unsigned)(row * p.ldw + c * 4) * 4u;
+        } else {
+            const int f = (wave * B_PW + i) * 64 + lane;
+            const int k = f / (BN / 4), j = (f % (BN / 4)) * 4;
+            b_voff[i] = (unsigned)(k * p.Cout + j) * 4u;
+        }
     }
     // split-K (gridDim.y > 1, linear epilogue only): this block reduces K-tiles [kt0, kt0 + nkt)
     const int nkt_all = p.Ktot / BK;
     const int kt0 = (int)((long long)nkt_all * blockIdx.y / gridDim.y);
     const int nkt = (int)((long long)nkt_all * (blockIdx.y + 1) / gridDim.y) - kt0;
     const float* a_base = X + m0 * p.ldx + (long long)kt0 * BK;
-    const float* b_base = Wp + n0 + (long long)kt0 * BK * p.Cout;
+    const float* b_base = BT ? Wp + (long long)n0 * p.ldw + (long long)kt0 * BK : Wp + n0 + (long long)kt0 * BK * p.Cout;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
     auto issue = [&](int kt, int stage) {
         const float* ga = a_base + (long long)kt * BK;
-        const float* gb = b_base + (long long)kt * BK * p.Cout;
+        const float* gb = BT ? b_base + (long long)kt * BK : b_base + (long long)kt * BK * p.Cout;
         const unsigned la = lds0 + (unsigned)(stage * STAGE + wave * A_PW * 256) * 4u;
         const unsigned lb = lds0 + (unsigned)(stage * STAGE + BM * BK + wave * B_PW * 256) * 4u;
 #pragma unroll
@@ -502,6 +515,13 @@ static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p)
         a_sw[tm] = (row >> 2) & 3;
     }
     const int b_off = ((lane >> 5) * 4) * BN + wn * TN * 32 + (lane & 31);
+    int bt_off[TN], bt_sw[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int row = wn * TN * 32 + tn * 32 + (lane & 31);
+        bt_off[tn] = row * BK;
+        bt_sw[tn] = (row >> 2) & 3;
+    }
     auto compute = [&](int stage) {
         const float* sa = smem + stage * STAGE;
         const float* sb = sa + BM * BK;
@@ -517,8 +537,14 @@ static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 float x[8];
+                if (BT) {
+                    const float4 u = *reinterpret_cast<const float4*>(sb + bt_off[tn] + (((2 * (lane >> 5)) ^ bt_sw[tn]) * 4));
+                    const float4 v = *reinterpret_cast<const float4*>(sb + bt_off[tn] + (((2 * (lane >> 5) + 1) ^ bt_sw[tn]) * 4));
+                    x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = sb[((lane >> 5) * 8 + j) * BN + wn * TN * 32 + tn * 32 + (lane & 31)];
+                    for (int j = 0; j < 8; ++j) x[j] = sb[((lane >> 5) * 8 + j) * BN + wn * TN * 32 + tn * 32 + (lane & 31)];
+                }
                 split3_bf16(x, bh[tn], bm[tn], bl[tn]);
             }
 #pragma unroll
@@ -535,9 +561,15 @@ static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p)
             for (int tm = 0; tm < TM; ++tm)
                 af[tm] = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((kk2 * 2 + (lane >> 5)) ^ a_sw[tm]) * 4));
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
+            for (int tn = 0; tn < TN; ++tn) {
+                if (BT) {
+                    const float4 t = *reinterpret_cast<const float4*>(sb + bt_off[tn] + (((kk2 * 2 + (lane >> 5)) ^ bt_sw[tn]) * 4));
+                    bf[tn][0] = t.x; bf[tn][1] = t.y; bf[tn][2] = t.z; bf[tn][3] = t.w;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bf[tn][j] = sb[b_off + (kk2 * 8 + j) * BN + tn * 32];
+                    for (int j = 0; j < 4; ++j) bf[tn][j] = sb[b_off + (kk2 * 8 + j) * BN + tn * 32];
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -789,6 +821,15 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
             // ... or nothing but a mask (the fc7 data gradient: ReLU + dropout of fc6)
             const bool mask_only = fast && a.mask && !a.bias && !a.addend && !a.relu && !a.dropout && a.alpha == 1.f && a.ldy % 4 == 0 && a.Cout % 4 == 0 && grid.y == 1;
             const bool epi = mode != 3 && !bias_only && !mask_only;
+            if (a.bt) {                                         // transposed B: plain batched GEMMs only (the adjoint Winograd data gradient)
+                static const std::string nb = "gemm_glds_nt_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>";
+                static const std::string nbx = "gemm_glds_nt_x3_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>";
+                if (mode != 3 || (long long)(BN - 1) * a.ldw >= (1LL << 29)) { fprintf(stderr, "fcn8s: transposed-B GEMM needs the plain batched form\n"); abort(); }
+                g_last_kernel = (g_mfma_split == 3 ? nbx : nb).c_str();
+                if (g_mfma_split == 3) hipLaunchKernelGGL((gemm_glds_nt_x3_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, s, a);
+                else                   hipLaunchKernelGGL((gemm_glds_nt_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, s, a);
+                return;
+            }
             g_last_kernel = gt[(epi ? 1 : 0) + (g_mfma_split == 3 ? 2 : 0)].c_str();
             if (g_mfma_split == 3) {
                 if (epi) hipLaunchKernelGGL((gemm_glds_x3_kernel<BM, BN, WM, WN, 3, true>), grid, dim3(256), 0, s, a);

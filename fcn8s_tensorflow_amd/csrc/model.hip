@@ -65,6 +65,9 @@ struct fcn8s_model {
     bool frozen = false;
     unsigned long long frozen_fp = 0; unsigned long long* d_fp = nullptr;   // fingerprint of the parameter buffer the cached banks were built from
     std::map<std::string, float*> u_cache;                               // layer -> transformed filter bank (hipMalloc'ed), valid while frozen
+    std::map<std::string, float*> u_train;                               // layer -> forward filter bank of the current training step: the adjoint data
+                                                                         // gradient reads it as a transposed B operand (no second, transposed bank)
+    bool fwd_train = false;                                              // forward() is running a training pass
     std::set<std::string> rbits_ok;                                       // layers whose forward pass wrote a ReLU bit mask ("rb:<layer>") this step
     std::string fused_v_layer;                                            // layer whose data-gradient input transform already sits in d_wino_v
     std::string dm_layer;                                                 // layer whose dM = A dY A^T sits in d_wino_m, ready for the adjoint data gradient
@@ -229,6 +232,9 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
 // Output tile of the Winograd path for a K x K SAME conv on an H x W map (0 = none).  K = 7 (fc6): 4 (sub-filter decomposition).
 // K = 3: F(6x6) [64 positions per 36 outputs, partial edge tiles] or F(4x4) [36 per 16, needs H, W % 4 == 0], whichever multiplies
 // less on this map (small maps lose more to F(6x6)'s partial tiles than they gain); F(2x2) as the fallback.
+// FCN8S_WINO_DGRAD_NT=0: the adjoint data gradient transforms the filters a second time into a transposed bank (round-2 default until
+// the transposed-B GEMM existed) instead of reading the forward bank of the same step
+static bool wino_dgrad_nt_enabled() { static const int on = [] { const char* e = getenv("FCN8S_WINO_DGRAD_NT"); return e ? atoi(e) : 1; }(); return on != 0; }
 int wino_tile_for(const fcn8s_model* m, int H, int W, int K = 3)
 {
     if (!m || H % 2 || W % 2) return 0;
@@ -271,6 +277,12 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
         else { cu = nullptr; (void)hipGetLastError(); }
         a.w = u;
     }
+    if (m && !u_cached && m->fwd_train && layer && !v_ready && ((KS == 3 && tile == 6) || (KS == 7 && tile == 4 && wino_r(7) == 4)) && wino_dgrad_nt_enabled() &&
+        std::string(tag).find("dgrad") == std::string::npos) {
+        float*& tu = m->u_train[std::string(layer) + "#" + std::to_string(tile)];
+        if (!tu && hipMalloc((void**)&tu, (size_t)P * Kg * Cout * sizeof(float)) != hipSuccess) { tu = nullptr; (void)hipGetLastError(); }
+        if (tu) { u = tu; a.w = u; }
+    }
     // v_ready: V was written together with the weight gradient's dM by the fused transform (launch_wino_input_dout)
     auto pre = [&]() { if (!u_cached) launch_wino_filter(tile, wk, u, Cin, Cout, KS, s); if (!v_ready) launch_wino_input(tile, x, v, N, H, W, Cin, KS, s, e.in_rbits_out); };
     auto post = [&]() { launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, (e.skip_y && e.pool) ? nullptr : y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s, e.pool, e.pidx, KS, e.rbits_out, e.rbits_in); };
@@ -305,11 +317,40 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
         a.out_scale = 1; a.phases_x = 1; a.w_phase_stride = (long long)Cin * Cout;
         a.alpha = 1.f; a.mask_scale = 1.f;
         a.batched = 1; a.x_batch_stride = wino_slab(T, Cin); a.y_batch_stride = wino_slab(T, Cout);
-        { ProfScope ps(m, "wino_transform", 0, (double)(9 + P) * 4 * Cin * Cout); launch_wino_filter(6, e.w_fwd, m->d_wino_u, Cout, Cin, 3, s, 1); }
+        auto kept = m->u_train.find(std::string(layer) + "#6");
+        if (wino_dgrad_nt_enabled() && kept != m->u_train.end() && kept->second) {
+            a.w = kept->second; a.bt = 1; a.ldw = Cin;          // the forward bank U[xi][ci_fwd = Cout here][co_fwd = Cin here], read transposed
+        } else {
+            ProfScope ps(m, "wino_transform", 0, (double)(9 + P) * 4 * Cin * Cout); launch_wino_filter(6, e.w_fwd, m->d_wino_u, Cout, Cin, 3, s, 1);
+        }
         { ProfScope ps(m, "wino_gemm_dgrad", 2.0 * P * T * Cin * Cout, 4.0 * P * (T * (double)(Cin + Cout) + (double)Cin * Cout), layer); launch_igemm(a, P, s); }
         { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout * (1.0 + (e.relu_bits_in ? 1.0 / 32 : (e.mask ? 1.0 : 0.0)) + (e.addend ? 1.0 : 0.0)) + (double)P * T * Cout));
           launch_wino_dgrad_output(m->d_wino_v, e.addend, e.mask, e.mask_scale, e.relu_bits_in, y, N, H, W, Cout, s); }
         return false;
+    }
+    if (m && wino7 && e.dgrad && layer && !m->dm_layer.empty() && m->dm_layer == layer && e.alpha == 1.f && !real_cin && !e.bias && !e.relu && !e.mask && !e.addend) {
+        auto kept = m->u_train.find(std::string(layer) + "#4");
+        if (kept != m->u_train.end() && kept->second) {
+            // fc6 data gradient as the adjoint of the forward sub-filter Winograd algorithm (here Cin = channels of dz = 4096, Cout = channels
+            // of dx = 512): dV[xi][t][sub * Cout + c] = dM[xi][t][:] . U[xi][sub * Cout + c][:] with the forward bank of this step read as a
+            // transposed B operand, then the overlap-add gather (winograd.hip).  No transform of dz, no second filter bank, no flipped copy.
+            m->dm_layer.clear(); m->fused_v_layer.clear();
+            const int P = 49, Ng = 4 * Cout;
+            const long long T = wino_tiles(4, N, H, W);
+            IgemmArgs a{};
+            a.x = m->d_wino_m; a.w = kept->second; a.y = m->d_wino_v;
+            a.N = 1; a.Ma = (int)T; a.Mb = 1; a.M = T;
+            a.Hi = (int)T; a.Wi = 1; a.Cin = Cin; a.ldx = Cin;
+            a.KW = 1; a.in_scale = 1; a.tap_step = 1; a.tap_off = 0; a.Ktot = Cin;
+            a.Ho = (int)T; a.Wo = 1; a.Cout = Ng; a.ldy = Ng;
+            a.out_scale = 1; a.phases_x = 1; a.w_phase_stride = (long long)Ng * Cin;
+            a.alpha = 1.f; a.mask_scale = 1.f;
+            a.batched = 1; a.x_batch_stride = wino_slab(T, Cin); a.y_batch_stride = wino_slab(T, Ng);
+            a.bt = 1; a.ldw = Cin;
+            { ProfScope ps(m, "wino_gemm_fc6_dgrad", 2.0 * P * T * Cin * Ng, 4.0 * P * (T * (double)(Cin + Ng) + (double)Cin * Ng), layer); launch_igemm(a, P, s); }
+            { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout + (double)P * T * Ng)); launch_wino_dgrad_output_sub44(m->d_wino_v, y, N, H, W, Cout, s); }
+            return false;
+        }
     }
     if (m) m->dm_layer.clear();
     if (e.lazy_wt && e.w_fwd) {
@@ -430,6 +471,9 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
                   if (fuse_dgrad_input && tile >= 4 && K == 3) fused = launch_wino_input_dout(tile, dz, m->d_wino_v, m->d_wino_m, N, H, W, Cout, s, pool_idx);
                   if (!fused) launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s, K);
               } }
+            // fc6: the non-fused transform above left dM = A dz A^T in d_wino_m; its adjoint data gradient (conv_same) consumes it
+            if (K == 7 && tile == 4 && !fused && wino_r(7) == 4 && wino_dgrad_nt_enabled() && wino_dgrad_adjoint_enabled() && Cin % 2 == 0 && Cout % 64 == 0 &&
+                (4 * Cin) % 64 == 0 && m->u_train.count(std::string(layer) + "#4")) dm_ready = true;
             m->fused_v_layer = fused ? layer : "";
             m->dm_layer = dm_ready ? layer : "";
             { ProfScope ps(m, K == 7 ? "wino_gemm_fc6_wgrad" : "wino_gemm_wgrad", 2.0 * NP * T * Kg * Cout, 4.0 * NP * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_wgrad(g, s); }
@@ -718,6 +762,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     }
     const bool fill_fp = m->frozen && m->u_cache.empty();
     prepare_forward_weights(m);
+    m->fwd_train = train;
     m->rbits_ok.clear();
     { ProfScope ps(m, "preprocess", 0, (double)N * H * W * (16 + (dtype ? 12 : 3))); launch_preprocess(img_dev, dtype, A(m, "x0"), (long long)N * H * W, s); }
     const float* x = A(m, "x0");
@@ -855,11 +900,10 @@ int compute_loss(fcn8s_model* m, const uint8_t* lab_dev, float l2_rate, bool wit
 void prepare_backward_weights(fcn8s_model* m)
 {
     hipStream_t s = m->stream;
-    ProfScope ps(m, "weight_relayout", 0, 8.0 * ((double)m->fc6k * m->fc6k * m->widths[4] * m->widths[5] + (double)m->widths[5] * m->widths[6] +
+    ProfScope ps(m, "weight_relayout", 0, 8.0 * ((double)m->widths[5] * m->widths[6] +
                                                  (double)m->C * (m->widths[2] + m->widths[3] + m->widths[6])));
-    // (the 3x3 layers' flipped + transposed kernels are made on demand in conv_same: the adjoint Winograd data gradient, which the
-    // wide layers take, reads the forward kernel)
-    launch_flip_transpose(Wp(m, "fc6/weights"), WTp(m, "fc6/weights"), m->fc6k * m->fc6k, m->widths[4], m->widths[5], s);
+    // (the 3x3 layers' and fc6's flipped + transposed kernels are made on demand in conv_same: the adjoint Winograd data gradients read
+    // the forward filter banks)
     launch_flip_transpose(Wp(m, "fc7/weights"), WTp(m, "fc7/weights"), 1, m->widths[5], m->widths[6], s);
     launch_flip_transpose(Wp(m, "pool3_1x1/kernel"), WTp(m, "pool3_1x1/kernel"), 1, m->widths[2], m->C, s);
     launch_flip_transpose(Wp(m, "pool4_1x1/kernel"), WTp(m, "pool4_1x1/kernel"), 1, m->widths[3], m->C, s);
@@ -912,7 +956,8 @@ void backward_bucket0(fcn8s_model* m)
       conv_same(m, "fc7_dgrad", m->gbuf[0], WTp(m, "fc7/weights"), m->gbuf[1], N, h5, w5, m->widths[6], m->widths[5], 1, e, s); }
     // fc6
     conv_wgrad(m, "fc6_wgrad", A(m, "pool5"), m->gbuf[1], Gp(m, "fc6/weights"), Gp(m, "fc6/biases"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, 1.f, s, 0, "fc6");
-    { Epi e; e.dgrad = 1; conv_same(m, "fc6_dgrad", m->gbuf[1], WTp(m, "fc6/weights"), m->gbuf[0], N, h5, w5, m->widths[5], m->widths[4], m->fc6k, e, s, 0, "fc6"); }
+    { Epi e; e.dgrad = 1; e.w_fwd = Wp(m, "fc6/weights"); e.lazy_wt = 1;      // (flipped + transposed copy only if the adjoint path is not taken)
+      conv_same(m, "fc6_dgrad", m->gbuf[1], WTp(m, "fc6/weights"), m->gbuf[0], N, h5, w5, m->widths[5], m->widths[4], m->fc6k, e, s, 0, "fc6"); }
     m->gcur = 0;   // gbuf[0] holds d(pool5)
 }
 
@@ -1112,6 +1157,7 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->d_v) hipFree(m->d_v);
     if (m->d_wt) hipFree(m->d_wt);
     if (m->d_w1pad) hipFree(m->d_w1pad);
+    for (auto& kv : m->u_train) if (kv.second) hipFree(kv.second);
     if (m->d_wino_u) hipFree(m->d_wino_u);
     for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
     if (m->d_wbf16) hipFree(m->d_wbf16);

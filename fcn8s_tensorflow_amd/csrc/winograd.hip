@@ -652,6 +652,70 @@ __global__ void wino_dfilter_kernel(const float* du, float* dw, int Cin, int Cou
     }
 }
 
+// ---- adjoint data gradient of the 7x7 layer (2 x 2 grid of 4x4 sub-filters through F(4x4,4x4)) --------------------------------
+// Forward: tile (ty, tx), sub-filter (sa, sb) reads the 7x7 patch at (4 ty + 4 sa - 3, 4 tx + 4 sb - 3), V = B^T d B, and the GEMM
+// sums over (sub, ci).  Backward: dV[xi][t][sub * Cin + ci] = dM[xi][t] U[xi]^T comes from the transposed-B GEMM, each patch gets
+// B dV B^T, and the patches (stride 4, size 7) overlap-add into dx.  As a gather: one thread = one 4x4 region (Ry, Rx) of dx x VEC
+// channels; a patch row range [4u - 3, 4u + 3], u = ty' + sa, meets the region's rows for u = Ry (patch rows 3..6 = region rows 0..3)
+// and u = Ry + 1 (patch rows 0..2 = region rows 1..3), each reached by (ty', sa) = (u, 0) and (u - 1, 1): 4 x 4 = 16 patches per
+// region, each transformed only in the rows / columns the region needs.  dV is read ~4x (L2), 205 MB at 16 x 1024x512.
+template <int KY, int KX, int VEC>
+static __device__ __forceinline__ void sub44_gather(const float4* __restrict__ dv, long long slab, int ldv, int C4, const TileIdx& ti, int th, int tw,
+                                                    float4 (&out)[4][4])
+{
+    typedef WinoMat<4, 4> WM;
+    constexpr int SA = KY & 1, DTY = KY == 0 ? 0 : KY == 1 ? -1 : KY == 2 ? 1 : 0, A0 = KY < 2 ? 3 : 0, R0 = KY < 2 ? 0 : 1, NR = KY < 2 ? 4 : 3;
+    constexpr int SB = KX & 1, DTX = KX == 0 ? 0 : KX == 1 ? -1 : KX == 2 ? 1 : 0, B0 = KX < 2 ? 3 : 0, S0 = KX < 2 ? 0 : 1, NS = KX < 2 ? 4 : 3;
+    const int ty = ti.ty + DTY, tx = ti.tx + DTX;
+    if ((unsigned)ty >= (unsigned)th || (unsigned)tx >= (unsigned)tw) return;
+    const float4* p = dv + (((long long)ti.n * th + ty) * tw + tx) * ldv + (SA * 2 + SB) * C4 + ti.c;
+    float4 tmp[NR][7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        float4 g[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) g[i] = p[(i * 7 + j) * slab];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {                 // rows: dd[a][.] = sum_i B^T[i][a] dV[i][.]
+            float4 t = f4zero();
+#pragma unroll
+            for (int i = 0; i < 7; ++i) if (WM::bt(i, A0 + r) != 0.f) t = f4fma(WM::bt(i, A0 + r), g[i], t);
+            tmp[r][j] = t;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {                 // columns: dd[a][b] = sum_j (.)[a][j] B^T[j][b]
+            float4 t = out[R0 + r][S0 + c];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) if (WM::bt(j, B0 + c) != 0.f) t = f4fma(WM::bt(j, B0 + c), tmp[r][j], t);
+            out[R0 + r][S0 + c] = t;
+        }
+}
+template <int VEC>
+__global__ __launch_bounds__(256) void wino_dgrad_output_sub44_kernel(const float4* __restrict__ dv, float4* __restrict__ dx, int N, int H, int W, int C4, long long slab)
+{
+    const int th = H / 4, tw = W / 4;
+    const TileIdx ti = tile_index(th, tw, C4, N);
+    if (!ti.ok) return;
+    const int ldv = C4 * 4;
+    float4 out[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[r][c] = f4zero();
+#define FCN8S_S44ROW(KY_) sub44_gather<KY_, 0, VEC>(dv, slab, ldv, C4, ti, th, tw, out); sub44_gather<KY_, 1, VEC>(dv, slab, ldv, C4, ti, th, tw, out); \
+                          sub44_gather<KY_, 2, VEC>(dv, slab, ldv, C4, ti, th, tw, out); sub44_gather<KY_, 3, VEC>(dv, slab, ldv, C4, ti, th, tw, out)
+    FCN8S_S44ROW(0); FCN8S_S44ROW(1); FCN8S_S44ROW(2); FCN8S_S44ROW(3);
+#undef FCN8S_S44ROW
+    float4* o = dx + (((long long)ti.n * H + 4 * ti.ty) * W + 4 * ti.tx) * C4 + ti.c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[(r * W + c) * C4] = out[r][c];
+}
+
 #undef f4fma
 #undef f4zero
 #undef float4
@@ -705,6 +769,13 @@ void launch_wino_dgrad_output(const float* dv, const float* addend, const float*
     else
         hipLaunchKernelGGL((wino_dgrad_output_kernel<2>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / 2), dim3(256), 0, s,
                            (const VecF<2>*)dv, (const VecF<2>*)addend, (const VecF<2>*)mask, mask_scale, rbits_in, (VecF<2>*)y, N, H, W, C / 2, wino_slab(T, C) / 2);
+}
+// dv: [49][T][4 * C] (T = N * H/4 * W/4 tiles, columns = sub-filter x channel), dx: [N,H,W,C]; H, W % 4 == 0, C % 2 == 0
+void launch_wino_dgrad_output_sub44(const float* dv, float* dx, int N, int H, int W, int C, hipStream_t s)
+{
+    const long long T = (long long)N * (H / 4) * (W / 4);
+    hipLaunchKernelGGL((wino_dgrad_output_sub44_kernel<2>), tile_grid(N, H / 4, W / 4, C / 2), dim3(256), 0, s,
+                       (const VecF<2>*)dv, (VecF<2>*)dx, N, H, W, C / 2, wino_slab(T, 4 * C) / 2);
 }
 bool wino_fuse_dz_enabled() { static const int on = env_flag("FCN8S_WINO_FUSE_DZ", 1); return on != 0; }
 bool launch_wino_input_dout(int tile, const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s, const unsigned char* pidx)
