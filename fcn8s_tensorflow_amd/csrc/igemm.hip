@@ -796,8 +796,9 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
     // ... or few blocks altogether (batch-1 inference: fc6 has 32 tiles per Winograd position and must still stream a 1.6 GB
     // filter bank at HBM speed)
     const bool linear = (mode == 1 || mode == 3) && !a.relu && !a.mask && !a.dropout && !a.addend && a.out_scale == 1 && a.ldy == a.Cout;
+    static const int splitk_min_kt = [] { const char* e = getenv("FCN8S_SPLITK_MIN_KT"); return e ? atoi(e) : 64; }();
     const unsigned nblocks = grid.x * (unsigned)phases, nkt_all = (unsigned)(a.Ktot / BKF);
-    if (linear && ((grid.x < 512 && nkt_all >= 512) || (nblocks < 2048 && nkt_all >= 64))) {
+    if (linear && ((grid.x < 512 && nkt_all >= 512) || (nblocks < 2048 && nkt_all >= (unsigned)splitk_min_kt))) {
         unsigned ks = nkt_all >= 512 && grid.x < 512 ? 1024 / grid.x : 4096 / nblocks;
         if (ks > 8) ks = 8;
         if (ks > nkt_all / 16) ks = nkt_all / 16;
