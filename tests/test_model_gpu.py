@@ -216,6 +216,29 @@ def test_f32x3_mode_holds_the_fp32_tolerances(widths, n, h, w, l2):
     e.close()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f32x3"])
+def test_training_overfits_one_batch(precision):
+    """The step is usable, not just locally correct: 40 TF-Adam steps on one fixed batch (small widths, dropout off) drive the loss
+    from ln(20)-ish well down, monotonically on a 5-step average, in either arithmetic mode; both modes end within a few percent of
+    each other (their steps differ by fp32 round-off only, which the optimisation does not amplify on this scale)."""
+    P = orc.init_params(20, SMALL, seed=3, decoder_std_scale=30.0, bias_std=0.05)
+    img, lab = batch(2, 64, 96, seed=5)
+    e = make_engine(SMALL)
+    e.set_params(P)
+    e.set_precision(precision)
+    losses = [e.train_step(img, lab, 2e-4, keep_prob=1.0)[0] for _ in range(40)]
+    e.close()
+    assert all(np.isfinite(losses))
+    avg = [float(np.mean(losses[i:i + 5])) for i in range(0, 40, 5)]
+    assert all(b < a for a, b in zip(avg, avg[1:])), avg
+    assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
+    test_training_overfits_one_batch.final = getattr(test_training_overfits_one_batch, "final", {})
+    test_training_overfits_one_batch.final[precision] = losses[-1]
+    f = test_training_overfits_one_batch.final
+    if len(f) == 2:
+        assert abs(f["fp32"] - f["f32x3"]) < 0.05 * f["fp32"], f
+
+
 def test_tf_adam_training_steps():
     """Three fused train steps (sess.run(train_op)): each step is checked against the oracle's
     gradient + TF-Adam update started from the library's own pre-step state, so that Adam's
