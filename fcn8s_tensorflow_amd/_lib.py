@@ -72,6 +72,8 @@ SIGNATURES = {
     "fcn8s_freeze_params": (_i, [_p, _i]),
     "fcn8s_set_precision": (_i, [_p, _i]),
     "fcn8s_get_precision": (_i, [_p]),
+    "fcn8s_set_option": (_i, [_p, C.c_char_p, _i64]),
+    "fcn8s_get_option": (_i, [_p, C.c_char_p, _i64p]),
     "fcn8s_get_activation": (_i, [_p, C.c_char_p, _p, _sz]),
     "fcn8s_get_dropout_masks": (_i, [_p, _p, _sz, _p, _sz]),
     "fcn8s_crc32c": (C.c_uint32, [_p, _sz, C.c_uint32]),
@@ -84,6 +86,7 @@ SIGNATURES = {
     "fcn8s_op_resample_u8": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_conv2d": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_conv2d_winograd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "fcn8s_op_conv3x3_winograd_fwd_bwd": (_i, [_p] * 11 + [_i] * 8),
     "fcn8s_op_conv2d_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_conv2d_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_maxpool2x2": (_i, [_p, _p, _p, _i, _i, _i, _i]),

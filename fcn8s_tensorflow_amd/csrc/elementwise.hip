@@ -576,7 +576,7 @@ void launch_colsum(const float* x, float* out, long long rows, int C, hipStream_
     int tpr = 1; while (tpr < C4 && tpr < 256) tpr *= 2;          // threads per row slice (power of two >= C4, at most 256)
     const int ctiles = (C4 + tpr - 1) / tpr, rgroups = 256 / tpr;
     long long rblocks = (rows + 16LL * rgroups - 1) / (16LL * rgroups);      // >= 16 rows per thread
-    static const int maxb_total = [] { const char* e = getenv("FCN8S_COLSUM_MAXB"); return e ? atoi(e) : 512; }();
+    constexpr int maxb_total = 512;
     const long long maxb = maxb_total / ctiles > 0 ? maxb_total / ctiles : 1;
     if (rblocks > maxb) rblocks = maxb;
     if (rblocks < 1) rblocks = 1;

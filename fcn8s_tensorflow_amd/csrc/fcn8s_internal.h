@@ -38,6 +38,7 @@ struct IgemmArgs {
     int batched; long long x_batch_stride, y_batch_stride;   // gridDim.z independent GEMMs (Winograd positions)
     int m_fastest;                                           // tile order, set by the launcher (see igemm.hip)
     int bt, ldw;                                             // bt: the B operand is stored transposed, w[z][n][k] with row stride ldw (plain batched GEMMs on the LDS-DMA kernel only)
+    int split;                                               // 3: the LDS-DMA kernels take their products as six bf16 MFMAs of the operands split in three (FCN8S_PREC_F32X3); 0: f32 MFMA
 };
 void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s);
 
@@ -75,6 +76,7 @@ struct WgradArgs {
     int batched; long long a_batch_stride, b_batch_stride;   // gridDim.z = independent GEMMs (C stride = Areal*ldc)
     int c_uninitialized;               // 0: C was zeroed by the caller (accumulate with atomics); 1: the launcher decides (plain store or memset)
     int plain_store;                   // set by the launcher
+    int split;                         // as IgemmArgs::split
 };
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
 // 3x3 / 7x7 SAME conv weight (+bias) gradient, several taps per block (3x3: all nine, 7x7: one filter row);
@@ -88,7 +90,6 @@ bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, 
 
 // conv1_1 forward with bias + ReLU on the LDS-DMA gather kernel (Cout = 64 only; returns false otherwise): x4 [N,H,W,4], w48 [48][64]
 // (taps x 4 channels, rows 36..47 zero), zero16 = 16 zero bytes in device memory (what taps outside the image read)
-bool conv1_ldsdma_enabled();
 bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, hipStream_t s);
 
 // weight gradient of the 16x16 / stride-8 transposed conv with 20 channels (VALU; dW zero-initialised, accumulated with atomics);
@@ -131,7 +132,6 @@ void launch_unblock_logits(const float* blocked, float* nhwc, const PixMap& map,
 void launch_onehot_to_ids(const void* oh, int elem_bytes, long long npix, int C, uint8_t* ids, int* bad, hipStream_t s);
 void launch_confusion(const uint8_t* labels, const long long* pred, long long npix,
                       unsigned long long* conf, int C, hipStream_t s);
-void set_mfma_split(int nsplit);      // igemm.hip: 3 = the LDS-DMA GEMM kernels run in f32x3 mode (fp32 operands split into three bf16 pieces), 0 = f32 MFMA
 // skinny.hip: 1x1 convs with <= 32 output (forward, weight gradient) or input (data gradient) channels; false = shape not covered
 bool launch_head_fwd(const float* x, const float* w, const float* bias, float* y, long long M, int K, int C, float alpha, hipStream_t s);
 bool launch_head_dgrad(const float* dy, const float* wt, const float* mask, float mask_scale, float* dx, long long M, int K, int C, float alpha,
@@ -154,7 +154,7 @@ void launch_dropout_mask(float* mask, long long n, float keep_prob, unsigned lon
 // tile 2 (tiles 4 and 6 handle partial edge tiles; T = N * ceil(H/tile) * ceil(W/tile)).
 // KS = 3: plain 3x3 conv.  KS = 7: the filter is cut into a 3x3 grid of 3x3 sub-filters whose products add up in the
 // Winograd domain (GEMM depth 9*C); u / v rows are then [sub][channel].
-int wino_r(int KS);                 // sub-filter size: 3 for 3x3 kernels; 7x7 (fc6): 4 by default (FCN8S_WINOGRAD_FC6_R=3 selects 3)
+int wino_r(int KS);                 // sub-filter size: 3 for 3x3 kernels; 7x7 (fc6): 4
 int wino_nsub(int KS);              // sub-filters per dimension: ceil(KS / r)
 int wino_alpha(int tile, int KS);   // tile + r - 1; the number of Winograd positions is alpha^2
 long long wino_slab(long long T, int C);   // floats between the slabs of consecutive Winograd positions of a [P][T][C] tensor (T*C + skew)
@@ -165,7 +165,6 @@ void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, 
 // pidx != nullptr: `dy` is instead the gradient of the 2x2/2 max-pool output, [N,H/2,W/2,C], and pidx the per-window argmax bytes
 // written by launch_wino_output -- the max-pool backward (with the ReLU mask) is applied on the fly and dy never exists in HBM.
 bool launch_wino_input_dout(int tile, const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s, const unsigned char* pidx = nullptr);
-bool wino_fuse_dz_enabled();
 void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
                         int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,
                         unsigned int stream_id, hipStream_t s, float* pool = nullptr, unsigned char* pidx = nullptr, int KS = 3,
@@ -176,7 +175,6 @@ size_t wino_rbits_words(int tile, int N, int H, int W, int C);
 //  if pidx != nullptr, one byte per pooled element: index 0..3 of the window's first maximum, 4 if that maximum is not > 0)
 void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s, int KS = 3, const unsigned char* pidx = nullptr);   // dy -> dm[P][T][C] = A dY A^T  (tile 6 with pidx: dy is d(pool), routed through the argmax bytes)
 // F(6x6,3x3) data gradient as the adjoint of the forward algorithm: dv[P][T][C] = dM U^T -> dx = overlap-added B dv B^T (+ skip addend, ReLU mask)
-bool wino_dgrad_adjoint_enabled();
 void launch_wino_dgrad_output_sub44(const float* dv, float* dx, int N, int H, int W, int C, hipStream_t s);   // fc6: see winograd.hip
 void launch_wino_dgrad_output(const float* dv, const float* addend, const float* mask, float mask_scale, const unsigned* rbits_in, float* y,
                               int N, int H, int W, int C, hipStream_t s);

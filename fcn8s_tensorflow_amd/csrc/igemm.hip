@@ -403,8 +403,7 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt() { asm volat
 // sched_group_barrier, or software-pipelined over K-tiles): 155-170 "TFLOP/s" against 122-136.  Not the default: the headline
 // number is measured on the exact f32 MFMA.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-static int g_mfma_split = [] { const char* e = getenv("FCN8S_F32X3"); return e && atoi(e) ? 3 : 0; }();     // (the environment switch serves the op-level entry points, which have no model)
-void set_mfma_split(int nsplit) { g_mfma_split = nsplit == 3 ? 3 : 0; }
+// (which arithmetic a launch uses travels in IgemmArgs::split / WgradArgs::split, set by the caller from its model's precision)
 static __device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo)
 {
     float r[8];
@@ -762,18 +761,15 @@ __global__ __launch_bounds__(256, 4) void conv1_glds_kernel(const Conv1Args p)
         __builtin_amdgcn_wave_barrier();
     }
 }
-bool conv1_ldsdma_enabled() { static const int on = [] { const char* e = getenv("FCN8S_CONV1_LDSDMA"); return e ? atoi(e) : 1; }(); return on != 0; }
 // x4: [N,H,W,4] (b, g, r, 0); w48: [48][64] = taps 0..8 x 4 channels, rows 36..47 zero; y = relu(conv + bias), [N,H,W,64]
 bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, hipStream_t s)
 {
-    if (!conv1_ldsdma_enabled() || Cout != 64 || !bias || !zero16) return false;
+    if (Cout != 64 || !bias || !zero16) return false;
     Conv1Args a{x4, w48, bias, y, zero16, N, H, W, (long long)N * H * W};
     g_last_kernel = "conv1_glds_kernel";
     hipLaunchKernelGGL(conv1_glds_kernel, dim3((unsigned)((a.M + 127) / 128)), dim3(256), 0, s, a);
     return true;
 }
-
-static bool glds_enabled() { static const int on = [] { const char* e = getenv("FCN8S_GEMM_LDSDMA"); return e ? atoi(e) : 1; }(); return on != 0; }
 
 template <int BM, int BN, int WM, int WN, int BKF = 16>
 static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
@@ -796,7 +792,7 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
     // ... or few blocks altogether (batch-1 inference: fc6 has 32 tiles per Winograd position and must still stream a 1.6 GB
     // filter bank at HBM speed)
     const bool linear = (mode == 1 || mode == 3) && !a.relu && !a.mask && !a.dropout && !a.addend && a.out_scale == 1 && a.ldy == a.Cout;
-    static const int splitk_min_kt = [] { const char* e = getenv("FCN8S_SPLITK_MIN_KT"); return e ? atoi(e) : 64; }();
+    constexpr int splitk_min_kt = 64;        // fewest K-tiles a few-block launch must have before its reduction is split (32 measured slower at batch 1)
     const unsigned nblocks = grid.x * (unsigned)phases, nkt_all = (unsigned)(a.Ktot / BKF);
     if (linear && ((grid.x < 512 && nkt_all >= 512) || (nblocks < 2048 && nkt_all >= (unsigned)splitk_min_kt))) {
         unsigned ks = nkt_all >= 512 && grid.x < 512 ? 1024 / grid.x : 4096 / nblocks;
@@ -814,7 +810,7 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
     // nothing but a per-column bias (and no split-K): the glds kernel's 16-byte-store epilogue adds it
     const bool bias_only = fast && a.bias && !a.addend && !a.mask && !a.relu && !a.dropout && a.alpha == 1.f && a.ldy % 4 == 0 && a.Cout % 4 == 0 && grid.y == 1;
     if constexpr (BN >= 64 && BKF == 16) {
-        if (glds_enabled() && rows1x1 && (mode == 3 || grid.y == 1) && (long long)(BM - 1) * a.ldx < (1LL << 29) && (long long)16 * a.Cout < (1LL << 29)) {
+        if (rows1x1 && (mode == 3 || grid.y == 1) && (long long)(BM - 1) * a.ldx < (1LL << 29) && (long long)16 * a.Cout < (1LL << 29)) {
             // (the kernel symbols as rocprofv3 prints them, so that bench.py can look the PMC traffic of the dominant kernel up by name)
             static const std::string gbase = "gemm_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3, ";
             static const std::string xbase = "gemm_glds_x3_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3, ";
@@ -826,13 +822,13 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
                 static const std::string nb = "gemm_glds_nt_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>";
                 static const std::string nbx = "gemm_glds_nt_x3_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>";
                 if (mode != 3 || (long long)(BN - 1) * a.ldw >= (1LL << 29)) { fprintf(stderr, "fcn8s: transposed-B GEMM needs the plain batched form\n"); abort(); }
-                g_last_kernel = (g_mfma_split == 3 ? nbx : nb).c_str();
-                if (g_mfma_split == 3) hipLaunchKernelGGL((gemm_glds_nt_x3_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, s, a);
+                g_last_kernel = (a.split == 3 ? nbx : nb).c_str();
+                if (a.split == 3) hipLaunchKernelGGL((gemm_glds_nt_x3_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, s, a);
                 else                   hipLaunchKernelGGL((gemm_glds_nt_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, s, a);
                 return;
             }
-            g_last_kernel = gt[(epi ? 1 : 0) + (g_mfma_split == 3 ? 2 : 0)].c_str();
-            if (g_mfma_split == 3) {
+            g_last_kernel = gt[(epi ? 1 : 0) + (a.split == 3 ? 2 : 0)].c_str();
+            if (a.split == 3) {
                 if (epi) hipLaunchKernelGGL((gemm_glds_x3_kernel<BM, BN, WM, WN, 3, true>), grid, dim3(256), 0, s, a);
                 else     hipLaunchKernelGGL((gemm_glds_x3_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(256), 0, s, a);
                 return;
@@ -841,6 +837,10 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
             else     hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(256), 0, s, a);
             return;
         }
+    }
+    if (a.bt) {      // igemm_fwd_kernel would read w[z][n][k] as if it were [k][n]: callers must only set bt for launches the branch above takes
+        fprintf(stderr, "fcn8s: transposed-B GEMM (M %lld, K %d, N %d, tile %dx%d) does not fit the LDS-DMA kernel\n", a.M, a.Ktot, a.Cout, BM, BN);
+        abort();
     }
     if (mode == 3)      hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 3, BKF>), grid, dim3(256), 0, s, a);
     else if (mode == 2) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 2, BKF>), grid, dim3(256), 0, s, a);
@@ -853,7 +853,7 @@ void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s)
     // largest tile that still yields about one block per CU (small batches / deep layers have few pixels:
     // 1024x512 bs1 gives conv5 only 2048 pixels = 64 tiles of 128x128 on 256 CUs)
     auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn) * phases; };
-    static const long long minb = [] { const char* e = getenv("FCN8S_GEMM_MIN_BLOCKS"); return e ? atoll(e) : 200LL; }();
+    constexpr long long minb = 200;
     if (a.Cout <= 32)      launch_igemm_cfg<128, 32, 4, 1>(a, phases, s);
     else if (a.Cout <= 64) {
         if (blocks(128, 64) >= minb) launch_igemm_cfg<128, 64, 2, 2>(a, phases, s);
@@ -1318,7 +1318,7 @@ bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, 
     Conv1WgradArgs a{(const float4*)X4, dZ, dW, db, N, H, W, (long long)N * H * (W / 64), 0};
     // 512 blocks: every block ends in 1792 atomics on the same addresses, and those serialise (2048 blocks: 0.67 ms, 512: 0.60 ms;
     // a register-staged prefetch of the next segment needed 256 VGPRs and was slower)
-    static const int maxb = [] { const char* e = getenv("FCN8S_CONV1_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+    constexpr int maxb = 512;
     long long blocks = a.nseg < maxb ? a.nseg : maxb;
     a.segs_per_block = (int)((a.nseg + blocks - 1) / blocks);
     blocks = (a.nseg + a.segs_per_block - 1) / a.segs_per_block;
@@ -1625,17 +1625,16 @@ static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
     g_last_kernel = tag.c_str();
     if constexpr (WK == 1 && BM >= 64 && BN >= 64) {
         const bool rows = a.batched || (a.ntaps == 1 && a.KW == 1 && a.a_scale == 1 && a.tap_off == 0 && a.Ha == a.Pa && a.Wa == a.Pb);
-        if (glds_enabled() && full_tiles && a.Adim % BM == 0 && a.Bdim % BN == 0 && rows && !b.colsum && a.lda <= (1 << 20) && a.ldb <= (1 << 20)) {
+        if (full_tiles && a.Adim % BM == 0 && a.Bdim % BN == 0 && rows && !b.colsum && a.lda <= (1 << 20) && a.ldb <= (1 << 20)) {
             // All blocks of a launch do the same work, so the launch runs in whole rounds of (256 CUs x resident blocks): pick the row
             // split that wastes least of the last round (2048 blocks on 768 slots = 2.67 rounds idle a ninth of the chip), then the fewest splits
             // (every split adds one pass of atomics over C).
             constexpr int slots = 256 * ((3 * (BM + BN) * 64 <= 40960) ? 4 : 3);
-            static const int min_rounds = [] { const char* e = getenv("FCN8S_WGRAD_MIN_ROUNDS"); return e ? atoi(e) : 1; }();
             long long best = 1; double best_score = -1e9;
             for (long long w = 1; w <= maxsplit && (w == 1 || tiles * w <= 8LL * slots); ++w) {
                 const double r = (double)tiles * w / slots;
                 double score = r / std::ceil(r) - 0.004 * (double)w;
-                if (r < (double)min_rounds) score -= 1.0;
+                if (r < 1.0) score -= 1.0;
                 if (score > best_score) { best_score = score; best = w; }
             }
             long long gchunk = ((a.P + best - 1) / best + 15) / 16 * 16;
@@ -1643,14 +1642,12 @@ static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
             b.plain_store = 0;
             if (a.c_uninitialized && gsplits == 1) b.plain_store = 1;
             else if (a.c_uninitialized && splits == 1) hipMemsetAsync(a.C, 0, (size_t)a.ntaps * a.Areal * a.ldc * sizeof(float), s);   // (zeroed above otherwise)
-            static const int preload = [] { const char* e = getenv("FCN8S_WGRAD_PRELOAD"); return e ? atoi(e) : 1; }();
             static const std::string gbase = "wgrad_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3, ";
-            static const std::string gtag[2] = {gbase + "false>", gbase + "true>"};
-            g_last_kernel = gtag[preload ? 1 : 0].c_str();
-            if (g_mfma_split == 3) { static const std::string xtag = "wgrad_glds_x3_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>"; g_last_kernel = xtag.c_str();
+            static const std::string gtag = gbase + "true>";     // (fragments of a whole K-tile preloaded before its MFMAs: +3 % over the interleaved order)
+            g_last_kernel = gtag.c_str();
+            if (a.split == 3) { static const std::string xtag = "wgrad_glds_x3_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>"; g_last_kernel = xtag.c_str();
                                      hipLaunchKernelGGL((wgrad_glds_x3_kernel<BM, BN, WM, WN, 3>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits); return; }
-            if (preload) hipLaunchKernelGGL((wgrad_glds_kernel<BM, BN, WM, WN, 3, true>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits);
-            else         hipLaunchKernelGGL((wgrad_glds_kernel<BM, BN, WM, WN, 3, false>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits);
+            hipLaunchKernelGGL((wgrad_glds_kernel<BM, BN, WM, WN, 3, true>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits);
             return;
         }
     }

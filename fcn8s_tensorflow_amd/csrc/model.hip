@@ -58,7 +58,8 @@ struct fcn8s_model {
     float *d_wino_u = nullptr, *d_wino_v = nullptr, *d_wino_m = nullptr;   // Winograd scratch: filters, transformed input / output
     int wino_min_cin = 64;                                              // 3x3 layers with Cin >= this use Winograd; 0 = never
     int wino_tile = 6;                                                    // largest 3x3 output tile: F(6x6,3x3) / F(4x4,3x3) per layer by cost, F(2x2,3x3) fallback
-    int wino_fc6 = 1;                                                     // fc6 7x7 as nine 3x3 sub-filters in the Winograd domain
+    int wino_fc6 = 1;                                                     // fc6 7x7 as a 2x2 grid of 4x4 sub-filters in the Winograd domain
+    int wino_force_tile = 0;                                              // != 0: every eligible 3x3 layer uses exactly this tile (op-level parity entry point)
     int precision = FCN8S_PREC_F32;                                       // FCN8S_PREC_BF16_FC: forward fc6 / fc7 on the bf16 MFMA
     bool pool_fused[5] = {false, false, false, false, false};            // forward wrote pool_b + argmax bytes from conv_b_last's output transform
     // fcn8s_freeze_params: the caller promises constant parameters; Winograd-transformed filters are then kept per layer
@@ -232,12 +233,16 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
 // Output tile of the Winograd path for a K x K SAME conv on an H x W map (0 = none).  K = 7 (fc6): 4 (sub-filter decomposition).
 // K = 3: F(6x6) [64 positions per 36 outputs, partial edge tiles] or F(4x4) [36 per 16, needs H, W % 4 == 0], whichever multiplies
 // less on this map (small maps lose more to F(6x6)'s partial tiles than they gain); F(2x2) as the fallback.
-// FCN8S_WINO_DGRAD_NT=0: the adjoint data gradient transforms the filters a second time into a transposed bank (round-2 default until
-// the transposed-B GEMM existed) instead of reading the forward bank of the same step
-static bool wino_dgrad_nt_enabled() { static const int on = [] { const char* e = getenv("FCN8S_WINO_DGRAD_NT"); return e ? atoi(e) : 1; }(); return on != 0; }
+// The adjoint data gradients read the forward filter bank of the same step as a transposed B operand (gemm_glds_nt_kernel).  That kernel
+// only exists in the LDS-DMA form: K % 16 == 0 and whole N tiles of the width launch_igemm picks (64 for N = 64, else 128).  Other widths
+// (e.g. 192) get a second, transposed bank instead (3x3 layers) or the forward-type data gradient (fc6).
+static bool bt_gemm_ok(int K, int N) { return K % 16 == 0 && (N == 64 || N % 128 == 0); }
+int g_op_split = 0;      // arithmetic of the op-level entry points, which have no model (fcn8s_set_option(NULL, "op_f32x3", 1))
+int split_of(const fcn8s_model* m) { return m ? (m->precision == FCN8S_PREC_F32X3 ? 3 : 0) : g_op_split; }
 int wino_tile_for(const fcn8s_model* m, int H, int W, int K = 3)
 {
     if (!m || H % 2 || W % 2) return 0;
+    if (m->wino_force_tile && K == 3) return (m->wino_force_tile == 6 || (H % m->wino_force_tile == 0 && W % m->wino_force_tile == 0)) ? m->wino_force_tile : 0;
     const bool t4 = m->wino_tile >= 4 && H % 4 == 0 && W % 4 == 0;
     if (K == 7) return t4 ? 4 : 0;
     if (m->wino_tile == 6) {
@@ -258,7 +263,7 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
     const int P = wino_alpha(tile, KS) * wino_alpha(tile, KS), nsub2 = wino_nsub(KS) * wino_nsub(KS);
     const long long T = wino_tiles(tile, N, H, W);
     const int Kg = nsub2 * Cin;
-    IgemmArgs a{};
+    IgemmArgs a{}; a.split = split_of(m);
     a.x = v; a.w = u; a.y = mm;
     a.N = 1; a.Ma = (int)T; a.Mb = 1; a.M = T;
     a.Hi = (int)T; a.Wi = 1; a.Cin = Kg; a.ldx = Kg;
@@ -277,7 +282,7 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
         else { cu = nullptr; (void)hipGetLastError(); }
         a.w = u;
     }
-    if (m && !u_cached && m->fwd_train && layer && !v_ready && ((KS == 3 && tile == 6) || (KS == 7 && tile == 4 && wino_r(7) == 4)) && wino_dgrad_nt_enabled() &&
+    if (m && !u_cached && m->fwd_train && layer && !v_ready && ((KS == 3 && tile == 6) || (KS == 7 && tile == 4)) &&
         std::string(tag).find("dgrad") == std::string::npos) {
         float*& tu = m->u_train[std::string(layer) + "#" + std::to_string(tile)];
         if (!tu && hipMalloc((void**)&tu, (size_t)P * Kg * Cout * sizeof(float)) != hipSuccess) { tu = nullptr; (void)hipGetLastError(); }
@@ -308,7 +313,7 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
         m->dm_layer.clear(); m->fused_v_layer.clear();
         const int P = 64;
         const long long T = wino_tiles(6, N, H, W);
-        IgemmArgs a{};
+        IgemmArgs a{}; a.split = split_of(m);
         a.x = m->d_wino_m; a.w = m->d_wino_u; a.y = m->d_wino_v;
         a.N = 1; a.Ma = (int)T; a.Mb = 1; a.M = T;
         a.Hi = (int)T; a.Wi = 1; a.Cin = Cin; a.ldx = Cin;
@@ -318,7 +323,7 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
         a.alpha = 1.f; a.mask_scale = 1.f;
         a.batched = 1; a.x_batch_stride = wino_slab(T, Cin); a.y_batch_stride = wino_slab(T, Cout);
         auto kept = m->u_train.find(std::string(layer) + "#6");
-        if (wino_dgrad_nt_enabled() && kept != m->u_train.end() && kept->second) {
+        if (kept != m->u_train.end() && kept->second && bt_gemm_ok(Cin, Cout)) {
             a.w = kept->second; a.bt = 1; a.ldw = Cin;          // the forward bank U[xi][ci_fwd = Cout here][co_fwd = Cin here], read transposed
         } else {
             ProfScope ps(m, "wino_transform", 0, (double)(9 + P) * 4 * Cin * Cout); launch_wino_filter(6, e.w_fwd, m->d_wino_u, Cout, Cin, 3, s, 1);
@@ -328,7 +333,8 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
           launch_wino_dgrad_output(m->d_wino_v, e.addend, e.mask, e.mask_scale, e.relu_bits_in, y, N, H, W, Cout, s); }
         return false;
     }
-    if (m && wino7 && e.dgrad && layer && !m->dm_layer.empty() && m->dm_layer == layer && e.alpha == 1.f && !real_cin && !e.bias && !e.relu && !e.mask && !e.addend) {
+    if (m && wino7 && e.dgrad && layer && !m->dm_layer.empty() && m->dm_layer == layer && e.alpha == 1.f && !real_cin && !e.bias && !e.relu && !e.mask && !e.addend &&
+        bt_gemm_ok(Cin, 4 * Cout)) {
         auto kept = m->u_train.find(std::string(layer) + "#4");
         if (kept != m->u_train.end() && kept->second) {
             // fc6 data gradient as the adjoint of the forward sub-filter Winograd algorithm (here Cin = channels of dz = 4096, Cout = channels
@@ -337,7 +343,7 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
             m->dm_layer.clear(); m->fused_v_layer.clear();
             const int P = 49, Ng = 4 * Cout;
             const long long T = wino_tiles(4, N, H, W);
-            IgemmArgs a{};
+            IgemmArgs a{}; a.split = split_of(m);
             a.x = m->d_wino_m; a.w = kept->second; a.y = m->d_wino_v;
             a.N = 1; a.Ma = (int)T; a.Mb = 1; a.M = T;
             a.Hi = (int)T; a.Wi = 1; a.Cin = Cin; a.ldx = Cin;
@@ -373,7 +379,7 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
         return e.pool_out != nullptr;
     }
     if (m) m->fused_v_layer.clear();
-    IgemmArgs a{};
+    IgemmArgs a{}; a.split = split_of(m);
     a.x = x; a.w = w; a.bias = e.bias; a.addend = e.addend; a.mask = e.mask; a.y = y;
     a.N = N; a.Ma = H; a.Mb = W; a.M = (long long)N * H * W;
     a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldx = Cin;
@@ -402,7 +408,7 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
 void tconv_fwd(fcn8s_model* m, const float* x, const float* wp, const float* bias, const float* addend,
                float* y, int N, int Hi, int Wi, int C, int K, int S, hipStream_t s)
 {
-    IgemmArgs a{};
+    IgemmArgs a{}; a.split = split_of(m);
     a.x = x; a.w = wp; a.bias = bias; a.addend = addend; a.mask = nullptr; a.y = y;
     a.N = N; a.Ma = Hi + 1; a.Mb = Wi + 1; a.M = (long long)N * a.Ma * a.Mb;
     a.Hi = Hi; a.Wi = Wi; a.Cin = C; a.ldx = C;
@@ -420,7 +426,7 @@ void tconv_fwd(fcn8s_model* m, const float* x, const float* wp, const float* bia
 void tconv_dgrad(fcn8s_model* m, const float* dy, const float* w, float* dx, int N, int Hi, int Wi, int C,
                  int K, int S, hipStream_t s)
 {
-    IgemmArgs a{};
+    IgemmArgs a{}; a.split = split_of(m);
     a.x = dy; a.w = w; a.y = dx;
     a.N = N; a.Ma = Hi; a.Mb = Wi; a.M = (long long)N * Hi * Wi;
     a.Hi = Hi * S; a.Wi = Wi * S; a.Cin = C; a.ldx = C;
@@ -436,7 +442,7 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
                 int N, int H, int W, int Cin, int Cout, int K, float alpha, hipStream_t s, int real_cin = 0,
                 const char* layer = nullptr, bool fuse_dgrad_input = false, const unsigned char* pool_idx = nullptr)
 {
-    WgradArgs a{};
+    WgradArgs a{}; a.split = split_of(m);
     a.A = x; a.B = dz; a.C = dw;
     a.N = N; a.Pa = H; a.Pb = W; a.P = (long long)N * H * W;
     a.Ha = H; a.Wa = W; a.Adim = Cin; a.lda = Cin; a.Areal = real_cin ? real_cin : Cin;
@@ -452,7 +458,7 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             const int tile = wino_tile_for(m, H, W, K), NP = wino_alpha(tile, K) * wino_alpha(tile, K);
             const long long T = wino_tiles(tile, N, H, W);
             const int Kg = wino_nsub(K) * wino_nsub(K) * Cin;           // rows of V / dU: [sub-filter][channel]
-            WgradArgs g{};
+            WgradArgs g{}; g.split = split_of(m);
             g.A = it->second.p; g.B = m->d_wino_m; g.C = m->d_wino_u;
             g.N = 1; g.Pa = 1; g.Pb = (int)T; g.P = T;
             g.Ha = 1; g.Wa = (int)T; g.Adim = Kg; g.lda = Kg; g.Areal = Kg;
@@ -461,19 +467,17 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             // fuse_dgrad_input: the data gradient of this layer follows and runs through Winograd too -- its input
             // transform V = B^T dz B is written into d_wino_v by the same kernel that writes dM (one read of dz)
             bool fused = false, dm_ready = false;
-            const bool adj_bytes = fuse_dgrad_input && tile == 6 && K == 3 && wino_dgrad_adjoint_enabled() && Cin % 64 == 0 && Cout % 64 == 0;
+            const bool adj_bytes = fuse_dgrad_input && tile == 6 && K == 3 && Cin % 64 == 0 && Cout % 64 == 0;
             { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout * (pool_idx ? 0.3125 : 1.0) + ((fuse_dgrad_input && !adj_bytes) ? 2.0 : 1.0) * NP * T * Cout));
               // pool_idx: dz is d(pool) [N,H/2,W/2,Cout]; the max-pool backward happens inside the transform (the caller checked eligibility)
               // adjoint data gradient (tile 6): it consumes dM itself, no second transform of dz
-              const bool adjoint = fuse_dgrad_input && tile == 6 && K == 3 && wino_dgrad_adjoint_enabled() && Cin % 64 == 0 && Cout % 64 == 0;
-              if (adjoint) { launch_wino_dout(6, dz, m->d_wino_m, N, H, W, Cout, s, 3, pool_idx); dm_ready = true; }
+              if (adj_bytes) { launch_wino_dout(6, dz, m->d_wino_m, N, H, W, Cout, s, 3, pool_idx); dm_ready = true; }
               else {
                   if (fuse_dgrad_input && tile >= 4 && K == 3) fused = launch_wino_input_dout(tile, dz, m->d_wino_v, m->d_wino_m, N, H, W, Cout, s, pool_idx);
                   if (!fused) launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s, K);
               } }
             // fc6: the non-fused transform above left dM = A dz A^T in d_wino_m; its adjoint data gradient (conv_same) consumes it
-            if (K == 7 && tile == 4 && !fused && wino_r(7) == 4 && wino_dgrad_nt_enabled() && wino_dgrad_adjoint_enabled() && Cin % 2 == 0 && Cout % 64 == 0 &&
-                (4 * Cin) % 64 == 0 && m->u_train.count(std::string(layer) + "#4")) dm_ready = true;
+            if (K == 7 && tile == 4 && !fused && Cin % 2 == 0 && bt_gemm_ok(Cout, 4 * Cin) && m->u_train.count(std::string(layer) + "#4")) dm_ready = true;
             m->fused_v_layer = fused ? layer : "";
             m->dm_layer = dm_ready ? layer : "";
             { ProfScope ps(m, K == 7 ? "wino_gemm_fc6_wgrad" : "wino_gemm_wgrad", 2.0 * NP * T * Kg * Cout, 4.0 * NP * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_wgrad(g, s); }
@@ -506,7 +510,7 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
 void tconv_wgrad(fcn8s_model* m, const float* x, const float* dy, float* dw, int N, int Hi, int Wi, int C,
                  int K, int S, hipStream_t s)
 {
-    WgradArgs a{};
+    WgradArgs a{}; a.split = split_of(m);
     a.A = dy; a.B = x; a.C = dw;
     a.N = N; a.Pa = Hi; a.Pb = Wi; a.P = (long long)N * Hi * Wi;
     a.Ha = Hi * S; a.Wa = Wi * S; a.Adim = C; a.lda = C; a.Areal = C;
@@ -521,7 +525,6 @@ void tconv_wgrad(fcn8s_model* m, const float* x, const float* dy, float* dw, int
 // ---- workspace --------------------------------------------------------------------
 int ensure_workspace(fcn8s_model* m, int N, int H, int W)
 {
-    set_mfma_split(m->precision == FCN8S_PREC_F32X3 ? 3 : 0);     // (process-wide launcher switch: re-asserted at every model entry point)
     if (N <= 0) return fail(m, FCN8S_ERR_SHAPE, "batch size must be positive");
     if (H <= 0 || W <= 0 || H % 32 || W % 32)
         return fail(m, FCN8S_ERR_SHAPE, "image height and width must be positive multiples of 32 (five 2x2 pools, then x2, x2, x8 upsampling must line up with the skip connections)");
@@ -681,6 +684,7 @@ void tconv_gemm_fwd(fcn8s_model* m)
     launch_tconv_pack_gemm(Wp(m, "fc7_pool4_pool3_conv2d_trans/kernel"), Wp(m, "fc7_pool4_pool3_conv2d_trans/bias"), m->tg_b2, m->tg_b2t, m->tg_bias, C, 8, KP, s);
     launch_tconv_im2col(m->acts.at("a3").p, m->tg_A, m->N, m->H / 8, m->W / 8, C, KP, s);
     IgemmArgs a = tg_rows_gemm(m->tg_A, KP, 4 * C, m->tg_b2, m->logits_b, NC, rows);
+    a.split = split_of(m);
     a.bias = m->tg_bias;
     launch_igemm(a, 1, s);
 }
@@ -691,6 +695,7 @@ void tconv_gemm_dgrad(fcn8s_model* m)
     const long long rows = (long long)m->N * m->pm.QH * m->pm.QW;
     ProfScope ps(m, "tconv_dgrad", 2.0 * rows * NC * KP, 4.0 * rows * (NC + KP));
     IgemmArgs a = tg_rows_gemm(m->dlogits_b, NC, NC, m->tg_b2t, m->tg_dA, KP, rows);
+    a.split = split_of(m);
     a.batched = 1;                                   // one slab: takes the plain (16-byte store) epilogue
     launch_igemm(a, 1, s);
     launch_tconv_col2im(m->tg_dA, m->da3, m->N, m->H / 8, m->W / 8, C, KP, s);
@@ -701,7 +706,7 @@ void tconv_gemm_wgrad(fcn8s_model* m)
     const int C = m->C, NC = 64 * C, KP = m->tg_kp;
     const long long rows = (long long)m->N * m->pm.QH * m->pm.QW;
     ProfScope ps(m, "tconv_wgrad", 2.0 * rows * KP * NC, 4.0 * rows * (NC + KP));
-    WgradArgs g{};
+    WgradArgs g{}; g.split = split_of(m);
     g.A = m->tg_A; g.B = m->dlogits_b; g.C = m->tg_db2;
     g.N = 1; g.Pa = 1; g.Pb = (int)rows; g.P = rows;
     g.Ha = 1; g.Wa = (int)rows; g.Adim = KP; g.lda = KP; g.Areal = KP;
@@ -743,7 +748,7 @@ bool pool_backward_fused(const fcn8s_model* m, int b, bool pooled_by_transform)
 {
     const int h = m->H >> (b - 1), w = m->W >> (b - 1), cw = m->widths[b - 1], nconv = kConvsPerBlock[b - 1];
     char last[32]; snprintf(last, sizeof last, "wv:conv%d_%d", b, nconv);
-    return pooled_by_transform && wino_fuse_dz_enabled() && m->wino_min_cin > 0 && cw >= m->wino_min_cin && m->d_wino_v &&
+    return pooled_by_transform && m->wino_min_cin > 0 && cw >= m->wino_min_cin && m->d_wino_v &&
            wino_tile_for(m, h, w) >= 4 && cw % 64 == 0 && nconv > 1 && m->acts.count(last);
 }
 
@@ -791,7 +796,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 e.skip_y = !train || pool_backward_fused(m, b + 1, true);
             }
             bool done = false;
-            if (first && m->widths[0] == 64 && conv1_ldsdma_enabled()) {            // conv1_1: write-bound gather kernel (igemm.hip: conv1_glds_kernel)
+            if (first && m->widths[0] == 64) {            // conv1_1: write-bound gather kernel (igemm.hip: conv1_glds_kernel)
                 ProfScope ps(m, "conv1_1_fwd", 2.0 * N * h * w * 27.0 * m->widths[0], 4.0 * N * h * w * (3.0 + m->widths[0]), nm);
                 done = launch_conv1_fwd(x, m->d_w1pad, e.bias, A(m, nm), m->d_w1pad + 12 * 4 * (size_t)m->widths[0], N, h, w, m->widths[0], s);
             }
@@ -1016,7 +1021,6 @@ int do_backward_bucket(fcn8s_model* m, int bucket)
 {
     if (!m->have_loss || !m->train_mode) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: call fcn8s_forward_loss first");
     if (bucket != m->next_bucket) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: buckets must be run in order 0,1,2");
-    set_mfma_split(m->precision == FCN8S_PREC_F32X3 ? 3 : 0);
     if (bucket == 0) backward_bucket0(m);
     else if (bucket == 1) backward_blocks(m, 5, 4);
     else backward_blocks(m, 3, 1);
@@ -1114,24 +1118,17 @@ int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
     if ((e = hipMalloc((void**)&m->d_tph[1], 16 * cc * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&m->d_tph[2], 256 * cc * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     {
-        const char* wm = getenv("FCN8S_WINOGRAD_MIN_CIN");          // tuning / A-B switch; 0 disables the Winograd path
-        if (wm) m->wino_min_cin = atoi(wm);
         int cmax = 0; for (int i = 0; i < 5; ++i) cmax = std::max(cmax, m->widths[i]);
-        const char* wt = getenv("FCN8S_WINOGRAD_TILE");             // 2 or 4 (A-B switch)
-        if (wt) { const int t = atoi(wt); m->wino_tile = t == 2 ? 2 : (t == 4 ? 4 : 6); }
-        const char* wf = getenv("FCN8S_WINOGRAD_FC6");
-        if (wf) m->wino_fc6 = atoi(wf) != 0;
         size_t ufl = 64 * (size_t)cmax * cmax;                        // F(6x6,3x3): 64 positions
-        if (m->wino_fc6 && m->fc6k == 7) ufl = std::max(ufl, 36 * 9 * (size_t)m->widths[4] * m->widths[5]);   // fc6: 36 positions x 9 sub-filters
+        if (m->fc6k == 7) ufl = std::max(ufl, 49 * 4 * (size_t)m->widths[4] * m->widths[5]);   // fc6: 49 positions x 4 sub-filters
         if ((e = hipMalloc((void**)&m->d_wino_u, ufl * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     }
     if ((e = hipMalloc((void**)&m->d_loss, (2 + 64) * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     m->d_regsum = m->d_loss + 1; m->d_lastbias = m->d_loss + 2;
     if ((e = hipMalloc((void**)&m->d_conf, cc * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&m->d_fp, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-    { const char* tg = getenv("FCN8S_TCONV_GEMM"); if (tg) m->tconv_gemm = atoi(tg) != 0; }
     m->tg_kp = (4 * m->C + 63) / 64 * 64;
-    if (m->tconv_gemm) {
+    {
         const size_t NC = 64 * (size_t)m->C, KP = (size_t)m->tg_kp;
         if ((e = hipMalloc((void**)&m->tg_b2, 4 * (size_t)m->C * NC * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
         if ((e = hipMalloc((void**)&m->tg_b2t, NC * KP * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
@@ -1216,10 +1213,53 @@ int fcn8s_set_precision(fcn8s_model* m, int precision)
         }
     }
     m->precision = precision;
-    set_mfma_split(precision == FCN8S_PREC_F32X3 ? 3 : 0);
     return FCN8S_OK;
 }
 int fcn8s_get_precision(const fcn8s_model* m) { return m ? m->precision : -1; }
+
+// Options select between maintained algorithm variants (parity reports separate the Winograd round-off from the summation order
+// with them); the defaults are the measured winners.  A model option drops the workspace and every cached filter bank.
+static int* model_option(fcn8s_model* m, const std::string& key)
+{
+    if (key == "winograd_min_cin") return &m->wino_min_cin;
+    if (key == "winograd_tile") return &m->wino_tile;
+    if (key == "winograd_fc6") return &m->wino_fc6;
+    if (key == "tconv_gemm") return &m->tconv_gemm;
+    return nullptr;
+}
+int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
+{
+    if (!key) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_option: null key");
+    const std::string k = key;
+    if (!m) {
+        if (k == "op_f32x3") { g_op_split = value ? 3 : 0; return FCN8S_OK; }
+        return fail(nullptr, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown process-wide option '" + k + "'");
+    }
+    int* slot = model_option(m, k);
+    if (!slot) return fail(m, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown option '" + k + "'");
+    if (k == "winograd_tile" && value != 2 && value != 4 && value != 6) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_tile must be 2, 4 or 6");
+    if (k == "winograd_min_cin" && value < 0) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_min_cin must be >= 0 (0 = direct convolution everywhere)");
+    if (*slot == (int)value) return FCN8S_OK;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    *slot = (k == "winograd_fc6" || k == "tconv_gemm") ? (value != 0) : (int)value;
+    if (m->arena) { hipFree(m->arena); m->arena = nullptr; m->arena_bytes = 0; m->N = m->H = m->W = 0; m->acts.clear(); }
+    m->have_forward = m->have_loss = false;
+    for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
+    m->u_cache.clear();
+    for (auto& kv : m->u_train) if (kv.second) hipFree(kv.second);
+    m->u_train.clear();
+    return FCN8S_OK;
+}
+int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value)
+{
+    if (!key || !value) return FCN8S_ERR_BAD_ARG;
+    const std::string k = key;
+    if (!m) { if (k == "op_f32x3") { *value = g_op_split == 3; return FCN8S_OK; } return FCN8S_ERR_NOT_FOUND; }
+    const int* slot = model_option(const_cast<fcn8s_model*>(m), k);
+    if (!slot) return FCN8S_ERR_NOT_FOUND;
+    *value = *slot;
+    return FCN8S_OK;
+}
 
 int fcn8s_set_stream(fcn8s_model* m, void* s) { if (!m) return FCN8S_ERR_BAD_ARG; m->stream = (hipStream_t)s; return FCN8S_OK; }
 int fcn8s_synchronize(fcn8s_model* m) { if (!m) return FCN8S_ERR_BAD_ARG; HIPCHK(m, hipStreamSynchronize(m->stream)); return FCN8S_OK; }
@@ -1675,6 +1715,50 @@ int fcn8s_op_conv2d_winograd(void* stream, const float* x, const float* w, const
     WinoEpi we; we.bias = bias; we.relu = relu;
     conv_winograd(nullptr, tile, K, "", x, w, y, u, v, mm, N, H, W, Cin, Cout, we, s, nullptr);
     hipStreamSynchronize(s); hipFree(u); hipFree(v); hipFree(mm);
+    OPCHK(); return FCN8S_OK;
+}
+
+int fcn8s_op_conv3x3_winograd_fwd_bwd(void* stream, const float* x, const float* w, const float* bias, const float* dy, const float* dx_addend,
+                                      float* y, float* pool, float* dx, float* dw, float* db,
+                                      int N, int H, int W, int Cin, int Cout, int tile, int pooled, int mask_mode)
+{
+    if ((tile != 2 && tile != 4 && tile != 6) || Cin % 64 || Cout % 64 || H % 2 || W % 2 || (tile != 6 && (H % tile || W % tile)) || !x || !w || !dy || !dx || !dw ||
+        (pooled && (!pool || tile < 4)) || (!pooled && !y) || mask_mode < 0 || mask_mode > 2)
+        return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv3x3_winograd_fwd_bwd: needs tile in {2,4,6}, Cin % 64 == 0, Cout % 64 == 0, even H and W (multiples of tile for tiles 2, 4), "
+                                                "pooled only with tiles 4 and 6, mask_mode in {0,1,2}");
+    hipStream_t s = (hipStream_t)stream;
+    // a bare model context: the launch sequences below are the model's own (conv_same / conv_wgrad), with one layer called "op"
+    fcn8s_model mm; fcn8s_model* m = &mm;
+    m->stream = s; m->wino_min_cin = 16; m->wino_tile = 6; m->wino_force_tile = tile; m->N = N; m->H = H; m->W = W;
+    m->precision = g_op_split == 3 ? FCN8S_PREC_F32X3 : FCN8S_PREC_F32;
+    const int al = tile + 2, P = al * al, cmax = std::max(Cin, Cout);
+    const size_t T = (size_t)wino_tiles(tile, N, H, W);
+    const size_t slab_max = (size_t)P * (size_t)wino_slab((long long)T, cmax), slab_in = (size_t)P * (size_t)wino_slab((long long)T, Cin);
+    std::vector<void*> owned;
+    auto dalloc = [&](size_t nfloats) -> float* { void* p = nullptr; if (hipMalloc(&p, nfloats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; } owned.push_back(p); return (float*)p; };
+    auto cleanup = [&]() { hipStreamSynchronize(s); for (void* p : owned) hipFree(p); for (auto& kv : m->u_train) if (kv.second) hipFree(kv.second); m->u_train.clear(); };
+    m->d_wino_u = dalloc((size_t)P * cmax * cmax); m->d_wino_v = dalloc(slab_max); m->d_wino_m = dalloc(slab_max);
+    float* wv = dalloc(slab_in); float* wt = dalloc((size_t)9 * Cin * Cout);
+    float* pidx = pooled ? dalloc(((size_t)N * (H / 2) * (W / 2) * Cout + 3) / 4) : nullptr;
+    float* rbits = mask_mode == 2 ? dalloc(wino_rbits_words(tile, N, H, W, Cin)) : nullptr;
+    if (!m->d_wino_u || !m->d_wino_v || !m->d_wino_m || !wv || !wt || (pooled && !pidx) || (mask_mode == 2 && !rbits)) { cleanup(); return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc"); }
+    Act a; a.p = wv; a.n = slab_in; m->acts["wv:op"] = a;
+    // forward (training mode: keeps V and the filter bank, writes the pool argmax bytes / the input's ReLU bit record)
+    m->fwd_train = true; m->train_mode = true;
+    { Epi e; e.bias = bias; e.relu = 1;
+      if (pooled) { e.pool_out = pool; e.pool_idx = (unsigned char*)pidx; e.skip_y = y == nullptr; }
+      if (mask_mode == 2) { e.in_relu_bits_out = (unsigned*)rbits; e.in_layer = "prev"; }
+      conv_same(m, "op", x, w, y, N, H, W, Cin, Cout, 3, e, s, 0, "op"); }
+    // backward: weight + bias gradient in the Winograd domain, then the data gradient (adjoint form for tile 6)
+    hipMemsetAsync(dw, 0, (size_t)9 * Cin * Cout * sizeof(float), s);
+    if (db) hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), s);
+    conv_wgrad(m, "op", x, dy, dw, db, N, H, W, Cin, Cout, 3, 1.f, s, 0, "op", tile >= 4, pooled ? (const unsigned char*)pidx : nullptr);
+    { Epi e; e.dgrad = 1; e.w_fwd = w; e.lazy_wt = 1; e.addend = dx_addend;
+      if (mask_mode) { e.mask = x; e.mask_scale = 1.f; }
+      if (mask_mode == 2 && m->rbits_ok.count("prev")) e.relu_bits_in = (const unsigned*)rbits;
+      conv_same(m, "op", dy, wt, dx, N, H, W, Cout, Cin, 3, e, s, 0, "op"); }
+    cleanup();
+    m->acts.clear();
     OPCHK(); return FCN8S_OK;
 }
 

@@ -99,8 +99,8 @@ template <> struct WinoMat<4, 4> {                  // F(4,4), points 0, 1, -1, 
     }
 };
 
-// VEC floats per lane along the channel axis.  F(2x2): 16 bytes (float4).  F(4x4): 8 bytes (float2) -- the 6x6 tile
-// of float4 needs 170-200 VGPRs (2 waves/SIMD); with float2 the same kernels fit 4+ waves/SIMD, which these
+// VEC floats per lane along the channel axis.  F(2x2): 16 bytes (four floats).  F(4x4): 8 bytes (two floats) -- the 6x6 tile
+// of four floats per lane needs 170-200 VGPRs (2 waves/SIMD); with float2 the same kernels fit 4+ waves/SIMD, which these
 // HBM-bound kernels need to keep enough loads in flight.
 template <int VEC> struct alignas(VEC * 4) VecF {
     float d[VEC];
@@ -113,7 +113,7 @@ template <int VEC> static __device__ __forceinline__ VecF<VEC> vfma(float s, con
 }
 #define f4fma vfma<VEC>
 #define f4zero vzero<VEC>
-#define float4 VecF<VEC>
+#define VF VecF<VEC>
 
 // ---- filters: u[xi][sub*Cin + ci][co] = (G g_sub G^T)[xi];  g_sub = taps (3a..3a+2, 3b..3b+2) of the KS x KS filter -----
 // transpose_out (nsub == 1 only): u[xi][co][ci] instead of u[xi][ci][co] -- the B operand of the data gradient computed as the
@@ -162,23 +162,10 @@ __global__ void wino_filter_kernel(const float* w, float* u, int Cin, int Cout, 
 // plus a scalar offset (the first version recomputed the full NHWC index per access: ~350 quarter-rate integer
 // multiplies per tile, more VALU time than the HBM time of the bytes it moved).
 struct TileIdx { int n, ty, tx, c; long long t; bool ok; };
-// Optional XCD-banded order (FCN8S_WINO_XCD_BAND=1).  The hardware deals consecutive workgroups round-robin to the 8 XCDs (each
-// with its own L2), so with the plain (x fastest, tile row next) order vertically adjacent tile rows -- which share two input
-// rows (input transform) or the neighbours' border positions (gather form of the adjoint data gradient) -- land on different
-// L2s and the shared rows are fetched twice over the fabric (+22 % / +28 % FETCH_SIZE in the PMC pass).  Banded, XCD k takes the
-// k-th contiguous band of tile rows: workgroup L is the (L / 8)-th of XCD L % 8 and gets logical index (L % 8) * (B / 8) + L / 8
-// (tile_grid pads the row count to a multiple of 8 so that B % 8 == 0; rows >= N * th do nothing).  Measured: no change in any
-// transform kernel's duration (the second fetch is served by the memory-side cache, not HBM), so the plain order stays the default.
-__device__ int g_wino_xcd_band = 0;
 static __device__ __forceinline__ TileIdx tile_index(int th, int tw, int C4, int N)
 {
     TileIdx r;
-    unsigned bx = blockIdx.x, by = blockIdx.y;
-    if (g_wino_xcd_band) {
-        const unsigned L = by * gridDim.x + bx, per = gridDim.x * gridDim.y / 8;
-        const unsigned Lp = (L & 7) * per + (L >> 3);
-        by = Lp / gridDim.x; bx = Lp - by * gridDim.x;
-    }
+    const unsigned bx = blockIdx.x, by = blockIdx.y;
     const int idx = bx * 256 + threadIdx.x;
     r.tx = idx / C4; r.c = idx - r.tx * C4;
     r.n = by / th; r.ty = by - r.n * th;
@@ -188,19 +175,12 @@ static __device__ __forceinline__ TileIdx tile_index(int th, int tw, int C4, int
 }
 static inline dim3 tile_grid(int N, int th, int tw, int C4, int z = 1)
 {
-    static const bool once = [] {
-        const char* e = getenv("FCN8S_WINO_XCD_BAND");
-        const int v = e ? atoi(e) : 0;
-        if (v != 0) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_xcd_band), &v, sizeof v);
-        return true;
-    }();
-    (void)once;
-    return dim3((unsigned)((tw * C4 + 255) / 256), (unsigned)((N * th + 7) / 8 * 8), (unsigned)z);
+    return dim3((unsigned)((tw * C4 + 255) / 256), (unsigned)(N * th), (unsigned)z);
 }
 
 // ---- input: one thread = one m x m output tile x VEC channels; alpha x alpha patch (zero outside), V = B^T d B --------
 template <int M, int VEC, int R>
-__global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restrict__ x, float4* __restrict__ v, int N, int H, int W, int C4, int pad, int nsub,
+__global__ __launch_bounds__(256) void wino_input_kernel(const VF* __restrict__ x, VF* __restrict__ v, int N, int H, int W, int C4, int pad, int nsub,
                                                          long long slab, unsigned* __restrict__ rbits_out)
 {
     constexpr int A = WinoMat<M, R>::A;
@@ -217,14 +197,14 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restric
     const TileIdx ti = tile_index(th, tw, C4, N);
     if (!ti.ok) return;
     const int y0 = M * ti.ty + R * sa - pad, x0 = M * ti.tx + R * sb - pad;
-    const float4* xp = x + (((long long)ti.n * H + y0) * W + x0) * C4 + ti.c;     // dereferenced only where (row, col) lies inside the image
+    const VF* xp = x + (((long long)ti.n * H + y0) * W + x0) * C4 + ti.c;     // dereferenced only where (row, col) lies inside the image
     bool rok[A], cok[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) { rok[a] = (unsigned)(y0 + a) < (unsigned)H; cok[a] = (unsigned)(x0 + a) < (unsigned)W; }
-    float4 q[A][A];                            // q = B^T d, built column by column so that d is never fully live
+    VF q[A][A];                            // q = B^T d, built column by column so that d is never fully live
 #pragma unroll
     for (int b = 0; b < A; ++b) {
-        float4 d[A];
+        VF d[A];
 #pragma unroll
         for (int a = 0; a < A; ++a) d[a] = (rok[a] && cok[b]) ? xp[(a * W + b) * C4] : f4zero();
         if (rbits_out && b >= 1 && b <= M) {
@@ -238,7 +218,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restric
         }
 #pragma unroll
         for (int a = 0; a < A; ++a) {
-            float4 s = f4zero();
+            VF s = f4zero();
 #pragma unroll
             for (int k = 0; k < A; ++k) if (WinoMat<M, R>::bt(a, k) != 0.f) s = f4fma(WinoMat<M, R>::bt(a, k), d[k], s);
             q[a][b] = s;
@@ -248,12 +228,12 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restric
 #pragma unroll
         for (int j = 0; j < RW; ++j) rbits_out[(ti.t * C4 + ti.c) * RW + j] = rb[j];
     }
-    float4* vp = v + ti.t * ldv + sub * C4 + ti.c;
+    VF* vp = v + ti.t * ldv + sub * C4 + ti.c;
 #pragma unroll
     for (int a = 0; a < A; ++a)
 #pragma unroll
         for (int b = 0; b < A; ++b) {          // V = q B
-            float4 s = f4zero();
+            VF s = f4zero();
 #pragma unroll
             for (int k = 0; k < A; ++k) if (WinoMat<M, R>::bt(b, k) != 0.f) s = f4fma(WinoMat<M, R>::bt(b, k), q[a][k], s);
             vp[(a * A + b) * slab] = s;
@@ -265,7 +245,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float4* __restric
 // POOL: dy is not materialised -- it is the max-pool backward of dpool [N,H/2,W/2,C] routed by the argmax bytes the forward
 // output transform kept (dy[pixel] = dpool[window] if the pixel is the window's first maximum and that maximum is > 0).
 template <int M, int VEC, bool POOL>
-__global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __restrict__ x, float4* __restrict__ v, float4* __restrict__ dm,
+__global__ __launch_bounds__(256) void wino_input_dout_kernel(const VF* __restrict__ x, VF* __restrict__ v, VF* __restrict__ dm,
                                                               int N, int H, int W, int C4, long long slab, const unsigned char* __restrict__ pidx)
 {
     constexpr int A = M + 2, NW = M / 2 + 2;           // NW: pool windows one patch row / column touches
@@ -273,24 +253,24 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
     const TileIdx ti = tile_index(th, tw, C4, N);
     if (!ti.ok) return;
     const int y0 = M * ti.ty - 1, x0 = M * ti.tx - 1;
-    const float4* xp = x + (((long long)ti.n * H + y0) * W + x0) * C4 + ti.c;
+    const VF* xp = x + (((long long)ti.n * H + y0) * W + x0) * C4 + ti.c;
     bool rok[A], cok[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) { rok[a] = (unsigned)(y0 + a) < (unsigned)H; cok[a] = (unsigned)(x0 + a) < (unsigned)W; }
-    float4 q[A][A], p[A][M];
+    VF q[A][A], p[A][M];
     // POOL: the patch rows y0..y0+M+1 = M ty - 1 .. M ty + M touch window rows (M/2) ty - 1 .. (M/2) ty + M/2 (NW of them); same for columns
     const int Hp = H / 2, Wp = W / 2;
     const long long wbase = (((long long)ti.n * Hp + ((M / 2) * ti.ty - 1)) * Wp + ((M / 2) * ti.tx - 1)) * C4 + ti.c;
 #pragma unroll
     for (int b = 0; b < A; ++b) {
-        float4 d[A];
+        VF d[A];
         if (POOL) {
             const int wc = (b + 1) >> 1;                                   // window column 0..3 of patch column b; (x0 + b) & 1 == (b + 1) & 1
 #pragma unroll
             for (int wr = 0; wr < NW; ++wr) {                              // window rows; patch rows 2wr-1, 2wr
                 const bool wok = (unsigned)((M / 2) * ti.ty - 1 + wr) < (unsigned)Hp && (unsigned)((M / 2) * ti.tx - 1 + wc) < (unsigned)Wp;
                 const long long wo = wbase + ((long long)wr * Wp + wc) * C4;
-                float4 g = f4zero();
+                VF g = f4zero();
                 unsigned char id[VEC];
                 _Pragma("unroll") for (int i = 0; i < VEC; ++i) id[i] = 4;
                 if (wok) { g = x[wo]; _Pragma("unroll") for (int i = 0; i < VEC; ++i) id[i] = pidx[wo * VEC + i]; }
@@ -307,7 +287,7 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
         }
 #pragma unroll
         for (int a = 0; a < A; ++a) {
-            float4 s = f4zero();
+            VF s = f4zero();
 #pragma unroll
             for (int k = 0; k < A; ++k) if (WinoMat<M, 3>::bt(a, k) != 0.f) s = f4fma(WinoMat<M, 3>::bt(a, k), d[k], s);
             q[a][b] = s;
@@ -315,7 +295,7 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
         if (b >= 1 && b <= M) {
 #pragma unroll
             for (int a = 0; a < A; ++a) {
-                float4 s = f4zero();
+                VF s = f4zero();
 #pragma unroll
                 for (int k = 0; k < M; ++k) if (WinoMat<M, 3>::at(k, a) != 0.f) s = f4fma(WinoMat<M, 3>::at(k, a), d[k + 1], s);
                 p[a][b - 1] = s;
@@ -327,7 +307,7 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
     for (int a = 0; a < A; ++a)
 #pragma unroll
         for (int b = 0; b < A; ++b) {
-            float4 s = f4zero();
+            VF s = f4zero();
 #pragma unroll
             for (int k = 0; k < A; ++k) if (WinoMat<M, 3>::bt(b, k) != 0.f) s = f4fma(WinoMat<M, 3>::bt(b, k), q[a][k], s);
             v[o + (a * A + b) * slab] = s;
@@ -336,7 +316,7 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
     for (int a = 0; a < A; ++a)
 #pragma unroll
         for (int b = 0; b < A; ++b) {
-            float4 s = f4zero();
+            VF s = f4zero();
 #pragma unroll
             for (int k = 0; k < M; ++k) if (WinoMat<M, 3>::at(k, b) != 0.f) s = f4fma(WinoMat<M, 3>::at(k, b), p[a][k], s);
             dm[o + (a * A + b) * slab] = s;
@@ -346,10 +326,10 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const float4* __re
 // ---- output: one thread = one tile x VEC channels; Y = A^T M A, then the conv epilogue --------------------------------
 // DROPOUT is a template parameter: the inlined Philox rounds (fc6 only) otherwise cost every launch their registers.
 template <int M, int VEC, bool DROPOUT, int R, bool POOL>
-__global__ __launch_bounds__(256, 3) void wino_output_kernel(const float4* __restrict__ m, const float4* __restrict__ bias, const float4* __restrict__ addend,
-                                                          const float4* __restrict__ mask, float mask_scale, int relu, float4* __restrict__ y,
+__global__ __launch_bounds__(256, 3) void wino_output_kernel(const VF* __restrict__ m, const VF* __restrict__ bias, const VF* __restrict__ addend,
+                                                          const VF* __restrict__ mask, float mask_scale, int relu, VF* __restrict__ y,
                                                           int N, int H, int W, int C4, float keep, unsigned long long seed, unsigned int stream_id,
-                                                          long long slab, float4* __restrict__ pool, unsigned char* __restrict__ pidx,
+                                                          long long slab, VF* __restrict__ pool, unsigned char* __restrict__ pidx,
                                                           unsigned* __restrict__ rbits_out, const unsigned* __restrict__ rbits_in)
 {
     constexpr int A = WinoMat<M, R>::A;
@@ -362,38 +342,38 @@ __global__ __launch_bounds__(256, 3) void wino_output_kernel(const float4* __res
     unsigned rb[RW];
 #pragma unroll
     for (int j = 0; j < RW; ++j) rb[j] = rbits_in ? rbits_in[(ti.t * C4 + ti.c) * RW + j] : 0u;
-    const float4* mp = m + ti.t * C4 + ti.c;
-    float4 q[M][A];                            // q = A^T M, column by column
+    const VF* mp = m + ti.t * C4 + ti.c;
+    VF q[M][A];                            // q = A^T M, column by column
 #pragma unroll
     for (int b = 0; b < A; ++b) {
-        float4 col[A];
+        VF col[A];
 #pragma unroll
         for (int a = 0; a < A; ++a) col[a] = mp[(a * A + b) * slab];
 #pragma unroll
         for (int o = 0; o < M; ++o) {
-            float4 s = f4zero();
+            VF s = f4zero();
 #pragma unroll
             for (int k = 0; k < A; ++k) if (WinoMat<M, R>::at(o, k) != 0.f) s = f4fma(WinoMat<M, R>::at(o, k), col[k], s);
             q[o][b] = s;
         }
     }
-    const float4 bv = bias ? bias[ti.c] : f4zero();
+    const VF bv = bias ? bias[ti.c] : f4zero();
     const long long off0 = (((long long)ti.n * H + M * ti.ty) * W + M * ti.tx) * C4 + ti.c;
     constexpr int PW = POOL ? M / 2 : 1;       // POOL: the launch also writes the 2x2/2 max-pool (a template flag keeps the other 80 % of the launches lean)
-    float4 pmax[PW][PW];                       // the 2x2/2 max-pool of this tile (tile origins are even), written below
+    VF pmax[PW][PW];                       // the 2x2/2 max-pool of this tile (tile origins are even), written below
     unsigned char parg[PW][PW][VEC];           // pidx != nullptr: which window element is the FIRST maximum (0..3; 4 = max not > 0, i.e. no
                                                // gradient through the ReLU) -- the routing rule of maxpool_bwd_kernel, kept for the backward pass
 #pragma unroll
     for (int oy = 0; oy < M; ++oy)
 #pragma unroll
         for (int ox = 0; ox < M; ++ox) {
-            float4 v = bv;
+            VF v = bv;
 #pragma unroll
             for (int k = 0; k < A; ++k) if (WinoMat<M, R>::at(ox, k) != 0.f) v = f4fma(WinoMat<M, R>::at(ox, k), q[oy][k], v);
             const long long off = off0 + (oy * W + ox) * C4;
             const bool inside = M * ti.ty + oy < H && M * ti.tx + ox < W;              // false only in partial edge tiles
             if (!inside) { if (POOL && (oy & 1) == 0 && (ox & 1) == 0) { pmax[POOL ? oy / 2 : 0][POOL ? ox / 2 : 0] = v; _Pragma("unroll") for (int i = 0; i < VEC; ++i) parg[POOL ? oy / 2 : 0][POOL ? ox / 2 : 0][i] = 0; } continue; }
-            if (addend) { const float4 ad = addend[off]; _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] += ad.d[i]; }
+            if (addend) { const VF ad = addend[off]; _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] += ad.d[i]; }
             if (relu) { _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = fmaxf(v.d[i], 0.f); }
             if (rbits_in) {
                 _Pragma("unroll") for (int i = 0; i < VEC; ++i) {
@@ -402,7 +382,7 @@ __global__ __launch_bounds__(256, 3) void wino_output_kernel(const float4* __res
                     v.d[i] = ((rb[bit >> 5] >> (bit & 31)) & 1u) ? v.d[i] * mask_scale : 0.f;
                 }
             } else if (mask) {
-                const float4 k = mask[off];
+                const VF k = mask[off];
                 _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = k.d[i] > 0.f ? v.d[i] * mask_scale : 0.f;
             }
             if (DROPOUT) {                     // same Philox stream as the direct kernel's epilogue: element index NHWC
@@ -451,18 +431,18 @@ __global__ __launch_bounds__(256, 3) void wino_output_kernel(const float4* __res
 // POOL: dy is not materialised -- it is the max-pool backward of dpool [N,H/2,W/2,C] routed by the argmax bytes the forward output
 // transform kept (see wino_input_dout_kernel); tile origins are even, so a tile covers whole windows.
 template <int M, int VEC, int R, bool POOL>
-__global__ __launch_bounds__(256) void wino_dout_kernel(const float4* __restrict__ dy, float4* __restrict__ dm, int N, int H, int W, int C4, long long slab,
+__global__ __launch_bounds__(256) void wino_dout_kernel(const VF* __restrict__ dy, VF* __restrict__ dm, int N, int H, int W, int C4, long long slab,
                                                         const unsigned char* __restrict__ pidx)
 {
     constexpr int A = WinoMat<M, R>::A;
     const int th = (H + M - 1) / M, tw = (W + M - 1) / M;      // partial tiles at the bottom / right edge (F(6x6): 512 = 85 * 6 + 2)
     const TileIdx ti = tile_index(th, tw, C4, N);
     if (!ti.ok) return;
-    const float4* yp = dy + (((long long)ti.n * H + M * ti.ty) * W + M * ti.tx) * C4 + ti.c;
+    const VF* yp = dy + (((long long)ti.n * H + M * ti.ty) * W + M * ti.tx) * C4 + ti.c;
     const int Hp = H / 2, Wp = W / 2;
     // POOL: the (M/2)^2 windows of the tile -- gradient and argmax bytes -- are all requested up front (one load latency per
     // thread instead of one per window column: the kernel spent 40 % of its time on these 15 % of its bytes)
-    float4 pg[POOL ? M / 2 : 1][POOL ? M / 2 : 1];
+    VF pg[POOL ? M / 2 : 1][POOL ? M / 2 : 1];
     unsigned pid[POOL ? M / 2 : 1][POOL ? M / 2 : 1];
     if (POOL) {
 #pragma unroll
@@ -482,14 +462,14 @@ __global__ __launch_bounds__(256) void wino_dout_kernel(const float4* __restrict
                 }
             }
     }
-    float4 q[A][M];                            // q = A dY  (A = (A^T)^T)
+    VF q[A][M];                            // q = A dY  (A = (A^T)^T)
 #pragma unroll
     for (int ox = 0; ox < M; ++ox) {
-        float4 col[M];
+        VF col[M];
         if (POOL) {
 #pragma unroll
             for (int wr = 0; wr < M / 2; ++wr) {
-                const float4 g = pg[wr][ox / 2];
+                const VF g = pg[wr][ox / 2];
                 const unsigned w = pid[wr][ox / 2];
                 _Pragma("unroll") for (int half = 0; half < 2; ++half) {
                     const unsigned pos = half * 2 + (ox & 1);
@@ -502,18 +482,18 @@ __global__ __launch_bounds__(256) void wino_dout_kernel(const float4* __restrict
         }
 #pragma unroll
         for (int a = 0; a < A; ++a) {
-            float4 s = f4zero();
+            VF s = f4zero();
 #pragma unroll
             for (int k = 0; k < M; ++k) if (WinoMat<M, R>::at(k, a) != 0.f) s = f4fma(WinoMat<M, R>::at(k, a), col[k], s);
             q[a][ox] = s;
         }
     }
-    float4* dp = dm + ti.t * C4 + ti.c;
+    VF* dp = dm + ti.t * C4 + ti.c;
 #pragma unroll
     for (int a = 0; a < A; ++a)
 #pragma unroll
         for (int b = 0; b < A; ++b) {          // dM = q A^T
-            float4 s = f4zero();
+            VF s = f4zero();
 #pragma unroll
             for (int k = 0; k < M; ++k) if (WinoMat<M, R>::at(k, b) != 0.f) s = f4fma(WinoMat<M, R>::at(k, b), q[a][k], s);
             dp[(a * A + b) * slab] = s;
@@ -529,9 +509,9 @@ __global__ __launch_bounds__(256) void wino_dout_kernel(const float4* __restrict
 // from slabs other threads of the same wave stream anyway.  Compared with transforming dY a second time (V' = B^T dY_patch B) this
 // removes one [P][T][C] write per layer from the backward pass.
 template <int VEC>
-__global__ __launch_bounds__(256, 2) void wino_dgrad_output_kernel(const float4* __restrict__ dv, const float4* __restrict__ addend,
-                                                                   const float4* __restrict__ mask, float mask_scale, const unsigned* __restrict__ rbits_in,
-                                                                   float4* __restrict__ y, int N, int H, int W, int C4, long long slab)
+__global__ __launch_bounds__(256, 2) void wino_dgrad_output_kernel(const VF* __restrict__ dv, const VF* __restrict__ addend,
+                                                                   const VF* __restrict__ mask, float mask_scale, const unsigned* __restrict__ rbits_in,
+                                                                   VF* __restrict__ y, int N, int H, int W, int C4, long long slab)
 {
     constexpr int M = 6, A = 8;
     typedef WinoMat<6, 3> WM;
@@ -543,15 +523,15 @@ __global__ __launch_bounds__(256, 2) void wino_dgrad_output_kernel(const float4*
     unsigned rb[RW];
 #pragma unroll
     for (int j = 0; j < RW; ++j) rb[j] = rbits_in ? rbits_in[o * RW + j] : 0u;
-    float4 tt[M][A];                           // tt[i][b] = sum_a B^T(a, i+1) dV[a][b]   (patch rows 1..6)
+    VF tt[M][A];                           // tt[i][b] = sum_a B^T(a, i+1) dV[a][b]   (patch rows 1..6)
 #pragma unroll
     for (int b = 0; b < A; ++b) {
-        float4 col[A];
+        VF col[A];
 #pragma unroll
         for (int a = 0; a < A; ++a) col[a] = dv[(a * A + b) * slab + o];
 #pragma unroll
         for (int i = 0; i < M; ++i) {
-            float4 s = f4zero();
+            VF s = f4zero();
 #pragma unroll
             for (int a = 0; a < A; ++a) if (WM::bt(a, i + 1) != 0.f) s = f4fma(WM::bt(a, i + 1), col[a], s);
             tt[i][b] = s;
@@ -559,19 +539,19 @@ __global__ __launch_bounds__(256, 2) void wino_dgrad_output_kernel(const float4*
     }
     // neighbours' border contributions
     const bool up = ti.ty > 0, down = ti.ty + 1 < th, left = ti.tx > 0, right = ti.tx + 1 < tw;
-    float4 nrow[2][M], ncol[2][M], corner[2][2];      // [0] = top / left, [1] = bottom / right
+    VF nrow[2][M], ncol[2][M], corner[2][2];      // [0] = top / left, [1] = bottom / right
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const bool okr = e == 0 ? up : down, okc = e == 0 ? left : right;
         const long long orow = o + (e == 0 ? -(long long)tw : (long long)tw) * C4, ocol = o + (e == 0 ? -1 : 1) * (long long)C4;
         const int pa = e == 0 ? 7 : 0;                 // the neighbour's position row / column that reaches into this region
         const float edge = WM::bt(pa, pa);             // the single non-zero of B's row `pa`
-        float4 r[A], c[A];
+        VF r[A], c[A];
 #pragma unroll
         for (int k = 0; k < A; ++k) { r[k] = okr ? dv[(pa * A + k) * slab + orow] : f4zero(); c[k] = okc ? dv[(k * A + pa) * slab + ocol] : f4zero(); }
 #pragma unroll
         for (int j = 0; j < M; ++j) {
-            float4 sr = f4zero(), sc = f4zero();
+            VF sr = f4zero(), sc = f4zero();
 #pragma unroll
             for (int k = 0; k < A; ++k) if (WM::bt(k, j + 1) != 0.f) { sr = f4fma(WM::bt(k, j + 1), r[k], sr); sc = f4fma(WM::bt(k, j + 1), c[k], sc); }
             _Pragma("unroll") for (int v = 0; v < VEC; ++v) { sr.d[v] *= edge; sc.d[v] *= edge; }
@@ -582,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void wino_dgrad_output_kernel(const float4*
             const bool okf = f == 0 ? left : right;
             const int pb = f == 0 ? 7 : 0;
             const long long oc = orow + (f == 0 ? -1 : 1) * (long long)C4;
-            float4 v = (okr && okf) ? dv[(pa * A + pb) * slab + oc] : f4zero();
+            VF v = (okr && okf) ? dv[(pa * A + pb) * slab + oc] : f4zero();
             _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] *= edge * WM::bt(pb, pb);
             corner[e][f] = v;
         }
@@ -592,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void wino_dgrad_output_kernel(const float4*
     for (int oy = 0; oy < M; ++oy)
 #pragma unroll
         for (int ox = 0; ox < M; ++ox) {
-            float4 v = f4zero();
+            VF v = f4zero();
 #pragma unroll
             for (int b = 0; b < A; ++b) if (WM::bt(b, ox + 1) != 0.f) v = f4fma(WM::bt(b, ox + 1), tt[oy][b], v);
             if (oy == 0)     { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += nrow[0][ox].d[k]; }
@@ -602,14 +582,14 @@ __global__ __launch_bounds__(256, 2) void wino_dgrad_output_kernel(const float4*
             if ((oy == 0 || oy == M - 1) && (ox == 0 || ox == M - 1)) { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += corner[oy == 0 ? 0 : 1][ox == 0 ? 0 : 1].d[k]; }
             if (!(M * ti.ty + oy < H && M * ti.tx + ox < W)) continue;                   // partial edge tiles
             const long long off = off0 + (oy * W + ox) * C4;
-            if (addend) { const float4 ad = addend[off]; _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += ad.d[k]; }
+            if (addend) { const VF ad = addend[off]; _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += ad.d[k]; }
             if (rbits_in) {
                 _Pragma("unroll") for (int k = 0; k < VEC; ++k) {
                     const int bit = (oy * M + ox) * VEC + k;
                     v.d[k] = ((rb[bit >> 5] >> (bit & 31)) & 1u) ? v.d[k] * mask_scale : 0.f;
                 }
             } else if (mask) {
-                const float4 mk = mask[off];
+                const VF mk = mask[off];
                 _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] = mk.d[k] > 0.f ? v.d[k] * mask_scale : 0.f;
             }
             y[off] = v;
@@ -660,24 +640,24 @@ __global__ void wino_dfilter_kernel(const float* du, float* dw, int Cin, int Cou
 // and u = Ry + 1 (patch rows 0..2 = region rows 1..3), each reached by (ty', sa) = (u, 0) and (u - 1, 1): 4 x 4 = 16 patches per
 // region, each transformed only in the rows / columns the region needs.  dV is read ~4x (L2), 205 MB at 16 x 1024x512.
 template <int KY, int KX, int VEC>
-static __device__ __forceinline__ void sub44_gather(const float4* __restrict__ dv, long long slab, int ldv, int C4, const TileIdx& ti, int th, int tw,
-                                                    float4 (&out)[4][4])
+static __device__ __forceinline__ void sub44_gather(const VF* __restrict__ dv, long long slab, int ldv, int C4, const TileIdx& ti, int th, int tw,
+                                                    VF (&out)[4][4])
 {
     typedef WinoMat<4, 4> WM;
     constexpr int SA = KY & 1, DTY = KY == 0 ? 0 : KY == 1 ? -1 : KY == 2 ? 1 : 0, A0 = KY < 2 ? 3 : 0, R0 = KY < 2 ? 0 : 1, NR = KY < 2 ? 4 : 3;
     constexpr int SB = KX & 1, DTX = KX == 0 ? 0 : KX == 1 ? -1 : KX == 2 ? 1 : 0, B0 = KX < 2 ? 3 : 0, S0 = KX < 2 ? 0 : 1, NS = KX < 2 ? 4 : 3;
     const int ty = ti.ty + DTY, tx = ti.tx + DTX;
     if ((unsigned)ty >= (unsigned)th || (unsigned)tx >= (unsigned)tw) return;
-    const float4* p = dv + (((long long)ti.n * th + ty) * tw + tx) * ldv + (SA * 2 + SB) * C4 + ti.c;
-    float4 tmp[NR][7];
+    const VF* p = dv + (((long long)ti.n * th + ty) * tw + tx) * ldv + (SA * 2 + SB) * C4 + ti.c;
+    VF tmp[NR][7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-        float4 g[7];
+        VF g[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) g[i] = p[(i * 7 + j) * slab];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {                 // rows: dd[a][.] = sum_i B^T[i][a] dV[i][.]
-            float4 t = f4zero();
+            VF t = f4zero();
 #pragma unroll
             for (int i = 0; i < 7; ++i) if (WM::bt(i, A0 + r) != 0.f) t = f4fma(WM::bt(i, A0 + r), g[i], t);
             tmp[r][j] = t;
@@ -687,20 +667,20 @@ static __device__ __forceinline__ void sub44_gather(const float4* __restrict__ d
     for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int c = 0; c < NS; ++c) {                 // columns: dd[a][b] = sum_j (.)[a][j] B^T[j][b]
-            float4 t = out[R0 + r][S0 + c];
+            VF t = out[R0 + r][S0 + c];
 #pragma unroll
             for (int j = 0; j < 7; ++j) if (WM::bt(j, B0 + c) != 0.f) t = f4fma(WM::bt(j, B0 + c), tmp[r][j], t);
             out[R0 + r][S0 + c] = t;
         }
 }
 template <int VEC>
-__global__ __launch_bounds__(256) void wino_dgrad_output_sub44_kernel(const float4* __restrict__ dv, float4* __restrict__ dx, int N, int H, int W, int C4, long long slab)
+__global__ __launch_bounds__(256) void wino_dgrad_output_sub44_kernel(const VF* __restrict__ dv, VF* __restrict__ dx, int N, int H, int W, int C4, long long slab)
 {
     const int th = H / 4, tw = W / 4;
     const TileIdx ti = tile_index(th, tw, C4, N);
     if (!ti.ok) return;
     const int ldv = C4 * 4;
-    float4 out[4][4];
+    VF out[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -709,7 +689,7 @@ __global__ __launch_bounds__(256) void wino_dgrad_output_sub44_kernel(const floa
                           sub44_gather<KY_, 2, VEC>(dv, slab, ldv, C4, ti, th, tw, out); sub44_gather<KY_, 3, VEC>(dv, slab, ldv, C4, ti, th, tw, out)
     FCN8S_S44ROW(0); FCN8S_S44ROW(1); FCN8S_S44ROW(2); FCN8S_S44ROW(3);
 #undef FCN8S_S44ROW
-    float4* o = dx + (((long long)ti.n * H + 4 * ti.ty) * W + 4 * ti.tx) * C4 + ti.c;
+    VF* o = dx + (((long long)ti.n * H + 4 * ti.ty) * W + 4 * ti.tx) * C4 + ti.c;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -718,16 +698,12 @@ __global__ __launch_bounds__(256) void wino_dgrad_output_sub44_kernel(const floa
 
 #undef f4fma
 #undef f4zero
-#undef float4
+#undef VF
 
 // ---- launchers (tile = 2 or 4; KS = 3, or 7 = grid of r x r sub-filters, r = wino_r(7)) ------------------------------------
-static int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-// sub-filter size used for a KS x KS kernel: 3 for the 3x3 layers; fc6 (7x7): 4 (2x2 grid, F(4x4,4x4)) unless FCN8S_WINOGRAD_FC6_R=3
-int wino_r(int KS)
-{
-    static const int r7 = env_flag("FCN8S_WINOGRAD_FC6_R", 4) == 3 ? 3 : 4;
-    return KS == 3 ? 3 : r7;
-}
+// sub-filter size used for a KS x KS kernel: 3 for the 3x3 layers; fc6 (7x7): 4 (2x2 grid of 4x4 sub-filters, F(4x4,4x4); a 3x3 grid of
+// 3x3 sub-filters through F(4x4,3x3) was measured slower in round 1: 20.25 instead of 12.25 multiplies per output)
+int wino_r(int KS) { return KS == 3 ? 3 : 4; }
 int wino_nsub(int KS) { const int r = wino_r(KS); return (KS + r - 1) / r; }
 // 32-bit words of the ReLU bit mask a [N,H,W,C] output of tile size `tile` needs (launch_wino_output's rbits_out / rbits_in)
 size_t wino_rbits_words(int tile, int N, int H, int W, int C)
@@ -742,8 +718,7 @@ int wino_alpha(int tile, int KS) { return tile + (tile == 6 ? 3 : wino_r(KS)) - 
 // same time.  The skew (4 KiB + 256 B) staggers the slabs across channels.
 long long wino_slab(long long T, int C)
 {
-    static const int skew = env_flag("FCN8S_WINO_SKEW", 1088) / 4 * 4;
-    return T * C + skew;
+    return T * C + 1088;
 }
 void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, int KS, hipStream_t s, int transpose_out)
 {
@@ -755,20 +730,14 @@ void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, i
     else if (tile == 4)               hipLaunchKernelGGL((wino_filter_kernel<4, 3>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub, transpose_out);
     else                              hipLaunchKernelGGL((wino_filter_kernel<2, 3>), dim3(g), dim3(256), 0, s, w, u, Cin, Cout, KS, nsub, transpose_out);
 }
-bool wino_dgrad_adjoint_enabled() { static const int on = env_flag("FCN8S_WINO_DGRAD_ADJOINT", 1); return on != 0; }
 void launch_wino_dgrad_output(const float* dv, const float* addend, const float* mask, float mask_scale, const unsigned* rbits_in, float* y,
                               int N, int H, int W, int C, hipStream_t s)
 {
     constexpr int M_ = 6;
-    static const int vec = env_flag("FCN8S_WINO_DGRAD_VEC", 2);
     const long long T = (long long)N * ((H + M_ - 1) / M_) * ((W + M_ - 1) / M_);
-    // (the ReLU bit words are laid out per (tile, channel pair): the one-channel-per-lane variant is only used without them)
-    if (vec == 1 && !rbits_in)
-        hipLaunchKernelGGL((wino_dgrad_output_kernel<1>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C), dim3(256), 0, s,
-                           (const VecF<1>*)dv, (const VecF<1>*)addend, (const VecF<1>*)mask, mask_scale, rbits_in, (VecF<1>*)y, N, H, W, C, wino_slab(T, C));
-    else
-        hipLaunchKernelGGL((wino_dgrad_output_kernel<2>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / 2), dim3(256), 0, s,
-                           (const VecF<2>*)dv, (const VecF<2>*)addend, (const VecF<2>*)mask, mask_scale, rbits_in, (VecF<2>*)y, N, H, W, C / 2, wino_slab(T, C) / 2);
+    // two channels per lane (one per lane was measured slower, and the ReLU bit words are laid out per (tile, channel pair))
+    hipLaunchKernelGGL((wino_dgrad_output_kernel<2>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / 2), dim3(256), 0, s,
+                       (const VecF<2>*)dv, (const VecF<2>*)addend, (const VecF<2>*)mask, mask_scale, rbits_in, (VecF<2>*)y, N, H, W, C / 2, wino_slab(T, C) / 2);
 }
 // dv: [49][T][4 * C] (T = N * H/4 * W/4 tiles, columns = sub-filter x channel), dx: [N,H,W,C]; H, W % 4 == 0, C % 2 == 0
 void launch_wino_dgrad_output_sub44(const float* dv, float* dx, int N, int H, int W, int C, hipStream_t s)
@@ -777,10 +746,9 @@ void launch_wino_dgrad_output_sub44(const float* dv, float* dx, int N, int H, in
     hipLaunchKernelGGL((wino_dgrad_output_sub44_kernel<2>), tile_grid(N, H / 4, W / 4, C / 2), dim3(256), 0, s,
                        (const VecF<2>*)dv, (VecF<2>*)dx, N, H, W, C / 2, wino_slab(T, 4 * C) / 2);
 }
-bool wino_fuse_dz_enabled() { static const int on = env_flag("FCN8S_WINO_FUSE_DZ", 1); return on != 0; }
 bool launch_wino_input_dout(int tile, const float* dy, float* v, float* dm, int N, int H, int W, int C, hipStream_t s, const unsigned char* pidx)
 {
-    if (!wino_fuse_dz_enabled() || (tile != 4 && tile != 6) || H % 2 || W % 2 || C % 2) return false;
+    if ((tile != 4 && tile != 6) || H % 2 || W % 2 || C % 2) return false;
     const int th = (H + tile - 1) / tile, tw = (W + tile - 1) / tile;
 #define FCN8S_WFUSE(M_, V_, P_) hipLaunchKernelGGL((wino_input_dout_kernel<M_, V_, P_>), tile_grid(N, th, tw, C / V_), dim3(256), 0, s, \
         (const VecF<V_>*)dy, (VecF<V_>*)v, (VecF<V_>*)dm, N, H, W, C / V_, wino_slab((long long)N * th * tw, C) / V_, pidx)
@@ -820,13 +788,9 @@ void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W,
 {
 #define FCN8S_WDOUT(M_, V_, R_) hipLaunchKernelGGL((wino_dout_kernel<M_, V_, R_, false>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / V_), dim3(256), 0, s, \
         (const VecF<V_>*)dy, (VecF<V_>*)dm, N, H, W, C / V_, wino_slab((long long)N * ((H + M_ - 1) / M_) * ((W + M_ - 1) / M_), C) / V_, nullptr)
-    static const int vec6 = env_flag("FCN8S_WINO_DOUT_VEC", 2), vec6p = env_flag("FCN8S_WINO_DOUT_POOL_VEC", 2);   // (16-byte lanes measured: the plain variant 5 % slower, the pooled one 7 % slower than 8-byte lanes)
-    if (tile == 6 && pidx && vec6p == 4 && C % 4 == 0)
-                                      hipLaunchKernelGGL((wino_dout_kernel<6, 4, 3, true>), tile_grid(N, (H + 5) / 6, (W + 5) / 6, C / 4), dim3(256), 0, s,
-                                                         (const VecF<4>*)dy, (VecF<4>*)dm, N, H, W, C / 4, wino_slab((long long)N * ((H + 5) / 6) * ((W + 5) / 6), C) / 4, pidx);
-    else if (tile == 6 && pidx)       hipLaunchKernelGGL((wino_dout_kernel<6, 2, 3, true>), tile_grid(N, (H + 5) / 6, (W + 5) / 6, C / 2), dim3(256), 0, s,
+    // (8-byte lanes; 16-byte lanes were measured 5 % slower for the plain variant and 7 % slower for the pool-routing one)
+    if (tile == 6 && pidx)       hipLaunchKernelGGL((wino_dout_kernel<6, 2, 3, true>), tile_grid(N, (H + 5) / 6, (W + 5) / 6, C / 2), dim3(256), 0, s,
                                                          (const VecF<2>*)dy, (VecF<2>*)dm, N, H, W, C / 2, wino_slab((long long)N * ((H + 5) / 6) * ((W + 5) / 6), C) / 2, pidx);
-    else if (tile == 6 && vec6 == 4 && C % 4 == 0) FCN8S_WDOUT(6, 4, 3);
     else if (tile == 6)               FCN8S_WDOUT(6, 2, 3);
     else if (tile == 4 && wino_r(KS) == 4) FCN8S_WDOUT(4, 2, 4);
     else if (tile == 4)               FCN8S_WDOUT(4, 2, 3);

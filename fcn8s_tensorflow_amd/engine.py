@@ -72,7 +72,8 @@ class Staged:
 
 
 class Engine:
-    def __init__(self, num_classes, widths=None, fc6_ksize=7, device_id=0, seed=0, process_group=None, precision='fp32', logical_classes=None):
+    def __init__(self, num_classes, widths=None, fc6_ksize=7, device_id=0, seed=0, process_group=None, precision='fp32', logical_classes=None,
+                 options=None):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("fcn8s_tensorflow_amd needs an AMD GPU (gfx950); there is no CPU fallback for the hot path")
@@ -102,6 +103,8 @@ class Engine:
         self.h = h
         self.widths = tuple(widths) if widths else (64, 128, 256, 512, 512, 4096, 4096)
         self.set_precision(precision)
+        for k, v in (options or {}).items():        # algorithm variants for parity reports (include/fcn8s_hip.h: fcn8s_set_option)
+            self.set_option(k, v)
         self.specs = OrderedDict()          # name -> (shape, offset)
         for i in range(L.lib.fcn8s_num_params(self.h)):
             name = C.c_char_p(); nd = C.c_int32(); shp = (C.c_int64 * 4)(); off = C.c_int64()
@@ -351,6 +354,15 @@ class Engine:
         code that writes into `flat_params` through torch must call `freeze(False)` first."""
         L.check(L.lib.fcn8s_freeze_params(self.h, 1 if frozen else 0), self.h)
 
+    def set_option(self, key, value):
+        """fcn8s_set_option: 'winograd_min_cin', 'winograd_tile', 'winograd_fc6', 'tconv_gemm' (defaults = the measured winners)."""
+        L.check(L.lib.fcn8s_set_option(self.h, key.encode(), int(value)), self.h)
+
+    def get_option(self, key):
+        v = C.c_int64()
+        L.check(L.lib.fcn8s_get_option(self.h, key.encode(), C.byref(v)), self.h)
+        return int(v.value)
+
     def set_precision(self, precision):
         """'fp32' (the reference's arithmetic), 'bf16_fc' (BASELINE config 5: forward fc6 / fc7 with bf16-rounded
         operands on the bf16 MFMA, fp32 accumulation; the rest of the step stays fp32) or 'f32x3' (every large GEMM on the
@@ -556,6 +568,22 @@ class Engine:
         a = np.empty(shape, np.float32)
         L.check(L.lib.fcn8s_get_activation(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size), self.h)
         return a
+
+    def relu_branches(self, nhw):
+        """Which ReLU units were on in the last forward pass: {name: bool array (N,h,w,c)} for the convs that feed another conv, each
+        block's pool (a block's last conv is never materialised; max(relu(z)) > 0 says the same for the window's maximum), fc6 and fc7
+        (with keep_prob 1).  Parity tests hand these to the checker so that both sides differentiate along the same branches."""
+        N, H, W = (int(x) for x in nhw)
+        out = OrderedDict()
+        h, w = H, W
+        for b, nconv in enumerate((2, 2, 3, 3, 3), start=1):
+            for i in range(1, nconv):
+                out["conv%d_%d" % (b, i)] = self.activation("conv%d_%d" % (b, i), (N, h, w, self.widths[b - 1])) > 0
+            h //= 2; w //= 2
+            out["pool%d" % b] = self.activation("pool%d" % b, (N, h, w, self.widths[b - 1])) > 0
+        out["fc6"] = self.activation("fc6", (N, h, w, self.widths[5])) > 0
+        out["fc7"] = self.activation("fc7", (N, h, w, self.widths[6])) > 0
+        return out
 
     def dropout_masks(self, shape6, shape7):
         m6 = np.empty(shape6, np.float32); m7 = np.empty(shape7, np.float32)

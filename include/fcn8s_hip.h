@@ -174,6 +174,19 @@ int fcn8s_freeze_params(fcn8s_model* m, int frozen);
 int fcn8s_set_precision(fcn8s_model* m, int precision);
 int fcn8s_get_precision(const fcn8s_model* m);
 
+/* Algorithm options (not in the reference).  They select between maintained variants of the same arithmetic so that a parity report can
+ * separate Winograd round-off from summation order; the defaults are the measured winners and production code never sets them.
+ *   model options (m != NULL; setting one drops the workspace and all cached filter banks):
+ *     "winograd_min_cin"  64   3x3 layers with at least this many input channels run through Winograd; 0 = direct convolution everywhere
+ *     "winograd_tile"     6    largest 3x3 output tile (6, 4 or 2); per layer the allowed tile with the fewest multiplies is used
+ *     "winograd_fc6"      1    fc6 as a 2x2 grid of 4x4 sub-filters through F(4x4,4x4); 0 = direct 7x7
+ *     "tconv_gemm"        1    the 16x16/8 transposed conv as one GEMM over output blocks (blocked logits); 0 = 64 sub-pixel phases
+ *   process-wide option (m == NULL), for the op-level entry points below, which have no model:
+ *     "op_f32x3"          0    their LDS-DMA GEMMs use the split-bf16 arithmetic of FCN8S_PREC_F32X3
+ * Unknown keys return FCN8S_ERR_NOT_FOUND. */
+int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value);
+int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value);
+
 int fcn8s_get_activation(fcn8s_model* m, const char* name, float* host, size_t nfloats);
 int fcn8s_get_dropout_masks(fcn8s_model* m, float* host_mask6, size_t n6, float* host_mask7, size_t n7);
 
@@ -214,6 +227,21 @@ int fcn8s_op_conv2d(void* stream, const float* x, const float* w_hwio, const flo
  * decomposition into 4x4 sub-filters, F(4x4,4x4)) */
 int fcn8s_op_conv2d_winograd(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,
                              int N, int H, int W, int Cin, int Cout, int K, int relu, int tile);
+/* One 3x3 SAME conv + bias + ReLU the way the model's 3x3 layers run in a TRAINING step, forward and backward, through the model's own
+ * launch sequences (Winograd F(tile x tile, 3x3), tile = 2, 4 or 6; Cin, Cout multiples of 64):
+ *   forward   y = relu(conv(x, w) + bias), keeping the transformed input V and the filter bank U; pooled != 0: the output transform
+ *             also writes pool = maxpool2x2(y) [N,H/2,W/2,Cout] and one argmax byte per window (y may then be NULL: a block's last
+ *             conv output is never materialised);
+ *   backward  dy = gradient w.r.t. the PRE-activation [N,H,W,Cout] (pooled == 0), or w.r.t. the pool output [N,H/2,W/2,Cout]
+ *             (pooled != 0: max-pool and ReLU backward happen inside the transform, routed by the argmax bytes);
+ *             dM = A dY A^T once; dw = Winograd-domain weight gradient V^T dM; db from dM's (1,1) slab; dx = data gradient, for tile 6
+ *             as the adjoint of the forward algorithm (dV = dM U^T on the transposed-B GEMM, overlap-add gather), for tiles 2 / 4 as a
+ *             forward-type Winograd conv on flipped filters; + dx_addend (optional skip gradient), then masked by (x > 0) if
+ *             mask_mode = 1 (x read as the mask) or 2 (one-bit record written by this conv's input transform, the conv1_1 case).
+ * Not in the reference; exists so that the Winograd backward has op-level parity tests. */
+int fcn8s_op_conv3x3_winograd_fwd_bwd(void* stream, const float* x, const float* w_hwio, const float* bias, const float* dy, const float* dx_addend,
+                                      float* y, float* pool, float* dx, float* dw, float* db,
+                                      int N, int H, int W, int Cin, int Cout, int tile, int pooled, int mask_mode);
 /* the same SAME conv with bf16-rounded operands and fp32 accumulation on the bf16 MFMA (FCN8S_PREC_BF16_FC's kernel);
  * Cin % 32 == 0, Cout % 128 == 0, K odd */
 int fcn8s_op_conv2d_bf16(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,

@@ -177,21 +177,33 @@ def _bf16_round(t):
     return t.detach().to(torch.bfloat16).to(t.dtype)
 
 
-def _fc_conv(x, w, b, bf16):
-    """fc6 / fc7: SAME conv + bias + ReLU.  bf16: the forward VALUE is the contraction of the bf16-rounded operands
-    (fp32 products and sums); the backward pass is the fp32 conv gradient taken with the unrounded operands -- the
-    mode only changes the forward arithmetic (BASELINE config 5: "bf16 fwd / fp32 accum")."""
-    if not bf16:
-        return conv2d_same_t(x, w, b, relu=True)
-    z = conv2d_same_t(x, w, b)
-    z = z + (conv2d_same_t(_bf16_round(x), _bf16_round(w), b.detach()) - z).detach()
+def _relu_branch(z, name, branches):
+    """ReLU -- or, when `branches` holds a 0/1 tensor for `name`, multiplication by that record of which units are on.
+    Gradient parity is only defined where both sides take the same ReLU branches: a pre-activation that one side computes as
+    -1e-7 of the layer's range and the other as +1e-7 (both inside fp32 round-off) switches one element of dZ on.  A parity test
+    feeds the branches the device took (see `branches_from_activations`) and checks separately that they differ from this
+    restatement's own only at units within round-off of zero."""
+    if branches is not None and name in branches:
+        return z * branches[name]
     return F.relu(z)
 
 
-def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False):
+def _fc_conv(x, w, b, bf16, name=None, branches=None):
+    """fc6 / fc7: SAME conv + bias + ReLU.  bf16: the forward VALUE is the contraction of the bf16-rounded operands
+    (fp32 products and sums); the backward pass is the fp32 conv gradient taken with the unrounded operands -- the
+    mode only changes the forward arithmetic (BASELINE config 5: "bf16 fwd / fp32 accum")."""
+    z = conv2d_same_t(x, w, b)
+    if bf16:
+        z = z + (conv2d_same_t(_bf16_round(x), _bf16_round(w), b.detach()) - z).detach()
+    return _relu_branch(z, name, branches)
+
+
+def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False, branches=None):
     """Forward pass on torch tensors.  P: name -> torch tensor (TF layouts).
     images_t: NHWC RGB float.  masks: optional (mask6, mask7) NHWC tensors.
     bf16_fc: BASELINE config 5 -- both operands of the fc6 / fc7 contractions rounded to bfloat16, fp32 accumulate.
+    branches: optional name -> 0/1 NCHW tensor ("conv1_1" ... for the convs that feed another conv, "pool1".."pool5" for each block's
+    last conv + pool, "fc6", "fc7"): the ReLU branches to take instead of this restatement's own (see _relu_branch).
     Returns logits NCHW (and the activation dict when keep=True)."""
     acts = OrderedDict()
     x = _nchw(preprocess_t(images_t))
@@ -199,21 +211,26 @@ def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False)
     for blk, nconv in enumerate(CONVS_PER_BLOCK, start=1):
         for i in range(1, nconv + 1):
             n = "conv%d_%d" % (blk, i)
-            x = conv2d_same_t(x, P[n + "/filter"], P[n + "/biases"], relu=True)
+            pooled_branch = branches is not None and i == nconv and ("pool%d" % blk) in branches
+            z = conv2d_same_t(x, P[n + "/filter"], P[n + "/biases"])
+            # (a block's last conv: max(relu(z)) = relu(max(z)), so its branch record lives on the pooled tensor)
+            x = z if pooled_branch else _relu_branch(z, n, branches)
             if keep:
-                acts[n] = x
+                acts[n] = F.relu(z) if pooled_branch else x
         x = maxpool2x2_t(x)
+        if branches is not None and ("pool%d" % blk) in branches:
+            x = x * branches["pool%d" % blk]
         pools[blk] = x
         if keep:
             acts["pool%d" % blk] = x
     m6 = m7 = None
     if masks is not None:
         m6, m7 = (_nchw(m) for m in masks)
-    x = _fc_conv(x, P["fc6/weights"], P["fc6/biases"], bf16_fc)
+    x = _fc_conv(x, P["fc6/weights"], P["fc6/biases"], bf16_fc, "fc6", branches)
     x = dropout_t(x, keep_prob, m6)
     if keep:
         acts["fc6"] = x
-    x = _fc_conv(x, P["fc7/weights"], P["fc7/biases"], bf16_fc)
+    x = _fc_conv(x, P["fc7/weights"], P["fc7/biases"], bf16_fc, "fc7", branches)
     x = dropout_t(x, keep_prob, m7)
     if keep:
         acts["fc7"] = x
@@ -259,13 +276,23 @@ def forward(params, images, keep_prob=1.0, masks=None, dtype=torch.float32, keep
         return _nhwc(out).contiguous().numpy()
 
 
+def branch_layers():
+    """Names whose ReLU branches `branches=` can carry: convs that feed another conv, each block's pool, fc6, fc7."""
+    names = []
+    for blk, nconv in enumerate(CONVS_PER_BLOCK, start=1):
+        names += ["conv%d_%d" % (blk, i) for i in range(1, nconv)] + ["pool%d" % blk]
+    return names + ["fc6", "fc7"]
+
+
 def loss_and_grads(params, images, labels_onehot, l2_rate=0.0, keep_prob=1.0, masks=None,
-                   dtype=torch.float32, bf16_fc=False):
+                   dtype=torch.float32, bf16_fc=False, branches=None):
     """total_loss and d(total_loss)/d(every variable) -- what
-    AdamOptimizer.minimize differentiates (var_list=None, :257)."""
+    AdamOptimizer.minimize differentiates (var_list=None, :257).
+    branches: optional name -> NHWC bool/0-1 array of post-ReLU activations that are on (activation > 0), see forward_t."""
     P = _params_t(params, dtype, requires_grad=True)
     mt = None if masks is None else tuple(_t(m, dtype) for m in masks)
-    logits = forward_t(P, _t(images, dtype), keep_prob, mt, bf16_fc=bf16_fc)
+    bt = None if branches is None else {k: _nchw(_t(np.asarray(v) > 0, dtype)) for k, v in branches.items()}
+    logits = forward_t(P, _t(images, dtype), keep_prob, mt, bf16_fc=bf16_fc, branches=bt)
     loss = total_loss_t(P, logits, _t(labels_onehot, dtype), l2_rate)
     grads = torch.autograd.grad(loss, list(P.values()))
     return (float(loss.detach()),

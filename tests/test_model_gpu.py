@@ -86,7 +86,8 @@ def test_forward_logits_and_argmax(widths, n, h, w):
 @pytest.mark.parametrize("widths,n,h,w,l2", [(SMALL, 2, 64, 64, 0.0), (SMALL, 1, 32, 96, 1e-2), (None, 1, 32, 32, 0.0),
                                                 (None, 2, 32, 64, 0.0),    # full width, W % 64 == 0: the specialised conv1_1 / 3x3 wgrad kernels
                                                 (SMALL, 1, 128, 128, 1e-3),   # 4x4 fc6 map: fc6 through the Winograd sub-filter decomposition
-                                                (SMALL, 1, 96, 160, 1e-3), (SMALL, 2, 64, 224, 0.0)])   # sizes that are not multiples of the 6x6 tile in any block
+                                                (SMALL, 1, 96, 160, 1e-3), (SMALL, 2, 64, 224, 0.0),    # sizes that are not multiples of the 6x6 tile in any block
+                                                ((64, 192, 192, 64, 64, 128, 192), 1, 96, 160, 0.0)])   # widths (192) the transposed-B GEMM of the adjoint data gradients does not take
 def test_gradients(widths, n, h, w, l2):
     P, img, lab = tie_free_case(widths, n, h, w, seed=2)
     e = make_engine(widths)
@@ -174,45 +175,60 @@ def test_bf16_fc_mode_config5(widths, n, h, w):
     e.close(); e2.close()
 
 
+def branch_disagreement(e, P, img, nhw):
+    """(branches the device took, number of ReLU units where they differ from the oracle's own, largest |activation| -- relative to the
+    layer's largest -- at such a unit on whichever side has it on).  A differing unit is legitimate only if it sits within fp32
+    round-off of zero."""
+    br = e.relu_branches(nhw)
+    _, acts = orc.forward(P, img, keep=True)
+    n_diff, worst = 0, 0.0
+    for k, on in br.items():
+        ref = acts[k]
+        d = on != (ref > 0)
+        if d.any():
+            n_diff += int(d.sum())
+            gpu = e.activation(k, ref.shape)
+            worst = max(worst, float(np.maximum(np.abs(gpu[d]), np.abs(ref[d])).max() / (np.abs(ref).max() + 1e-30)))
+    return br, n_diff, worst
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f32x3"])
 @pytest.mark.parametrize("widths,n,h,w,l2", [(None, 2, 32, 64, 0.0), (SMALL, 1, 128, 128, 1e-3), (SMALL, 1, 96, 160, 1e-3)])
-def test_f32x3_mode_holds_the_fp32_tolerances(widths, n, h, w, l2):
-    """FCN8S_PREC_F32X3: the large GEMMs run on the bf16 MFMA with every fp32 operand split exactly into three bf16 pieces.  Not
-    bit-identical to fp32, but as accurate: the same element-wise bounds as the fp32 tests (logits 1e-3, gradients 2e-3 of each
-    tensor's range), and the split kernels are the ones that ran (profile view keyed by kernel symbol).
-    Gradient parity is only defined where both sides take the same ReLU / max-pool branches: a pre-activation the oracle computes
-    as -1e-7 of the layer's range and the GPU as +1e-7 (both inside fp32 round-off) switches one element of dZ on.  On random cases
-    that happens to the fp32 mode and to this mode equally often (seeds 2..15 at full width, 2 x 32 x 64: 5 and 6 of 14 cases; all
-    others agree with the oracle to 1e-4 in both modes), so the test takes the first seed whose ReLU / pool branches agree --
-    i.e. where the bounds hold -- and requires one among eight."""
+def test_gradients_along_the_device_branches(precision, widths, n, h, w, l2):
+    """Gradient parity on a FIXED seed in both arithmetic modes, made independent of ReLU coin flips: a pre-activation the oracle computes as
+    -1e-7 of the layer's range and the GPU as +1e-7 (both inside fp32 round-off) switches one element of dZ on, which moves a whole
+    row of a weight gradient by far more than any tolerance (on random full-width cases at 2 x 32 x 64 that happens in 5 of 14 seeds).
+    So the oracle differentiates along the branches the device took (Engine.relu_branches -> oracle `branches=`), and the test checks
+    separately that those differ from the oracle's own only at units within round-off of zero.  FCN8S_PREC_F32X3 (every large GEMM on
+    the bf16 MFMA, fp32 operands split exactly into three bf16 pieces) must hold the same bounds as fp32 and must have run the split kernels."""
     e = make_engine(widths)
-    e.set_precision('f32x3')
-    tried = []
-    for seed in range(2, 10):
-        P = orc.init_params(20, widths or orc.DEFAULT_WIDTHS, seed=seed, decoder_std_scale=30.0, bias_std=0.05)
-        img, lab = batch(n, h, w, seed=seed + 100)
-        e.set_params(P)
-        e.profile(2); e.profile_reset()
-        loss = e.forward_backward(img, orc.one_hot(lab, 20), keep_prob=1.0, l2_rate=l2)
-        kernels = [k for k in e.profile_results() if k.startswith("kernel:")]
-        e.profile(0)
+    e.set_precision(precision)
+    seed = 2
+    P = orc.init_params(20, widths or orc.DEFAULT_WIDTHS, seed=seed, decoder_std_scale=30.0, bias_std=0.05)
+    img, lab = batch(n, h, w, seed=seed + 100)
+    e.set_params(P)
+    e.profile(2); e.profile_reset()
+    loss = e.forward_backward(img, orc.one_hot(lab, 20), keep_prob=1.0, l2_rate=l2)
+    kernels = [k for k in e.profile_results() if k.startswith("kernel:")]
+    e.profile(0)
+    if precision == "f32x3":
         assert any("gemm_glds_x3_kernel" in k for k in kernels) and any("wgrad_glds_x3_kernel" in k for k in kernels), kernels
         assert not any("gemm_glds_kernel" in k or "wgrad_glds_kernel" in k for k in kernels), kernels
-        loss_ref, g_ref, _ = orc.loss_and_grads(P, img, orc.one_hot(lab, 20).astype(np.float32), l2_rate=l2)
-        assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))           # (the forward pass has no branch sensitivity at this level)
-        logits = e.activation("logits", (n, h, w, 20))
-        ref, _ = orc.forward(P, img, keep=True)
-        assert np.abs(logits - ref).max() < 1e-3 * max(1.0, np.abs(ref).max())
-        g = e.get_grads()
-        worst = max(rel(g[k], g_ref[k]) for k in g_ref)
-        tried.append((seed, worst))
-        if worst < 2e-3:
-            break
     else:
-        raise AssertionError("gradient bounds held for none of %r" % (tried,))
-    e.set_precision('fp32')
-    loss32 = e.forward_backward(img, orc.one_hot(lab, 20), keep_prob=1.0, l2_rate=l2)
-    assert abs(loss - loss32) < 1e-5 * max(1.0, abs(loss32))
-    print("f32x3 vs oracle (seed, worst gradient error):", tried)
+        assert not any("_x3_kernel" in k for k in kernels), kernels
+    g = e.get_grads()
+    logits = e.activation("logits", (n, h, w, 20))
+    br, n_diff, worst = branch_disagreement(e, P, img, (n, h, w))
+    n_units = sum(v.size for v in br.values())
+    assert n_diff <= 1e-4 * n_units and worst < 1e-5, (n_diff, n_units, worst)       # only units within round-off of zero may differ
+    loss_ref, g_ref, logits_ref = orc.loss_and_grads(P, img, orc.one_hot(lab, 20).astype(np.float32), l2_rate=l2, branches=br)
+    assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    assert np.abs(logits - logits_ref).max() < 1e-3 * max(1.0, np.abs(logits_ref).max())
+    errs = {k: rel(g[k], g_ref[k]) for k in g_ref}
+    worst_k = max(errs, key=errs.get)
+    print("%s %s: %d of %d ReLU units differ from the oracle's (largest such activation %.1e of its layer's max); worst gradient error %s %.2e"
+          % (precision, (widths, n, h, w), n_diff, n_units, worst, worst_k, errs[worst_k]))
+    assert errs[worst_k] < 1e-3, (worst_k, errs[worst_k])
     e.close()
 
 
@@ -354,6 +370,39 @@ def test_out_of_range_label_ids_are_ignored():
     for k in g_ref:
         assert rel(g_ids[k], g_ref[k]) < 2e-3, k
     e.close()
+
+
+def test_algorithm_options():
+    """fcn8s_set_option: the maintained variants of the 3x3 stack (F(6x6) / F(4x4) / direct) and of the last transposed conv agree
+    with each other to fp32 round-off, options round-trip, unknown keys are errors."""
+    P = orc.init_params(20, SMALL, seed=5, decoder_std_scale=30.0, bias_std=0.05)
+    img, lab = batch(1, 96, 160, seed=3)
+    outs = {}
+    for name, opts in (("default", {}), ("f4", {"winograd_tile": 4}), ("direct", {"winograd_min_cin": 0, "winograd_fc6": 0}), ("phases", {"tconv_gemm": 0})):
+        e = make_engine(SMALL)
+        for k, v in opts.items():
+            e.set_option(k, v)
+            assert e.get_option(k) == v
+        e.set_params(P)
+        e.forward_backward(img, lab, keep_prob=1.0)
+        outs[name] = (e.activation("logits", (1, 96, 160, 20)), e.get_grads())
+        if name == "default":
+            assert e.get_option("winograd_tile") == 6 and e.get_option("winograd_min_cin") == 64
+            with pytest.raises(ValueError):
+                e.set_option("no_such_option", 1)
+            with pytest.raises(ValueError):
+                e.set_option("winograd_tile", 5)
+            e.set_option("winograd_tile", 4)                   # switching after a pass: the workspace is rebuilt
+            e.forward_backward(img, lab, keep_prob=1.0)
+            np.testing.assert_allclose(e.activation("logits", (1, 96, 160, 20)), outs["default"][0], rtol=0, atol=1e-3 * np.abs(outs["default"][0]).max())
+        e.close()
+    ref_l, ref_g = outs["direct"]
+    for name in ("default", "f4", "phases"):
+        l, g = outs[name]
+        assert np.abs(l - ref_l).max() < 1e-3 * np.abs(ref_l).max(), name
+        if name != "direct":
+            assert not np.array_equal(l, ref_l) or name == "phases"
+    assert not np.array_equal(outs["default"][0], outs["f4"][0])          # the options really select different arithmetic
 
 
 def test_errors_are_python_exceptions():

@@ -13,7 +13,11 @@ from oracle import fcn8s_oracle as orc  # noqa: E402  (checker only)
 
 
 def _lib():
+    import os
     from fcn8s_tensorflow_amd import _lib
+    # test_conv_ops_in_f32x3_mode_hold_the_fp32_tolerances re-runs this module with the op-level entry points switched to the split-bf16 arithmetic
+    if os.environ.get("FCN8S_TEST_OP_F32X3") == "1":
+        _lib.check(_lib.lib.fcn8s_set_option(None, b"op_f32x3", 1))
     return _lib
 
 
@@ -104,6 +108,74 @@ def test_conv3x3_winograd(N, H, W, Cin, Cout, tile, K=3):
     L.check(L.lib.fcn8s_op_conv2d(None, ptr(xd), ptr(wd), ptr(bd), ptr(yd), N, H, W, Cin, Cout, K, 1))
     torch.cuda.synchronize()
     assert rel_err(y_.cpu().numpy(), yd.cpu().numpy()) < tol       # and against the direct kernel
+
+
+WINO_BWD_CASES = [
+    # N, H, W, Cin, Cout, tile, pooled, mask_mode
+    (1, 34, 22, 64, 64, 6, 0, 0),        # ragged: partial edge tiles in both directions
+    (1, 34, 22, 64, 64, 6, 1, 2),        # ... with the pool routing and the one-bit ReLU record of the input (conv1_1 -> conv1_2)
+    (1, 96, 160, 64, 128, 6, 1, 1),
+    (2, 24, 36, 128, 128, 6, 0, 1),
+    (1, 46, 70, 128, 256, 6, 1, 0),
+    (1, 30, 54, 256, 256, 6, 1, 1),
+    (1, 18, 42, 256, 512, 6, 0, 2),
+    (1, 12, 24, 512, 512, 6, 1, 1),
+    (2, 12, 18, 192, 192, 6, 0, 1),      # widths the transposed-B GEMM does not take (N = 192): second, transposed filter bank
+    (1, 12, 18, 64, 192, 6, 1, 0),
+    (1, 16, 32, 64, 64, 4, 1, 1),        # F(4x4): the fused kernel that writes both backward operands from one read of dy
+    (2, 8, 16, 128, 256, 4, 0, 0),
+    (1, 8, 8, 512, 512, 4, 1, 1),
+    (1, 8, 12, 64, 128, 2, 0, 1),        # F(2x2) fallback
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,tile,pooled,mask_mode", WINO_BWD_CASES)
+def test_conv3x3_winograd_backward(N, H, W, Cin, Cout, tile, pooled, mask_mode):
+    """The 3x3 layers' real training path at op level: forward that keeps V / U / pool argmax bytes / ReLU bits, then the
+    Winograd-domain weight gradient, the bias gradient from dM's (1,1) slab and the data gradient -- for tile 6 the adjoint of the forward
+    algorithm on the transposed-B GEMM + overlap-add gather -- against float64 autograd.  Tolerance 1e-4 of each tensor's largest value
+    (the fp32 F(6x6,3x3) transforms carry ~2e-5 of the range per pass, tools/winograd_matrices.py)."""
+    L = _lib()
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = (0.3 * rng.standard_normal(Cout)).astype(np.float32)
+    skip = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    xt = torch.tensor(x).permute(0, 3, 1, 2).double().requires_grad_(True)
+    wt = torch.tensor(w).double().requires_grad_(True)
+    bt = torch.tensor(b).double().requires_grad_(True)
+    z = orc.conv2d_same_t(xt, wt, bt, relu=False)
+    yt = torch.relu(z)
+    if pooled:
+        out = orc.maxpool2x2_t(yt)
+        dy = rng.standard_normal((N, H // 2, W // 2, Cout)).astype(np.float32)
+        out.backward(torch.tensor(dy).permute(0, 3, 1, 2).double())
+    else:
+        dy = rng.standard_normal((N, H, W, Cout)).astype(np.float32)      # gradient w.r.t. the pre-activation (the ReLU mask is the consumer's job)
+        z.backward(torch.tensor(dy).permute(0, 3, 1, 2).double())
+        out = None
+    dx_ref = xt.grad.permute(0, 2, 3, 1).numpy() + skip
+    if mask_mode:
+        dx_ref = dx_ref * (x > 0)
+    dw_ref, db_ref = wt.grad.numpy(), bt.grad.numpy()
+    xd, wd, bd, dyd, sk = dev(x), dev(w), dev(b), dev(dy), dev(skip)
+    y_ = None if pooled else torch.empty(N, H, W, Cout).cuda()
+    pool_ = torch.empty(N, H // 2, W // 2, Cout).cuda() if pooled else None
+    dx_, dw_, db_ = torch.empty(N, H, W, Cin).cuda(), torch.empty(3, 3, Cin, Cout).cuda(), torch.empty(Cout).cuda()
+    L.check(L.lib.fcn8s_op_conv3x3_winograd_fwd_bwd(None, ptr(xd), ptr(wd), ptr(bd), ptr(dyd), ptr(sk), ptr(y_), ptr(pool_), ptr(dx_), ptr(dw_), ptr(db_),
+                                                    N, H, W, Cin, Cout, tile, pooled, mask_mode))
+    torch.cuda.synchronize()
+    tol = 2e-5 if tile == 2 else 1e-4
+    if pooled:
+        assert rel_err(pool_.cpu().numpy(), out.detach().permute(0, 2, 3, 1).numpy()) < tol
+    else:
+        assert rel_err(y_.cpu().numpy(), yt.detach().permute(0, 2, 3, 1).numpy()) < tol
+    assert rel_err(dx_.cpu().numpy(), dx_ref) < tol, rel_err(dx_.cpu().numpy(), dx_ref)
+    assert rel_err(dw_.cpu().numpy(), dw_ref) < tol, rel_err(dw_.cpu().numpy(), dw_ref)
+    assert rel_err(db_.cpu().numpy(), db_ref) < tol, rel_err(db_.cpu().numpy(), db_ref)
+    # exact zeros where the mask says so (integer work: bit-exact)
+    if mask_mode:
+        assert (dx_.cpu().numpy()[x <= 0] == 0).all()
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(1, 4, 4, 16, 32), (2, 8, 12, 64, 128), (1, 16, 32, 32, 64)])
@@ -270,10 +342,10 @@ def test_preprocess():
 
 
 def test_conv_ops_in_f32x3_mode_hold_the_fp32_tolerances():
-    """FCN8S_F32X3=1 routes every LDS-DMA GEMM of the op-level entry points through the split-bf16 kernels (the model-level switch
-    is fcn8s_set_precision): the convolution cases above must hold their fp32 tolerances (2e-5) unchanged."""
+    """fcn8s_set_option(NULL, "op_f32x3", 1) routes every LDS-DMA GEMM of the op-level entry points through the split-bf16 kernels (the
+    model-level switch is fcn8s_set_precision): the convolution cases above must hold their fp32 tolerances (2e-5) unchanged."""
     import os, subprocess, sys
-    env = dict(os.environ, FCN8S_F32X3="1")
+    env = dict(os.environ, FCN8S_TEST_OP_F32X3="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "conv and not f32x3"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
