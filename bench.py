@@ -40,12 +40,50 @@ def pmc_traffic(kernel):
         for name, v in d.get("kernels", {}).items():
             if name.replace(" ", "").startswith("voidfcn8s::" + kernel.replace(" ", "")) or name.replace(" ", "").startswith("fcn8s::" + kernel.replace(" ", "")):
                 out = {"hbm_mb_per_launch": v["hbm_mb_per_launch"], "fetch_mb": v["fetch_mb_per_launch"],
-                       "write_mb": v["write_mb_per_launch"], "source": d.get("source")}
+                       "write_mb": v["write_mb_per_launch"], "source": d.get("source"),
+                       "traffic_source": "committed profile (profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                         "command on an MI355X, tools/collect_profiles.sh) -- not measured in this run; `--live-traffic` re-measures it"}
                 if "fetch_mb_per_launch_uncorrected" in v:      # the x2 FETCH_SIZE correction is an upper bound for 64-byte row-segment loads
                     out["hbm_mb_per_launch_lower_bound"] = round(v["fetch_mb_per_launch_uncorrected"] + v["write_mb_per_launch"], 3)
                 return out
     except Exception:
         pass
+    return None
+
+
+def live_traffic(argv, kernel):
+    """Re-measure the HBM traffic of `kernel` now: two rocprofv3 PMC passes (FETCH_SIZE; WRITE_SIZE; --kernel-trace only, as the
+    microarch guide prescribes) over a 2-step run of this same command, summarised by tools/pmc_summary.py.  Minutes, hence opt-in."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    tmp = tempfile.mkdtemp(prefix="fcn8s_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    keep = [a for a in argv if a not in ("--live-traffic",)]
+    base = [sys.executable, os.path.abspath(__file__)] + keep + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--repeats", "1"]
+    try:
+        for ctr, d in (("FETCH_SIZE", "f"), ("WRITE_SIZE", "w")):
+            subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, d), "-o", "b", "--"] + base,
+                           env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
+        import glob
+        f = glob.glob(os.path.join(tmp, "f", "**", "b_counter_collection.csv"), recursive=True)[0]
+        w = glob.glob(os.path.join(tmp, "w", "**", "b_counter_collection.csv"), recursive=True)[0]
+        out = os.path.join(tmp, "t.json")
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), f, w, out, "live: rocprofv3 --pmc passes inside this bench run"],
+                       stdout=subprocess.DEVNULL, check=True)
+        d = json.load(open(out))
+        for name, v in d["kernels"].items():
+            n = name.replace(" ", "")
+            if n.startswith("voidfcn8s::" + kernel.replace(" ", "")) or n.startswith("fcn8s::" + kernel.replace(" ", "")):
+                return {"hbm_mb_per_launch": v["hbm_mb_per_launch"], "fetch_mb": v["fetch_mb_per_launch"], "write_mb": v["write_mb_per_launch"],
+                        "hbm_mb_per_launch_lower_bound": round(v["fetch_mb_per_launch_uncorrected"] + v["write_mb_per_launch"], 3),
+                        "traffic_source": "live (two rocprofv3 --pmc passes of this command, 2 steps each, run by bench.py --live-traffic)"}
+    except Exception as ex:
+        return {"error": repr(ex)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     return None
 
 
@@ -109,8 +147,11 @@ def cpu_baseline(h, w, seconds_budget=200.0, optimizer="sgd"):
     med = _median(t_c3)
     return {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": cores, "host_threads_available": ncpu, "kind": "port",
             "sample": "bs1 training step (fwd+bwd+%s) of one %dx%d image on torch-CPU fp32: 1 warm-up + %d timed, median %.1f s "
-                      "(CPU restatement of the reference graph; TF1 unavailable)"
-                      % ("TF-Adam" if optimizer == "adam" else "SGD+momentum", w, h, len(t_c3), med),
+                      "(CPU restatement of the reference graph; TF1 unavailable).  Deviations from SURVEY 8d, which asks for a bs2 step, "
+                      "3 warm-up + 10 timed, all physical cores: bs1 and 1 + <= 3 runs keep the leg inside the ~30 s budget of a default bench "
+                      "run (images/s does not depend on the batch size on the CPU), and %d of %d hardware threads because that count was "
+                      "the fastest of %s on the 256x256 leg (one-image oneDNN convolutions slow down beyond it)"
+                      % ("TF-Adam" if optimizer == "adam" else "SGD+momentum", w, h, len(t_c3), med, cores, ncpu, cands),
             "train_step_s": [round(t, 2) for t in t_c3],
             "c1_256x256_fwd_argmax": {"median_s": round(_median(t_c1), 3), "runs": len(t_c1), "images_per_sec": round(1.0 / _median(t_c1), 3)},
             "fwd_%dx%d_bs1" % (w, h): {"median_s": round(_median(t_c2), 3), "runs": len(t_c2), "images_per_sec": round(1.0 / _median(t_c2), 3)},
@@ -243,6 +284,11 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL); 'gloo' lets the "
                     "multi-rank path be exercised on a single-GPU box together with --device")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
+    ap.add_argument("--repeats", type=int, default=3, help="how many times the timed region of exactly --steps steps is run; value / ms_per_step "
+                    "are those of the median region, all regions are listed in `timed_regions_ms_per_step`")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="library algorithm option (fcn8s_set_option), e.g. winograd_tile=4")
+    ap.add_argument("--live-traffic", action="store_true", help="measure roofline.traffic now with two rocprofv3 --pmc passes (minutes) instead of "
+                    "reading the committed profile")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
@@ -258,7 +304,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev = local_rank if args.device is None else args.device
-    if world > 1:
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ      # torchrun, even with one rank: RCCL is initialised and used
+    if under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(dev)
@@ -273,7 +320,9 @@ def main():
             print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
     N, H, W = args.batch, args.height, args.width
     mark("process group up; creating engine")
-    eng = Engine(20, device_id=dev, seed=1234 + rank, precision=args.precision)
+    options = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.option}
+    eng = Engine(20, device_id=dev, seed=1234 + rank, precision=args.precision, options=options)
+    eng.dp_always = under_launcher                # a one-rank process group still runs the bucketed all-reduces (RCCL with one rank)
     eng.init_params(seed=0)                       # He-normal VGG, reference decoder init (same on every rank)
     mark("broadcast params")
     eng.broadcast_params(0)
@@ -293,7 +342,7 @@ def main():
             eng.predict(images, argmax=True)
 
     def fence():
-        if world > 1:
+        if under_launcher:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -302,17 +351,27 @@ def main():
         mark("warmup step %d enqueued" % i)
     fence()
     mark("warmup done")
-    # ---- the timed region: exactly K steps, no in-library event recording
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    mark("timed region done")
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # ---- the timed region: exactly K steps between two fences (barrier + device sync), no in-library event recording; the MAX over
+    # ranks is the region's time.  The region is run --repeats times; the median region is the one reported (all are listed).
+    regions, per_rank_regions = [], []
+    for _ in range(max(1, args.repeats)):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt_local = time.perf_counter() - t0
+        if under_launcher:
+            allt = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+            dist.all_gather(allt, torch.tensor([dt_local], dtype=torch.float64, device="cuda"))
+            per_rank = [float(x.item()) for x in allt]
+        else:
+            per_rank = [dt_local]
+        regions.append(max(per_rank)); per_rank_regions.append(per_rank)
+    mark("timed regions done")
+    order = sorted(range(len(regions)), key=lambda i: regions[i])
+    mid = order[(len(order) - 1) // 2]
+    dt = regions[mid]
+    per_rank_ms = [round(t / args.steps * 1e3, 3) for t in per_rank_regions[mid]]
     # ---- a second pass over the same steps with the library's HIP events on (recorded on the launch stream, one pair per
     # kernel launch): per-kernel durations for the roofline block.  Kept out of the timed region (the event pairs cost ~1 %).
     psteps = min(args.steps, 10)
@@ -331,7 +390,7 @@ def main():
         v["launches"] = int(round(v["launches"] * args.steps / psteps))
     # ---- data-parallel runs: what the gradient exchange costs
     comm = None
-    if world > 1 and args.mode == "train":
+    if under_launcher and args.mode == "train":
         per_bucket = []
         for off, n in eng.buckets:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -351,9 +410,40 @@ def main():
         tt = torch.tensor([local_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         local_ms = float(tt.item())
-        comm = {"backend": args.backend, "rccl_ranks": dist.get_world_size(), "bucket_mb": [round(n * 4 / 1e6, 1) for _, n in eng.buckets],
+        # issue -> complete timestamps of each bucket's all-reduce inside the step (ms after the step's first kernel; averaged over psteps)
+        eng.comm_trace = []
+        fence()
+        for _ in range(psteps):
+            eng.train_step(images, labels, 1e-4, keep_prob=0.5, l2_rate=0.0, optimizer=opt, fetch_loss=False)
+        fence()
+        tr, eng.comm_trace = eng.comm_trace, None
+        nb = len(eng.buckets)
+        issue, done, span = [0.0] * nb, [0.0] * nb, 0.0
+        start = None
+        for kind, a, b in tr:
+            if kind == "step":
+                start = a
+            elif kind == "end":
+                span += start.elapsed_time(a) / psteps
+            else:
+                issue[kind] += start.elapsed_time(a) / psteps
+                done[kind] += start.elapsed_time(b) / psteps
+        busy, cur_s, cur_e = 0.0, None, None            # union of the [issue, complete] intervals
+        for s_, e_ in sorted(zip(issue, done)):
+            if cur_e is None or s_ > cur_e:
+                busy += (cur_e - cur_s) if cur_e is not None else 0.0
+                cur_s, cur_e = s_, e_
+            else:
+                cur_e = max(cur_e, e_)
+        busy += (cur_e - cur_s) if cur_e is not None else 0.0
+        exposed = dt / args.steps * 1e3 - local_ms
+        comm = {"backend": args.backend, "rccl_ranks": dist.get_world_size() if args.backend == "nccl" else 0, "ranks": dist.get_world_size(),
+                "bucket_mb": [round(n * 4 / 1e6, 1) for _, n in eng.buckets],
                 "allreduce_ms_per_bucket_standalone": per_bucket, "local_only_ms_per_step": round(local_ms, 3),
-                "exposed_comm_ms_per_step": round(dt / args.steps * 1e3 - local_ms, 3)}
+                "exposed_comm_ms_per_step": round(exposed, 3),
+                "bucket_issue_ms": [round(x, 3) for x in issue], "bucket_complete_ms": [round(x, 3) for x in done],
+                "step_span_ms_traced": round(span, 3), "comm_busy_ms_per_step": round(busy, 3),
+                "overlap_frac": (round(max(0.0, min(1.0, 1.0 - max(exposed, 0.0) / busy)), 4) if busy > 0 else None)}
         eng.broadcast_params(0)                   # the local-only steps let the replicas drift; re-align before the final loss
     loss = eng.forward_backward(images, labels, keep_prob=1.0) if args.mode == "train" else None
 
@@ -371,7 +461,9 @@ def main():
         if dom:
             g = kern[dom]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-            tr = pmc_traffic(dom)
+            tr = live_traffic(sys.argv[1:], dom) if args.live_traffic else None
+            if not tr or "error" in tr:
+                tr = pmc_traffic(dom)
             # f32x3 mode: six bf16 MFMA products per fp32-equivalent multiply-add -> peak = bf16 dense peak / 6
             peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if args.precision == "f32x3" and "_x3_" in dom else PEAK_F32_MFMA_TFLOPS
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
@@ -408,8 +500,13 @@ def main():
             "fp32_direct_conv_ceiling_images_per_sec_per_gpu": round(PEAK_F32_MFMA_TFLOPS * 1e3 / gflop_img, 1),
             "roofline": roof,
             "roofline_hbm": hbm_roof,
+            "timed_regions_ms_per_step": [round(t / args.steps * 1e3, 3) for t in regions],
+            "timed_regions": {"count": len(regions), "reported": "median region", "min_ms_per_step": round(min(regions) / args.steps * 1e3, 3),
+                              "max_ms_per_step": round(max(regions) / args.steps * 1e3, 3)},
+            "per_rank_ms": per_rank_ms,
+            "options": options,
             "profiled_pass": {"steps": psteps, "ms_per_step": round(dtp / psteps * 1e3, 3)},
-            "rccl_ranks": world if args.backend == "nccl" else 0,
+            "rccl_ranks": dist.get_world_size() if (under_launcher and args.backend == "nccl") else 0,
             "comm": comm,
             "kernel_groups_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
             "kernel_groups_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0},
@@ -423,7 +520,7 @@ def main():
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if under_launcher:
         dist.destroy_process_group()
 
 

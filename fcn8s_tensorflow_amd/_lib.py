@@ -82,8 +82,8 @@ SIGNATURES = {
     "fcn8s_profile_num_groups": (_i, [_p]),
     "fcn8s_profile_get": (_i, [_p, _i, C.POINTER(C.c_char_p), _dp, _i64p, _dp, _dp]),
     "fcn8s_op_preprocess": (_i, [_p, _p, _i, _p, _i64]),
-    "fcn8s_op_augment_u8": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
-    "fcn8s_op_resample_u8": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
+    "fcn8s_op_augment_u8": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
+    "fcn8s_op_resample_u8": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_conv2d": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_conv2d_winograd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_conv3x3_winograd_fwd_bwd": (_i, [_p] * 11 + [_i] * 8),

@@ -11,11 +11,13 @@ Contract kept (pinned by tests/golden/batchgen_contract.npz, captured from the r
   * the order of `np.random` / `random` draws per sample (crop y, crop x, brightness, flip,
     translate, scale), so seeded runs place crops where the reference does.
 
-Not kept: OpenCV and `scipy.misc` are not available offline; PNG I/O, bilinear / nearest resize
-use Pillow, flips and translations use NumPy.  Interpolated pixel values can differ from
-cv2.INTER_LINEAR by rounding; ground-truth resampling (nearest) is exact.  The two helper
-conversions the reference calls without importing (`convert_between_IDs_and_colors`,
-`convert_IDs_to_IDs_partial`, :258/:264 -> NameError there) work here.
+  * the bytes: every OpenCV call of the reference (cv2.resize INTER_LINEAR / INTER_NEAREST :329-330, :367, :377; the 8-bit
+    RGB -> HSV -> RGB round trip of `_brightness` :469-486; cv2.flip :341; the integer-translation cv2.warpAffine :355;
+    COLOR_RGB2GRAY :387) is restated in OpenCV's own integer / float32 arithmetic by `cv2_compat.py` (OpenCV is not installable
+    offline), pinned by tests/golden/cv2_vectors.npz.
+
+Not kept: `scipy.misc` PNG I/O (removed from SciPy) is done with Pillow.  The two helper conversions the reference calls
+without importing (`convert_between_IDs_and_colors`, `convert_IDs_to_IDs_partial`, :258/:264 -> NameError there) work here.
 """
 from __future__ import annotations
 
@@ -28,6 +30,7 @@ from math import ceil
 
 import numpy as np
 
+from . import cv2_compat
 from .ground_truth_conversion_utils import (convert_between_IDs_and_colors, convert_IDs_to_IDs,
                                             convert_IDs_to_IDs_partial, convert_IDs_to_one_hot)
 
@@ -57,27 +60,18 @@ def _imsave(path, array):
 
 
 def _resize(array, height, width, nearest):
-    from PIL import Image
-    return np.asarray(Image.fromarray(array).resize((width, height), Image.NEAREST if nearest else Image.BILINEAR))
+    """cv2.resize(array, (width, height), INTER_NEAREST | INTER_LINEAR) (:329-330, :367, :377)"""
+    return cv2_compat.resize_nearest(array, height, width) if nearest else cv2_compat.resize_linear(array, height, width)
 
 
 def _shift(array, x_shift, y_shift, fill):
-    """Integer translation with constant border (cv2.warpAffine with a pure translation matrix)."""
-    out = np.full_like(array, 0 if fill is None else fill)
-    h, w = array.shape[:2]
-    ys, yd = (slice(0, h - y_shift), slice(y_shift, h)) if y_shift >= 0 else (slice(-y_shift, h), slice(0, h + y_shift))
-    xs, xd = (slice(0, w - x_shift), slice(x_shift, w)) if x_shift >= 0 else (slice(-x_shift, w), slice(0, w + x_shift))
-    if abs(y_shift) < h and abs(x_shift) < w:
-        out[yd, xd] = array[ys, xs]
-    return out
+    """cv2.warpAffine with a pure integer translation and a constant border (:350-356)."""
+    return cv2_compat.translate(array, x_shift, y_shift, fill)
 
 
 def _brightness(image, factor):
-    """Scale the HSV value channel by `factor`, saturating at 255 (:473-488)."""
-    img = image.astype(np.float32)
-    v = img.max(axis=2, keepdims=True)
-    scaled = np.where(v * factor > 255, 255.0 / np.maximum(v, 1.0), factor)
-    return np.clip(np.rint(img * scaled), 0, 255).astype(np.uint8)
+    """The reference's `_brightness` (:469-486) for an already drawn factor: 8-bit HSV, V scaled, saturated at 255, truncated."""
+    return cv2_compat.brightness(image, factor)
 
 
 def _place_or_crop(array, out_h, out_w, ymin, xmin, fill):
@@ -408,9 +402,9 @@ class BatchGenerator:
         if 'gain' in d:
             image = _brightness(image, d['gain'])
         if d.get('flip'):
-            image = np.ascontiguousarray(image[:, ::-1])
+            image = cv2_compat.flip_horizontal(image)
             if gt is not None:
-                gt = np.ascontiguousarray(gt[:, ::-1])
+                gt = cv2_compat.flip_horizontal(gt)
         if 'shift' in d:
             x_shift, y_shift = d['shift']
             image = _shift(image, x_shift, y_shift, 0)
@@ -432,8 +426,7 @@ class BatchGenerator:
             if gt is not None:
                 gt = rescale(gt, True, void_class_id)
         if gray:
-            lum = image[..., 0] * 0.299 + image[..., 1] * 0.587 + image[..., 2] * 0.114
-            image = np.expand_dims(np.clip(np.rint(lum), 0, 255).astype(np.uint8), axis=2)
+            image = np.expand_dims(cv2_compat.rgb2gray(image), axis=2)          # cv2.cvtColor(image, cv2.COLOR_RGB2GRAY) (:387)
         return image, gt
 
     def generate(self,

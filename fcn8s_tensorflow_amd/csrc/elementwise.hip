@@ -752,50 +752,116 @@ void launch_init_normal(float* w, long long n, float stddev, int truncated, unsi
 }
 
 // ---- GPU-side augmentation of a uint8 batch: per-image crop window / canvas placement, horizontal flip and
-// brightness gain, the three geometric + photometric augmentations of data_generator/batch_generator.py:293-379 that do
+// brightness, the three geometric + photometric augmentations of data_generator/batch_generator.py:293-379 that do
 // not resample.  out[n, y, x] = in[n, y + oy[n], flip ? (Wo-1-x) + ox[n] : x + ox[n]] (outside the source: image 0, label void).
+// OpenCV's 8-bit RGB <-> HSV (H in [0,180)) in its own arithmetic (imgproc color_hsv: RGB2HSV_b integer path with 12-bit reciprocal
+// tables, HSV2RGB_b float32 path), as restated in fcn8s_tensorflow_amd/cv2_compat.py.  The float steps use the *_rn intrinsics so that
+// the compiler cannot contract a multiply and a subtract into one FMA (OpenCV's scalar code rounds after each operation).
+static __device__ __forceinline__ void cv_rgb2hsv_u8(int r, int g, int b, int& h, int& s, int& v)
+{
+    v = max(max(r, g), b);
+    const int vmin = min(min(r, g), b), diff = v - vmin;
+    const int sdiv = v ? (int)rint((double)(255 << 12) / (double)v) : 0;
+    const int hdiv = diff ? (int)rint((double)(180 << 12) / (6.0 * (double)diff)) : 0;
+    s = (diff * sdiv + (1 << 11)) >> 12;
+    int hh = v == r ? (g - b) : (v == g ? (b - r + 2 * diff) : (r - g + 4 * diff));
+    hh = (hh * hdiv + (1 << 11)) >> 12;
+    h = hh < 0 ? hh + 180 : hh;
+}
+static __device__ __forceinline__ void cv_hsv2rgb_u8(int H, int S, int V, int& r, int& g, int& b)
+{
+    const float s = __fmul_rn((float)S, 1.f / 255.f), v = __fmul_rn((float)V, 1.f / 255.f);
+    float fb, fg, fr;
+    if (s == 0.f) fb = fg = fr = v;
+    else {
+        float h = __fmul_rn((float)H, 6.f / 180.f);
+        if (h >= 6.f) h = __fsub_rn(h, 6.f);
+        int sector = (int)floorf(h);
+        h = __fsub_rn(h, (float)sector);
+        if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
+        const float t0 = v, t1 = __fmul_rn(v, __fsub_rn(1.f, s)), t2 = __fmul_rn(v, __fsub_rn(1.f, __fmul_rn(s, h))),
+                    t3 = __fmul_rn(v, __fsub_rn(1.f, __fmul_rn(s, __fsub_rn(1.f, h))));
+        switch (sector) {                      // sector_data: tab index of (b, g, r)
+            case 0:  fb = t1; fg = t3; fr = t0; break;
+            case 1:  fb = t1; fg = t0; fr = t2; break;
+            case 2:  fb = t3; fg = t0; fr = t1; break;
+            case 3:  fb = t0; fg = t2; fr = t1; break;
+            case 4:  fb = t0; fg = t1; fr = t3; break;
+            default: fb = t2; fg = t1; fr = t0; break;
+        }
+    }
+    auto sat = [](float x) { const int q = (int)rintf(__fmul_rn(x, 255.f)); return q < 0 ? 0 : (q > 255 ? 255 : q); };
+    r = sat(fr); g = sat(fg); b = sat(fb);
+}
+
+// crop / canvas placement, horizontal flip and brightness of data_generator/batch_generator.py:268-341, :469-486 on a uint8 batch.
+// params: int[4] per image = {y offset, x offset, flip, brightness on/off}; vlut: [N][256] new V of every old V (the host evaluates the
+// reference's float64 `V * random_br`, saturation and uint8 truncation once per image); brightness = RGB -> HSV, V = vlut[V], HSV -> RGB.
 __global__ void augment_u8_kernel(const unsigned char* img, const unsigned char* lab, unsigned char* oimg, unsigned char* olab,
-                                  const int* params, int N, int H, int W, int Ho, int Wo, int void_id)
+                                  const int* params, const unsigned char* vlut, int N, int H, int W, int Ho, int Wo, int void_id)
 {
     const long long total = (long long)N * Ho * Wo;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % Wo); const long long r = i / Wo;
         const int y = (int)(r % Ho), n = (int)(r / Ho);
-        const int oy = params[4 * n], ox = params[4 * n + 1], flip = params[4 * n + 2];
-        const float gain = __int_as_float(params[4 * n + 3]);
+        const int oy = params[4 * n], ox = params[4 * n + 1], flip = params[4 * n + 2], bright = params[4 * n + 3];
         const int sy = y + oy, sx = (flip ? Wo - 1 - x : x) + ox;
         const bool in = (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
         const long long src = ((long long)n * H + sy) * W + sx;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v = in ? (float)img[src * 3 + c] * gain : 0.f;
-            v = fminf(fmaxf(v, 0.f), 255.f);
-            oimg[i * 3 + c] = (unsigned char)(v + 0.5f);
+        int pr = 0, pg = 0, pb = 0;
+        if (in) { pr = img[src * 3]; pg = img[src * 3 + 1]; pb = img[src * 3 + 2]; }
+        if (bright && vlut) {              // (the reference brightens before it flips and after it crops: canvas pixels are black and stay black)
+            int h, s_, v;
+            cv_rgb2hsv_u8(pr, pg, pb, h, s_, v);
+            cv_hsv2rgb_u8(h, s_, vlut[n * 256 + v], pr, pg, pb);
         }
+        oimg[i * 3] = (unsigned char)pr; oimg[i * 3 + 1] = (unsigned char)pg; oimg[i * 3 + 2] = (unsigned char)pb;
         if (lab) olab[i] = in ? lab[src] : (unsigned char)void_id;
     }
 }
 void launch_augment_u8(const unsigned char* img, const unsigned char* lab, unsigned char* oimg, unsigned char* olab, const int* params,
-                       int N, int H, int W, int Ho, int Wo, int void_id, hipStream_t s)
+                       const unsigned char* vlut, int N, int H, int W, int Ho, int Wo, int void_id, hipStream_t s)
 {
-    hipLaunchKernelGGL(augment_u8_kernel, dim3(cap_blocks((long long)N * Ho * Wo, 256)), dim3(256), 0, s, img, lab, oimg, olab, params, N, H, W, Ho, Wo, void_id);
+    hipLaunchKernelGGL(augment_u8_kernel, dim3(cap_blocks((long long)N * Ho * Wo, 256)), dim3(256), 0, s, img, lab, oimg, olab, params, vlut, N, H, W, Ho, Wo, void_id);
 }
 
 
 // ---- GPU-side resampling augmentations of a uint8 batch: resize, random scale, translate of
-// data_generator/batch_generator.py:328-384 in one kernel.  Per image n: the source [H,W] is (virtually) resized to [rh,rw] --
-// images with the triangle filter whose support grows with the shrink factor (what Pillow's BILINEAR resize, the repo's host
-// path, computes: horizontal pass rounded to 8 bits, then the vertical pass), labels by nearest neighbour -- and placed with its
-// top-left corner at (oy,ox) of the [Ho,Wo] output (negative = crop); pixels not covered get 0 / void_id.
+// data_generator/batch_generator.py:328-384 in one kernel.  Per image n: the source [H,W] is (virtually) resized to [rh,rw] -- images
+// as cv2.resize(INTER_LINEAR) does for 8-bit data, labels as cv2.resize(INTER_NEAREST) does (both restated from OpenCV's resize.cpp in
+// fcn8s_tensorflow_amd/cv2_compat.py, which this kernel matches bit for bit) -- and placed with its top-left corner at (oy,ox) of the
+// [Ho,Wo] output (negative = crop); pixels not covered get 0 / void_id.
 //   resize to (h',w')        : rh = Ho = h', rw = Wo = w', offset 0
 //   scale by f <= 1 / f > 1  : rh = int(H f), rw = int(W f), offset = +/- |int((H - rh) / 2)| ...
 //   translate by (dx,dy)     : rh = H, rw = W (exact copy), offset = (dy,dx)
-// ytab / xtab (optional, [N][tab_stride]): source row / column of each resized row / column for the nearest-neighbour path, as the
-// host computes them (a running double sum, so that exact .0 boundaries fall as they do there); NULL = floor((r + 0.5) * H / rh).
+// INTER_LINEAR: f = float((d + 0.5) * scale - 0.5) with scale = 1 / (dst / src) in double; s = floor(f); f -= s; columns clamp s and zero f
+// at the borders, rows clamp the two row numbers; taps rounded to 11-bit fixed point; horizontal pass in int32; vertical pass
+// (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.  An exact 2x shrink in both directions is the 2x2 box mean (INTER_AREA).
+// INTER_NEAREST: s = min(floor(d * (1 / (dst / src))), src - 1).
+struct CvTap { int s; int w0, w1; };
+static __device__ __forceinline__ CvTap cv_linear_tap(int d, int src, int dst, bool clamp_index)
+{
+    const double scale = 1.0 / ((double)dst / (double)src);
+    float f = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);
+    int s = (int)floorf(f);
+    f = __fsub_rn(f, (float)s);
+    if (clamp_index) {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= src - 1) { f = 0.f; s = src - 1; }
+    }
+    CvTap t; t.s = s;
+    t.w0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, f), 2048.f)); t.w1 = (int)rintf(__fmul_rn(f, 2048.f));
+    return t;
+}
+static __device__ __forceinline__ int cv_nearest_index(int d, int src, int dst)
+{
+    const double ifx = 1.0 / ((double)dst / (double)src);
+    const int s = (int)floor(__dmul_rn((double)d, ifx));
+    return s < src - 1 ? s : src - 1;
+}
 __global__ __launch_bounds__(256) void resample_u8_kernel(const unsigned char* __restrict__ img, const unsigned char* __restrict__ lab,
                                                           unsigned char* __restrict__ oimg, unsigned char* __restrict__ olab,
-                                                          const int* __restrict__ params, const int* __restrict__ ytab, const int* __restrict__ xtab,
-                                                          int tab_stride, int N, int H, int W, int Ho, int Wo, int void_id)
+                                                          const int* __restrict__ params, int N, int H, int W, int Ho, int Wo, int void_id)
 {
     const long long total = (long long)N * Ho * Wo;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -808,55 +874,39 @@ __global__ __launch_bounds__(256) void resample_u8_kernel(const unsigned char* _
             if (olab) olab[i] = (unsigned char)void_id;
             continue;
         }
-        if (olab) {
-            const float sy = (float)H / (float)rh, sx = (float)W / (float)rw;
-            int ly = ytab ? ytab[(long long)n * tab_stride + ry] : (int)(((float)ry + 0.5f) * sy);
-            int lx = xtab ? xtab[(long long)n * tab_stride + rx] : (int)(((float)rx + 0.5f) * sx);
-            ly = ly < 0 ? 0 : (ly >= H ? H - 1 : ly); lx = lx < 0 ? 0 : (lx >= W ? W - 1 : lx);
-            olab[i] = lab[((long long)n * H + ly) * W + lx];
-        }
+        if (olab) olab[i] = lab[((long long)n * H + cv_nearest_index(ry, H, rh)) * W + cv_nearest_index(rx, W, rw)];
         if (!oimg) continue;
+        const unsigned char* base = img + (long long)n * H * W * 3;
         if (rh == H && rw == W) {
-            const long long src = (((long long)n * H + ry) * W + rx) * 3;
-            oimg[i * 3] = img[src]; oimg[i * 3 + 1] = img[src + 1]; oimg[i * 3 + 2] = img[src + 2];
+            const long long src = ((long long)ry * W + rx) * 3;
+            oimg[i * 3] = base[src]; oimg[i * 3 + 1] = base[src + 1]; oimg[i * 3 + 2] = base[src + 2];
             continue;
         }
-        // Pillow's two-pass resampler restated in its own arithmetic: double-precision triangle weights, normalised, rounded to 22-bit
-        // fixed point; horizontal pass accumulated in integers and stored as 8 bits, then the vertical pass likewise
-        const double dsy = (double)H / (double)rh, dsx = (double)W / (double)rw;
-        const double fy = dsy < 1.0 ? 1.0 : dsy, fx = dsx < 1.0 ? 1.0 : dsx;
-        const double cy = ((double)ry + 0.5) * dsy, cx = ((double)rx + 0.5) * dsx;
-        int y0 = (int)(cy - fy + 0.5), y1 = (int)(cy + fy + 0.5), x0 = (int)(cx - fx + 0.5), x1 = (int)(cx + fx + 0.5);
-        y0 = y0 < 0 ? 0 : y0; y1 = y1 > H ? H : y1; x0 = x0 < 0 ? 0 : x0; x1 = x1 > W ? W : x1;
-        auto tri = [](double t) { t = t < 0.0 ? -t : t; return t < 1.0 ? 1.0 - t : 0.0; };
-        double wxs = 0.0, wys = 0.0;
-        for (int k = x0; k < x1; ++k) wxs += tri(((double)k - cx + 0.5) / fx);
-        for (int k = y0; k < y1; ++k) wys += tri(((double)k - cy + 0.5) / fy);
-        auto fix = [](double w) { return w < 0.0 ? (int)(-0.5 + w * 4194304.0) : (int)(0.5 + w * 4194304.0); };     // 1 << 22
-        auto clip8 = [](int v) { v >>= 22; return v < 0 ? 0 : (v > 255 ? 255 : v); };
-        int acc0 = 1 << 21, acc1 = 1 << 21, acc2 = 1 << 21;
-        for (int ky = y0; ky < y1; ++ky) {
-            double wy = tri(((double)ky - cy + 0.5) / fy); if (wys != 0.0) wy /= wys;
-            const int ky_c = fix(wy);
-            const unsigned char* row = img + (((long long)n * H + ky) * W) * 3;
-            int h0 = 1 << 21, h1 = 1 << 21, h2 = 1 << 21;
-            for (int kx = x0; kx < x1; ++kx) {
-                double wx = tri(((double)kx - cx + 0.5) / fx); if (wxs != 0.0) wx /= wxs;
-                const int kx_c = fix(wx);
-                h0 += (int)row[kx * 3] * kx_c; h1 += (int)row[kx * 3 + 1] * kx_c; h2 += (int)row[kx * 3 + 2] * kx_c;
-            }
-            acc0 += clip8(h0) * ky_c; acc1 += clip8(h1) * ky_c; acc2 += clip8(h2) * ky_c;
+        if (H == 2 * rh && W == 2 * rw) {
+            const unsigned char* p0 = base + ((long long)(2 * ry) * W + 2 * rx) * 3;
+            const unsigned char* p1 = p0 + (long long)W * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) oimg[i * 3 + c] = (unsigned char)(((int)p0[c] + p0[3 + c] + p1[c] + p1[3 + c] + 2) >> 2);
+            continue;
         }
-        oimg[i * 3] = (unsigned char)clip8(acc0);
-        oimg[i * 3 + 1] = (unsigned char)clip8(acc1);
-        oimg[i * 3 + 2] = (unsigned char)clip8(acc2);
+        const CvTap tx = cv_linear_tap(rx, W, rw, true), ty = cv_linear_tap(ry, H, rh, false);
+        const int x1 = tx.s + 1 < W ? tx.s + 1 : W - 1;                       // (weight 0 there)
+        const int r0 = ty.s < 0 ? 0 : (ty.s >= H ? H - 1 : ty.s), r1 = ty.s + 1 < 0 ? 0 : (ty.s + 1 >= H ? H - 1 : ty.s + 1);
+        const unsigned char* q0 = base + (long long)r0 * W * 3;
+        const unsigned char* q1 = base + (long long)r1 * W * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int S0 = (int)q0[tx.s * 3 + c] * tx.w0 + (int)q0[x1 * 3 + c] * tx.w1;
+            const int S1 = (int)q1[tx.s * 3 + c] * tx.w0 + (int)q1[x1 * 3 + c] * tx.w1;
+            oimg[i * 3 + c] = (unsigned char)((((ty.w0 * (S0 >> 4)) >> 16) + ((ty.w1 * (S1 >> 4)) >> 16) + 2) >> 2);
+        }
     }
 }
 void launch_resample_u8(const unsigned char* img, const unsigned char* lab, unsigned char* oimg, unsigned char* olab, const int* params,
-                        const int* ytab, const int* xtab, int tab_stride, int N, int H, int W, int Ho, int Wo, int void_id, hipStream_t s)
+                        int N, int H, int W, int Ho, int Wo, int void_id, hipStream_t s)
 {
     hipLaunchKernelGGL(resample_u8_kernel, dim3(cap_blocks((long long)N * Ho * Wo, 256)), dim3(256), 0, s, img, lab, oimg, olab, params,
-                       ytab, xtab, tab_stride, N, H, W, Ho, Wo, void_id);
+                       N, H, W, Ho, Wo, void_id);
 }
 
 

@@ -179,12 +179,12 @@ void launch_wino_dgrad_output_sub44(const float* dv, float* dx, int N, int H, in
 void launch_wino_dgrad_output(const float* dv, const float* addend, const float* mask, float mask_scale, const unsigned* rbits_in, float* y,
                               int N, int H, int W, int C, hipStream_t s);
 void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, int KS, hipStream_t s);        // du[P][nsub*Cin][Cout] -> dw[KS*KS][Cin][Cout]
-// params: int[4] per image = {y offset, x offset, flip, float bits of the brightness gain}
+// params: int[4] per image = {y offset, x offset, flip, brightness on/off}; vlut: [N][256] new V per old V (may be nullptr)
 void launch_augment_u8(const unsigned char* img, const unsigned char* lab, unsigned char* oimg, unsigned char* olab, const int* params,
-                       int N, int H, int W, int Ho, int Wo, int void_id, hipStream_t s);
-// params: int[4] per image = {resized height, resized width, y offset, x offset}; ytab / xtab: optional nearest-neighbour source tables
+                       const unsigned char* vlut, int N, int H, int W, int Ho, int Wo, int void_id, hipStream_t s);
+// params: int[4] per image = {resized height, resized width, y offset, x offset}
 void launch_resample_u8(const unsigned char* img, const unsigned char* lab, unsigned char* oimg, unsigned char* olab, const int* params,
-                        const int* ytab, const int* xtab, int tab_stride, int N, int H, int W, int Ho, int Wo, int void_id, hipStream_t s);
+                        int N, int H, int W, int Ho, int Wo, int void_id, hipStream_t s);
 // wrapping sum over every 61st element's bit pattern (weighted by position): changes whenever an optimizer step or a bulk copy touches the buffer
 void launch_fingerprint(const float* x, long long n, unsigned long long* out, hipStream_t s);
 void launch_init_normal(float* w, long long n, float stddev, int truncated, unsigned long long seed,

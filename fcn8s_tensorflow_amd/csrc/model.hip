@@ -59,6 +59,7 @@ struct fcn8s_model {
     int wino_min_cin = 64;                                              // 3x3 layers with Cin >= this use Winograd; 0 = never
     int wino_tile = 6;                                                    // largest 3x3 output tile: F(6x6,3x3) / F(4x4,3x3) per layer by cost, F(2x2,3x3) fallback
     int wino_fc6 = 1;                                                     // fc6 7x7 as a 2x2 grid of 4x4 sub-filters in the Winograd domain
+    int wino_tile_hires = 0, wino_hires_pixels = 0;                       // != 0: 3x3 layers on maps of at least wino_hires_pixels pixels (per image) use at most this tile
     int wino_force_tile = 0;                                              // != 0: every eligible 3x3 layer uses exactly this tile (op-level parity entry point)
     int precision = FCN8S_PREC_F32;                                       // FCN8S_PREC_BF16_FC: forward fc6 / fc7 on the bf16 MFMA
     bool pool_fused[5] = {false, false, false, false, false};            // forward wrote pool_b + argmax bytes from conv_b_last's output transform
@@ -243,9 +244,11 @@ int wino_tile_for(const fcn8s_model* m, int H, int W, int K = 3)
 {
     if (!m || H % 2 || W % 2) return 0;
     if (m->wino_force_tile && K == 3) return (m->wino_force_tile == 6 || (H % m->wino_force_tile == 0 && W % m->wino_force_tile == 0)) ? m->wino_force_tile : 0;
-    const bool t4 = m->wino_tile >= 4 && H % 4 == 0 && W % 4 == 0;
-    if (K == 7) return t4 ? 4 : 0;
-    if (m->wino_tile == 6) {
+    int tmax = m->wino_tile;
+    if (K == 3 && m->wino_tile_hires && m->wino_hires_pixels > 0 && (long long)H * W >= m->wino_hires_pixels && m->wino_tile_hires < tmax) tmax = m->wino_tile_hires;
+    const bool t4 = tmax >= 4 && H % 4 == 0 && W % 4 == 0;
+    if (K == 7) return (m->wino_tile >= 4 && H % 4 == 0 && W % 4 == 0) ? 4 : 0;
+    if (tmax == 6) {
         const long long c6 = 64LL * ((H + 5) / 6) * ((W + 5) / 6), c4 = t4 ? 36LL * (H / 4) * (W / 4) : 16LL * (H / 2) * (W / 2);
         if (c6 < c4) return 6;
     }
@@ -1225,6 +1228,8 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "winograd_tile") return &m->wino_tile;
     if (key == "winograd_fc6") return &m->wino_fc6;
     if (key == "tconv_gemm") return &m->tconv_gemm;
+    if (key == "winograd_tile_hires") return &m->wino_tile_hires;
+    if (key == "winograd_hires_pixels") return &m->wino_hires_pixels;
     return nullptr;
 }
 int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
@@ -1238,6 +1243,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
     int* slot = model_option(m, k);
     if (!slot) return fail(m, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown option '" + k + "'");
     if (k == "winograd_tile" && value != 2 && value != 4 && value != 6) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_tile must be 2, 4 or 6");
+    if (k == "winograd_tile_hires" && value != 0 && value != 2 && value != 4 && value != 6) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_tile_hires must be 0, 2, 4 or 6");
     if (k == "winograd_min_cin" && value < 0) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_min_cin must be >= 0 (0 = direct convolution everywhere)");
     if (*slot == (int)value) return FCN8S_OK;
     HIPCHK(m, hipStreamSynchronize(m->stream));
@@ -1674,22 +1680,20 @@ int fcn8s_op_preprocess(void* stream, const void* images, int dtype, float* out4
 { launch_preprocess(images, dtype, out4, npix, (hipStream_t)stream); OPCHK(); return FCN8S_OK; }
 
 int fcn8s_op_augment_u8(void* stream, const uint8_t* images, const uint8_t* labels, uint8_t* out_images, uint8_t* out_labels,
-                        const int32_t* params, int N, int H, int W, int Ho, int Wo, int void_id)
+                        const int32_t* params, const uint8_t* vlut, int N, int H, int W, int Ho, int Wo, int void_id)
 {
     if (!images || !out_images || !params || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || (labels && !out_labels))
         return fail(nullptr, FCN8S_ERR_BAD_ARG, "augment_u8: bad argument");
-    launch_augment_u8(images, labels, out_images, out_labels, params, N, H, W, Ho, Wo, void_id, (hipStream_t)stream);
+    launch_augment_u8(images, labels, out_images, out_labels, params, vlut, N, H, W, Ho, Wo, void_id, (hipStream_t)stream);
     OPCHK(); return FCN8S_OK;
 }
 
 int fcn8s_op_resample_u8(void* stream, const uint8_t* images, const uint8_t* labels, uint8_t* out_images, uint8_t* out_labels,
-                         const int32_t* params, const int32_t* ytab, const int32_t* xtab, int tab_stride,
-                         int N, int H, int W, int Ho, int Wo, int void_id)
+                         const int32_t* params, int N, int H, int W, int Ho, int Wo, int void_id)
 {
-    if ((!images && !labels) || (images && !out_images) || (labels && !out_labels) || !params || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 ||
-        ((ytab || xtab) && tab_stride <= 0))
+    if ((!images && !labels) || (images && !out_images) || (labels && !out_labels) || !params || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0)
         return fail(nullptr, FCN8S_ERR_BAD_ARG, "resample_u8: bad argument");
-    launch_resample_u8(images, labels, images ? out_images : nullptr, labels ? out_labels : nullptr, params, ytab, xtab, tab_stride, N, H, W, Ho, Wo, void_id, (hipStream_t)stream);
+    launch_resample_u8(images, labels, images ? out_images : nullptr, labels ? out_labels : nullptr, params, N, H, W, Ho, Wo, void_id, (hipStream_t)stream);
     OPCHK(); return FCN8S_OK;
 }
 

@@ -45,20 +45,40 @@ def layout(num_classes, widths=None, fc6_ksize=7):
 
 
 class BucketReducer:
-    """Issues one asynchronous SUM all-reduce per gradient bucket and waits for all of them."""
+    """Issues one asynchronous SUM all-reduce per gradient bucket and waits for all of them.
+    trace: optional list; then every bucket appends (issue event on the compute stream, completion event on a side stream that
+    waits for nothing but that all-reduce) -- bench.py turns them into issue -> complete timestamps per bucket."""
 
-    def __init__(self, flat_grads, buckets, group=None):
+    def __init__(self, flat_grads, buckets, group=None, trace=None, always=False):
         self.flat = flat_grads
         self.buckets = buckets
         self.group = group
         self.works = []
+        self.trace = trace
+        self.always = always          # run the collectives in a one-rank group too (bench.py under torchrun with one rank)
+        self._side = None
 
     def reduce_bucket(self, b):
         d = dist_or_none()
-        if d is None or d.get_world_size(self.group) == 1:
+        if d is None or (d.get_world_size(self.group) == 1 and not self.always):
             return
         off, n = self.buckets[b]
-        self.works.append(d.all_reduce(self.flat[off:off + n], op=d.ReduceOp.SUM, group=self.group, async_op=True))
+        ev = None
+        if self.trace is not None and self.flat.is_cuda:
+            import torch
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+        w = d.all_reduce(self.flat[off:off + n], op=d.ReduceOp.SUM, group=self.group, async_op=True)
+        self.works.append(w)
+        if ev is not None:
+            import torch
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.flat.device)
+            done = torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(self._side):
+                w.wait()                      # (NCCL/RCCL: the side stream waits for the collective; gloo: the host does)
+                done.record()
+            self.trace.append((b, ev, done))
 
     def wait(self):
         for w in self.works:

@@ -382,7 +382,8 @@ class Engine:
         N, H, W = (int(x) for x in nhw)
         ws = self.world_size
         loss = C.c_float(0.0)
-        if ws == 1 and optimizer == L.OPT_TF_ADAM:
+        always = bool(getattr(self, "dp_always", False)) and _dist() is not None
+        if ws == 1 and optimizer == L.OPT_TF_ADAM and not always:
             step = C.c_int64(0)
             L.check(L.lib.fcn8s_train_step(self.h, pi, dt, pl, N, H, W, float(learning_rate), float(keep_prob),
                                            float(l2_rate), where, None, C.byref(step)), self.h)
@@ -392,13 +393,20 @@ class Engine:
             return (float(loss.value) if fetch_loss else None), int(step.value)
         L.check(L.lib.fcn8s_forward_loss(self.h, pi, dt, pl, N, H, W, float(keep_prob), float(l2_rate), where), self.h)
         self._release(ka)
-        red = BucketReducer(self.flat_grads, self.buckets, self.pg)
+        trace = getattr(self, "comm_trace", None)          # bench.py: a list collects (step start, per-bucket issue / completion events)
+        if trace is not None:
+            t0 = self.torch.cuda.Event(enable_timing=True); t0.record()
+            trace.append(("step", t0, None))
+        red = BucketReducer(self.flat_grads, self.buckets, self.pg, trace=trace, always=always)
         for b in range(L.NUM_BUCKETS):
             L.check(L.lib.fcn8s_backward_bucket(self.h, b), self.h)
             if reduce:
                 red.reduce_bucket(b)      # RCCL moves bucket b while the next bucket's backward runs
         red.wait()
         L.check(L.lib.fcn8s_apply_update(self.h, optimizer, float(learning_rate), red.grad_scale() if reduce else 1.0), self.h)
+        if trace is not None:
+            t1 = self.torch.cuda.Event(enable_timing=True); t1.record()
+            trace.append(("end", t1, None))
         if fetch_loss:
             L.check(L.lib.fcn8s_read_loss(self.h, C.byref(loss)), self.h)
         return (float(loss.value) if fetch_loss else None), self.global_step
@@ -470,8 +478,9 @@ class Engine:
         """GPU-side augmentation of a uint8 batch already on the device (not in the reference, whose BatchGenerator augments on
         the host: batch_generator.py:293-379).  images: uint8 cuda tensor [N,H,W,3]; labels: uint8 cuda tensor [N,H,W] or None.
         Per image: `offsets[n] = (y, x)` top-left corner of the output window in the source (negative = place the source inside a
-        larger canvas, like `random_crop` does), `flips[n]` horizontal flip, `gains[n]` brightness factor.  Returns the
-        augmented (images, labels) as new cuda tensors of size `out_hw` (default: unchanged)."""
+        larger canvas, like `random_crop` does), `flips[n]` horizontal flip, `gains[n]` brightness factor (None / NaN = no brightness step
+        for that image; a factor, 1.0 included, runs the reference's 8-bit HSV round trip, which is not the identity).  Bit-exact with
+        the host BatchGenerator (cv2_compat.py).  Returns the augmented (images, labels) as new cuda tensors of size `out_hw`."""
         torch = self.torch
         self._sync_stream()
         if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3 or not images.is_cuda:
@@ -483,7 +492,12 @@ class Engine:
             par[:, :2] = np.asarray(offsets, np.int32).reshape(N, 2)
         if flips is not None:
             par[:, 2] = np.asarray(flips).astype(np.int32).reshape(N)
-        par[:, 3] = np.asarray(gains if gains is not None else np.ones(N), np.float32).reshape(N).view(np.int32)
+        vl = None
+        if gains is not None:
+            g = np.asarray([np.nan if x is None else x for x in gains], np.float64).reshape(N)
+            par[:, 3] = ~np.isnan(g)
+            v = np.arange(256, dtype=np.uint8)[None, :] * np.where(np.isnan(g), 1.0, g)[:, None]      # the reference's float64 `hsv[:,:,2] * random_br`
+            vl = torch.from_numpy(np.where(v > 255, 255, v).astype(np.uint8)).to(self.device)         # ... saturated, truncated on the uint8 store
         pd = torch.from_numpy(par).to(self.device)
         images = images.contiguous()
         out = torch.empty((N, Ho, Wo, 3), dtype=torch.uint8, device=self.device)
@@ -496,23 +510,16 @@ class Engine:
             lp, lo = C.c_void_p(labels.data_ptr()), C.c_void_p(lab_out.data_ptr())
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         L.check(L.lib.fcn8s_op_augment_u8(stream, C.c_void_p(images.data_ptr()), lp, C.c_void_p(out.data_ptr()), lo,
-                                          C.c_void_p(pd.data_ptr()), N, H, W, Ho, Wo, int(void_class_id)))
+                                          C.c_void_p(pd.data_ptr()), C.c_void_p(vl.data_ptr()) if vl is not None else None,
+                                          N, H, W, Ho, Wo, int(void_class_id)))
         return out, lab_out
-
-    @staticmethod
-    def nearest_table(in_size, out_size):
-        """Source index of every output index of a nearest-neighbour resize in_size -> out_size, computed the way the host path
-        (Pillow's affine NEAREST) does: a running double-precision sum 0.5 s, 1.5 s, ... truncated -- so that positions which are
-        exact integers in real arithmetic fall on the same side as there."""
-        s = float(in_size) / float(out_size)
-        steps = np.full(out_size, s, np.float64); steps[0] = 0.5 * s
-        return np.minimum(np.cumsum(steps).astype(np.int64), in_size - 1).astype(np.int32)
 
     def resample(self, images, labels=None, out_hw=None, sizes=None, offsets=None, void_class_id=0):
         """GPU-side resize / scale / translate of a uint8 batch already on the device (fcn8s_op_resample_u8; the reference's
         BatchGenerator does these on the host, batch_generator.py:328-384).  images: uint8 cuda tensor [N,H,W,3]; labels: uint8 cuda
         tensor [N,H,W] or None.  Per image: `sizes[n] = (rh, rw)` size the source is resized to (default: out_hw), `offsets[n] =
-        (oy, ox)` where its top-left corner lands in the output (negative = crop).  Returns new (images, labels) of size out_hw."""
+        (oy, ox)` where its top-left corner lands in the output (negative = crop).  Images follow cv2.resize(INTER_LINEAR), labels
+        cv2.resize(INTER_NEAREST), bit-exact with the host BatchGenerator (cv2_compat.py).  Returns new (images, labels) of size out_hw."""
         torch = self.torch
         self._sync_stream()
         if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3 or not images.is_cuda:
@@ -523,12 +530,7 @@ class Engine:
         par[:, :2] = np.asarray(sizes, np.int32).reshape(N, 2) if sizes is not None else (Ho, Wo)
         if offsets is not None:
             par[:, 2:] = np.asarray(offsets, np.int32).reshape(N, 2)
-        stride = int(max(par[:, 0].max(), par[:, 1].max()))
-        ytab = np.zeros((N, stride), np.int32); xtab = np.zeros((N, stride), np.int32)
-        for n in range(N):
-            ytab[n, :par[n, 0]] = self.nearest_table(H, int(par[n, 0]))
-            xtab[n, :par[n, 1]] = self.nearest_table(W, int(par[n, 1]))
-        pd, yd, xd = (torch.from_numpy(a).to(self.device) for a in (par, ytab, xtab))
+        pd = torch.from_numpy(par).to(self.device)
         images = images.contiguous()
         out = torch.empty((N, Ho, Wo, 3), dtype=torch.uint8, device=self.device)
         lab_out = None; lp = lo = None
@@ -540,8 +542,7 @@ class Engine:
             lp, lo = C.c_void_p(labels.data_ptr()), C.c_void_p(lab_out.data_ptr())
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         L.check(L.lib.fcn8s_op_resample_u8(stream, C.c_void_p(images.data_ptr()), lp, C.c_void_p(out.data_ptr()), lo,
-                                           C.c_void_p(pd.data_ptr()), C.c_void_p(yd.data_ptr()), C.c_void_p(xd.data_ptr()), stride,
-                                           N, H, W, Ho, Wo, int(void_class_id)))
+                                           C.c_void_p(pd.data_ptr()), N, H, W, Ho, Wo, int(void_class_id)))
         return out, lab_out
 
     def predict(self, images, argmax=True):

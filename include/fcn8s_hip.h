@@ -179,6 +179,8 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *   model options (m != NULL; setting one drops the workspace and all cached filter banks):
  *     "winograd_min_cin"  64   3x3 layers with at least this many input channels run through Winograd; 0 = direct convolution everywhere
  *     "winograd_tile"     6    largest 3x3 output tile (6, 4 or 2); per layer the allowed tile with the fewest multiplies is used
+ *     "winograd_tile_hires", "winograd_hires_pixels"  0, 0   3x3 layers whose map has at least `hires_pixels` pixels per image use at most
+ *                              tile `tile_hires` (F(4x4) carries half the round-off of F(6x6); the layers next to the input see the longest sums)
  *     "winograd_fc6"      1    fc6 as a 2x2 grid of 4x4 sub-filters through F(4x4,4x4); 0 = direct 7x7
  *     "tconv_gemm"        1    the 16x16/8 transposed conv as one GEMM over output blocks (blocked logits); 0 = 64 sub-pixel phases
  *   process-wide option (m == NULL), for the op-level entry points below, which have no model:
@@ -207,19 +209,20 @@ int fcn8s_profile_get(fcn8s_model* m, int group, const char** name, double* tota
  * uses).  `stream` may be NULL (default stream).                                 */
 int fcn8s_op_preprocess(void* stream, const void* images, int image_dtype, float* out4, int64_t npix);
 /* GPU-side augmentation of a uint8 batch on DEVICE pointers (the crop / canvas placement, horizontal flip and
- * brightness steps of data_generator/batch_generator.py:293-379, which do not resample).  params: int32[4] per image =
- * {y offset, x offset, flip (0|1), IEEE-754 bits of the float brightness gain}; out[n,y,x] = in[n, y+oy, (flip ? Wo-1-x : x) + ox]
- * * gain (clamped to 0..255, rounded), zero / void_id outside the source.  labels / out_labels may be NULL. */
+ * brightness steps of data_generator/batch_generator.py:293-341, :469-486, which do not resample).  params: int32[4] per image =
+ * {y offset, x offset, flip (0|1), brightness (0|1)}; out[n,y,x] = in[n, y+oy, (flip ? Wo-1-x : x) + ox], zero / void_id outside the
+ * source.  Brightness is the reference's `_brightness` in OpenCV's 8-bit arithmetic (cv2.COLOR_RGB2HSV integer path, V replaced through
+ * vlut[n][V] -- uint8[N][256], the host's evaluation of `V * random_br` saturated at 255 and truncated --, cv2.COLOR_HSV2RGB float32 path);
+ * bit-exact with fcn8s_tensorflow_amd/cv2_compat.py.  labels / out_labels / vlut may be NULL. */
 int fcn8s_op_augment_u8(void* stream, const uint8_t* images, const uint8_t* labels, uint8_t* out_images, uint8_t* out_labels,
-                        const int32_t* params, int N, int H, int W, int Ho, int Wo, int void_id);
+                        const int32_t* params, const uint8_t* vlut, int N, int H, int W, int Ho, int Wo, int void_id);
 /* the resampling augmentations of data_generator/batch_generator.py:328-384 (resize :328-331, translate :344-356, scale :358-384) on
- * DEVICE uint8 batches: image n is resized to params[4n+0] x params[4n+1] (images: triangle filter with shrink-proportional
- * support, the BILINEAR resize of the repo's host path; labels: nearest neighbour) and placed at offset (params[4n+2],
- * params[4n+3]) of the [Ho,Wo] output, uncovered pixels 0 / void_id.  ytab / xtab: optional [N][tab_stride] source-index tables
- * of the nearest path (NULL: floor((r + 0.5) * H / rh)).  images / labels may each be NULL.                                   */
+ * DEVICE uint8 batches: image n is resized to params[4n+0] x params[4n+1] -- images as cv2.resize(INTER_LINEAR) does for 8-bit data (11-bit
+ * fixed-point taps; 2x2 box mean for an exact 2x shrink), labels as cv2.resize(INTER_NEAREST) does (floor(dst * src/dst)) -- and placed at
+ * offset (params[4n+2], params[4n+3]) of the [Ho,Wo] output, uncovered pixels 0 / void_id.  Bit-exact with cv2_compat.py.
+ * images / labels may each be NULL. */
 int fcn8s_op_resample_u8(void* stream, const uint8_t* images, const uint8_t* labels, uint8_t* out_images, uint8_t* out_labels,
-                         const int32_t* params, const int32_t* ytab, const int32_t* xtab, int tab_stride,
-                         int N, int H, int W, int Ho, int Wo, int void_id);
+                         const int32_t* params, int N, int H, int W, int Ho, int Wo, int void_id);
 int fcn8s_op_conv2d(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,
                     int N, int H, int W, int Cin, int Cout, int K, int relu);
 /* the same SAME conv through Winograd F(tile x tile, 3x3), tile = 2, 4 or 6 (the path the model takes for its 3x3

@@ -250,28 +250,42 @@ def test_tensorflow_checkpoint_files_round_trip(tmp_path):
 
 
 def test_gpu_augmentation_matches_host_crop_flip_brightness():
-    """crop / canvas placement, horizontal flip and brightness on the GPU, against NumPy doing what
-    data_generator/batch_generator.py:293-379 does on the host for those (non-resampling) steps."""
+    """crop / canvas placement, horizontal flip and brightness on the GPU, bit-exact against the host BatchGenerator's
+    steps (data_generator/batch_generator.py:268-341, :469-486 through cv2_compat: OpenCV's 8-bit HSV round trip, V scaled in float64,
+    saturated, truncated)."""
     import torch
     from fcn8s_tensorflow_amd.engine import Engine
+    from fcn8s_tensorflow_amd import cv2_compat as cv
+    from fcn8s_tensorflow_amd.batch_generator import _place_or_crop
     rng = np.random.default_rng(3)
-    N, H, W, Ho, Wo = 3, 20, 28, 16, 24
+    N, H, W, Ho, Wo = 4, 20, 28, 16, 24
     img = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8); lab = rng.integers(0, 20, (N, H, W), dtype=np.uint8)
-    offs = np.array([[2, 3], [-3, -5], [4, 0]]); flips = np.array([0, 1, 1]); gains = np.array([1.0, 1.5, 0.5], np.float32)
+    img[0, :4] = np.linspace(0, 255, 28).astype(np.uint8)[:, None]           # greys (s == 0) and saturated primaries
+    img[0, 4, :3] = [[255, 0, 0], [0, 255, 0], [0, 0, 255]]
+    offs = np.array([[2, 3], [-3, -5], [4, 0], [0, 0]]); flips = np.array([0, 1, 1, 0]); gains = [0.6180339887, 1.5, None, 1.0]
     e = Engine(20, widths=(8, 8, 8, 8, 8, 16, 16))
     out, lo = e.augment(torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda(), out_hw=(Ho, Wo), offsets=offs, flips=flips, gains=gains,
-                        void_class_id=0)
+                        void_class_id=5)
     out, lo = out.cpu().numpy(), lo.cpu().numpy()
     for n in range(N):
-        ref = np.zeros((Ho, Wo, 3), np.float32); rl = np.zeros((Ho, Wo), np.uint8)
+        ref = np.zeros((Ho, Wo, 3), np.uint8); rl = np.full((Ho, Wo), 5, np.uint8)
         for y in range(Ho):
             for x in range(Wo):
                 sy, sx = y + offs[n, 0], (Wo - 1 - x if flips[n] else x) + offs[n, 1]
                 if 0 <= sy < H and 0 <= sx < W:
-                    ref[y, x] = img[n, sy, sx].astype(np.float32) * gains[n]; rl[y, x] = lab[n, sy, sx]
-        ref = np.floor(np.clip(ref, 0, 255) + 0.5).astype(np.uint8)
+                    ref[y, x] = img[n, sy, sx]; rl[y, x] = lab[n, sy, sx]
+        if gains[n] is not None:
+            ref = cv.brightness(ref, gains[n])
         np.testing.assert_array_equal(out[n], ref)
         np.testing.assert_array_equal(lo[n], rl)
+    assert not np.array_equal(out[3], img[3, :Ho, :Wo])          # factor 1.0 still runs the 8-bit HSV round trip, as the reference would
+    # every RGB value class through the GPU's HSV round trip: a 64 x 64 x 3-plane sweep of the colour cube (262 144 colours in all
+    # would be 4 MB; a stride-5 lattice plus the faces covers each sector and both saturations of V)
+    v = np.arange(0, 256, 5, dtype=np.uint8)
+    cube = np.stack(np.meshgrid(v, v, v, indexing="ij"), -1).reshape(1, 52, 52 * 52, 3)
+    for g in (0.37, 1.0, 1.9):
+        got, _ = e.augment(torch.from_numpy(cube).cuda(), None, gains=[g])
+        np.testing.assert_array_equal(got[0].cpu().numpy(), cv.brightness(cube[0], g))
     with pytest.raises(ValueError):
         e.augment(torch.zeros(1, 4, 4, 3).cuda())
     e.close()

@@ -76,6 +76,64 @@ def test_augmentations_keep_shapes_and_labels_consistent(dataset):
     assert xg.shape == (1, 8, 16, 1)
 
 
+def test_opencv_restatement_against_known_answers():
+    """cv2_compat.py (the OpenCV calls of data_generator/batch_generator.py:328-331, :341, :355, :367, :377, :387, :469-486 in OpenCV's own
+    8-bit arithmetic) against tests/golden/cv2_vectors.npz: an independent pixel-by-pixel transcription of resize.cpp / color_hsv /
+    color_yuv (tests/golden/make_cv2_vectors.py, which also asserts the hand-derived values) -- bit-exact."""
+    from fcn8s_tensorflow_amd import cv2_compat as cv
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "cv2_vectors.npz"))
+    for i, (h, w) in enumerate(d["sizes"]):
+        np.testing.assert_array_equal(cv.resize_linear(d["img"], int(h), int(w)), d["linear_%d" % i])
+        np.testing.assert_array_equal(cv.resize_nearest(d["lab"], int(h), int(w)), d["nearest_%d" % i])
+    np.testing.assert_array_equal(cv.resize_linear(d["img2"], 6, 8), d["linear_half"])                 # exact 2x shrink: INTER_AREA's box mean
+    np.testing.assert_array_equal(cv.resize_linear(d["img2"], 12, 8), d["linear_half_x_only"])
+    np.testing.assert_array_equal(cv.rgb2hsv(d["px"]), d["hsv"])
+    np.testing.assert_array_equal(cv.hsv2rgb(d["hsv_in"]), d["rgb_from_hsv"])
+    for i, f in enumerate(d["factors"]):
+        np.testing.assert_array_equal(cv.brightness(d["px"], float(f)), d["bright_%d" % i])
+    np.testing.assert_array_equal(cv.rgb2gray(d["px"]), d["gray"])
+    # hand-derived (make_cv2_vectors.py HAND; DESIGN.md section 2): cv2.resize of the row [0, 100] to 4 pixels, the primaries' hues
+    np.testing.assert_array_equal(cv.resize_linear(np.array([[0, 100]], np.uint8), 1, 4), [[0, 25, 75, 100]])
+    np.testing.assert_array_equal(cv.rgb2hsv(np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [128, 64, 32]], np.uint8)),
+                                  [[0, 255, 255], [60, 255, 255], [120, 255, 255], [10, 191, 128]])
+    np.testing.assert_array_equal(cv.resize_nearest(np.arange(5, dtype=np.uint8)[None], 1, 3), [[0, 1, 3]])          # floor(x * 5/3), not pixel centres
+    # label ids: nearest never invents a class, bilinear of a constant image is that constant, the identity resize is a copy
+    lab = d["lab"]
+    assert set(np.unique(cv.resize_nearest(lab, 29, 5))) <= set(np.unique(lab))
+    np.testing.assert_array_equal(cv.resize_linear(np.full((9, 7, 3), 201, np.uint8), 20, 13), np.full((20, 13, 3), 201, np.uint8))
+    np.testing.assert_array_equal(cv.resize_linear(d["img"], 11, 14), d["img"])
+    np.testing.assert_array_equal(cv.translate(lab, 3, -2, 9)[:-2, 3:], lab[2:, :-3])
+    assert (cv.translate(lab, 3, -2, 9)[-2:] == 9).all() and (cv.translate(lab, 3, -2, 9)[:, :3] == 9).all()
+
+
+def test_generator_resize_scale_brightness_gray_use_the_opencv_arithmetic(dataset):
+    """generate() routes resize / scale / brightness / gray through cv2_compat, in the reference's order of operations and draws."""
+    from fcn8s_tensorflow_amd import cv2_compat as cv
+    gen, d, _ = dataset
+    x, y = next(gen.generate(batch_size=3, convert_to_one_hot=False, resize=(13, 21), shuffle=False))
+    for i in range(3):
+        np.testing.assert_array_equal(x[i], cv.resize_linear(d["imgs"][i], 13, 21))
+        np.testing.assert_array_equal(y[i], cv.resize_nearest(d["gts"][i], 13, 21))
+    np.random.seed(5)
+    xb, _ = next(gen.generate(batch_size=1, convert_to_one_hot=False, brightness=(0.5, 2.0, 1.0), shuffle=False))
+    np.random.seed(5)
+    np.random.uniform(0, 1)                             # p
+    factor = np.random.uniform(0.5, 2.0)                # random_br, drawn inside _brightness (:476)
+    np.testing.assert_array_equal(xb[0], cv.brightness(d["imgs"][0], factor))
+    np.random.seed(6)
+    xs, ys = next(gen.generate(batch_size=1, convert_to_one_hot=False, scale=(0.5, 0.9, 1.0), void_class_id=7, shuffle=False))
+    np.random.seed(6)
+    np.random.uniform(0, 1)
+    f = np.random.uniform(0.5, 0.9)
+    h, w = d["imgs"][0].shape[:2]
+    sh, sw = int(h * f), int(w * f); yo, xo = abs(int((h - sh) / 2)), abs(int((w - sw) / 2))
+    want = np.zeros_like(d["imgs"][0]); want[yo:yo + sh, xo:xo + sw] = cv.resize_linear(d["imgs"][0], sh, sw)
+    wl = np.full_like(d["gts"][0], 7); wl[yo:yo + sh, xo:xo + sw] = cv.resize_nearest(d["gts"][0], sh, sw)
+    np.testing.assert_array_equal(xs[0], want); np.testing.assert_array_equal(ys[0], wl)
+    xg, _ = next(gen.generate(batch_size=1, convert_to_one_hot=False, gray=True, shuffle=False))
+    np.testing.assert_array_equal(xg[0, ..., 0], cv.rgb2gray(d["imgs"][0]))
+
+
 def test_errors_and_process_all(dataset, tmp_path):
     gen, d, root = dataset
     with pytest.raises(DataError):

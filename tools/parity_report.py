@@ -33,6 +33,8 @@ VARIANTS = {
     "f6": {},
     "f4": {"winograd_tile": 4},
     "direct": {"winograd_min_cin": 0, "winograd_fc6": 0},
+    "f6_b1f4": {"winograd_tile_hires": 4, "winograd_hires_pixels": 512 * 1024},            # block 1 (conv1_2) on F(4x4), the rest F(6x6)
+    "f6_b12f4": {"winograd_tile_hires": 4, "winograd_hires_pixels": 256 * 512},            # blocks 1 and 2 on F(4x4)
 }
 
 
