@@ -43,7 +43,10 @@ def main():
                     (gt is None or (gt_shape is not None and tuple(gt.shape) == tuple(gt_shape) and gt.dtype == np.uint8))
                 if ok:
                     if path not in maps:
-                        maps.clear()                      # the parent re-creates its buffers when the batch geometry changes
+                        # the parent alternates between two slot files per batch geometry and makes new ones when the geometry
+                        # changes: keep the two most recent mappings
+                        while len(maps) >= 2:
+                            maps.pop(next(iter(maps)))
                         maps[path] = np.memmap(path, dtype=np.uint8, mode="r+")
                     buf = maps[path]
                     buf[img_off:img_off + image.size] = image.reshape(-1)

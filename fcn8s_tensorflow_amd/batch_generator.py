@@ -177,12 +177,22 @@ class _WorkerPool:
         for i, t in enumerate(tasks):
             _write(self.procs[i % len(self.procs)].stdin, (t, dests[i]))
         images, gts = [None] * n, [None] * n
+        # every reply of this batch is collected before an error is raised: a reply left in a pipe would be read as the next
+        # batch's acknowledgement, and that batch would be returned while workers are still writing it
+        replies, failure = [], None
         for i in range(n):
             r = _read(self.procs[i % len(self.procs)].stdout)
             if r is None:
-                raise RuntimeError("a BatchGenerator decode worker died")
+                failure = failure or "a BatchGenerator decode worker died"
+                break                                   # a dead worker never answers its other tasks: the pool is unusable
             if r[0] == "err":
-                raise RuntimeError("BatchGenerator decode worker: " + r[1])
+                failure = failure or "BatchGenerator decode worker: " + r[1]
+            replies.append(r)
+        if failure:
+            if len(replies) < n:
+                self.close()
+            raise RuntimeError(failure)
+        for i, r in enumerate(replies):
             if r[0] == "arr":
                 images[i], gts[i] = r[1], r[2]
             else:

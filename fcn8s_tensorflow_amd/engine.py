@@ -249,6 +249,20 @@ class Engine:
             return t, C.c_void_p(t.data_ptr()), (L.IMG_U8 if a.dtype == np.uint8 else L.IMG_F32), L.DEVICE, a.shape[:3]
         return a, a.ctypes.data_as(C.c_void_p), (L.IMG_U8 if a.dtype == np.uint8 else L.IMG_F32), L.HOST, a.shape[:3]
 
+    def _check_ids(self, ids):
+        """Class ids that would select a padding class (num_classes padded to a multiple of 4 by the facade) are an error, as
+        `np.eye(num_classes)[ids]` is in the reference (helpers/ground_truth_conversion_utils.py:84-88: IndexError); ids at or above
+        the padded count stay what include/fcn8s_hip.h says they are: 'ignore'.  Only costs anything when classes are padded."""
+        if self.logical_classes == self.num_classes:
+            return
+        lo, hi = self.logical_classes, self.num_classes
+        if isinstance(ids, np.ndarray):
+            bad = bool(((ids >= lo) & (ids < hi)).any())
+        else:
+            bad = bool(((ids >= lo) & (ids < hi)).any().item())
+        if bad:
+            raise ValueError("class ids must be below num_classes = %d (ids from %d on mean 'ignore')" % (lo, hi))
+
     def _onehot_to_ids(self, t, nhw):
         """One-hot rows (N,H,W,C) on the device -> uint8 class ids on the device (library kernel).
         The first batches are also checked for being one-hot (costs one host sync each)."""
@@ -309,12 +323,14 @@ class Engine:
             t = t.to(torch.uint8).contiguous()
             if where == L.DEVICE:
                 t = t.to(self.device)
+                self._check_ids(t)
                 return (ka_i, t), pi, dt, C.c_void_p(t.data_ptr()), where, nhw
             labels = t.cpu().numpy()
         a = np.asarray(labels)
         if tuple(a.shape) != tuple(nhw):
             raise ValueError("labels shape %s does not match images %s" % (tuple(a.shape), tuple(nhw)))
         a = np.ascontiguousarray(a, dtype=np.uint8)
+        self._check_ids(a)
         if where == L.DEVICE:
             t = torch.from_numpy(a).to(self.device)
             return (ka_i, t), pi, dt, C.c_void_p(t.data_ptr()), where, nhw
@@ -336,6 +352,7 @@ class Engine:
             lab = np.ascontiguousarray(label_ids, dtype=np.uint8)
             if tuple(lab.shape) != tuple(a.shape[:3]):
                 raise ValueError("labels shape %s does not match images %s" % (tuple(lab.shape), tuple(a.shape[:3])))
+            self._check_ids(lab)
         pi, pl = C.c_void_p(), C.c_void_p()
         N, H, W = (int(x) for x in a.shape[:3])
         dt = L.IMG_U8 if a.dtype == np.uint8 else L.IMG_F32

@@ -254,17 +254,20 @@ class FCN8s:
         bar = trange(steps, file=sys.stdout, disable=self.engine.rank != 0)
         bar.set_description(title)
         feed = _Feeder(self.engine, generator, steps)        # batch k+1 is decoded / staged / copied while step k runs
-        for _ in bar:
-            lr = self._lr
-            images, labels = feed.next()
-            loss, self.g_step = self.engine.train_step(images, labels, learning_rate=lr, keep_prob=keep_prob, l2_rate=l2_rate)
-            self.variables_updated = True
-            if log is not None and (self.g_step - 1) % log_every == 0:
-                log.add(self.g_step, total_loss=loss, learning_rate=lr)
-            recent.append(loss)
-            self.training_loss = float(np.mean(recent))
-            bar.set_postfix(ordered_dict={'loss': self.training_loss, 'learning rate': lr})
-            self._lr = schedule(self.g_step)
+        try:
+            for _ in bar:
+                lr = self._lr
+                images, labels = feed.next()
+                loss, self.g_step = self.engine.train_step(images, labels, learning_rate=lr, keep_prob=keep_prob, l2_rate=l2_rate)
+                self.variables_updated = True
+                if log is not None and (self.g_step - 1) % log_every == 0:
+                    log.add(self.g_step, total_loss=loss, learning_rate=lr)
+                recent.append(loss)
+                self.training_loss = float(np.mean(recent))
+                bar.set_postfix(ordered_dict={'loss': self.training_loss, 'learning rate': lr})
+                self._lr = schedule(self.g_step)
+        finally:
+            feed.close()
 
     def _improved(self, name, i):
         '''Whether metric `i` beat its best.  The reference compares the name against
@@ -298,12 +301,13 @@ class FCN8s:
         tr.set_description(description)
 
         self.engine.freeze(True)            # no training inside an evaluation loop: transformed filters are built once
+        feed = _Feeder(self.engine, data_generator, num_batches)
         try:
-            feed = _Feeder(self.engine, data_generator, num_batches)
             for step in tr:
                 batch_images, batch_labels = feed.next()
                 self.engine.eval_step(batch_images, batch_labels, l2_rate=l2_regularization)
         finally:
+            feed.close()
             self.engine.freeze(False)
 
         self.engine.metrics_allreduce()
@@ -580,20 +584,34 @@ class _Feeder:
         import threading
         self.q = queue.Queue(maxsize=1)
         self.err = None
+        self.stop = threading.Event()
+
+        def put(item):
+            while not self.stop.is_set():
+                try:
+                    self.q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def work():
             try:
                 pull = getattr(generator, 'next_ids', None)
                 for i in range(count):
+                    if self.stop.is_set():
+                        return
                     images, labels = pull() if pull is not None else next(generator)
                     if (isinstance(images, np.ndarray) and images.dtype == np.uint8 and isinstance(labels, np.ndarray)
                             and labels.dtype == np.uint8 and labels.ndim == 3 and images.ndim == 4):
-                        self.q.put((engine.stage(images, labels, slot=i % L.NUM_STAGE_SLOTS), None))
+                        item = (engine.stage(images, labels, slot=i % L.NUM_STAGE_SLOTS), None)
                     else:
-                        self.q.put((images, labels))
+                        item = (images, labels)
+                    if not put(item):
+                        return
             except BaseException as e:          # surfaces in the consumer
                 self.err = e
-                self.q.put(None)
+                put(None)
 
         self.t = threading.Thread(target=work, daemon=True)
         self.t.start()
@@ -603,6 +621,18 @@ class _Feeder:
         if item is None:
             raise self.err
         return item
+
+    def close(self):
+        """Stops the helper thread and waits for it: after a step raised (or Ctrl-C) it must not keep pulling batches from the
+        user's generator, nor sit inside fcn8s_stage_inputs while the model is being closed."""
+        import queue
+        self.stop.set()
+        try:
+            while True:
+                self.q.get_nowait()
+        except queue.Empty:
+            pass
+        self.t.join()
 
 
 class _ScalarLog:

@@ -204,3 +204,61 @@ def test_worker_processes_and_class_id_batches_do_not_change_what_a_seeded_run_y
             np.testing.assert_array_equal(np.argmax(g0, -1).astype(np.uint8), g1 if ids else np.argmax(g1, -1).astype(np.uint8))
             if ids:
                 assert g1.dtype == np.uint8 and g1.ndim == 3
+
+
+def test_worker_pool_error_does_not_leave_replies_behind(tmp_path):
+    """A sample that fails in a decode worker raises in the parent only after every reply of that batch has been collected: the
+    next batch must not read the previous batch's acknowledgements as its own (it would return a buffer still being written)."""
+    import random
+    make = _png_tree(tmp_path)
+    random.seed(1); np.random.seed(1)
+    gen = make()
+    g = gen.generate(batch_size=2, workers=2, shuffle=False)
+    first = g.next_ids()
+    victim = gen.image_paths[2]
+    os.rename(victim, victim + ".gone")
+    with pytest.raises(RuntimeError):
+        g.next_ids()                                   # batch (2, 3): sample 2 cannot be read, sample 3's reply is still collected
+    os.rename(victim + ".gone", victim)
+    random.seed(1); np.random.seed(1)
+    ref = make().generate(batch_size=2, workers=0, shuffle=False)
+    want = [ref.next_ids() for _ in range(4)]
+    got = g.next_ids()                                 # the generator carries on behind the failed batch: (4,), then wraps
+    np.testing.assert_array_equal(got[0], want[2][0]); np.testing.assert_array_equal(got[1], want[2][1])
+    got = g.next_ids()
+    np.testing.assert_array_equal(got[0], want[3][0]); np.testing.assert_array_equal(got[1], want[3][1])
+    np.testing.assert_array_equal(first[0], want[0][0])
+    g.close()
+
+
+def test_feeder_thread_stops_when_the_consumer_gives_up():
+    """_Feeder.close() (called from a finally in the train / evaluate loops) ends the helper thread: it pulls no further batches from
+    the user's generator and is not left inside Engine.stage while the model closes."""
+    import itertools
+    import time
+    from fcn8s_tensorflow_amd.fcn8s import _Feeder
+    pulled = []
+
+    def gen():
+        for i in itertools.count():
+            pulled.append(i)
+            yield np.zeros((1, 32, 32, 3), np.float32), np.zeros((1, 32, 32, 20), bool)      # not the stageable kind: engine unused
+    f = _Feeder(None, gen(), 100)
+    a, b = f.next()
+    assert a.shape == (1, 32, 32, 3)
+    f.close()
+    assert not f.t.is_alive()
+    n = len(pulled)
+    assert n <= 4
+    time.sleep(0.2)
+    assert len(pulled) == n
+
+    def bad():
+        yield np.zeros((1, 32, 32, 3), np.float32), np.zeros((1, 32, 32, 20), bool)
+        raise KeyError("boom")
+    f = _Feeder(None, bad(), 5)
+    f.next()
+    with pytest.raises(KeyError):
+        f.next()
+    f.close()
+    assert not f.t.is_alive()
