@@ -115,6 +115,30 @@ void launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H
                        (const float4*)x, (const float4*)dy, (float4*)dx, N, H, W, C / 4, relu_mask);
 }
 
+// which element of each 2x2 window maxpool_bwd_kernel routes to (0..3, first maximum; 4 = the maximum is not > 0: no gradient) -- the
+// record fcn8s_get_pool_routing hands to the parity checker for blocks whose routing is not already kept as argmax bytes
+__global__ void maxpool_route_kernel(const float* x, unsigned char* r, int N, int H, int W, int C)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)N * Ho * Wo * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int w = (int)(t % Wo); t /= Wo;
+        const int h = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const long long b0 = (((long long)n * H + 2 * h) * W + 2 * w) * C + c;
+        float oa, ob, oc, od;
+        route(x[b0], x[b0 + C], x[b0 + (long long)W * C], x[b0 + (long long)W * C + C], 1.f, 1, oa, ob, oc, od);
+        r[i] = oa != 0.f ? 0 : ob != 0.f ? 1 : oc != 0.f ? 2 : od != 0.f ? 3 : 4;
+    }
+}
+void launch_maxpool_route(const float* x, unsigned char* r, int N, int H, int W, int C, hipStream_t s)
+{
+    const long long total = (long long)N * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(maxpool_route_kernel, dim3(cap_blocks(total, 256)), dim3(256), 0, s, x, r, N, H, W, C);
+}
+
 // ---- block reduction helper --------------------------------------------------
 static __device__ __forceinline__ double block_sum(double v, double* sh)
 {

@@ -1596,6 +1596,25 @@ int fcn8s_get_activation(fcn8s_model* m, const char* name, float* host, size_t n
     return FCN8S_OK;
 }
 
+int fcn8s_get_pool_routing(fcn8s_model* m, int block, unsigned char* host, size_t n)
+{
+    if (!m || !host || block < 1 || block > 5) return FCN8S_ERR_BAD_ARG;
+    if (!m->have_forward || !m->train_mode) return fail(m, FCN8S_ERR_STATE, "fcn8s_get_pool_routing: no training forward pass has been run");
+    const int h = m->H >> (block - 1), w = m->W >> (block - 1), cw = m->widths[block - 1];
+    const size_t want = (size_t)m->N * (h / 2) * (w / 2) * cw;
+    if (n != want) return fail(m, FCN8S_ERR_SHAPE, "pool routing of block " + std::to_string(block) + " has " + std::to_string(want) + " bytes");
+    char ix[16]; snprintf(ix, sizeof ix, "pidx%d", block);
+    unsigned char* d = (unsigned char*)A(m, ix);
+    if (!pool_backward_fused(m, block, m->pool_fused[block - 1])) {
+        // the backward pass routes through maxpool_bwd_kernel on the block's last conv output (materialised in this case): same rule
+        char last[32]; snprintf(last, sizeof last, "conv%d_%d", block, kConvsPerBlock[block - 1]);
+        launch_maxpool_route(A(m, last), d, m->N, h, w, cw, m->stream);
+    }
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    HIPCHK(m, hipMemcpy(host, d, n, hipMemcpyDeviceToHost));
+    return FCN8S_OK;
+}
+
 int fcn8s_get_dropout_masks(fcn8s_model* m, float* h6, size_t n6, float* h7, size_t n7)
 {
     if (!m || !m->have_forward) return fail(m, FCN8S_ERR_STATE, "no forward pass has been run");

@@ -88,3 +88,33 @@ class BucketReducer:
     def grad_scale(self):
         d = dist_or_none()
         return 1.0 if d is None else 1.0 / d.get_world_size(self.group)
+
+
+def replica_fingerprint(flat_params, global_step, samples=1 << 16):
+    """(global step, integer checksum of a strided sample of the parameter bits) of this rank's replica, as an int64 tensor on the
+    parameters' device.  Bit patterns, not values: replicas must be *identical* (same all-reduced gradients, same update kernel),
+    so any difference -- a rank that skipped a step, a diverged dropout-free buffer, a NaN -- changes the checksum."""
+    import torch
+    n = flat_params.numel()
+    stride = max(1, n // int(samples))
+    bits = flat_params.view(torch.int32)[::stride].to(torch.int64)
+    w = torch.arange(1, bits.numel() + 1, dtype=torch.int64, device=bits.device)       # position-weighted: a swap of two values shows
+    return torch.stack([torch.tensor(int(global_step), dtype=torch.int64, device=bits.device), (bits * w).sum()])
+
+
+def check_replicas(flat_params, global_step, group=None):
+    """Raises RuntimeError on every rank when the replicas of a data-parallel run are not identical (global step or parameter
+    checksum differ between ranks).  One 32-byte all-reduce; FCN8s.train calls it every `replica_check_every` steps."""
+    d = dist_or_none()
+    if d is None or d.get_world_size(group) == 1:
+        return True
+    import torch
+    fp = replica_fingerprint(flat_params, global_step)
+    both = torch.cat([fp, -fp])                      # MAX of (x, -x) gives max and -min in one collective
+    d.all_reduce(both, op=d.ReduceOp.MAX, group=group)
+    both = both.cpu()
+    hi, lo = both[:2], -both[2:]
+    if not bool((hi == lo).all()):
+        what = "global step (%d .. %d)" % (int(lo[0]), int(hi[0])) if int(hi[0]) != int(lo[0]) else "parameter checksum"
+        raise RuntimeError("data-parallel replicas have diverged: %s differs between ranks (this rank: step %d)" % (what, int(global_step)))
+    return True

@@ -118,6 +118,7 @@ class Engine:
         self._label_checks_left = 2
         self._label_calls = 0
         self._bad = None
+        self.replica_check_every = 100      # data-parallel runs: compare global step + parameter checksum across ranks every so many steps (0 = never)
         self._sync_stream()
 
     # ---- plumbing ---------------------------------------------------------------------
@@ -150,6 +151,14 @@ class Engine:
     def param_view(self, name):
         shape, off = self.specs[name]
         return self.flat_params[off:off + int(np.prod(shape))].view(*shape)
+
+    def logical_param_view(self, name):
+        """param_view without the padding classes (a strided view when num_classes was padded to a multiple of 4)."""
+        v = self.param_view(name)
+        if self.logical_classes != self.num_classes:
+            for ax in _CLASS_AXES.get(name, ()):
+                v = v.narrow(ax, 0, self.logical_classes)
+        return v
 
     def grad_view(self, name):
         shape, off = self.specs[name]
@@ -426,7 +435,16 @@ class Engine:
             trace.append(("end", t1, None))
         if fetch_loss:
             L.check(L.lib.fcn8s_read_loss(self.h, C.byref(loss)), self.h)
-        return (float(loss.value) if fetch_loss else None), self.global_step
+        step = self.global_step
+        every = int(getattr(self, "replica_check_every", 0) or 0)
+        if reduce and ws > 1 and every > 0 and step % every == 0:
+            self.check_replicas()
+        return (float(loss.value) if fetch_loss else None), step
+
+    def check_replicas(self):
+        """Data-parallel guard (dp.check_replicas): every rank must hold the same global step and bit-identical parameters."""
+        from .dp import check_replicas          # (the library works on torch's current stream: the reads below are ordered behind the update)
+        return check_replicas(self.flat_params, self.global_step, self.pg)
 
     def forward_backward(self, images, labels, keep_prob=1.0, l2_rate=0.0):
         """Gradients only (no update): returns the loss; gradients via get_grads()/grad_view()."""
@@ -601,6 +619,17 @@ class Engine:
             out["pool%d" % b] = self.activation("pool%d" % b, (N, h, w, self.widths[b - 1])) > 0
         out["fc6"] = self.activation("fc6", (N, h, w, self.widths[5])) > 0
         out["fc7"] = self.activation("fc7", (N, h, w, self.widths[6])) > 0
+        return out
+
+    def pool_routes(self, nhw):
+        """Where the last training forward/backward pass routes each max-pool gradient: {"pool<b>": uint8 (N,h/2,w/2,c)}, 0..3 = window
+        element (2*row + col), 4 = ReLU off (include/fcn8s_hip.h: fcn8s_get_pool_routing).  For the parity checker."""
+        N, H, W = (int(x) for x in nhw)
+        out = OrderedDict()
+        for b in range(1, 6):
+            a = np.empty((N, H >> b, W >> b, self.widths[b - 1]), np.uint8)
+            L.check(L.lib.fcn8s_get_pool_routing(self.h, b, a.ctypes.data_as(C.c_void_p), a.size), self.h)
+            out["pool%d" % b] = a
         return out
 
     def dropout_masks(self, shape6, shape7):

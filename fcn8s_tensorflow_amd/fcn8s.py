@@ -197,9 +197,10 @@ class FCN8s:
               summaries_dir=None,
               summaries_name=None,
               training_loss_display_averaging=3):
-        '''Trains the model; arguments as fcn8s_tensorflow.py:424-503.  Summaries are written as
-        JSON lines (`<summaries_dir>/<summaries_name>/scalars.jsonl`) instead of TensorBoard
-        event files; if `summaries_dir` is None nothing is recorded.'''
+        '''Trains the model; arguments as fcn8s_tensorflow.py:424-503.  Summaries are written as TensorBoard
+        event files (`<summaries_dir>/<summaries_name>[_eval]/events.out.tfevents.*`: total_loss, learning_rate and
+        mean / stddev / max / min / histogram of the ten watched weight-bias pairs, :331-366) and, for reading
+        without TensorBoard, as JSON lines (`scalars.jsonl`) next to them; if `summaries_dir` is None nothing is recorded.'''
         _check_metric_names(metrics)
         if eval_dataset not in ('train', 'val'):
             raise ValueError("`eval_dataset` must be one of 'train' or 'val', but is '{}'.".format(eval_dataset))
@@ -216,7 +217,7 @@ class FCN8s:
         train_log = eval_log = None
         if record_summaries and summaries_dir is not None and self.engine.rank == 0:
             run = summaries_name or 'training'
-            train_log = _ScalarLog(os.path.join(summaries_dir, run))
+            train_log = _ScalarLog(os.path.join(summaries_dir, run), engine=self.engine)
             if metrics:
                 eval_log = _ScalarLog(os.path.join(summaries_dir, run + '_eval'))
 
@@ -233,7 +234,7 @@ class FCN8s:
                 generator, num_batches, description = eval_source
                 self._evaluate(generator, metrics, num_batches, l2_regularization, description)
                 if eval_log is not None:
-                    eval_log.add(self.g_step, **dict(zip(self.metric_names, self.metric_values)))
+                    eval_log.add(self.g_step, **{('mean_loss' if n == 'loss' else n): v for n, v in zip(self.metric_names, self.metric_values)})    # tags of :360-362
 
             if save_during_training and epoch % save_frequency == 0 and self._wants_save(save_best_only, monitor):
                 self.save(model_save_dir=save_dir, saver=saver, tags=save_tags, name=save_name,
@@ -636,13 +637,94 @@ class _Feeder:
 
 
 class _ScalarLog:
-    def __init__(self, logdir):
+    """One of the reference's two tf.summary.FileWriters (fcn8s_tensorflow.py:531-535): a TensorBoard event file
+    (`events.out.tfevents.*`, tf_events.py) in `logdir`, plus the same scalars as JSON lines (`scalars.jsonl`) for reading without
+    TensorBoard.  With an engine, every record also carries what `_build_summary_ops` (:331-350) attaches to the ten watched
+    weight / bias pairs: mean, stddev, max, min and a histogram (helpers/tf_variable_summaries.py:3-20), computed on the GPU."""
+
+    def __init__(self, logdir, engine=None):
+        from .tf_events import EventFileWriter
         os.makedirs(logdir, exist_ok=True)
         self.path = os.path.join(logdir, 'scalars.jsonl')
+        self.events = EventFileWriter(logdir)
+        self.engine = engine
 
     def add(self, step, **scalars):
+        from . import tf_events
         with open(self.path, 'a') as f:
             f.write(json.dumps(dict(step=int(step), **{k: float(v) for k, v in scalars.items()})) + '\n')
+        summary = b''
+        if self.engine is not None:
+            for name, scope in tf_events.WATCHED_VARIABLES:
+                if name in self.engine.specs:
+                    summary += tf_events.add_variable_summaries(self.engine.logical_param_view(name), scope)
+        summary += b''.join(tf_events.scalar_value(k, v) for k, v in scalars.items())
+        self.events.add_summary(summary, int(step))
+
+    def close(self):
+        self.events.close()
+
+
+def create_video_from_images(video_output_name, image_input_dir, frame_rate=30.0, image_file_extension='png'):
+    '''helpers/visualization_utils.py:102-120: a video from the images of a directory (sorted by name).  The reference encodes
+    MP4 through moviepy (ffmpeg); when moviepy is importable that is what happens here, otherwise -- this image has neither moviepy
+    nor ffmpeg -- the frames are written as Motion-JPEG into an AVI container (`<video_output_name>.avi`, plays everywhere, no
+    dependencies beyond Pillow).  Returns the path written.'''
+    image_paths = sorted(glob(os.path.join(image_input_dir, '*.' + image_file_extension)))
+    if not image_paths:
+        raise ValueError("no '*.{}' images in {}".format(image_file_extension, image_input_dir))
+    try:
+        from moviepy.editor import ImageSequenceClip
+    except ImportError:
+        ImageSequenceClip = None
+    if ImageSequenceClip is not None:
+        out = "{}.mp4".format(video_output_name)
+        ImageSequenceClip(image_paths, fps=frame_rate).write_videofile(out)
+        return out
+    return _write_mjpeg_avi("{}.avi".format(video_output_name), image_paths, frame_rate)
+
+
+def _write_mjpeg_avi(path, image_paths, frame_rate, quality=90):
+    '''RIFF/AVI 1.0 with one MJPG video stream: hdrl (avih + strl(strh, strf)), movi (one '00dc' chunk per JPEG frame), idx1.'''
+    import io
+    import struct
+    from PIL import Image
+    frames, size = [], None
+    for p in image_paths:
+        im = Image.open(p).convert('RGB')
+        if size is None:
+            size = im.size
+        elif im.size != size:
+            im = im.resize(size)
+        buf = io.BytesIO()
+        im.save(buf, format='JPEG', quality=quality)
+        frames.append(buf.getvalue())
+    w, h = size
+    n = len(frames)
+    usec = int(round(1e6 / float(frame_rate)))
+    rate, scale = int(round(float(frame_rate) * 1000)), 1000
+    maxb = max(len(f) for f in frames)
+
+    def chunk(fourcc, data):
+        return fourcc + struct.pack('<I', len(data)) + data + (b'\x00' if len(data) & 1 else b'')
+
+    def lst(kind, data):
+        return b'LIST' + struct.pack('<I', 4 + len(data)) + kind + data
+
+    avih = struct.pack('<14I', usec, maxb * rate // scale, 0, 0x10, n, 0, 1, maxb, w, h, 0, 0, 0, 0)           # 0x10 = AVIF_HASINDEX
+    strh = b'vids' + b'MJPG' + struct.pack('<IHHIIIIIIII', 0, 0, 0, 0, scale, rate, 0, n, maxb, 0xFFFFFFFF, 0) + struct.pack('<4H', 0, 0, w, h)
+    strf = struct.pack('<IiiHH4sIiiII', 40, w, h, 1, 24, b'MJPG', w * h * 3, 0, 0, 0, 0)
+    hdrl = lst(b'hdrl', chunk(b'avih', avih) + lst(b'strl', chunk(b'strh', strh) + chunk(b'strf', strf)))
+    movi_data, index, off = b'', b'', 4
+    for f in frames:
+        c = chunk(b'00dc', f)
+        index += b'00dc' + struct.pack('<III', 0x10, off, len(f))           # 0x10 = AVIIF_KEYFRAME; offset relative to 'movi'
+        movi_data += c
+        off += len(c)
+    body = b'AVI ' + hdrl + lst(b'movi', movi_data) + chunk(b'idx1', index)
+    with open(path, 'wb') as fh:
+        fh.write(b'RIFF' + struct.pack('<I', len(body)) + body)
+    return path
 
 
 def print_segmentation_onto_image(image, prediction, color_map):

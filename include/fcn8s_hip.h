@@ -191,6 +191,12 @@ int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value);
 
 int fcn8s_get_activation(fcn8s_model* m, const char* name, float* host, size_t nfloats);
 int fcn8s_get_dropout_masks(fcn8s_model* m, float* host_mask6, size_t n6, float* host_mask7, size_t n7);
+/* Parity instrumentation (no counterpart in the reference): which element of each 2x2 window the backward pass of pool `block` (1..5)
+ * routes the gradient to -- one byte per pooled element [N, h/2, w/2, c]: 0..3 = window element (2*row + col) holding the FIRST maximum,
+ * 4 = the maximum is not > 0 (ReLU off: no gradient).  Max-pool's argmax is discontinuous at ties; the checker differentiates along
+ * the recorded routes and verifies separately that every route that differs from its own is a tie to round-off.  Valid after a
+ * training forward pass (fcn8s_forward_loss / fcn8s_train_step). */
+int fcn8s_get_pool_routing(fcn8s_model* m, int block, unsigned char* host, size_t nbytes);
 
 /* ---- host helper for the TF tensor-bundle writer (tf_bundle.py): CRC-32C (Castagnoli) of a host buffer ----- */
 uint32_t fcn8s_crc32c(const void* data, size_t nbytes, uint32_t crc);

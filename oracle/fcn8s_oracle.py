@@ -198,12 +198,25 @@ def _fc_conv(x, w, b, bf16, name=None, branches=None):
     return _relu_branch(z, name, branches)
 
 
-def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False, branches=None):
+def _pool_routed(z, route):
+    """2x2/2 max-pool of relu(z) taken along recorded routes instead of this restatement's own argmax: route (N,C,h/2,w/2) int64 holds
+    the window element (2*row + col) the gradient goes to, 4 = ReLU off.  max-pool's argmax is discontinuous where two window entries
+    agree to round-off; a parity test feeds the routes the device took and checks separately (pool_routes) that they differ from this
+    restatement's own only at such ties."""
+    n, c, h, w = z.shape
+    win = z.reshape(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
+    on = (route < 4).to(z.dtype)
+    return torch.gather(win, -1, route.clamp(max=3).unsqueeze(-1)).squeeze(-1) * on
+
+
+def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False, branches=None, routes=None):
     """Forward pass on torch tensors.  P: name -> torch tensor (TF layouts).
     images_t: NHWC RGB float.  masks: optional (mask6, mask7) NHWC tensors.
     bf16_fc: BASELINE config 5 -- both operands of the fc6 / fc7 contractions rounded to bfloat16, fp32 accumulate.
     branches: optional name -> 0/1 NCHW tensor ("conv1_1" ... for the convs that feed another conv, "pool1".."pool5" for each block's
     last conv + pool, "fc6", "fc7"): the ReLU branches to take instead of this restatement's own (see _relu_branch).
+    routes: optional "pool1".."pool5" -> int64 (N,C,h/2,w/2) tensor of max-pool routes (see _pool_routed); takes the place of that
+    block's pool branch record (route 4 = off).
     Returns logits NCHW (and the activation dict when keep=True)."""
     acts = OrderedDict()
     x = _nchw(preprocess_t(images_t))
@@ -211,15 +224,19 @@ def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False,
     for blk, nconv in enumerate(CONVS_PER_BLOCK, start=1):
         for i in range(1, nconv + 1):
             n = "conv%d_%d" % (blk, i)
-            pooled_branch = branches is not None and i == nconv and ("pool%d" % blk) in branches
+            routed = routes is not None and ("pool%d" % blk) in routes
+            pooled_branch = i == nconv and (routed or (branches is not None and ("pool%d" % blk) in branches))
             z = conv2d_same_t(x, P[n + "/filter"], P[n + "/biases"])
             # (a block's last conv: max(relu(z)) = relu(max(z)), so its branch record lives on the pooled tensor)
             x = z if pooled_branch else _relu_branch(z, n, branches)
             if keep:
                 acts[n] = F.relu(z) if pooled_branch else x
-        x = maxpool2x2_t(x)
-        if branches is not None and ("pool%d" % blk) in branches:
-            x = x * branches["pool%d" % blk]
+        if routed:
+            x = _pool_routed(x, routes["pool%d" % blk])
+        else:
+            x = maxpool2x2_t(x)
+            if branches is not None and ("pool%d" % blk) in branches:
+                x = x * branches["pool%d" % blk]
         pools[blk] = x
         if keep:
             acts["pool%d" % blk] = x
@@ -284,15 +301,36 @@ def branch_layers():
     return names + ["fc6", "fc7"]
 
 
+def pool_routes(acts):
+    """This restatement's own max-pool routes, from the NHWC activations of forward(..., keep=True): "pool1".."pool5" -> uint8
+    (N,h/2,w/2,C), the window element (2*row + col) holding the FIRST maximum of the block's last (post-ReLU) conv output, 4 where that
+    maximum is not > 0 -- the rule of TF's MaxPoolGrad on a ReLU output, and the encoding of fcn8s_get_pool_routing.  Second result:
+    per block, the gap between the largest and second-largest window entry relative to the largest (0 = exact tie)."""
+    routes, gaps = OrderedDict(), OrderedDict()
+    for blk, nconv in enumerate(CONVS_PER_BLOCK, start=1):
+        x = np.asarray(acts["conv%d_%d" % (blk, nconv)])
+        n, h, w, c = x.shape
+        win = x.reshape(n, h // 2, 2, w // 2, 2, c).transpose(0, 1, 3, 5, 2, 4).reshape(n, h // 2, w // 2, c, 4)
+        r = np.argmax(win, -1).astype(np.uint8)                      # numpy: first maximum
+        top = win.max(-1)
+        r[~(top > 0)] = 4
+        srt = np.sort(win, -1)
+        gaps["pool%d" % blk] = (srt[..., 3] - srt[..., 2]) / np.maximum(np.abs(srt[..., 3]), 1e-30)
+        routes["pool%d" % blk] = r
+    return routes, gaps
+
+
 def loss_and_grads(params, images, labels_onehot, l2_rate=0.0, keep_prob=1.0, masks=None,
-                   dtype=torch.float32, bf16_fc=False, branches=None):
+                   dtype=torch.float32, bf16_fc=False, branches=None, routes=None):
     """total_loss and d(total_loss)/d(every variable) -- what
     AdamOptimizer.minimize differentiates (var_list=None, :257).
-    branches: optional name -> NHWC bool/0-1 array of post-ReLU activations that are on (activation > 0), see forward_t."""
+    branches: optional name -> NHWC bool/0-1 array of post-ReLU activations that are on (activation > 0), see forward_t.
+    routes: optional "pool<b>" -> NHWC uint8 array of max-pool routes (the encoding of pool_routes), see forward_t."""
     P = _params_t(params, dtype, requires_grad=True)
     mt = None if masks is None else tuple(_t(m, dtype) for m in masks)
     bt = None if branches is None else {k: _nchw(_t(np.asarray(v) > 0, dtype)) for k, v in branches.items()}
-    logits = forward_t(P, _t(images, dtype), keep_prob, mt, bf16_fc=bf16_fc, branches=bt)
+    rt = None if routes is None else {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v).transpose(0, 3, 1, 2))).to(torch.int64) for k, v in routes.items()}
+    logits = forward_t(P, _t(images, dtype), keep_prob, mt, bf16_fc=bf16_fc, branches=bt, routes=rt)
     loss = total_loss_t(P, logits, _t(labels_onehot, dtype), l2_rate)
     grads = torch.autograd.grad(loss, list(P.values()))
     return (float(loss.detach()),

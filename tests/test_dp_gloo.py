@@ -68,3 +68,45 @@ def test_bucket_reducer_is_a_noop_without_process_group():
     red = dp.BucketReducer(t, [(0, 5), (5, 5)])
     red.reduce_bucket(0); red.reduce_bucket(1); red.wait()
     assert red.grad_scale() == 1.0 and (t == 1).all()
+
+
+def _guard_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fcn8s_tensorflow_amd import dp
+    g = torch.Generator().manual_seed(3)
+    flat = torch.randn(300000, generator=g)
+    res = [dp.check_replicas(flat, 7)]                                  # identical replicas pass
+    for mutate in ("step", "param", "swap", "nan"):
+        f, step = flat.clone(), 7
+        if rank == 1:
+            if mutate == "step":
+                step = 8
+            elif mutate == "param":
+                f[(f.numel() // (1 << 16)) * 5] += 1e-7 * (1 + abs(float(f[(f.numel() // (1 << 16)) * 5])))
+            elif mutate == "swap":
+                st = f.numel() // (1 << 16)
+                a, b = float(f[st * 10]), float(f[st * 20]); f[st * 10] = b; f[st * 20] = a
+            else:
+                f[0] = float("nan")
+        try:
+            dp.check_replicas(f, step)
+            res.append("passed")
+        except RuntimeError as e:
+            res.append(str(e))
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_replica_guard_raises_on_every_rank_when_replicas_differ():
+    """FCN8s.train's data-parallel guard (`global_step` identical on all ranks, replicas identical up to nothing): a
+    differing step, a one-ulp parameter difference, two swapped values and a NaN are each seen by BOTH ranks."""
+    world = 2
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_guard_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        res = out[r]
+        assert res[0] is True
+        assert "global step (7 .. 8)" in res[1], res[1]
+        for msg in res[2:]:
+            assert "parameter checksum" in msg, msg

@@ -65,6 +65,17 @@ def test_train_evaluate_predict_save_resume(tmp_path, capsys):
     saved = [d for d in os.listdir(tmp_path) if d.startswith('saved_model__(globalstep-')]   # save_name='' -> 'saved_model_' + '' + '_(globalstep-..', as in the reference
     assert saved and all('(eval_on_val_dataset)' in d and '(trainloss-' in d and '(mean_iou-' in d for d in saved)
     assert os.path.isfile(tmp_path / 'tb' / 'run' / 'scalars.jsonl')
+    # TensorBoard event files like the reference's two FileWriters write (fcn8s_tensorflow.py:331-366, :531-535)
+    from glob import glob
+    from fcn8s_tensorflow_amd import tf_events
+    (tr,) = glob(str(tmp_path / 'tb' / 'run' / 'events.out.tfevents.*'))
+    evs = tf_events.read_events(tr)
+    assert evs[0]['file_version'] == 'brain.Event:2' and len(evs) >= 2
+    rec = evs[1]
+    assert {'total_loss', 'learning_rate', 'fc6/kernel/mean', 'fc6/kernel/stddev_1', 'conv3_3/bias/max', 'pool3_1x1/kernel/min'} <= set(rec['scalars'])
+    assert len(rec['histograms']) == 20 and rec['histograms']['fc7/kernel/histogram']['num'] == float(np.prod(m.engine.specs['fc7/weights'][0]))
+    (ev,) = glob(str(tmp_path / 'tb' / 'run_eval' / 'events.out.tfevents.*'))
+    assert set(tf_events.read_events(ev)[1]['scalars']) == {'mean_loss', 'mean_iou', 'accuracy'}
 
     m.evaluate(gen(2, 32, 64, 2), num_batches=2, metrics={'loss', 'mean_iou'}, dataset='val')
     assert m.metric_names == ['loss', 'mean_iou'] and m.eval_dataset == 'val'

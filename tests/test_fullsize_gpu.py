@@ -95,28 +95,57 @@ def test_config2_inference_1024x512_bs1_vs_oracle():
     e.close()
 
 
-def test_config3_gradients_1024x512_bs1_vs_oracle():
+@pytest.mark.parametrize("variant,options,bound", [
+    ("F(6x6) everywhere (the default)", {}, 2e-3),
+    ("F(4x4) for blocks 1-2", {"winograd_tile_hires": 4, "winograd_hires_pixels": 256 * 512}, 1.25e-3)])
+def test_config3_gradients_1024x512_bs1_vs_oracle(variant, options, bound):
     """Every one of the 42 gradient tensors of a full-width training step at 1024x512 against the oracle (autograd over the CPU
     restatement): F(6x6,3x3) data / weight gradients at 14 706 tiles per image, fc6's F(4x4,4x4) weight gradient at depth 2048,
-    split-K atomics, conv1_1's VALU weight gradient at 512x1024 -- none of which the small cases reach at this size.
-    Tolerance: 2e-3 of each tensor's largest gradient; the measured worst case is printed."""
+    split-K atomics, conv1_1's VALU weight gradient at 512x1024 -- none of which the small cases reach at this size.  The oracle
+    differentiates along the ReLU / max-pool decisions the device took, after the test has checked that those differ from the oracle's
+    own only at fp32 coin flips (units within 1e-5 of zero, window maxima within 2e-5 of each other).
+    Bounds (error / largest gradient of the tensor; DESIGN.md section 2 and profiles/parity_r03.json for what is behind them): the fp32
+    oracle is itself 0.94e-3 away from its own float64 run on conv1_1/filter, the end of the backward chain, so 1e-3 against the *fp32*
+    oracle is the distance between two equally good fp32 answers; the direct-convolution variant of this library measures 0.98e-3, the
+    default (F(6x6) for all twelve 3x3 layers) 1.75e-3, with F(4x4) in blocks 1-2 (option, -6 % throughput) 1.08e-3."""
     from fcn8s_tensorflow_amd.engine import Engine
     P = orc.init_params(20, seed=4, decoder_std_scale=30.0, bias_std=0.05)
     img, lab = orc.synthetic_batch(1, 512, 1024)
-    e = Engine(20)
+    e = Engine(20, options=options)
     e.set_params(P)
     loss = e.forward_backward(img, lab, keep_prob=1.0, l2_rate=1e-3)
     g = e.get_grads()
+    br = e.relu_branches((1, 512, 1024))
+    rt = e.pool_routes((1, 512, 1024))
+    acts_dev = {k: e.activation(k, v.shape) for k, v in br.items()}
     e.close()
-    loss_ref, g_ref, _ = orc.loss_and_grads(P, img, orc.one_hot(lab, 20).astype(np.float32), l2_rate=1e-3)
+    _, acts = orc.forward(P, img, keep=True)
+    n_relu = n_route = 0
+    for k, on in br.items():
+        d = on != (acts[k] > 0)
+        n_relu += int(d.sum())
+        if d.any():
+            assert np.maximum(np.abs(acts_dev[k][d]), np.abs(acts[k][d])).max() < 1e-5 * np.abs(acts[k]).max(), k
+    own, gaps = orc.pool_routes(acts)
+    for k in rt:
+        d = rt[k] != own[k]
+        n_route += int(d.sum())
+        tie = d & ((rt[k] == 4) == (own[k] == 4))
+        if tie.any():
+            assert gaps[k][tie].max() <= 2e-5, (k, float(gaps[k][tie].max()))
+        onoff = d & ~tie
+        if onoff.any():
+            assert np.abs(acts[k][onoff]).max() < 1e-5 * np.abs(acts[k]).max(), k
+    del acts, acts_dev, own, gaps
+    loss_ref, g_ref, _ = orc.loss_and_grads(P, img, orc.one_hot(lab, 20).astype(np.float32), l2_rate=1e-3, branches=br, routes=rt)
     assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref)), (loss, loss_ref)
     assert len(g_ref) == 42
     errs = {k: float(np.abs(np.asarray(g[k], np.float64) - g_ref[k]).max() / (np.abs(g_ref[k]).max() + 1e-30)) for k in g_ref}
     ranked = sorted(errs.items(), key=lambda kv: -kv[1])
-    print("config 3 gradients at 1024x512, error / max per tensor, worst five:", ", ".join("%s %.2e" % kv for kv in ranked[:5]),
-          "; median %.2e" % float(np.median(list(errs.values()))))
+    print("config 3 gradients at 1024x512 [%s]: %d ReLU units and %d pool routes differ from the oracle's (all coin flips); error / max per tensor, "
+          "worst five:" % (variant, n_relu, n_route), ", ".join("%s %.2e" % kv for kv in ranked[:5]), "; median %.2e" % float(np.median(list(errs.values()))))
     for k, err in ranked:
-        assert err < 2e-3, (k, err)
+        assert err < bound, (k, err)
 
 
 def test_config3_training_step_1024x512_bs16_properties():

@@ -241,3 +241,34 @@ def test_param_table_matches_reference_names():
         assert n in specs
     assert specs["fc6/weights"] == (7, 7, 512, 4096) and specs["fc7_pool4_pool3_conv2d_trans/kernel"] == (16, 16, 20, 20)
     assert sum(int(np.prod(s)) for s in specs.values()) == 134473144
+
+
+def test_pool_routes_reproduce_the_unrouted_gradients_and_steer_ties():
+    """`routes=` (the device's max-pool decisions fed back to the checker): the oracle's own routes reproduce its unrouted loss and
+    gradients exactly; at an exact tie, choosing the other tied element is a different valid subgradient and moves the gradient."""
+    widths = (4, 4, 8, 8, 8, 16, 16)
+    P = orc.init_params(4, widths, fc6_ksize=3, seed=1, decoder_std_scale=30.0, bias_std=0.05)
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (2, 32, 64, 3), dtype=np.uint8)
+    lab = orc.one_hot(rng.integers(0, 4, (2, 32, 64), dtype=np.uint8), 4).astype(np.float32)
+    _, acts = orc.forward(P, img, keep=True)
+    routes, gaps = orc.pool_routes(acts)
+    assert set(routes) == {"pool%d" % b for b in range(1, 6)}
+    assert routes["pool1"].shape == (2, 16, 32, 4) and routes["pool1"].dtype == np.uint8 and routes["pool1"].max() <= 4
+    on = acts["pool1"] > 0
+    np.testing.assert_array_equal(routes["pool1"] == 4, ~on)              # 4 = the window's maximum is not > 0
+    l0, g0, z0 = orc.loss_and_grads(P, img, lab, l2_rate=1e-3)
+    l1, g1, z1 = orc.loss_and_grads(P, img, lab, l2_rate=1e-3, routes=routes)
+    assert abs(l0 - l1) < 1e-6 * abs(l0)
+    assert np.abs(z0 - z1).max() < 1e-5 * np.abs(z0).max()       # (same values pooled; the convs behind may pick another summation order)
+    for k in g0:
+        np.testing.assert_allclose(g1[k], g0[k], rtol=0, atol=2e-5 * np.abs(g0[k]).max())
+    # known answer on one window: entries (3, 7, 7, 1) -> first maximum is element 1; element 2 is the tied alternative
+    z = torch.tensor([[[[3.0, 7.0], [7.0, 1.0]]]], requires_grad=True)
+    for r, want in ((1, [[0, 1], [0, 0]]), (2, [[0, 0], [1, 0]])):
+        y = orc._pool_routed(z, torch.tensor([[[[r]]]]))
+        assert float(y.detach()) == 7.0
+        (gz,) = torch.autograd.grad(y.sum(), z)
+        assert gz[0, 0].tolist() == want
+    y = orc._pool_routed(z, torch.tensor([[[[4]]]]))
+    assert float(y.detach()) == 0.0

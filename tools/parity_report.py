@@ -13,8 +13,9 @@ For each algorithm variant of the 3x3 stack -- "f6" (the default: Winograd F(6x6
   c3 (1024x512, one image, full width): the error of each of the 42 gradient tensors, as max |g - g_ref| / max |g_ref| and as
       |g - g_ref|_2 / |g_ref|_2, against the fp32 oracle AND against the same oracle run in float64 -- next to the fp32 oracle's own
       distance from float64, which is what "as accurate as the reference's fp32 CPU path" has to be measured against.  Each comparison
-      is made twice: against the oracle's own ReLU branches ("raw") and against the oracle differentiating along the branches the device
-      took ("aligned", Engine.relu_branches -> oracle `branches=`), with the number of units that differ and how close to zero they sit.
+      is made twice: against the oracle's own ReLU / max-pool decisions ("raw") and against the oracle differentiating along the decisions
+      the device took ("aligned", Engine.relu_branches / pool_routes -> oracle `branches=` / `routes=`), with the number of units / windows
+      that differ and how close to a tie they sit.
 
 Imports only the package and oracle/ (checker)."""
 import argparse
@@ -113,6 +114,7 @@ def main():
     onehot = orc.one_hot(lab2, 20).astype(np.float32)
     loss32, g32, _ = orc.loss_and_grads(P_g, img2, onehot, l2_rate=1e-3)
     _, acts_g = orc.forward(P_g, img2, keep=True)
+    own_routes, route_gaps = orc.pool_routes(acts_g)
     acts_g = {k: acts_g[k] for k in orc.branch_layers()}
     rep["oracle_seconds_fp32"] = time.time() - t0
     g64 = None
@@ -149,15 +151,28 @@ def main():
                 n_diff += int(d.sum())
                 gpu = e.activation(k, acts_g[k].shape)
                 worst = max(worst, float(np.maximum(np.abs(gpu[d]), np.abs(acts_g[k][d])).max() / (np.abs(acts_g[k]).max() + 1e-30)))
+        rt = e.pool_routes((1, H2, W2))
+        n_win, n_rdiff, worst_gap = 0, 0, 0.0
+        for k in rt:
+            d = rt[k] != own_routes[k]
+            n_win += rt[k].size
+            if d.any():
+                n_rdiff += int(d.sum())
+                tie = d & ((rt[k] == 4) == (own_routes[k] == 4))
+                if tie.any():
+                    worst_gap = max(worst_gap, float(route_gaps[k][tie].max()))
+        block["c3"]["pool_windows"] = n_win
+        block["c3"]["pool_routes_differing_from_oracle"] = n_rdiff
+        block["c3"]["largest_relative_gap_between_the_two_window_maxima_at_a_differing_route"] = worst_gap
         block["c3"]["relu_units"] = n_units
         block["c3"]["relu_units_differing_from_oracle"] = n_diff
         block["c3"]["largest_activation_at_a_differing_unit_over_layer_max"] = worst
         e.close()
-        _, ga32, _ = orc.loss_and_grads(P_g, img2, onehot, l2_rate=1e-3, branches=br)
+        _, ga32, _ = orc.loss_and_grads(P_g, img2, onehot, l2_rate=1e-3, branches=br, routes=rt)
         ea32 = grad_errors(g, ga32)
         block["c3"]["aligned_vs_oracle_fp32"] = {"summary": summarize(ea32), "per_tensor": ea32}
         if g64 is not None:
-            _, ga64, _ = orc.loss_and_grads(P_g, img2, onehot, l2_rate=1e-3, dtype=torch.float64, branches=br)
+            _, ga64, _ = orc.loss_and_grads(P_g, img2, onehot, l2_rate=1e-3, dtype=torch.float64, branches=br, routes=rt)
             ea64 = grad_errors(g, ga64)
             block["c3"]["aligned_vs_oracle_fp64"] = {"summary": summarize(ea64), "per_tensor": ea64}
             eo = grad_errors(ga32, ga64)
@@ -166,7 +181,7 @@ def main():
         rep["variants"][key] = block
         print(key, "c2 x30:", block["c2"]["decoder_x30"], "\n   c3 vs fp32 oracle:", block["c3"]["vs_oracle_fp32"]["summary"],
               "\n   c3 vs fp64 oracle:", block["c3"].get("vs_oracle_fp64", {}).get("summary"),
-              "\n   c3 relu units differing:", n_diff, "of", n_units, "worst", worst,
+              "\n   c3 relu units differing:", n_diff, "of", n_units, "worst", worst, "; pool routes differing:", n_rdiff, "of", n_win, "worst gap", worst_gap,
               "\n   c3 aligned vs fp32 oracle:", block["c3"]["aligned_vs_oracle_fp32"]["summary"],
               "\n   c3 aligned vs fp64 oracle:", block["c3"].get("aligned_vs_oracle_fp64", {}).get("summary"), flush=True)
     if g64 is not None:
