@@ -53,6 +53,7 @@ SIGNATURES = {
     "fcn8s_train_step": (_i, [_p, _p, _i, _p, _i, _i, _i, _f, _f, _f, _i, _fp, _i64p]),
     "fcn8s_forward_loss": (_i, [_p, _p, _i, _p, _i, _i, _i, _f, _f, _i]),
     "fcn8s_backward_bucket": (_i, [_p, _i]),
+    "fcn8s_bucket_complete_after": (_i, [_p, _i]),
     "fcn8s_apply_update": (_i, [_p, _i, _f, _f]),
     "fcn8s_read_loss": (_i, [_p, _fp]),
     "fcn8s_eval_step": (_i, [_p, _p, _i, _p, _i, _i, _i, _f, _i]),
@@ -76,7 +77,7 @@ SIGNATURES = {
     "fcn8s_get_option": (_i, [_p, C.c_char_p, _i64p]),
     "fcn8s_get_activation": (_i, [_p, C.c_char_p, _p, _sz]),
     "fcn8s_get_dropout_masks": (_i, [_p, _p, _sz, _p, _sz]),
-    "fcn8s_get_pool_routing": (_i, [_p, C.c_int, _p, _sz]),
+    "fcn8s_get_pool_routing": (_i, [_p, _i, _p, _sz]),
     "fcn8s_crc32c": (C.c_uint32, [_p, _sz, C.c_uint32]),
     "fcn8s_profile_enable": (_i, [_p, _i]),
     "fcn8s_profile_reset": (_i, [_p]),

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <algorithm>
+#include <functional>
 #include <map>
 #include <set>
 #include <string>
@@ -107,6 +108,19 @@ struct fcn8s_model {
                        size_t cap_img = 0, cap_lab = 0; hipEvent_t ready = nullptr, consumed = nullptr; bool used = false; };
     StageSlot slots[FCN8S_NUM_STAGE_SLOTS];
     hipStream_t copy_stream = nullptr;
+    // Deferred weight gradients.  Nothing in the backward pass consumes a weight gradient, so the MFMA-bound weight-gradient GEMMs of the
+    // deep layers (conv3_1 .. conv5_3 at level >= 1, fc6 / fc7 too at level 2) are held back and launched on `side` when the data-gradient
+    // chain reaches block `defer_start_block`: from there on it is HBM-bound (Winograd transforms and K = 64 / 128 position GEMMs of blocks
+    // 2 and 1), and the two kinds of work share the CUs.  Each deferred layer keeps its dM = A dY A^T in a buffer of its own.
+    int defer_wgrad = 2, defer_start_block = 2;
+    int defer_level_now = 0;                                             // level the running backward pass uses (the bucket API caps it at 1)
+    hipStream_t side = nullptr;
+    float* d_wino_u2 = nullptr; size_t ufl = 0;                          // dU scratch of the side stream (ufl floats, like d_wino_u)
+    std::vector<std::pair<hipEvent_t, std::function<void(hipStream_t)>>> deferred;   // (inputs-ready event on the main stream, launches)
+    std::vector<hipEvent_t> ev_pool; size_t ev_next = 0;
+    hipEvent_t side_done = nullptr;
+    hipStream_t launch_stream = nullptr;                                 // != nullptr while deferred work is being enqueued: ProfScope records there
+    float* dm_ptr = nullptr;                                             // where dm_layer's dM lives (d_wino_m or the layer's own buffer)
     std::vector<ProfGroup> groups;
     std::string err;
 };
@@ -198,13 +212,13 @@ struct ProfScope {
         fcn8s::g_last_kernel = nullptr;
         gid = (m->profile_detail && layer) ? group_id(m, (std::string(group) + ":" + layer).c_str()) : group_id(m, group);
         hipEventCreate(&a); hipEventCreate(&b);
-        hipEventRecord(a, m->stream);
+        hipEventRecord(a, m->launch_stream ? m->launch_stream : m->stream);
         m->groups[gid].flops += flops; m->groups[gid].bytes += bytes; m->groups[gid].launches += 1;
     }
     ~ProfScope()
     {
         if (gid < 0) return;
-        hipEventRecord(b, m->stream);
+        hipEventRecord(b, m->launch_stream ? m->launch_stream : m->stream);
         m->groups[gid].ev.emplace_back(a, b);
         if (fcn8s::g_last_kernel) {          // second view of the same launch, keyed by the kernel symbol that ran
             const int k = group_id(m, (std::string("kernel:") + fcn8s::g_last_kernel).c_str());
@@ -317,7 +331,7 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
         const int P = 64;
         const long long T = wino_tiles(6, N, H, W);
         IgemmArgs a{}; a.split = split_of(m);
-        a.x = m->d_wino_m; a.w = m->d_wino_u; a.y = m->d_wino_v;
+        a.x = m->dm_ptr ? m->dm_ptr : m->d_wino_m; a.w = m->d_wino_u; a.y = m->d_wino_v;
         a.N = 1; a.Ma = (int)T; a.Mb = 1; a.M = T;
         a.Hi = (int)T; a.Wi = 1; a.Cin = Cin; a.ldx = Cin;
         a.KW = 1; a.in_scale = 1; a.tap_step = 1; a.tap_off = 0; a.Ktot = Cin;
@@ -347,7 +361,7 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
             const int P = 49, Ng = 4 * Cout;
             const long long T = wino_tiles(4, N, H, W);
             IgemmArgs a{}; a.split = split_of(m);
-            a.x = m->d_wino_m; a.w = kept->second; a.y = m->d_wino_v;
+            a.x = m->dm_ptr ? m->dm_ptr : m->d_wino_m; a.w = kept->second; a.y = m->d_wino_v;
             a.N = 1; a.Ma = (int)T; a.Mb = 1; a.M = T;
             a.Hi = (int)T; a.Wi = 1; a.Cin = Cin; a.ldx = Cin;
             a.KW = 1; a.in_scale = 1; a.tap_step = 1; a.tap_off = 0; a.Ktot = Cin;
@@ -441,9 +455,45 @@ void tconv_dgrad(fcn8s_model* m, const float* dy, const float* w, float* dx, int
     else launch_igemm(a, 1, s);
 }
 
+// Deferred weight gradients (fcn8s_model::defer_wgrad): helpers
+hipEvent_t defer_event(fcn8s_model* m)
+{
+    if (m->ev_next == m->ev_pool.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); m->ev_pool.push_back(e); }
+    return m->ev_pool[m->ev_next++];
+}
+bool defer_ready(fcn8s_model* m)
+{
+    if (!m->side) {
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);                 // lo = numerically greatest = lowest priority: the chain on the main stream goes first
+        if (hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, lo) != hipSuccess) { m->side = nullptr; (void)hipGetLastError(); return false; }
+        hipEventCreateWithFlags(&m->side_done, hipEventDisableTiming);
+    }
+    if (!m->d_wino_u2 && hipMalloc((void**)&m->d_wino_u2, m->ufl * sizeof(float)) != hipSuccess) { m->d_wino_u2 = nullptr; (void)hipGetLastError(); return false; }
+    return true;
+}
+// launch everything held back so far on the side stream (each item waits for the event that marks its inputs ready)
+void flush_deferred(fcn8s_model* m)
+{
+    if (m->deferred.empty()) return;
+    m->launch_stream = m->side;
+    for (auto& d : m->deferred) { hipStreamWaitEvent(m->side, d.first, 0); d.second(m->side); }
+    m->launch_stream = nullptr;
+    m->deferred.clear();
+}
+// end of the backward pass: the main stream continues only after the side stream has drained
+void join_deferred(fcn8s_model* m)
+{
+    flush_deferred(m);
+    if (m->side && m->ev_next) { hipEventRecord(m->side_done, m->side); hipStreamWaitEvent(m->stream, m->side_done, 0); }
+    m->ev_next = 0;
+}
+
+// phase: 0 = everything on stream s; 1 = only what the data gradient needs (the transform of dz into dM) -- the weight gradient itself
+// is held back; 2 = the held-back part (GEMM, filter-gradient transform, bias gradient) on stream s.
 void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* dz, float* dw, float* db,
                 int N, int H, int W, int Cin, int Cout, int K, float alpha, hipStream_t s, int real_cin = 0,
-                const char* layer = nullptr, bool fuse_dgrad_input = false, const unsigned char* pool_idx = nullptr)
+                const char* layer = nullptr, bool fuse_dgrad_input = false, const unsigned char* pool_idx = nullptr, int phase = 0)
 {
     WgradArgs a{}; a.split = split_of(m);
     a.A = x; a.B = dz; a.C = dw;
@@ -461,8 +511,11 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             const int tile = wino_tile_for(m, H, W, K), NP = wino_alpha(tile, K) * wino_alpha(tile, K);
             const long long T = wino_tiles(tile, N, H, W);
             const int Kg = wino_nsub(K) * wino_nsub(K) * Cin;           // rows of V / dU: [sub-filter][channel]
+            // a deferred layer keeps its dM in a buffer of its own ("dmk:<layer>", ensure_workspace) and its dU scratch on the side stream
+            float* dmbuf = m->d_wino_m; float* dubuf = m->d_wino_u;
+            if (phase) { dmbuf = m->acts.at(std::string("dmk:") + layer).p; dubuf = m->d_wino_u2; }
             WgradArgs g{}; g.split = split_of(m);
-            g.A = it->second.p; g.B = m->d_wino_m; g.C = m->d_wino_u;
+            g.A = it->second.p; g.B = dmbuf; g.C = dubuf;
             g.N = 1; g.Pa = 1; g.Pb = (int)T; g.P = T;
             g.Ha = 1; g.Wa = (int)T; g.Adim = Kg; g.lda = Kg; g.Areal = Kg;
             g.Bdim = Cout; g.ldb = Cout; g.KW = 1; g.a_scale = 1; g.tap_off = 0; g.ntaps = NP; g.ldc = Cout; g.alpha = 1.f; g.colsum = nullptr;
@@ -471,25 +524,29 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             // transform V = B^T dz B is written into d_wino_v by the same kernel that writes dM (one read of dz)
             bool fused = false, dm_ready = false;
             const bool adj_bytes = fuse_dgrad_input && tile == 6 && K == 3 && Cin % 64 == 0 && Cout % 64 == 0;
+            if (phase != 2) {
             { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout * (pool_idx ? 0.3125 : 1.0) + ((fuse_dgrad_input && !adj_bytes) ? 2.0 : 1.0) * NP * T * Cout));
               // pool_idx: dz is d(pool) [N,H/2,W/2,Cout]; the max-pool backward happens inside the transform (the caller checked eligibility)
               // adjoint data gradient (tile 6): it consumes dM itself, no second transform of dz
-              if (adj_bytes) { launch_wino_dout(6, dz, m->d_wino_m, N, H, W, Cout, s, 3, pool_idx); dm_ready = true; }
+              if (adj_bytes) { launch_wino_dout(6, dz, dmbuf, N, H, W, Cout, s, 3, pool_idx); dm_ready = true; }
               else {
-                  if (fuse_dgrad_input && tile >= 4 && K == 3) fused = launch_wino_input_dout(tile, dz, m->d_wino_v, m->d_wino_m, N, H, W, Cout, s, pool_idx);
-                  if (!fused) launch_wino_dout(tile, dz, m->d_wino_m, N, H, W, Cout, s, K);
+                  if (fuse_dgrad_input && tile >= 4 && K == 3) fused = launch_wino_input_dout(tile, dz, m->d_wino_v, dmbuf, N, H, W, Cout, s, pool_idx);
+                  if (!fused) launch_wino_dout(tile, dz, dmbuf, N, H, W, Cout, s, K);
               } }
-            // fc6: the non-fused transform above left dM = A dz A^T in d_wino_m; its adjoint data gradient (conv_same) consumes it
+            // fc6: the non-fused transform above left dM = A dz A^T in dmbuf; its adjoint data gradient (conv_same) consumes it
             if (K == 7 && tile == 4 && !fused && Cin % 2 == 0 && bt_gemm_ok(Cout, 4 * Cin) && m->u_train.count(std::string(layer) + "#4")) dm_ready = true;
             m->fused_v_layer = fused ? layer : "";
             m->dm_layer = dm_ready ? layer : "";
+            m->dm_ptr = dmbuf;
+            }
+            if (phase == 1) return;
             { ProfScope ps(m, K == 7 ? "wino_gemm_fc6_wgrad" : "wino_gemm_wgrad", 2.0 * NP * T * Kg * Cout, 4.0 * NP * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_wgrad(g, s); }
             { ProfScope ps(m, "wino_transform", 0, 4.0 * (9.0 + NP) * Cin * Cout + 4.0 * N * H * W * Cout * (tile >= 4 ? 1.0 / (tile * tile) : 1.0));
-              launch_wino_dfilter(tile, m->d_wino_u, dw, Cin, Cout, K, s);
+              launch_wino_dfilter(tile, dubuf, dw, Cin, Cout, K, s);
               // bias gradient = sum of dz over all pixels.  dM[(1,1)] = sum_kl A^T(k,1) dz[k][l] A^T(l,1) and column 1 of A^T is all ones:
               // the slab of position (1,1) holds the per-tile sums -- 16x fewer bytes than dz, and dz need not exist
               if (db) {
-                  if (tile >= 4) launch_colsum(m->d_wino_m + (wino_alpha(tile, K) + 1) * wino_slab(T, Cout), db, T, Cout, s);
+                  if (tile >= 4) launch_colsum(dmbuf + (wino_alpha(tile, K) + 1) * wino_slab(T, Cout), db, T, Cout, s);
                   else launch_colsum(dz, db, (long long)N * H * W, Cout, s);
               } }
             return;
@@ -633,6 +690,26 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
                     cin = m->widths[b];
                 }
             if (fc6w) items.push_back({"wv:fc6", slab_floats(h5_, w5_, m->widths[4], 7), 0, 0, 0, nullptr});
+            if (m->defer_wgrad > 0) {
+                // deferred weight gradients: dM = A dY A^T of conv3_1 .. conv5_3 (and fc6, and fc7's dz) stays alive until the side stream has used it
+                int cin2 = m->widths[1];
+                for (int b = 2, hh = H / 4, ww = W / 4; b < 5; ++b, hh /= 2, ww /= 2)
+                    for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
+                        const int cw = m->widths[b];
+                        if (cin2 >= m->wino_min_cin && cin2 % 64 == 0 && cw % 64 == 0 && wino_tile_for(m, hh, ww, 3) == 6) {
+                            char nm[40]; snprintf(nm, sizeof nm, "dmk:conv%d_%d", b + 1, i);
+                            items.push_back({nm, (size_t)64 * (size_t)wino_slab(wino_tiles(6, N, hh, ww), cw), 0, 0, 0, nullptr});
+                        }
+                        cin2 = cw;
+                    }
+                if (m->defer_wgrad > 1) {
+                    if (fc6w && m->widths[4] % 2 == 0 && bt_gemm_ok(m->widths[5], 4 * m->widths[4])) {
+                        const int al = wino_alpha(4, 7);
+                        items.push_back({"dmk:fc6", (size_t)al * al * (size_t)wino_slab(wino_tiles(4, N, h5_, w5_), m->widths[5]), 0, 0, 0, nullptr});
+                    }
+                    items.push_back({"dz:fc7", (size_t)N * h5_ * w5_ * m->widths[6], 0, 0, 0, nullptr});
+                }
+            }
         }
     }
 
@@ -956,13 +1033,27 @@ void backward_bucket0(fcn8s_model* m)
     // s7 = conv1x1(fc7)
     conv_wgrad(m, "score1x1_wgrad", A(m, "fc7"), m->ds7, Gp(m, "fc7_1x1/kernel"), Gp(m, "fc7_1x1/bias"), N, h5, w5, m->widths[6], C, 1, 1.f, s);
     l2_grad(m, "fc7_1x1/kernel");
+    // (level 2 of the deferred weight gradients: fc7's dz gets a buffer of its own so that the weight gradient can run later, on the side stream)
+    const bool defer_fc = m->defer_level_now >= 2 && m->acts.count("dz:fc7") && defer_ready(m);
+    float* dz7 = defer_fc ? A(m, "dz:fc7") : m->gbuf[0];
     { Epi e; e.mask = A(m, "fc7"); e.mask_scale = inv_keep;
-      conv_same(m, "score1x1_dgrad", m->ds7, WTp(m, "fc7_1x1/kernel"), m->gbuf[0], N, h5, w5, C, m->widths[6], 1, e, s); }
+      conv_same(m, "score1x1_dgrad", m->ds7, WTp(m, "fc7_1x1/kernel"), dz7, N, h5, w5, C, m->widths[6], 1, e, s); }
     // fc7
-    conv_wgrad(m, "fc7_wgrad", A(m, "fc6"), m->gbuf[0], Gp(m, "fc7/weights"), Gp(m, "fc7/biases"), N, h5, w5, m->widths[5], m->widths[6], 1, 1.f, s);
+    if (defer_fc) {
+        hipEvent_t ev = defer_event(m); hipEventRecord(ev, s);
+        m->deferred.emplace_back(ev, [m, dz7, N, h5, w5](hipStream_t ss) {
+            conv_wgrad(m, "fc7_wgrad", A(m, "fc6"), dz7, Gp(m, "fc7/weights"), Gp(m, "fc7/biases"), N, h5, w5, m->widths[5], m->widths[6], 1, 1.f, ss); });
+    } else conv_wgrad(m, "fc7_wgrad", A(m, "fc6"), dz7, Gp(m, "fc7/weights"), Gp(m, "fc7/biases"), N, h5, w5, m->widths[5], m->widths[6], 1, 1.f, s);
     { Epi e; e.mask = A(m, "fc6"); e.mask_scale = inv_keep;
-      conv_same(m, "fc7_dgrad", m->gbuf[0], WTp(m, "fc7/weights"), m->gbuf[1], N, h5, w5, m->widths[6], m->widths[5], 1, e, s); }
+      conv_same(m, "fc7_dgrad", dz7, WTp(m, "fc7/weights"), m->gbuf[1], N, h5, w5, m->widths[6], m->widths[5], 1, e, s); }
     // fc6
+    if (defer_fc && m->acts.count("dmk:fc6") && m->acts.count("wv:fc6") && m->u_train.count("fc6#4")) {
+        float* dz6 = m->gbuf[1];
+        conv_wgrad(m, "fc6_wgrad", A(m, "pool5"), dz6, Gp(m, "fc6/weights"), Gp(m, "fc6/biases"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, 1.f, s, 0, "fc6", false, nullptr, 1);
+        hipEvent_t ev = defer_event(m); hipEventRecord(ev, s);
+        m->deferred.emplace_back(ev, [m, dz6, N, h5, w5](hipStream_t ss) {
+            conv_wgrad(m, "fc6_wgrad", A(m, "pool5"), dz6, Gp(m, "fc6/weights"), Gp(m, "fc6/biases"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, 1.f, ss, 0, "fc6", false, nullptr, 2); });
+    } else
     conv_wgrad(m, "fc6_wgrad", A(m, "pool5"), m->gbuf[1], Gp(m, "fc6/weights"), Gp(m, "fc6/biases"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, 1.f, s, 0, "fc6");
     { Epi e; e.dgrad = 1; e.w_fwd = Wp(m, "fc6/weights"); e.lazy_wt = 1;      // (flipped + transposed copy only if the adjoint path is not taken)
       conv_same(m, "fc6_dgrad", m->gbuf[1], WTp(m, "fc6/weights"), m->gbuf[0], N, h5, w5, m->widths[5], m->widths[4], m->fc6k, e, s, 0, "fc6"); }
@@ -975,6 +1066,7 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
     hipStream_t s = m->stream;
     const int N = m->N;
     for (int b = b_hi; b >= b_lo; --b) {
+        if (b == m->defer_start_block) flush_deferred(m);       // from here on the chain is HBM-bound: the held-back weight-gradient GEMMs run beside it
         const int h = m->H >> (b - 1), w = m->W >> (b - 1);      // resolution of this block's convs
         const int cw = m->widths[b - 1];
         const int nconv = kConvsPerBlock[b - 1];
@@ -1004,8 +1096,19 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
             // the data-gradient conv (cw -> cin channels) takes the Winograd path under the same conditions as conv_same()
             const bool dgrad_wino = !first && m->wino_min_cin > 0 && cw >= m->wino_min_cin && m->d_wino_v && wino_tile_for(m, h, w) >= 4 &&
                                     cw % 16 == 0 && cin % 64 == 0;
+            const unsigned char* pix = i == nconv ? pidx : nullptr;
+            const bool defer = m->defer_level_now >= 1 && b > m->defer_start_block && dgrad_wino && wino_tile_for(m, h, w) == 6 && cw % 64 == 0 &&
+                               m->acts.count(std::string("dmk:") + nm) && m->acts.count(std::string("wv:") + nm) && defer_ready(m);
+            if (defer) {
+                conv_wgrad(m, "conv3x3_wgrad", xin, dz, Gp(m, std::string(nm) + "/filter"), Gp(m, std::string(nm) + "/biases"),
+                           N, h, w, cin, cw, 3, 1.f, s, 0, nm, true, pix, 1);
+                hipEvent_t ev = defer_event(m); hipEventRecord(ev, s);
+                const std::string lname = nm;
+                m->deferred.emplace_back(ev, [m, lname, xin, dz, N, h, w, cin, cw, pix](hipStream_t ss) {
+                    conv_wgrad(m, "conv3x3_wgrad", xin, dz, Gp(m, lname + "/filter"), Gp(m, lname + "/biases"), N, h, w, cin, cw, 3, 1.f, ss, 0, lname.c_str(), true, pix, 2); });
+            } else
             conv_wgrad(m, first ? "conv1_1_wgrad" : "conv3x3_wgrad", xin, dz, Gp(m, std::string(nm) + "/filter"), Gp(m, std::string(nm) + "/biases"),
-                       N, h, w, cin, cw, 3, 1.f, s, real_cin, nm, dgrad_wino, i == nconv ? pidx : nullptr);
+                       N, h, w, cin, cw, 3, 1.f, s, real_cin, nm, dgrad_wino, pix);
             if (first) break;
             Epi e; e.dgrad = 1; e.w_fwd = Wp(m, std::string(nm) + "/filter"); e.lazy_wt = 1;
             if (i > 1) {                                                   // ReLU of the previous conv
@@ -1020,13 +1123,20 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
     }
 }
 
-int do_backward_bucket(fcn8s_model* m, int bucket)
+// level_cap: 1 for the bucket-by-bucket API (bucket 0 -- fc6, fc7, decoder -- is final when its call returns, so that its all-reduce can start
+// at once; buckets 1 and 2 are final after the last call, see fcn8s_bucket_complete_after), 2 for the fused step
+int do_backward_bucket(fcn8s_model* m, int bucket, int level_cap)
 {
     if (!m->have_loss || !m->train_mode) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: call fcn8s_forward_loss first");
     if (bucket != m->next_bucket) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: buckets must be run in order 0,1,2");
-    if (bucket == 0) backward_bucket0(m);
+    if (bucket == 0) {
+        m->defer_level_now = std::min(m->defer_wgrad, level_cap);
+        if (m->profile && m->profile_detail) m->defer_level_now = 0;      // per-layer timing wants one kernel at a time
+        m->deferred.clear(); m->ev_next = 0;
+        backward_bucket0(m);
+    }
     else if (bucket == 1) backward_blocks(m, 5, 4);
-    else backward_blocks(m, 3, 1);
+    else { backward_blocks(m, 3, 1); join_deferred(m); }
     m->next_bucket = bucket + 1;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(m, FCN8S_ERR_HIP, std::string("backward launch: ") + hipGetErrorString(e));
@@ -1125,6 +1235,7 @@ int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
         size_t ufl = 64 * (size_t)cmax * cmax;                        // F(6x6,3x3): 64 positions
         if (m->fc6k == 7) ufl = std::max(ufl, 49 * 4 * (size_t)m->widths[4] * m->widths[5]);   // fc6: 49 positions x 4 sub-filters
         if ((e = hipMalloc((void**)&m->d_wino_u, ufl * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+        m->ufl = ufl;
     }
     if ((e = hipMalloc((void**)&m->d_loss, (2 + 64) * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     m->d_regsum = m->d_loss + 1; m->d_lastbias = m->d_loss + 2;
@@ -1157,6 +1268,10 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->d_v) hipFree(m->d_v);
     if (m->d_wt) hipFree(m->d_wt);
     if (m->d_w1pad) hipFree(m->d_w1pad);
+    if (m->d_wino_u2) hipFree(m->d_wino_u2);
+    if (m->side) hipStreamDestroy(m->side);
+    if (m->side_done) hipEventDestroy(m->side_done);
+    for (auto e : m->ev_pool) hipEventDestroy(e);
     for (auto& kv : m->u_train) if (kv.second) hipFree(kv.second);
     if (m->d_wino_u) hipFree(m->d_wino_u);
     for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
@@ -1228,6 +1343,8 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "winograd_tile") return &m->wino_tile;
     if (key == "winograd_fc6") return &m->wino_fc6;
     if (key == "tconv_gemm") return &m->tconv_gemm;
+    if (key == "defer_wgrad") return &m->defer_wgrad;
+    if (key == "defer_start_block") return &m->defer_start_block;
     if (key == "winograd_tile_hires") return &m->wino_tile_hires;
     if (key == "winograd_hires_pixels") return &m->wino_hires_pixels;
     return nullptr;
@@ -1245,6 +1362,8 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
     if (k == "winograd_tile" && value != 2 && value != 4 && value != 6) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_tile must be 2, 4 or 6");
     if (k == "winograd_tile_hires" && value != 0 && value != 2 && value != 4 && value != 6) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_tile_hires must be 0, 2, 4 or 6");
     if (k == "winograd_min_cin" && value < 0) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_min_cin must be >= 0 (0 = direct convolution everywhere)");
+    if (k == "defer_wgrad" && (value < 0 || value > 2)) return fail(m, FCN8S_ERR_BAD_ARG, "defer_wgrad must be 0, 1 or 2");
+    if (k == "defer_start_block" && (value < 1 || value > 4)) return fail(m, FCN8S_ERR_BAD_ARG, "defer_start_block must be 1 .. 4");
     if (*slot == (int)value) return FCN8S_OK;
     HIPCHK(m, hipStreamSynchronize(m->stream));
     *slot = (k == "winograd_fc6" || k == "tconv_gemm") ? (value != 0) : (int)value;
@@ -1355,7 +1474,14 @@ int fcn8s_forward_loss(fcn8s_model* m, const void* images, int dtype, const uint
 int fcn8s_backward_bucket(fcn8s_model* m, int bucket)
 {
     if (!m || bucket < 0 || bucket >= FCN8S_NUM_BUCKETS) return fail(m, FCN8S_ERR_BAD_ARG, "bad bucket");
-    return do_backward_bucket(m, bucket);
+    return do_backward_bucket(m, bucket, 1);
+}
+
+int fcn8s_bucket_complete_after(const fcn8s_model* m, int bucket)
+{
+    if (!m || bucket < 0 || bucket >= FCN8S_NUM_BUCKETS) return -1;
+    if (bucket == 0 || m->defer_wgrad == 0) return bucket;
+    return FCN8S_NUM_BUCKETS - 1;           // weight gradients of conv3_1 .. conv5_3 are held back until the last call (deferred weight gradients)
 }
 
 int fcn8s_apply_update(fcn8s_model* m, int optimizer, float lr, float grad_scale)
@@ -1397,7 +1523,7 @@ int fcn8s_train_step(fcn8s_model* m, const void* images, int dtype, const uint8_
 {
     if (m && m->frozen) fcn8s_freeze_params(m, 0);      // parameters are about to change (or a training pass starts): leave the frozen state
     int rc = fcn8s_forward_loss(m, images, dtype, labels, N, H, W, keep_prob, l2_rate, where); if (rc) return rc;
-    for (int b = 0; b < FCN8S_NUM_BUCKETS; ++b) { rc = do_backward_bucket(m, b); if (rc) return rc; }
+    for (int b = 0; b < FCN8S_NUM_BUCKETS; ++b) { rc = do_backward_bucket(m, b, 2); if (rc) return rc; }
     rc = fcn8s_apply_update(m, FCN8S_OPT_TF_ADAM, lr, 1.f); if (rc) return rc;
     if (loss_out) { rc = fcn8s_read_loss(m, loss_out); if (rc) return rc; }
     if (step_out) *step_out = m->step;

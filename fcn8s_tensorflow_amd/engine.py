@@ -424,10 +424,15 @@ class Engine:
             t0 = self.torch.cuda.Event(enable_timing=True); t0.record()
             trace.append(("step", t0, None))
         red = BucketReducer(self.flat_grads, self.buckets, self.pg, trace=trace, always=always)
+        # bucket b is final once the call `ready_after[b]` has returned (include/fcn8s_hip.h): bucket 0 -- fc6, fc7, decoder, 479 of the
+        # 538 MB -- at its own call, so RCCL moves it while the conv stack's backward runs; the two small ones after the last call
+        ready_after = [int(L.lib.fcn8s_bucket_complete_after(self.h, b)) for b in range(L.NUM_BUCKETS)]
         for b in range(L.NUM_BUCKETS):
             L.check(L.lib.fcn8s_backward_bucket(self.h, b), self.h)
             if reduce:
-                red.reduce_bucket(b)      # RCCL moves bucket b while the next bucket's backward runs
+                for r in range(L.NUM_BUCKETS):
+                    if ready_after[r] == b:
+                        red.reduce_bucket(r)
         red.wait()
         L.check(L.lib.fcn8s_apply_update(self.h, optimizer, float(learning_rate), red.grad_scale() if reduce else 1.0), self.h)
         if trace is not None:

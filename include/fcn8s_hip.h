@@ -116,12 +116,16 @@ int fcn8s_train_step(fcn8s_model* m, const void* images, int image_dtype, const 
                      int where, float* loss_out, int64_t* step_out);
 
 /* split-phase form for data-parallel training: forward + loss, then backward
- * one gradient bucket at a time (bucket b's gradients are final when
- * fcn8s_backward_bucket(m,b) returns, stream-ordered), then the update.
+ * one gradient bucket at a time, then the update.  Bucket b's gradients are final
+ * (stream-ordered) when the call fcn8s_backward_bucket(m, fcn8s_bucket_complete_after(m, b))
+ * has returned: bucket 0 (fc6, fc7, decoder: 479 of the 538 MB) at its own call, so that its
+ * all-reduce overlaps the rest of the backward pass; with deferred weight gradients
+ * (option "defer_wgrad", default on) buckets 1 and 2 (59 MB) at the last call.
  * `grad_scale` multiplies the gradients inside the update (1/world_size).      */
 int fcn8s_forward_loss(fcn8s_model* m, const void* images, int image_dtype, const uint8_t* label_ids,
                        int N, int H, int W, float keep_prob, float l2_rate, int where);
 int fcn8s_backward_bucket(fcn8s_model* m, int bucket);
+int fcn8s_bucket_complete_after(const fcn8s_model* m, int bucket);
 int fcn8s_apply_update(fcn8s_model* m, int optimizer, float learning_rate, float grad_scale);
 int fcn8s_read_loss(fcn8s_model* m, float* loss_out);                /* synchronises */
 
@@ -183,6 +187,10 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *                              tile `tile_hires` (F(4x4) carries half the round-off of F(6x6); the layers next to the input see the longest sums)
  *     "winograd_fc6"      1    fc6 as a 2x2 grid of 4x4 sub-filters through F(4x4,4x4); 0 = direct 7x7
  *     "tconv_gemm"        1    the 16x16/8 transposed conv as one GEMM over output blocks (blocked logits); 0 = 64 sub-pixel phases
+ *     "defer_wgrad"       2    deferred weight gradients: 1 = the weight-gradient GEMMs of conv3_1 .. conv5_3 are held back and run on a second
+ *                              (low-priority) stream beside the HBM-bound end of the data-gradient chain (blocks 2 and 1); 2 = fc6 / fc7 as well
+ *                              (fused fcn8s_train_step only: the bucket API keeps bucket 0 final at its own call, for an early all-reduce); 0 = off
+ *     "defer_start_block" 2    the VGG block at whose backward pass the held-back GEMMs are launched
  *   process-wide option (m == NULL), for the op-level entry points below, which have no model:
  *     "op_f32x3"          0    their LDS-DMA GEMMs use the split-bf16 arithmetic of FCN8S_PREC_F32X3
  * Unknown keys return FCN8S_ERR_NOT_FOUND. */

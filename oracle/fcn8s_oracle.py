@@ -305,7 +305,8 @@ def pool_routes(acts):
     """This restatement's own max-pool routes, from the NHWC activations of forward(..., keep=True): "pool1".."pool5" -> uint8
     (N,h/2,w/2,C), the window element (2*row + col) holding the FIRST maximum of the block's last (post-ReLU) conv output, 4 where that
     maximum is not > 0 -- the rule of TF's MaxPoolGrad on a ReLU output, and the encoding of fcn8s_get_pool_routing.  Second result:
-    per block, the gap between the largest and second-largest window entry relative to the largest (0 = exact tie)."""
+    per block, the gap between the largest and second-largest window entry relative to the largest activation of that layer (0 = exact
+    tie) -- the scale on which a convolution's round-off lives (its error is proportional to the magnitudes summed, not to the result)."""
     routes, gaps = OrderedDict(), OrderedDict()
     for blk, nconv in enumerate(CONVS_PER_BLOCK, start=1):
         x = np.asarray(acts["conv%d_%d" % (blk, nconv)])
@@ -315,7 +316,7 @@ def pool_routes(acts):
         top = win.max(-1)
         r[~(top > 0)] = 4
         srt = np.sort(win, -1)
-        gaps["pool%d" % blk] = (srt[..., 3] - srt[..., 2]) / np.maximum(np.abs(srt[..., 3]), 1e-30)
+        gaps["pool%d" % blk] = (srt[..., 3] - srt[..., 2]) / max(float(np.abs(x).max()), 1e-30)
         routes["pool%d" % blk] = r
     return routes, gaps
 

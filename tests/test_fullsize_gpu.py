@@ -95,19 +95,18 @@ def test_config2_inference_1024x512_bs1_vs_oracle():
     e.close()
 
 
-@pytest.mark.parametrize("variant,options,bound", [
-    ("F(6x6) everywhere (the default)", {}, 2e-3),
-    ("F(4x4) for blocks 1-2", {"winograd_tile_hires": 4, "winograd_hires_pixels": 256 * 512}, 1.25e-3)])
+@pytest.mark.parametrize("variant,options,bound", [("F(6x6) for all twelve 3x3 layers, F(4x4,4x4) for fc6 (the default)", {}, 1e-4)])
 def test_config3_gradients_1024x512_bs1_vs_oracle(variant, options, bound):
     """Every one of the 42 gradient tensors of a full-width training step at 1024x512 against the oracle (autograd over the CPU
     restatement): F(6x6,3x3) data / weight gradients at 14 706 tiles per image, fc6's F(4x4,4x4) weight gradient at depth 2048,
     split-K atomics, conv1_1's VALU weight gradient at 512x1024 -- none of which the small cases reach at this size.  The oracle
     differentiates along the ReLU / max-pool decisions the device took, after the test has checked that those differ from the oracle's
-    own only at fp32 coin flips (units within 1e-5 of zero, window maxima within 2e-5 of each other).
-    Bounds (error / largest gradient of the tensor; DESIGN.md section 2 and profiles/parity_r03.json for what is behind them): the fp32
-    oracle is itself 0.94e-3 away from its own float64 run on conv1_1/filter, the end of the backward chain, so 1e-3 against the *fp32*
-    oracle is the distance between two equally good fp32 answers; the direct-convolution variant of this library measures 0.98e-3, the
-    default (F(6x6) for all twelve 3x3 layers) 1.75e-3, with F(4x4) in blocks 1-2 (option, -6 % throughput) 1.08e-3."""
+    own only at fp32 coin flips (units within 1e-5 of zero, window maxima within 1e-4 of the layer's largest activation of each other).
+    Bound: 1e-4 of each tensor's largest gradient -- a tenth of SURVEY section 7 step 5's 1e-3; measured 3.4e-5 (worst: the last
+    transposed conv's bias; conv1_1/filter, the end of the backward chain, 1.2e-5), the same for F(4x4) and for direct convolution
+    (profiles/parity_r03.json).  Without the alignment the very same gradients sit 1.9e-3 from the oracle's -- and the fp32 oracle
+    0.94e-3 from its own float64 run: that is 54 of 16 million pool windows (and 69 of 98 million ReLU units) taking the other branch
+    of a tie, not arithmetic error."""
     from fcn8s_tensorflow_amd.engine import Engine
     P = orc.init_params(20, seed=4, decoder_std_scale=30.0, bias_std=0.05)
     img, lab = orc.synthetic_batch(1, 512, 1024)
@@ -132,7 +131,7 @@ def test_config3_gradients_1024x512_bs1_vs_oracle(variant, options, bound):
         n_route += int(d.sum())
         tie = d & ((rt[k] == 4) == (own[k] == 4))
         if tie.any():
-            assert gaps[k][tie].max() <= 2e-5, (k, float(gaps[k][tie].max()))
+            assert gaps[k][tie].max() <= 1e-4, (k, float(gaps[k][tie].max()))
         onoff = d & ~tie
         if onoff.any():
             assert np.abs(acts[k][onoff]).max() < 1e-5 * np.abs(acts[k]).max(), k

@@ -1,7 +1,8 @@
 """Whole-path parity: the HIP library (through the C ABI) against the CPU oracle on
 the same seeded inputs.  Tolerances: logits within 1e-3 absolute (BASELINE.json
 north_star), argmax identical wherever the oracle's top-2 softmax margin exceeds
-1e-4, gradients within 2e-3 relative to each tensor's max magnitude."""
+1e-4, gradients within 3e-4 of each tensor's max magnitude along the device's ReLU / max-pool
+decisions (device_decisions: fixed seeds, no search for tie-free cases)."""
 import numpy as np
 import pytest
 
@@ -29,12 +30,14 @@ def case(widths, n, h, w, seed, decoder_std_scale=30.0):
     return P, img, lab
 
 
-def device_decisions(e, P, img, nhw, relu_tol=1e-5, tie_tol=2e-5, **fwd_kw):
+def device_decisions(e, P, img, nhw, relu_tol=1e-5, tie_tol=1e-4, **fwd_kw):
     """The discrete decisions the device's last training pass took -- which ReLU units are on (Engine.relu_branches) and where each
     max-pool window routes its gradient (Engine.pool_routes) -- after checking that they differ from the oracle's own decisions only
     where the decision is a coin flip in fp32: a ReLU unit may differ only if its activation is within `relu_tol` of zero (relative to
-    the layer's largest), a pool route only if the oracle's two largest window entries agree to `tie_tol` (or the window's maximum is
-    within relu_tol of zero, for routes that differ in on/off).  Gradient parity is then taken along these decisions
+    the layer's largest), a pool route only if the oracle's two largest window entries agree to `tie_tol` of the layer's largest
+    activation (Winograd F(6x6) carries a round-off of 2e-5 of the output range, tools/winograd_matrices.py; measured worst gap at a
+    differing route: 3e-5) -- or the window's maximum is within relu_tol of zero, for routes that differ in on/off.  Gradient parity is
+    then taken along these decisions
     (oracle `branches=` / `routes=`): both sides differentiate the same piecewise-linear function, on any seed."""
     br = e.relu_branches(nhw)
     rt = e.pool_routes(nhw)
@@ -124,7 +127,7 @@ def test_gradients(widths, n, h, w, l2):
     errs = {k: rel(g[k], g_ref[k]) for k in g_ref}
     worst = max(errs, key=errs.get)
     print("%s: %s; worst gradient error %s %.2e" % ((widths, n, h, w), stats, worst, errs[worst]))
-    assert errs[worst] < 1e-3, (worst, errs[worst])
+    assert errs[worst] < 3e-4, (worst, errs[worst])        # measured: at most 1e-4 (the last transposed conv's kernel), 4e-5 elsewhere
 
 
 @pytest.mark.parametrize("n,hw", [(2, 64), (1, 128)])      # 128: fc6 runs through the Winograd path (dropout fused in its output transform)
@@ -167,8 +170,10 @@ def test_bf16_fc_mode_config5(widths, n, h, w):
     # (an input that differs from the oracle's by fp32 round-off can land on the other side of a bf16 rounding
     #  boundary, a 2^-9 step for that operand -- hence 1e-3 here where the fp32 mode holds 1e-4)
     assert rel(e.activation("fc7", acts["fc7"].shape), acts["fc7"]) < 1e-3
-    ok, _ = argmax_agree(pred, orc.softmax(ref))
-    assert ok
+    # argmax: identical wherever the oracle's top-2 LOGIT margin exceeds twice the logit tolerance of this mode
+    srt = np.sort(ref, -1)
+    safe = (srt[..., -1] - srt[..., -2]) > 2e-3 * scale
+    assert safe.mean() > 0.9 and (pred[safe] == np.argmax(ref, -1)[safe]).all()
     ref32 = orc.forward(P, img)
     cost = float(np.abs(ref - ref32).max()) / scale
     assert 1e-6 < cost < 5e-2, cost                      # bf16 rounding is visible, and small
@@ -176,8 +181,10 @@ def test_bf16_fc_mode_config5(widths, n, h, w):
 
     onehot = orc.one_hot(lab, 20)
     loss = e.forward_backward(img, onehot, keep_prob=1.0, l2_rate=1e-3)
-    rt = e.pool_routes((n, h, w))
-    loss_ref, g_ref, _ = orc.loss_and_grads(P, img, onehot.astype(np.float32), l2_rate=1e-3, bf16_fc=True, routes=rt)
+    # along the device's decisions; a bf16 rounding-boundary flip moves fc6 / fc7 pre-activations by ~2e-4 of their scale, so ReLU units
+    # up to 1e-3 of the layer's largest may legitimately sit on the other side
+    br, rt, _ = device_decisions(e, P, img, (n, h, w), relu_tol=1e-3, bf16_fc=True)
+    loss_ref, g_ref, _ = orc.loss_and_grads(P, img, onehot.astype(np.float32), l2_rate=1e-3, bf16_fc=True, branches=br, routes=rt)
     assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
     g = e.get_grads()
     for k in g_ref:
@@ -238,7 +245,7 @@ def test_gradients_along_the_device_branches(precision, widths, n, h, w, l2):
     worst_k = max(errs, key=errs.get)
     print("%s %s: %d of %d ReLU units differ from the oracle's (largest such activation %.1e of its layer's max); worst gradient error %s %.2e"
           % (precision, (widths, n, h, w), n_diff, n_units, worst, worst_k, errs[worst_k]))
-    assert errs[worst_k] < 1e-3, (worst_k, errs[worst_k])
+    assert errs[worst_k] < 3e-4, (worst_k, errs[worst_k])
     e.close()
 
 
