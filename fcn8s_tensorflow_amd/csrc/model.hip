@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <algorithm>
 #include <functional>
+#include <tuple>
+#include <mutex>
 #include <map>
 #include <set>
 #include <string>
@@ -112,9 +114,14 @@ struct fcn8s_model {
     // deep layers (conv3_1 .. conv5_3 at level >= 1, fc6 / fc7 too at level 2) are held back and launched on `side` when the data-gradient
     // chain reaches block `defer_start_block`: from there on it is HBM-bound (Winograd transforms and K = 64 / 128 position GEMMs of blocks
     // 2 and 1), and the two kinds of work share the CUs.  Each deferred layer keeps its dM = A dY A^T in a buffer of its own.
-    int defer_wgrad = 2, defer_start_block = 2;
+    int defer_wgrad = 0, defer_start_block = 2;                          // measured zero-sum (profiles/r03_overlap_*.txt): off by default
+    // Sharing CUs between the two kinds of work is zero-sum on gfx950 (profiles/r03_overlap_shared_cus.txt: both slow down by what the other
+    // gains); on DISJOINT CUs they do not disturb each other at all (tools/cumask_lab.hip).  defer_tail_cus = n > 0: from the start block on
+    // the data-gradient chain moves to a stream restricted to the first n CUs and the held-back GEMMs run on the other 256 - n.
+    int defer_tail_cus = 0;
+    hipStream_t tail = nullptr; hipEvent_t tail_done = nullptr; bool on_tail = false;
     int defer_level_now = 0;                                             // level the running backward pass uses (the bucket API caps it at 1)
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr; bool side_owned = false;
     float* d_wino_u2 = nullptr; size_t ufl = 0;                          // dU scratch of the side stream (ufl floats, like d_wino_u)
     std::vector<std::pair<hipEvent_t, std::function<void(hipStream_t)>>> deferred;   // (inputs-ready event on the main stream, launches)
     std::vector<hipEvent_t> ev_pool; size_t ev_next = 0;
@@ -461,30 +468,75 @@ hipEvent_t defer_event(fcn8s_model* m)
     if (m->ev_next == m->ev_pool.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); m->ev_pool.push_back(e); }
     return m->ev_pool[m->ev_next++];
 }
+// CU-masked streams are made once per (device, mask) and never destroyed (destroying one and creating another hung on ROCm 7.2 in
+// tools/cumask_lab.hip); models of one process share them, which only serialises their held-back work
+hipStream_t masked_stream(int device, int first, int count)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int>, hipStream_t> pool;
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_tuple(device, first, count);
+    auto it = pool.find(key);
+    if (it != pool.end()) return it->second;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    const int ncu = p.multiProcessorCount;
+    if (first < 0 || count <= 0 || first + count > ncu) return nullptr;
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (int c = first; c < first + count; ++c) mask[c / 32] |= 1u << (c % 32);
+    hipStream_t st = nullptr;
+    if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
+    pool[key] = st;
+    return st;
+}
+int device_cus(int device)
+{
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return p.multiProcessorCount;
+}
+
 bool defer_ready(fcn8s_model* m)
 {
     if (!m->side) {
-        int lo = 0, hi = 0;
-        hipDeviceGetStreamPriorityRange(&lo, &hi);                 // lo = numerically greatest = lowest priority: the chain on the main stream goes first
-        if (hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, lo) != hipSuccess) { m->side = nullptr; (void)hipGetLastError(); return false; }
+        const int ncu = device_cus(m->device);
+        if (m->defer_tail_cus > 0 && m->defer_tail_cus < ncu) {
+            m->tail = masked_stream(m->device, 0, m->defer_tail_cus);
+            m->side = m->tail ? masked_stream(m->device, m->defer_tail_cus, ncu - m->defer_tail_cus) : nullptr;
+            if (!m->side) m->tail = nullptr;
+            m->side_owned = false;
+        }
+        if (!m->side) {
+            int lo = 0, hi = 0;
+            hipDeviceGetStreamPriorityRange(&lo, &hi);             // lo = numerically greatest = lowest priority: the chain on the main stream goes first
+            if (hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, lo) != hipSuccess) { m->side = nullptr; (void)hipGetLastError(); return false; }
+            m->side_owned = true;
+        }
         hipEventCreateWithFlags(&m->side_done, hipEventDisableTiming);
+        hipEventCreateWithFlags(&m->tail_done, hipEventDisableTiming);
     }
     if (!m->d_wino_u2 && hipMalloc((void**)&m->d_wino_u2, m->ufl * sizeof(float)) != hipSuccess) { m->d_wino_u2 = nullptr; (void)hipGetLastError(); return false; }
     return true;
 }
 // launch everything held back so far on the side stream (each item waits for the event that marks its inputs ready)
-void flush_deferred(fcn8s_model* m)
+void flush_deferred(fcn8s_model* m, hipEvent_t here = nullptr)
 {
     if (m->deferred.empty()) return;
+    // the host enqueues far ahead of the GPU: without this event the side stream would start each item as soon as its inputs exist, i.e. beside
+    // the MFMA-bound data-gradient GEMMs of the deep layers, which gains nothing.  It has to wait until the MAIN stream gets here.
+    if (!here) { here = defer_event(m); hipEventRecord(here, m->on_tail ? m->tail : m->stream); }
+    hipStreamWaitEvent(m->side, here, 0);
+    hipStream_t was = m->launch_stream;
     m->launch_stream = m->side;
     for (auto& d : m->deferred) { hipStreamWaitEvent(m->side, d.first, 0); d.second(m->side); }
-    m->launch_stream = nullptr;
+    m->launch_stream = was;
     m->deferred.clear();
 }
 // end of the backward pass: the main stream continues only after the side stream has drained
 void join_deferred(fcn8s_model* m)
 {
     flush_deferred(m);
+    if (m->on_tail) { hipEventRecord(m->tail_done, m->tail); hipStreamWaitEvent(m->stream, m->tail_done, 0); m->on_tail = false; m->launch_stream = nullptr; }
     if (m->side && m->ev_next) { hipEventRecord(m->side_done, m->side); hipStreamWaitEvent(m->stream, m->side_done, 0); }
     m->ev_next = 0;
 }
@@ -1063,10 +1115,21 @@ void backward_bucket0(fcn8s_model* m)
 // blocks [b_hi .. b_lo] (1-based VGG block numbers), going backwards
 void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
 {
-    hipStream_t s = m->stream;
+    hipStream_t s = m->on_tail ? m->tail : m->stream;
     const int N = m->N;
     for (int b = b_hi; b >= b_lo; --b) {
-        if (b == m->defer_start_block) flush_deferred(m);       // from here on the chain is HBM-bound: the held-back weight-gradient GEMMs run beside it
+        if (b == m->defer_start_block && !m->deferred.empty()) {
+            // from here on the chain is HBM-bound: the held-back weight-gradient GEMMs run beside it -- on CUs of their own if masks are on
+            // (ONE event, recorded before anything is put on the side stream: the caller's stream may be the legacy default stream, on which
+            //  every operation -- an event record too -- first waits for all work already queued on blocking streams such as the masked ones)
+            hipEvent_t here = defer_event(m);
+            hipEventRecord(here, m->stream);
+            if (m->tail) {
+                hipStreamWaitEvent(m->tail, here, 0);
+                s = m->tail; m->on_tail = true; m->launch_stream = m->tail;
+            }
+            flush_deferred(m, here);
+        }
         const int h = m->H >> (b - 1), w = m->W >> (b - 1);      // resolution of this block's convs
         const int cw = m->widths[b - 1];
         const int nconv = kConvsPerBlock[b - 1];
@@ -1269,7 +1332,8 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->d_wt) hipFree(m->d_wt);
     if (m->d_w1pad) hipFree(m->d_w1pad);
     if (m->d_wino_u2) hipFree(m->d_wino_u2);
-    if (m->side) hipStreamDestroy(m->side);
+    if (m->side && m->side_owned) hipStreamDestroy(m->side);
+    if (m->tail_done) hipEventDestroy(m->tail_done);
     if (m->side_done) hipEventDestroy(m->side_done);
     for (auto e : m->ev_pool) hipEventDestroy(e);
     for (auto& kv : m->u_train) if (kv.second) hipFree(kv.second);
@@ -1345,6 +1409,7 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "tconv_gemm") return &m->tconv_gemm;
     if (key == "defer_wgrad") return &m->defer_wgrad;
     if (key == "defer_start_block") return &m->defer_start_block;
+    if (key == "defer_tail_cus") return &m->defer_tail_cus;
     if (key == "winograd_tile_hires") return &m->wino_tile_hires;
     if (key == "winograd_hires_pixels") return &m->wino_hires_pixels;
     return nullptr;
@@ -1364,9 +1429,17 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
     if (k == "winograd_min_cin" && value < 0) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_min_cin must be >= 0 (0 = direct convolution everywhere)");
     if (k == "defer_wgrad" && (value < 0 || value > 2)) return fail(m, FCN8S_ERR_BAD_ARG, "defer_wgrad must be 0, 1 or 2");
     if (k == "defer_start_block" && (value < 1 || value > 4)) return fail(m, FCN8S_ERR_BAD_ARG, "defer_start_block must be 1 .. 4");
+    if (k == "defer_tail_cus" && (value < 0 || value > 248 || value % 8)) return fail(m, FCN8S_ERR_BAD_ARG, "defer_tail_cus must be a multiple of 8 in 0 .. 248");
     if (*slot == (int)value) return FCN8S_OK;
     HIPCHK(m, hipStreamSynchronize(m->stream));
     *slot = (k == "winograd_fc6" || k == "tconv_gemm") ? (value != 0) : (int)value;
+    if (k == "defer_tail_cus" && m->side) {         // the side / tail streams are re-made for the new split on next use
+        hipDeviceSynchronize();
+        if (m->side_owned) hipStreamDestroy(m->side);
+        m->side = m->tail = nullptr;
+        if (m->side_done) { hipEventDestroy(m->side_done); m->side_done = nullptr; }
+        if (m->tail_done) { hipEventDestroy(m->tail_done); m->tail_done = nullptr; }
+    }
     if (m->arena) { hipFree(m->arena); m->arena = nullptr; m->arena_bytes = 0; m->N = m->H = m->W = 0; m->acts.clear(); }
     m->have_forward = m->have_loss = false;
     for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);

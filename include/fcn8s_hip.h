@@ -187,10 +187,13 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *                              tile `tile_hires` (F(4x4) carries half the round-off of F(6x6); the layers next to the input see the longest sums)
  *     "winograd_fc6"      1    fc6 as a 2x2 grid of 4x4 sub-filters through F(4x4,4x4); 0 = direct 7x7
  *     "tconv_gemm"        1    the 16x16/8 transposed conv as one GEMM over output blocks (blocked logits); 0 = 64 sub-pixel phases
- *     "defer_wgrad"       2    deferred weight gradients: 1 = the weight-gradient GEMMs of conv3_1 .. conv5_3 are held back and run on a second
- *                              (low-priority) stream beside the HBM-bound end of the data-gradient chain (blocks 2 and 1); 2 = fc6 / fc7 as well
- *                              (fused fcn8s_train_step only: the bucket API keeps bucket 0 final at its own call, for an early all-reduce); 0 = off
+ *     "defer_wgrad"       0    deferred weight gradients (an experiment kept for its evidence, profiles/r03_overlap_*.txt: co-running gains nothing on
+ *                              gfx950, on shared or on disjoint CUs): 1 = the weight-gradient GEMMs of conv3_1 .. conv5_3 are held back and run on a
+ *                              second stream beside the end of the data-gradient chain (blocks 2 and 1); 2 = fc6 / fc7 as well (fused
+ *                              fcn8s_train_step only: the bucket API keeps bucket 0 final at its own call, for an early all-reduce)
  *     "defer_start_block" 2    the VGG block at whose backward pass the held-back GEMMs are launched
+ *     "defer_tail_cus"    0    > 0: from that block on the data-gradient chain runs on a stream restricted to the first n CUs and the held-back
+ *                              GEMMs on the remaining 256 - n (hipExtStreamCreateWithCUMask); 0: both share all CUs
  *   process-wide option (m == NULL), for the op-level entry points below, which have no model:
  *     "op_f32x3"          0    their LDS-DMA GEMMs use the split-bf16 arithmetic of FCN8S_PREC_F32X3
  * Unknown keys return FCN8S_ERR_NOT_FOUND. */

@@ -456,3 +456,31 @@ def test_frozen_parameters_cache_and_invalidation():
     np.testing.assert_array_equal(after, e.predict(img, argmax=False))
     assert np.abs(after - e2.predict(img, argmax=False)).max() > 0     # and the step did change the weights
     e.close(); e2.close()
+
+
+@pytest.mark.parametrize("options", [{"defer_wgrad": 2}, {"defer_wgrad": 2, "defer_tail_cus": 96}, {"defer_wgrad": 1, "defer_start_block": 3}])
+def test_deferred_weight_gradients_change_nothing(options):
+    """The `defer_wgrad` experiment (weight-gradient GEMMs of the deep layers on a second stream, optionally on CUs of their own;
+    include/fcn8s_hip.h) only reorders independent work: a full-width fused training step and a split-phase step produce the gradients of the
+    default schedule."""
+    from fcn8s_tensorflow_amd.engine import Engine
+    P = orc.init_params(20, seed=3, decoder_std_scale=30.0, bias_std=0.05)
+    img, lab = batch(1, 192, 192, seed=9)
+    out = []
+    for opts in ({}, options):
+        e = Engine(20, options=opts)
+        for k, v in opts.items():
+            assert e.get_option(k) == v
+        e.set_params(P)
+        loss, step = e.train_step(img, lab, 1e-3, keep_prob=1.0, l2_rate=1e-3)         # fused step (level 2 allowed)
+        g1, p1 = e.get_grads(), e.get_params()
+        loss2 = e.forward_backward(img, lab, keep_prob=1.0, l2_rate=1e-3)               # bucket API (level capped at 1)
+        g2 = e.get_grads()
+        out.append((loss, g1, p1, loss2, g2))
+        e.close()
+    (l0, g0, p0, l20, g20), (l1, g1, p1, l21, g21) = out
+    assert l0 == l1 and l20 == l21
+    for k in g0:
+        # (split-K sums use float atomics: their order is not reproducible between two runs of the SAME schedule either)
+        assert rel(g1[k], g0[k]) < 1e-5, k
+        assert rel(g21[k], g20[k]) < 1e-5, k
