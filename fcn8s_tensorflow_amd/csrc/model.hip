@@ -82,6 +82,7 @@ struct fcn8s_model {
     int64_t step = 0;
     // workspace for the current (N,H,W)
     int N = 0, H = 0, W = 0;
+    int plan_N = 0;
     char* arena = nullptr; size_t arena_bytes = 0;
     std::map<std::string, Act> acts;
     // the last transposed conv (k = 2s = 16) as one GEMM over output blocks (PixMap, elementwise.hip): logits / dlogits live in that blocked layout
@@ -270,7 +271,12 @@ int wino_tile_for(const fcn8s_model* m, int H, int W, int K = 3)
     const bool t4 = tmax >= 4 && H % 4 == 0 && W % 4 == 0;
     if (K == 7) return (m->wino_tile >= 4 && H % 4 == 0 && W % 4 == 0) ? 4 : 0;
     if (tmax == 6) {
-        const long long c6 = 64LL * ((H + 5) / 6) * ((W + 5) / 6), c4 = t4 ? 36LL * (H / 4) * (W / 4) : 16LL * (H / 2) * (W / 2);
+        // multiplies per channel pair = positions x GEMM rows.  For a single image the rows are rounded up to the 64-row GEMM tile: a 32x64
+        // map has 66 F(6x6) tiles -- two row tiles, the second one nearly empty -- but exactly 128 F(4x4) tiles.  Batches of two or more
+        // images are NOT treated this way: the arithmetic applied to an image must not depend on how many others share its batch (the
+        // gradient of a batch equals the mean over its halves, data-parallel shards equal the big batch).
+        auto rows = [&](long long tiles) { return m->plan_N == 1 ? (tiles + 63) / 64 * 64 : tiles; };
+        const long long c6 = 64LL * rows((long long)((H + 5) / 6) * ((W + 5) / 6)), c4 = t4 ? 36LL * rows((long long)(H / 4) * (W / 4)) : 16LL * rows((long long)(H / 2) * (W / 2));
         if (c6 < c4) return 6;
     }
     return t4 ? 4 : 2;
@@ -642,6 +648,7 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
         return fail(m, FCN8S_ERR_SHAPE, "image height and width must be positive multiples of 32 (five 2x2 pools, then x2, x2, x8 upsampling must line up with the skip connections)");
     if (m->arena && m->N == N && m->H == H && m->W == W) return FCN8S_OK;
     if (m->arena) { hipStreamSynchronize(m->stream); hipFree(m->arena); m->arena = nullptr; }
+    m->plan_N = N;                 // the batch size the per-layer Winograd tiles are chosen for (wino_tile_for), from here until the next re-plan
     m->acts.clear();
     m->have_forward = m->have_loss = false;
     const int C = m->C;

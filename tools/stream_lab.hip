@@ -1,0 +1,98 @@
+// Lab: what does a read+write stream reach on this MI355X box?  (The Winograd transforms move 4.85 TB/s; the spec says 8, the
+// microarch guide 6.3 for a float4 copy.)  Variants of a 2 GiB -> 2 GiB float4 copy: grid size, loads in flight per thread,
+// non-temporal loads / stores; plus read-only (sum) and write-only (fill) streams, hipMemcpyDtoD and hipMemset for reference.
+//   hipcc -O3 --offload-arch=gfx950 tools/stream_lab.hip -o scratch/stream_lab && scratch/stream_lab
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int U, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void copy_k(const float4* __restrict__ a, float4* __restrict__ b, long long n)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (NTL) { f4 t = __builtin_nontemporal_load((const f4*)(a + i + u * stride)); v[u] = make_float4(t.x, t.y, t.z, t.w); }
+            else v[u] = a[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (NTS) { f4 t = {v[u].x, v[u].y, v[u].z, v[u].w}; __builtin_nontemporal_store(t, (f4*)(b + i + u * stride)); }
+            else b[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n; i += stride) b[i] = a[i];
+}
+// contiguous chunk per block (no grid stride): block b copies [b*chunk, (b+1)*chunk)
+template <int U>
+__global__ __launch_bounds__(256) void copy_chunk_k(const float4* __restrict__ a, float4* __restrict__ b, long long n, long long chunk)
+{
+    const long long lo = blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256LL * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (i + u * 256 < hi) v[u] = a[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (i + u * 256 < hi) b[i + u * 256] = v[u];
+    }
+}
+__global__ __launch_bounds__(256) void sum_k(const float4* __restrict__ a, float* out, long long n)
+{
+    float s = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) { float4 v = a[i]; s += v.x + v.y + v.z + v.w; }
+    if (s == 1.2345f) out[0] = s;
+}
+__global__ __launch_bounds__(256) void fill_k(float4* __restrict__ b, long long n)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) b[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+
+template <class F> static float timeit(F f, int reps = 10)
+{
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, 0));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+
+int main()
+{
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const size_t bytes = 2ull << 30; const long long n = bytes / 16;
+    float4 *a, *b; float* o;
+    CK(hipMalloc((void**)&a, bytes)); CK(hipMalloc((void**)&b, bytes)); CK(hipMalloc((void**)&o, 64));
+    CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 0, bytes));
+    auto rep = [&](const char* name, float ms, double factor) { printf("%-58s %8.3f ms  %6.2f TB/s\n", name, ms, factor * bytes / ms * 1e-9); };
+    rep("hipMemcpyDtoD", timeit([&] { hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0); }), 2);
+    rep("hipMemset", timeit([&] { hipMemsetAsync(b, 0, bytes, 0); }), 1);
+    for (int g : {1024, 2048, 4096, 8192, 16384}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "copy grid %5d U1", g); rep(nm, timeit([&] { hipLaunchKernelGGL((copy_k<1, false, false>), dim3(g), dim3(256), 0, 0, a, b, n); }), 2);
+        snprintf(nm, sizeof nm, "copy grid %5d U2", g); rep(nm, timeit([&] { hipLaunchKernelGGL((copy_k<2, false, false>), dim3(g), dim3(256), 0, 0, a, b, n); }), 2);
+        snprintf(nm, sizeof nm, "copy grid %5d U4", g); rep(nm, timeit([&] { hipLaunchKernelGGL((copy_k<4, false, false>), dim3(g), dim3(256), 0, 0, a, b, n); }), 2);
+        snprintf(nm, sizeof nm, "copy grid %5d U8", g); rep(nm, timeit([&] { hipLaunchKernelGGL((copy_k<8, false, false>), dim3(g), dim3(256), 0, 0, a, b, n); }), 2);
+        snprintf(nm, sizeof nm, "copy grid %5d U4 nt-store", g); rep(nm, timeit([&] { hipLaunchKernelGGL((copy_k<4, false, true>), dim3(g), dim3(256), 0, 0, a, b, n); }), 2);
+        snprintf(nm, sizeof nm, "copy grid %5d U4 nt-load nt-store", g); rep(nm, timeit([&] { hipLaunchKernelGGL((copy_k<4, true, true>), dim3(g), dim3(256), 0, 0, a, b, n); }), 2);
+    }
+    for (int g : {2048, 8192, 65536}) {
+        char nm[96];
+        const long long chunk = (n + g - 1) / g;
+        snprintf(nm, sizeof nm, "copy contiguous chunk per block, grid %5d U4", g); rep(nm, timeit([&] { hipLaunchKernelGGL((copy_chunk_k<4>), dim3(g), dim3(256), 0, 0, a, b, n, chunk); }), 2);
+    }
+    for (int g : {2048, 8192}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "read-only sum grid %5d", g); rep(nm, timeit([&] { hipLaunchKernelGGL(sum_k, dim3(g), dim3(256), 0, 0, a, o, n); }), 1);
+        snprintf(nm, sizeof nm, "write-only fill grid %5d", g); rep(nm, timeit([&] { hipLaunchKernelGGL(fill_k, dim3(g), dim3(256), 0, 0, b, n); }), 1);
+    }
+    return 0;
+}
