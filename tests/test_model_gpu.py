@@ -429,6 +429,24 @@ def test_errors_are_python_exceptions():
         e.set_params({"nope/filter": np.zeros(3, np.float32)})
     with pytest.raises(ValueError):
         e.train_step(batch(1, 32, 32)[0], np.zeros((1, 32, 16), np.uint8), 1e-3)
+    # parity instrumentation: only after a TRAINING forward pass, and only with the exact size
+    import ctypes as C
+    from fcn8s_tensorflow_amd import _lib as L
+    buf = np.empty(8, np.uint8)
+    assert L.lib.fcn8s_get_pool_routing(e.h, 1, buf.ctypes.data_as(C.c_void_p), buf.size) == L.ERR_STATE
+    e.predict(batch(1, 32, 32)[0])
+    assert L.lib.fcn8s_get_pool_routing(e.h, 1, buf.ctypes.data_as(C.c_void_p), buf.size) == L.ERR_STATE      # a prediction keeps no routes
+    img32, lab32 = batch(1, 32, 32)
+    e.forward_backward(img32, lab32)
+    assert L.lib.fcn8s_get_pool_routing(e.h, 1, buf.ctypes.data_as(C.c_void_p), buf.size) == L.ERR_SHAPE
+    assert L.lib.fcn8s_get_pool_routing(e.h, 6, buf.ctypes.data_as(C.c_void_p), buf.size) == L.ERR_BAD_ARG
+    routes = e.pool_routes((1, 32, 32))
+    assert [routes["pool%d" % b].shape for b in range(1, 6)] == [(1, 32 >> b, 32 >> b, SMALL[b - 1]) for b in range(1, 6)]
+    assert all(r.max() <= 4 for r in routes.values())
+    # the routes say where pool_b's gradient goes: a route of 4 (off) exactly where the pooled activation is not > 0
+    p1 = e.activation("pool1", (1, 16, 16, SMALL[0]))
+    np.testing.assert_array_equal(routes["pool1"] == 4, ~(p1 > 0))
+    assert e.check_replicas() is True                  # one rank: nothing to compare
     e.close()
 
 
