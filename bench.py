@@ -323,6 +323,7 @@ def main():
     options = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.option}
     eng = Engine(20, device_id=dev, seed=1234 + rank, precision=args.precision, options=options)
     eng.dp_always = under_launcher                # a one-rank process group still runs the bucketed all-reduces (RCCL with one rank)
+    eng.replica_check_every = 0                   # the replica guard of FCN8s.train stays out of the measurement (and the local-only leg below lets replicas drift on purpose)
     eng.init_params(seed=0)                       # He-normal VGG, reference decoder init (same on every rank)
     mark("broadcast params")
     eng.broadcast_params(0)

@@ -1200,7 +1200,7 @@ int do_backward_bucket(fcn8s_model* m, int bucket, int level_cap)
     if (!m->have_loss || !m->train_mode) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: call fcn8s_forward_loss first");
     if (bucket != m->next_bucket) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: buckets must be run in order 0,1,2");
     if (bucket == 0) {
-        m->defer_level_now = std::min(m->defer_wgrad, level_cap);
+        m->defer_level_now = m->defer_wgrad >= 3 ? 2 : std::min(m->defer_wgrad, level_cap);      // 3: the caller does not consume bucket 0 early
         if (m->profile && m->profile_detail) m->defer_level_now = 0;      // per-layer timing wants one kernel at a time
         m->deferred.clear(); m->ev_next = 0;
         backward_bucket0(m);
@@ -1434,7 +1434,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
     if (k == "winograd_tile" && value != 2 && value != 4 && value != 6) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_tile must be 2, 4 or 6");
     if (k == "winograd_tile_hires" && value != 0 && value != 2 && value != 4 && value != 6) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_tile_hires must be 0, 2, 4 or 6");
     if (k == "winograd_min_cin" && value < 0) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_min_cin must be >= 0 (0 = direct convolution everywhere)");
-    if (k == "defer_wgrad" && (value < 0 || value > 2)) return fail(m, FCN8S_ERR_BAD_ARG, "defer_wgrad must be 0, 1 or 2");
+    if (k == "defer_wgrad" && (value < 0 || value > 3)) return fail(m, FCN8S_ERR_BAD_ARG, "defer_wgrad must be 0 .. 3");
     if (k == "defer_start_block" && (value < 1 || value > 4)) return fail(m, FCN8S_ERR_BAD_ARG, "defer_start_block must be 1 .. 4");
     if (k == "defer_tail_cus" && (value < 0 || value > 248 || value % 8)) return fail(m, FCN8S_ERR_BAD_ARG, "defer_tail_cus must be a multiple of 8 in 0 .. 248");
     if (*slot == (int)value) return FCN8S_OK;
@@ -1560,7 +1560,7 @@ int fcn8s_backward_bucket(fcn8s_model* m, int bucket)
 int fcn8s_bucket_complete_after(const fcn8s_model* m, int bucket)
 {
     if (!m || bucket < 0 || bucket >= FCN8S_NUM_BUCKETS) return -1;
-    if (bucket == 0 || m->defer_wgrad == 0) return bucket;
+    if (m->defer_wgrad == 0 || (bucket == 0 && m->defer_wgrad < 3)) return bucket;
     return FCN8S_NUM_BUCKETS - 1;           // weight gradients of conv3_1 .. conv5_3 are held back until the last call (deferred weight gradients)
 }
 

@@ -190,7 +190,8 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *     "defer_wgrad"       0    deferred weight gradients (an experiment kept for its evidence, profiles/r03_overlap_*.txt: co-running gains nothing on
  *                              gfx950, on shared or on disjoint CUs): 1 = the weight-gradient GEMMs of conv3_1 .. conv5_3 are held back and run on a
  *                              second stream beside the end of the data-gradient chain (blocks 2 and 1); 2 = fc6 / fc7 as well (fused
- *                              fcn8s_train_step only: the bucket API keeps bucket 0 final at its own call, for an early all-reduce)
+ *                              fcn8s_train_step only: the bucket API keeps bucket 0 final at its own call, for an early all-reduce);
+ *                              3 = fc6 / fc7 through the bucket API too (fcn8s_bucket_complete_after then names the last call for every bucket)
  *     "defer_start_block" 2    the VGG block at whose backward pass the held-back GEMMs are launched
  *     "defer_tail_cus"    0    > 0: from that block on the data-gradient chain runs on a stream restricted to the first n CUs and the held-back
  *                              GEMMs on the remaining 256 - n (hipExtStreamCreateWithCUMask); 0: both share all CUs
