@@ -57,6 +57,17 @@ struct Bf16ConvArgs {
 void launch_w_to_bf16_tiles(const float* w, unsigned short* wt, int K, int Cout, hipStream_t s);   // w[K][Cout] -> wt[K/32][Cout][32]
 bool launch_conv_bf16(const Bf16ConvArgs& a, hipStream_t s);
 void launch_f32_to_bf16(const float* x, unsigned short* y, long long n, hipStream_t s);                // n % 8 == 0
+// 256 x 256 tile variant (gemm_bf16.hip): zero-padded bf16 activations [N][H + K - 1][W + K - 1][Cin], kernel transposed to wt[Cout][K*K*Cin] bf16
+struct Bf16Conv256Args {
+    const unsigned short* xp; const unsigned short* wt; const float* bias; float* y;
+    int N, H, W, Cin, Cout, K;
+    int relu, dropout; float keep_prob; unsigned long long seed; unsigned int stream_id;
+    long long M; int m_fastest;        // filled in by the launcher
+};
+bool conv_bf16_256_ok(long long M, int Cin, int Cout, int mode);      // mode 0 never, 1 when it fills the chip, 2 whenever the shapes allow
+void launch_w_to_bf16_t(const float* w, unsigned short* wt, int K, int Cout, hipStream_t s);
+void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H, int W, int C, int pad, hipStream_t s);
+bool launch_conv_bf16_256(const Bf16Conv256Args& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // Weight-gradient GEMM on the f32 MFMA:

@@ -76,7 +76,9 @@ struct fcn8s_model {
     std::set<std::string> rbits_ok;                                       // layers whose forward pass wrote a ReLU bit mask ("rb:<layer>") this step
     std::string fused_v_layer;                                            // layer whose data-gradient input transform already sits in d_wino_v
     std::string dm_layer;                                                 // layer whose dM = A dY A^T sits in d_wino_m, ready for the adjoint data gradient
-    unsigned short* d_wbf16 = nullptr;                                    // bf16 K-tile-major copy of the fc6 / fc7 kernel (one at a time)
+    unsigned short* d_wbf16 = nullptr;                                    // bf16 copy of the fc6 / fc7 kernel (one at a time; K-tile-major or transposed)
+    std::map<std::string, unsigned short*> wbf16_cache;                   // ... per layer, valid while frozen
+    int bf16_gemm256 = 1;                                                 // bf16_fc mode: 256 x 256 LDS-DMA kernel -- 0 never, 1 when it fills the chip, 2 whenever shapes allow
     unsigned short* d_abf16 = nullptr; size_t abf16_elems = 0;            // bf16 copy of the layer's input activations
     hipStream_t stream = nullptr;
     int64_t step = 0;
@@ -902,7 +904,12 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
         unsigned long long fp = 0;
         hipMemcpyAsync(&fp, m->d_fp, sizeof fp, hipMemcpyDeviceToHost, s);
         hipStreamSynchronize(s);
-        if (fp != m->frozen_fp) { for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second); m->u_cache.clear(); }
+        if (fp != m->frozen_fp) {
+            for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
+            m->u_cache.clear();
+            for (auto& kv : m->wbf16_cache) if (kv.second) hipFree(kv.second);
+            m->wbf16_cache.clear();
+        }
     }
     const bool fill_fp = m->frozen && m->u_cache.empty();
     prepare_forward_weights(m);
@@ -954,20 +961,44 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
         // config 5: bf16-rounded operands, fp32 accumulate, fp32 epilogue and output (gemm_bf16.hip)
         auto fc = [&](const char* tag, const char* wname, const char* bname, const float* in, float* out, int cin, int cout, int k, uint32_t stream_id) {
             const int K = k * k * cin;
-            { ProfScope ps(m, "weight_relayout", 0, 6.0 * K * cout); launch_w_to_bf16_tiles(Wp(m, wname), m->d_wbf16, K, cout, s); }
+            const long long Mrows = (long long)N * h5 * w5;
+            const bool big = conv_bf16_256_ok(Mrows, cin, cout, m->bf16_gemm256);      // 256 x 256 tiles, LDS-DMA, staggered wave groups
+            // weights: bf16, K-tile-major blocks for the 128 x 128 kernel or transposed [Cout][K] for the 256 x 256 one; with frozen parameters
+            // (evaluation / serving loops) each layer's copy is made once and kept
+            unsigned short* wbuf = m->d_wbf16;
+            bool have = false;
+            if (m->frozen) {
+                unsigned short*& c = m->wbf16_cache[std::string(wname) + (big ? "#t" : "#b")];
+                if (c) { wbuf = c; have = true; }
+                else if (hipMalloc((void**)&c, (size_t)K * cout * sizeof(unsigned short)) == hipSuccess) wbuf = c;
+                else { c = nullptr; (void)hipGetLastError(); }
+            }
+            if (!have) { ProfScope ps(m, "weight_relayout", 0, 6.0 * K * cout);
+                         if (big) launch_w_to_bf16_t(Wp(m, wname), wbuf, K, cout, s); else launch_w_to_bf16_tiles(Wp(m, wname), wbuf, K, cout, s); }
+            const int pad = big ? (k - 1) / 2 : 0;
+            const size_t nin = (size_t)N * (h5 + 2 * pad) * (w5 + 2 * pad) * cin;
+            if (nin % 8 == 0 && m->abf16_elems < nin) {
+                if (m->d_abf16) { hipStreamSynchronize(s); hipFree(m->d_abf16); m->d_abf16 = nullptr; m->abf16_elems = 0; }
+                if (hipMalloc((void**)&m->d_abf16, nin * sizeof(unsigned short)) == hipSuccess) m->abf16_elems = nin; else (void)hipGetLastError();
+            }
+            const double M = (double)Mrows;
+            if (big && m->d_abf16 && m->abf16_elems >= nin) {
+                { ProfScope ps(m, "weight_relayout", 0, 4.0 * Mrows * cin + 2.0 * nin); launch_f32_to_bf16_padded(in, m->d_abf16, N, h5, w5, cin, pad, s); }
+                Bf16Conv256Args g{};
+                g.xp = m->d_abf16; g.wt = wbuf; g.bias = Wp(m, bname); g.y = out;
+                g.N = N; g.H = h5; g.W = w5; g.Cin = cin; g.Cout = cout; g.K = k;
+                g.relu = 1; g.dropout = drop; g.keep_prob = keep_prob; g.seed = m->seed; g.stream_id = stream_id;
+                ProfScope ps(m, tag, 2.0 * M * K * cout, 4.0 * M * cout + 2.0 * M * cin + 2.0 * K * cout);
+                if (launch_conv_bf16_256(g, s)) return;
+            }
+            if (big) { launch_w_to_bf16_tiles(Wp(m, wname), m->d_wbf16, K, cout, s); wbuf = m->d_wbf16; }      // (could not take the 256 path after all)
             Bf16ConvArgs a{};
-            a.x = in; a.wt = m->d_wbf16; a.bias = Wp(m, bname); a.y = out;
-            const size_t nin = (size_t)N * h5 * w5 * cin;
-            if (nin % 8 == 0) {         // activations to bf16 once: the GEMM re-reads each A tile Cout/128 times
-                if (m->abf16_elems < nin) {
-                    if (m->d_abf16) { hipStreamSynchronize(s); hipFree(m->d_abf16); m->d_abf16 = nullptr; m->abf16_elems = 0; }
-                    if (hipMalloc((void**)&m->d_abf16, nin * sizeof(unsigned short)) == hipSuccess) m->abf16_elems = nin; else (void)hipGetLastError();
-                }
-                if (m->d_abf16) { ProfScope ps(m, "weight_relayout", 0, 6.0 * nin); launch_f32_to_bf16(in, m->d_abf16, (long long)nin, s); a.xh = m->d_abf16; }
+            a.x = in; a.wt = wbuf; a.bias = Wp(m, bname); a.y = out;
+            if (nin % 8 == 0 && m->d_abf16) {         // activations to bf16 once: the GEMM re-reads each A tile Cout/128 times
+                ProfScope ps(m, "weight_relayout", 0, 6.0 * nin); launch_f32_to_bf16(in, m->d_abf16, (long long)N * h5 * w5 * cin, s); a.xh = m->d_abf16;
             }
             a.N = N; a.H = h5; a.W = w5; a.Cin = cin; a.Cout = cout; a.K = k;
             a.relu = 1; a.dropout = drop; a.keep_prob = keep_prob; a.seed = m->seed; a.stream_id = stream_id;
-            const double M = (double)N * h5 * w5;
             ProfScope ps(m, tag, 2.0 * M * K * cout, 4.0 * M * (cin + cout) + 2.0 * K * cout);
             launch_conv_bf16(a, s);
         };
@@ -1347,6 +1378,7 @@ int fcn8s_destroy(fcn8s_model* m)
     for (auto& kv : m->u_train) if (kv.second) hipFree(kv.second);
     if (m->d_wino_u) hipFree(m->d_wino_u);
     for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
+    for (auto& kv : m->wbf16_cache) if (kv.second) hipFree(kv.second);
     if (m->d_wbf16) hipFree(m->d_wbf16);
     if (m->d_abf16) hipFree(m->d_abf16);
     for (int i = 0; i < 3; ++i) if (m->d_tph[i]) hipFree(m->d_tph[i]);
@@ -1377,10 +1409,12 @@ const char* fcn8s_last_error(const fcn8s_model* m) { return m ? m->err.c_str() :
 
 static void drop_u_cache(fcn8s_model* m)
 {
-    if (m->u_cache.empty()) return;
+    if (m->u_cache.empty() && m->wbf16_cache.empty()) return;
     hipStreamSynchronize(m->stream);
     for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
     m->u_cache.clear();
+    for (auto& kv : m->wbf16_cache) if (kv.second) hipFree(kv.second);
+    m->wbf16_cache.clear();
 }
 int fcn8s_freeze_params(fcn8s_model* m, int frozen)
 {
@@ -1418,6 +1452,7 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "defer_wgrad") return &m->defer_wgrad;
     if (key == "defer_start_block") return &m->defer_start_block;
     if (key == "defer_tail_cus") return &m->defer_tail_cus;
+    if (key == "bf16_gemm256") return &m->bf16_gemm256;
     if (key == "winograd_tile_hires") return &m->wino_tile_hires;
     if (key == "winograd_hires_pixels") return &m->wino_hires_pixels;
     return nullptr;
@@ -1451,6 +1486,8 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
     if (m->arena) { hipFree(m->arena); m->arena = nullptr; m->arena_bytes = 0; m->N = m->H = m->W = 0; m->acts.clear(); }
     m->have_forward = m->have_loss = false;
     for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
+    for (auto& kv : m->wbf16_cache) if (kv.second) hipFree(kv.second);
+    m->wbf16_cache.clear();
     m->u_cache.clear();
     for (auto& kv : m->u_train) if (kv.second) hipFree(kv.second);
     m->u_train.clear();

@@ -195,6 +195,8 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *     "defer_start_block" 2    the VGG block at whose backward pass the held-back GEMMs are launched
  *     "defer_tail_cus"    0    > 0: from that block on the data-gradient chain runs on a stream restricted to the first n CUs and the held-back
  *                              GEMMs on the remaining 256 - n (hipExtStreamCreateWithCUMask); 0: both share all CUs
+ *     "bf16_gemm256"      1    FCN8S_PREC_BF16_FC: fc6 / fc7 forward on the 256 x 256 LDS-DMA kernel -- 0 never, 1 when the launch has at least
+ *                              128 tiles (training batches), 2 whenever the shapes allow (rows and Cout multiples of 256)
  *   process-wide option (m == NULL), for the op-level entry points below, which have no model:
  *     "op_f32x3"          0    their LDS-DMA GEMMs use the split-bf16 arithmetic of FCN8S_PREC_F32X3
  * Unknown keys return FCN8S_ERR_NOT_FOUND. */

@@ -502,3 +502,45 @@ def test_deferred_weight_gradients_change_nothing(options):
         # (split-K sums use float atomics: their order is not reproducible between two runs of the SAME schedule either)
         assert rel(g1[k], g0[k]) < 1e-5, k
         assert rel(g21[k], g20[k]) < 1e-5, k
+
+
+def test_bf16_fc_256_tile_kernel():
+    """The 256 x 256 LDS-DMA kernel of the bf16_fc mode (gemm_bf16.hip: zero-padded bf16 activations, transposed bf16 kernel, staggered
+    wave groups) at a shape it takes -- full width, 4 x 256x256, i.e. 256 GEMM rows -- against the oracle applying the same operand
+    rounding, and against the 128 x 128 kernel of the same mode (same products, another summation order); dropout uses the same Philox
+    stream in both.  `bf16_gemm256` = 2 forces the kernel where option 1 (the default) would find too few tiles to fill the chip."""
+    from fcn8s_tensorflow_amd.engine import Engine
+    n, h, w = 4, 256, 256
+    P = orc.init_params(20, seed=8, decoder_std_scale=6.0, bias_std=0.05)
+    img, lab = batch(n, h, w, seed=21)
+    outs = {}
+    for mode in (2, 0):
+        e = Engine(20, precision='bf16_fc', options={"bf16_gemm256": mode})
+        e.set_params(P)
+        e.profile(2); e.profile_reset()
+        loss = e.forward_backward(img, lab, keep_prob=1.0, l2_rate=0.0)
+        kernels = [k for k in e.profile_results() if k.startswith("kernel:")]
+        e.profile(0)
+        assert any("conv_bf16_256_kernel" in k for k in kernels) == (mode == 2), kernels
+        fc6 = e.activation("fc6", (n, h // 32, w // 32, 4096)); fc7 = e.activation("fc7", (n, h // 32, w // 32, 4096))
+        logits = e.activation("logits", (n, h, w, 20))
+        loss_d = e.forward_backward(img, lab, keep_prob=0.5)
+        m6, m7 = e.dropout_masks((n, h // 32, w // 32, 4096), (n, h // 32, w // 32, 4096))
+        if mode == 2:        # frozen parameters: the transposed bf16 kernels are made once and reused, predictions unchanged
+            e.freeze(True)
+            p1 = e.predict(img, argmax=False); p2 = e.predict(img, argmax=False)
+            np.testing.assert_array_equal(p1, p2)
+            e.freeze(False)
+            np.testing.assert_array_equal(p1, e.predict(img, argmax=False))
+        outs[mode] = (loss, fc6, fc7, logits, loss_d, m6, m7)
+        e.close()
+    ref, acts = orc.forward(P, img, keep=True, bf16_fc=True)
+    scale = max(1.0, float(np.abs(ref).max()))
+    loss, fc6, fc7, logits = outs[2][:4]
+    assert rel(fc6, acts["fc6"]) < 1e-3 and rel(fc7, acts["fc7"]) < 1e-3
+    assert np.abs(logits - ref).max() < 1e-3 * scale
+    # the two kernels of the mode agree to summation order
+    assert rel(outs[2][1], outs[0][1]) < 1e-4 and rel(outs[2][2], outs[0][2]) < 1e-3 and abs(outs[2][0] - outs[0][0]) < 1e-4 * max(1.0, abs(outs[0][0]))
+    np.testing.assert_array_equal(outs[2][5], outs[0][5]); np.testing.assert_array_equal(outs[2][6], outs[0][6])
+    loss_dref, _, _ = orc.loss_and_grads(P, img, orc.one_hot(lab, 20).astype(np.float32), keep_prob=0.5, masks=(outs[2][5], outs[2][6]), bf16_fc=True)
+    assert abs(outs[2][4] - loss_dref) < 1e-3 * max(1.0, abs(loss_dref))
