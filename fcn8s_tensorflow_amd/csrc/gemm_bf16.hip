@@ -373,6 +373,9 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_256_kernel(const Bf16Conv256
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the reads are DONE in this tick: the stage may be refilled two ticks later
     };
     auto mfma_phase = [&]() {
+        // priority over the partner wave of the SIMD, which is in its load phase: without it that wave's ds_read / LDS-DMA / waitcnt
+        // issue delays the MFMA stream (lab, same box: 900 -> 948 TFLOP/s at fc7's shape, 847 -> 902 at fc6's)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -380,6 +383,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_256_kernel(const Bf16Conv256
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][tm], bfr[ks][tn], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
     };
 
     const int nkt = Ktot / G_BK;

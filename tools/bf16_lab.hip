@@ -60,7 +60,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(const Args p)
     const unsigned short* b_base = p.Bt + (long long)n0 * p.ldb;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     auto issue = [&](int kt) {
-        if ((p.mode == 1 || p.mode >= 4) && kt >= S - 1) return;
+        if ((p.mode == 1 || p.mode == 4 || p.mode == 5) && kt >= S - 1) return;
         const unsigned st = lds0 + (unsigned)((kt % S) * STAGE_BYTES);
         const unsigned short* ga = a_base + (long long)kt * BK;
         const unsigned short* gb = b_base + (long long)kt * BK;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(const Args p)
     for (int tn = 0; tn < 2; ++tn) b_row[tn] = wn * 64 + tn * 32 + (lane & 31);
     bf16x8 af[2][4], bfr[2][2];
     auto load_frags = [&](int kt) {
-        if ((p.mode == 3 || p.mode >= 4) && kt > 0) return;
+        if ((p.mode == 3 || p.mode == 4 || p.mode == 5) && kt > 0) return;
         const unsigned char* st = smem + (kt % S) * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(const Args p)
     };
     auto mfma_phase = [&]() {
         if (p.mode == 2) return;
+        if (p.mode != 6) __builtin_amdgcn_s_setprio(1);      // (mode 6: without the priority)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(const Args p)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][tm], bfr[ks][tn], acc[tm][tn], 0, 0, 0);
+        if (p.mode != 6) __builtin_amdgcn_s_setprio(0);
     };
 
     const int nkt = p.K / BK;
@@ -229,6 +231,9 @@ int main()
     run_case(8192, 4096, 4096, false, 10, 1);
     run_case(8192, 4096, 4096, false, 10, 2);
     run_case(8192, 4096, 4096, false, 10, 3);
+    printf("WITHOUT s_setprio(1) around the MFMA phase (fc7 / fc6 shapes)\n");
+    run_case(8192, 4096, 4096, false, 10, 6);
+    run_case(8192, 4096, 25088, false, 3, 6);
     printf("MFMAs + barriers only / MFMAs only\n");
     run_case(8192, 4096, 4096, false, 10, 4);
     run_case(8192, 4096, 4096, false, 10, 5);
