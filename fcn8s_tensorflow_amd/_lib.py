@@ -17,7 +17,7 @@ IMG_U8, IMG_F32 = 0, 1
 OPT_TF_ADAM, OPT_SGD_MOMENTUM, OPT_NONE = 0, 1, 2
 NUM_BUCKETS = 3
 NUM_STAGE_SLOTS = 3
-PREC_F32, PREC_BF16_FC, PREC_F32X3 = 0, 1, 2
+PREC_F32, PREC_BF16_FC, PREC_F32X3, PREC_BF16_FWD = 0, 1, 2, 3
 
 
 class Config(C.Structure):

@@ -76,7 +76,7 @@ struct fcn8s_model {
     std::set<std::string> rbits_ok;                                       // layers whose forward pass wrote a ReLU bit mask ("rb:<layer>") this step
     std::string fused_v_layer;                                            // layer whose data-gradient input transform already sits in d_wino_v
     std::string dm_layer;                                                 // layer whose dM = A dY A^T sits in d_wino_m, ready for the adjoint data gradient
-    unsigned short* d_wbf16 = nullptr;                                    // bf16 copy of the fc6 / fc7 kernel (one at a time; K-tile-major or transposed)
+    unsigned short* d_wbf16 = nullptr; size_t wbf16_elems = 0;            // bf16 copy of one layer's kernel at a time (K-tile-major or transposed)
     std::map<std::string, unsigned short*> wbf16_cache;                   // ... per layer, valid while frozen
     int bf16_gemm256 = 1;                                                 // bf16_fc mode: 256 x 256 LDS-DMA kernel -- 0 never, 1 when it fills the chip, 2 whenever shapes allow
     unsigned short* d_abf16 = nullptr; size_t abf16_elems = 0;            // bf16 copy of the layer's input activations
@@ -263,7 +263,7 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
 // (e.g. 192) get a second, transposed bank instead (3x3 layers) or the forward-type data gradient (fc6).
 static bool bt_gemm_ok(int K, int N) { return K % 16 == 0 && (N == 64 || N % 128 == 0); }
 int g_op_split = 0;      // arithmetic of the op-level entry points, which have no model (fcn8s_set_option(NULL, "op_f32x3", 1))
-int split_of(const fcn8s_model* m) { return m ? (m->precision == FCN8S_PREC_F32X3 ? 3 : 0) : g_op_split; }
+int split_of(const fcn8s_model* m) { return m ? ((m->precision == FCN8S_PREC_F32X3 || m->precision == FCN8S_PREC_BF16_FWD) ? 3 : 0) : g_op_split; }
 int wino_tile_for(const fcn8s_model* m, int H, int W, int K = 3)
 {
     if (!m || H % 2 || W % 2) return 0;
@@ -893,6 +893,85 @@ bool pool_backward_fused(const fcn8s_model* m, int b, bool pooled_by_transform)
            wino_tile_for(m, h, w) >= 4 && cw % 64 == 0 && nconv > 1 && m->acts.count(last);
 }
 
+// One SAME convolution with bf16-rounded operands and fp32 accumulation on the bf16 MFMA (gemm_bf16.hip), fp32 bias / ReLU / dropout epilogue,
+// fp32 output: fc6 / fc7 of FCN8S_PREC_BF16_FC, and conv3_1 .. conv5_3 as well in FCN8S_PREC_BF16_FWD.  Returns false if no bf16 kernel
+// takes the shape (the caller then uses the fp32 path).
+bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const char* bname, const float* in, float* out,
+                     int N, int h, int w, int cin, int cout, int k, int drop, float keep_prob, uint32_t stream_id, hipStream_t s, bool allow_small = true)
+{
+    const int K = k * k * cin;
+    const long long Mrows = (long long)N * h * w;
+    const bool big = conv_bf16_256_ok(Mrows, cin, cout, m->bf16_gemm256);      // 256 x 256 tiles, LDS-DMA, staggered wave groups
+    if (!big && (!allow_small || cin % 32 || cout % 128)) return false;
+    const size_t wneed = (size_t)K * cout;
+    if (m->wbf16_elems < wneed) {
+        if (m->d_wbf16) { hipStreamSynchronize(s); hipFree(m->d_wbf16); m->d_wbf16 = nullptr; m->wbf16_elems = 0; }
+        if (hipMalloc((void**)&m->d_wbf16, wneed * sizeof(unsigned short)) != hipSuccess) { (void)hipGetLastError(); return false; }
+        m->wbf16_elems = wneed;
+    }
+    // weights: bf16, K-tile-major blocks for the 128 x 128 kernel or transposed [Cout][K] for the 256 x 256 one; with frozen parameters
+    // (evaluation / serving loops) each layer's copy is made once and kept
+    unsigned short* wbuf = m->d_wbf16;
+    bool have = false;
+    if (m->frozen) {
+        unsigned short*& c = m->wbf16_cache[std::string(wname) + (big ? "#t" : "#b")];
+        if (c) { wbuf = c; have = true; }
+        else if (hipMalloc((void**)&c, wneed * sizeof(unsigned short)) == hipSuccess) wbuf = c;
+        else { c = nullptr; (void)hipGetLastError(); }
+    }
+    if (!have) { ProfScope ps(m, "weight_relayout", 0, 6.0 * K * cout);
+                 if (big) launch_w_to_bf16_t(Wp(m, wname), wbuf, K, cout, s); else launch_w_to_bf16_tiles(Wp(m, wname), wbuf, K, cout, s); }
+    const int pad = big ? (k - 1) / 2 : 0;
+    const size_t nin = (size_t)N * (h + 2 * pad) * (w + 2 * pad) * cin;
+    if (nin % 8 == 0 && m->abf16_elems < nin) {
+        if (m->d_abf16) { hipStreamSynchronize(s); hipFree(m->d_abf16); m->d_abf16 = nullptr; m->abf16_elems = 0; }
+        if (hipMalloc((void**)&m->d_abf16, nin * sizeof(unsigned short)) == hipSuccess) m->abf16_elems = nin; else (void)hipGetLastError();
+    }
+    const double M = (double)Mrows;
+    if (big && m->d_abf16 && m->abf16_elems >= nin) {
+        { ProfScope ps(m, "weight_relayout", 0, 4.0 * Mrows * cin + 2.0 * nin); launch_f32_to_bf16_padded(in, m->d_abf16, N, h, w, cin, pad, s); }
+        Bf16Conv256Args g{};
+        g.xp = m->d_abf16; g.wt = wbuf; g.bias = Wp(m, bname); g.y = out;
+        g.N = N; g.H = h; g.W = w; g.Cin = cin; g.Cout = cout; g.K = k;
+        g.relu = 1; g.dropout = drop; g.keep_prob = keep_prob; g.seed = m->seed; g.stream_id = stream_id;
+        ProfScope ps(m, tag, 2.0 * M * K * cout, 4.0 * M * cout + 2.0 * M * cin + 2.0 * K * cout);
+        if (launch_conv_bf16_256(g, s)) return true;
+    }
+    if (!allow_small || cin % 32 || cout % 128) return false;
+    if (big) { launch_w_to_bf16_tiles(Wp(m, wname), m->d_wbf16, K, cout, s); wbuf = m->d_wbf16; }      // (could not take the 256 path after all)
+    Bf16ConvArgs a{};
+    a.x = in; a.wt = wbuf; a.bias = Wp(m, bname); a.y = out;
+    if (nin % 8 == 0 && m->d_abf16) {         // activations to bf16 once: the GEMM re-reads each A tile Cout/128 times
+        ProfScope ps(m, "weight_relayout", 0, 6.0 * nin); launch_f32_to_bf16(in, m->d_abf16, (long long)N * h * w * cin, s); a.xh = m->d_abf16;
+    }
+    a.N = N; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.K = k;
+    a.relu = 1; a.dropout = drop; a.keep_prob = keep_prob; a.seed = m->seed; a.stream_id = stream_id;
+    ProfScope ps(m, tag, 2.0 * M * K * cout, 4.0 * M * (cin + cout) + 2.0 * K * cout);
+    return launch_conv_bf16(a, s);
+}
+
+// What the backward pass of a Winograd layer expects from the forward pass when the forward convolution itself did not run through
+// Winograd (the bf16 modes): the transformed input V (kept for the weight gradient in the Winograd domain) and, for the adjoint data
+// gradient, the forward filter bank of THIS step's weights (a bank left over from an earlier step would be silently wrong).
+void wino_backward_operands(fcn8s_model* m, const char* layer, const float* x, const float* wk, int N, int H, int W, int Cin, int Cout, int KS, hipStream_t s)
+{
+    const int tile = wino_tile_for(m, H, W, KS);
+    if (!tile) return;
+    auto it = m->acts.find(std::string("wv:") + layer);
+    if (it == m->acts.end()) return;
+    const int P = wino_alpha(tile, KS) * wino_alpha(tile, KS), nsub2 = wino_nsub(KS) * wino_nsub(KS), Kg = nsub2 * Cin;
+    const long long T = wino_tiles(tile, N, H, W);
+    { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg));
+      launch_wino_input(tile, x, it->second.p, N, H, W, Cin, KS, s); }
+    const std::string key = std::string(layer) + "#" + std::to_string(tile);
+    if ((KS == 3 && tile == 6) || (KS == 7 && tile == 4)) {
+        float*& tu = m->u_train[key];
+        if (!tu && hipMalloc((void**)&tu, (size_t)P * Kg * Cout * sizeof(float)) != hipSuccess) { tu = nullptr; (void)hipGetLastError(); }
+        if (tu) { ProfScope ps(m, "wino_transform", 0, (double)(KS * KS + P * nsub2) * 4 * Cin * Cout); launch_wino_filter(tile, wk, tu, Cin, Cout, KS, s); }
+        else m->u_train.erase(key);
+    }
+}
+
 int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, bool train)
 {
     hipStream_t s = m->stream;
@@ -946,6 +1025,14 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 ProfScope ps(m, "conv1_1_fwd", 2.0 * N * h * w * 27.0 * m->widths[0], 4.0 * N * h * w * (3.0 + m->widths[0]), nm);
                 done = launch_conv1_fwd(x, m->d_w1pad, e.bias, A(m, nm), m->d_w1pad + 12 * 4 * (size_t)m->widths[0], N, h, w, m->widths[0], s);
             }
+            if (!done && m->precision == FCN8S_PREC_BF16_FWD && b >= 2) {
+                // FCN8S_PREC_BF16_FWD: conv3_1 .. conv5_3 as direct convolutions with bf16-rounded operands on the 256 x 256 bf16 kernel (the
+                // output is materialised, the block's pool runs as its own kernel, ReLU masks come from the activations); the backward pass
+                // stays in the Winograd domain, so the transformed input and this step's filter bank are made here
+                done = bf16_conv_layer(m, "conv3x3_fwd_bf16", (std::string(nm) + "/filter").c_str(), (std::string(nm) + "/biases").c_str(), x, A(m, nm),
+                                       N, h, w, cin, m->widths[b], 3, 0, 1.f, 0, s, /*allow_small=*/false);
+                if (done && train) wino_backward_operands(m, nm, x, wt, N, h, w, cin, m->widths[b], 3, s);
+            }
             if (!done) pooled = conv_same(m, first ? "conv1_1_fwd" : "conv3x3_fwd", x, wt, A(m, nm), N, h, w, cin, m->widths[b], 3, e, s, first ? 3 : 0, nm);
             x = A(m, nm); cin = m->widths[b];
         }
@@ -957,60 +1044,12 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     const int h5 = h, w5 = w;
     const bool drop = train && keep_prob < 1.f;
     m->drop_stream = (uint32_t)(2 * m->step);
-    if (m->precision == FCN8S_PREC_BF16_FC) {
+    if (m->precision == FCN8S_PREC_BF16_FC || m->precision == FCN8S_PREC_BF16_FWD) {
         // config 5: bf16-rounded operands, fp32 accumulate, fp32 epilogue and output (gemm_bf16.hip)
-        auto fc = [&](const char* tag, const char* wname, const char* bname, const float* in, float* out, int cin, int cout, int k, uint32_t stream_id) {
-            const int K = k * k * cin;
-            const long long Mrows = (long long)N * h5 * w5;
-            const bool big = conv_bf16_256_ok(Mrows, cin, cout, m->bf16_gemm256);      // 256 x 256 tiles, LDS-DMA, staggered wave groups
-            // weights: bf16, K-tile-major blocks for the 128 x 128 kernel or transposed [Cout][K] for the 256 x 256 one; with frozen parameters
-            // (evaluation / serving loops) each layer's copy is made once and kept
-            unsigned short* wbuf = m->d_wbf16;
-            bool have = false;
-            if (m->frozen) {
-                unsigned short*& c = m->wbf16_cache[std::string(wname) + (big ? "#t" : "#b")];
-                if (c) { wbuf = c; have = true; }
-                else if (hipMalloc((void**)&c, (size_t)K * cout * sizeof(unsigned short)) == hipSuccess) wbuf = c;
-                else { c = nullptr; (void)hipGetLastError(); }
-            }
-            if (!have) { ProfScope ps(m, "weight_relayout", 0, 6.0 * K * cout);
-                         if (big) launch_w_to_bf16_t(Wp(m, wname), wbuf, K, cout, s); else launch_w_to_bf16_tiles(Wp(m, wname), wbuf, K, cout, s); }
-            const int pad = big ? (k - 1) / 2 : 0;
-            const size_t nin = (size_t)N * (h5 + 2 * pad) * (w5 + 2 * pad) * cin;
-            if (nin % 8 == 0 && m->abf16_elems < nin) {
-                if (m->d_abf16) { hipStreamSynchronize(s); hipFree(m->d_abf16); m->d_abf16 = nullptr; m->abf16_elems = 0; }
-                if (hipMalloc((void**)&m->d_abf16, nin * sizeof(unsigned short)) == hipSuccess) m->abf16_elems = nin; else (void)hipGetLastError();
-            }
-            const double M = (double)Mrows;
-            if (big && m->d_abf16 && m->abf16_elems >= nin) {
-                { ProfScope ps(m, "weight_relayout", 0, 4.0 * Mrows * cin + 2.0 * nin); launch_f32_to_bf16_padded(in, m->d_abf16, N, h5, w5, cin, pad, s); }
-                Bf16Conv256Args g{};
-                g.xp = m->d_abf16; g.wt = wbuf; g.bias = Wp(m, bname); g.y = out;
-                g.N = N; g.H = h5; g.W = w5; g.Cin = cin; g.Cout = cout; g.K = k;
-                g.relu = 1; g.dropout = drop; g.keep_prob = keep_prob; g.seed = m->seed; g.stream_id = stream_id;
-                ProfScope ps(m, tag, 2.0 * M * K * cout, 4.0 * M * cout + 2.0 * M * cin + 2.0 * K * cout);
-                if (launch_conv_bf16_256(g, s)) return;
-            }
-            if (big) { launch_w_to_bf16_tiles(Wp(m, wname), m->d_wbf16, K, cout, s); wbuf = m->d_wbf16; }      // (could not take the 256 path after all)
-            Bf16ConvArgs a{};
-            a.x = in; a.wt = wbuf; a.bias = Wp(m, bname); a.y = out;
-            if (nin % 8 == 0 && m->d_abf16) {         // activations to bf16 once: the GEMM re-reads each A tile Cout/128 times
-                ProfScope ps(m, "weight_relayout", 0, 6.0 * nin); launch_f32_to_bf16(in, m->d_abf16, (long long)N * h5 * w5 * cin, s); a.xh = m->d_abf16;
-            }
-            a.N = N; a.H = h5; a.W = w5; a.Cin = cin; a.Cout = cout; a.K = k;
-            a.relu = 1; a.dropout = drop; a.keep_prob = keep_prob; a.seed = m->seed; a.stream_id = stream_id;
-            ProfScope ps(m, tag, 2.0 * M * K * cout, 4.0 * M * (cin + cout) + 2.0 * K * cout);
-            launch_conv_bf16(a, s);
-        };
-        fc("fc6_fwd_bf16", "fc6/weights", "fc6/biases", x, A(m, "fc6"), m->widths[4], m->widths[5], m->fc6k, m->drop_stream);
-        if (train) {            // the fp32 weight gradient of fc6 runs in the Winograd domain and wants the transformed input
-            auto it = m->acts.find("wv:fc6");
-            if (it != m->acts.end()) {
-                ProfScope ps(m, "wino_transform", 0, 4.0 * N * h5 * w5 * m->widths[4] * (9 + 20.25));
-                launch_wino_input(4, x, it->second.p, N, h5, w5, m->widths[4], 7, s);
-            }
-        }
-        fc("fc7_fwd_bf16", "fc7/weights", "fc7/biases", A(m, "fc6"), A(m, "fc7"), m->widths[5], m->widths[6], 1, m->drop_stream + 1);
+        bf16_conv_layer(m, "fc6_fwd_bf16", "fc6/weights", "fc6/biases", x, A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, drop, keep_prob, m->drop_stream, s);
+        // the fp32 gradients of fc6 run in the Winograd domain and want the transformed input and this step's filter bank
+        if (train) wino_backward_operands(m, "fc6", x, Wp(m, "fc6/weights"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, s);
+        bf16_conv_layer(m, "fc7_fwd_bf16", "fc7/weights", "fc7/biases", A(m, "fc6"), A(m, "fc7"), N, h5, w5, m->widths[5], m->widths[6], 1, drop, keep_prob, m->drop_stream + 1, s);
     } else {
         {
             Epi e; e.bias = Wp(m, "fc6/biases"); e.relu = 1; e.dropout = drop; e.keep = keep_prob; e.stream_id = m->drop_stream;
@@ -1427,14 +1466,19 @@ int fcn8s_freeze_params(fcn8s_model* m, int frozen)
 int fcn8s_set_precision(fcn8s_model* m, int precision)
 {
     if (!m) return FCN8S_ERR_BAD_ARG;
-    if (precision != FCN8S_PREC_F32 && precision != FCN8S_PREC_BF16_FC && precision != FCN8S_PREC_F32X3) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_precision: unknown precision");
-    if (precision == FCN8S_PREC_BF16_FC) {
+    if (precision != FCN8S_PREC_F32 && precision != FCN8S_PREC_BF16_FC && precision != FCN8S_PREC_F32X3 && precision != FCN8S_PREC_BF16_FWD)
+        return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_precision: unknown precision");
+    if (precision == FCN8S_PREC_BF16_FC || precision == FCN8S_PREC_BF16_FWD) {
         if (m->widths[4] % 32 || m->widths[5] % 128 || m->widths[6] % 128)
-            return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_precision: BF16_FC needs conv5 width % 32 == 0 and fc6 / fc7 widths % 128 == 0");
-        if (!m->d_wbf16) {
-            const size_t n = std::max((size_t)m->fc6k * m->fc6k * m->widths[4] * m->widths[5], (size_t)m->widths[5] * m->widths[6]);
-            HIPCHK(m, hipMalloc((void**)&m->d_wbf16, n * sizeof(unsigned short)));
-        }
+            return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_precision: the bf16 modes need conv5 width % 32 == 0 and fc6 / fc7 widths % 128 == 0");
+    }
+    if (precision != m->precision) {
+        // the forward filter banks kept for the adjoint data gradients belong to the arithmetic that made them (and a mode whose forward
+        // pass does not refresh a bank must never find an old one)
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+        for (auto& kv : m->u_train) if (kv.second) hipFree(kv.second);
+        m->u_train.clear();
+        drop_u_cache(m);
     }
     m->precision = precision;
     return FCN8S_OK;

@@ -391,11 +391,13 @@ class Engine:
 
     def set_precision(self, precision):
         """'fp32' (the reference's arithmetic), 'bf16_fc' (BASELINE config 5: forward fc6 / fc7 with bf16-rounded
-        operands on the bf16 MFMA, fp32 accumulation; the rest of the step stays fp32) or 'f32x3' (every large GEMM on the
-        bf16 MFMA with each fp32 operand split exactly into three bf16 pieces: fp32 accuracy, not bit-identical to fp32)."""
-        modes = {'fp32': L.PREC_F32, 'bf16_fc': L.PREC_BF16_FC, 'f32x3': L.PREC_F32X3}
+        operands on the bf16 MFMA, fp32 accumulation; the rest of the step stays fp32), 'f32x3' (every large GEMM on the
+        bf16 MFMA with each fp32 operand split exactly into three bf16 pieces: fp32 accuracy, not bit-identical to fp32) or
+        'bf16_fwd' (config 5 taken further: conv3_1 .. conv5_3, fc6 and fc7 forward with bf16-rounded operands, every other GEMM
+        in the f32x3 arithmetic: all matrix work on the bf16 MFMA)."""
+        modes = {'fp32': L.PREC_F32, 'bf16_fc': L.PREC_BF16_FC, 'f32x3': L.PREC_F32X3, 'bf16_fwd': L.PREC_BF16_FWD}
         if precision not in modes:
-            raise ValueError("`precision` must be 'fp32', 'bf16_fc' or 'f32x3', but is '{}'.".format(precision))
+            raise ValueError("`precision` must be 'fp32', 'bf16_fc', 'f32x3' or 'bf16_fwd', but is '{}'.".format(precision))
         L.check(L.lib.fcn8s_set_precision(self.h, modes[precision]), self.h)
         self.precision = precision
 

@@ -59,6 +59,12 @@ extern "C" {
                                      bf16 pieces and six of the nine piece products are accumulated in fp32 -- error below one fp32
                                      rounding per product, not bit-identical to an fmaf chain; 1.25x faster GEMMs.  Not the default. */
 
+#define FCN8S_PREC_BF16_FWD 3      /* BASELINE.json config 5 taken further ("bf16 fwd / fp32 accum"): besides fc6 / fc7, the forward convolutions of
+                                     conv3_1 .. conv5_3 (Cout a multiple of 256) run as direct convolutions with bf16-rounded operands on the bf16
+                                     MFMA, fp32 accumulation, fp32 outputs; every other GEMM of the step -- conv1_2 / conv2_x forward, all data and
+                                     weight gradients -- uses the F32X3 arithmetic, i.e. all matrix work is on the bf16 MFMA.  Gradients are those of
+                                     the fp32 graph evaluated at the bf16-forward activations (straight-through rounding). */
+
 typedef struct fcn8s_model fcn8s_model;
 
 typedef struct fcn8s_config {

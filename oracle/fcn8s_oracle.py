@@ -209,10 +209,18 @@ def _pool_routed(z, route):
     return torch.gather(win, -1, route.clamp(max=3).unsqueeze(-1)).squeeze(-1) * on
 
 
-def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False, branches=None, routes=None):
+def _conv_bf16_value(x, w, b):
+    """SAME conv + bias whose forward VALUE is the contraction of the bf16-rounded operands (fp32 products and sums) and whose backward
+    pass is the fp32 conv gradient at the unrounded operands -- the arithmetic of the library's bf16 modes (straight-through rounding)."""
+    z = conv2d_same_t(x, w, b)
+    return z + (conv2d_same_t(_bf16_round(x), _bf16_round(w), b.detach()) - z).detach()
+
+
+def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False, branches=None, routes=None, bf16_convs=False):
     """Forward pass on torch tensors.  P: name -> torch tensor (TF layouts).
     images_t: NHWC RGB float.  masks: optional (mask6, mask7) NHWC tensors.
     bf16_fc: BASELINE config 5 -- both operands of the fc6 / fc7 contractions rounded to bfloat16, fp32 accumulate.
+    bf16_convs: the same for the forward convolutions conv3_1 .. conv5_3 (FCN8S_PREC_BF16_FWD; implies nothing about fc6 / fc7).
     branches: optional name -> 0/1 NCHW tensor ("conv1_1" ... for the convs that feed another conv, "pool1".."pool5" for each block's
     last conv + pool, "fc6", "fc7"): the ReLU branches to take instead of this restatement's own (see _relu_branch).
     routes: optional "pool1".."pool5" -> int64 (N,C,h/2,w/2) tensor of max-pool routes (see _pool_routed); takes the place of that
@@ -226,7 +234,7 @@ def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False,
             n = "conv%d_%d" % (blk, i)
             routed = routes is not None and ("pool%d" % blk) in routes
             pooled_branch = i == nconv and (routed or (branches is not None and ("pool%d" % blk) in branches))
-            z = conv2d_same_t(x, P[n + "/filter"], P[n + "/biases"])
+            z = (_conv_bf16_value if (bf16_convs and blk >= 3) else conv2d_same_t)(x, P[n + "/filter"], P[n + "/biases"])
             # (a block's last conv: max(relu(z)) = relu(max(z)), so its branch record lives on the pooled tensor)
             x = z if pooled_branch else _relu_branch(z, n, branches)
             if keep:
@@ -281,12 +289,12 @@ def _params_t(params, dtype, requires_grad=False):
     return OrderedDict((k, _t(v, dtype).requires_grad_(requires_grad)) for k, v in params.items())
 
 
-def forward(params, images, keep_prob=1.0, masks=None, dtype=torch.float32, keep=False, bf16_fc=False):
+def forward(params, images, keep_prob=1.0, masks=None, dtype=torch.float32, keep=False, bf16_fc=False, bf16_convs=False):
     """numpy front-end.  Returns logits NHWC (and activations NHWC if keep)."""
     with torch.no_grad():
         P = _params_t(params, dtype)
         mt = None if masks is None else tuple(_t(m, dtype) for m in masks)
-        out = forward_t(P, _t(images, dtype), keep_prob, mt, keep, bf16_fc)
+        out = forward_t(P, _t(images, dtype), keep_prob, mt, keep, bf16_fc, bf16_convs=bf16_convs)
         if keep:
             logits, acts = out
             return _nhwc(logits).contiguous().numpy(), {k: _nhwc(v).contiguous().numpy() for k, v in acts.items()}
@@ -322,7 +330,7 @@ def pool_routes(acts):
 
 
 def loss_and_grads(params, images, labels_onehot, l2_rate=0.0, keep_prob=1.0, masks=None,
-                   dtype=torch.float32, bf16_fc=False, branches=None, routes=None):
+                   dtype=torch.float32, bf16_fc=False, branches=None, routes=None, bf16_convs=False):
     """total_loss and d(total_loss)/d(every variable) -- what
     AdamOptimizer.minimize differentiates (var_list=None, :257).
     branches: optional name -> NHWC bool/0-1 array of post-ReLU activations that are on (activation > 0), see forward_t.
@@ -331,7 +339,7 @@ def loss_and_grads(params, images, labels_onehot, l2_rate=0.0, keep_prob=1.0, ma
     mt = None if masks is None else tuple(_t(m, dtype) for m in masks)
     bt = None if branches is None else {k: _nchw(_t(np.asarray(v) > 0, dtype)) for k, v in branches.items()}
     rt = None if routes is None else {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v).transpose(0, 3, 1, 2))).to(torch.int64) for k, v in routes.items()}
-    logits = forward_t(P, _t(images, dtype), keep_prob, mt, bf16_fc=bf16_fc, branches=bt, routes=rt)
+    logits = forward_t(P, _t(images, dtype), keep_prob, mt, bf16_fc=bf16_fc, branches=bt, routes=rt, bf16_convs=bf16_convs)
     loss = total_loss_t(P, logits, _t(labels_onehot, dtype), l2_rate)
     grads = torch.autograd.grad(loss, list(P.values()))
     return (float(loss.detach()),

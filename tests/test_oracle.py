@@ -272,3 +272,30 @@ def test_pool_routes_reproduce_the_unrouted_gradients_and_steer_ties():
         assert gz[0, 0].tolist() == want
     y = orc._pool_routed(z, torch.tensor([[[[4]]]]))
     assert float(y.detach()) == 0.0
+
+
+def test_bf16_convs_mode_of_the_oracle():
+    """`bf16_convs` (FCN8S_PREC_BF16_FWD's forward arithmetic for conv3_1 .. conv5_3): the forward VALUE of those layers is the fp32
+    convolution of the bf16-rounded operands -- checked on one layer against an explicit rounding -- the backward pass is the fp32 one
+    (straight-through), and blocks 1-2 are untouched."""
+    widths = (4, 4, 8, 8, 8, 16, 16)
+    P = orc.init_params(4, widths, fc6_ksize=3, seed=2, decoder_std_scale=30.0, bias_std=0.05)
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (1, 32, 32, 3), dtype=np.uint8)
+    _, a32 = orc.forward(P, img, keep=True)
+    _, a16 = orc.forward(P, img, keep=True, bf16_convs=True)
+    for k in ("conv1_1", "conv1_2", "conv2_1", "conv2_2", "pool2"):
+        np.testing.assert_array_equal(a32[k], a16[k])
+    d = np.abs(a16["conv3_1"] - a32["conv3_1"]).max() / np.abs(a32["conv3_1"]).max()
+    assert 1e-5 < d < 2e-2, d                                                 # bf16 rounding is visible, and small
+    x = torch.from_numpy(a32["pool2"]).permute(0, 3, 1, 2)
+    w = torch.from_numpy(P["conv3_1/filter"]); b = torch.from_numpy(P["conv3_1/biases"])
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    want = torch.relu(torch.nn.functional.conv2d(rb(x), rb(w).permute(3, 2, 0, 1), b, padding=1)).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(a16["conv3_1"], want, rtol=0, atol=1e-5 * np.abs(want).max())
+    lab = orc.one_hot(rng.integers(0, 4, (1, 32, 32), dtype=np.uint8), 4).astype(np.float32)
+    l16, g16, _ = orc.loss_and_grads(P, img, lab, bf16_convs=True, bf16_fc=True)
+    l32, g32, _ = orc.loss_and_grads(P, img, lab)
+    assert np.isfinite(l16) and abs(l16 - l32) < 0.1 * abs(l32)
+    for k in g32:
+        assert np.isfinite(g16[k]).all() and g16[k].shape == g32[k].shape
