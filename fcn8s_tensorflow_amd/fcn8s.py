@@ -224,29 +224,34 @@ class FCN8s:
         eval_source = {'train': (train_generator, steps_per_epoch, 'Evaluation on training dataset'),
                        'val': (val_generator, val_steps, 'Evaluation on validation dataset')}[eval_dataset]
 
-        for epoch in range(1, epochs + 1):
-            self._run_epoch(train_generator, steps_per_epoch, learning_rate_schedule, keep_prob, l2_regularization,
-                            'Epoch {}/{}'.format(epoch, epochs), training_loss_display_averaging,
-                            train_log, summaries_frequency)
-            eval_epoch = epoch % eval_frequency == 0
+        try:
+            for epoch in range(1, epochs + 1):
+                self._run_epoch(train_generator, steps_per_epoch, learning_rate_schedule, keep_prob, l2_regularization,
+                                'Epoch {}/{}'.format(epoch, epochs), training_loss_display_averaging,
+                                train_log, summaries_frequency)
+                eval_epoch = epoch % eval_frequency == 0
 
-            if metrics and eval_epoch:
-                generator, num_batches, description = eval_source
-                self._evaluate(generator, metrics, num_batches, l2_regularization, description)
-                if eval_log is not None:
-                    eval_log.add(self.g_step, **{('mean_loss' if n == 'loss' else n): v for n, v in zip(self.metric_names, self.metric_values)})    # tags of :360-362
+                if metrics and eval_epoch:
+                    generator, num_batches, description = eval_source
+                    self._evaluate(generator, metrics, num_batches, l2_regularization, description)
+                    if eval_log is not None:
+                        eval_log.add(self.g_step, **{('mean_loss' if n == 'loss' else n): v for n, v in zip(self.metric_names, self.metric_values)})    # tags of :360-362
 
-            if save_during_training and epoch % save_frequency == 0 and self._wants_save(save_best_only, monitor):
-                self.save(model_save_dir=save_dir, saver=saver, tags=save_tags, name=save_name,
-                          include_global_step=True, include_last_training_loss=True,
-                          include_metrics=bool(self.metric_names))
+                if save_during_training and epoch % save_frequency == 0 and self._wants_save(save_best_only, monitor):
+                    self.save(model_save_dir=save_dir, saver=saver, tags=save_tags, name=save_name,
+                              include_global_step=True, include_last_training_loss=True,
+                              include_metrics=bool(self.metric_names))
 
-            # Bests are updated after the save decision (fcn8s_tensorflow.py:648-658).
-            self.best_training_loss = min(self.best_training_loss, self.training_loss)
-            if eval_epoch:
-                for i, name in enumerate(self.metric_names):
-                    if self._improved(name, i):
-                        self.best_metric_values[i] = self.metric_values[i]
+                # Bests are updated after the save decision (fcn8s_tensorflow.py:648-658).
+                self.best_training_loss = min(self.best_training_loss, self.training_loss)
+                if eval_epoch:
+                    for i, name in enumerate(self.metric_names):
+                        if self._improved(name, i):
+                            self.best_metric_values[i] = self.metric_values[i]
+        finally:
+            for log in (train_log, eval_log):          # the event files are complete and closed when train() returns or raises
+                if log is not None:
+                    log.close()
 
     def _run_epoch(self, generator, steps, schedule, keep_prob, l2_rate, title, window, log, log_every):
         '''One epoch of train steps (fcn8s_tensorflow.py:542-590): a step runs with the schedule's value
