@@ -101,8 +101,8 @@ def test_config3_gradients_1024x512_bs1_vs_oracle(variant, options, bound):
     restatement): F(6x6,3x3) data / weight gradients at 14 706 tiles per image, fc6's F(4x4,4x4) weight gradient at depth 2048,
     split-K atomics, conv1_1's VALU weight gradient at 512x1024 -- none of which the small cases reach at this size.  The oracle
     differentiates along the ReLU / max-pool decisions the device took, after the test has checked that those differ from the oracle's
-    own only at fp32 coin flips (units within 1e-5 of zero, window maxima within 1e-4 of the layer's largest activation of each other).
-    Bound: 1e-4 of each tensor's largest gradient -- a tenth of SURVEY section 7 step 5's 1e-3; measured 3.4e-5 (worst: the last
+    own only at fp32 coin flips (units within 1e-5 of zero, window maxima within 2e-5 of the layer's largest activation of each other).
+    Bound: 1e-4 of each tensor's largest gradient -- a tenth of SURVEY section 7 step 5's 1e-3; measured 3.4-4.5e-5 (worst: the last
     transposed conv's bias; conv1_1/filter, the end of the backward chain, 1.2e-5), the same for F(4x4) and for direct convolution
     (profiles/parity_r03.json).  Without the alignment the very same gradients sit 1.9e-3 from the oracle's -- and the fp32 oracle
     0.94e-3 from its own float64 run: that is 54 of 16 million pool windows (and 69 of 98 million ReLU units) taking the other branch
@@ -131,7 +131,7 @@ def test_config3_gradients_1024x512_bs1_vs_oracle(variant, options, bound):
         n_route += int(d.sum())
         tie = d & ((rt[k] == 4) == (own[k] == 4))
         if tie.any():
-            assert gaps[k][tie].max() <= 1e-4, (k, float(gaps[k][tie].max()))
+            assert gaps[k][tie].max() <= 2e-5, (k, float(gaps[k][tie].max()))
         onoff = d & ~tie
         if onoff.any():
             assert np.abs(acts[k][onoff]).max() < 1e-5 * np.abs(acts[k]).max(), k

@@ -30,13 +30,13 @@ def case(widths, n, h, w, seed, decoder_std_scale=30.0):
     return P, img, lab
 
 
-def device_decisions(e, P, img, nhw, relu_tol=1e-5, tie_tol=1e-4, max_frac=1e-4, **fwd_kw):
+def device_decisions(e, P, img, nhw, relu_tol=1e-5, tie_tol=2e-5, max_frac=1e-4, **fwd_kw):
     """The discrete decisions the device's last training pass took -- which ReLU units are on (Engine.relu_branches) and where each
     max-pool window routes its gradient (Engine.pool_routes) -- after checking that they differ from the oracle's own decisions only
     where the decision is a coin flip in fp32: a ReLU unit may differ only if its activation is within `relu_tol` of zero (relative to
     the layer's largest), a pool route only if the oracle's two largest window entries agree to `tie_tol` of the layer's largest
     activation (Winograd F(6x6) carries a round-off of 2e-5 of the output range, tools/winograd_matrices.py; measured worst gap at a
-    differing route: 3e-5) -- or the window's maximum is within relu_tol of zero, for routes that differ in on/off.  Gradient parity is
+    differing route at 1024x512: 4.4e-6) -- or the window's maximum is within relu_tol of zero, for routes that differ in on/off.  Gradient parity is
     then taken along these decisions
     (oracle `branches=` / `routes=`): both sides differentiate the same piecewise-linear function, on any seed."""
     br = e.relu_branches(nhw)
@@ -183,7 +183,7 @@ def test_bf16_fc_mode_config5(widths, n, h, w):
     loss = e.forward_backward(img, onehot, keep_prob=1.0, l2_rate=1e-3)
     # along the device's decisions; a bf16 rounding-boundary flip moves fc6 / fc7 pre-activations by ~2e-4 of their scale, so ReLU units
     # up to 1e-3 of the layer's largest may legitimately sit on the other side
-    br, rt, _ = device_decisions(e, P, img, (n, h, w), relu_tol=1e-3, bf16_fc=True)
+    br, rt, _ = device_decisions(e, P, img, (n, h, w), relu_tol=1e-3, tie_tol=1e-3, bf16_fc=True)
     loss_ref, g_ref, _ = orc.loss_and_grads(P, img, onehot.astype(np.float32), l2_rate=1e-3, bf16_fc=True, branches=br, routes=rt)
     assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
     g = e.get_grads()
@@ -500,8 +500,8 @@ def test_deferred_weight_gradients_change_nothing(options):
     assert l0 == l1 and l20 == l21 and l0 == l20
     for k in g0:
         # (split-K sums use float atomics: their order is not reproducible between two runs of the SAME schedule either)
-        assert rel(g1[k], g0[k]) < 1e-5, k
-        assert rel(g21[k], g20[k]) < 1e-5, k
+        assert rel(g1[k], g0[k]) < 1e-4, k
+        assert rel(g21[k], g20[k]) < 1e-4, k
 
 
 def test_bf16_fc_256_tile_kernel():
