@@ -108,6 +108,14 @@ def _load():
         raise ImportError(
             "libfcn8s_hip.so not found at %s. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C fcn8s_tensorflow_amd/csrc`. There is no CPU fallback for the FCN-8s hot path." % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so); this library is linked against the one under /opt/rocm.  Whichever
+    # is loaded first serves both, and a process that ends up with the two of them sees "no ROCm-capable device" from the second
+    # (observed: `from fcn8s_tensorflow_amd.fcn8s import FCN8s` before any `import torch`).  The engine keeps its buffers in torch tensors
+    # anyway, so torch goes first -- always the same single runtime, whatever the caller's import order.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol

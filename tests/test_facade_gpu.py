@@ -377,3 +377,19 @@ def test_class_counts_that_are_not_multiples_of_four(C, tmp_path):
     assert t['fc7_conv2d_trans/kernel'].shape == (4, 4, C, C) and t['fc7_1x1/bias/adam_optimizer'].shape == (C,)
     assert 'optimizer/beta1_power' in t and abs(float(np.asarray(t['optimizer/beta1_power']).reshape(-1)[0]) - 0.9 ** (e.global_step + 1)) < 1e-6
     m.close(); m2.close()
+
+
+def test_import_order_package_before_torch():
+    """`from fcn8s_tensorflow_amd.fcn8s import FCN8s` as the first import of a process (the drop-in usage of INTEGRATION.md A) works: the
+    package makes sure a single HIP runtime serves torch and libfcn8s_hip.so (with the library's runtime loaded first, fcn8s_create
+    failed with 'no ROCm-capable device')."""
+    import subprocess, sys
+    code = ("from fcn8s_tensorflow_amd.fcn8s import FCN8s\n"
+            "import numpy as np\n"
+            "m = FCN8s(vgg16_dir='synthetic:0', num_classes=20, widths=(8, 16, 32, 64, 64, 128, 128))\n"
+            "p = m.predict(np.zeros((1, 32, 32, 3), np.uint8))\n"
+            "assert p.shape == (1, 32, 32)\n"
+            "m.close(); print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
