@@ -761,11 +761,99 @@ __global__ __launch_bounds__(256, 4) void conv1_glds_kernel(const Conv1Args p)
         __builtin_amdgcn_wave_barrier();
     }
 }
+// Round 3: the same layer with the input staged as a SPATIAL tile.  The gather above fetches nine scattered 16-byte taps per pixel (1.2 GB of
+// 16-byte requests for a 134 MB image: its time went into address processing, not into the 2.15 GB it writes).  Here a block owns 8 x 16
+// pixels of one image, loads the 10 x 18 halo tile once (row-contiguous 16-byte loads, zero outside the image) and every MFMA A fragment is
+// one ds_read_b128 straight from it: lane (pixel p, k-half h) of K-step (kt, kk2) needs the four channels of tap 4 kt + 2 kk2 + h at
+// pixel p, i.e. halo[(py + dy + 1)][(px + dx + 1)] -- 16 consecutive pixels are 256 contiguous bytes, conflict-free.  Same products, same
+// K order and the same epilogue as conv1_glds_kernel, so the results are bit-identical.
+__global__ __launch_bounds__(256, 4) void conv1_tile_kernel(const Conv1Args p)
+{
+    constexpr int TH = 8, TW = 16, BN = 64, BK = 16, NKT = 3, WN = 2, TM = 2, HW_ = TW + 2, HH_ = TH + 2;
+    constexpr int LDT = 36;
+    __shared__ __attribute__((aligned(16))) float sB[NKT * BK * BN];           // the 48 x 64 kernel (rows 36..47 zero)
+    __shared__ __attribute__((aligned(16))) float4 halo[HH_ * HW_];
+    __shared__ __attribute__((aligned(16))) float patches[4 * 32 * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_x = p.W / TW, tiles_y = p.H / TH;
+    const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, n = blockIdx.x / (tiles_x * tiles_y);
+    const int y0 = by * TH, x0 = bx * TW;
+    // B: 48 x 64 floats = 768 float4, three per thread
+#pragma unroll
+    for (int i = 0; i < 3; ++i) reinterpret_cast<float4*>(sB)[tid + i * 256] = ldg4(p.w48 + (tid + i * 256) * 4);
+    if (tid < HH_ * HW_) {
+        const int hy = tid / HW_, hx = tid - hy * HW_, yy = y0 + hy - 1, xx = x0 + hx - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) v = ldg4(p.x4 + (((long long)n * p.H + yy) * p.W + xx) * 4);
+        halo[tid] = v;
+    }
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    __syncthreads();
+    // pixel of this lane in pixel group tm of the wave: group g = wm * TM + tm covers tile rows 2 g, 2 g + 1
+    int hbase[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int g = wm * TM + tm, py = 2 * g + ((lane & 31) >> 4), px = lane & 15;
+        hbase[tm] = (py + 1) * HW_ + (px + 1);
+    }
+    const int b_off = ((lane >> 5) * 4) * BN + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int kk2 = 0; kk2 < BK / 8; ++kk2) {
+            if (kt == NKT - 1 && kk2 == 1) continue;        // taps 10, 11: padding (all-zero rows of w48)
+            // this lane half's tap; tap 9 (kt 2, kk2 0, upper half) is padding too: it reads a valid pixel against zero kernel rows
+            const int t = kt * 4 + kk2 * 2 + (lane >> 5), tt = t < 9 ? t : 4, dy = tt / 3 - 1, dx = tt % 3 - 1;
+            float4 af[TM]; float bf[3];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) af[tm] = halo[hbase[tm] + dy * HW_ + dx];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bf[j] = sB[kt * BK * BN + b_off + (kk2 * 8 + j) * BN];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const float av = j == 0 ? af[tm].x : j == 1 ? af[tm].y : af[tm].z;
+                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[j], acc[tm], 0, 0, 0);
+                }
+        }
+    }
+    float* patch = patches + wave * 32 * LDT;
+    const float4 bv = ldg4(p.bias + wn * 32 + (lane & 7) * 4);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + (lane & 31)] = acc[tm][r];
+        __builtin_amdgcn_wave_barrier();
+        const int g = wm * TM + tm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = j * 8 + (lane >> 3);              // pixel within the group: tile row 2 g + row / 16, column row % 16
+            float4 v = *reinterpret_cast<const float4*>(&patch[row * LDT + (lane & 7) * 4]);
+            v.x = fmaxf(v.x + bv.x, 0.f); v.y = fmaxf(v.y + bv.y, 0.f); v.z = fmaxf(v.z + bv.z, 0.f); v.w = fmaxf(v.w + bv.w, 0.f);
+            const long long pix = ((long long)n * p.H + y0 + 2 * g + (row >> 4)) * p.W + x0 + (row & 15);
+            *reinterpret_cast<float4*>(p.y + pix * BN + wn * 32 + (lane & 7) * 4) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int g_conv1_tiled = 1;       // 0: the LDS-DMA gather kernel (A/B, tests)
 // x4: [N,H,W,4] (b, g, r, 0); w48: [48][64] = taps 0..8 x 4 channels, rows 36..47 zero; y = relu(conv + bias), [N,H,W,64]
 bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, hipStream_t s)
 {
     if (Cout != 64 || !bias || !zero16) return false;
     Conv1Args a{x4, w48, bias, y, zero16, N, H, W, (long long)N * H * W};
+    if (g_conv1_tiled && H % 8 == 0 && W % 16 == 0) {
+        g_last_kernel = "conv1_tile_kernel";
+        hipLaunchKernelGGL(conv1_tile_kernel, dim3((unsigned)((long long)N * (H / 8) * (W / 16))), dim3(256), 0, s, a);
+        return true;
+    }
     g_last_kernel = "conv1_glds_kernel";
     hipLaunchKernelGGL(conv1_glds_kernel, dim3((unsigned)((a.M + 127) / 128)), dim3(256), 0, s, a);
     return true;

@@ -611,3 +611,28 @@ def test_bf16_fwd_mode():
     e2 = Engine(20); e2.set_params(P)
     np.testing.assert_array_equal(a, e2.predict(img, argmax=False))
     e.close(); e2.close()
+
+
+def test_conv1_1_tile_kernel_is_bit_identical_to_the_gather_kernel():
+    """conv1_1 forward: the spatial-tile kernel (halo tile in LDS, MFMA fragments read straight from it) performs the same products in the
+    same order as the LDS-DMA gather kernel -- identical bits -- on image sizes with partial edge handling in every direction."""
+    from fcn8s_tensorflow_amd.engine import Engine
+    P = orc.init_params(20, seed=11, decoder_std_scale=6.0, bias_std=0.05)
+    for n, h, w in ((2, 32, 64), (1, 96, 160)):
+        img, _ = batch(n, h, w, seed=41)
+        outs = []
+        for tiled in (1, 0):
+            e = Engine(20, options={"conv1_tiled": tiled})
+            assert e.get_option("conv1_tiled") == tiled
+            e.set_params(P)
+            e.profile(2); e.profile_reset()
+            e.predict(img)
+            ks = [k for k in e.profile_results() if k.startswith("kernel:")]
+            e.profile(0)
+            assert any("conv1_tile_kernel" in k for k in ks) == bool(tiled) and any("conv1_glds_kernel" in k for k in ks) == (not tiled), ks
+            outs.append(e.activation("conv1_1", (n, h, w, 64)))
+            e.close()
+        np.testing.assert_array_equal(outs[0], outs[1])
+        ref = orc.forward(P, img, keep=True)[1]["conv1_1"]
+        assert rel(outs[0], ref) < 1e-5
+    Engine(20, options={"conv1_tiled": 1}).close()          # leave the process-wide default in place
