@@ -767,6 +767,7 @@ __global__ __launch_bounds__(256, 4) void conv1_glds_kernel(const Conv1Args p)
 // one ds_read_b128 straight from it: lane (pixel p, k-half h) of K-step (kt, kk2) needs the four channels of tap 4 kt + 2 kk2 + h at
 // pixel p, i.e. halo[(py + dy + 1)][(px + dx + 1)] -- 16 consecutive pixels are 256 contiguous bytes, conflict-free.  Same products, same
 // K order and the same epilogue as conv1_glds_kernel, so the results are bit-identical.
+template <int TPB>        // tiles per block, consecutive along x: the kernel (12 KB) is staged once per block
 __global__ __launch_bounds__(256, 4) void conv1_tile_kernel(const Conv1Args p)
 {
     constexpr int TH = 8, TW = 16, BN = 64, BK = 16, NKT = 3, WN = 2, TM = 2, HW_ = TW + 2, HH_ = TH + 2;
@@ -776,12 +777,18 @@ __global__ __launch_bounds__(256, 4) void conv1_tile_kernel(const Conv1Args p)
     __shared__ __attribute__((aligned(16))) float patches[4 * 32 * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int tiles_x = p.W / TW, tiles_y = p.H / TH;
+    const int tiles_x = p.W / TW / TPB, tiles_y = p.H / TH;
     const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, n = blockIdx.x / (tiles_x * tiles_y);
-    const int y0 = by * TH, x0 = bx * TW;
+    const int y0 = by * TH;
     // B: 48 x 64 floats = 768 float4, three per thread
 #pragma unroll
     for (int i = 0; i < 3; ++i) reinterpret_cast<float4*>(sB)[tid + i * 256] = ldg4(p.w48 + (tid + i * 256) * 4);
+    const float4 bv = ldg4(p.bias + wn * 32 + (lane & 7) * 4);
+    float* patch = patches + wave * 32 * LDT;
+#pragma unroll 1
+  for (int it = 0; it < TPB; ++it) {
+    const int x0 = (bx * TPB + it) * TW;
+    if (it) __syncthreads();                               // every wave is done with the previous halo tile
     if (tid < HH_ * HW_) {
         const int hy = tid / HW_, hx = tid - hy * HW_, yy = y0 + hy - 1, xx = x0 + hx - 1;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -823,8 +830,6 @@ __global__ __launch_bounds__(256, 4) void conv1_tile_kernel(const Conv1Args p)
                 }
         }
     }
-    float* patch = patches + wave * 32 * LDT;
-    const float4 bv = ldg4(p.bias + wn * 32 + (lane & 7) * 4);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -841,6 +846,7 @@ __global__ __launch_bounds__(256, 4) void conv1_tile_kernel(const Conv1Args p)
         }
         __builtin_amdgcn_wave_barrier();
     }
+  }
 }
 
 int g_conv1_tiled = 1;       // 0: the LDS-DMA gather kernel (A/B, tests)
@@ -851,7 +857,10 @@ bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, floa
     Conv1Args a{x4, w48, bias, y, zero16, N, H, W, (long long)N * H * W};
     if (g_conv1_tiled && H % 8 == 0 && W % 16 == 0) {
         g_last_kernel = "conv1_tile_kernel";
-        hipLaunchKernelGGL(conv1_tile_kernel, dim3((unsigned)((long long)N * (H / 8) * (W / 16))), dim3(256), 0, s, a);
+        const long long tiles = (long long)N * (H / 8) * (W / 16);
+        // (four tiles per block once there are enough of them: the 12 KB kernel is staged once per block -- 0.53 -> 0.46 ms; eight: the same)
+        if (W % 64 == 0 && tiles >= 4 * 4096) hipLaunchKernelGGL(conv1_tile_kernel<4>, dim3((unsigned)(tiles / 4)), dim3(256), 0, s, a);
+        else                                  hipLaunchKernelGGL(conv1_tile_kernel<1>, dim3((unsigned)tiles), dim3(256), 0, s, a);
         return true;
     }
     g_last_kernel = "conv1_glds_kernel";
