@@ -1409,8 +1409,89 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradArgs p
     }
 }
 
+// Round 3: the same gradient on the matrix core.  dW[(tap, ci)][co] = sum over pixels of x[pixel + tap][ci] * dZ[pixel][co] is a
+// (27 -> 32) x 64 product with the pixels as the reduction: rows = (tap, ci), ROW 27 = all ones (its result is the bias gradient), K = two
+// pixels per v_mfma_f32_32x32x2_f32, columns = two tiles of 32 couts.  A block walks 8 x 16 pixel tiles; the 10 x 18 input halo of a tile
+// sits in LDS (as in conv1_tile_kernel) and a lane's A value is one ds_read_b32 of it; the B values come straight from dZ (lanes 0..31: 32
+// consecutive couts of one pixel, lanes 32..63: of the pixel below) -- all 32 loads of a tile are in flight before the halo is staged.
+// Each wave owns two rows of the tile and keeps its 2 x 16 accumulator registers over all tiles of the block; one LDS reduction over the
+// four waves and one set of atomics per block at the end.  8.4 M MFMAs are 0.22 ms of matrix-pipe time: the kernel is bound by reading dZ.
+__global__ __launch_bounds__(256, 4) void conv1_wgrad_mfma_kernel(const Conv1WgradArgs p, const int tiles_per_block, const long long ntiles)
+{
+    constexpr int TH = 8, TW = 16, HW_ = TW + 2, HH_ = TH + 2;
+    __shared__ __attribute__((aligned(16))) float halo[HH_ * HW_ * 4];
+    __shared__ float red[4 * 32 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = p.W / TW, tiles_y = p.H / TH;
+    const int i = lane & 31, h = lane >> 5;                      // MFMA row (tap, ci) of this lane's A values; which pixel of the K pair
+    const int tap = i < 27 ? i / 3 : 4, ci = i < 27 ? i % 3 : 0, dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const int a_off = ((2 * wave + h + dy + 1) * HW_ + (dx + 1)) * 4 + ci;       // + 4 kp: halo float of pixel (2 wave + h, kp) at this lane's tap
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const long long t0 = (long long)blockIdx.x * tiles_per_block;
+    long long t1 = t0 + tiles_per_block; if (t1 > ntiles) t1 = ntiles;
+    // software pipeline: the dZ values and the halo pixel of tile t + 1 are loaded (into registers) before the MFMAs of tile t are issued
+    float bn[16][2];
+    float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](long long t) {
+        const int bx = (int)(t % tiles_x), by = (int)((t / tiles_x) % tiles_y), n = (int)(t / ((long long)tiles_x * tiles_y));
+        const int y0 = by * TH, x0 = bx * TW;
+        // K pair kp = pixels (2 wave + h, kp); MFMA column i of N-tile t is cout 2 i + t: one 8-byte load per lane and pixel
+        const float2* dzp = reinterpret_cast<const float2*>(p.dZ + (((long long)n * p.H + y0 + 2 * wave + h) * p.W + x0) * 64) + i;
+#pragma unroll
+        for (int kp = 0; kp < 16; ++kp) { const float2 v = dzp[kp * 32]; bn[kp][0] = v.x; bn[kp][1] = v.y; }
+        if (tid < HH_ * HW_) {
+            const int hy = tid / HW_, hx = tid - hy * HW_, yy = y0 + hy - 1, xx = x0 + hx - 1;
+            hv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) hv = p.X4[((long long)n * p.H + yy) * p.W + xx];
+        }
+    };
+    if (t0 < t1) fetch(t0);
+    for (long long t = t0; t < t1; ++t) {
+        float bz[16][2];
+#pragma unroll
+        for (int kp = 0; kp < 16; ++kp) { bz[kp][0] = bn[kp][0]; bz[kp][1] = bn[kp][1]; }
+        __syncthreads();                          // the previous tile's readers are done with the halo
+        if (tid < HH_ * HW_) reinterpret_cast<float4*>(halo)[tid] = hv;
+        __syncthreads();
+        if (t + 1 < t1) fetch(t + 1);
+#pragma unroll
+        for (int kp = 0; kp < 16; ++kp) {
+            float a = halo[a_off + 4 * kp];
+            a = i < 27 ? a : (i == 27 ? 1.f : 0.f);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bz[kp][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bz[kp][1], acc[1], 0, 0, 0);
+        }
+    }
+    // sum over the four waves, then one atomic per element and block
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + 2 * i + t] = acc[t][r];
+    __syncthreads();
+    for (int e = tid; e < 28 * 64; e += 256) {
+        const float sum = red[e] + red[32 * 64 + e] + red[2 * 32 * 64 + e] + red[3 * 32 * 64 + e];
+        if (e < 27 * 64) unsafeAtomicAdd(p.dW + e, sum);                 // dW[tap * 3 + ci][co]
+        else if (p.db) unsafeAtomicAdd(p.db + (e - 27 * 64), sum);
+    }
+}
+
+int g_conv1_wgrad_mfma = 1;       // 0: the VALU kernel above (A/B, tests)
 bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, int N, int H, int W, int Cout, hipStream_t s)
 {
+    if (Cout == 64 && g_conv1_wgrad_mfma && H % 8 == 0 && W % 16 == 0) {
+        Conv1WgradArgs a{(const float4*)X4, dZ, dW, db, N, H, W, 0, 0};
+        const long long ntiles = (long long)N * (H / 8) * (W / 16);
+        long long blocks = ntiles < 1024 ? ntiles : 1024;               // 4 per CU, all resident; measured flat from 1024 to 2048, slower below (0.47 ms at 512)
+        const int tpb = (int)((ntiles + blocks - 1) / blocks);
+        blocks = (ntiles + tpb - 1) / tpb;
+        g_last_kernel = "conv1_wgrad_mfma_kernel";
+        hipLaunchKernelGGL(conv1_wgrad_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, tpb, ntiles);
+        return true;
+    }
     if (Cout != 64 || W % 64) return false;
     Conv1WgradArgs a{(const float4*)X4, dZ, dW, db, N, H, W, (long long)N * H * (W / 64), 0};
     // 512 blocks: every block ends in 1792 atomics on the same addresses, and those serialise (2048 blocks: 0.67 ms, 512: 0.60 ms;

@@ -1511,6 +1511,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
         return fail(nullptr, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown process-wide option '" + k + "'");
     }
     if (k == "conv1_tiled") { fcn8s::g_conv1_tiled = value ? 1 : 0; return FCN8S_OK; }       // process-wide, also reachable through a model
+    if (k == "conv1_wgrad_mfma") { fcn8s::g_conv1_wgrad_mfma = value ? 1 : 0; return FCN8S_OK; }
     int* slot = model_option(m, k);
     if (!slot) return fail(m, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown option '" + k + "'");
     if (k == "winograd_tile" && value != 2 && value != 4 && value != 6) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_tile must be 2, 4 or 6");
@@ -1549,6 +1550,7 @@ int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value)
         return FCN8S_ERR_NOT_FOUND;
     }
     if (k == "conv1_tiled") { *value = fcn8s::g_conv1_tiled; return FCN8S_OK; }
+    if (k == "conv1_wgrad_mfma") { *value = fcn8s::g_conv1_wgrad_mfma; return FCN8S_OK; }
     const int* slot = model_option(const_cast<fcn8s_model*>(m), k);
     if (!slot) return FCN8S_ERR_NOT_FOUND;
     *value = *slot;

@@ -206,6 +206,7 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *   process-wide option (m == NULL), for the op-level entry points below, which have no model:
  *     "op_f32x3"          0    their LDS-DMA GEMMs use the split-bf16 arithmetic of FCN8S_PREC_F32X3
  *     "conv1_tiled"       1    conv1_1 forward on the spatial-tile kernel (halo tile in LDS); 0 = the LDS-DMA gather kernel (bit-identical results)
+ *     "conv1_wgrad_mfma"  1    conv1_1 weight gradient as a (27 -> 32) x 64 MFMA product over pixels; 0 = the VALU kernel
  * Unknown keys return FCN8S_ERR_NOT_FOUND. */
 int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value);
 int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value);

@@ -636,3 +636,28 @@ def test_conv1_1_tile_kernel_is_bit_identical_to_the_gather_kernel():
         ref = orc.forward(P, img, keep=True)[1]["conv1_1"]
         assert rel(outs[0], ref) < 1e-5
     Engine(20, options={"conv1_tiled": 1}).close()          # leave the process-wide default in place
+
+
+def test_conv1_1_weight_gradient_mfma_kernel():
+    """conv1_1's weight and bias gradients: the MFMA kernel ((27 taps x channels + a row of ones) x 64 product over the pixels, halo tile in
+    LDS) against the previous kernels on the same engine state -- same sums in another order, so 2e-5 of the tensor's largest entry --
+    on a size only the generic kernel took before (W % 64 != 0) and on one the VALU kernel took."""
+    from fcn8s_tensorflow_amd.engine import Engine
+    P = orc.init_params(20, seed=12, decoder_std_scale=6.0, bias_std=0.05)
+    for n, h, w in ((2, 32, 64), (1, 96, 160), (3, 32, 96)):
+        img, lab = batch(n, h, w, seed=43)
+        got = []
+        for mfma in (1, 0):
+            e = Engine(20, options={"conv1_wgrad_mfma": mfma})
+            assert e.get_option("conv1_wgrad_mfma") == mfma
+            e.set_params(P)
+            e.profile(2); e.profile_reset()
+            e.forward_backward(img, orc.one_hot(lab, 20), keep_prob=1.0, l2_rate=0.0)
+            ks = [k for k in e.profile_results() if k.startswith("kernel:")]
+            e.profile(0)
+            assert any("conv1_wgrad_mfma_kernel" in k for k in ks) == bool(mfma), ks
+            got.append((e.grad_view("conv1_1/filter").cpu().numpy().copy(), e.grad_view("conv1_1/biases").cpu().numpy().copy()))
+            e.close()
+        for a, b in zip(got[0], got[1]):
+            assert np.abs(b).max() > 0 and rel(a, b) < 2e-5, (n, h, w, rel(a, b))
+    Engine(20, options={"conv1_wgrad_mfma": 1}).close()          # leave the process-wide default in place
