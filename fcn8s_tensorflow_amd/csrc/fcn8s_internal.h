@@ -189,6 +189,7 @@ size_t wino_rbits_words(int tile, int N, int H, int W, int C);
 //  if pidx != nullptr, one byte per pooled element: index 0..3 of the window's first maximum, 4 if that maximum is not > 0)
 void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s, int KS = 3, const unsigned char* pidx = nullptr);   // dy -> dm[P][T][C] = A dY A^T  (tile 6 with pidx: dy is d(pool), routed through the argmax bytes)
 // F(6x6,3x3) data gradient as the adjoint of the forward algorithm: dv[P][T][C] = dM U^T -> dx = overlap-added B dv B^T (+ skip addend, ReLU mask)
+void launch_wino_dgrad_output_dout(const float* dv, const unsigned* rbits_in, float* dm, int N, int H, int W, int C, hipStream_t s);   // ... followed in registers by the previous layer's dM = A dZ A^T (dZ is not written)
 void launch_wino_dgrad_output_sub44(const float* dv, float* dx, int N, int H, int W, int C, hipStream_t s);   // fc6: see winograd.hip
 void launch_wino_dgrad_output(const float* dv, const float* addend, const float* mask, float mask_scale, const unsigned* rbits_in, float* y,
                               int N, int H, int W, int C, hipStream_t s);

@@ -76,6 +76,8 @@ struct fcn8s_model {
     std::set<std::string> rbits_ok;                                       // layers whose forward pass wrote a ReLU bit mask ("rb:<layer>") this step
     std::string fused_v_layer;                                            // layer whose data-gradient input transform already sits in d_wino_v
     std::string dm_layer;                                                 // layer whose dM = A dY A^T sits in d_wino_m, ready for the adjoint data gradient
+    std::string dm_prefilled;                                             // layer whose dM the data gradient of the layer after it has already written into d_wino_m (fused transform)
+    int fuse_dgrad_dout = 1;                                              // option: allow that fusion
     unsigned short* d_wbf16 = nullptr; size_t wbf16_elems = 0;            // bf16 copy of one layer's kernel at a time (K-tile-major or transposed)
     std::map<std::string, unsigned short*> wbf16_cache;                   // ... per layer, valid while frozen
     int bf16_gemm256 = 1;                                                 // bf16_fc mode: 256 x 256 LDS-DMA kernel -- 0 never, 1 when it fills the chip, 2 whenever shapes allow
@@ -250,6 +252,7 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
              unsigned* in_relu_bits_out = nullptr;       // forward, Winograd path: record (x > 0) of the input too (see wino_input_kernel) ...
              const char* in_layer = nullptr;              // ... under this producer's name in rbits_ok
              int lazy_wt = 0;                            // data gradient: `w` is still to be filled from w_fwd (flip + transpose) if the adjoint path is not taken
+             float* dm_out = nullptr; const char* dm_out_layer = nullptr;   // adjoint data gradient: write dM of the producing layer (name) here instead of its dZ into y
              int skip_y = 0; };                          // Winograd path with pool_out: do not write the full-resolution output (only its pool is consumed)            // data gradient: the layer's forward kernel [3,3,Cout_of_this_conv... = Cin here][...] (adjoint Winograd path)
 
 // 3x3 SAME conv through Winograd F(tile x tile, 3x3): filter transform, input transform, (tile+2)^2 batched GEMMs
@@ -361,6 +364,13 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
             ProfScope ps(m, "wino_transform", 0, (double)(9 + P) * 4 * Cin * Cout); launch_wino_filter(6, e.w_fwd, m->d_wino_u, Cout, Cin, 3, s, 1);
         }
         { ProfScope ps(m, "wino_gemm_dgrad", 2.0 * P * T * Cin * Cout, 4.0 * P * (T * (double)(Cin + Cout) + (double)Cin * Cout), layer); launch_igemm(a, P, s); }
+        if (e.dm_out && e.dm_out_layer && e.relu_bits_in && !e.addend && e.mask_scale == 1.f) {
+            // the consumer of this gradient is the previous conv's weight gradient in the Winograd domain: hand it dM, skip dZ
+            ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout / 32 + 2.0 * P * T * Cout));
+            launch_wino_dgrad_output_dout(m->d_wino_v, e.relu_bits_in, e.dm_out, N, H, W, Cout, s);
+            m->dm_prefilled = e.dm_out_layer;
+            return false;
+        }
         { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout * (1.0 + (e.relu_bits_in ? 1.0 / 32 : (e.mask ? 1.0 : 0.0)) + (e.addend ? 1.0 : 0.0)) + (double)P * T * Cout));
           launch_wino_dgrad_output(m->d_wino_v, e.addend, e.mask, e.mask_scale, e.relu_bits_in, y, N, H, W, Cout, s); }
         return false;
@@ -555,6 +565,10 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
                 int N, int H, int W, int Cin, int Cout, int K, float alpha, hipStream_t s, int real_cin = 0,
                 const char* layer = nullptr, bool fuse_dgrad_input = false, const unsigned char* pool_idx = nullptr, int phase = 0)
 {
+    // the data gradient of the layer after this one may have written this layer's dM instead of dz (backward_blocks): dz then holds nothing
+    const bool promised = m && layer && phase != 2 && !m->dm_prefilled.empty() && m->dm_prefilled == layer;
+    if (m && phase != 2) m->dm_prefilled.clear();
+    auto broken_promise = [&]() { fprintf(stderr, "fcn8s: %s was handed dM instead of dZ but does not take the Winograd-domain path\n", layer); abort(); };
     WgradArgs a{}; a.split = split_of(m);
     a.A = x; a.B = dz; a.C = dw;
     a.N = N; a.Pa = H; a.Pb = W; a.P = (long long)N * H * W;
@@ -584,7 +598,10 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             // transform V = B^T dz B is written into d_wino_v by the same kernel that writes dM (one read of dz)
             bool fused = false, dm_ready = false;
             const bool adj_bytes = fuse_dgrad_input && tile == 6 && K == 3 && Cin % 64 == 0 && Cout % 64 == 0;
-            if (phase != 2) {
+            const bool prefilled = promised && phase == 0 && adj_bytes && !pool_idx;      // dM already in d_wino_m (wino_dgrad_output_dout_kernel)
+            if (promised && !prefilled) broken_promise();
+            if (prefilled) dm_ready = true;
+            else if (phase != 2) {
             { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cout * (pool_idx ? 0.3125 : 1.0) + ((fuse_dgrad_input && !adj_bytes) ? 2.0 : 1.0) * NP * T * Cout));
               // pool_idx: dz is d(pool) [N,H/2,W/2,Cout]; the max-pool backward happens inside the transform (the caller checked eligibility)
               // adjoint data gradient (tile 6): it consumes dM itself, no second transform of dz
@@ -595,6 +612,8 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
               } }
             // fc6: the non-fused transform above left dM = A dz A^T in dmbuf; its adjoint data gradient (conv_same) consumes it
             if (K == 7 && tile == 4 && !fused && Cin % 2 == 0 && bt_gemm_ok(Cout, 4 * Cin) && m->u_train.count(std::string(layer) + "#4")) dm_ready = true;
+            }
+            if (phase != 2) {
             m->fused_v_layer = fused ? layer : "";
             m->dm_layer = dm_ready ? layer : "";
             m->dm_ptr = dmbuf;
@@ -612,6 +631,7 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             return;
         }
     }
+    if (promised) broken_promise();
     const bool taps = (K == 3 || K == 7) && alpha == 1.f && !real_cin;
     const bool first = K == 3 && alpha == 1.f && real_cin == 3 && Cin == 4;
     auto run = [&]() {
@@ -1254,6 +1274,14 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
             if (i > 1) {                                                   // ReLU of the previous conv
                 e.mask = xin; e.mask_scale = 1.f;
                 if (m->rbits_ok.count(inname)) e.relu_bits_in = (const unsigned*)A(m, (std::string("rb:") + inname).c_str());
+                // The previous conv takes this gradient only through dM = A dZ A^T (weight gradient in the Winograd domain, adjoint data
+                // gradient): the gather kernel can write dM directly.  Conditions = those of conv_wgrad's adjoint branch for that layer.
+                const int cin_prev = i > 2 ? cw : (b > 1 ? m->widths[b - 2] : 4);
+                const bool prev_first = (b == 1 && i == 2);
+                if (m->fuse_dgrad_dout && e.relu_bits_in && !prev_first && m->defer_level_now == 0 && m->train_mode && m->d_wino_m &&
+                    wino_tile_for(m, h, w) == 6 && cw % 64 == 0 && cin_prev % 64 == 0 && m->acts.count(std::string("wv:") + inname)) {
+                    e.dm_out = m->d_wino_m; e.dm_out_layer = inname;
+                }
             }
             else if (b == 5) e.addend = m->gskip4;                        // d(pool4) also receives the pool4_1x1 path
             else if (b == 4) e.addend = m->gskip3;                        // d(pool3) also receives the pool3_1x1 path
@@ -1493,6 +1521,7 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "winograd_tile") return &m->wino_tile;
     if (key == "winograd_fc6") return &m->wino_fc6;
     if (key == "tconv_gemm") return &m->tconv_gemm;
+    if (key == "fuse_dgrad_dout") return &m->fuse_dgrad_dout;
     if (key == "defer_wgrad") return &m->defer_wgrad;
     if (key == "defer_start_block") return &m->defer_start_block;
     if (key == "defer_tail_cus") return &m->defer_tail_cus;
@@ -1508,6 +1537,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
     if (!m) {
         if (k == "op_f32x3") { g_op_split = value ? 3 : 0; return FCN8S_OK; }
         if (k == "conv1_tiled") { fcn8s::g_conv1_tiled = value ? 1 : 0; return FCN8S_OK; }
+        if (k == "conv1_wgrad_mfma") { fcn8s::g_conv1_wgrad_mfma = value ? 1 : 0; return FCN8S_OK; }
         return fail(nullptr, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown process-wide option '" + k + "'");
     }
     if (k == "conv1_tiled") { fcn8s::g_conv1_tiled = value ? 1 : 0; return FCN8S_OK; }       // process-wide, also reachable through a model
@@ -1547,6 +1577,7 @@ int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value)
     if (!m) {
         if (k == "op_f32x3") { *value = g_op_split == 3; return FCN8S_OK; }
         if (k == "conv1_tiled") { *value = fcn8s::g_conv1_tiled; return FCN8S_OK; }
+        if (k == "conv1_wgrad_mfma") { *value = fcn8s::g_conv1_wgrad_mfma; return FCN8S_OK; }
         return FCN8S_ERR_NOT_FOUND;
     }
     if (k == "conv1_tiled") { *value = fcn8s::g_conv1_tiled; return FCN8S_OK; }

@@ -596,6 +596,110 @@ __global__ __launch_bounds__(256, 2) void wino_dgrad_output_kernel(const VF* __r
         }
 }
 
+// ---- the same gather, followed at once by the NEXT layer's weight-gradient transform ---------------------------------------------
+// Inside a block the data gradient of conv L is the output gradient of conv L-1 at the same resolution and on the same 6x6 tile grid:
+// the 6x6 region a thread has just gathered is exactly the tile whose dM = A dZ A^T the weight gradient (and the adjoint data gradient) of
+// L-1 needs.  This kernel applies the ReLU bits of L-1 to the region and transforms it in registers, so dZ of L-1 is neither written
+// nor read back (2 x 4 N H W C bytes per layer pair): 100 loads + 64 stores per thread instead of (100 + 36) + (36 + 64).
+// The region is transformed row by row (r[oy][:] = dZ[oy][:] A^T takes the place of tt[oy][:]) to stay within the registers of two waves per SIMD.
+template <int VEC>
+__global__ __launch_bounds__(256, 2) void wino_dgrad_output_dout_kernel(const VF* __restrict__ dv, const unsigned* __restrict__ rbits_in,
+                                                                        VF* __restrict__ dm, int N, int H, int W, int C4, long long slab_v, long long slab_m)
+{
+    constexpr int M = 6, A = 8;
+    typedef WinoMat<6, 3> WM;
+    constexpr int RW = (M * M * VEC + 31) / 32;
+    const int th = (H + M - 1) / M, tw = (W + M - 1) / M;
+    const TileIdx ti = tile_index(th, tw, C4, N);
+    if (!ti.ok) return;
+    const long long o = ti.t * C4 + ti.c;
+    unsigned rb[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) rb[j] = rbits_in[o * RW + j];
+    VF tt[M][A];                           // tt[i][b] = sum_a B^T(a, i+1) dV[a][b]   (patch rows 1..6)
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+        VF col[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) col[a] = dv[(a * A + b) * slab_v + o];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            VF s = f4zero();
+#pragma unroll
+            for (int a = 0; a < A; ++a) if (WM::bt(a, i + 1) != 0.f) s = f4fma(WM::bt(a, i + 1), col[a], s);
+            tt[i][b] = s;
+        }
+    }
+    const bool up = ti.ty > 0, down = ti.ty + 1 < th, left = ti.tx > 0, right = ti.tx + 1 < tw;
+    VF nrow[2][M], ncol[2][M], corner[2][2];      // [0] = top / left, [1] = bottom / right
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const bool okr = e == 0 ? up : down, okc = e == 0 ? left : right;
+        const long long orow = o + (e == 0 ? -(long long)tw : (long long)tw) * C4, ocol = o + (e == 0 ? -1 : 1) * (long long)C4;
+        const int pa = e == 0 ? 7 : 0;
+        const float edge = WM::bt(pa, pa);
+        VF r[A], c[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k) { r[k] = okr ? dv[(pa * A + k) * slab_v + orow] : f4zero(); c[k] = okc ? dv[(k * A + pa) * slab_v + ocol] : f4zero(); }
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            VF sr = f4zero(), sc = f4zero();
+#pragma unroll
+            for (int k = 0; k < A; ++k) if (WM::bt(k, j + 1) != 0.f) { sr = f4fma(WM::bt(k, j + 1), r[k], sr); sc = f4fma(WM::bt(k, j + 1), c[k], sc); }
+            _Pragma("unroll") for (int v = 0; v < VEC; ++v) { sr.d[v] *= edge; sc.d[v] *= edge; }
+            nrow[e][j] = sr; ncol[e][j] = sc;
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const bool okf = f == 0 ? left : right;
+            const int pb = f == 0 ? 7 : 0;
+            const long long oc = orow + (f == 0 ? -1 : 1) * (long long)C4;
+            VF v = (okr && okf) ? dv[(pa * A + pb) * slab_v + oc] : f4zero();
+            _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] *= edge * WM::bt(pb, pb);
+            corner[e][f] = v;
+        }
+    }
+    VF r[M][A];                            // r[oy][b] = sum_ox dZ[oy][ox] A^T(ox, b)
+#pragma unroll
+    for (int oy = 0; oy < M; ++oy) {
+        VF z[M];
+#pragma unroll
+        for (int ox = 0; ox < M; ++ox) {
+            VF v = f4zero();
+#pragma unroll
+            for (int b = 0; b < A; ++b) if (WM::bt(b, ox + 1) != 0.f) v = f4fma(WM::bt(b, ox + 1), tt[oy][b], v);
+            if (oy == 0)     { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += nrow[0][ox].d[k]; }
+            if (oy == M - 1) { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += nrow[1][ox].d[k]; }
+            if (ox == 0)     { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += ncol[0][oy].d[k]; }
+            if (ox == M - 1) { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += ncol[1][oy].d[k]; }
+            if ((oy == 0 || oy == M - 1) && (ox == 0 || ox == M - 1)) { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += corner[oy == 0 ? 0 : 1][ox == 0 ? 0 : 1].d[k]; }
+            const bool inside = M * ti.ty + oy < H && M * ti.tx + ox < W;              // partial edge tiles
+            _Pragma("unroll") for (int k = 0; k < VEC; ++k) {
+                const int bit = (oy * M + ox) * VEC + k;
+                v.d[k] = (inside && ((rb[bit >> 5] >> (bit & 31)) & 1u)) ? v.d[k] : 0.f;
+            }
+            z[ox] = v;
+        }
+#pragma unroll
+        for (int b = 0; b < A; ++b) {
+            VF s = f4zero();
+#pragma unroll
+            for (int k = 0; k < M; ++k) if (WM::at(k, b) != 0.f) s = f4fma(WM::at(k, b), z[k], s);
+            r[oy][b] = s;
+        }
+    }
+    VF* dp = dm + o;
+#pragma unroll
+    for (int b = 0; b < A; ++b)
+#pragma unroll
+        for (int a = 0; a < A; ++a) {          // dM[a][b] = sum_oy A^T(oy, a) r[oy][b]
+            VF s = f4zero();
+#pragma unroll
+            for (int k = 0; k < M; ++k) if (WM::at(k, a) != 0.f) s = f4fma(WM::at(k, a), r[k][b], s);
+            dp[(a * A + b) * slab_m] = s;
+        }
+}
+
 // ---- dg_sub = G^T dU_sub G, scattered back to the taps (3a+i, 3b+j) < KS of the KS x KS filter gradient -----------------
 template <int M, int R>
 __global__ void wino_dfilter_kernel(const float* du, float* dw, int Cin, int Cout, int KS, int nsub)
@@ -740,6 +844,15 @@ void launch_wino_dgrad_output(const float* dv, const float* addend, const float*
                        (const VecF<2>*)dv, (const VecF<2>*)addend, (const VecF<2>*)mask, mask_scale, rbits_in, (VecF<2>*)y, N, H, W, C / 2, wino_slab(T, C) / 2);
 }
 // dv: [49][T][4 * C] (T = N * H/4 * W/4 tiles, columns = sub-filter x channel), dx: [N,H,W,C]; H, W % 4 == 0, C % 2 == 0
+void launch_wino_dgrad_output_dout(const float* dv, const unsigned* rbits_in, float* dm, int N, int H, int W, int C, hipStream_t s)
+{
+    constexpr int M_ = 6;
+    const long long T = (long long)N * ((H + M_ - 1) / M_) * ((W + M_ - 1) / M_);
+    g_last_kernel = "wino_dgrad_output_dout_kernel<2>";
+    hipLaunchKernelGGL((wino_dgrad_output_dout_kernel<2>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / 2), dim3(256), 0, s,
+                       (const VecF<2>*)dv, rbits_in, (VecF<2>*)dm, N, H, W, C / 2, wino_slab(T, C) / 2, wino_slab(T, C) / 2);
+}
+
 void launch_wino_dgrad_output_sub44(const float* dv, float* dx, int N, int H, int W, int C, hipStream_t s)
 {
     const long long T = (long long)N * (H / 4) * (W / 4);

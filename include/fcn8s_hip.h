@@ -201,6 +201,8 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *     "defer_start_block" 2    the VGG block at whose backward pass the held-back GEMMs are launched
  *     "defer_tail_cus"    0    > 0: from that block on the data-gradient chain runs on a stream restricted to the first n CUs and the held-back
  *                              GEMMs on the remaining 256 - n (hipExtStreamCreateWithCUMask); 0: both share all CUs
+ *     "fuse_dgrad_dout"   1    inside a VGG block the gather kernel of a conv's data gradient writes dM = A dZ A^T of the previous conv directly
+ *                              (that conv's weight gradient and adjoint data gradient consume only dM): its dZ is never written; 0 = two kernels
  *     "bf16_gemm256"      1    FCN8S_PREC_BF16_FC: fc6 / fc7 forward on the 256 x 256 LDS-DMA kernel -- 0 never, 1 when the launch has at least
  *                              128 tiles (training batches), 2 whenever the shapes allow (rows and Cout multiples of 256)
  *   process-wide option (m == NULL), for the op-level entry points below, which have no model:

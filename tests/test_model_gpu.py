@@ -661,3 +661,30 @@ def test_conv1_1_weight_gradient_mfma_kernel():
         for a, b in zip(got[0], got[1]):
             assert np.abs(b).max() > 0 and rel(a, b) < 2e-5, (n, h, w, rel(a, b))
     Engine(20, options={"conv1_wgrad_mfma": 1}).close()          # leave the process-wide default in place
+
+
+@pytest.mark.parametrize("widths,n,h,w,expect", [(None, 2, 32, 64, None), (None, 1, 96, 160, True), ((64, 192, 192, 64, 64, 128, 192), 1, 96, 160, True),
+                                                   (SMALL, 2, 64, 224, None), (SMALL, 1, 192, 192, None)])
+def test_fused_dgrad_output_and_next_dout_transform(widths, n, h, w, expect):
+    """Inside a block the gather kernel of a conv's data gradient hands the previous conv dM = A dZ A^T directly (dZ is never written).
+    Same gradients as the two-kernel form (another summation order inside the tile transform: 2e-5 of each tensor's largest entry), and the
+    fused kernel really runs where the conditions hold (channels % 64 == 0 on both sides, F(6x6)) -- 96x160 has partial edge tiles."""
+    from fcn8s_tensorflow_amd.engine import Engine
+    P, img, lab = case(widths, n, h, w, seed=5)
+    got, ran = [], []
+    for fuse in (1, 0):
+        e = Engine(20, widths=widths, options={"fuse_dgrad_dout": fuse})
+        e.set_params(P)
+        e.profile(2); e.profile_reset()
+        loss = e.forward_backward(img, orc.one_hot(lab, 20), keep_prob=1.0, l2_rate=1e-3)
+        ks = [k for k in e.profile_results() if k.startswith("kernel:")]
+        e.profile(0)
+        ran.append(any("wino_dgrad_output_dout_kernel" in k for k in ks))
+        got.append((loss, e.get_grads()))
+        e.close()
+    assert not ran[1]
+    if expect is not None:              # (small maps pick F(4x4) / F(2x2) tiles, narrow layers the direct kernels: nothing to fuse there)
+        assert ran[0] == expect, ran
+    assert got[0][0] == got[1][0]
+    for k in got[1][1]:
+        assert rel(got[0][1][k], got[1][1][k]) < 2e-5, (k, rel(got[0][1][k], got[1][1][k]))
