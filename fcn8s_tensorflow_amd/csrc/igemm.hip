@@ -449,7 +449,18 @@ static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p)
     static_assert(S * STAGE >= 4 * 32 * 36, "epilogue patches");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    // At most 32 rows in a 64-row tile (fc6 at batch 1: 32 Winograd tiles per position, a 1.6 GB filter bank to stream): the waves of the
+    // lower half would multiply padding only.  They skip their MFMAs (they still load and synchronise), and which two waves -- i.e. which
+    // two SIMDs -- do the work alternates between the blocks that share a CU (256 apart in dispatch order: 8 XCDs x 32 CUs round-robin).
+    int cwave = wave;
+    bool idle = false;
+    if constexpr (BM == 64 && WM == 2 && WN == 2) {
+        if (p.M <= 32) {
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      // dispatch order
+            cwave = wave ^ (int)(((lin >> 8) & 1u) << 1); idle = cwave >= 2;
+        }
+    }
+    const int wm = cwave / WN, wn = cwave % WN;
     const int pz = blockIdx.z;
     const float* __restrict__ Wp = p.w + (long long)pz * p.w_phase_stride;
     const float* __restrict__ X = p.batched ? p.x + (long long)pz * p.x_batch_stride : p.x;
@@ -522,6 +533,7 @@ static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p)
         bt_sw[tn] = (row >> 2) & 3;
     }
     auto compute = [&](int stage) {
+        if (idle) return;
         const float* sa = smem + stage * STAGE;
         const float* sb = sa + BM * BK;
         if constexpr (NSPLIT == 3) {                   // one K = 16 step of the bf16 MFMA per K-tile: lane half h holds k = 8h .. 8h + 7
