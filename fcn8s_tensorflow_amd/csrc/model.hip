@@ -973,7 +973,9 @@ bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const c
 // What the backward pass of a Winograd layer expects from the forward pass when the forward convolution itself did not run through
 // Winograd (the bf16 modes): the transformed input V (kept for the weight gradient in the Winograd domain) and, for the adjoint data
 // gradient, the forward filter bank of THIS step's weights (a bank left over from an earlier step would be silently wrong).
-void wino_backward_operands(fcn8s_model* m, const char* layer, const float* x, const float* wk, int N, int H, int W, int Cin, int Cout, int KS, hipStream_t s)
+// in_rbits_out / in_layer: the input is the ReLU output of conv `in_layer`, whose (x > 0) record the transform writes on the way (wino_input_kernel)
+void wino_backward_operands(fcn8s_model* m, const char* layer, const float* x, const float* wk, int N, int H, int W, int Cin, int Cout, int KS, hipStream_t s,
+                            unsigned* in_rbits_out = nullptr, const char* in_layer = nullptr)
 {
     const int tile = wino_tile_for(m, H, W, KS);
     if (!tile) return;
@@ -982,7 +984,8 @@ void wino_backward_operands(fcn8s_model* m, const char* layer, const float* x, c
     const int P = wino_alpha(tile, KS) * wino_alpha(tile, KS), nsub2 = wino_nsub(KS) * wino_nsub(KS), Kg = nsub2 * Cin;
     const long long T = wino_tiles(tile, N, H, W);
     { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg));
-      launch_wino_input(tile, x, it->second.p, N, H, W, Cin, KS, s); }
+      launch_wino_input(tile, x, it->second.p, N, H, W, Cin, KS, s, KS == 3 ? in_rbits_out : nullptr);
+      if (in_rbits_out && in_layer && KS == 3) m->rbits_ok.insert(in_layer); }
     const std::string key = std::string(layer) + "#" + std::to_string(tile);
     if ((KS == 3 && tile == 6) || (KS == 7 && tile == 4)) {
         float*& tu = m->u_train[key];
@@ -1051,7 +1054,16 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 // stays in the Winograd domain, so the transformed input and this step's filter bank are made here
                 done = bf16_conv_layer(m, "conv3x3_fwd_bf16", (std::string(nm) + "/filter").c_str(), (std::string(nm) + "/biases").c_str(), x, A(m, nm),
                                        N, h, w, cin, m->widths[b], 3, 0, 1.f, 0, s, /*allow_small=*/false);
-                if (done && train) wino_backward_operands(m, nm, x, wt, N, h, w, cin, m->widths[b], 3, s);
+                if (done && train) {
+                    // the previous conv of the block came from the bf16 kernel too (no ReLU record): this transform of its output writes one
+                    unsigned* irb = nullptr; char prev[32] = "";
+                    if (i > 1) {
+                        snprintf(prev, sizeof prev, "conv%d_%d", b + 1, i - 1);
+                        auto it = m->acts.find(std::string("rb:") + prev);
+                        if (it != m->acts.end() && !m->rbits_ok.count(prev)) irb = (unsigned*)it->second.p;
+                    }
+                    wino_backward_operands(m, nm, x, wt, N, h, w, cin, m->widths[b], 3, s, irb, irb ? prev : nullptr);
+                }
             }
             if (!done) pooled = conv_same(m, first ? "conv1_1_fwd" : "conv3x3_fwd", x, wt, A(m, nm), N, h, w, cin, m->widths[b], 3, e, s, first ? 3 : 0, nm);
             x = A(m, nm); cin = m->widths[b];
