@@ -959,20 +959,28 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
 
 void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s)
 {
-    // largest tile that still yields about one block per CU (small batches / deep layers have few pixels:
-    // 1024x512 bs1 gives conv5 only 2048 pixels = 64 tiles of 128x128 on 256 CUs)
-    auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn) * phases; };
-    constexpr long long minb = 200;
+    // Tile choice.  With many blocks per CU the 128 x 128 tile wins (most MFMAs per LDS byte).  Small batches / deep layers have few row
+    // tiles (1024x512 at batch 1: conv3_x 946 Winograd tiles per position, conv5_x 128), and then what matters is how the blocks fall onto the
+    // 256 CUs: n = blocks per CU, of which `bpc` are resident at a time; a last, partial group of co-resident blocks runs below the CU's
+    // rate (one 4-wave block alone reaches less than half of it).  cost = (full groups + penalised remainder) x tile area / tile efficiency,
+    // fitted to batch-1 measurements (conv3_2: 0.094 / 0.078 / 0.076 ms for 128x128 / 64x128 / 64x64, conv4_2: 0.075 / 0.074 / 0.079,
+    // conv5_x: - / 0.039 / 0.032); at training sizes (n >= 9) it keeps 128 x 128 everywhere.
+    auto cost = [&](int bm, int bn, int bpc, double eff) {
+        const long long blocks = ((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn) * phases;
+        const long long n = (blocks + 255) / 256, rem = n % bpc;
+        const double tail = rem == 0 ? 0.0 : (rem == 1 ? 2.0 : (rem == 2 ? 2.4 : 3.0));
+        return ((double)(n / bpc) * bpc + tail) * bm * bn / eff;
+    };
     if (a.Cout <= 32)      launch_igemm_cfg<128, 32, 4, 1>(a, phases, s);
     else if (a.Cout <= 64) {
-        if (blocks(128, 64) >= minb) launch_igemm_cfg<128, 64, 2, 2>(a, phases, s);
-        else                        launch_igemm_cfg<64, 64, 2, 2>(a, phases, s);
+        if (cost(128, 64, 4, 1.0) <= cost(64, 64, 4, 0.9)) launch_igemm_cfg<128, 64, 2, 2>(a, phases, s);
+        else                                               launch_igemm_cfg<64, 64, 2, 2>(a, phases, s);
     } else {
-        // (at most 64 rows -- fc6 at batch 1 has 32 tiles per Winograd position: a 128-row tile would spend 3/4 of its MFMAs on padding)
-        if (a.M <= 64 && blocks(64, 128) >= minb) launch_igemm_cfg<64, 128, 2, 2>(a, phases, s);
-        else if (blocks(128, 128) >= minb) launch_igemm_cfg<128, 128, 2, 2>(a, phases, s);   // (K-tile depth 32 and 256x64 tiles measured slower: fewer resident waves)
-        else if (blocks(64, 128) >= minb) launch_igemm_cfg<64, 128, 2, 2>(a, phases, s);
-        else                             launch_igemm_cfg<64, 64, 2, 2>(a, phases, s);
+        const double c128 = cost(128, 128, 3, 1.0), c64x128 = cost(64, 128, 4, 0.9), c64 = cost(64, 64, 4, 0.85);
+        // (at most 32 rows -- fc6 at batch 1 -- the 64-row kernels idle the waves of the padded half, see gemm_glds_body)
+        if (a.M > 64 && c128 <= c64x128 && c128 <= c64) launch_igemm_cfg<128, 128, 2, 2>(a, phases, s);   // (K-tile depth 32 and 256x64 tiles measured slower: fewer resident waves)
+        else if (c64x128 <= c64)                        launch_igemm_cfg<64, 128, 2, 2>(a, phases, s);
+        else                                            launch_igemm_cfg<64, 64, 2, 2>(a, phases, s);
     }
 }
 
