@@ -624,28 +624,13 @@ static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p)
         __builtin_amdgcn_s_barrier();            // every wave is done reading the last stage
         constexpr int LDT = 36;
         float* patch = smem + wave * 32 * LDT;
-        // mask epilogue (fc7's data gradient: ReLU + dropout of fc6): the 4 mask vectors of a 32x32 patch are requested one patch ahead --
-        // loaded at their point of use they cost one exposed HBM latency each, 64 per block (fc7_dgrad: 2.46 ms against 2.0 for the forward GEMM)
-        float4 mkq[2][4];
-        auto load_masks = [&](int tm, int tn, float4* mk) {
-            const long long mrow = m0 + wm * TM * 32 + tm * 32;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = j * 8 + (lane >> 3);
-                mk[j] = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (mrow + row < p.M) mk[j] = ldg4(p.mask + (mrow + row) * p.ldy + n0 + wn * TN * 32 + tn * 32 + (lane & 7) * 4);
-            }
-        };
-        if (p.mask) load_masks(0, 0, mkq[0]);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
-                const int pi = tn * TM + tm;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + (lane & 31)] = acc[tm][tn][r];
                 __builtin_amdgcn_wave_barrier();
-                if (p.mask && pi + 1 < TM * TN) load_masks((pi + 1) % TM, (pi + 1) / TM, mkq[(pi + 1) & 1]);
                 const long long mrow = m0 + wm * TM * 32 + tm * 32;
                 float* yb = Y + n0 + wn * TN * 32 + tn * 32 + (lane & 7) * 4;
                 const float4 bv = p.bias ? ldg4(p.bias + n0 + wn * TN * 32 + tn * 32 + (lane & 7) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -656,7 +641,7 @@ static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p)
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;           // (the epilogue ops this path knows: a per-column bias, or a ReLU/dropout mask)
                     if (mrow + row < p.M) {
                         if (p.mask) {
-                            const float4 mk = mkq[pi & 1][j];
+                            const float4 mk = ldg4(p.mask + (mrow + row) * p.ldy + n0 + wn * TN * 32 + tn * 32 + (lane & 7) * 4);
                             v.x = mk.x > 0.f ? v.x * p.mask_scale : 0.f; v.y = mk.y > 0.f ? v.y * p.mask_scale : 0.f;
                             v.z = mk.z > 0.f ? v.z * p.mask_scale : 0.f; v.w = mk.w > 0.f ? v.w * p.mask_scale : 0.f;
                         }
