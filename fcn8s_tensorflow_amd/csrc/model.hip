@@ -1014,7 +1014,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
         }
     }
     const bool fill_fp = m->frozen && m->u_cache.empty();
-    prepare_forward_weights(m);
+    if (!m->frozen || fill_fp) prepare_forward_weights(m);        // frozen and the kept banks still valid: so are the padded / phase-packed kernels
     m->fwd_train = train;
     m->rbits_ok.clear();
     { ProfScope ps(m, "preprocess", 0, (double)N * H * W * (16 + (dtype ? 12 : 3))); launch_preprocess(img_dev, dtype, A(m, "x0"), (long long)N * H * W, s); }
