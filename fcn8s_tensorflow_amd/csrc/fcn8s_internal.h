@@ -147,7 +147,8 @@ void launch_onehot_to_ids(const void* oh, int elem_bytes, long long npix, int C,
 void launch_confusion(const uint8_t* labels, const long long* pred, long long npix,
                       unsigned long long* conf, int C, hipStream_t s);
 // skinny.hip: 1x1 convs with <= 32 output (forward, weight gradient) or input (data gradient) channels; false = shape not covered
-bool launch_head_fwd(const float* x, const float* w, const float* bias, float* y, long long M, int K, int C, float alpha, hipStream_t s);
+bool launch_head_fwd(const float* x, const float* w, const float* bias, float* y, long long M, int K, int C, float alpha, hipStream_t s,
+                     float* scratch = nullptr, size_t scratch_floats = 0);      // scratch: lets a launch with few row blocks split K over more blocks (two-pass sum)
 bool launch_head_dgrad(const float* dy, const float* wt, const float* mask, float mask_scale, float* dx, long long M, int K, int C, float alpha,
                        hipStream_t s);
 bool launch_head_wgrad(const float* x, const float* dy, float* dw, long long M, int K, int C, float alpha, hipStream_t s);

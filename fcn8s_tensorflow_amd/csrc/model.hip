@@ -436,7 +436,7 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
     // 1x1 score heads: one skinny dimension (skinny.hip); everything else goes through the general tile kernels
     auto run = [&]() {
         if (K == 1 && !real_cin && !e.addend && !e.relu && !e.dropout) {
-            if (Cout <= 32 && !e.mask && launch_head_fwd(x, w, e.bias, y, a.M, Cin, Cout, e.alpha, s)) return;
+            if (Cout <= 32 && !e.mask && launch_head_fwd(x, w, e.bias, y, a.M, Cin, Cout, e.alpha, s, m ? m->d_wino_u : nullptr, m ? m->ufl : 0)) return;      // (the filter-bank scratch is idle between convolutions)
             if (Cin <= 32 && !e.bias && launch_head_dgrad(x, w, e.mask, e.mask_scale, y, a.M, Cout, Cin, e.alpha, s)) return;
         }
         launch_igemm(a, 1, s);

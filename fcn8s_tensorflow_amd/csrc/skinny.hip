@@ -18,8 +18,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // flight while the current one is multiplied (two register stages).
 template <int NW, int C>
 __global__ __launch_bounds__(NW * 64) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                          float* __restrict__ y, long long M, int K, float alpha)
+                                                          float* __restrict__ y, long long M, int K, float alpha, float* __restrict__ part)
 {
+    // part (few rows, long K -- fc7's head at batch 1: 16 row blocks on 256 CUs): gridDim.y blocks split K once more; each writes its
+    // alpha-scaled partial sums to part[blockIdx.y][M][C], head_fwd_reduce_kernel adds them in a fixed order and the bias
     __shared__ float red[NW][16 * 2 * 20 + 16 * 2 * 12 * (NW <= 8)];      // [wave][i][h][col]: 32 columns for <= 8 waves, 20 (C <= 20) for 16
     constexpr int RC = NW <= 8 ? 32 : 20;
     __shared__ __attribute__((aligned(16))) float outt[32 * 32];
@@ -28,9 +30,9 @@ __global__ __launch_bounds__(NW * 64) void head_fwd_kernel(const float* __restri
     const long long row0 = (long long)blockIdx.x * 32;
     long long row = row0 + r;
     if (row >= M) row = M - 1;                                  // rows / columns past the edge compute garbage that is never stored
-    const int ks = K / NW;
-    const float* xp = x + row * K + wave * ks + 4 * h;
-    const float* wp = w + (long long)(wave * ks + 4 * h) * C + (r < C ? r : C - 1);
+    const int Kb = K / (int)gridDim.y, k0 = (int)blockIdx.y * Kb, ks = Kb / NW;
+    const float* xp = x + row * K + k0 + wave * ks + 4 * h;
+    const float* wp = w + (long long)(k0 + wave * ks + 4 * h) * C + (r < C ? r : C - 1);
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto load = [&](int kk, float4 (&a)[4], float (&b)[4][4]) {
 #pragma unroll
@@ -82,12 +84,12 @@ __global__ __launch_bounds__(NW * 64) void head_fwd_kernel(const float* __restri
         const int ih = idx / RC, ocol = idx - ih * RC;
         const int i = ih >> 1, hh = ih & 1;
         const int orow = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        if (ocol < C) outt[orow * C + ocol] = s * alpha + (bias ? bias[ocol] : 0.f);
+        if (ocol < C) outt[orow * C + ocol] = s * alpha + ((bias && !part) ? bias[ocol] : 0.f);
     }
     __syncthreads();
     const long long left = M - row0;
     const int n4 = (int)(left < 32 ? left : 32) * C / 4;        // the block's 32 rows x C floats are contiguous in y
-    float4* dst = reinterpret_cast<float4*>(y + row0 * C);
+    float4* dst = reinterpret_cast<float4*>((part ? part + (long long)blockIdx.y * M * C : y) + row0 * C);
     for (int idx = tid; idx < n4; idx += NW * 64) dst[idx] = reinterpret_cast<const float4*>(outt)[idx];
 }
 
@@ -218,21 +220,36 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
     }
 }
 
+__global__ __launch_bounds__(256) void head_fwd_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y, long long n, int C, int splits)
+{
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= n) return;
+    float s = part[i];
+    for (int k = 1; k < splits; ++k) s += part[(long long)k * n + i];
+    y[i] = s + (bias ? bias[i % C] : 0.f);
+}
 template <int C>
-static bool launch_head_fwd_c(const float* x, const float* w, const float* bias, float* y, long long M, int K, float alpha, hipStream_t s)
+static bool launch_head_fwd_c(const float* x, const float* w, const float* bias, float* y, long long M, int K, float alpha, hipStream_t s, float* scratch, size_t scratch_floats)
 {
     const unsigned blocks = (unsigned)((M + 31) / 32);
-    if (K >= 2048 && K % 128 == 0) hipLaunchKernelGGL((head_fwd_kernel<16, C>), dim3(blocks), dim3(1024), 0, s, x, w, bias, y, M, K, alpha);
-    else if (K >= 2048 && K % 64 == 0) hipLaunchKernelGGL((head_fwd_kernel<8, C>), dim3(blocks), dim3(512), 0, s, x, w, bias, y, M, K, alpha);
-    else if (K % 32 == 0) hipLaunchKernelGGL((head_fwd_kernel<4, C>), dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, K, alpha);
+    // few row blocks and a long reduction: split K over 8 blocks as well (deterministic two-pass sum)
+    constexpr int SPLITS = 8;
+    if (blocks <= 64 && K % (SPLITS * 16 * 32) == 0 && scratch && scratch_floats >= (size_t)SPLITS * M * C && (M * C) % 4 == 0) {
+        hipLaunchKernelGGL((head_fwd_kernel<16, C>), dim3(blocks, SPLITS), dim3(1024), 0, s, x, w, bias, y, M, K, alpha, scratch);
+        hipLaunchKernelGGL(head_fwd_reduce_kernel, dim3((unsigned)((M * C + 255) / 256)), dim3(256), 0, s, scratch, bias, y, M * C, C, SPLITS);
+        return true;
+    }
+    if (K >= 2048 && K % 128 == 0) hipLaunchKernelGGL((head_fwd_kernel<16, C>), dim3(blocks), dim3(1024), 0, s, x, w, bias, y, M, K, alpha, (float*)nullptr);
+    else if (K >= 2048 && K % 64 == 0) hipLaunchKernelGGL((head_fwd_kernel<8, C>), dim3(blocks), dim3(512), 0, s, x, w, bias, y, M, K, alpha, (float*)nullptr);
+    else if (K % 32 == 0) hipLaunchKernelGGL((head_fwd_kernel<4, C>), dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, K, alpha, (float*)nullptr);
     else return false;
     return true;
 }
-bool launch_head_fwd(const float* x, const float* w, const float* bias, float* y, long long M, int K, int C, float alpha, hipStream_t s)
+bool launch_head_fwd(const float* x, const float* w, const float* bias, float* y, long long M, int K, int C, float alpha, hipStream_t s, float* scratch, size_t scratch_floats)
 {
     if (M < 1) return false;
-    if (C == 20) return launch_head_fwd_c<20>(x, w, bias, y, M, K, alpha, s);
-    if (C == 4) return launch_head_fwd_c<4>(x, w, bias, y, M, K, alpha, s);
+    if (C == 20) return launch_head_fwd_c<20>(x, w, bias, y, M, K, alpha, s, scratch, scratch_floats);
+    if (C == 4) return launch_head_fwd_c<4>(x, w, bias, y, M, K, alpha, s, scratch, scratch_floats);
     return false;
 }
 
