@@ -133,6 +133,41 @@ __global__ void maxpool_route_kernel(const float* x, unsigned char* r, int N, in
         r[i] = oa != 0.f ? 0 : ob != 0.f ? 1 : oc != 0.f ? 2 : od != 0.f ? 3 : 4;
     }
 }
+// forward max-pool that also keeps the routing bytes (same rule, same layout as the Winograd output transform's argmax bytes): the backward
+// pass of a block whose last conv did not come from that transform (the bf16 modes) can then route d(pool) inside wino_dout_kernel too
+__global__ void maxpool_fwd_route_kernel(const float4* x, float4* y, unsigned* r, int N, int H, int W, int C4)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)N * Ho * Wo * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long t = i / C4;
+        const int w = (int)(t % Wo); t /= Wo;
+        const int h = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const long long base = (((long long)n * H + 2 * h) * W + 2 * w) * C4 + c;
+        const float4 a = x[base], b = x[base + C4], cc = x[base + (long long)W * C4], d = x[base + (long long)W * C4 + C4];
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {cc.x, cc.y, cc.z, cc.w}, dv[4] = {d.x, d.y, d.z, d.w};
+        float mv[4]; unsigned word = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned bi = 0; float m = av[k];
+            if (bv[k] > m) { m = bv[k]; bi = 1; }
+            if (cv[k] > m) { m = cv[k]; bi = 2; }
+            if (dv[k] > m) { m = dv[k]; bi = 3; }
+            if (!(m > 0.f)) bi = 4;
+            mv[k] = fmaxf(fmaxf(av[k], bv[k]), fmaxf(cv[k], dv[k]));
+            word |= bi << (8 * k);
+        }
+        y[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
+        r[i] = word;
+    }
+}
+void launch_maxpool_fwd_route(const float* x, float* y, unsigned char* r, int N, int H, int W, int C, hipStream_t s)
+{
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_route_kernel, dim3(cap_blocks(total, 256)), dim3(256), 0, s, (const float4*)x, (float4*)y, (unsigned*)r, N, H, W, C / 4);
+}
 void launch_maxpool_route(const float* x, unsigned char* r, int N, int H, int W, int C, hipStream_t s)
 {
     const long long total = (long long)N * (H / 2) * (W / 2) * C;

@@ -1070,7 +1070,14 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
         }
         snprintf(pn, sizeof pn, "pool%d", b + 1);
         m->pool_fused[b] = pooled && train;
-        if (!pooled) { ProfScope ps(m, "maxpool_fwd", 0, 4.0 * N * h * w * cin * 1.25); launch_maxpool_fwd(x, A(m, pn), N, h, w, cin, s); }
+        if (!pooled) {
+            // a block whose last conv did not run through the Winograd output transform (bf16 modes) but whose backward pass does run in the
+            // Winograd domain: keep the same routing bytes, so that d(pool) is routed inside wino_dout_kernel and dZ is never written
+            const bool route = train && cin % 4 == 0 && pool_backward_fused(m, b + 1, true);
+            ProfScope ps(m, "maxpool_fwd", 0, 4.0 * N * h * w * cin * (route ? 1.3125 : 1.25));
+            if (route) { char ix[16]; snprintf(ix, sizeof ix, "pidx%d", b + 1); launch_maxpool_fwd_route(x, A(m, pn), (unsigned char*)A(m, ix), N, h, w, cin, s); m->pool_fused[b] = true; }
+            else launch_maxpool_fwd(x, A(m, pn), N, h, w, cin, s);
+        }
         x = A(m, pn); h /= 2; w /= 2;
     }
     const int h5 = h, w5 = w;
