@@ -1320,6 +1320,7 @@ int do_backward_bucket(fcn8s_model* m, int bucket, int level_cap)
         m->defer_level_now = m->defer_wgrad >= 3 ? 2 : std::min(m->defer_wgrad, level_cap);      // 3: the caller does not consume bucket 0 early
         if (m->profile && m->profile_detail) m->defer_level_now = 0;      // per-layer timing wants one kernel at a time
         m->deferred.clear(); m->ev_next = 0;
+        m->dm_prefilled.clear();                                           // (a promise left over from a backward pass that ended in an error)
         m->on_tail = false; m->launch_stream = nullptr;                    // (a backward pass that ended in an error may have left them set)
         backward_bucket0(m);
     }
