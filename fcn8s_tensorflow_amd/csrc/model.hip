@@ -69,6 +69,7 @@ struct fcn8s_model {
     // fcn8s_freeze_params: the caller promises constant parameters; Winograd-transformed filters are then kept per layer
     bool frozen = false;
     unsigned long long frozen_fp = 0; unsigned long long* d_fp = nullptr;   // fingerprint of the parameter buffer the cached banks were built from
+    unsigned long long* h_fp = nullptr; hipEvent_t fp_event = nullptr;      // pinned landing place of the guard's fingerprint, and the event behind its copy
     std::map<std::string, float*> u_cache;                               // layer -> transformed filter bank (hipMalloc'ed), valid while frozen
     std::map<std::string, float*> u_train;                               // layer -> forward filter bank of the current training step: the adjoint data
                                                                          // gradient reads it as a transposed B operand (no second, transposed bank)
@@ -997,20 +998,33 @@ void wino_backward_operands(fcn8s_model* m, const char* layer, const float* x, c
 
 int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, bool train)
 {
+    auto drop_banks = [&]() {
+        hipStreamSynchronize(m->stream);
+        for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
+        m->u_cache.clear();
+        for (auto& kv : m->wbf16_cache) if (kv.second) hipFree(kv.second);
+        m->wbf16_cache.clear();
+    };
     hipStream_t s = m->stream;
     const int N = m->N, H = m->H, W = m->W, C = m->C;
+    bool guard_pending = false;
     if (m->frozen && !m->u_cache.empty()) {
         // the caller promised constant parameters; a cheap strided fingerprint catches the promise being broken through a side
-        // door (a torch optimizer or copy_ over views of ext_params): the cached filter banks are then rebuilt instead of reused
+        // door (a torch optimizer or copy_ over views of ext_params): the cached filter banks are then rebuilt instead of reused.
+        // The check does not hold the pass up: the fingerprint is taken first on the stream, the pass is enqueued behind it with the kept
+        // banks, and the host compares when the (long finished) copy is looked at -- at the end of this function; a mismatch repeats the pass.
         launch_fingerprint(m->d_params, (long long)m->total, m->d_fp, s);
-        unsigned long long fp = 0;
-        hipMemcpyAsync(&fp, m->d_fp, sizeof fp, hipMemcpyDeviceToHost, s);
-        hipStreamSynchronize(s);
-        if (fp != m->frozen_fp) {
-            for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
-            m->u_cache.clear();
-            for (auto& kv : m->wbf16_cache) if (kv.second) hipFree(kv.second);
-            m->wbf16_cache.clear();
+        if (!m->h_fp && hipHostMalloc((void**)&m->h_fp, sizeof(unsigned long long)) != hipSuccess) { m->h_fp = nullptr; (void)hipGetLastError(); }
+        if (m->h_fp && !m->fp_event) hipEventCreateWithFlags(&m->fp_event, hipEventDisableTiming);
+        if (m->h_fp && m->fp_event) {
+            hipMemcpyAsync(m->h_fp, m->d_fp, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+            hipEventRecord(m->fp_event, s);
+            guard_pending = true;
+        } else {
+            unsigned long long fp = 0;
+            hipMemcpyAsync(&fp, m->d_fp, sizeof fp, hipMemcpyDeviceToHost, s);
+            hipStreamSynchronize(s);
+            if (fp != m->frozen_fp) drop_banks();
         }
     }
     const bool fill_fp = m->frozen && m->u_cache.empty();
@@ -1115,6 +1129,13 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
         launch_fingerprint(m->d_params, (long long)m->total, m->d_fp, s);
         hipMemcpyAsync(&m->frozen_fp, m->d_fp, sizeof m->frozen_fp, hipMemcpyDeviceToHost, s);
         hipStreamSynchronize(s);
+    }
+    if (guard_pending) {
+        hipEventSynchronize(m->fp_event);
+        if (*m->h_fp != m->frozen_fp) {            // the parameters changed behind the library's back: this pass used stale banks -- again, without them
+            drop_banks();
+            return forward(m, img_dev, dtype, keep_prob, train);
+        }
     }
     m->have_forward = true; m->train_mode = train; m->keep_prob = keep_prob;
     return FCN8S_OK;
@@ -1474,6 +1495,8 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->loss_ev) hipEventDestroy(m->loss_ev);
     if (m->d_conf) hipFree(m->d_conf);
     if (m->d_fp) hipFree(m->d_fp);
+    if (m->h_fp) hipHostFree(m->h_fp);
+    if (m->fp_event) hipEventDestroy(m->fp_event);
     if (m->tg_b2) hipFree(m->tg_b2);
     if (m->tg_b2t) hipFree(m->tg_b2t);
     if (m->tg_db2) hipFree(m->tg_db2);
