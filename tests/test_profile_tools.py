@@ -34,3 +34,21 @@ def test_clock_summary_reproducible(tmp_path):
     pub = json.load(open(os.path.join(P, "r03_pmc_clock.json")))[DOMINANT]
     assert got == pub
     assert 1.5 < got["effective_clock_ghz"] <= 2.45 and 0.5 < got["mfma_pipe_busy"] <= 1.0
+
+
+def test_launch_gap_report_on_a_synthetic_trace(tmp_path):
+    """tools/launch_gap_report.py: 15 passes of three kernels each, 100 us long, 2 us apart, 10 us between passes."""
+    import csv
+    path = tmp_path / "t_kernel_trace.csv"
+    t = 1_000_000
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kind", "Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+        for _ in range(15):
+            for name in ("fcn8s::preprocess_kernel(void const*)", "a", "b"):
+                w.writerow(["KERNEL_DISPATCH", name, t, t + 100_000])
+                t += 102_000
+            t += 8_000
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "launch_gap_report.py"), str(path)], check=True, capture_output=True, text=True).stdout
+    assert "wall span per pass           314.0 us" in out and "a kernel is running          300.0 us" in out, out
+    assert "idle between its kernels       4.0 us" in out and "3 launches, 2.00 us per gap" in out and "idle before the next pass     10.0 us" in out, out
