@@ -111,6 +111,13 @@ template <int VEC> static __device__ __forceinline__ VecF<VEC> vfma(float s, con
     _Pragma("unroll") for (int i = 0; i < VEC; ++i) acc.d[i] = fmaf(s, a.d[i], acc.d[i]);
     return acc;
 }
+template <int VEC> static __device__ __forceinline__ VecF<VEC> vload_nt(const VecF<VEC>* p)
+{
+    typedef float vt __attribute__((ext_vector_type(VEC)));
+    const vt v = __builtin_nontemporal_load(reinterpret_cast<const vt*>(p));
+    VecF<VEC> r; _Pragma("unroll") for (int i = 0; i < VEC; ++i) r.d[i] = v[i];
+    return r;
+}
 #define f4fma vfma<VEC>
 #define f4zero vzero<VEC>
 #define VF VecF<VEC>
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(256, 3) void wino_output_kernel(const VF* __restric
     for (int b = 0; b < A; ++b) {
         VF col[A];
 #pragma unroll
-        for (int a = 0; a < A; ++a) col[a] = mp[(a * A + b) * slab];
+        for (int a = 0; a < A; ++a) col[a] = vload_nt<VEC>(mp + (a * A + b) * slab);       // read exactly once, fully coalesced: non-temporal (-0.15 ms/step; on the gathers' dV, the pool gradients, the loss kernel's logits and conv1_1's dZ the same hint measured neutral to slower)
 #pragma unroll
         for (int o = 0; o < M; ++o) {
             VF s = f4zero();
