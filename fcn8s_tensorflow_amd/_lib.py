@@ -17,7 +17,7 @@ IMG_U8, IMG_F32 = 0, 1
 OPT_TF_ADAM, OPT_SGD_MOMENTUM, OPT_NONE = 0, 1, 2
 NUM_BUCKETS = 3
 NUM_STAGE_SLOTS = 3
-PREC_F32, PREC_BF16_FC, PREC_F32X3, PREC_BF16_FWD = 0, 1, 2, 3
+PREC_F32, PREC_BF16_FC, PREC_F32X3, PREC_BF16_FWD, PREC_F32X2, PREC_BF16_FWD_X2 = 0, 1, 2, 3, 4, 5
 
 
 class Config(C.Structure):

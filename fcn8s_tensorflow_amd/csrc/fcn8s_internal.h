@@ -38,7 +38,7 @@ struct IgemmArgs {
     int batched; long long x_batch_stride, y_batch_stride;   // gridDim.z independent GEMMs (Winograd positions)
     int m_fastest;                                           // tile order, set by the launcher (see igemm.hip)
     int bt, ldw;                                             // bt: the B operand is stored transposed, w[z][n][k] with row stride ldw (plain batched GEMMs on the LDS-DMA kernel only)
-    int split;                                               // 3: the LDS-DMA kernels take their products as six bf16 MFMAs of the operands split in three (FCN8S_PREC_F32X3); 0: f32 MFMA
+    int split;                                               // 3: the LDS-DMA kernels take their products as six bf16 MFMAs of the operands split in three (FCN8S_PREC_F32X3); 2: three MFMAs of two pieces (FCN8S_PREC_F32X2); 0: f32 MFMA
 };
 void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s);
 

@@ -404,22 +404,35 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt() { asm volat
 // number is measured on the exact f32 MFMA.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // (which arithmetic a launch uses travels in IgemmArgs::split / WgradArgs::split, set by the caller from its model's precision)
-static __device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo)
+// f32x2 (FCN8S_PREC_F32X2 / FCN8S_PREC_BF16_FWD_X2): the same with two pieces, x ~ hi + lo (16 significand bits kept: the residual after lo is
+// below 2^-17 |x|) and a*b taken as lo*hi + hi*lo + hi*hi -- three MFMAs and two conversions per value instead of six and three.  A
+// reduced-precision arithmetic (between TF32's 11 bits and fp32's 24), never used by the fp32 mode.
+template <int NS> struct Bf16Pieces { bf16x8 p[NS]; };          // p[0] = hi, p[1] = mid (or lo for NS = 2), p[2] = lo
+template <int NS>
+static __device__ __forceinline__ void split_bf16(const float (&x)[8], Bf16Pieces<NS>& o)
 {
     float r[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { hi[i] = (__bf16)x[i]; r[i] = x[i] - (float)hi[i]; }
+    for (int i = 0; i < 8; ++i) { o.p[0][i] = (__bf16)x[i]; r[i] = x[i] - (float)o.p[0][i]; }
+    if constexpr (NS == 3) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { mid[i] = (__bf16)r[i]; r[i] = r[i] - (float)mid[i]; lo[i] = (__bf16)r[i]; }
+        for (int i = 0; i < 8; ++i) { o.p[1][i] = (__bf16)r[i]; r[i] = r[i] - (float)o.p[1][i]; o.p[2][i] = (__bf16)r[i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.p[1][i] = (__bf16)r[i];
+    }
 }
-static __device__ __forceinline__ f32x16 mfma_x3(const bf16x8& ah, const bf16x8& am, const bf16x8& al, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl, f32x16 acc)
+template <int NS>
+static __device__ __forceinline__ f32x16 mfma_split(const Bf16Pieces<NS>& a, const Bf16Pieces<NS>& b, f32x16 acc)
 {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);          // small terms first
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    if constexpr (NS == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], b.p[0], acc, 0, 0, 0);          // small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[1], acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[1], acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], acc, 0, 0, 0);
 }
 
 template <int BM, int BN, int WM, int WN, int S, bool EPI, int NSPLIT, bool BT = false>
@@ -436,6 +449,10 @@ template <int BM, int BN, int WM, int WN, int S>
 __global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void gemm_glds_nt_kernel(const IgemmArgs p) { gemm_glds_body<BM, BN, WM, WN, S, false, 0, true>(p); }
 template <int BM, int BN, int WM, int WN, int S>
 __global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void gemm_glds_nt_x3_kernel(const IgemmArgs p) { gemm_glds_body<BM, BN, WM, WN, S, false, 3, true>(p); }
+template <int BM, int BN, int WM, int WN, int S, bool EPI>
+__global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void gemm_glds_x2_kernel(const IgemmArgs p) { gemm_glds_body<BM, BN, WM, WN, S, EPI, 2>(p); }
+template <int BM, int BN, int WM, int WN, int S>
+__global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void gemm_glds_nt_x2_kernel(const IgemmArgs p) { gemm_glds_body<BM, BN, WM, WN, S, false, 2, true>(p); }
 template <int BM, int BN, int WM, int WN, int S, bool EPI, int NSPLIT, bool BT>
 static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p)
 {
@@ -536,14 +553,14 @@ static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p)
         if (idle) return;
         const float* sa = smem + stage * STAGE;
         const float* sb = sa + BM * BK;
-        if constexpr (NSPLIT == 3) {                   // one K = 16 step of the bf16 MFMA per K-tile: lane half h holds k = 8h .. 8h + 7
-            bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+        if constexpr (NSPLIT >= 2) {                   // one K = 16 step of the bf16 MFMA per K-tile: lane half h holds k = 8h .. 8h + 7
+            Bf16Pieces<NSPLIT> ap[TM], bp[TN];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const float4 u = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((2 * (lane >> 5)) ^ a_sw[tm]) * 4));
                 const float4 v = *reinterpret_cast<const float4*>(sa + a_off[tm] + (((2 * (lane >> 5) + 1) ^ a_sw[tm]) * 4));
                 const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-                split3_bf16(x, ah[tm], am[tm], al[tm]);
+                split_bf16<NSPLIT>(x, ap[tm]);
             }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
@@ -556,12 +573,12 @@ static __device__ __forceinline__ void gemm_glds_body(const IgemmArgs& p)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x[j] = sb[((lane >> 5) * 8 + j) * BN + wn * TN * 32 + tn * 32 + (lane & 31)];
                 }
-                split3_bf16(x, bh[tn], bm[tn], bl[tn]);
+                split_bf16<NSPLIT>(x, bp[tn]);
             }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_x3(ah[tm], am[tm], al[tm], bh[tn], bm[tn], bl[tn], acc[tm][tn]);
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_split<NSPLIT>(ap[tm], bp[tn], acc[tm][tn]);
             return;
         }
 #pragma unroll
@@ -931,8 +948,10 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
                 static const std::string nb = "gemm_glds_nt_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>";
                 static const std::string nbx = "gemm_glds_nt_x3_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>";
                 if (mode != 3 || (long long)(BN - 1) * a.ldw >= (1LL << 29)) { fprintf(stderr, "fcn8s: transposed-B GEMM needs the plain batched form\n"); abort(); }
-                g_last_kernel = (a.split == 3 ? nbx : nb).c_str();
+                static const std::string nbx2 = "gemm_glds_nt_x2_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>";
+                g_last_kernel = (a.split == 3 ? nbx : a.split == 2 ? nbx2 : nb).c_str();
                 if (a.split == 3) hipLaunchKernelGGL((gemm_glds_nt_x3_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, s, a);
+                else if (a.split == 2) hipLaunchKernelGGL((gemm_glds_nt_x2_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, s, a);
                 else                   hipLaunchKernelGGL((gemm_glds_nt_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, s, a);
                 return;
             }
@@ -940,6 +959,14 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
             if (a.split == 3) {
                 if (epi) hipLaunchKernelGGL((gemm_glds_x3_kernel<BM, BN, WM, WN, 3, true>), grid, dim3(256), 0, s, a);
                 else     hipLaunchKernelGGL((gemm_glds_x3_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(256), 0, s, a);
+                return;
+            }
+            if (a.split == 2) {
+                static const std::string x2base = "gemm_glds_x2_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3, ";
+                static const std::string x2t[2] = {x2base + "false>", x2base + "true>"};
+                g_last_kernel = x2t[epi ? 1 : 0].c_str();
+                if (epi) hipLaunchKernelGGL((gemm_glds_x2_kernel<BM, BN, WM, WN, 3, true>), grid, dim3(256), 0, s, a);
+                else     hipLaunchKernelGGL((gemm_glds_x2_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(256), 0, s, a);
                 return;
             }
             if (epi) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, 3, true>), grid, dim3(256), 0, s, a);
@@ -1642,6 +1669,8 @@ template <int BM, int BN, int WM, int WN, int S, bool PRELOAD>
 __global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void wgrad_glds_kernel(const WgradArgs p, const int chunk, const int nsplit) { wgrad_glds_body<BM, BN, WM, WN, S, PRELOAD, 0>(p, chunk, nsplit); }
 template <int BM, int BN, int WM, int WN, int S>
 __global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void wgrad_glds_x3_kernel(const WgradArgs p, const int chunk, const int nsplit) { wgrad_glds_body<BM, BN, WM, WN, S, true, 3>(p, chunk, nsplit); }
+template <int BM, int BN, int WM, int WN, int S>
+__global__ __launch_bounds__(256, (S * (BM + BN) * 64 <= 40960) ? 4 : 3) void wgrad_glds_x2_kernel(const WgradArgs p, const int chunk, const int nsplit) { wgrad_glds_body<BM, BN, WM, WN, S, true, 2>(p, chunk, nsplit); }
 template <int BM, int BN, int WM, int WN, int S, bool PRELOAD, int NSPLIT>
 static __device__ __forceinline__ void wgrad_glds_body(const WgradArgs& p, const int chunk, const int nsplit)
 {
@@ -1702,28 +1731,28 @@ static __device__ __forceinline__ void wgrad_glds_body(const WgradArgs& p, const
     const int a_off = (lane >> 5) * BM + wm * TM * 32 + (lane & 31);
     const int b_off = (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
     auto compute = [&](int stage) {
-        if constexpr (NSPLIT == 3) {                   // f32x3 (see split3_bf16): lane half h holds rows k = 8h .. 8h + 7 of the K-tile
+        if constexpr (NSPLIT >= 2) {                   // f32x3 / f32x2 (see split_bf16): lane half h holds rows k = 8h .. 8h + 7 of the K-tile
             const float* sa3 = smem + stage * STAGE + (lane >> 5) * 8 * BM + wm * TM * 32 + (lane & 31);
             const float* sb3 = smem + stage * STAGE + BK * BM + (lane >> 5) * 8 * BN + wn * TN * 32 + (lane & 31);
-            bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+            Bf16Pieces<NSPLIT> ap[TM], bp[TN];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 float x[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[j] = sa3[j * BM + tm * 32];
-                split3_bf16(x, ah[tm], am[tm], al[tm]);
+                split_bf16<NSPLIT>(x, ap[tm]);
             }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 float x[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[j] = sb3[j * BN + tn * 32];
-                split3_bf16(x, bh[tn], bm[tn], bl[tn]);
+                split_bf16<NSPLIT>(x, bp[tn]);
             }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_x3(ah[tm], am[tm], al[tm], bh[tn], bm[tn], bl[tn], acc[tm][tn]);
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_split<NSPLIT>(ap[tm], bp[tn], acc[tm][tn]);
             return;
         }
         const float* sa = smem + stage * STAGE + a_off;
@@ -1845,6 +1874,8 @@ static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
             g_last_kernel = gtag.c_str();
             if (a.split == 3) { static const std::string xtag = "wgrad_glds_x3_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>"; g_last_kernel = xtag.c_str();
                                      hipLaunchKernelGGL((wgrad_glds_x3_kernel<BM, BN, WM, WN, 3>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits); return; }
+            if (a.split == 2) { static const std::string x2tag = "wgrad_glds_x2_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>"; g_last_kernel = x2tag.c_str();
+                                     hipLaunchKernelGGL((wgrad_glds_x2_kernel<BM, BN, WM, WN, 3>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits); return; }
             hipLaunchKernelGGL((wgrad_glds_kernel<BM, BN, WM, WN, 3, true>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits);
             return;
         }

@@ -267,7 +267,14 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
 // (e.g. 192) get a second, transposed bank instead (3x3 layers) or the forward-type data gradient (fc6).
 static bool bt_gemm_ok(int K, int N) { return K % 16 == 0 && (N == 64 || N % 128 == 0); }
 int g_op_split = 0;      // arithmetic of the op-level entry points, which have no model (fcn8s_set_option(NULL, "op_f32x3", 1))
-int split_of(const fcn8s_model* m) { return m ? ((m->precision == FCN8S_PREC_F32X3 || m->precision == FCN8S_PREC_BF16_FWD) ? 3 : 0) : g_op_split; }
+int split_of(const fcn8s_model* m)
+{
+    if (!m) return g_op_split;
+    if (m->precision == FCN8S_PREC_F32X3 || m->precision == FCN8S_PREC_BF16_FWD) return 3;
+    if (m->precision == FCN8S_PREC_F32X2 || m->precision == FCN8S_PREC_BF16_FWD_X2) return 2;
+    return 0;
+}
+static inline bool bf16_fwd_mode(const fcn8s_model* m) { return m->precision == FCN8S_PREC_BF16_FWD || m->precision == FCN8S_PREC_BF16_FWD_X2; }
 int wino_tile_for(const fcn8s_model* m, int H, int W, int K = 3)
 {
     if (!m || H % 2 || W % 2) return 0;
@@ -1062,7 +1069,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 ProfScope ps(m, "conv1_1_fwd", 2.0 * N * h * w * 27.0 * m->widths[0], 4.0 * N * h * w * (3.0 + m->widths[0]), nm);
                 done = launch_conv1_fwd(x, m->d_w1pad, e.bias, A(m, nm), m->d_w1pad + 12 * 4 * (size_t)m->widths[0], N, h, w, m->widths[0], s);
             }
-            if (!done && m->precision == FCN8S_PREC_BF16_FWD && b >= 2) {
+            if (!done && bf16_fwd_mode(m) && b >= 2) {
                 // FCN8S_PREC_BF16_FWD: conv3_1 .. conv5_3 as direct convolutions with bf16-rounded operands on the 256 x 256 bf16 kernel (the
                 // output is materialised, the block's pool runs as its own kernel, ReLU masks come from the activations); the backward pass
                 // stays in the Winograd domain, so the transformed input and this step's filter bank are made here
@@ -1097,7 +1104,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     const int h5 = h, w5 = w;
     const bool drop = train && keep_prob < 1.f;
     m->drop_stream = (uint32_t)(2 * m->step);
-    if (m->precision == FCN8S_PREC_BF16_FC || m->precision == FCN8S_PREC_BF16_FWD) {
+    if (m->precision == FCN8S_PREC_BF16_FC || bf16_fwd_mode(m)) {
         // config 5: bf16-rounded operands, fp32 accumulate, fp32 epilogue and output (gemm_bf16.hip)
         bf16_conv_layer(m, "fc6_fwd_bf16", "fc6/weights", "fc6/biases", x, A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, drop, keep_prob, m->drop_stream, s);
         // the fp32 gradients of fc6 run in the Winograd domain and want the transformed input and this step's filter bank
@@ -1537,9 +1544,9 @@ int fcn8s_freeze_params(fcn8s_model* m, int frozen)
 int fcn8s_set_precision(fcn8s_model* m, int precision)
 {
     if (!m) return FCN8S_ERR_BAD_ARG;
-    if (precision != FCN8S_PREC_F32 && precision != FCN8S_PREC_BF16_FC && precision != FCN8S_PREC_F32X3 && precision != FCN8S_PREC_BF16_FWD)
+    if (precision < FCN8S_PREC_F32 || precision > FCN8S_PREC_BF16_FWD_X2)
         return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_precision: unknown precision");
-    if (precision == FCN8S_PREC_BF16_FC || precision == FCN8S_PREC_BF16_FWD) {
+    if (precision == FCN8S_PREC_BF16_FC || precision == FCN8S_PREC_BF16_FWD || precision == FCN8S_PREC_BF16_FWD_X2) {
         if (m->widths[4] % 32 || m->widths[5] % 128 || m->widths[6] % 128)
             return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_precision: the bf16 modes need conv5 width % 32 == 0 and fc6 / fc7 widths % 128 == 0");
     }
@@ -1579,6 +1586,10 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
     const std::string k = key;
     if (!m) {
         if (k == "op_f32x3") { g_op_split = value ? 3 : 0; return FCN8S_OK; }
+        if (k == "op_split_pieces") {
+            if (value != 0 && value != 2 && value != 3) return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_set_option: op_split_pieces is 0, 2 or 3");
+            g_op_split = (int)value; return FCN8S_OK;
+        }
         if (k == "conv1_tiled") { fcn8s::g_conv1_tiled = value ? 1 : 0; return FCN8S_OK; }
         if (k == "conv1_wgrad_mfma") { fcn8s::g_conv1_wgrad_mfma = value ? 1 : 0; return FCN8S_OK; }
         return fail(nullptr, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown process-wide option '" + k + "'");
@@ -1619,6 +1630,7 @@ int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value)
     const std::string k = key;
     if (!m) {
         if (k == "op_f32x3") { *value = g_op_split == 3; return FCN8S_OK; }
+        if (k == "op_split_pieces") { *value = g_op_split; return FCN8S_OK; }
         if (k == "conv1_tiled") { *value = fcn8s::g_conv1_tiled; return FCN8S_OK; }
         if (k == "conv1_wgrad_mfma") { *value = fcn8s::g_conv1_wgrad_mfma; return FCN8S_OK; }
         return FCN8S_ERR_NOT_FOUND;
@@ -2124,7 +2136,7 @@ int fcn8s_op_conv3x3_winograd_fwd_bwd(void* stream, const float* x, const float*
     // a bare model context: the launch sequences below are the model's own (conv_same / conv_wgrad), with one layer called "op"
     fcn8s_model mm; fcn8s_model* m = &mm;
     m->stream = s; m->wino_min_cin = 16; m->wino_tile = 6; m->wino_force_tile = tile; m->N = N; m->H = H; m->W = W;
-    m->precision = g_op_split == 3 ? FCN8S_PREC_F32X3 : FCN8S_PREC_F32;
+    m->precision = g_op_split == 3 ? FCN8S_PREC_F32X3 : g_op_split == 2 ? FCN8S_PREC_F32X2 : FCN8S_PREC_F32;
     const int al = tile + 2, P = al * al, cmax = std::max(Cin, Cout);
     const size_t T = (size_t)wino_tiles(tile, N, H, W);
     const size_t slab_max = (size_t)P * (size_t)wino_slab((long long)T, cmax), slab_in = (size_t)P * (size_t)wino_slab((long long)T, Cin);

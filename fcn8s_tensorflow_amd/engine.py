@@ -394,10 +394,12 @@ class Engine:
         operands on the bf16 MFMA, fp32 accumulation; the rest of the step stays fp32), 'f32x3' (every large GEMM on the
         bf16 MFMA with each fp32 operand split exactly into three bf16 pieces: fp32 accuracy, not bit-identical to fp32) or
         'bf16_fwd' (config 5 taken further: conv3_1 .. conv5_3, fc6 and fc7 forward with bf16-rounded operands, every other GEMM
-        in the f32x3 arithmetic: all matrix work on the bf16 MFMA)."""
-        modes = {'fp32': L.PREC_F32, 'bf16_fc': L.PREC_BF16_FC, 'f32x3': L.PREC_F32X3, 'bf16_fwd': L.PREC_BF16_FWD}
+        in the f32x3 arithmetic: all matrix work on the bf16 MFMA); 'f32x2' / 'bf16_fwd_x2' = 'f32x3' / 'bf16_fwd' with two bf16
+        pieces per operand instead of three (16 significand bits enter each product: reduced precision, half the matrix work)."""
+        modes = {'fp32': L.PREC_F32, 'bf16_fc': L.PREC_BF16_FC, 'f32x3': L.PREC_F32X3, 'bf16_fwd': L.PREC_BF16_FWD,
+                 'f32x2': L.PREC_F32X2, 'bf16_fwd_x2': L.PREC_BF16_FWD_X2}
         if precision not in modes:
-            raise ValueError("`precision` must be 'fp32', 'bf16_fc', 'f32x3' or 'bf16_fwd', but is '{}'.".format(precision))
+            raise ValueError("`precision` must be 'fp32', 'bf16_fc', 'f32x3', 'bf16_fwd', 'f32x2' or 'bf16_fwd_x2', but is '{}'.".format(precision))
         L.check(L.lib.fcn8s_set_precision(self.h, modes[precision]), self.h)
         self.precision = precision
 

@@ -64,6 +64,12 @@ extern "C" {
                                      MFMA, fp32 accumulation, fp32 outputs; every other GEMM of the step -- conv1_2 / conv2_x forward, all data and
                                      weight gradients -- uses the F32X3 arithmetic, i.e. all matrix work is on the bf16 MFMA.  Gradients are those of
                                      the fp32 graph evaluated at the bf16-forward activations (straight-through rounding). */
+#define FCN8S_PREC_F32X2   4      /* like F32X3 with two pieces per operand, x ~ hi + lo: 16 significand bits of each operand enter the product
+                                     (what is cut off is below 2^-17 |x|), three of the four piece products are accumulated in fp32.  Between TF32
+                                     (11 bits) and fp32 (24); a reduced-precision mode, half the matrix-pipe and conversion work of F32X3. */
+#define FCN8S_PREC_BF16_FWD_X2 5   /* BF16_FWD with the F32X2 arithmetic in place of F32X3 for every GEMM that is not a bf16 forward convolution
+                                     (conv1_2 / conv2_x forward, all data and weight gradients): config 5's "bf16 fwd / fp32 accum" with 16-bit
+                                     operands in the backward pass */
 
 typedef struct fcn8s_model fcn8s_model;
 
@@ -207,6 +213,7 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *                              128 tiles (training batches), 2 whenever the shapes allow (rows and Cout multiples of 256)
  *   process-wide option (m == NULL), for the op-level entry points below, which have no model:
  *     "op_f32x3"          0    their LDS-DMA GEMMs use the split-bf16 arithmetic of FCN8S_PREC_F32X3
+ *     "op_split_pieces"   0    the same switch by piece count: 0 = f32 MFMA, 3 = FCN8S_PREC_F32X3, 2 = FCN8S_PREC_F32X2
  *     "conv1_tiled"       1    conv1_1 forward on the spatial-tile kernel (halo tile in LDS); 0 = the LDS-DMA gather kernel (bit-identical results)
  *     "conv1_wgrad_mfma"  1    conv1_1 weight gradient as a (27 -> 32) x 64 MFMA product over pixels; 0 = the VALU kernel
  * Unknown keys return FCN8S_ERR_NOT_FOUND. */

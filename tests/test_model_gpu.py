@@ -249,6 +249,39 @@ def test_gradients_along_the_device_branches(precision, widths, n, h, w, l2):
     e.close()
 
 
+def test_f32x2_mode_gradients():
+    """FCN8S_PREC_F32X2 ('f32x2'): every LDS-DMA GEMM of the step with two bf16 pieces per operand (16 significand bits enter each
+    product, fp32 accumulation) -- a reduced-precision mode, so its bound is its own: logits to 1e-3 (the fp32 bound still holds) and
+    gradients along the device's decisions to 3e-3 of each tensor's largest entry (fp32 / f32x3: 3e-4; measured here 1.05e-3, on the last
+    transposed conv's kernel, whose entries are sums over every pixel of products that nearly cancel), on the full-width case of
+    test_gradients_along_the_device_branches.  The split kernels must have run, the f32 and x3 ones must not."""
+    e = make_engine(None)
+    e.set_precision("f32x2")
+    n, h, w, seed = 2, 32, 64, 2
+    P = orc.init_params(20, orc.DEFAULT_WIDTHS, seed=seed, decoder_std_scale=30.0, bias_std=0.05)
+    img, lab = batch(n, h, w, seed=seed + 100)
+    e.set_params(P)
+    e.profile(2); e.profile_reset()
+    loss = e.forward_backward(img, orc.one_hot(lab, 20), keep_prob=1.0, l2_rate=0.0)
+    kernels = [k for k in e.profile_results() if k.startswith("kernel:")]
+    e.profile(0)
+    assert any("gemm_glds_x2_kernel" in k for k in kernels) and any("wgrad_glds_x2_kernel" in k for k in kernels) and any("gemm_glds_nt_x2_kernel" in k for k in kernels), kernels
+    assert not any("gemm_glds_kernel" in k or "wgrad_glds_kernel" in k or "_x3_kernel" in k for k in kernels), kernels
+    g = e.get_grads()
+    logits = e.activation("logits", (n, h, w, 20))
+    br, rt, stats = device_decisions(e, P, img, (n, h, w), relu_tol=1e-4, tie_tol=1e-4)
+    loss_ref, g_ref, logits_ref = orc.loss_and_grads(P, img, orc.one_hot(lab, 20).astype(np.float32), l2_rate=0.0, branches=br, routes=rt)
+    assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    lerr = float(np.abs(logits - logits_ref).max() / max(1.0, np.abs(logits_ref).max()))
+    errs = {k: rel(g[k], g_ref[k]) for k in g_ref}
+    worst_k = max(errs, key=errs.get)
+    print("f32x2: logits %.2e of their scale; worst gradient error %s %.2e; %d of %d ReLU units on the other side (largest %.1e)"
+          % (lerr, worst_k, errs[worst_k], stats["relu_differ"], stats["relu_units"], stats["relu_worst"]))
+    assert lerr < 1e-3
+    assert errs[worst_k] < 3e-3, (worst_k, errs[worst_k])
+    e.close()
+
+
 @pytest.mark.parametrize("precision", ["fp32", "f32x3"])
 def test_training_overfits_one_batch(precision):
     """The step is usable, not just locally correct: 40 TF-Adam steps on one fixed batch (small widths, dropout off) drive the loss
@@ -546,8 +579,11 @@ def test_bf16_fc_256_tile_kernel():
     assert abs(outs[2][4] - loss_dref) < 1e-3 * max(1.0, abs(loss_dref))
 
 
-def test_bf16_fwd_mode():
-    """FCN8S_PREC_BF16_FWD ('bf16_fwd'): conv3_1 .. conv5_3, fc6 and fc7 forward with bf16-rounded operands on the bf16 MFMA (fp32
+@pytest.mark.parametrize("mode", ["bf16_fwd", "bf16_fwd_x2"])
+def test_bf16_fwd_mode(mode):
+    """FCN8S_PREC_BF16_FWD_X2 ('bf16_fwd_x2') is the same mode with two bf16 pieces per operand instead of three in the non-bf16 GEMMs (16
+    significand bits: far inside this test's bounds, which the 8-bit forward rounding sets).
+    FCN8S_PREC_BF16_FWD ('bf16_fwd'): conv3_1 .. conv5_3, fc6 and fc7 forward with bf16-rounded operands on the bf16 MFMA (fp32
     accumulate), every other GEMM in the f32x3 arithmetic -- against the oracle applying the same rounding to the same layers
     (`bf16_fc=True, bf16_convs=True`): logits to 1e-3 of their scale, gradients along the device's decisions to 1e-2 in L2 (a bf16
     rounding-boundary flip moves pre-activations by ~2e-4 of their scale, so units up to 1e-3 of a layer's largest may sit on the other
@@ -556,7 +592,7 @@ def test_bf16_fwd_mode():
     n, h, w = 1, 256, 256
     P = orc.init_params(20, seed=9, decoder_std_scale=6.0, bias_std=0.05)
     img, lab = batch(n, h, w, seed=31)
-    e = Engine(20, precision='bf16_fwd', options={"bf16_gemm256": 2})
+    e = Engine(20, precision=mode, options={"bf16_gemm256": 2})
     e.set_params(P)
     e.profile(2); e.profile_reset()
     onehot = orc.one_hot(lab, 20)
@@ -565,7 +601,8 @@ def test_bf16_fwd_mode():
     e.profile(0)
     k256 = [v for k, v in prof.items() if k.startswith("kernel:") and "conv_bf16_256_kernel" in k]
     assert k256 and sum(int(v["launches"]) for v in k256) >= 9, {k: v["launches"] for k, v in prof.items() if k.startswith("kernel:")}
-    assert any("_x3_kernel" in k for k in prof) and not any(k.startswith("kernel:") and ("gemm_glds_kernel" in k or "wgrad_glds_kernel<" in k) for k in prof)
+    mine, other = ("_x3_kernel", "_x2_kernel") if mode == "bf16_fwd" else ("_x2_kernel", "_x3_kernel")
+    assert any(mine in k for k in prof) and not any(k.startswith("kernel:") and ("gemm_glds_kernel" in k or "wgrad_glds_kernel<" in k or other in k) for k in prof)
     logits = e.activation("logits", (n, h, w, 20))
     # (1) the arithmetic of each bf16 layer, exactly: the layer's output on the device against the oracle's convolution of the bf16-rounded
     #     operands applied to the DEVICE's own input of that layer -- identical rounding, only the fp32 summation order differs

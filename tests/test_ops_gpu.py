@@ -349,6 +349,51 @@ def test_preprocess():
     assert (o[..., 3] == 0).all()
 
 
+def test_split_piece_count_sets_the_product_accuracy():
+    """The three arithmetics of the LDS-DMA GEMMs on one 1x1 conv (a plain [2048 x 512] x [512 x 256] GEMM) against a float64 product of the
+    same operands: the f32 MFMA and the three-piece split (f32x3) agree with it to fp32 round-off; the two-piece split (f32x2, 16 significand
+    bits of each operand) sits one to two orders above, well under TF32's 2^-11, and equals -- to fp32 summation order -- the float64
+    product of the operands cut to their two pieces (that is what the mode is defined as)."""
+    L = _lib()
+    rng = np.random.default_rng(12)
+    N, H, W, Cin, Cout = 2, 32, 32, 512, 256
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((1, 1, Cin, Cout)) / np.sqrt(Cin)).astype(np.float32)
+    xd, wd = dev(x), dev(w)
+    want = x.reshape(-1, Cin).astype(np.float64) @ w.reshape(Cin, Cout).astype(np.float64)
+
+    def two_pieces(a):
+        t = torch.from_numpy(a)
+        hi = t.to(torch.bfloat16).to(torch.float32)
+        lo = (t - hi).to(torch.bfloat16).to(torch.float32)
+        return (hi.double() + lo.double()).numpy()
+    x2, w2 = two_pieces(x).reshape(-1, Cin), two_pieces(w).reshape(Cin, Cout)
+    hi = lambda a: torch.from_numpy(a).to(torch.bfloat16).double().numpy()
+    # a b ~ hi hi + hi lo + lo hi (the lo lo term is dropped)
+    want2 = x2 @ w2 - (x2 - hi(x).reshape(-1, Cin)) @ (w2 - hi(w).reshape(Cin, Cout))
+    prev = C.c_int64()
+    L.check(L.lib.fcn8s_get_option(None, b"op_split_pieces", C.byref(prev)))
+    err = {}
+    try:
+        for pieces in (0, 3, 2):
+            L.check(L.lib.fcn8s_set_option(None, b"op_split_pieces", pieces))
+            y = torch.empty(N, H, W, Cout).cuda()
+            L.check(L.lib.fcn8s_op_conv2d(None, ptr(xd), ptr(wd), None, ptr(y), N, H, W, Cin, Cout, 1, 0))
+            torch.cuda.synchronize()
+            got = y.cpu().numpy().reshape(-1, Cout)
+            err[pieces] = rel_err(got, want)
+            if pieces == 2:
+                err["2 vs its definition"] = rel_err(got, want2)
+        assert L.lib.fcn8s_set_option(None, b"op_split_pieces", 1) != 0          # 0, 2 or 3 only
+    finally:
+        L.check(L.lib.fcn8s_set_option(None, b"op_split_pieces", int(prev.value)))
+    print("max error / max |y| against float64: f32 MFMA %.1e, three pieces %.1e, two pieces %.1e (vs the two-piece product in float64 %.1e)"
+          % (err[0], err[3], err[2], err["2 vs its definition"]))
+    assert err[0] < 2e-6 and err[3] < 2e-6, err
+    assert 1e-6 < err[2] < 3e-5, err                   # 2^-17 per operand, random signs over K = 512
+    assert err["2 vs its definition"] < 2e-6, err
+
+
 def test_conv_ops_in_f32x3_mode_hold_the_fp32_tolerances():
     """fcn8s_set_option(NULL, "op_f32x3", 1) routes every LDS-DMA GEMM of the op-level entry points through the split-bf16 kernels (the
     model-level switch is fcn8s_set_precision): the convolution cases above must hold their fp32 tolerances (2e-5) unchanged."""
