@@ -21,6 +21,10 @@ python bench.py --steps 10 --warmup 3 --height 1024 --width 2048 --batch 4 --pre
 python bench.py --steps 10 --warmup 3 --mode infer --batch 1 --precision f32x3 --no-cpu-baseline > $OUT/bench_infer_bs1_f32x3.json 2>> $OUT/bench.err
 python bench.py --steps 10 --warmup 3 --precision bf16_fwd --no-cpu-baseline > $OUT/bench_train_bs16_bf16_fwd.json 2>> $OUT/bench.err
 python bench.py --steps 10 --warmup 3 --height 1024 --width 2048 --batch 4 --precision bf16_fwd --no-cpu-baseline > $OUT/bench_c5_2048x1024_bs4_bf16_fwd.json 2>> $OUT/bench.err
+for p in f32x2 bf16_fwd_x2; do
+python bench.py --steps 10 --warmup 3 --precision $p --no-cpu-baseline > $OUT/bench_train_bs16_$p.json 2>> $OUT/bench.err
+python bench.py --steps 10 --warmup 3 --height 1024 --width 2048 --batch 4 --precision $p --no-cpu-baseline > $OUT/bench_c5_2048x1024_bs4_$p.json 2>> $OUT/bench.err
+done
 # BASELINE config 5's per-GPU shape and arithmetic (2048x1024, 4 images, bf16 fc6/fc7), config 2, and the end-to-end run
 python bench.py --steps 10 --warmup 3 --height 1024 --width 2048 --batch 4 --precision bf16_fc --no-cpu-baseline > $OUT/bench_c5_2048x1024_bs4_bf16_fc.json 2>> $OUT/bench.err
 python bench.py --steps 10 --warmup 3 --height 1024 --width 2048 --batch 4 --no-cpu-baseline > $OUT/bench_c5_2048x1024_bs4_fp32.json 2>> $OUT/bench.err
