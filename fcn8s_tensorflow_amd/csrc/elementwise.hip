@@ -212,6 +212,12 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel_c(const float* logits
                                                              float* dlogits, double* partials,
                                                              long long npix, float gscale, float* colsum, const PixMap map)
 {
+    // One thread = one pixel, but a pixel's C floats are C / 4 16-byte units 4 C bytes apart: read per thread, every load instruction of a
+    // wave touches 64 x 16 B spread over 64 x 4C bytes (3.9 TB/s).  So a wave moves its 64 pixels as a block -- U coalesced 1 KiB
+    // accesses (lane l <-> unit i * 64 + l) -- through a wave-private LDS patch from which every lane picks up its own pixel (units
+    // l * U + j: stride 4C bytes = 20 banks for C = 20, conflict-free for 16-byte reads), and takes the gradient back the same way.
+    constexpr int U = C / 4;
+    __shared__ float4 patch[U > 1 ? 4 * 64 * U : 1];
     __shared__ double sh[4];
     __shared__ float cs[C];
     float csum[C];                             // colsum != nullptr: column sums of dlogits (= the last bias gradient), saves a pass over dlogits
@@ -219,46 +225,65 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel_c(const float* logits
     for (int i = 0; i < C; ++i) csum[i] = 0.f;
     if (threadIdx.x < C) cs[threadIdx.x] = 0.f;
     double lsum = 0;
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix;
-         p += (long long)gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4* wp = patch + (U > 1 ? wave * 64 * U : 0);
+    const long long nunits = npix * U;
+    for (long long p0 = blockIdx.x * (long long)blockDim.x + wave * 64; p0 < npix; p0 += (long long)gridDim.x * blockDim.x) {    // wave-uniform
+        const long long p = p0 + lane;
+        const long long pix = p < npix ? slot_pixel(p, map) : -1;          // npix counts slots here; labels are indexed by pixel
         float v[C];
-        const long long pix = slot_pixel(p, map);          // npix counts slots here; labels are indexed by pixel
-        if (pix < 0) {                                     // a slot outside the image: its gradient is defined as 0
-            if (dlogits) {
-                float4* dst = reinterpret_cast<float4*>(dlogits + p * C);
+        if constexpr (U > 1) {
+            const float4* src = reinterpret_cast<const float4*>(logits) + p0 * U;
 #pragma unroll
-                for (int i = 0; i < C / 4; ++i) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            continue;
+            for (int i = 0; i < U; ++i) { const int u = i * 64 + lane; if (p0 * U + u < nunits) wp[u] = src[u]; }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < U; ++i) { const float4 t = wp[lane * U + i]; v[4*i] = t.x; v[4*i+1] = t.y; v[4*i+2] = t.z; v[4*i+3] = t.w; }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            const float4 t = p < npix ? reinterpret_cast<const float4*>(logits)[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         }
-        const float4* src = reinterpret_cast<const float4*>(logits + p * C);
+        float4 g[U];
 #pragma unroll
-        for (int i = 0; i < C / 4; ++i) { const float4 t = src[i]; v[4*i] = t.x; v[4*i+1] = t.y; v[4*i+2] = t.z; v[4*i+3] = t.w; }
-        float m = v[0];
+        for (int i = 0; i < U; ++i) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);       // a slot outside the image: its gradient is defined as 0
+        if (pix >= 0) {
+            float m = v[0];
 #pragma unroll
-        for (int i = 1; i < C; ++i) m = fmaxf(m, v[i]);
-        float e[C]; float s = 0.f;
+            for (int i = 1; i < C; ++i) m = fmaxf(m, v[i]);
+            float e[C]; float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < C; ++i) { e[i] = expf(v[i] - m); s += e[i]; }
-        const int lab = labels[pix];
-        const bool ign = lab >= C;                 // ids outside [0, C) (e.g. a 255 "ignore" id, an all-zero one-hot row): no loss, no gradient
-        float vl = 0.f;
+            for (int i = 0; i < C; ++i) { e[i] = expf(v[i] - m); s += e[i]; }
+            const int lab = labels[pix];
+            const bool ign = lab >= C;                 // ids outside [0, C) (e.g. a 255 "ignore" id, an all-zero one-hot row): no loss, no gradient
+            float vl = 0.f;
 #pragma unroll
-        for (int i = 0; i < C; ++i) vl = (i == lab) ? v[i] : vl;
-        if (!ign) lsum += (double)(m + logf(s) - vl);
-        if (dlogits) {
-            const float inv = ign ? 0.f : gscale / s;
-            float4* dst = reinterpret_cast<float4*>(dlogits + p * C);
+            for (int i = 0; i < C; ++i) vl = (i == lab) ? v[i] : vl;
+            if (!ign) lsum += (double)(m + logf(s) - vl);
+            if (dlogits) {
+                const float inv = ign ? 0.f : gscale / s;
 #pragma unroll
-            for (int i = 0; i < C / 4; ++i) {
-                float4 t;
-                t.x = e[4*i] * inv - ((4*i) == lab ? gscale : 0.f);
-                t.y = e[4*i+1] * inv - ((4*i+1) == lab ? gscale : 0.f);
-                t.z = e[4*i+2] * inv - ((4*i+2) == lab ? gscale : 0.f);
-                t.w = e[4*i+3] * inv - ((4*i+3) == lab ? gscale : 0.f);
-                dst[i] = t;
-                csum[4*i] += t.x; csum[4*i+1] += t.y; csum[4*i+2] += t.z; csum[4*i+3] += t.w;
+                for (int i = 0; i < U; ++i) {
+                    float4 t;
+                    t.x = e[4*i] * inv - ((4*i) == lab ? gscale : 0.f);
+                    t.y = e[4*i+1] * inv - ((4*i+1) == lab ? gscale : 0.f);
+                    t.z = e[4*i+2] * inv - ((4*i+2) == lab ? gscale : 0.f);
+                    t.w = e[4*i+3] * inv - ((4*i+3) == lab ? gscale : 0.f);
+                    g[i] = t;
+                    csum[4*i] += t.x; csum[4*i+1] += t.y; csum[4*i+2] += t.z; csum[4*i+3] += t.w;
+                }
             }
+        }
+        if (dlogits) {
+            if constexpr (U > 1) {
+#pragma unroll
+                for (int i = 0; i < U; ++i) wp[lane * U + i] = g[i];
+                __builtin_amdgcn_wave_barrier();
+                float4* dst = reinterpret_cast<float4*>(dlogits) + p0 * U;
+#pragma unroll
+                for (int i = 0; i < U; ++i) { const int u = i * 64 + lane; if (p0 * U + u < nunits) dst[u] = wp[u]; }
+                __builtin_amdgcn_wave_barrier();
+            } else if (p < npix) reinterpret_cast<float4*>(dlogits)[p] = g[0];
         }
     }
     const double t = block_sum(lsum, sh);

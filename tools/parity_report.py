@@ -86,7 +86,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_r03.json"))
     ap.add_argument("--variants", default="f6,f4,direct")
-    ap.add_argument("--precisions", default="fp32", help="comma list out of fp32,f32x3 (run for the f6 variant only)")
+    ap.add_argument("--precisions", default="fp32", help="comma list out of fp32,f32x3,f32x2 (run for the f6 variant only)")
     ap.add_argument("--threads", type=int, default=32)
     ap.add_argument("--skip-f64", action="store_true")
     ap.add_argument("--small", action="store_true", help="quarter-size c2 / c3 (plumbing check)")
