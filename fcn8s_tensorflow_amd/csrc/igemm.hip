@@ -408,19 +408,31 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // below 2^-17 |x|) and a*b taken as lo*hi + hi*lo + hi*hi -- three MFMAs and two conversions per value instead of six and three.  A
 // reduced-precision arithmetic (between TF32's 11 bits and fp32's 24), never used by the fp32 mode.
 template <int NS> struct Bf16Pieces { bf16x8 p[NS]; };          // p[0] = hi, p[1] = mid (or lo for NS = 2), p[2] = lo
+// (two values at a time, in the shapes of v_cvt_pk_bf16_f32 / v_pk_add_f32: one packed conversion per pair and piece, the pieces
+//  widened again by a shift / a mask of the packed word -- 2.5 VALU instructions per value for two pieces; element by element hipcc
+//  spent 3.3.  Same conversions (RNE), same bits.)
 template <int NS>
 static __device__ __forceinline__ void split_bf16(const float (&x)[8], Bf16Pieces<NS>& o)
 {
-    float r[8];
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w[NS];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { o.p[0][i] = (__bf16)x[i]; r[i] = x[i] - (float)o.p[0][i]; }
-    if constexpr (NS == 3) {
+    for (int i = 0; i < 4; ++i) {
+        f32x2 r = {x[2 * i], x[2 * i + 1]};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { o.p[1][i] = (__bf16)r[i]; r[i] = r[i] - (float)o.p[1][i]; o.p[2][i] = (__bf16)r[i]; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o.p[1][i] = (__bf16)r[i];
+        for (int k = 0; k < NS; ++k) {
+            const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+            w[k][i] = pk;
+            if (k + 1 < NS) {
+                const f32x2 back = {__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
+                r = r - back;
+            }
+        }
     }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) o.p[k] = __builtin_bit_cast(bf16x8, w[k]);
 }
 template <int NS>
 static __device__ __forceinline__ f32x16 mfma_split(const Bf16Pieces<NS>& a, const Bf16Pieces<NS>& b, f32x16 acc)
