@@ -42,7 +42,7 @@ def pmc_traffic(kernel):
                 out = {"hbm_mb_per_launch": v["hbm_mb_per_launch"], "fetch_mb": v["fetch_mb_per_launch"],
                        "write_mb": v["write_mb_per_launch"], "source": d.get("source"),
                        "traffic_source": "committed profile (profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                         "command on an MI355X, tools/collect_profiles.sh) -- not measured in this run; `--live-traffic` re-measures it"}
+                                         "command on an MI355X, tools/collect_profiles.sh) -- not measured in this run (`--live-traffic` re-measures it; the default one-GPU training run does)"}
                 if "fetch_mb_per_launch_uncorrected" in v:      # the x2 FETCH_SIZE correction is an upper bound for 64-byte row-segment loads
                     out["hbm_mb_per_launch_lower_bound"] = round(v["fetch_mb_per_launch_uncorrected"] + v["write_mb_per_launch"], 3)
                 return out
@@ -53,7 +53,8 @@ def pmc_traffic(kernel):
 
 def live_traffic(argv, kernel):
     """Re-measure the HBM traffic of `kernel` now: two rocprofv3 PMC passes (FETCH_SIZE; WRITE_SIZE; --kernel-trace only, as the
-    microarch guide prescribes) over a 2-step run of this same command, summarised by tools/pmc_summary.py.  Minutes, hence opt-in."""
+    microarch guide prescribes) over a 2-step run of this same command, summarised by tools/pmc_summary.py.  About a minute; runs after
+    the timed regions, so it cannot disturb them.  Any failure falls back to the committed profile."""
     import shutil
     import subprocess
     import tempfile
@@ -62,11 +63,11 @@ def live_traffic(argv, kernel):
     tmp = tempfile.mkdtemp(prefix="fcn8s_pmc_")
     env = dict(os.environ, TMPDIR="/tmp")
     keep = [a for a in argv if a not in ("--live-traffic",)]
-    base = [sys.executable, os.path.abspath(__file__)] + keep + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--repeats", "1"]
+    base = [sys.executable, os.path.abspath(__file__)] + keep + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--repeats", "1", "--no-live-traffic"]
     try:
         for ctr, d in (("FETCH_SIZE", "f"), ("WRITE_SIZE", "w")):
             subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, d), "-o", "b", "--"] + base,
-                           env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
+                           env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
         import glob
         f = glob.glob(os.path.join(tmp, "f", "**", "b_counter_collection.csv"), recursive=True)[0]
         w = glob.glob(os.path.join(tmp, "w", "**", "b_counter_collection.csv"), recursive=True)[0]
@@ -79,7 +80,7 @@ def live_traffic(argv, kernel):
             if n.startswith("voidfcn8s::" + kernel.replace(" ", "")) or n.startswith("fcn8s::" + kernel.replace(" ", "")):
                 return {"hbm_mb_per_launch": v["hbm_mb_per_launch"], "fetch_mb": v["fetch_mb_per_launch"], "write_mb": v["write_mb_per_launch"],
                         "hbm_mb_per_launch_lower_bound": round(v["fetch_mb_per_launch_uncorrected"] + v["write_mb_per_launch"], 3),
-                        "traffic_source": "live (two rocprofv3 --pmc passes of this command, 2 steps each, run by bench.py --live-traffic)"}
+                        "traffic_source": "live (two rocprofv3 --pmc passes of this command, 2 steps each, run by bench.py after its timed regions)"}
     except Exception as ex:
         return {"error": repr(ex)}
     finally:
@@ -287,8 +288,10 @@ def main():
     ap.add_argument("--repeats", type=int, default=3, help="how many times the timed region of exactly --steps steps is run; value / ms_per_step "
                     "are those of the median region, all regions are listed in `timed_regions_ms_per_step`")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="library algorithm option (fcn8s_set_option), e.g. winograd_tile=4")
-    ap.add_argument("--live-traffic", action="store_true", help="measure roofline.traffic now with two rocprofv3 --pmc passes (minutes) instead of "
-                    "reading the committed profile")
+    ap.add_argument("--live-traffic", action="store_true", help="measure roofline.traffic now with two rocprofv3 --pmc passes (about a minute) instead of "
+                    "reading the committed profile.  Default: on for the plain one-GPU training run with the CPU baseline (the driver's "
+                    "bench line), when rocprofv3 is on PATH and this process is not itself being profiled; off otherwise")
+    ap.add_argument("--no-live-traffic", action="store_true", help="never spawn the rocprofv3 passes; roofline.traffic comes from profiles/pmc_traffic.json")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
@@ -462,7 +465,9 @@ def main():
         if dom:
             g = kern[dom]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-            tr = live_traffic(sys.argv[1:], dom) if args.live_traffic else None
+            profiled = any(k.startswith(("ROCPROF", "ROCP_")) or k == "HSA_TOOLS_LIB" for k in os.environ)
+            auto_live = world == 1 and not under_launcher and args.mode == "train" and not args.no_cpu_baseline and not profiled
+            tr = live_traffic(sys.argv[1:], dom) if (args.live_traffic or auto_live) and not args.no_live_traffic else None
             if not tr or "error" in tr:
                 tr = pmc_traffic(dom)
             # f32x3 mode: six bf16 MFMA products per fp32-equivalent multiply-add -> peak = bf16 dense peak / 6
