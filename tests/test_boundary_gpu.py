@@ -108,6 +108,23 @@ def test_bench_self_launches_two_ranks():
     assert len(out["timed_regions_ms_per_step"]) == 3 and out["timed_regions"]["min_ms_per_step"] <= out["ms_per_step"] <= out["timed_regions"]["max_ms_per_step"]
 
 
+def test_bench_measures_roofline_traffic_live():
+    """The plain one-GPU training run re-measures roofline.traffic itself (two rocprofv3 --pmc passes of its own command after the timed
+    regions); here forced on a small case: the line must say the figure is live and carry both counters of the dominant kernel."""
+    import shutil
+    if not shutil.which("rocprofv3"):
+        pytest.skip("rocprofv3 not on PATH")
+    out = _run_bench("--steps", "2", "--warmup", "1", "--batch", "2", "--height", "128", "--width", "128", "--no-cpu-baseline", "--live-traffic", timeout=900)
+    r = out["roofline"]
+    d = r["traffic_detail"]
+    assert d and "error" not in d, d
+    assert d["traffic_source"].startswith("live"), d
+    assert r["traffic"] == round(d["hbm_mb_per_launch"] * 1e6) and d["fetch_mb"] > 0 and d["write_mb"] > 0
+    quiet = _run_bench("--steps", "2", "--warmup", "1", "--batch", "2", "--height", "128", "--width", "128", "--no-cpu-baseline")
+    src = (quiet["roofline"].get("traffic_detail") or {}).get("traffic_source", "committed")
+    assert not src.startswith("live")               # side benches stay quick: live only on request or in the default headline run
+
+
 def test_bench_under_torchrun_one_rank_rccl():
     """bench.py launched the way the driver launches it for N > 1 -- `python -m torch.distributed.run ... bench.py --gpus N` -- with the one
     rank this box has: the process group is RCCL (backend nccl), the three bucketed all-reduces run through it inside every step, and the
