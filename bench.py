@@ -67,7 +67,7 @@ def live_traffic(argv, kernel):
     try:
         for ctr, d in (("FETCH_SIZE", "f"), ("WRITE_SIZE", "w")):
             subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, d), "-o", "b", "--"] + base,
-                           env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+                           env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
         import glob
         f = glob.glob(os.path.join(tmp, "f", "**", "b_counter_collection.csv"), recursive=True)[0]
         w = glob.glob(os.path.join(tmp, "w", "**", "b_counter_collection.csv"), recursive=True)[0]
