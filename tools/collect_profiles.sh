@@ -19,6 +19,7 @@ python bench.py --steps 10 --warmup 3 --optimizer adam --no-cpu-baseline > $OUT/
 python bench.py --steps 10 --warmup 3 --precision f32x3 --no-cpu-baseline > $OUT/bench_train_bs16_f32x3.json 2>> $OUT/bench.err
 python bench.py --steps 10 --warmup 3 --height 1024 --width 2048 --batch 4 --precision f32x3 --no-cpu-baseline > $OUT/bench_c5_2048x1024_bs4_f32x3.json 2>> $OUT/bench.err
 python bench.py --steps 10 --warmup 3 --mode infer --batch 1 --precision f32x3 --no-cpu-baseline > $OUT/bench_infer_bs1_f32x3.json 2>> $OUT/bench.err
+python bench.py --steps 10 --warmup 3 --mode infer --batch 1 --precision f32x2 --no-cpu-baseline > $OUT/bench_infer_bs1_f32x2.json 2>> $OUT/bench.err
 python bench.py --steps 10 --warmup 3 --precision bf16_fwd --no-cpu-baseline > $OUT/bench_train_bs16_bf16_fwd.json 2>> $OUT/bench.err
 python bench.py --steps 10 --warmup 3 --height 1024 --width 2048 --batch 4 --precision bf16_fwd --no-cpu-baseline > $OUT/bench_c5_2048x1024_bs4_bf16_fwd.json 2>> $OUT/bench.err
 for p in f32x2 bf16_fwd_x2; do

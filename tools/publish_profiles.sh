@@ -18,7 +18,7 @@ cp $SRC/pmc_summary.txt                  $DST/${R}_pmc_summary.txt
 cp $SRC/pmc_clock_summary.txt            $DST/${R}_pmc_clock_summary.txt
 cp $SRC/pmc_clock.json                   $DST/${R}_pmc_clock.json
 cp $SRC/pmc_traffic.json                 $DST/pmc_traffic.json
-for f in bench_c5_2048x1024_bs4_bf16_fc bench_c5_2048x1024_bs4_fp32 bench_e2e_train_bs16 bench_2ranks_one_gpu_gloo bench_train_bs16_f32x3 bench_c5_2048x1024_bs4_f32x3 bench_infer_bs1_f32x3 bench_train_bs16_bf16_fwd bench_c5_2048x1024_bs4_bf16_fwd bench_train_bs16_f32x2 bench_c5_2048x1024_bs4_f32x2 bench_train_bs16_bf16_fwd_x2 bench_c5_2048x1024_bs4_bf16_fwd_x2; do
+for f in bench_c5_2048x1024_bs4_bf16_fc bench_c5_2048x1024_bs4_fp32 bench_e2e_train_bs16 bench_2ranks_one_gpu_gloo bench_train_bs16_f32x3 bench_c5_2048x1024_bs4_f32x3 bench_infer_bs1_f32x3 bench_train_bs16_bf16_fwd bench_c5_2048x1024_bs4_bf16_fwd bench_train_bs16_f32x2 bench_c5_2048x1024_bs4_f32x2 bench_train_bs16_bf16_fwd_x2 bench_c5_2048x1024_bs4_bf16_fwd_x2 bench_infer_bs1_f32x2; do
     [ -f $SRC/$f.json ] && cp $SRC/$f.json $DST/${R}_$f.json
 done
 [ -f $SRC/layer_bench.txt ] && cp $SRC/layer_bench.txt $DST/${R}_layer_bench.txt
