@@ -265,3 +265,39 @@ def test_config5_shape_2048x1024_bs4_properties():
     loss, step = e.train_step(imgd, labd, 1e-4, keep_prob=0.5)
     assert np.isfinite(loss) and step == 1
     e.close()
+
+
+def test_batch_of_64_is_its_four_images_sixteen_times():
+    """Size independence at the top of the range (1024x512 x 64 images: 160 GB of the 288 GB, Winograd images of 4 G elements -- past
+    every 32-bit index): a batch made of four images repeated sixteen times must give the loss, all 42 gradient tensors (the loss is a
+    mean over the batch) and, image by image, the logits of the four-image batch.  A wrapped index anywhere shows up in the late images."""
+    import torch
+    from fcn8s_tensorflow_amd.engine import Engine
+    R, REP, H, W, C = 4, 16, 512, 1024, 20
+    P = orc.init_params(C, seed=4, decoder_std_scale=30.0, bias_std=0.05)
+    img, lab = orc.synthetic_batch(R, H, W)
+    imgd, labd = torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda()
+    e = Engine(C)
+    e.set_params(P)
+    loss4 = e.forward_backward(imgd, labd, keep_prob=1.0, l2_rate=1e-3)
+    g4 = e.flat_grads.clone()
+    logits4 = e.activation("logits", (R, H, W, C))
+    scale = float(np.abs(logits4).max())
+    big_i, big_l = imgd.repeat(REP, 1, 1, 1).contiguous(), labd.repeat(REP, 1, 1).contiguous()
+    loss64 = e.forward_backward(big_i, big_l, keep_prob=1.0, l2_rate=1e-3)
+    assert abs(loss64 - loss4) < 1e-5 * max(1.0, abs(loss4)), (loss64, loss4)
+    g64 = e.flat_grads
+    worst = ("", 0.0)
+    for name, (shape, off) in e.specs.items():
+        n = int(np.prod(shape))
+        a, b = g64[off:off + n], g4[off:off + n]
+        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+        if err > worst[1]:
+            worst = (name, err)
+    print("batch 64 vs its 4 images: loss %.7f / %.7f, worst gradient difference %s %.2e of the tensor's largest entry" % (loss64, loss4, worst[0], worst[1]))
+    assert worst[1] < 1e-4, worst              # fp32 summation order only (16x more rows per reduction)
+    logits64 = e.activation("logits", (R * REP, H, W, C))
+    for i in (0, 5, 37, 62, 63):
+        d = float(np.abs(logits64[i] - logits4[i % R]).max())
+        assert d <= 1e-5 * scale, (i, d, scale)
+    e.close()
