@@ -102,7 +102,6 @@ bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, 
 // conv1_1 forward with bias + ReLU on the LDS-DMA gather kernel (Cout = 64 only; returns false otherwise): x4 [N,H,W,4], w48 [48][64]
 // (taps x 4 channels, rows 36..47 zero), zero16 = 16 zero bytes in device memory (what taps outside the image read)
 extern int g_conv1_tiled;      // 1 (default): spatial-tile kernel; 0: LDS-DMA gather kernel
-extern int g_gemm_tail_split;  // 1 (default): the positions of a batched GEMM that would form a mostly empty last round of 128 x 128 blocks run on 64 x 64 tiles
 extern int g_conv1_wgrad_mfma; // 1 (default): conv1_1 weight gradient on the matrix core; 0: the VALU kernel
 bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, hipStream_t s);
 

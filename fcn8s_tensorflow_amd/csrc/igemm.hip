@@ -891,7 +891,6 @@ __global__ __launch_bounds__(256, 4) void conv1_tile_kernel(const Conv1Args p)
 }
 
 int g_conv1_tiled = 1;       // 0: the LDS-DMA gather kernel (A/B, tests)
-int g_gemm_tail_split = 1;   // 0: one tile shape per batched GEMM launch (A/B)
 // x4: [N,H,W,4] (b, g, r, 0); w48: [48][64] = taps 0..8 x 4 channels, rows 36..47 zero; y = relu(conv + bias), [N,H,W,64]
 bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, hipStream_t s)
 {
@@ -1018,29 +1017,7 @@ void launch_igemm(const IgemmArgs& a, int phases, hipStream_t s)
     } else {
         const double c128 = cost(128, 128, 3, 1.0), c64x128 = cost(64, 128, 4, 0.9), c64 = cost(64, 64, 4, 0.85);
         // (at most 32 rows -- fc6 at batch 1 -- the 64-row kernels idle the waves of the padded half, see gemm_glds_body)
-        if (a.M > 64 && c128 <= c64x128 && c128 <= c64) {
-            // All blocks of such a launch take the same time, so it runs in rounds of 768 resident blocks (256 CUs x 3) and a last, partly filled
-            // round costs a whole one: fc6 forward at 16 images is 6272 blocks = 8.17 rounds, run as 9 (3.14 ms against 2.88 per 16 images at
-            // 64 images).  When that round would be less than 0.6 full, only as many whole Winograd positions as fill the full rounds go on
-            // 128 x 128 tiles; the remaining positions take 64 x 64 tiles -- 4 blocks per CU of a quarter of the work each, so the tail is a
-            // fraction of a round.  Same K order per output element in both kernels: the result does not depend on where the cut falls.
-            constexpr long long slots = 256 * 3;
-            const long long tiles = ((a.M + 127) / 128) * (a.Cout / 128), blocks = tiles * phases;
-            if (g_gemm_tail_split && a.batched && phases > 1 && a.Cout % 128 == 0 && blocks > 2 * slots) {
-                const long long rounds = blocks / slots, rem = blocks % slots;
-                const int zp = (int)(rounds * slots / tiles);
-                if (rem > 0 && rem * 10 < slots * 6 && zp >= 1 && zp < phases) {
-                    launch_igemm_cfg<128, 128, 2, 2>(a, zp, s);
-                    const char* head = g_last_kernel;
-                    IgemmArgs t = a;
-                    t.x += (long long)zp * a.x_batch_stride; t.w += (long long)zp * a.w_phase_stride; t.y += (long long)zp * a.y_batch_stride;
-                    launch_igemm_cfg<64, 64, 2, 2>(t, phases - zp, s);
-                    g_last_kernel = head;               // the profile keys the whole operation by the kernel that did (nearly) all of it
-                    return;
-                }
-            }
-            launch_igemm_cfg<128, 128, 2, 2>(a, phases, s);   // (K-tile depth 32 and 256x64 tiles measured slower: fewer resident waves)
-        }
+        if (a.M > 64 && c128 <= c64x128 && c128 <= c64) launch_igemm_cfg<128, 128, 2, 2>(a, phases, s);   // (K-tile depth 32 and 256x64 tiles measured slower: fewer resident waves)
         else if (c64x128 <= c64)                        launch_igemm_cfg<64, 128, 2, 2>(a, phases, s);
         else                                            launch_igemm_cfg<64, 64, 2, 2>(a, phases, s);
     }

@@ -1592,11 +1592,9 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
         }
         if (k == "conv1_tiled") { fcn8s::g_conv1_tiled = value ? 1 : 0; return FCN8S_OK; }
         if (k == "conv1_wgrad_mfma") { fcn8s::g_conv1_wgrad_mfma = value ? 1 : 0; return FCN8S_OK; }
-        if (k == "gemm_tail_split") { fcn8s::g_gemm_tail_split = value ? 1 : 0; return FCN8S_OK; }
         return fail(nullptr, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown process-wide option '" + k + "'");
     }
     if (k == "conv1_tiled") { fcn8s::g_conv1_tiled = value ? 1 : 0; return FCN8S_OK; }       // process-wide, also reachable through a model
-    if (k == "gemm_tail_split") { fcn8s::g_gemm_tail_split = value ? 1 : 0; return FCN8S_OK; }
     if (k == "conv1_wgrad_mfma") { fcn8s::g_conv1_wgrad_mfma = value ? 1 : 0; return FCN8S_OK; }
     int* slot = model_option(m, k);
     if (!slot) return fail(m, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown option '" + k + "'");
@@ -1635,11 +1633,9 @@ int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value)
         if (k == "op_split_pieces") { *value = g_op_split; return FCN8S_OK; }
         if (k == "conv1_tiled") { *value = fcn8s::g_conv1_tiled; return FCN8S_OK; }
         if (k == "conv1_wgrad_mfma") { *value = fcn8s::g_conv1_wgrad_mfma; return FCN8S_OK; }
-        if (k == "gemm_tail_split") { *value = fcn8s::g_gemm_tail_split; return FCN8S_OK; }
         return FCN8S_ERR_NOT_FOUND;
     }
     if (k == "conv1_tiled") { *value = fcn8s::g_conv1_tiled; return FCN8S_OK; }
-    if (k == "gemm_tail_split") { *value = fcn8s::g_gemm_tail_split; return FCN8S_OK; }
     if (k == "conv1_wgrad_mfma") { *value = fcn8s::g_conv1_wgrad_mfma; return FCN8S_OK; }
     const int* slot = model_option(const_cast<fcn8s_model*>(m), k);
     if (!slot) return FCN8S_ERR_NOT_FOUND;
