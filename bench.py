@@ -32,6 +32,12 @@ PEAK_HBM_GBS = 8000.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0           # dense bf16 MFMA peak (same guide); the f32x3 mode's roof is a sixth of it
 
 
+DTYPE_LABEL = {"fp32": "f32", "bf16_fc": "bf16_fc+f32", "f32x3": "f32x3 (fp32 operands as three bf16 pieces on the bf16 MFMA, fp32 accumulate)",
+               "bf16_fwd": "bf16 forward (conv3_1..conv5_3, fc6, fc7: bf16-rounded operands, fp32 accumulate) + f32x3 for every other GEMM",
+               "f32x2": "f32x2 (fp32 operands as two bf16 pieces = 16 significand bits on the bf16 MFMA, fp32 accumulate; reduced precision)",
+               "bf16_fwd_x2": "bf16 forward (conv3_1..conv5_3, fc6, fc7: bf16-rounded operands, fp32 accumulate) + f32x2 (two bf16 pieces per operand) for every other GEMM"}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
     (profiles/pmc_traffic.json, written by tools/pmc_summary.py); None if not collected."""
@@ -223,6 +229,8 @@ def e2e(args):
         train_gen.next_ids()
     feeder_ips = 4 * N / (time.perf_counter() - tf0)
     model = FCN8s(vgg16_dir='synthetic:0', num_classes=20, device_id=args.device or 0)
+    if args.precision != "fp32":
+        model.engine.set_precision(args.precision)
     sched = lambda step: 1e-4
     import contextlib
     import io
@@ -250,7 +258,7 @@ def e2e(args):
     out = {"metric": "training images/sec at 1024x512 bs16, end to end (PNG decode + augmentation + H2D + FCN8s.train)",
            "value": round(value, 3), "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic PNG files (%d pairs, generated in %.1f s)" % (4 * N, t_data),
+           "dtype": DTYPE_LABEL[args.precision], "data": "synthetic PNG files (%d pairs, generated in %.1f s)" % (4 * N, t_data),
            "config": {"workload": "FCN8s.train() from BatchGenerator(workers=%d, flip 0.5, one-hot contract) over %dx%d PNG pairs, %d images/step, TF-Adam, loss fetched every step"
                                   % (args.workers, W, H, N), "global_batch": N, "parallelism": "dp1"},
            "resident_input_images_per_sec": round(resident, 3), "e2e_over_resident": round(value / resident, 4),
@@ -498,10 +506,7 @@ def main():
             "metric": "training images/sec at 1024x512 bs16" if args.mode == "train" else "inference images/sec at 1024x512",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16_fc": "bf16_fc+f32", "f32x3": "f32x3 (fp32 operands as three bf16 pieces on the bf16 MFMA, fp32 accumulate)",
-                      "bf16_fwd": "bf16 forward (conv3_1..conv5_3, fc6, fc7: bf16-rounded operands, fp32 accumulate) + f32x3 for every other GEMM",
-                      "f32x2": "f32x2 (fp32 operands as two bf16 pieces = 16 significand bits on the bf16 MFMA, fp32 accumulate; reduced precision)",
-                      "bf16_fwd_x2": "bf16 forward (conv3_1..conv5_3, fc6, fc7: bf16-rounded operands, fp32 accumulate) + f32x2 (two bf16 pieces per operand) for every other GEMM"}[args.precision], "data": "synthetic",
+            "dtype": DTYPE_LABEL[args.precision], "data": "synthetic",
             "config": {"workload": "FCN-8s (VGG-16, fc6 7x7, 20 classes) %s step, %dx%d, %d images/GPU, %s, keep_prob 0.5"
                                    % (args.mode, W, H, N, "TF-Adam" if args.optimizer == "adam" else "SGD+momentum"),
                        "global_batch": N * world, "parallelism": "dp%d" % world},
