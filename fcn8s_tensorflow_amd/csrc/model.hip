@@ -54,7 +54,10 @@ struct fcn8s_model {
     std::vector<ParamInfo> params;
     std::map<std::string, int> index;
     size_t total = 0;
-    size_t bucket_off[FCN8S_NUM_BUCKETS] = {0, 0, 0}, bucket_n[FCN8S_NUM_BUCKETS] = {0, 0, 0};
+    size_t bucket_off[FCN8S_MAX_BUCKETS] = {0}, bucket_n[FCN8S_MAX_BUCKETS] = {0};
+    hipEvent_t bucket_ev[FCN8S_MAX_BUCKETS] = {nullptr};                 // recorded right behind the last kernel that writes into the bucket
+    bool bucket_final[FCN8S_MAX_BUCKETS] = {false};                      // ... this backward pass (fcn8s_bucket_wait)
+    float* dz7_cur = nullptr; bool defer_fc_cur = false;                 // handed from backward phase 0 (decoder, fc7 weights) to phase 1 (fc6)
     float *d_params = nullptr, *d_grads = nullptr, *d_m = nullptr, *d_v = nullptr, *d_wt = nullptr;
     bool own_params = false, own_grads = false;
     float *d_w1pad = nullptr, *d_tph[3] = {nullptr, nullptr, nullptr};
@@ -151,8 +154,10 @@ int fail(fcn8s_model* m, int code, const std::string& msg)
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+const int kNumBuckets = 4;      // (what fcn8s_num_buckets reports; callers size nothing by a compile-time constant)
+
 void build_param_table(int C, const int widths[7], int fc6k, std::vector<ParamInfo>& out, size_t& total,
-                       size_t boff[3], size_t bn[3])
+                       size_t boff[FCN8S_MAX_BUCKETS], size_t bn[FCN8S_MAX_BUCKETS])
 {
     out.clear();
     size_t off = 0;
@@ -164,7 +169,7 @@ void build_param_table(int C, const int widths[7], int fc6k, std::vector<ParamIn
         out.push_back(p);
     };
     int cin = 3;
-    size_t conv4_start = 0, fc6_start = 0;
+    size_t conv4_start = 0, fc6_start = 0, fc7_start = 0;
     for (int b = 0; b < 5; ++b)
         for (int i = 1; i <= kConvsPerBlock[b]; ++i) {
             char nm[32]; snprintf(nm, sizeof nm, "conv%d_%d", b + 1, i);
@@ -176,6 +181,7 @@ void build_param_table(int C, const int widths[7], int fc6k, std::vector<ParamIn
     fc6_start = off;
     add("fc6/weights", {fc6k, fc6k, widths[4], widths[5]});
     add("fc6/biases", {widths[5]});
+    fc7_start = off;
     add("fc7/weights", {1, 1, widths[5], widths[6]});
     add("fc7/biases", {widths[6]});
     add("pool3_1x1/kernel", {1, 1, widths[2], C});
@@ -191,10 +197,14 @@ void build_param_table(int C, const int widths[7], int fc6k, std::vector<ParamIn
     add("fc7_pool4_pool3_conv2d_trans/kernel", {16, 16, C, C});
     add("fc7_pool4_pool3_conv2d_trans/bias", {C});
     total = off;
-    // gradient buckets in backward-production order: {fc6.., decoder} | {conv4, conv5} | {conv1..conv3}
-    boff[0] = fc6_start;   bn[0] = total - fc6_start;
-    boff[1] = conv4_start; bn[1] = fc6_start - conv4_start;
-    boff[2] = 0;           bn[2] = conv4_start;
+    // gradient buckets = contiguous slices in backward-production order: {fc7, decoder} (68 MB, final first) | {fc6} (411 MB) |
+    // {conv4, conv5} (52 MB) | {conv1..conv3} (7 MB).  fc6 has a bucket of its own so that the exchange of the other 68 MB of the head does
+    // not wait for the 3 ms of fc6's weight-gradient GEMMs, and fc6's own starts the moment they end (round 3 had one 479 MB bucket).
+    for (int i = 0; i < FCN8S_MAX_BUCKETS; ++i) { boff[i] = 0; bn[i] = 0; }
+    boff[0] = fc7_start;   bn[0] = total - fc7_start;
+    boff[1] = fc6_start;   bn[1] = fc7_start - fc6_start;
+    boff[2] = conv4_start; bn[2] = fc6_start - conv4_start;
+    boff[3] = 0;           bn[3] = conv4_start;
 }
 
 void resolve_cfg(const fcn8s_config* cfg, int& C, int widths[7], int& fc6k)
@@ -1196,7 +1206,16 @@ void l2_grad(fcn8s_model* m, const char* kernel)
     if (m->l2_rate != 0.f) launch_axpy(Gp(m, kernel), Wp(m, kernel), m->l2_rate, (long long)P(m, kernel).numel, m->stream);
 }
 
-void backward_bucket0(fcn8s_model* m)
+// the gradients of bucket b are final behind the last kernel queued on `s`: record the event fcn8s_bucket_wait hands to other streams
+void mark_bucket_final(fcn8s_model* m, int b, hipStream_t s)
+{
+    if (!m->bucket_ev[b]) hipEventCreateWithFlags(&m->bucket_ev[b], hipEventDisableTiming);
+    hipEventRecord(m->bucket_ev[b], s);
+    m->bucket_final[b] = true;
+}
+
+// backward phase 0: the decoder and fc7's weight gradient (bucket 0 = {fc7, decoder})
+void backward_head(fcn8s_model* m)
 {
     hipStream_t s = m->stream;
     const int N = m->N, H = m->H, W = m->W, C = m->C;
@@ -1239,7 +1258,21 @@ void backward_bucket0(fcn8s_model* m)
         hipEvent_t ev = defer_event(m); hipEventRecord(ev, s);
         m->deferred.emplace_back(ev, [m, dz7, N, h5, w5](hipStream_t ss) {
             conv_wgrad(m, "fc7_wgrad", A(m, "fc6"), dz7, Gp(m, "fc7/weights"), Gp(m, "fc7/biases"), N, h5, w5, m->widths[5], m->widths[6], 1, 1.f, ss); });
-    } else conv_wgrad(m, "fc7_wgrad", A(m, "fc6"), dz7, Gp(m, "fc7/weights"), Gp(m, "fc7/biases"), N, h5, w5, m->widths[5], m->widths[6], 1, 1.f, s);
+    } else {
+        conv_wgrad(m, "fc7_wgrad", A(m, "fc6"), dz7, Gp(m, "fc7/weights"), Gp(m, "fc7/biases"), N, h5, w5, m->widths[5], m->widths[6], 1, 1.f, s);
+        mark_bucket_final(m, 0, s);
+    }
+    m->dz7_cur = dz7; m->defer_fc_cur = defer_fc;
+}
+
+// backward phase 1: fc7's data gradient, fc6 (bucket 1 = {fc6}: final behind its weight gradient, before its data gradient is queued)
+void backward_fc6(fcn8s_model* m)
+{
+    hipStream_t s = m->stream;
+    const int N = m->N, H = m->H, W = m->W;
+    const int h5 = H / 32, w5 = W / 32;
+    const float inv_keep = (m->train_mode && m->keep_prob < 1.f) ? 1.f / m->keep_prob : 1.f;
+    float* dz7 = m->dz7_cur; const bool defer_fc = m->defer_fc_cur;
     { Epi e; e.mask = A(m, "fc6"); e.mask_scale = inv_keep;
       conv_same(m, "fc7_dgrad", dz7, WTp(m, "fc7/weights"), m->gbuf[1], N, h5, w5, m->widths[6], m->widths[5], 1, e, s); }
     // fc6
@@ -1249,8 +1282,10 @@ void backward_bucket0(fcn8s_model* m)
         hipEvent_t ev = defer_event(m); hipEventRecord(ev, s);
         m->deferred.emplace_back(ev, [m, dz6, N, h5, w5](hipStream_t ss) {
             conv_wgrad(m, "fc6_wgrad", A(m, "pool5"), dz6, Gp(m, "fc6/weights"), Gp(m, "fc6/biases"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, 1.f, ss, 0, "fc6", false, nullptr, 2); });
-    } else
-    conv_wgrad(m, "fc6_wgrad", A(m, "pool5"), m->gbuf[1], Gp(m, "fc6/weights"), Gp(m, "fc6/biases"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, 1.f, s, 0, "fc6");
+    } else {
+        conv_wgrad(m, "fc6_wgrad", A(m, "pool5"), m->gbuf[1], Gp(m, "fc6/weights"), Gp(m, "fc6/biases"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, 1.f, s, 0, "fc6");
+        mark_bucket_final(m, 1, s);
+    }
     { Epi e; e.dgrad = 1; e.w_fwd = Wp(m, "fc6/weights"); e.lazy_wt = 1;      // (flipped + transposed copy only if the adjoint path is not taken)
       conv_same(m, "fc6_dgrad", m->gbuf[1], WTp(m, "fc6/weights"), m->gbuf[0], N, h5, w5, m->widths[5], m->widths[4], m->fc6k, e, s, 0, "fc6"); }
     m->gcur = 0;   // gbuf[0] holds d(pool5)
@@ -1338,22 +1373,34 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
     }
 }
 
-// level_cap: 1 for the bucket-by-bucket API (bucket 0 -- fc6, fc7, decoder -- is final when its call returns, so that its all-reduce can start
-// at once; buckets 1 and 2 are final after the last call, see fcn8s_bucket_complete_after), 2 for the fused step
+int bucket_complete_after(const fcn8s_model* m, int bucket)
+{
+    if (m->defer_wgrad == 0 || (bucket <= 1 && m->defer_wgrad < 3)) return bucket;
+    return kNumBuckets - 1;           // weight gradients of conv3_1 .. conv5_3 (level 3: fc6 / fc7 too) are held back until the last call
+}
+
+// level_cap: 1 for the bucket-by-bucket API (buckets 0 and 1 -- fc7 + decoder, fc6 -- are final when their calls return, so that their
+// all-reduces can start at once; with deferred weight gradients the conv buckets are final after the last call, see
+// fcn8s_bucket_complete_after), 2 for the fused step
 int do_backward_bucket(fcn8s_model* m, int bucket, int level_cap)
 {
     if (!m->have_loss || !m->train_mode) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: call fcn8s_forward_loss first");
-    if (bucket != m->next_bucket) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: buckets must be run in order 0,1,2");
+    if (bucket != m->next_bucket) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: buckets must be run in order 0, 1, ... fcn8s_num_buckets() - 1");
     if (bucket == 0) {
         m->defer_level_now = m->defer_wgrad >= 3 ? 2 : std::min(m->defer_wgrad, level_cap);      // 3: the caller does not consume bucket 0 early
         if (m->profile && m->profile_detail) m->defer_level_now = 0;      // per-layer timing wants one kernel at a time
         m->deferred.clear(); m->ev_next = 0;
         m->dm_prefilled.clear();                                           // (a promise left over from a backward pass that ended in an error)
         m->on_tail = false; m->launch_stream = nullptr;                    // (a backward pass that ended in an error may have left them set)
-        backward_bucket0(m);
+        for (int b = 0; b < kNumBuckets; ++b) m->bucket_final[b] = false;
+        backward_head(m);
     }
-    else if (bucket == 1) backward_blocks(m, 5, 4);
+    else if (bucket == 1) backward_fc6(m);
+    else if (bucket == 2) backward_blocks(m, 5, 4);
     else { backward_blocks(m, 3, 1); join_deferred(m); }
+    // whatever this call completed and no kernel-exact point has marked yet (the conv buckets; everything held back to the last call)
+    for (int b = 0; b < kNumBuckets; ++b)
+        if (!m->bucket_final[b] && bucket_complete_after(m, b) == bucket && (level_cap == 1 || bucket == kNumBuckets - 1)) mark_bucket_final(m, b, m->stream);
     m->next_bucket = bucket + 1;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(m, FCN8S_ERR_HIP, std::string("backward launch: ") + hipGetErrorString(e));
@@ -1381,7 +1428,7 @@ size_t fcn8s_param_floats(const fcn8s_config* cfg)
 {
     if (!cfg || cfg->num_classes <= 0) return 0;
     int C, widths[7], k; resolve_cfg(cfg, C, widths, k);
-    std::vector<ParamInfo> t; size_t total, bo[3], bn[3];
+    std::vector<ParamInfo> t; size_t total, bo[FCN8S_MAX_BUCKETS], bn[FCN8S_MAX_BUCKETS];
     build_param_table(C, widths, k, t, total, bo, bn);
     return total;
 }
@@ -1390,7 +1437,7 @@ int fcn8s_layout_num_params(const fcn8s_config* cfg)
 {
     if (!cfg || cfg->num_classes <= 0) return 0;
     int C, widths[7], k; resolve_cfg(cfg, C, widths, k);
-    std::vector<ParamInfo> t; size_t total, bo[3], bn[3];
+    std::vector<ParamInfo> t; size_t total, bo[FCN8S_MAX_BUCKETS], bn[FCN8S_MAX_BUCKETS];
     build_param_table(C, widths, k, t, total, bo, bn);
     return (int)t.size();
 }
@@ -1398,7 +1445,7 @@ int fcn8s_layout_param(const fcn8s_config* cfg, int index, char name_out[64], in
 {
     if (!cfg || cfg->num_classes <= 0) return FCN8S_ERR_BAD_ARG;
     int C, widths[7], k; resolve_cfg(cfg, C, widths, k);
-    std::vector<ParamInfo> t; size_t total, bo[3], bn[3];
+    std::vector<ParamInfo> t; size_t total, bo[FCN8S_MAX_BUCKETS], bn[FCN8S_MAX_BUCKETS];
     build_param_table(C, widths, k, t, total, bo, bn);
     if (index < 0 || index >= (int)t.size()) return FCN8S_ERR_BAD_ARG;
     if (name_out) { strncpy(name_out, t[index].name.c_str(), 63); name_out[63] = 0; }
@@ -1407,11 +1454,12 @@ int fcn8s_layout_param(const fcn8s_config* cfg, int index, char name_out[64], in
     if (off) *off = (int64_t)t[index].offset;
     return FCN8S_OK;
 }
+int fcn8s_layout_num_buckets(const fcn8s_config* cfg) { return (cfg && cfg->num_classes > 0) ? kNumBuckets : 0; }
 int fcn8s_layout_bucket(const fcn8s_config* cfg, int bucket, size_t* off, size_t* n)
 {
-    if (!cfg || cfg->num_classes <= 0 || bucket < 0 || bucket >= FCN8S_NUM_BUCKETS) return FCN8S_ERR_BAD_ARG;
+    if (!cfg || cfg->num_classes <= 0 || bucket < 0 || bucket >= kNumBuckets) return FCN8S_ERR_BAD_ARG;
     int C, widths[7], k; resolve_cfg(cfg, C, widths, k);
-    std::vector<ParamInfo> t; size_t total, bo[3], bn[3];
+    std::vector<ParamInfo> t; size_t total, bo[FCN8S_MAX_BUCKETS], bn[FCN8S_MAX_BUCKETS];
     build_param_table(C, widths, k, t, total, bo, bn);
     if (off) *off = bo[bucket];
     if (n) *n = bn[bucket];
@@ -1490,6 +1538,7 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->tail_done) hipEventDestroy(m->tail_done);
     if (m->side_done) hipEventDestroy(m->side_done);
     for (auto e : m->ev_pool) hipEventDestroy(e);
+    for (auto& e : m->bucket_ev) if (e) { hipEventDestroy(e); e = nullptr; }
     for (auto& kv : m->u_train) if (kv.second) hipFree(kv.second);
     if (m->d_wino_u) hipFree(m->d_wino_u);
     for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
@@ -1684,9 +1733,10 @@ int fcn8s_get_param(fcn8s_model* m, const char* name, float* host, size_t n) { r
 int fcn8s_get_grad(fcn8s_model* m, const char* name, float* host, size_t n) { return xfer_named(m, m ? m->d_grads : nullptr, name, host, n, false); }
 void* fcn8s_param_buffer(fcn8s_model* m, size_t* n) { if (!m) return nullptr; if (n) *n = m->total; return m->d_params; }
 void* fcn8s_grad_buffer(fcn8s_model* m, size_t* n) { if (!m) return nullptr; if (n) *n = m->total; return m->d_grads; }
+int fcn8s_num_buckets(const fcn8s_model* m) { return m ? kNumBuckets : 0; }
 int fcn8s_bucket_range(const fcn8s_model* m, int b, size_t* off, size_t* n)
 {
-    if (!m || b < 0 || b >= FCN8S_NUM_BUCKETS) return FCN8S_ERR_BAD_ARG;
+    if (!m || b < 0 || b >= kNumBuckets) return FCN8S_ERR_BAD_ARG;
     if (off) *off = m->bucket_off[b];
     if (n) *n = m->bucket_n[b];
     return FCN8S_OK;
@@ -1730,15 +1780,23 @@ int fcn8s_forward_loss(fcn8s_model* m, const void* images, int dtype, const uint
 
 int fcn8s_backward_bucket(fcn8s_model* m, int bucket)
 {
-    if (!m || bucket < 0 || bucket >= FCN8S_NUM_BUCKETS) return fail(m, FCN8S_ERR_BAD_ARG, "bad bucket");
+    if (!m || bucket < 0 || bucket >= kNumBuckets) return fail(m, FCN8S_ERR_BAD_ARG, "bad bucket");
     return do_backward_bucket(m, bucket, 1);
+}
+
+int fcn8s_bucket_wait(fcn8s_model* m, int bucket, void* hip_stream)
+{
+    if (!m || bucket < 0 || bucket >= kNumBuckets) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_bucket_wait: bad bucket");
+    if (!m->bucket_final[bucket] || !m->bucket_ev[bucket])
+        return fail(m, FCN8S_ERR_STATE, "fcn8s_bucket_wait: the bucket's gradients are not queued yet (call fcn8s_backward_bucket up to fcn8s_bucket_complete_after(bucket) first)");
+    HIPCHK(m, hipStreamWaitEvent((hipStream_t)hip_stream, m->bucket_ev[bucket], 0));
+    return FCN8S_OK;
 }
 
 int fcn8s_bucket_complete_after(const fcn8s_model* m, int bucket)
 {
-    if (!m || bucket < 0 || bucket >= FCN8S_NUM_BUCKETS) return -1;
-    if (m->defer_wgrad == 0 || (bucket == 0 && m->defer_wgrad < 3)) return bucket;
-    return FCN8S_NUM_BUCKETS - 1;           // weight gradients of conv3_1 .. conv5_3 are held back until the last call (deferred weight gradients)
+    if (!m || bucket < 0 || bucket >= kNumBuckets) return -1;
+    return bucket_complete_after(m, bucket);
 }
 
 int fcn8s_apply_update(fcn8s_model* m, int optimizer, float lr, float grad_scale)
@@ -1780,7 +1838,7 @@ int fcn8s_train_step(fcn8s_model* m, const void* images, int dtype, const uint8_
 {
     if (m && m->frozen) fcn8s_freeze_params(m, 0);      // parameters are about to change (or a training pass starts): leave the frozen state
     int rc = fcn8s_forward_loss(m, images, dtype, labels, N, H, W, keep_prob, l2_rate, where); if (rc) return rc;
-    for (int b = 0; b < FCN8S_NUM_BUCKETS; ++b) { rc = do_backward_bucket(m, b, 2); if (rc) return rc; }
+    for (int b = 0; b < kNumBuckets; ++b) { rc = do_backward_bucket(m, b, 2); if (rc) return rc; }
     rc = fcn8s_apply_update(m, FCN8S_OPT_TF_ADAM, lr, 1.f); if (rc) return rc;
     if (loss_out) { rc = fcn8s_read_loss(m, loss_out); if (rc) return rc; }
     if (step_out) *step_out = m->step;

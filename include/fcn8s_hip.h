@@ -37,7 +37,6 @@ extern "C" {
 #define FCN8S_ERR_HIP       4
 #define FCN8S_ERR_STATE     5   /* call order violated (e.g. backward before forward) */
 #define FCN8S_ERR_NOT_FOUND 6   /* unknown variable / activation name */
-
 #define FCN8S_HOST   0
 #define FCN8S_DEVICE 1
 
@@ -48,7 +47,8 @@ extern "C" {
 #define FCN8S_OPT_SGD_MOMENTUM 1  /* BASELINE.json config 3 */
 #define FCN8S_OPT_NONE         2  /* caller updates the parameter buffer itself (torch optimizer over views) */
 
-#define FCN8S_NUM_BUCKETS 3       /* gradient buckets in backward-production order */
+#define FCN8S_ERR_RCCL      7   /* a collective of the library's own RCCL communicator failed (fcn8s_comm_*) */
+#define FCN8S_MAX_BUCKETS 8       /* upper bound of fcn8s_num_buckets(): gradient buckets in backward-production order */
 #define FCN8S_NUM_STAGE_SLOTS 3   /* host-input staging slots (fcn8s_stage_inputs) */
 
 #define FCN8S_PREC_F32     0      /* everything exact fp32 (the reference's arithmetic; default) */
@@ -88,6 +88,7 @@ size_t      fcn8s_param_floats(const fcn8s_config* cfg);             /* size of 
 int         fcn8s_layout_num_params(const fcn8s_config* cfg);
 int         fcn8s_layout_param(const fcn8s_config* cfg, int index, char name_out[64], int32_t* ndim,
                                int64_t shape[4], int64_t* offset_floats);
+int         fcn8s_layout_num_buckets(const fcn8s_config* cfg);       /* = fcn8s_num_buckets of a model made from cfg */
 int         fcn8s_layout_bucket(const fcn8s_config* cfg, int bucket, size_t* offset_floats, size_t* nfloats);
 
 /* ---- lifetime: FCN8s.__init__ :19-125 / close :946-952 ------------------- */
@@ -107,6 +108,7 @@ int    fcn8s_get_param(fcn8s_model* m, const char* name, float* host, size_t nfl
 int    fcn8s_get_grad(fcn8s_model* m, const char* name, float* host, size_t nfloats);
 void*  fcn8s_param_buffer(fcn8s_model* m, size_t* nfloats);          /* DEVICE pointers, flat, name->offset via param_info */
 void*  fcn8s_grad_buffer(fcn8s_model* m, size_t* nfloats);
+int    fcn8s_num_buckets(const fcn8s_model* m);                       /* a run-time value (4 today): size nothing by a constant */
 int    fcn8s_bucket_range(const fcn8s_model* m, int bucket, size_t* offset_floats, size_t* nfloats);
 int    fcn8s_init_params(fcn8s_model* m, uint64_t seed);              /* synthetic init: He-normal VGG, truncated-normal decoder (:159-160) */
 
@@ -127,17 +129,22 @@ int fcn8s_train_step(fcn8s_model* m, const void* images, int image_dtype, const 
                      int N, int H, int W, float learning_rate, float keep_prob, float l2_rate,
                      int where, float* loss_out, int64_t* step_out);
 
-/* split-phase form for data-parallel training: forward + loss, then backward
- * one gradient bucket at a time, then the update.  Bucket b's gradients are final
- * (stream-ordered) when the call fcn8s_backward_bucket(m, fcn8s_bucket_complete_after(m, b))
- * has returned: bucket 0 (fc6, fc7, decoder: 479 of the 538 MB) at its own call, so that its
- * all-reduce overlaps the rest of the backward pass; with deferred weight gradients
- * (option "defer_wgrad", default on) buckets 1 and 2 (59 MB) at the last call.
+/* split-phase form for data-parallel training (no counterpart in the single-device reference): forward + loss, then
+ * the backward pass in fcn8s_num_buckets() calls, then the update.  The gradient buffer is cut into that many contiguous buckets in
+ * backward-production order -- {fc7, decoder} (68 MB) | {fc6} (411 MB) | {conv4, conv5} (52 MB) | {conv1 .. conv3} (7 MB) at full
+ * width -- and bucket b's gradients are final (stream-ordered) once the call
+ * fcn8s_backward_bucket(m, fcn8s_bucket_complete_after(m, b)) has returned.  By default ("defer_wgrad" 0) that is call b itself, so
+ * every bucket's exchange overlaps the rest of the backward pass; with defer_wgrad >= 1 the conv buckets (2, 3) are final only at the
+ * last call, with defer_wgrad = 3 all four are.
+ * fcn8s_bucket_wait makes another stream (RCCL's, a torch side stream) wait for exactly the last kernel that writes into bucket b
+ * -- for fc6 that is its weight gradient, 3 ms of data gradient earlier than the end of call 1 -- without blocking the host; it is
+ * valid once the completing call has returned and until the next fcn8s_forward_loss.
  * `grad_scale` multiplies the gradients inside the update (1/world_size).      */
 int fcn8s_forward_loss(fcn8s_model* m, const void* images, int image_dtype, const uint8_t* label_ids,
                        int N, int H, int W, float keep_prob, float l2_rate, int where);
 int fcn8s_backward_bucket(fcn8s_model* m, int bucket);
 int fcn8s_bucket_complete_after(const fcn8s_model* m, int bucket);
+int fcn8s_bucket_wait(fcn8s_model* m, int bucket, void* hip_stream);
 int fcn8s_apply_update(fcn8s_model* m, int optimizer, float learning_rate, float grad_scale);
 int fcn8s_read_loss(fcn8s_model* m, float* loss_out);                /* synchronises */
 
@@ -202,7 +209,7 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *     "defer_wgrad"       0    deferred weight gradients (an experiment kept for its evidence, profiles/r03_overlap_*.txt: co-running gains nothing on
  *                              gfx950, on shared or on disjoint CUs): 1 = the weight-gradient GEMMs of conv3_1 .. conv5_3 are held back and run on a
  *                              second stream beside the end of the data-gradient chain (blocks 2 and 1); 2 = fc6 / fc7 as well (fused
- *                              fcn8s_train_step only: the bucket API keeps bucket 0 final at its own call, for an early all-reduce);
+ *                              fcn8s_train_step only: the bucket API keeps buckets 0 and 1 final at their own calls, for an early all-reduce);
  *                              3 = fc6 / fc7 through the bucket API too (fcn8s_bucket_complete_after then names the last call for every bucket)
  *     "defer_start_block" 2    the VGG block at whose backward pass the held-back GEMMs are launched
  *     "defer_tail_cus"    0    > 0: from that block on the data-gradient chain runs on a stream restricted to the first n CUs and the held-back

@@ -68,7 +68,11 @@ def test_config2_inference_1024x512_bs1_vs_oracle():
     assert safe.mean() > 0.95, safe.mean()
     ref_arg = np.argmax(orc.softmax(ref), -1)
     assert (pred[safe] == ref_arg[safe]).all(), int((pred[safe] != ref_arg[safe]).sum())
-    assert (pred != ref_arg).mean() < 1e-3                  # and the ambiguous pixels are a negligible fraction
+    # ... and the ambiguous pixels are a handful: at most 16 of the 524 288 (measured 2-7 over decoders and boxes, every one of them
+    # a pixel whose two best logits are closer than the logit error itself; profiles/parity_r04.json holds the count)
+    n_diff = int((pred != ref_arg).sum())
+    print("config 2: %d of %d pixels differ from the oracle's argmax, all at top-2 margins <= 2e-3 x logit scale" % (n_diff, pred.size))
+    assert n_diff <= 16, n_diff
     # with the reference's own decoder init (sigma 1e-3 / 1e-2, fcn8s_tensorflow.py:159-160) the logits are tiny;
     # check them in relative terms as well
     P2 = orc.init_params(20, seed=0)
@@ -262,6 +266,103 @@ def test_config5_shape_2048x1024_bs4_properties():
         n = int(np.prod(shape))
         a, b = g_full[off:off + n], g_mean[off:off + n]
         assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-12, name
+    loss, step = e.train_step(imgd, labd, 1e-4, keep_prob=0.5)
+    assert np.isfinite(loss) and step == 1
+    e.close()
+
+
+@pytest.mark.parametrize("mode", ["bf16_fwd", "bf16_fwd_x2"])
+def test_config5_bf16_fwd_2048x1024_bs4(mode):
+    """BASELINE.json configs[4] in its own arithmetic at its own size: 2048x1024, 4 images per GPU, forward convolutions conv3_1 .. conv5_3,
+    fc6 and fc7 on the bf16 MFMA with fp32 accumulation (`bf16_fwd`; `bf16_fwd_x2` = the same forward with the remaining GEMMs on two bf16
+    pieces per operand).  The CPU oracle cannot run the whole graph at this size inside a test, so:
+      (i)   each bf16 layer of image 3 of the batch is compared with the oracle's convolution of the bf16-rounded operands applied to the
+            DEVICE's own input of that layer (identical rounding; only the fp32 summation order differs): conv3_1, conv4_2, conv5_3, fc6,
+            fc7 at <= 1e-4 of the layer's largest output;
+      (ii)  closed-form loss / last-bias gradient at zero decoder weights, and batch linearity of the gradients;
+      (iii) image k of the batch predicts what image k predicts alone."""
+    import torch
+    from fcn8s_tensorflow_amd.engine import Engine
+    N, H, W, C = 4, 1024, 2048, 20
+    e = Engine(C, seed=5, precision=mode)
+    img, lab = orc.synthetic_batch(N, H, W)
+    imgd, labd = torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda()
+    P = orc.init_params(C, seed=6, decoder_std_scale=6.0, bias_std=0.05)
+    e.set_params(P)
+    e.profile(2); e.profile_reset()
+    loss = e.forward_backward(imgd, labd, keep_prob=1.0)
+    prof = e.profile_results()
+    e.profile(0)
+    assert np.isfinite(loss)
+    k256 = [v for k, v in prof.items() if k.startswith("kernel:") and "conv_bf16_256_kernel" in k]
+    assert k256 and sum(int(v["launches"]) for v in k256) >= 11, {k: v["launches"] for k, v in prof.items() if k.startswith("kernel:")}
+    mine, other = ("_x3_kernel", "_x2_kernel") if mode == "bf16_fwd" else ("_x2_kernel", "_x3_kernel")
+    assert any(mine in k for k in prof) and not any(k.startswith("kernel:") and ("gemm_glds_kernel<" in k or "wgrad_glds_kernel<" in k or other in k) for k in prof)
+
+    # (i) per-layer arithmetic, image 3 of the batch
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    wd = e.widths
+    K = 3
+    shapes = {"pool2": (N, H // 4, W // 4, wd[1]), "conv3_1": (N, H // 4, W // 4, wd[2]), "conv4_1": (N, H // 8, W // 8, wd[3]), "conv4_2": (N, H // 8, W // 8, wd[3]),
+              "conv5_2": (N, H // 16, W // 16, wd[4]), "conv5_3": (N, H // 16, W // 16, wd[4]), "pool5": (N, H // 32, W // 32, wd[4]),
+              "fc6": (N, H // 32, W // 32, wd[5]), "fc7": (N, H // 32, W // 32, wd[6])}
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    worst = {}
+    for src, dst, wname, bname in (("pool2", "conv3_1", "conv3_1/filter", "conv3_1/biases"), ("conv4_1", "conv4_2", "conv4_2/filter", "conv4_2/biases"),
+                                   ("conv5_2", "conv5_3", "conv5_3/filter", "conv5_3/biases"), ("pool5", "fc6", "fc6/weights", "fc6/biases"),
+                                   ("fc6", "fc7", "fc7/weights", "fc7/biases")):
+        x = torch.from_numpy(e.activation(src, shapes[src])[K:K + 1]).permute(0, 3, 1, 2)
+        wk = torch.from_numpy(P[wname]); k = wk.shape[0]
+        want = torch.relu(torch.nn.functional.conv2d(rb(x), rb(wk).permute(3, 2, 0, 1), torch.from_numpy(P[bname]), padding=(k - 1) // 2)).permute(0, 2, 3, 1).numpy()
+        got = e.activation(dst, shapes[dst])[K:K + 1]
+        assert np.abs(want).max() > 0
+        worst[dst] = float(np.abs(got - want).max() / np.abs(want).max())
+        del x, want, got
+    print("config 5 [%s] 2048x1024 x 4: per-layer error against the same-rounding convolution of the device's own input:" % mode,
+          ", ".join("%s %.2e" % kv for kv in worst.items()))
+    for k, v in worst.items():
+        assert v < 1e-4, (k, v)
+
+    # (iii) image k of the batch equals image k alone -- up to what bf16 operand rounding does to fp32 summation-order differences: a batch of
+    #       one takes other tile shapes (and F(4x4) for conv1_2 / conv2_x is chosen per launch size), an activation that differs in its last
+    #       fp32 bit can round to the other bf16 neighbour (a 2^-8 step), so the logits agree to a few 1e-3 of their scale, not to fp32
+    #       round-off; the argmax must agree wherever the top-2 margin exceeds twice the bound
+    full = np.asarray(torch.as_tensor(e.predict(imgd, argmax=True)).cpu())[K]
+    lg_full = e.activation("logits", (N, H, W, C))[K].copy()
+    one = np.asarray(torch.as_tensor(e.predict(imgd[K:K + 1], argmax=True)).cpu())[0]
+    lg_one = e.activation("logits", (1, H, W, C))[0]
+    scale = max(1.0, float(np.abs(lg_one).max()))
+    d = float(np.abs(lg_full - lg_one).max()) / scale
+    srt = np.sort(lg_one, -1)
+    safe = (srt[..., -1] - srt[..., -2]) > 2e-2 * scale
+    print("config 5 [%s]: image %d in the batch vs alone: logits differ by %.2e of their scale, argmax on %d of %d pixels (%d of them above the margin)"
+          % (mode, K, d, int((full != one).sum()), one.size, int((full != one)[safe].sum())))
+    assert d < 1e-2, d
+    assert safe.mean() > 0.5 and (full[safe] == one[safe]).all()
+    del lg_full, lg_one, srt
+
+    # (ii) closed forms and batch linearity
+    zero = {k: np.zeros(s[0], np.float32) for k, s in e.specs.items() if "1x1" in k or "trans" in k}
+    e.set_params(zero)
+    loss = e.forward_backward(imgd, labd, keep_prob=1.0)
+    assert abs(loss - np.log(C)) < 1e-5
+    gb = e.grad_view("fc7_pool4_pool3_conv2d_trans/bias").cpu().numpy()
+    assert np.abs(gb - (1.0 / C - np.bincount(lab.ravel(), minlength=C) / lab.size)).max() < 1e-6
+    assert float(e.grad_view("conv1_1/filter").abs().max()) == 0.0 and float(e.grad_view("fc6/weights").abs().max()) == 0.0
+    e.set_params(P)
+    e.forward_backward(imgd, labd, keep_prob=1.0)
+    g_full = e.flat_grads.clone()
+    e.forward_backward(imgd[:2], labd[:2], keep_prob=1.0)
+    g_a = e.flat_grads.clone()
+    e.forward_backward(imgd[2:], labd[2:], keep_prob=1.0)
+    g_mean = 0.5 * (g_a + e.flat_grads)
+    for name in ("conv1_2/filter", "conv3_1/filter", "conv4_2/filter", "conv5_3/filter", "fc6/weights", "fc7/weights", "fc7/biases", "fc7_1x1/kernel",
+                 "fc7_pool4_pool3_conv2d_trans/kernel"):
+        shape, off = e.specs[name]
+        n = int(np.prod(shape))
+        a, b = g_full[off:off + n], g_mean[off:off + n]
+        assert float(b.abs().max()) > 0
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-12, (name, float((a - b).abs().max()) / float(b.abs().max()))
     loss, step = e.train_step(imgd, labd, 1e-4, keep_prob=0.5)
     assert np.isfinite(loss) and step == 1
     e.close()

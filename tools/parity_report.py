@@ -2,7 +2,7 @@
 """Parity report: the HIP path (through the C ABI) against the CPU oracle at BASELINE.json's sizes, as numbers in a tracked file
 instead of pytest dots.  Runs on the GPU box:
 
-    python tools/parity_report.py --out gpurun_out/parity_r03.json          (then copy to profiles/)
+    python tools/parity_report.py --out gpurun_out/parity_r04.json          (then copy to profiles/)
 
 For each algorithm variant of the 3x3 stack -- "f6" (the default: Winograd F(6x6,3x3) + F(4x4,4x4) for fc6), "f4" (largest tile
 4x4), "direct" (no Winograd anywhere: summation order is then the only difference from the oracle) -- it records
@@ -39,6 +39,10 @@ VARIANTS = {
 }
 
 
+# what the oracle has to round for a precision mode to be "the same arithmetic" (oracle.forward / loss_and_grads keywords)
+ORACLE_KW = {"bf16_fc": {"bf16_fc": True}, "bf16_fwd": {"bf16_fc": True, "bf16_convs": True}, "bf16_fwd_x2": {"bf16_fc": True, "bf16_convs": True}}
+
+
 def make_engine(options, precision="fp32"):
     from fcn8s_tensorflow_amd.engine import Engine
     return Engine(20, options=options, precision=precision)
@@ -59,6 +63,7 @@ def logits_block(e, P, img, ref, ref_arg):
         "max_abs_logit_error": float(np.abs(logits - ref).max()),
         "max_logit_error_over_scale": float(np.abs(logits - ref).max() / scale),
         "pixels": int(pred.size),
+        "argmax_mismatch_total": int(wrong.sum()),
         "argmax_mismatch_margin_gt_2e-3": int((wrong & (margin > thr)).sum()),
         "argmax_mismatch_margin_le_2e-3": int((wrong & (margin <= thr)).sum()),
         "pixels_with_margin_le_2e-3": int((margin <= thr).sum()),
@@ -84,9 +89,10 @@ def summarize(errs):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_r03.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_r04.json"))
     ap.add_argument("--variants", default="f6,f4,direct")
-    ap.add_argument("--precisions", default="fp32", help="comma list out of fp32,f32x3,f32x2 (run for the f6 variant only)")
+    ap.add_argument("--precisions", default="fp32", help="comma list out of fp32,f32x3,f32x2,bf16_fc,bf16_fwd,bf16_fwd_x2 (run for the f6 variant only; the bf16 modes "
+                    "are compared with the oracle applying the same operand rounding to the same layers)")
     ap.add_argument("--threads", type=int, default=32)
     ap.add_argument("--skip-f64", action="store_true")
     ap.add_argument("--small", action="store_true", help="quarter-size c2 / c3 (plumbing check)")
@@ -106,31 +112,42 @@ def main():
     P_hi = orc.init_params(20, seed=0, decoder_std_scale=30.0, bias_std=0.05)            # logits O(100): real margins
     P_lo = orc.init_params(20, seed=1, decoder_std_scale=5.0, bias_std=0.05)             # logits O(1-10): north_star's absolute 1e-3
     P_g = orc.init_params(20, seed=4, decoder_std_scale=30.0, bias_std=0.05)             # the gradient case of tests/test_fullsize_gpu.py
-    fwd = {}
-    for cname, img in (("c1", img1), ("c2", img2)):
-        for pname, P in (("decoder_x30", P_hi), ("decoder_x5", P_lo)):
-            ref = orc.forward(P, img)
-            fwd[(cname, pname)] = (P, img, ref, np.argmax(orc.softmax(ref), -1))
     onehot = orc.one_hot(lab2, 20).astype(np.float32)
-    loss32, g32, _ = orc.loss_and_grads(P_g, img2, onehot, l2_rate=1e-3)
-    _, acts_g = orc.forward(P_g, img2, keep=True)
-    own_routes, route_gaps = orc.pool_routes(acts_g)
-    acts_g = {k: acts_g[k] for k in orc.branch_layers()}
-    rep["oracle_seconds_fp32"] = time.time() - t0
-    g64 = None
-    if not args.skip_f64:
-        t1 = time.time()
-        loss64, g64, _ = orc.loss_and_grads(P_g, img2, onehot, l2_rate=1e-3, dtype=torch.float64)
-        rep["oracle_seconds_fp64"] = time.time() - t1
-        e = grad_errors(g32, g64)
-        rep["oracle_fp32_vs_fp64"] = {"loss_fp32": loss32, "loss_fp64": loss64, "summary": summarize(e), "per_tensor": e}
+
+    def oracle_side(kw, want_f64):
+        """Everything the comparisons need from the oracle for one arithmetic (kw = the operand rounding it applies)."""
+        fwd = {}
+        for cname, img in (("c1", img1), ("c2", img2)):
+            for pname, P in (("decoder_x30", P_hi), ("decoder_x5", P_lo)):
+                ref = orc.forward(P, img, **kw)
+                fwd[(cname, pname)] = (P, img, ref, np.argmax(orc.softmax(ref), -1))
+        loss32, g32, _ = orc.loss_and_grads(P_g, img2, onehot, l2_rate=1e-3, **kw)
+        _, acts_g = orc.forward(P_g, img2, keep=True, **kw)
+        own_routes, route_gaps = orc.pool_routes(acts_g)
+        acts_g = {k: acts_g[k] for k in orc.branch_layers()}
+        g64 = loss64 = None
+        if want_f64:
+            loss64, g64, _ = orc.loss_and_grads(P_g, img2, onehot, l2_rate=1e-3, dtype=torch.float64, **kw)
+        return {"fwd": fwd, "loss32": loss32, "g32": g32, "acts_g": acts_g, "own_routes": own_routes, "route_gaps": route_gaps, "g64": g64, "loss64": loss64}
+
+    sides = {"": oracle_side({}, not args.skip_f64)}
+    rep["oracle_seconds_fp32_and_fp64"] = time.time() - t0
+    if sides[""]["g64"] is not None:
+        e = grad_errors(sides[""]["g32"], sides[""]["g64"])
+        rep["oracle_fp32_vs_fp64"] = {"loss_fp32": sides[""]["loss32"], "loss_fp64": sides[""]["loss64"], "summary": summarize(e), "per_tensor": e}
     # ---- GPU side ---------------------------------------------------------------------------------------------------------------------
     runs = [(v, "fp32") for v in args.variants.split(",") if v]
     runs += [("f6", p) for p in args.precisions.split(",") if p and p != "fp32"]
     for vname, prec in runs:
         key = vname if prec == "fp32" else vname + "/" + prec
+        kw = ORACLE_KW.get(prec, {})
+        skey = json.dumps(kw, sort_keys=True) if kw else ""
+        if skey not in sides:
+            sides[skey] = oracle_side(kw, False)           # (the float64 run of a rounded graph says nothing new)
+        S = sides[skey]
+        fwd, loss32, g32, acts_g, own_routes, route_gaps, g64 = S["fwd"], S["loss32"], S["g32"], S["acts_g"], S["own_routes"], S["route_gaps"], S["g64"]
         e = make_engine(VARIANTS[vname], prec)
-        block = {"options": VARIANTS[vname], "precision": prec}
+        block = {"options": VARIANTS[vname], "precision": prec, "oracle_rounding": kw}
         for (cname, pname), (P, img, ref, ref_arg) in fwd.items():
             block.setdefault(cname, {})[pname] = logits_block(e, P, img, ref, ref_arg)
         e.set_params(P_g)
@@ -168,11 +185,11 @@ def main():
         block["c3"]["relu_units_differing_from_oracle"] = n_diff
         block["c3"]["largest_activation_at_a_differing_unit_over_layer_max"] = worst
         e.close()
-        _, ga32, _ = orc.loss_and_grads(P_g, img2, onehot, l2_rate=1e-3, branches=br, routes=rt)
+        _, ga32, _ = orc.loss_and_grads(P_g, img2, onehot, l2_rate=1e-3, branches=br, routes=rt, **kw)
         ea32 = grad_errors(g, ga32)
         block["c3"]["aligned_vs_oracle_fp32"] = {"summary": summarize(ea32), "per_tensor": ea32}
         if g64 is not None:
-            _, ga64, _ = orc.loss_and_grads(P_g, img2, onehot, l2_rate=1e-3, dtype=torch.float64, branches=br, routes=rt)
+            _, ga64, _ = orc.loss_and_grads(P_g, img2, onehot, l2_rate=1e-3, dtype=torch.float64, branches=br, routes=rt, **kw)
             ea64 = grad_errors(g, ga64)
             block["c3"]["aligned_vs_oracle_fp64"] = {"summary": summarize(ea64), "per_tensor": ea64}
             eo = grad_errors(ga32, ga64)
@@ -184,7 +201,7 @@ def main():
               "\n   c3 relu units differing:", n_diff, "of", n_units, "worst", worst, "; pool routes differing:", n_rdiff, "of", n_win, "worst gap", worst_gap,
               "\n   c3 aligned vs fp32 oracle:", block["c3"]["aligned_vs_oracle_fp32"]["summary"],
               "\n   c3 aligned vs fp64 oracle:", block["c3"].get("aligned_vs_oracle_fp64", {}).get("summary"), flush=True)
-    if g64 is not None:
+    if "oracle_fp32_vs_fp64" in rep:
         print("oracle fp32 vs fp64:", rep["oracle_fp32_vs_fp64"]["summary"])
     rep["seconds"] = time.time() - t0
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
