@@ -9,7 +9,7 @@ resident in HBM.  `python bench.py --gpus N --steps K --warmup W` prints ONE JSO
 line on rank 0.  For N > 1 it is either launched under torchrun (RANK / WORLD_SIZE
 in the environment) or, called plainly, re-launches itself as N ranks through
 `python -m torch.distributed.run`: one process per GPU, gradients all-reduced over
-RCCL/xGMI in three buckets that overlap with the backward pass (weak scaling:
+RCCL/xGMI in four buckets that overlap with the backward pass (weak scaling:
 16 images per GPU).  `--mode e2e` drives FCN8s.train() from BatchGenerator over
 generated PNG files instead (host feeder + H2D included), `--mode infer` the
 serving loop.
@@ -98,6 +98,63 @@ def _median(xs):
     xs = sorted(xs)
     n = len(xs)
     return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def physical_cores():
+    """Physical cores of this host (distinct thread-sibling sets in sysfs); os.cpu_count() if sysfs does not say."""
+    try:
+        import glob
+        sib = {open(f).read().strip() for f in glob.glob("/sys/devices/system/cpu/cpu[0-9]*/topology/thread_siblings_list")}
+        return len(sib) or (os.cpu_count() or 1)
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline_full(h, w, optimizer="sgd"):
+    """SURVEY 8d's CPU baseline to the letter (`--cpu-baseline-full`; minutes, so not part of the default run): the oracle on ALL
+    physical cores of this host (count printed), 3 warm-up + 10 timed runs per leg, median: (c1) 256x256 forward + argmax,
+    1024x512 bs1 forward, 1024x512 bs2 training step (fwd + bwd + optimizer)."""
+    import torch
+    from oracle import fcn8s_oracle as orc
+    cores = physical_cores()
+    torch.set_num_threads(cores)
+    P = orc.init_params(20, seed=0)
+    t_start = time.perf_counter()
+
+    def timed(fn, warm=3, runs=10):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(runs):
+            a = time.perf_counter(); fn(); ts.append(time.perf_counter() - a)
+        return ts
+
+    img1 = np.random.default_rng(7).integers(0, 256, (1, 256, 256, 3), dtype=np.uint8)
+    t_c1 = timed(lambda: np.argmax(orc.softmax(orc.forward(P, img1)), -1))
+    img, lab = orc.synthetic_batch(2, h, w)
+    t_c2 = timed(lambda: orc.forward(P, img[:1]))
+    onehot = orc.one_hot(lab, 20).astype(np.float32)
+    state = {"P": P, "m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}, "t": 0}
+
+    def train_step():
+        Pc, m, v_ = state["P"], state["m"], state["v"]
+        _, g, _ = orc.loss_and_grads(Pc, img, onehot)
+        state["t"] += 1
+        for k in Pc:
+            if optimizer == "adam":
+                Pc[k], m[k], v_[k] = orc.tf_adam_step(Pc[k], g[k], m[k], v_[k], state["t"], 1e-4)
+            else:
+                Pc[k], m[k] = orc.sgd_momentum_step(Pc[k], g[k], m[k], 1e-4)
+
+    t_c3 = timed(train_step)
+    med = _median(t_c3)
+    return {"value": round(2.0 / med, 4), "unit": "images/sec", "cores": cores, "host_threads_available": os.cpu_count(), "kind": "port",
+            "sample": "SURVEY 8d to the letter: bs2 training step (fwd+bwd+%s) at %dx%d on torch-CPU fp32, all %d physical cores, 3 warm-up + 10 timed, "
+                      "median %.2f s (CPU restatement of the reference graph; TF1 unavailable)" % ("TF-Adam" if optimizer == "adam" else "SGD+momentum", w, h, cores, med),
+            "train_step_s": [round(t, 2) for t in t_c3],
+            "c1_256x256_fwd_argmax": {"median_s": round(_median(t_c1), 3), "runs": len(t_c1), "images_per_sec": round(1.0 / _median(t_c1), 3)},
+            "fwd_%dx%d_bs1" % (w, h): {"median_s": round(_median(t_c2), 3), "runs": len(t_c2), "images_per_sec": round(1.0 / _median(t_c2), 3)},
+            "total_s": round(time.perf_counter() - t_start, 1)}
 
 
 def cpu_baseline(h, w, seconds_budget=200.0, optimizer="sgd"):
@@ -255,7 +312,8 @@ def e2e(args):
     torch.cuda.synchronize()
     dres = time.perf_counter() - t2
     value, resident = N * args.steps / dt, N * args.steps / dres
-    out = {"metric": "training images/sec at 1024x512 bs16, end to end (PNG decode + augmentation + H2D + FCN8s.train)",
+    out = {"metric": "training images/sec at %dx%d bs%d, end to end (PNG decode + augmentation + H2D + FCN8s.train)" % (W, H, N)
+                     + ("" if args.precision == "fp32" else " (%s arithmetic)" % args.precision),
            "value": round(value, 3), "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": DTYPE_LABEL[args.precision], "data": "synthetic PNG files (%d pairs, generated in %.1f s)" % (4 * N, t_data),
@@ -286,6 +344,10 @@ def main():
                     help="fp32 = the reference's arithmetic (the headline number); bf16_fc = BASELINE config 5's mode (forward "
                          "fc6/fc7 with bf16 operands on the bf16 MFMA, fp32 accumulate) -- reported as dtype 'bf16_fc+f32'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="time the CPU baseline exactly as SURVEY 8d words it (bs2 training step, 3 warm-up + 10 "
+                    "timed, all physical cores) instead of the bounded default sample; takes minutes")
+    ap.add_argument("--comm", default="torch", choices=["torch", "native"], help="who moves the gradient buckets for --gpus > 1: torch.distributed "
+                    "(the default) or the library's own RCCL communicator behind the C ABI (fcn8s_comm_init / fcn8s_allreduce_bucket)")
     ap.add_argument("--mode", default="train", choices=["train", "infer", "e2e"],
                     help="train = the headline step on HBM-resident synthetic batches; infer = serving loop; e2e = FCN8s.train() fed by "
                          "BatchGenerator from generated PNG files (decode + augmentation + H2D inside the timed region)")
@@ -333,6 +395,13 @@ def main():
     mark("process group up; creating engine")
     options = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.option}
     eng = Engine(20, device_id=dev, seed=1234 + rank, precision=args.precision, options=options)
+    numa = None
+    if under_launcher and world > 1:              # each rank (and whatever it forks) next to its GPU's memory controller
+        from fcn8s_tensorflow_amd.dp import bind_to_gpu_numa
+        numa = bind_to_gpu_numa(dev, int(os.environ.get("LOCAL_WORLD_SIZE", world)) if args.device is None else 1)
+        mark("numa: %s" % numa)
+    if under_launcher and args.comm == "native":
+        eng.comm_init_native()                    # the 128-byte id travels through the torch group once; the collectives are the library's
     eng.dp_always = under_launcher                # a one-rank process group still runs the bucketed all-reduces (RCCL with one rank)
     eng.replica_check_every = 0                   # the replica guard of FCN8s.train stays out of the measurement (and the local-only leg below lets replicas drift on purpose)
     eng.init_params(seed=0)                       # He-normal VGG, reference decoder init (same on every rank)
@@ -403,6 +472,13 @@ def main():
     # ---- data-parallel runs: what the gradient exchange costs
     comm = None
     if under_launcher and args.mode == "train":
+        replicas_ok = None
+        if world > 1:
+            try:
+                replicas_ok = bool(eng.check_replicas())      # every step so far exchanged its gradients: the replicas must hold the same bits
+            except RuntimeError as ex:
+                replicas_ok = False
+                mark("replica check failed: %s" % ex)
         per_bucket = []
         for off, n in eng.buckets:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -413,6 +489,7 @@ def main():
                 dist.all_reduce(view)
             e1.record(); torch.cuda.synchronize()
             per_bucket.append(round(e0.elapsed_time(e1) / 3, 3))
+        eng.flat_grads.zero_()                    # (the standalone runs summed garbage into the buffer; every step rewrites it anyway)
         fence()
         tl = time.perf_counter()
         for _ in range(psteps):                   # the same step without the exchange (each rank alone)
@@ -422,7 +499,8 @@ def main():
         tt = torch.tensor([local_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         local_ms = float(tt.item())
-        # issue -> complete timestamps of each bucket's all-reduce inside the step (ms after the step's first kernel; averaged over psteps)
+        # ready -> complete timestamps of each bucket's all-reduce inside the step (ms after the step's first kernel, i.e. the forward pass
+        # included; "issue" = the moment the bucket's last gradient kernel ended; averaged over psteps)
         eng.comm_trace = []
         fence()
         for _ in range(psteps):
@@ -449,15 +527,65 @@ def main():
                 cur_e = max(cur_e, e_)
         busy += (cur_e - cur_s) if cur_e is not None else 0.0
         exposed = dt / args.steps * 1e3 - local_ms
-        comm = {"backend": args.backend, "rccl_ranks": dist.get_world_size() if args.backend == "nccl" else 0, "ranks": dist.get_world_size(),
+        try:
+            rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version()) if args.backend == "nccl" else None
+        except Exception:
+            rccl_version = None
+        if rccl_version is None:
+            v = eng.comm_info()["rccl_version"]   # the library's own view (dlopen of librccl); 22707 = 2.27.7
+            rccl_version = "%d.%d.%d" % (v // 10000, v // 100 % 100, v % 100) if v else None
+        ws_ = dist.get_world_size()
+        comm = {"backend": args.backend, "collectives_by": "libfcn8s_hip (fcn8s_allreduce_bucket)" if eng.native_comm else "torch.distributed",
+                "rccl_ranks": dist.get_world_size() if args.backend == "nccl" else 0, "ranks": dist.get_world_size(),
+                "rccl_version": rccl_version, "nccl_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))},
+                "numa": numa, "replicas_identical_after_timed_steps": replicas_ok,
+                "bucket_names": ["fc7+decoder", "fc6", "conv4+conv5", "conv1..conv3"][:len(eng.buckets)],
                 "bucket_mb": [round(n * 4 / 1e6, 1) for _, n in eng.buckets],
-                "allreduce_ms_per_bucket_standalone": per_bucket, "local_only_ms_per_step": round(local_ms, 3),
+                "allreduce_ms_per_bucket_standalone": per_bucket,
+                # bus bandwidth of a ring all-reduce: 2 (n - 1) / n x bytes / time -- the figure to hold against one xGMI link (~153 GB/s)
+                "allreduce_gbs_per_bucket_standalone": [round(n * 4 / 1e9 / (t * 1e-3), 1) if t > 0 else None for (_, n), t in zip(eng.buckets, per_bucket)],
+                "allreduce_busbw_gbs_per_bucket_standalone": [round(2.0 * (ws_ - 1) / ws_ * n * 4 / 1e9 / (t * 1e-3), 1) if t > 0 else None
+                                                              for (_, n), t in zip(eng.buckets, per_bucket)],
+                "local_only_ms_per_step": round(local_ms, 3),
                 "exposed_comm_ms_per_step": round(exposed, 3),
                 "bucket_issue_ms": [round(x, 3) for x in issue], "bucket_complete_ms": [round(x, 3) for x in done],
                 "step_span_ms_traced": round(span, 3), "comm_busy_ms_per_step": round(busy, 3),
                 "overlap_frac": (round(max(0.0, min(1.0, 1.0 - max(exposed, 0.0) / busy)), 4) if busy > 0 else None)}
         eng.broadcast_params(0)                   # the local-only steps let the replicas drift; re-align before the final loss
     loss = eng.forward_backward(images, labels, keep_prob=1.0) if args.mode == "train" else None
+    fetch_ms, bcheck = None, None
+    if args.mode == "train" and world == 1:
+        # the same steps with the loss scalar fetched every step, as the reference's sess.run does
+        fence()
+        tf_ = time.perf_counter()
+        for _ in range(args.steps):
+            eng.train_step(images, labels, 1e-4, keep_prob=0.5, l2_rate=0.0, optimizer=opt, fetch_loss=True)
+        fence()
+        fetch_ms = round((time.perf_counter() - tf_) / args.steps * 1e3, 3)
+        # is the backward pass the derivative of the forward pass?  Central difference of the loss along the gradient on 2 images of
+        # the batch: (L(theta + eps g) - L(theta - eps g)) / (2 eps |g|^2) must be 1 (tests/test_fullsize_gpu.py does the same at 4 images).
+        # The decoder is scaled up for this: with the reference's init the loss is flat to fp32 resolution.
+        try:
+            keep = eng.flat_params.clone()
+            for k, (shape, off) in eng.specs.items():
+                if ("1x1" in k or "trans" in k) and len(shape) > 1:
+                    eng.flat_params[off:off + int(np.prod(shape))].mul_(30.0)
+            theta = eng.flat_params.clone()
+            nb_ = min(2, N)
+            eng.forward_backward(images[:nb_], labels[:nb_], keep_prob=1.0)
+            g = eng.flat_grads.clone()
+            norm2 = float((g.double() ** 2).sum())
+            ratios = []
+            for target in (2e-5, 4e-5, 6e-5):
+                eps = target / max(norm2, 1e-30)
+                eng.flat_params.copy_(theta - eps * g); lm = eng.forward_backward(images[:nb_], labels[:nb_], keep_prob=1.0)
+                eng.flat_params.copy_(theta + eps * g); lp = eng.forward_backward(images[:nb_], labels[:nb_], keep_prob=1.0)
+                ratios.append(round((lp - lm) / (2 * target), 4))
+            eng.flat_params.copy_(keep)
+            bcheck = {"directional_derivative_ratios": ratios, "ok": bool(any(0.97 < r < 1.03 for r in ratios)),
+                      "what": "central difference of the loss along its own gradient / |g|^2 at three step sizes (2 images, decoder x30, keep_prob 1): 1 = the backward pass is the derivative of the forward pass"}
+        except Exception as ex:
+            bcheck = {"error": repr(ex)}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -503,7 +631,9 @@ def main():
                         "algorithmic_mb_per_launch": round(g["bytes"] / g["launches"] / 1e6, 2),
                         "share_of_step_time": round(g["ms"] / (dt * 1e3), 3)}
         out = {
-            "metric": "training images/sec at 1024x512 bs16" if args.mode == "train" else "inference images/sec at 1024x512",
+            # BASELINE.json's metric string for its own configuration; any other size / batch / arithmetic says so in the metric itself
+            "metric": ("training images/sec at %dx%d bs%d" % (W, H, N) if args.mode == "train" else
+                       "inference images/sec at %dx%d" % (W, H) + ("" if N == 1 else " bs%d" % N)) + ("" if args.precision == "fp32" else " (%s arithmetic)" % args.precision),
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_LABEL[args.precision], "data": "synthetic",
@@ -528,10 +658,20 @@ def main():
             "kernel_groups_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0},
             "kernel_groups_gbs": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in prof.items() if v["flops"] == 0 and v["ms"] > 0},
             "final_loss": loss,
+            # synthetic labels are uniform noise, so nothing can be learned: with the reference's decoder init (sigma 1e-3 / 1e-2,
+            # fcn8s_tensorflow.py:159-160) the logits stay ~0 and the loss stays at ln 20 -- a NaN, a diverging or a sign-flipped update
+            # shows here; `backward_check` below is what shows a wrong gradient
+            "expected_final_loss": round(float(np.log(20.0)), 5) if args.mode == "train" else None,
+            "final_loss_ok": (bool(abs(loss - np.log(20.0)) < 2e-3) if (args.mode == "train" and loss is not None) else None),
+            "backward_check": bcheck,
+            # the timed steps queue the loss kernel but do not copy its scalar to the host (the reference fetches total_loss in every
+            # sess.run, fcn8s_tensorflow.py:554-572); the same K steps with the fetch are timed separately, after the regions
+            "loss_fetch": "deferred" if args.mode == "train" else None,
+            "ms_per_step_with_loss_fetch": fetch_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(H, W, optimizer=args.optimizer)
+                out["cpu_baseline"] = (cpu_baseline_full if args.cpu_baseline_full else cpu_baseline)(H, W, optimizer=args.optimizer)
             except Exception as ex:  # the oracle is only a reported baseline
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out), flush=True)

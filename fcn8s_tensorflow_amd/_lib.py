@@ -11,11 +11,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfcn8s_hip.so")
 
-OK, ERR_BAD_ARG, ERR_SHAPE, ERR_OOM, ERR_HIP, ERR_STATE, ERR_NOT_FOUND = range(7)
+OK, ERR_BAD_ARG, ERR_SHAPE, ERR_OOM, ERR_HIP, ERR_STATE, ERR_NOT_FOUND, ERR_RCCL = range(8)
 HOST, DEVICE = 0, 1
 IMG_U8, IMG_F32 = 0, 1
 OPT_TF_ADAM, OPT_SGD_MOMENTUM, OPT_NONE = 0, 1, 2
-NUM_BUCKETS = 3
+MAX_BUCKETS = 8          # the number of gradient buckets is a run-time value: lib.fcn8s_num_buckets(handle) / fcn8s_layout_num_buckets(cfg)
+COMM_ID_BYTES = 128
 NUM_STAGE_SLOTS = 3
 PREC_F32, PREC_BF16_FC, PREC_F32X3, PREC_BF16_FWD, PREC_F32X2, PREC_BF16_FWD_X2 = 0, 1, 2, 3, 4, 5
 
@@ -33,6 +34,7 @@ SIGNATURES = {
     "fcn8s_param_floats": (_sz, [C.POINTER(Config)]),
     "fcn8s_layout_num_params": (_i, [C.POINTER(Config)]),
     "fcn8s_layout_param": (_i, [C.POINTER(Config), _i, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(_i64 * 4), _i64p]),
+    "fcn8s_layout_num_buckets": (_i, [C.POINTER(Config)]),
     "fcn8s_layout_bucket": (_i, [C.POINTER(Config), _i, C.POINTER(_sz), C.POINTER(_sz)]),
     "fcn8s_create": (_i, [C.POINTER(Config), C.POINTER(_p)]),
     "fcn8s_destroy": (_i, [_p]),
@@ -47,6 +49,7 @@ SIGNATURES = {
     "fcn8s_get_grad": (_i, [_p, C.c_char_p, _p, _sz]),
     "fcn8s_param_buffer": (_p, [_p, C.POINTER(_sz)]),
     "fcn8s_grad_buffer": (_p, [_p, C.POINTER(_sz)]),
+    "fcn8s_num_buckets": (_i, [_p]),
     "fcn8s_bucket_range": (_i, [_p, _i, C.POINTER(_sz), C.POINTER(_sz)]),
     "fcn8s_init_params": (_i, [_p, C.c_uint64]),
     "fcn8s_onehot_to_ids": (_i, [_p, _p, _i, _i64, _i, _p, _p]),
@@ -54,6 +57,16 @@ SIGNATURES = {
     "fcn8s_forward_loss": (_i, [_p, _p, _i, _p, _i, _i, _i, _f, _f, _i]),
     "fcn8s_backward_bucket": (_i, [_p, _i]),
     "fcn8s_bucket_complete_after": (_i, [_p, _i]),
+    "fcn8s_bucket_wait": (_i, [_p, _i, _p]),
+    "fcn8s_device_pci_bus_id": (_i, [_i, C.c_char_p, _sz]),
+    "fcn8s_comm_unique_id": (_i, [_p, _sz]),
+    "fcn8s_comm_init": (_i, [_p, _p, _sz, _i, _i]),
+    "fcn8s_comm_destroy": (_i, [_p]),
+    "fcn8s_comm_info": (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "fcn8s_allreduce_bucket": (_i, [_p, _i]),
+    "fcn8s_comm_wait": (_i, [_p]),
+    "fcn8s_comm_broadcast_params": (_i, [_p, _i]),
+    "fcn8s_comm_allreduce_metrics": (_i, [_p]),
     "fcn8s_apply_update": (_i, [_p, _i, _f, _f]),
     "fcn8s_read_loss": (_i, [_p, _fp]),
     "fcn8s_eval_step": (_i, [_p, _p, _i, _p, _i, _i, _i, _f, _i]),

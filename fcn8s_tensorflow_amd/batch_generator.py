@@ -150,6 +150,7 @@ class _WorkerPool:
         import tempfile
         self.dir = tempfile.mkdtemp(prefix="fcn8s_feed_%d_" % os.getpid(), dir=shm)
         self.shapes = None            # (image shape, gt shape or None) of one sample, learnt from the first batch
+        self.closed = self.failed = False
         self.slot = 0
         self.maps = {}
 
@@ -164,6 +165,9 @@ class _WorkerPool:
 
     def run(self, tasks):
         from ._feed_worker import _read, _write
+        if self.closed:
+            raise RuntimeError("BatchGenerator worker pool was shut down" + (" after a worker died" if self.failed else "") +
+                               "; make a new generator (generate(..., workers=n)) to continue")
         n = len(tasks)
         dests = [None] * n
         buf = None
@@ -174,8 +178,13 @@ class _WorkerPool:
             path, buf = self._buffer(self.slot, max(1, n * (isz + gsz)))
             dests = [(path, i * isz, ishape, n * isz + i * gsz, gshape) for i in range(n)]
         # deal the samples round-robin, then collect in order (each worker answers its tasks in the order it got them)
-        for i, t in enumerate(tasks):
-            _write(self.procs[i % len(self.procs)].stdin, (t, dests[i]))
+        try:
+            for i, t in enumerate(tasks):
+                _write(self.procs[i % len(self.procs)].stdin, (t, dests[i]))
+        except (BrokenPipeError, OSError):              # the worker behind this pipe is gone: nothing dealt so far can be trusted to come back
+            self.failed = True
+            self.close()
+            raise RuntimeError("a BatchGenerator decode worker died")
         images, gts = [None] * n, [None] * n
         # every reply of this batch is collected before an error is raised: a reply left in a pipe would be read as the next
         # batch's acknowledgement, and that batch would be returned while workers are still writing it
@@ -190,6 +199,7 @@ class _WorkerPool:
             replies.append(r)
         if failure:
             if len(replies) < n:
+                self.failed = True
                 self.close()
             raise RuntimeError(failure)
         for i, r in enumerate(replies):
@@ -204,6 +214,7 @@ class _WorkerPool:
         return images, gts
 
     def close(self):
+        self.closed = True
         for p in self.procs:
             try:
                 p.stdin.close()

@@ -97,13 +97,11 @@ bool launch_wgrad_taps(const float* X, const float* dZ, float* dW, float* db, in
 
 // conv1_1 (3 -> 64 channels, 4-channel padded input) weight + bias gradient, VALU, HBM-bound;
 // returns false if the shape is not covered (Cout != 64 or W % 64).
-bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, int N, int H, int W, int Cout, hipStream_t s);
+bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, int N, int H, int W, int Cout, int mfma, hipStream_t s);
 
 // conv1_1 forward with bias + ReLU on the LDS-DMA gather kernel (Cout = 64 only; returns false otherwise): x4 [N,H,W,4], w48 [48][64]
 // (taps x 4 channels, rows 36..47 zero), zero16 = 16 zero bytes in device memory (what taps outside the image read)
-extern int g_conv1_tiled;      // 1 (default): spatial-tile kernel; 0: LDS-DMA gather kernel
-extern int g_conv1_wgrad_mfma; // 1 (default): conv1_1 weight gradient on the matrix core; 0: the VALU kernel
-bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, hipStream_t s);
+bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, int tiled, hipStream_t s);
 
 // weight gradient of the 16x16 / stride-8 transposed conv with 20 channels (VALU; dW zero-initialised, accumulated with atomics);
 // returns false for any other shape: the caller then uses launch_wgrad.

@@ -890,13 +890,13 @@ __global__ __launch_bounds__(256, 4) void conv1_tile_kernel(const Conv1Args p)
   }
 }
 
-int g_conv1_tiled = 1;       // 0: the LDS-DMA gather kernel (A/B, tests)
 // x4: [N,H,W,4] (b, g, r, 0); w48: [48][64] = taps 0..8 x 4 channels, rows 36..47 zero; y = relu(conv + bias), [N,H,W,64]
-bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, hipStream_t s)
+// tiled: 1 = the spatial-tile kernel, 0 = the LDS-DMA gather kernel (model option "conv1_tiled"; bit-identical results)
+bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, int tiled, hipStream_t s)
 {
     if (Cout != 64 || !bias || !zero16) return false;
     Conv1Args a{x4, w48, bias, y, zero16, N, H, W, (long long)N * H * W};
-    if (g_conv1_tiled && H % 8 == 0 && W % 16 == 0) {
+    if (tiled && H % 8 == 0 && W % 16 == 0) {
         g_last_kernel = "conv1_tile_kernel";
         const long long tiles = (long long)N * (H / 8) * (W / 16);
         // (four tiles per block once there are enough of them: the 12 KB kernel is staged once per block -- 0.53 -> 0.46 ms; eight: the same)
@@ -1538,10 +1538,10 @@ __global__ __launch_bounds__(256, 4) void conv1_wgrad_mfma_kernel(const Conv1Wgr
     }
 }
 
-int g_conv1_wgrad_mfma = 1;       // 0: the VALU kernel above (A/B, tests)
-bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, int N, int H, int W, int Cout, hipStream_t s)
+// mfma: 1 = the matrix-core kernel, 0 = the VALU kernel above (model option "conv1_wgrad_mfma")
+bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, int N, int H, int W, int Cout, int mfma, hipStream_t s)
 {
-    if (Cout == 64 && g_conv1_wgrad_mfma && H % 8 == 0 && W % 16 == 0) {
+    if (Cout == 64 && mfma && H % 8 == 0 && W % 16 == 0) {
         Conv1WgradArgs a{(const float4*)X4, dZ, dW, db, N, H, W, 0, 0};
         const long long ntiles = (long long)N * (H / 8) * (W / 16);
         long long blocks = ntiles < 1024 ? ntiles : 1024;               // 4 per CU, all resident; measured flat from 1024 to 2048, slower below (0.47 ms at 512)

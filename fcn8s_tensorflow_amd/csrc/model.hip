@@ -7,6 +7,8 @@
 #include "../../include/fcn8s_hip.h"
 #include "fcn8s_internal.h"
 
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -58,6 +60,10 @@ struct fcn8s_model {
     hipEvent_t bucket_ev[FCN8S_MAX_BUCKETS] = {nullptr};                 // recorded right behind the last kernel that writes into the bucket
     bool bucket_final[FCN8S_MAX_BUCKETS] = {false};                      // ... this backward pass (fcn8s_bucket_wait)
     float* dz7_cur = nullptr; bool defer_fc_cur = false;                 // handed from backward phase 0 (decoder, fc7 weights) to phase 1 (fc6)
+    // the library's own RCCL communicator (fcn8s_comm_*): one rank per model, collectives on a stream of its own behind the bucket events
+    ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t comm_done[FCN8S_MAX_BUCKETS] = {nullptr}; bool comm_pending[FCN8S_MAX_BUCKETS] = {false};
     float *d_params = nullptr, *d_grads = nullptr, *d_m = nullptr, *d_v = nullptr, *d_wt = nullptr;
     bool own_params = false, own_grads = false;
     float *d_w1pad = nullptr, *d_tph[3] = {nullptr, nullptr, nullptr};
@@ -82,6 +88,7 @@ struct fcn8s_model {
     std::string dm_layer;                                                 // layer whose dM = A dY A^T sits in d_wino_m, ready for the adjoint data gradient
     std::string dm_prefilled;                                             // layer whose dM the data gradient of the layer after it has already written into d_wino_m (fused transform)
     int fuse_dgrad_dout = 1;                                              // option: allow that fusion
+    int conv1_tiled = 1, conv1_wgrad_mfma = 1;                            // options: conv1_1 forward on the spatial-tile kernel / its weight gradient on the matrix core
     unsigned short* d_wbf16 = nullptr; size_t wbf16_elems = 0;            // bf16 copy of one layer's kernel at a time (K-tile-major or transposed)
     std::map<std::string, unsigned short*> wbf16_cache;                   // ... per layer, valid while frozen
     int bf16_gemm256 = 1;                                                 // bf16_fc mode: 256 x 256 LDS-DMA kernel -- 0 never, 1 when it fills the chip, 2 whenever shapes allow
@@ -276,10 +283,12 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
 // only exists in the LDS-DMA form: K % 16 == 0 and whole N tiles of the width launch_igemm picks (64 for N = 64, else 128).  Other widths
 // (e.g. 192) get a second, transposed bank instead (3x3 layers) or the forward-type data gradient (fc6).
 static bool bt_gemm_ok(int K, int N) { return K % 16 == 0 && (N == 64 || N % 128 == 0); }
-int g_op_split = 0;      // arithmetic of the op-level entry points, which have no model (fcn8s_set_option(NULL, "op_f32x3", 1))
+// Arithmetic of the op-level entry points, which have no model: the context of the CALLING THREAD (fcn8s_set_option(NULL, "op_split_pieces", n)
+// from that thread), copied into the bare model each such call builds -- never read by a real model, never shared between threads.
+thread_local int t_op_split = 0;
 int split_of(const fcn8s_model* m)
 {
-    if (!m) return g_op_split;
+    if (!m) return t_op_split;
     if (m->precision == FCN8S_PREC_F32X3 || m->precision == FCN8S_PREC_BF16_FWD) return 3;
     if (m->precision == FCN8S_PREC_F32X2 || m->precision == FCN8S_PREC_BF16_FWD_X2) return 2;
     return 0;
@@ -658,7 +667,7 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             return;
         }
         if (taps && launch_wgrad_taps(x, dz, dw, db, N, H, W, Cin, Cout, K, s)) return;
-        if (first && launch_conv1_wgrad(x, dz, dw, db, N, H, W, Cout, s)) return;
+        if (first && launch_conv1_wgrad(x, dz, dw, db, N, H, W, Cout, m->conv1_wgrad_mfma, s)) return;
         launch_wgrad(a, s);
     };
     if (m) { ProfScope ps(m, group, flops, bytes, layer); run(); }
@@ -1077,7 +1086,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
             bool done = false;
             if (first && m->widths[0] == 64) {            // conv1_1: write-bound gather kernel (igemm.hip: conv1_glds_kernel)
                 ProfScope ps(m, "conv1_1_fwd", 2.0 * N * h * w * 27.0 * m->widths[0], 4.0 * N * h * w * (3.0 + m->widths[0]), nm);
-                done = launch_conv1_fwd(x, m->d_w1pad, e.bias, A(m, nm), m->d_w1pad + 12 * 4 * (size_t)m->widths[0], N, h, w, m->widths[0], s);
+                done = launch_conv1_fwd(x, m->d_w1pad, e.bias, A(m, nm), m->d_w1pad + 12 * 4 * (size_t)m->widths[0], N, h, w, m->widths[0], m->conv1_tiled, s);
             }
             if (!done && bf16_fwd_mode(m) && b >= 2) {
                 // FCN8S_PREC_BF16_FWD: conv3_1 .. conv5_3 as direct convolutions with bf16-rounded operands on the 256 x 256 bf16 kernel (the
@@ -1538,6 +1547,7 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->tail_done) hipEventDestroy(m->tail_done);
     if (m->side_done) hipEventDestroy(m->side_done);
     for (auto e : m->ev_pool) hipEventDestroy(e);
+    fcn8s_comm_destroy(m);
     for (auto& e : m->bucket_ev) if (e) { hipEventDestroy(e); e = nullptr; }
     for (auto& kv : m->u_train) if (kv.second) hipFree(kv.second);
     if (m->d_wino_u) hipFree(m->d_wino_u);
@@ -1627,6 +1637,8 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "bf16_gemm256") return &m->bf16_gemm256;
     if (key == "winograd_tile_hires") return &m->wino_tile_hires;
     if (key == "winograd_hires_pixels") return &m->wino_hires_pixels;
+    if (key == "conv1_tiled") return &m->conv1_tiled;
+    if (key == "conv1_wgrad_mfma") return &m->conv1_wgrad_mfma;
     return nullptr;
 }
 int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
@@ -1634,17 +1646,17 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
     if (!key) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_option: null key");
     const std::string k = key;
     if (!m) {
-        if (k == "op_f32x3") { g_op_split = value ? 3 : 0; return FCN8S_OK; }
+        if (k == "op_f32x3") { t_op_split = value ? 3 : 0; return FCN8S_OK; }
         if (k == "op_split_pieces") {
             if (value != 0 && value != 2 && value != 3) return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_set_option: op_split_pieces is 0, 2 or 3");
-            g_op_split = (int)value; return FCN8S_OK;
+            t_op_split = (int)value; return FCN8S_OK;
         }
-        if (k == "conv1_tiled") { fcn8s::g_conv1_tiled = value ? 1 : 0; return FCN8S_OK; }
-        if (k == "conv1_wgrad_mfma") { fcn8s::g_conv1_wgrad_mfma = value ? 1 : 0; return FCN8S_OK; }
-        return fail(nullptr, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown process-wide option '" + k + "'");
+        return fail(nullptr, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown op-context option '" + k + "' (model options need a model)");
     }
-    if (k == "conv1_tiled") { fcn8s::g_conv1_tiled = value ? 1 : 0; return FCN8S_OK; }       // process-wide, also reachable through a model
-    if (k == "conv1_wgrad_mfma") { fcn8s::g_conv1_wgrad_mfma = value ? 1 : 0; return FCN8S_OK; }
+    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma") {        // pick a kernel per launch: nothing cached depends on them
+        *model_option(m, k) = value ? 1 : 0;
+        return FCN8S_OK;
+    }
     int* slot = model_option(m, k);
     if (!slot) return fail(m, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown option '" + k + "'");
     if (k == "winograd_tile" && value != 2 && value != 4 && value != 6) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_tile must be 2, 4 or 6");
@@ -1678,14 +1690,10 @@ int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value)
     if (!key || !value) return FCN8S_ERR_BAD_ARG;
     const std::string k = key;
     if (!m) {
-        if (k == "op_f32x3") { *value = g_op_split == 3; return FCN8S_OK; }
-        if (k == "op_split_pieces") { *value = g_op_split; return FCN8S_OK; }
-        if (k == "conv1_tiled") { *value = fcn8s::g_conv1_tiled; return FCN8S_OK; }
-        if (k == "conv1_wgrad_mfma") { *value = fcn8s::g_conv1_wgrad_mfma; return FCN8S_OK; }
+        if (k == "op_f32x3") { *value = t_op_split == 3; return FCN8S_OK; }
+        if (k == "op_split_pieces") { *value = t_op_split; return FCN8S_OK; }
         return FCN8S_ERR_NOT_FOUND;
     }
-    if (k == "conv1_tiled") { *value = fcn8s::g_conv1_tiled; return FCN8S_OK; }
-    if (k == "conv1_wgrad_mfma") { *value = fcn8s::g_conv1_wgrad_mfma; return FCN8S_OK; }
     const int* slot = model_option(const_cast<fcn8s_model*>(m), k);
     if (!slot) return FCN8S_ERR_NOT_FOUND;
     *value = *slot;
@@ -1799,10 +1807,162 @@ int fcn8s_bucket_complete_after(const fcn8s_model* m, int bucket)
     return bucket_complete_after(m, bucket);
 }
 
+// ---- the library's own RCCL communicator ------------------------------------------------------------------------------------------
+// librccl is opened at run time (dlopen by soname): a process that already holds PyTorch-ROCm's copy gets that one, a plain C caller gets
+// /opt/rocm's, and a single-GPU user of the library never loads the 570 MB of it.
+namespace {
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+RcclApi* rccl()
+{
+    static RcclApi api; static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { api.h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (api.h) break; }
+        if (!api.h) { const char* e = dlerror(); api.err = std::string("dlopen(librccl.so.1): ") + (e ? e : "not found"); return; }
+        auto sym = [&](const char* n) { void* p = dlsym(api.h, n); if (!p && api.err.empty()) api.err = std::string("librccl has no symbol ") + n; return p; };
+        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+        api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
+        api.GetVersion = (decltype(api.GetVersion))sym("ncclGetVersion");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    });
+    return &api;
+}
+int rccl_fail(fcn8s_model* m, const char* what, ncclResult_t r)
+{
+    RcclApi* a = rccl();
+    return fail(m, FCN8S_ERR_RCCL, std::string(what) + ": " + ((a->GetErrorString && r != ncclSuccess) ? a->GetErrorString(r) : a->err.c_str()));
+}
+#define RCCLCHK(m, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return rccl_fail(m, #call, r_); } while (0)
+}  // namespace
+
+int fcn8s_device_pci_bus_id(int device_id, char* out, size_t len)
+{
+    if (!out || len < 16) return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_device_pci_bus_id: need a buffer of at least 16 bytes");
+    hipError_t e = hipDeviceGetPCIBusId(out, (int)len, device_id);
+    if (e != hipSuccess) return fail(nullptr, FCN8S_ERR_HIP, std::string("hipDeviceGetPCIBusId: ") + hipGetErrorString(e));
+    return FCN8S_OK;
+}
+
+int fcn8s_comm_unique_id(void* id_out, size_t nbytes)
+{
+    if (!id_out || nbytes < sizeof(ncclUniqueId)) return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_comm_unique_id: need a buffer of FCN8S_COMM_ID_BYTES bytes");
+    RcclApi* a = rccl();
+    if (!a->err.empty()) return rccl_fail(nullptr, "fcn8s_comm_unique_id", ncclSuccess);
+    ncclUniqueId id;
+    RCCLCHK(nullptr, a->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return FCN8S_OK;
+}
+
+int fcn8s_comm_init(fcn8s_model* m, const void* unique_id, size_t nbytes, int rank, int world)
+{
+    if (!m || !unique_id || nbytes < sizeof(ncclUniqueId) || world < 1 || rank < 0 || rank >= world) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_comm_init: bad argument");
+    if (m->comm) return fail(m, FCN8S_ERR_STATE, "fcn8s_comm_init: this model already has a communicator (fcn8s_comm_destroy first)");
+    RcclApi* a = rccl();
+    if (!a->err.empty()) return rccl_fail(m, "fcn8s_comm_init", ncclSuccess);
+    HIPCHK(m, hipSetDevice(m->device));
+    ncclUniqueId id; memcpy(&id, unique_id, sizeof id);
+    RCCLCHK(m, a->CommInitRank(&m->comm, world, id, rank));
+    m->comm_rank = rank; m->comm_world = world;
+    if (!m->comm_stream) HIPCHK(m, hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking));
+    return FCN8S_OK;
+}
+
+int fcn8s_comm_destroy(fcn8s_model* m)
+{
+    if (!m) return FCN8S_ERR_BAD_ARG;
+    if (m->comm) {
+        if (m->comm_stream) hipStreamSynchronize(m->comm_stream);
+        rccl()->CommDestroy(m->comm); m->comm = nullptr;
+    }
+    for (int b = 0; b < FCN8S_MAX_BUCKETS; ++b) { if (m->comm_done[b]) { hipEventDestroy(m->comm_done[b]); m->comm_done[b] = nullptr; } m->comm_pending[b] = false; }
+    if (m->comm_stream) { hipStreamDestroy(m->comm_stream); m->comm_stream = nullptr; }
+    m->comm_rank = 0; m->comm_world = 1;
+    return FCN8S_OK;
+}
+
+int fcn8s_comm_info(const fcn8s_model* m, int* rank, int* world, int* rccl_version)
+{
+    if (!m) return FCN8S_ERR_BAD_ARG;
+    if (rank) *rank = m->comm_rank;
+    if (world) *world = m->comm ? m->comm_world : 0;
+    if (rccl_version) { *rccl_version = 0; RcclApi* a = rccl(); if (a->GetVersion) a->GetVersion(rccl_version); }
+    return FCN8S_OK;
+}
+
+int fcn8s_allreduce_bucket(fcn8s_model* m, int bucket)
+{
+    if (!m || bucket < 0 || bucket >= kNumBuckets) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_allreduce_bucket: bad bucket");
+    if (!m->comm) return fail(m, FCN8S_ERR_STATE, "fcn8s_allreduce_bucket: no communicator (fcn8s_comm_init first)");
+    if (!m->bucket_final[bucket]) return fail(m, FCN8S_ERR_STATE, "fcn8s_allreduce_bucket: the bucket's gradients are not queued yet (fcn8s_bucket_complete_after)");
+    if (m->comm_pending[bucket]) return fail(m, FCN8S_ERR_STATE, "fcn8s_allreduce_bucket: this bucket is already being reduced");
+    HIPCHK(m, hipStreamWaitEvent(m->comm_stream, m->bucket_ev[bucket], 0));
+    float* g = m->d_grads + m->bucket_off[bucket];
+    RCCLCHK(m, rccl()->AllReduce(g, g, m->bucket_n[bucket], ncclFloat, ncclSum, m->comm, m->comm_stream));
+    if (!m->comm_done[bucket]) HIPCHK(m, hipEventCreateWithFlags(&m->comm_done[bucket], hipEventDisableTiming));
+    HIPCHK(m, hipEventRecord(m->comm_done[bucket], m->comm_stream));
+    m->comm_pending[bucket] = true;
+    return FCN8S_OK;
+}
+
+int fcn8s_comm_wait(fcn8s_model* m)
+{
+    if (!m) return FCN8S_ERR_BAD_ARG;
+    for (int b = 0; b < kNumBuckets; ++b)
+        if (m->comm_pending[b]) { HIPCHK(m, hipStreamWaitEvent(m->stream, m->comm_done[b], 0)); m->comm_pending[b] = false; }
+    return FCN8S_OK;
+}
+
+int fcn8s_comm_broadcast_params(fcn8s_model* m, int root)
+{
+    if (!m || root < 0) return FCN8S_ERR_BAD_ARG;
+    if (!m->comm) return fail(m, FCN8S_ERR_STATE, "fcn8s_comm_broadcast_params: no communicator (fcn8s_comm_init first)");
+    if (root >= m->comm_world) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_comm_broadcast_params: root outside the communicator");
+    if (m->frozen) fcn8s_freeze_params(m, 0);
+    RCCLCHK(m, rccl()->Broadcast(m->d_params, m->d_params, m->total, ncclFloat, root, m->comm, m->stream));
+    return FCN8S_OK;
+}
+
+int fcn8s_comm_allreduce_metrics(fcn8s_model* m)
+{
+    if (!m) return FCN8S_ERR_BAD_ARG;
+    if (!m->comm) return fail(m, FCN8S_ERR_STATE, "fcn8s_comm_allreduce_metrics: no communicator (fcn8s_comm_init first)");
+    // confusion counts (exact as doubles below 2^53), the sum of the per-batch losses and their count: one SUM all-reduce
+    const size_t cc = (size_t)m->C * m->C, n = cc + 2;
+    std::vector<int64_t> conf(cc); double ls; int64_t lc;
+    int rc = fcn8s_metrics_raw(m, conf.data(), &ls, &lc); if (rc) return rc;
+    std::vector<double> h(n);
+    for (size_t i = 0; i < cc; ++i) h[i] = (double)conf[i];
+    h[cc] = ls; h[cc + 1] = (double)lc;
+    double* d = nullptr;
+    HIPCHK(m, hipMalloc((void**)&d, n * sizeof(double)));
+    hipMemcpyAsync(d, h.data(), n * sizeof(double), hipMemcpyHostToDevice, m->stream);
+    ncclResult_t r = rccl()->AllReduce(d, d, n, ncclDouble, ncclSum, m->comm, m->stream);
+    hipMemcpyAsync(h.data(), d, n * sizeof(double), hipMemcpyDeviceToHost, m->stream);
+    hipStreamSynchronize(m->stream);
+    hipFree(d);
+    if (r != ncclSuccess) return rccl_fail(m, "ncclAllReduce(metrics)", r);
+    for (size_t i = 0; i < cc; ++i) conf[i] = (int64_t)llround(h[i]);
+    return fcn8s_metrics_set_raw(m, conf.data(), h[cc], (int64_t)llround(h[cc + 1]));
+}
+
 int fcn8s_apply_update(fcn8s_model* m, int optimizer, float lr, float grad_scale)
 {
     if (m && m->frozen) fcn8s_freeze_params(m, 0);      // parameters are about to change (or a training pass starts): leave the frozen state
     if (!m) return FCN8S_ERR_BAD_ARG;
+    { int rcw = fcn8s_comm_wait(m); if (rcw) return rcw; }      // gradient buckets still being all-reduced by the library's own communicator
     const int64_t t = m->step + 1;
     if (optimizer == FCN8S_OPT_TF_ADAM) {
         int rc = ensure_opt_state(m); if (rc) return rc;
@@ -2194,7 +2354,7 @@ int fcn8s_op_conv3x3_winograd_fwd_bwd(void* stream, const float* x, const float*
     // a bare model context: the launch sequences below are the model's own (conv_same / conv_wgrad), with one layer called "op"
     fcn8s_model mm; fcn8s_model* m = &mm;
     m->stream = s; m->wino_min_cin = 16; m->wino_tile = 6; m->wino_force_tile = tile; m->N = N; m->H = H; m->W = W;
-    m->precision = g_op_split == 3 ? FCN8S_PREC_F32X3 : g_op_split == 2 ? FCN8S_PREC_F32X2 : FCN8S_PREC_F32;
+    m->precision = t_op_split == 3 ? FCN8S_PREC_F32X3 : t_op_split == 2 ? FCN8S_PREC_F32X2 : FCN8S_PREC_F32;
     const int al = tile + 2, P = al * al, cmax = std::max(Cin, Cout);
     const size_t T = (size_t)wino_tiles(tile, N, H, W);
     const size_t slab_max = (size_t)P * (size_t)wino_slab((long long)T, cmax), slab_in = (size_t)P * (size_t)wino_slab((long long)T, Cin);

@@ -37,11 +37,77 @@ def layout(num_classes, widths=None, fc6_ksize=7):
         L.check(L.lib.fcn8s_layout_param(C.byref(cfg), i, name, C.byref(nd), C.byref(shp), C.byref(off)))
         specs[name.value.decode()] = (tuple(int(shp[k]) for k in range(nd.value)), int(off.value))
     buckets = []
-    for b in range(L.NUM_BUCKETS):
+    for b in range(L.lib.fcn8s_layout_num_buckets(C.byref(cfg))):
         o = C.c_size_t(); n = C.c_size_t()
         L.check(L.lib.fcn8s_layout_bucket(C.byref(cfg), b, C.byref(o), C.byref(n)))
         buckets.append((o.value, n.value))
     return specs, total, buckets
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist syntax) -> [0, 1, 2, 3, 8, 10, 11]"""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def numa_share(node_of_device, cpus_of_node, device, allowed=None):
+    """The CPUs rank `device` should run on: the CPUs of its GPU's NUMA node (restricted to `allowed`, the affinity the process was
+    started with), cut into equal contiguous slices among the devices that sit on the same node.  Pure host logic (tests/test_dp_gloo.py).
+    node_of_device: list, entry d = NUMA node of device d (-1 = unknown); cpus_of_node: dict node -> [cpu].  None = leave the affinity alone."""
+    node = node_of_device[device]
+    if node < 0 or not cpus_of_node.get(node):
+        return None
+    cpus = [c for c in cpus_of_node[node] if allowed is None or c in allowed]
+    peers = [d for d, n in enumerate(node_of_device) if n == node]
+    per = len(cpus) // len(peers)
+    if per < 1:
+        return None
+    i = peers.index(device)
+    return cpus[i * per:(i + 1) * per]
+
+
+def bind_to_gpu_numa(device, local_world=None):
+    """Bind this process (and everything it forks later: the BatchGenerator decode workers, the feeder thread) to the CPUs of the NUMA
+    node its GPU hangs off -- pinned staging copies and PNG decode then stay on the memory controller next to the GPU's PCIe root.
+    Ranks whose GPUs share a node split its CPUs evenly.  Returns a dict for the log / bench line; FCN8S_NUMA_BIND=0 switches it off."""
+    import os
+    from . import _lib as L
+    info = {"bound": False}
+    if os.environ.get("FCN8S_NUMA_BIND", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        info["why"] = "disabled"
+        return info
+    try:
+        n = int(local_world if local_world is not None else os.environ.get("LOCAL_WORLD_SIZE", "1"))
+        nodes, cpus = [], {}
+        for d in range(max(n, device + 1)):
+            buf = C.create_string_buffer(32)
+            if L.lib.fcn8s_device_pci_bus_id(d, buf, 32) != 0:
+                nodes.append(-1)
+                continue
+            base = "/sys/bus/pci/devices/" + buf.value.decode().lower()
+            try:
+                node = int(open(base + "/numa_node").read())
+                if node >= 0 and node not in cpus:
+                    cpus[node] = parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read())
+            except OSError:
+                node = -1
+            nodes.append(node)
+        allowed = os.sched_getaffinity(0)
+        mine = numa_share(nodes, cpus, device, allowed)
+        info.update({"numa_node": nodes[device], "devices_on_node": sum(1 for x in nodes if x == nodes[device] and x >= 0)})
+        if mine:
+            os.sched_setaffinity(0, mine)
+            info.update({"bound": True, "cpus": len(mine), "first_cpu": mine[0], "last_cpu": mine[-1]})
+        else:
+            info["why"] = "no NUMA node reported for this GPU" if nodes[device] < 0 else "no CPUs left to bind to"
+    except Exception as ex:            # binding is an optimisation: never let it stop a run
+        info["why"] = repr(ex)
+    return info
 
 
 class BucketReducer:
@@ -49,7 +115,7 @@ class BucketReducer:
     trace: optional list; then every bucket appends (issue event on the compute stream, completion event on a side stream that
     waits for nothing but that all-reduce) -- bench.py turns them into issue -> complete timestamps per bucket."""
 
-    def __init__(self, flat_grads, buckets, group=None, trace=None, always=False):
+    def __init__(self, flat_grads, buckets, group=None, trace=None, always=False, ready=None):
         self.flat = flat_grads
         self.buckets = buckets
         self.group = group
@@ -57,6 +123,7 @@ class BucketReducer:
         self.trace = trace
         self.always = always          # run the collectives in a one-rank group too (bench.py under torchrun with one rank)
         self._side = None
+        self.ready = ready            # callable b -> torch stream that waits for bucket b's last gradient kernel (Engine._bucket_ready), or None
 
     def reduce_bucket(self, b):
         d = dist_or_none()
@@ -64,11 +131,19 @@ class BucketReducer:
             return
         off, n = self.buckets[b]
         ev = None
+        st = self.ready(b) if (self.ready is not None and self.flat.is_cuda) else None
         if self.trace is not None and self.flat.is_cuda:
             import torch
             ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-        w = d.all_reduce(self.flat[off:off + n], op=d.ReduceOp.SUM, group=self.group, async_op=True)
+            ev.record(st) if st is not None else ev.record()      # (on the bucket's stream: the moment its last gradient kernel ended)
+        if st is not None:
+            # issued with the bucket's stream current: RCCL's stream then waits for the bucket's last gradient kernel only, not for whatever
+            # the compute stream has queued behind it (fc6's bucket is final 3 ms of data-gradient GEMMs before its backward call ends)
+            import torch
+            with torch.cuda.stream(st):
+                w = d.all_reduce(self.flat[off:off + n], op=d.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            w = d.all_reduce(self.flat[off:off + n], op=d.ReduceOp.SUM, group=self.group, async_op=True)
         self.works.append(w)
         if ev is not None:
             import torch
@@ -91,20 +166,23 @@ class BucketReducer:
 
 
 def replica_fingerprint(flat_params, global_step, samples=1 << 16):
-    """(global step, integer checksum of a strided sample of the parameter bits) of this rank's replica, as an int64 tensor on the
-    parameters' device.  Bit patterns, not values: replicas must be *identical* (same all-reduced gradients, same update kernel),
-    so any difference -- a rank that skipped a step, a diverged dropout-free buffer, a NaN -- changes the checksum."""
+    """(global step, integer checksum of a strided SAMPLE of the parameter bits) of this rank's replica, as an int64 tensor on the
+    parameters' device.  Bit patterns, not values: replicas must be *identical* (same all-reduced gradients, same update kernel), so a
+    rank that skipped a step, a diverged buffer or a NaN that has spread changes the checksum.  It is a sample (65 536 of 134 M elements
+    per check): a difference confined to elements outside it passes this check; the sample's offset is the global step modulo the
+    stride, so successive checks look at different elements, and `samples=numel` checks everything."""
     import torch
     n = flat_params.numel()
     stride = max(1, n // int(samples))
-    bits = flat_params.view(torch.int32)[::stride].to(torch.int64)
+    first = int(global_step) % stride            # the sample moves with the step: over `stride` checks every element has been looked at
+    bits = flat_params.view(torch.int32)[first::stride].to(torch.int64)
     w = torch.arange(1, bits.numel() + 1, dtype=torch.int64, device=bits.device)       # position-weighted: a swap of two values shows
     return torch.stack([torch.tensor(int(global_step), dtype=torch.int64, device=bits.device), (bits * w).sum()])
 
 
 def check_replicas(flat_params, global_step, group=None):
-    """Raises RuntimeError on every rank when the replicas of a data-parallel run are not identical (global step or parameter
-    checksum differ between ranks).  One 32-byte all-reduce; FCN8s.train calls it every `replica_check_every` steps."""
+    """Raises RuntimeError on every rank when the replicas of a data-parallel run are seen to differ (global step, or the checksum of
+    the sampled parameter bits -- see replica_fingerprint -- differ between ranks).  One 32-byte all-reduce; FCN8s.train calls it every `replica_check_every` steps."""
     d = dist_or_none()
     if d is None or d.get_world_size(group) == 1:
         return True

@@ -111,7 +111,10 @@ class Engine:
             L.check(L.lib.fcn8s_param_info(self.h, i, C.byref(name), C.byref(nd), C.byref(shp), C.byref(off)), self.h)
             self.specs[name.value.decode()] = (tuple(int(shp[k]) for k in range(nd.value)), int(off.value))
         self.buckets = []
-        for b in range(L.NUM_BUCKETS):
+        self.num_buckets = int(L.lib.fcn8s_num_buckets(self.h))
+        self.native_comm = False                    # True: gradients are exchanged by the library's own RCCL communicator (comm_init_native)
+        self._side = None
+        for b in range(self.num_buckets):
             o = C.c_size_t(); m = C.c_size_t()
             L.check(L.lib.fcn8s_bucket_range(self.h, b, C.byref(o), C.byref(m)), self.h)
             self.buckets.append((o.value, m.value))
@@ -139,11 +142,15 @@ class Engine:
 
     @property
     def world_size(self):
+        if getattr(self, "native_comm", False):
+            return self.comm_world
         d = _dist()
         return d.get_world_size(self.pg) if d else 1
 
     @property
     def rank(self):
+        if getattr(self, "native_comm", False):
+            return self.comm_rank
         d = _dist()
         return d.get_rank(self.pg) if d else 0
 
@@ -208,6 +215,10 @@ class Engine:
                     v.narrow(ax, c, self.num_classes - c).fill_(fill)
 
     def broadcast_params(self, src=0):
+        if self.native_comm:
+            self._sync_stream()
+            L.check(L.lib.fcn8s_comm_broadcast_params(self.h, int(src)), self.h)
+            return
         d = _dist()
         if d and self.world_size > 1:
             self.freeze(False)
@@ -413,7 +424,7 @@ class Engine:
         ws = self.world_size
         loss = C.c_float(0.0)
         always = bool(getattr(self, "dp_always", False)) and _dist() is not None
-        if ws == 1 and optimizer == L.OPT_TF_ADAM and not always:
+        if ws == 1 and optimizer == L.OPT_TF_ADAM and not always and not self.native_comm:
             step = C.c_int64(0)
             L.check(L.lib.fcn8s_train_step(self.h, pi, dt, pl, N, H, W, float(learning_rate), float(keep_prob),
                                            float(l2_rate), where, None, C.byref(step)), self.h)
@@ -421,24 +432,29 @@ class Engine:
             if fetch_loss:
                 L.check(L.lib.fcn8s_read_loss(self.h, C.byref(loss)), self.h)
             return (float(loss.value) if fetch_loss else None), int(step.value)
-        L.check(L.lib.fcn8s_forward_loss(self.h, pi, dt, pl, N, H, W, float(keep_prob), float(l2_rate), where), self.h)
-        self._release(ka)
         trace = getattr(self, "comm_trace", None)          # bench.py: a list collects (step start, per-bucket issue / completion events)
-        if trace is not None:
+        if trace is not None:                              # t0 in front of the forward pass: the traced times are "ms after the step's first kernel"
             t0 = self.torch.cuda.Event(enable_timing=True); t0.record()
             trace.append(("step", t0, None))
-        red = BucketReducer(self.flat_grads, self.buckets, self.pg, trace=trace, always=always)
-        # bucket b is final once the call `ready_after[b]` has returned (include/fcn8s_hip.h): bucket 0 -- fc6, fc7, decoder, 479 of the
-        # 538 MB -- at its own call, so RCCL moves it while the conv stack's backward runs; the two small ones after the last call
-        ready_after = [int(L.lib.fcn8s_bucket_complete_after(self.h, b)) for b in range(L.NUM_BUCKETS)]
-        for b in range(L.NUM_BUCKETS):
+        L.check(L.lib.fcn8s_forward_loss(self.h, pi, dt, pl, N, H, W, float(keep_prob), float(l2_rate), where), self.h)
+        self._release(ka)
+        red = BucketReducer(self.flat_grads, self.buckets, self.pg, trace=trace, always=always, ready=self._bucket_ready)
+        # bucket b is final once the call `ready_after[b]` has returned (include/fcn8s_hip.h) -- by default call b itself: {fc7, decoder},
+        # {fc6}, {conv4, conv5}, {conv1 .. conv3} leave in that order, each while the rest of the backward pass runs
+        nb = self.num_buckets
+        ready_after = [int(L.lib.fcn8s_bucket_complete_after(self.h, b)) for b in range(nb)]
+        for b in range(nb):
             L.check(L.lib.fcn8s_backward_bucket(self.h, b), self.h)
             if reduce:
-                for r in range(L.NUM_BUCKETS):
+                for r in range(nb):
                     if ready_after[r] == b:
-                        red.reduce_bucket(r)
+                        if self.native_comm:
+                            L.check(L.lib.fcn8s_allreduce_bucket(self.h, r), self.h)
+                        else:
+                            red.reduce_bucket(r)
         red.wait()
-        L.check(L.lib.fcn8s_apply_update(self.h, optimizer, float(learning_rate), red.grad_scale() if reduce else 1.0), self.h)
+        scale = (1.0 / self.comm_world) if (self.native_comm and reduce) else (red.grad_scale() if reduce else 1.0)
+        L.check(L.lib.fcn8s_apply_update(self.h, optimizer, float(learning_rate), scale), self.h)     # (waits for the native all-reduces itself)
         if trace is not None:
             t1 = self.torch.cuda.Event(enable_timing=True); t1.record()
             trace.append(("end", t1, None))
@@ -450,8 +466,45 @@ class Engine:
             self.check_replicas()
         return (float(loss.value) if fetch_loss else None), step
 
+    def _bucket_ready(self, b):
+        """A torch side stream that waits for exactly the last kernel writing into gradient bucket b (fcn8s_bucket_wait): a collective
+        issued with that stream current starts when the bucket is final, not when everything queued behind it has run."""
+        torch = self.torch
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.num_buckets)]
+        st = self._side[b]
+        L.check(L.lib.fcn8s_bucket_wait(self.h, b, C.c_void_p(st.cuda_stream)), self.h)
+        return st
+
+    def comm_init_native(self, unique_id=None, rank=None, world=None):
+        """Give this model a RCCL rank of its own inside libfcn8s_hip.so (fcn8s_comm_init): from then on train_step exchanges the gradient
+        buckets through fcn8s_allreduce_bucket instead of torch.distributed.  Without arguments the unique id is made by rank 0 of the
+        current torch.distributed group and handed round through it (any backend: the group only carries 128 bytes, once)."""
+        d = _dist()
+        if unique_id is None:
+            rank = d.get_rank(self.pg) if d else 0
+            world = d.get_world_size(self.pg) if d else 1
+            buf = C.create_string_buffer(L.COMM_ID_BYTES)
+            if rank == 0:
+                L.check(L.lib.fcn8s_comm_unique_id(buf, L.COMM_ID_BYTES))
+            if d and world > 1:
+                box = [bytes(buf.raw)]
+                d.broadcast_object_list(box, src=d.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+                buf = C.create_string_buffer(box[0], L.COMM_ID_BYTES)
+            unique_id = buf.raw
+        self._sync_stream()
+        L.check(L.lib.fcn8s_comm_init(self.h, unique_id, len(unique_id), int(rank), int(world)), self.h)
+        self.native_comm, self.comm_world, self.comm_rank = True, int(world), int(rank)
+        return unique_id
+
+    def comm_info(self):
+        r, w, v = C.c_int(), C.c_int(), C.c_int()
+        L.check(L.lib.fcn8s_comm_info(self.h, C.byref(r), C.byref(w), C.byref(v)), self.h)
+        return {"rank": r.value, "world": w.value, "rccl_version": v.value}
+
     def check_replicas(self):
-        """Data-parallel guard (dp.check_replicas): every rank must hold the same global step and bit-identical parameters."""
+        """Data-parallel guard (dp.check_replicas): every rank must hold the same global step and the same bits in a sample of the
+        parameters (the sample moves with the step; replicas are identical by construction, this catches the day they are not)."""
         from .dp import check_replicas          # (the library works on torch's current stream: the reads below are ordered behind the update)
         return check_replicas(self.flat_params, self.global_step, self.pg)
 
@@ -462,7 +515,7 @@ class Engine:
         N, H, W = (int(x) for x in nhw)
         L.check(L.lib.fcn8s_forward_loss(self.h, pi, dt, pl, N, H, W, float(keep_prob), float(l2_rate), where), self.h)
         self._release(ka)
-        for b in range(L.NUM_BUCKETS):
+        for b in range(self.num_buckets):
             L.check(L.lib.fcn8s_backward_bucket(self.h, b), self.h)
         loss = C.c_float(0.0)
         L.check(L.lib.fcn8s_read_loss(self.h, C.byref(loss)), self.h)
@@ -498,6 +551,10 @@ class Engine:
 
     def metrics_allreduce(self):
         """Sum the confusion matrix and the per-batch loss samples over ranks."""
+        if self.native_comm:
+            self._sync_stream()
+            L.check(L.lib.fcn8s_comm_allreduce_metrics(self.h), self.h)
+            return
         d = _dist()
         if not d or self.world_size == 1:
             return

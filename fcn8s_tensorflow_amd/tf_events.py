@@ -128,12 +128,23 @@ def variable_stats(t):
     except ImportError:          # pragma: no cover
         torch = None
     if torch is not None and isinstance(t, torch.Tensor):
-        x = t.detach().reshape(-1).to(torch.float64)
-        lim = torch.from_numpy(_LIMITS).to(x.device)
-        idx = torch.bucketize(x, lim, right=True).clamp_(max=lim.numel() - 1)
-        counts = torch.bincount(idx, minlength=lim.numel()).cpu().numpy().astype(np.float64)
-        s, ss, mx, mn = float(x.sum()), float((x * x).sum()), float(x.max()), float(x.min())
-        n = x.numel()
+        # in chunks of 8 M elements (64 MB as float64: fc6's 103 M weights never exist as one 0.8 GB float64 copy), every partial result
+        # kept on the tensor's device and fetched in ONE transfer at the end (one host sync per variable instead of five)
+        flat = t.detach().reshape(-1)
+        lim = torch.from_numpy(_LIMITS).to(flat.device)
+        n = flat.numel()
+        counts_t = torch.zeros(lim.numel(), dtype=torch.int64, device=flat.device)
+        acc = torch.zeros(2, dtype=torch.float64, device=flat.device)
+        ext = torch.tensor([-float("inf"), float("inf")], dtype=torch.float64, device=flat.device)      # running (max, min)
+        for a in range(0, n, 1 << 23):
+            x = flat[a:a + (1 << 23)].to(torch.float64)
+            idx = torch.bucketize(x, lim, right=True).clamp_(max=lim.numel() - 1)
+            counts_t += torch.bincount(idx, minlength=lim.numel())
+            acc += torch.stack([x.sum(), (x * x).sum()])
+            ext = torch.stack([torch.maximum(ext[0], x.max()), torch.minimum(ext[1], x.min())])
+        got = torch.cat([acc, ext, counts_t.to(torch.float64)]).cpu().numpy()
+        s, ss, mx, mn = float(got[0]), float(got[1]), float(got[2]), float(got[3])
+        counts = got[4:].astype(np.float64)
     else:
         x = np.asarray(t, np.float64).reshape(-1)
         idx = np.minimum(np.searchsorted(_LIMITS, x, side="right"), len(_LIMITS) - 1)

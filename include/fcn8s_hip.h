@@ -145,8 +145,33 @@ int fcn8s_forward_loss(fcn8s_model* m, const void* images, int image_dtype, cons
 int fcn8s_backward_bucket(fcn8s_model* m, int bucket);
 int fcn8s_bucket_complete_after(const fcn8s_model* m, int bucket);
 int fcn8s_bucket_wait(fcn8s_model* m, int bucket, void* hip_stream);
-int fcn8s_apply_update(fcn8s_model* m, int optimizer, float learning_rate, float grad_scale);
+int fcn8s_apply_update(fcn8s_model* m, int optimizer, float learning_rate, float grad_scale);   /* waits (stream-ordered) for pending fcn8s_allreduce_bucket calls */
 int fcn8s_read_loss(fcn8s_model* m, float* loss_out);                /* synchronises */
+
+/* ---- data parallelism inside the library: one RCCL rank per model (SURVEY section 7 step 7, 8b "RCCL error"; the reference is one
+ * tf.Session on one device, fcn8s_tensorflow.py:65, so there is nothing to cite for the collective itself).  A caller that keeps the
+ * reference's Python and binds this ABI gets multi-GPU training without torch.distributed:
+ *     rank 0: fcn8s_comm_unique_id(id)  -> hand the FCN8S_COMM_ID_BYTES bytes to every rank by any means (file, socket, MPI)
+ *     all   : fcn8s_comm_init(m, id, FCN8S_COMM_ID_BYTES, rank, world);  fcn8s_comm_broadcast_params(m, 0)
+ *     step  : fcn8s_forward_loss; for b in 0 .. fcn8s_num_buckets-1 { fcn8s_backward_bucket(m, b); for every bucket r with
+ *             fcn8s_bucket_complete_after(m, r) == b: fcn8s_allreduce_bucket(m, r) }; fcn8s_apply_update(m, opt, lr, 1.0f / world)
+ *     eval  : fcn8s_eval_step ...; fcn8s_comm_allreduce_metrics(m); fcn8s_metrics_get
+ * fcn8s_allreduce_bucket queues an in-place SUM all-reduce of the bucket on a stream the library owns, behind the event of the last
+ * kernel that writes into the bucket (never behind later backward kernels) and returns at once; fcn8s_comm_wait makes the model's
+ * stream wait for all of them (fcn8s_apply_update does it implicitly).  librccl is opened with dlopen at the first fcn8s_comm_* call:
+ * a failure there, or in any collective, is FCN8S_ERR_RCCL with RCCL's text in fcn8s_last_error.                                      */
+/* "dddd:bb:dd.f" of a HIP device (hipDeviceGetPCIBusId): lets a launcher bind each rank's host threads and decode workers to the
+ * NUMA node of its GPU through /sys/bus/pci/devices/<id>/local_cpulist (fcn8s_tensorflow_amd/dp.py: bind_to_gpu_numa). */
+int fcn8s_device_pci_bus_id(int device_id, char* out, size_t len);
+#define FCN8S_COMM_ID_BYTES 128
+int fcn8s_comm_unique_id(void* id_out, size_t nbytes);
+int fcn8s_comm_init(fcn8s_model* m, const void* unique_id, size_t nbytes, int rank, int world);
+int fcn8s_comm_destroy(fcn8s_model* m);
+int fcn8s_comm_info(const fcn8s_model* m, int* rank, int* world, int* rccl_version);   /* world = 0 without a communicator */
+int fcn8s_allreduce_bucket(fcn8s_model* m, int bucket);
+int fcn8s_comm_wait(fcn8s_model* m);
+int fcn8s_comm_broadcast_params(fcn8s_model* m, int root);
+int fcn8s_comm_allreduce_metrics(fcn8s_model* m);
 
 /* ---- asynchronous host boundary (the reference's feed_dict copies, :558-560, are synchronous inside sess.run) ----------------
  * fcn8s_stage_inputs copies one host batch (images [N,H,W,3] uint8/float32, optional uint8 class ids [N,H,W]) into pinned
@@ -218,11 +243,14 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *                              (that conv's weight gradient and adjoint data gradient consume only dM): its dZ is never written; 0 = two kernels
  *     "bf16_gemm256"      1    FCN8S_PREC_BF16_FC: fc6 / fc7 forward on the 256 x 256 LDS-DMA kernel -- 0 never, 1 when the launch has at least
  *                              128 tiles (training batches), 2 whenever the shapes allow (rows and Cout multiples of 256)
- *   process-wide option (m == NULL), for the op-level entry points below, which have no model:
- *     "op_f32x3"          0    their LDS-DMA GEMMs use the split-bf16 arithmetic of FCN8S_PREC_F32X3
- *     "op_split_pieces"   0    the same switch by piece count: 0 = f32 MFMA, 3 = FCN8S_PREC_F32X3, 2 = FCN8S_PREC_F32X2
  *     "conv1_tiled"       1    conv1_1 forward on the spatial-tile kernel (halo tile in LDS); 0 = the LDS-DMA gather kernel (bit-identical results)
  *     "conv1_wgrad_mfma"  1    conv1_1 weight gradient as a (27 -> 32) x 64 MFMA product over pixels; 0 = the VALU kernel
+ *                              (these two pick a kernel per launch and drop nothing)
+ *   op-context options (m == NULL): the arithmetic of the op-level entry points below, which have no model.  The value belongs to the
+ *   CALLING THREAD (thread-local) and is read by that thread's later fcn8s_op_* calls only; no model ever reads it, so two models -- or a
+ *   feeder thread beside a compute thread -- cannot change each other's kernels:
+ *     "op_f32x3"          0    their LDS-DMA GEMMs use the split-bf16 arithmetic of FCN8S_PREC_F32X3
+ *     "op_split_pieces"   0    the same switch by piece count: 0 = f32 MFMA, 3 = FCN8S_PREC_F32X3, 2 = FCN8S_PREC_F32X2
  * Unknown keys return FCN8S_ERR_NOT_FOUND. */
 int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value);
 int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value);

@@ -55,13 +55,27 @@ def test_layout_matches_reference_variable_table():
             prev_end = off.value + int(np.prod(specs[nm]))
         assert names == list(specs) and prev_end <= total
         # gradient buckets: contiguous partition of the flat buffer, produced in backward order
+        nb = _lib.lib.fcn8s_layout_num_buckets(C.byref(cfg))
+        assert 3 <= nb <= _lib.MAX_BUCKETS
         rng = []
-        for b in range(3):
+        for b in range(nb):
             o = C.c_size_t(); m = C.c_size_t()
             assert _lib.lib.fcn8s_layout_bucket(C.byref(cfg), b, C.byref(o), C.byref(m)) == 0
             rng.append((o.value, m.value))
-        assert rng[2][0] == 0 and rng[2][0] + rng[2][1] == rng[1][0] and rng[1][0] + rng[1][1] == rng[0][0]
-        assert rng[0][0] + rng[0][1] == total
+        assert _lib.lib.fcn8s_layout_bucket(C.byref(cfg), nb, C.byref(o), C.byref(m)) == _lib.ERR_BAD_ARG
+        # ... the last-produced bucket starts at 0, each earlier one follows it, the first-produced one ends the buffer
+        assert rng[-1][0] == 0 and rng[0][0] + rng[0][1] == total
+        for b in range(nb - 1, 0, -1):
+            assert rng[b][0] + rng[b][1] == rng[b - 1][0]
+        # fc6's kernel has a bucket of its own (its 411 MB must not hold back the rest of the head, nor wait for it)
+        offs = {nm: None for nm in names}
+        for i in range(n):
+            name = C.create_string_buffer(64); nd = C.c_int32(); shp = (C.c_int64 * 4)(); off = C.c_int64()
+            _lib.lib.fcn8s_layout_param(C.byref(cfg), i, name, C.byref(nd), C.byref(shp), C.byref(off))
+            offs[name.value.decode()] = off.value
+        inb = lambda nm: [b for b, (o_, n_) in enumerate(rng) if o_ <= offs[nm] < o_ + n_][0]
+        assert inb("fc7/weights") == inb("pool3_1x1/kernel") == inb("fc7_pool4_pool3_conv2d_trans/bias") == 0
+        assert inb("fc6/weights") == inb("fc6/biases") == 1 and inb("conv5_3/filter") == inb("conv4_1/filter") == 2 and inb("conv1_1/filter") == inb("conv3_3/biases") == 3
 
 
 def test_bad_config_is_rejected_without_gpu():

@@ -101,11 +101,28 @@ def test_bench_self_launches_two_ranks():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     c = out["comm"]
     assert c["backend"] == "gloo" and c["rccl_ranks"] == 0 and out["rccl_ranks"] == 0 and c["ranks"] == 2       # gloo ranks are not RCCL ranks
-    assert len(c["allreduce_ms_per_bucket_standalone"]) == 3 and len(out["per_rank_ms"]) == 2
-    assert len(c["bucket_issue_ms"]) == 3 and all(d >= i for i, d in zip(c["bucket_issue_ms"], c["bucket_complete_ms"]))
+    assert len(c["allreduce_ms_per_bucket_standalone"]) == 4 and len(out["per_rank_ms"]) == 2
+    assert len(c["bucket_issue_ms"]) == 4 and all(d >= i for i, d in zip(c["bucket_issue_ms"], c["bucket_complete_ms"]))
     assert c["bucket_issue_ms"] == sorted(c["bucket_issue_ms"])                        # buckets leave in backward-production order
     assert out["value"] > 0 and np.isfinite(out["final_loss"])
     assert len(out["timed_regions_ms_per_step"]) == 3 and out["timed_regions"]["min_ms_per_step"] <= out["ms_per_step"] <= out["timed_regions"]["max_ms_per_step"]
+
+
+def test_bench_eight_ranks_dry_run_on_one_gpu():
+    """The first 8-GPU run must not be the first time eight ranks meet: `python bench.py --gpus 8` exactly as the driver calls it, the eight
+    ranks sharing this box's one GPU over gloo.  Eight per-rank times, global batch 8 x 2, all four buckets traced in backward-production
+    order, every rank bound (or knowingly not) to its GPU's NUMA node, and the replicas still bit-identical after the timed steps."""
+    out = _run_bench("--gpus", "8", "--backend", "gloo", "--device", "0", "--steps", "2", "--warmup", "1", "--repeats", "1", "--batch", "2",
+                     "--height", "64", "--width", "64", "--no-cpu-baseline", timeout=1500)
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp8"
+    assert len(out["per_rank_ms"]) == 8 and all(t > 0 for t in out["per_rank_ms"])
+    c = out["comm"]
+    assert c["ranks"] == 8 and c["rccl_ranks"] == 0 and c["replicas_identical_after_timed_steps"] is True
+    assert len(c["bucket_mb"]) == len(c["bucket_issue_ms"]) == len(c["bucket_complete_ms"]) == len(c["allreduce_ms_per_bucket_standalone"]) == 4
+    assert abs(sum(c["bucket_mb"]) - 537.9) < 1.0 and c["bucket_mb"][1] > 400                      # fc6 alone
+    assert c["bucket_issue_ms"] == sorted(c["bucket_issue_ms"]) and all(d >= i for i, d in zip(c["bucket_issue_ms"], c["bucket_complete_ms"]))
+    assert c["exposed_comm_ms_per_step"] is not None and c["local_only_ms_per_step"] > 0 and isinstance(c["numa"], dict)
+    assert out["value"] > 0 and np.isfinite(out["final_loss"])
 
 
 def test_bench_measures_roofline_traffic_live():
@@ -127,7 +144,7 @@ def test_bench_measures_roofline_traffic_live():
 
 def test_bench_under_torchrun_one_rank_rccl():
     """bench.py launched the way the driver launches it for N > 1 -- `python -m torch.distributed.run ... bench.py --gpus N` -- with the one
-    rank this box has: the process group is RCCL (backend nccl), the three bucketed all-reduces run through it inside every step, and the
+    rank this box has: the process group is RCCL (backend nccl), the four bucketed all-reduces run through it inside every step, and the
     line says so (rccl_ranks == 1).  More ranks than GPUs cannot run over RCCL here; the 2-rank path is covered over gloo above."""
     import socket
     with socket.socket() as so:
@@ -140,7 +157,8 @@ def test_bench_under_torchrun_one_rank_rccl():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     c = out["comm"]
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and c["backend"] == "nccl" and c["rccl_ranks"] == 1
-    assert len(c["bucket_issue_ms"]) == 3 and all(d >= i for i, d in zip(c["bucket_issue_ms"], c["bucket_complete_ms"]))
+    assert len(c["bucket_issue_ms"]) == 4 and all(d >= i for i, d in zip(c["bucket_issue_ms"], c["bucket_complete_ms"]))
+    assert c["rccl_version"] and "nccl_env" in c and len(c["allreduce_gbs_per_bucket_standalone"]) == 4
     assert all(np.isfinite(x) and x >= 0 for x in c["allreduce_ms_per_bucket_standalone"])
     assert c["overlap_frac"] is None or 0.0 <= c["overlap_frac"] <= 1.0
     assert np.isfinite(out["final_loss"]) and out["value"] > 0
@@ -154,6 +172,72 @@ def test_run_dp_launches_two_ranks_and_trains():
                         "--height", "64", "--width", "64", "--steps-per-epoch", "2", "--workers", "0"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "rank 0: 2 ranks x 2 images/step, global step 2" in r.stdout, r.stdout[-1000:]
+
+
+def test_run_dp_eight_ranks_dry_run():
+    """run_dp.py with eight ranks on the one GPU (gloo): FCN8s.train() on eight file shards, evaluation all-reduced, replica guard on."""
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_dp.py"), "--gpus", "8", "--backend", "gloo", "--device", "0", "--batch", "1",
+                        "--height", "64", "--width", "64", "--steps-per-epoch", "2", "--workers", "0"], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rank 0: 8 ranks x 1 images/step, global step 2" in r.stdout, r.stdout[-1000:]
+
+
+def test_bench_under_torchrun_one_rank_native_rccl():
+    """`--comm native`: the gradient buckets are all-reduced by the library's own RCCL communicator (fcn8s_comm_init /
+    fcn8s_allreduce_bucket behind the C ABI), torch.distributed only carried the 128-byte id.  One rank is all this box has."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--height", "64", "--width", "64", "--no-cpu-baseline", "--comm", "native"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = out["comm"]
+    assert c["collectives_by"].startswith("libfcn8s_hip") and c["rccl_version"]
+    assert np.isfinite(out["final_loss"]) and out["value"] > 0 and out["backward_check"]["ok"]
+
+
+def test_native_rccl_communicator_one_rank():
+    """fcn8s_comm_* through the C ABI with the one rank this box has (ncclCommInitRank, world 1): a training step whose four buckets go
+    through fcn8s_allreduce_bucket (SUM over one rank = identity, scale 1/1) equals the plain step; the call-order errors are reported;
+    fcn8s_bucket_wait makes a foreign stream wait for a bucket; the metrics all-reduce leaves one rank's counts unchanged."""
+    from fcn8s_tensorflow_amd import _lib as L
+    P = orc.init_params(20, SMALL, seed=1, decoder_std_scale=30.0, bias_std=0.05)
+    img, lab = _batch(2, 32, 64, 3)
+    a, b = _engine(), _engine()
+    a.set_params(P); b.set_params(P)
+    assert b.comm_info()["world"] == 0
+    assert L.lib.fcn8s_allreduce_bucket(b.h, 0) == L.ERR_STATE and b"fcn8s_comm_init" in L.lib.fcn8s_last_error(b.h)
+    b.comm_init_native()
+    info = b.comm_info()
+    assert info["world"] == 1 and info["rank"] == 0 and info["rccl_version"] >= 20000 and b.world_size == 1
+    assert L.lib.fcn8s_comm_init(b.h, b"\0" * 128, 128, 0, 1) == L.ERR_STATE            # one communicator per model
+    nb = b.num_buckets
+    assert nb == 4 and [int(L.lib.fcn8s_bucket_complete_after(b.h, r)) for r in range(nb)] == list(range(nb))
+    b._sync_stream()
+    assert L.lib.fcn8s_bucket_wait(b.h, 0, None) == L.ERR_STATE                           # nothing queued yet
+    la, sa = a.train_step(img, lab, 1e-3, keep_prob=1.0, optimizer=L.OPT_SGD_MOMENTUM)
+    lb, sb = b.train_step(img, lab, 1e-3, keep_prob=1.0, optimizer=L.OPT_SGD_MOMENTUM)
+    assert la == lb and sa == sb == 1
+    assert float((a.flat_params - b.flat_params).abs().max()) <= 1e-6 * float(a.flat_params.abs().max())     # (weight-gradient atomics: order only)
+    # a foreign stream can wait for each bucket after its call, and a bucket cannot be reduced twice in one pass
+    b.forward_backward(img, lab, keep_prob=1.0)
+    side = torch.cuda.Stream()
+    for r in range(nb):
+        assert L.lib.fcn8s_bucket_wait(b.h, r, C.c_void_p(side.cuda_stream)) == 0
+    assert L.lib.fcn8s_allreduce_bucket(b.h, 1) == 0 and L.lib.fcn8s_allreduce_bucket(b.h, 1) == L.ERR_STATE
+    assert L.lib.fcn8s_comm_wait(b.h) == 0
+    side.synchronize(); torch.cuda.synchronize()
+    b.metrics_reset(); b.eval_step(img, lab); before = b.metrics_raw()
+    b.metrics_allreduce(); after = b.metrics_raw()
+    np.testing.assert_array_equal(before[0], after[0]); assert before[1:] == after[1:] and after[0].sum() == lab.size
+    b.broadcast_params(0)
+    np.testing.assert_array_equal(b.get_params()["conv1_1/filter"], b.get_params()["conv1_1/filter"])
+    assert L.lib.fcn8s_comm_destroy(b.h) == 0 and b.comm_info()["world"] == 0
+    a.close(); b.close()
 
 
 def test_bench_single_gpu_line_and_end_to_end_mode():

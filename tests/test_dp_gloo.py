@@ -83,12 +83,13 @@ def _guard_worker(rank, world, port, out):
             if mutate == "step":
                 step = 8
             elif mutate == "param":
-                f[(f.numel() // (1 << 16)) * 5] += 1e-7 * (1 + abs(float(f[(f.numel() // (1 << 16)) * 5])))
+                st = f.numel() // (1 << 16); i0 = step % st              # (the sample starts at global_step % stride)
+                f[i0 + st * 5] += 1e-7 * (1 + abs(float(f[i0 + st * 5])))
             elif mutate == "swap":
-                st = f.numel() // (1 << 16)
-                a, b = float(f[st * 10]), float(f[st * 20]); f[st * 10] = b; f[st * 20] = a
+                st = f.numel() // (1 << 16); i0 = step % st
+                a, b = float(f[i0 + st * 10]), float(f[i0 + st * 20]); f[i0 + st * 10] = b; f[i0 + st * 20] = a
             else:
-                f[0] = float("nan")
+                f[step % (f.numel() // (1 << 16))] = float("nan")
         try:
             dp.check_replicas(f, step)
             res.append("passed")
@@ -110,3 +111,32 @@ def test_replica_guard_raises_on_every_rank_when_replicas_differ():
         assert "global step (7 .. 8)" in res[1], res[1]
         for msg in res[2:]:
             assert "parameter checksum" in msg, msg
+
+
+def test_numa_share_and_cpulist():
+    """Host logic of dp.bind_to_gpu_numa: the CPUs of a GPU's NUMA node, cut evenly among the ranks whose GPUs share the node."""
+    from fcn8s_tensorflow_amd import dp
+    assert dp.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and dp.parse_cpulist("") == []
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]                                   # eight GPUs on two sockets
+    cpus = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    shares = [dp.numa_share(nodes, cpus, d) for d in range(8)]
+    assert all(len(s_) == 32 for s_ in shares)
+    assert sorted(sum(shares[:4], [])) == sorted(cpus[0]) and sorted(sum(shares[4:], [])) == sorted(cpus[1])      # disjoint, complete
+    assert dp.numa_share([-1], cpus, 0) is None                                                # node unknown: leave the affinity alone
+    assert dp.numa_share([0], {0: [0, 1, 2, 3]}, 0, allowed={2, 3, 9}) == [2, 3]                  # never outside the inherited affinity
+    assert dp.numa_share([0, 0, 0], {0: [0, 1]}, 1) is None                                    # fewer CPUs than ranks: do not bind
+    import torch
+    if not torch.cuda.is_available():
+        assert dp.bind_to_gpu_numa(0)["bound"] is False                                        # no GPU: reports why, never raises
+
+
+def test_replica_fingerprint_sample_moves_with_the_step():
+    """The guard looks at a strided sample; its offset is the global step modulo the stride, so a corrupted element outside one
+    check's sample is inside a later one's."""
+    import torch
+    from fcn8s_tensorflow_amd import dp
+    a = torch.arange(1000, dtype=torch.float32)
+    b = a.clone(); b[7] += 1.0                                           # stride 10: element 7 is in the sample of steps 7, 17, ...
+    same = [bool((dp.replica_fingerprint(a, t, samples=100) == dp.replica_fingerprint(b, t, samples=100)).all()) for t in range(10)]
+    assert same == [True] * 7 + [False] + [True] * 2
+    assert not bool((dp.replica_fingerprint(a, 0, samples=1000) == dp.replica_fingerprint(b, 0, samples=1000)).all())   # samples = numel: everything

@@ -231,6 +231,22 @@ def test_worker_pool_error_does_not_leave_replies_behind(tmp_path):
     g.close()
 
 
+def test_worker_pool_says_it_is_closed_after_a_worker_died(tmp_path):
+    """A decode worker that dies takes the pool down (its other replies never come); whoever catches that error and pulls another batch
+    gets a clear RuntimeError about the closed pool -- not a ZeroDivisionError from an empty process list."""
+    import random
+    make = _png_tree(tmp_path)
+    random.seed(1); np.random.seed(1)
+    g = make().generate(batch_size=2, workers=2, shuffle=False)
+    g.next_ids()
+    g.pool.procs[0].kill(); g.pool.procs[0].wait()
+    with pytest.raises(RuntimeError, match="worker died"):
+        g.next_ids()
+    with pytest.raises(RuntimeError, match="shut down after a worker died"):
+        g.next_ids()
+    g.close()
+
+
 def test_feeder_thread_stops_when_the_consumer_gives_up():
     """_Feeder.close() (called from a finally in the train / evaluate loops) ends the helper thread: it pulls no further batches from
     the user's generator and is not left inside Engine.stage while the model closes."""

@@ -672,7 +672,6 @@ def test_conv1_1_tile_kernel_is_bit_identical_to_the_gather_kernel():
         np.testing.assert_array_equal(outs[0], outs[1])
         ref = orc.forward(P, img, keep=True)[1]["conv1_1"]
         assert rel(outs[0], ref) < 1e-5
-    Engine(20, options={"conv1_tiled": 1}).close()          # leave the process-wide default in place
 
 
 def test_conv1_1_weight_gradient_mfma_kernel():
@@ -697,7 +696,6 @@ def test_conv1_1_weight_gradient_mfma_kernel():
             e.close()
         for a, b in zip(got[0], got[1]):
             assert np.abs(b).max() > 0 and rel(a, b) < 2e-5, (n, h, w, rel(a, b))
-    Engine(20, options={"conv1_wgrad_mfma": 1}).close()          # leave the process-wide default in place
 
 
 @pytest.mark.parametrize("widths,n,h,w,expect", [(None, 2, 32, 64, None), (None, 1, 96, 160, True), ((64, 192, 192, 64, 64, 128, 192), 1, 96, 160, True),
@@ -725,3 +723,53 @@ def test_fused_dgrad_output_and_next_dout_transform(widths, n, h, w, expect):
     assert got[0][0] == got[1][0]
     for k in got[1][1]:
         assert rel(got[0][1][k], got[1][1][k]) < 2e-5, (k, rel(got[0][1][k], got[1][1][k]))
+
+
+def test_two_engines_with_different_options_do_not_touch_each_other():
+    """Every algorithm option lives in the model it was set on (round 3 still had three process-wide switches): two engines alive in one
+    process with opposite settings each keep running their own kernels, in either order of use, and a third engine made afterwards has
+    the defaults.  The op-level context (fcn8s_set_option(NULL, ...)) is per thread and never reaches a model."""
+    from fcn8s_tensorflow_amd.engine import Engine
+    from fcn8s_tensorflow_amd import _lib as L
+    import ctypes as C
+    P = orc.init_params(20, seed=12, decoder_std_scale=6.0, bias_std=0.05)
+    img, lab = batch(2, 32, 64, seed=43)
+    a = Engine(20, options={"conv1_tiled": 0, "conv1_wgrad_mfma": 0})
+    b = Engine(20, options={"conv1_tiled": 1, "conv1_wgrad_mfma": 1}, precision="f32x2")
+    L.check(L.lib.fcn8s_set_option(None, b"op_split_pieces", 3))          # this thread's op context: must not leak into either model
+    try:
+        def kernels(e):
+            e.set_params(P)
+            e.profile(2); e.profile_reset()
+            e.forward_backward(img, lab, keep_prob=1.0)
+            ks = [k for k in e.profile_results() if k.startswith("kernel:")]
+            e.profile(0)
+            return ks
+        for order in ((a, b), (b, a), (a, b)):
+            for e in order:
+                ks = kernels(e)
+                if e is a:
+                    assert any("conv1_glds_kernel" in k for k in ks) and not any("conv1_tile_kernel" in k for k in ks), ks
+                    assert not any("conv1_wgrad_mfma_kernel" in k for k in ks), ks
+                    assert any("gemm_glds_kernel<" in k for k in ks) and not any("_x2_kernel" in k or "_x3_kernel" in k for k in ks), ks
+                else:
+                    assert any("conv1_tile_kernel" in k for k in ks) and any("conv1_wgrad_mfma_kernel" in k for k in ks), ks
+                    assert any("_x2_kernel" in k for k in ks) and not any("gemm_glds_kernel<" in k or "_x3_kernel" in k for k in ks), ks
+        assert (a.get_option("conv1_tiled"), a.get_option("conv1_wgrad_mfma")) == (0, 0) and (b.get_option("conv1_tiled"), b.get_option("conv1_wgrad_mfma")) == (1, 1)
+        c = Engine(20)
+        assert (c.get_option("conv1_tiled"), c.get_option("conv1_wgrad_mfma")) == (1, 1)
+        ks = kernels(c)
+        assert any("conv1_tile_kernel" in k for k in ks) and any("gemm_glds_kernel<" in k for k in ks) and not any("_x3_kernel" in k for k in ks), ks
+        c.close()
+        # the op context belongs to the thread that set it
+        import threading
+        seen = []
+        def other():
+            v = C.c_int64(-1); L.check(L.lib.fcn8s_get_option(None, b"op_split_pieces", C.byref(v))); seen.append(int(v.value))
+        t = threading.Thread(target=other); t.start(); t.join()
+        v = C.c_int64(-1); L.check(L.lib.fcn8s_get_option(None, b"op_split_pieces", C.byref(v)))
+        assert seen == [0] and v.value == 3
+        assert L.lib.fcn8s_set_option(None, b"conv1_tiled", 0) == L.ERR_NOT_FOUND           # a model option needs a model
+    finally:
+        L.check(L.lib.fcn8s_set_option(None, b"op_split_pieces", 0))
+        a.close(); b.close()
