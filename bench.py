@@ -564,13 +564,9 @@ def main():
         fetch_ms = round((time.perf_counter() - tf_) / args.steps * 1e3, 3)
         # is the backward pass the derivative of the forward pass?  Central difference of the loss along the gradient on 2 images of
         # the batch: (L(theta + eps g) - L(theta - eps g)) / (2 eps |g|^2) must be 1 (tests/test_fullsize_gpu.py does the same at 4 images).
-        # The decoder is scaled up for this: with the reference's init the loss is flat to fp32 resolution.
         try:
             keep = eng.flat_params.clone()
-            for k, (shape, off) in eng.specs.items():
-                if ("1x1" in k or "trans" in k) and len(shape) > 1:
-                    eng.flat_params[off:off + int(np.prod(shape))].mul_(30.0)
-            theta = eng.flat_params.clone()
+            theta = keep
             nb_ = min(2, N)
             eng.forward_backward(images[:nb_], labels[:nb_], keep_prob=1.0)
             g = eng.flat_grads.clone()
@@ -583,7 +579,7 @@ def main():
                 ratios.append(round((lp - lm) / (2 * target), 4))
             eng.flat_params.copy_(keep)
             bcheck = {"directional_derivative_ratios": ratios, "ok": bool(any(0.97 < r < 1.03 for r in ratios)),
-                      "what": "central difference of the loss along its own gradient / |g|^2 at three step sizes (2 images, decoder x30, keep_prob 1): 1 = the backward pass is the derivative of the forward pass"}
+                      "what": "central difference of the loss along its own gradient / |g|^2 at three step sizes (2 images, keep_prob 1): 1 = the backward pass is the derivative of the forward pass"}
         except Exception as ex:
             bcheck = {"error": repr(ex)}
 

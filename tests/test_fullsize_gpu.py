@@ -99,6 +99,41 @@ def test_config2_inference_1024x512_bs1_vs_oracle():
     e.close()
 
 
+@pytest.mark.parametrize("mode,kw,rel_bound,abs_bound_x5,max_mismatch,margin", [
+    # (precision, what the oracle rounds, logit error / scale, absolute logit error with the O(1-10) decoder, differing pixels allowed, safe margin / scale)
+    ("f32x3", {}, 1e-4, 1e-3, 16, 2e-3),                    # fp32-accurate by construction: the fp32 bounds (measured 7e-6, 1.1e-4, 3-5 pixels)
+    ("f32x2", {}, 4e-4, 4e-3, 160, 2e-3),                   # 16 significand bits: measured 1.2e-4, 1.9e-3 ABSOLUTE (outside north_star's 1e-3: a reduced-precision mode), 47-54 pixels
+    ("bf16_fwd", {"bf16_fc": True, "bf16_convs": True}, 3e-2, 0.5, 10500, 6e-2),      # 8-bit forward operands against the same-rounding oracle: measured 8e-3 .. 1e-2, 0.16, 0.7-0.8 % of the pixels
+    ("bf16_fwd_x2", {"bf16_fc": True, "bf16_convs": True}, 3e-2, 0.5, 10500, 6e-2)])
+def test_config2_precision_modes_1024x512_bs1_vs_oracle(mode, kw, rel_bound, abs_bound_x5, max_mismatch, margin):
+    """Config 2's size in every optional arithmetic (round 3 gated these modes at 2 x 32x64 and 256x256 only; the figures were in
+    profiles/parity_r03.json but no test held them): logits against the oracle -- for the bf16-forward modes the oracle that rounds the
+    same operands of the same layers -- relative to the logit scale with the x30 decoder and ABSOLUTE with the O(1-10) decoder, the
+    argmax identical wherever the oracle's top-2 margin exceeds `margin` x scale, and the number of differing pixels bounded."""
+    from fcn8s_tensorflow_amd.engine import Engine
+    img, _ = orc.synthetic_batch(1, 512, 1024)
+    e = Engine(20, precision=mode)
+    for pname, P in (("x30", orc.init_params(20, seed=0, decoder_std_scale=30.0, bias_std=0.05)), ("x5", orc.init_params(20, seed=1, decoder_std_scale=5.0, bias_std=0.05))):
+        e.set_params(P)
+        pred = e.predict(img, argmax=True)
+        logits = e.activation("logits", (1, 512, 1024, 20))
+        ref = orc.forward(P, img, **kw)
+        scale = max(1.0, float(np.abs(ref).max()))
+        err = float(np.abs(logits - ref).max())
+        srt = np.sort(ref, -1)
+        safe = (srt[..., -1] - srt[..., -2]) > margin * scale
+        ref_arg = np.argmax(orc.softmax(ref), -1)
+        n_diff = int((pred != ref_arg).sum())
+        print("config 2 [%s, decoder %s]: max |logit| %.1f, error %.3e (%.2e of scale), %d of %d pixels differ, %d above the margin"
+              % (mode, pname, scale, err, err / scale, n_diff, pred.size, int((pred != ref_arg)[safe].sum())))
+        assert err < rel_bound * scale, (pname, err / scale)
+        if pname == "x5":
+            assert 0.5 < scale < 50.0 and err < abs_bound_x5, err
+        assert safe.mean() > 0.1 and (pred[safe] == ref_arg[safe]).all(), (float(safe.mean()), int((pred != ref_arg)[safe].sum()))
+        assert n_diff <= max_mismatch, n_diff
+    e.close()
+
+
 @pytest.mark.parametrize("variant,options,bound", [("F(6x6) for all twelve 3x3 layers, F(4x4,4x4) for fc6 (the default)", {}, 1e-4)])
 def test_config3_gradients_1024x512_bs1_vs_oracle(variant, options, bound):
     """Every one of the 42 gradient tensors of a full-width training step at 1024x512 against the oracle (autograd over the CPU
@@ -325,8 +360,8 @@ def test_config5_bf16_fwd_2048x1024_bs4(mode):
 
     # (iii) image k of the batch equals image k alone -- up to what bf16 operand rounding does to fp32 summation-order differences: a batch of
     #       one takes other tile shapes (and F(4x4) for conv1_2 / conv2_x is chosen per launch size), an activation that differs in its last
-    #       fp32 bit can round to the other bf16 neighbour (a 2^-8 step), so the logits agree to a few 1e-3 of their scale, not to fp32
-    #       round-off; the argmax must agree wherever the top-2 margin exceeds twice the bound
+    #       fp32 bit can round to the other bf16 neighbour (a 2^-8 step), so the logits agree to 7e-3 of their scale (measured), not to
+    #       fp32 round-off; the argmax must agree wherever the top-2 margin exceeds twice the bound
     full = np.asarray(torch.as_tensor(e.predict(imgd, argmax=True)).cpu())[K]
     lg_full = e.activation("logits", (N, H, W, C))[K].copy()
     one = np.asarray(torch.as_tensor(e.predict(imgd[K:K + 1], argmax=True)).cpu())[0]
@@ -334,11 +369,11 @@ def test_config5_bf16_fwd_2048x1024_bs4(mode):
     scale = max(1.0, float(np.abs(lg_one).max()))
     d = float(np.abs(lg_full - lg_one).max()) / scale
     srt = np.sort(lg_one, -1)
-    safe = (srt[..., -1] - srt[..., -2]) > 2e-2 * scale
+    safe = (srt[..., -1] - srt[..., -2]) > 4e-2 * scale
     print("config 5 [%s]: image %d in the batch vs alone: logits differ by %.2e of their scale, argmax on %d of %d pixels (%d of them above the margin)"
           % (mode, K, d, int((full != one).sum()), one.size, int((full != one)[safe].sum())))
-    assert d < 1e-2, d
-    assert safe.mean() > 0.5 and (full[safe] == one[safe]).all()
+    assert d < 2e-2, d                                        # measured 7.2e-3 .. 7.4e-3
+    assert safe.mean() > 0.1 and (full[safe] == one[safe]).all()
     del lg_full, lg_one, srt
 
     # (ii) closed forms and batch linearity
