@@ -91,6 +91,7 @@ SIGNATURES = {
     "fcn8s_get_activation": (_i, [_p, C.c_char_p, _p, _sz]),
     "fcn8s_get_dropout_masks": (_i, [_p, _p, _sz, _p, _sz]),
     "fcn8s_get_pool_routing": (_i, [_p, _i, _p, _sz]),
+    "fcn8s_get_relu_record": (_i, [_p, C.c_char_p, _p, _sz]),
     "fcn8s_crc32c": (C.c_uint32, [_p, _sz, C.c_uint32]),
     "fcn8s_profile_enable": (_i, [_p, _i]),
     "fcn8s_profile_reset": (_i, [_p]),

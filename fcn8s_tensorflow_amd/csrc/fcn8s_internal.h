@@ -193,6 +193,7 @@ void launch_wino_dgrad_output_dout(const float* dv, const unsigned* rbits_in, fl
 void launch_wino_dgrad_output_sub44(const float* dv, float* dx, int N, int H, int W, int C, hipStream_t s);   // fc6: see winograd.hip
 void launch_wino_dgrad_output(const float* dv, const float* addend, const float* mask, float mask_scale, const unsigned* rbits_in, float* y,
                               int N, int H, int W, int C, hipStream_t s);
+bool launch_wino_out_in(const float* m, const float* bias, float* v, unsigned* rbits_out, int N, int H, int W, int C, hipStream_t s, bool always = false);   // conv L's output transform + conv L+1's input transform in one kernel (Y never written); false = shape not covered
 void launch_wino_dfilter(int tile, const float* du, float* dw, int Cin, int Cout, int KS, hipStream_t s);        // du[P][nsub*Cin][Cout] -> dw[KS*KS][Cin][Cout]
 // params: int[4] per image = {y offset, x offset, flip, brightness on/off}; vlut: [N][256] new V per old V (may be nullptr)
 void launch_augment_u8(const unsigned char* img, const unsigned char* lab, unsigned char* oimg, unsigned char* olab, const int* params,

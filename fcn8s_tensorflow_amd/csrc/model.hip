@@ -88,6 +88,9 @@ struct fcn8s_model {
     std::string dm_layer;                                                 // layer whose dM = A dY A^T sits in d_wino_m, ready for the adjoint data gradient
     std::string dm_prefilled;                                             // layer whose dM the data gradient of the layer after it has already written into d_wino_m (fused transform)
     int fuse_dgrad_dout = 1;                                              // option: allow that fusion
+    int fuse_out_in = 1;                                                  // option: inside a block, conv L's output transform writes conv L+1's V directly (Y is never written): 0 never, 1 when the launch fills the chip, 2 always
+    std::string fwd_v_layer;                                              // forward: layer whose V the previous layer's fused output transform has already written
+    std::set<std::string> y_unwritten;                                    // layers whose activation tensor was not materialised by the last forward pass
     int conv1_tiled = 1, conv1_wgrad_mfma = 1;                            // options: conv1_1 forward on the spatial-tile kernel / its weight gradient on the matrix core
     unsigned short* d_wbf16 = nullptr; size_t wbf16_elems = 0;            // bf16 copy of one layer's kernel at a time (K-tile-major or transposed)
     std::map<std::string, unsigned short*> wbf16_cache;                   // ... per layer, valid while frozen
@@ -271,6 +274,7 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
              const char* in_layer = nullptr;              // ... under this producer's name in rbits_ok
              int lazy_wt = 0;                            // data gradient: `w` is still to be filled from w_fwd (flip + transpose) if the adjoint path is not taken
              float* dm_out = nullptr; const char* dm_out_layer = nullptr;   // adjoint data gradient: write dM of the producing layer (name) here instead of its dZ into y
+             float* next_v = nullptr; const char* next_layer = nullptr;   // forward, Winograd F(6x6) path: write the NEXT conv's V here instead of this conv's output
              int skip_y = 0; };                          // Winograd path with pool_out: do not write the full-resolution output (only its pool is consumed)            // data gradient: the layer's forward kernel [3,3,Cout_of_this_conv... = Cin here][...] (adjoint Winograd path)
 
 // 3x3 SAME conv through Winograd F(tile x tile, 3x3): filter transform, input transform, (tile+2)^2 batched GEMMs
@@ -317,7 +321,8 @@ long long wino_tiles(int tile, int N, int H, int W) { return (long long)N * ((H 
 struct WinoEpi { const float* bias = nullptr; const float* addend = nullptr; const float* mask = nullptr; float mask_scale = 1.f;
                  int relu = 0; int dropout = 0; float keep = 1.f; unsigned long long seed = 0; unsigned int stream_id = 0; float* pool = nullptr; unsigned char* pidx = nullptr;
                  unsigned* rbits_out = nullptr; const unsigned* rbits_in = nullptr; int skip_y = 0;
-                 unsigned* in_rbits_out = nullptr; };     // ReLU bit record of the INPUT, written by the input transform
+                 unsigned* in_rbits_out = nullptr;       // ReLU bit record of the INPUT, written by the input transform
+                 float* next_v = nullptr; bool* fused_out = nullptr; };     // output transform fused with the next conv's input transform (winograd.hip: wino_out_in_kernel)
 // KS = 3, or 7 (3x3 grid of 3x3 sub-filters, GEMM depth 9*Cin -- see winograd.hip)
 void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const float* x, const float* wk, float* y, float* u, float* v, float* mm,
                    int N, int H, int W, int Cin, int Cout, const WinoEpi& e, hipStream_t s, const char* layer, bool v_ready = false)
@@ -337,26 +342,31 @@ void conv_winograd(fcn8s_model* m, int tile, int KS, const char* tag, const floa
     const double tb = 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg), ob = 4.0 * ((double)N * H * W * Cout * ((e.pool ? (e.skip_y ? 0.25 : 1.25) : 1.0) + (e.rbits_in ? 1.0 / 32 : (e.mask ? 1.0 : 0.0)) + (e.addend ? 1.0 : 0.0) + (e.rbits_out ? 1.0 / 32 : 0.0)) + (double)P * T * Cout);   // y (+ pool) written, ReLU mask / skip addend read
     // frozen parameters (evaluate / predict loops): the transformed filter bank of each forward layer is computed once and kept
     bool u_cached = false;
-    if (m && m->frozen && layer && !v_ready && std::string(tag).find("dgrad") == std::string::npos) {
+    const bool fwd_call = std::string(tag).find("dgrad") == std::string::npos;      // (v_ready in a forward call = V written by the previous conv's fused output transform)
+    if (m && m->frozen && layer && fwd_call) {
         float*& cu = m->u_cache[std::string(layer) + "#" + std::to_string(tile)];       // (the tile, hence the bank's shape, depends on the image size)
         if (cu) { u = cu; u_cached = true; }
         else if (hipMalloc((void**)&cu, (size_t)P * Kg * Cout * sizeof(float)) == hipSuccess) u = cu;       // filled below, reused from the next call on
         else { cu = nullptr; (void)hipGetLastError(); }
         a.w = u;
     }
-    if (m && !u_cached && m->fwd_train && layer && !v_ready && ((KS == 3 && tile == 6) || (KS == 7 && tile == 4)) &&
-        std::string(tag).find("dgrad") == std::string::npos) {
+    if (m && !u_cached && m->fwd_train && layer && fwd_call && ((KS == 3 && tile == 6) || (KS == 7 && tile == 4))) {
         float*& tu = m->u_train[std::string(layer) + "#" + std::to_string(tile)];
         if (!tu && hipMalloc((void**)&tu, (size_t)P * Kg * Cout * sizeof(float)) != hipSuccess) { tu = nullptr; (void)hipGetLastError(); }
         if (tu) { u = tu; a.w = u; }
     }
     // v_ready: V was written together with the weight gradient's dM by the fused transform (launch_wino_input_dout)
     auto pre = [&]() { if (!u_cached) launch_wino_filter(tile, wk, u, Cin, Cout, KS, s); if (!v_ready) launch_wino_input(tile, x, v, N, H, W, Cin, KS, s, e.in_rbits_out); };
-    auto post = [&]() { launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, (e.skip_y && e.pool) ? nullptr : y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s, e.pool, e.pidx, KS, e.rbits_out, e.rbits_in); };
+    auto post = [&]() {
+        if (e.next_v && tile == 6 && KS == 3 && e.relu && e.bias && !e.addend && !e.mask && !e.dropout && !e.pool && !e.rbits_in &&
+            launch_wino_out_in(mm, e.bias, e.next_v, e.rbits_out, N, H, W, Cout, s, m && m->fuse_out_in >= 2)) { if (e.fused_out) *e.fused_out = true; return; }
+        launch_wino_output(tile, mm, e.bias, e.addend, e.mask, e.mask_scale, e.relu, (e.skip_y && e.pool) ? nullptr : y, N, H, W, Cout, e.dropout, e.keep, e.seed, e.stream_id, s, e.pool, e.pidx, KS, e.rbits_out, e.rbits_in); };
+    // (bytes of the fused form: M read, the next conv's V written, the ReLU record)
+    const double ob_fused = 4.0 * (2.0 * P * T * Cout + (e.rbits_out ? (double)N * H * W * Cout / 32 : 0.0));
     if (m) {
         { ProfScope ps(m, "wino_transform", 0, (v_ready ? 0.0 : tb) + (u_cached ? 0.0 : (double)(KS * KS + P * nsub2) * 4 * Cin * Cout)); pre(); }
         { ProfScope ps(m, tag, 2.0 * P * T * Kg * Cout, 4.0 * P * (T * (double)(Kg + Cout) + (double)Kg * Cout), layer); launch_igemm(a, P, s); }
-        { ProfScope ps(m, "wino_transform", 0, ob); post(); }
+        { ProfScope ps(m, "wino_transform", 0, ob); post(); if (e.fused_out && *e.fused_out && m->profile && !m->groups.empty()) { const int g = group_id(m, "wino_transform"); m->groups[g].bytes += ob_fused - ob; } }
     } else { pre(); launch_igemm(a, P, s); post(); }
 }
 
@@ -435,8 +445,9 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
     if ((wino3 || wino7) && Cin % 16 == 0 && Cout % 64 == 0 && e.alpha == 1.f && !real_cin) {
         const bool dgrad = e.dgrad != 0;
         float* vbuf = m->d_wino_v;
-        const bool v_ready = dgrad && layer && !m->fused_v_layer.empty() && m->fused_v_layer == layer;
-        m->fused_v_layer.clear();
+        const bool v_ready = (dgrad && layer && !m->fused_v_layer.empty() && m->fused_v_layer == layer) ||
+                             (!dgrad && layer && !m->fwd_v_layer.empty() && m->fwd_v_layer == layer);      // (forward: written by the previous conv's fused output transform)
+        m->fused_v_layer.clear(); m->fwd_v_layer.clear();
         if (!dgrad && layer) { auto it = m->acts.find(std::string("wv:") + layer); if (it != m->acts.end()) vbuf = it->second.p; }
         WinoEpi we; we.bias = e.bias; we.addend = e.addend; we.mask = e.mask; we.mask_scale = e.mask_scale; we.relu = e.relu;
         we.dropout = e.dropout; we.keep = e.keep; we.seed = m->seed; we.stream_id = e.stream_id; we.pool = e.pool_out; we.pidx = e.pool_idx;
@@ -444,7 +455,10 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
         if (e.relu_bits_out && layer) m->rbits_ok.insert(layer);
         if (e.in_relu_bits_out && e.in_layer && K == 3 && !dgrad) { we.in_rbits_out = e.in_relu_bits_out; m->rbits_ok.insert(e.in_layer); }
         const char* tag = K == 7 ? (dgrad ? "wino_gemm_fc6_dgrad" : "wino_gemm_fc6_fwd") : (dgrad ? "wino_gemm_dgrad" : "wino_gemm_fwd");
+        bool fused_out = false;
+        if (!dgrad && e.next_v && e.next_layer) { we.next_v = e.next_v; we.fused_out = &fused_out; }
         conv_winograd(m, wino_tile_for(m, H, W, K), K, tag, x, w, y, m->d_wino_u, vbuf, m->d_wino_m, N, H, W, Cin, Cout, we, s, layer, v_ready);
+        if (fused_out) { m->fwd_v_layer = e.next_layer; if (layer) m->y_unwritten.insert(layer); }
         return e.pool_out != nullptr;
     }
     if (m) m->fused_v_layer.clear();
@@ -1056,7 +1070,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     const bool fill_fp = m->frozen && m->u_cache.empty();
     if (!m->frozen || fill_fp) prepare_forward_weights(m);        // frozen and the kept banks still valid: so are the padded / phase-packed kernels
     m->fwd_train = train;
-    m->rbits_ok.clear();
+    m->rbits_ok.clear(); m->y_unwritten.clear(); m->fwd_v_layer.clear();
     { ProfScope ps(m, "preprocess", 0, (double)N * H * W * (16 + (dtype ? 12 : 3))); launch_preprocess(img_dev, dtype, A(m, "x0"), (long long)N * H * W, s); }
     const float* x = A(m, "x0");
     int h = H, w = W, cin = 4;
@@ -1082,6 +1096,18 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 // pass routes through the argmax bytes), the full-resolution tensor is never read again and is not written at all
                 // (2.15 GB for conv1_2 at 16 x 1024x512); fcn8s_get_activation of such a layer then returns stale data.
                 e.skip_y = !train || pool_backward_fused(m, b + 1, true);
+            }
+            char nxt[32] = "";
+            if (m->fuse_out_in && !first && i < kConvsPerBlock[b] && !(bf16_fwd_mode(m) && b >= 2) && (!train || e.relu_bits_out) &&
+                m->wino_min_cin > 0 && cin >= m->wino_min_cin && m->widths[b] >= m->wino_min_cin && m->widths[b] % 64 == 0 && cin % 16 == 0 &&
+                m->d_wino_v && wino_tile_for(m, h, w, 3) == 6) {
+                // this conv and the next one both run through F(6x6,3x3) on the same tile grid: its output transform writes the next conv's
+                // transformed input directly (training: into the buffer kept for that conv's weight gradient) and its own output never exists
+                snprintf(nxt, sizeof nxt, "conv%d_%d", b + 1, i + 1);
+                auto it = train ? m->acts.find(std::string("wv:") + nxt) : m->acts.end();
+                // (training: only if the next conv keeps its V for a Winograd-domain weight gradient -- a direct weight gradient would read the
+                //  activation that no longer exists)
+                if (!train || it != m->acts.end()) { e.next_v = train ? it->second.p : m->d_wino_v; e.next_layer = nxt; }
             }
             bool done = false;
             if (first && m->widths[0] == 64) {            // conv1_1: write-bound gather kernel (igemm.hip: conv1_glds_kernel)
@@ -1631,6 +1657,7 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "winograd_fc6") return &m->wino_fc6;
     if (key == "tconv_gemm") return &m->tconv_gemm;
     if (key == "fuse_dgrad_dout") return &m->fuse_dgrad_dout;
+    if (key == "fuse_out_in") return &m->fuse_out_in;
     if (key == "defer_wgrad") return &m->defer_wgrad;
     if (key == "defer_start_block") return &m->defer_start_block;
     if (key == "defer_tail_cus") return &m->defer_tail_cus;
@@ -1663,6 +1690,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
     if (k == "winograd_tile_hires" && value != 0 && value != 2 && value != 4 && value != 6) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_tile_hires must be 0, 2, 4 or 6");
     if (k == "winograd_min_cin" && value < 0) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_min_cin must be >= 0 (0 = direct convolution everywhere)");
     if (k == "defer_wgrad" && (value < 0 || value > 3)) return fail(m, FCN8S_ERR_BAD_ARG, "defer_wgrad must be 0 .. 3");
+    if (k == "fuse_out_in" && (value < 0 || value > 2)) return fail(m, FCN8S_ERR_BAD_ARG, "fuse_out_in must be 0, 1 or 2");
     if (k == "defer_start_block" && (value < 1 || value > 4)) return fail(m, FCN8S_ERR_BAD_ARG, "defer_start_block must be 1 .. 4");
     if (k == "defer_tail_cus" && (value < 0 || value > 248 || value % 8)) return fail(m, FCN8S_ERR_BAD_ARG, "defer_tail_cus must be a multiple of 8 in 0 .. 248");
     if (*slot == (int)value) return FCN8S_OK;
@@ -2192,8 +2220,44 @@ int fcn8s_get_activation(fcn8s_model* m, const char* name, float* host, size_t n
         m->logits_nhwc_valid = true;
     }
     if (n != it->second.n) return fail(m, FCN8S_ERR_SHAPE, std::string("activation '") + name + "' has " + std::to_string(it->second.n) + " elements");
+    if (m->y_unwritten.count(name))
+        return fail(m, FCN8S_ERR_STATE, std::string("activation '") + name + "' was not materialised by the last forward pass: its output transform wrote the next conv's "
+                                        "transformed input directly (option \"fuse_out_in\" = 0 keeps it)");
     HIPCHK(m, hipStreamSynchronize(m->stream));
     HIPCHK(m, hipMemcpy(host, it->second.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return FCN8S_OK;
+}
+
+int fcn8s_get_relu_record(fcn8s_model* m, const char* layer, unsigned char* host, size_t n)
+{
+    if (!m || !layer || !host) return FCN8S_ERR_BAD_ARG;
+    if (!m->have_forward || !m->train_mode) return fail(m, FCN8S_ERR_STATE, "fcn8s_get_relu_record: no training forward pass has been run");
+    int b = 0, i = 0;
+    if (sscanf(layer, "conv%d_%d", &b, &i) != 2 || b < 1 || b > 5 || i < 1 || i >= kConvsPerBlock[b - 1])
+        return fail(m, FCN8S_ERR_NOT_FOUND, std::string("fcn8s_get_relu_record: '") + layer + "' is not a conv that feeds another conv");
+    auto it = m->acts.find(std::string("rb:") + layer);
+    if (it == m->acts.end() || !m->rbits_ok.count(layer))
+        return fail(m, FCN8S_ERR_STATE, std::string("fcn8s_get_relu_record: the last forward pass kept no ReLU record of '") + layer + "' (the backward pass reads the activation itself)");
+    const int H = m->H >> (b - 1), W = m->W >> (b - 1), Cc = m->widths[b - 1], N = m->N;
+    if (n != (size_t)N * H * W * Cc) return fail(m, FCN8S_ERR_SHAPE, std::string("ReLU record of '") + layer + "' has " + std::to_string((size_t)N * H * W * Cc) + " elements");
+    // layout of wino_output_kernel / wino_input_kernel / wino_out_in_kernel: RW words per (tile, channel vector), bit (oy * M + ox) * VEC + lane-channel
+    const int tile = wino_tile_for(m, H, W, 3), vec = tile == 2 ? 4 : 2, RW = (tile * tile * vec + 31) / 32, C4 = Cc / vec;
+    const int th = (H + tile - 1) / tile, tw = (W + tile - 1) / tile;
+    const size_t words = wino_rbits_words(tile, N, H, W, Cc);
+    std::vector<unsigned> w(words);
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    HIPCHK(m, hipMemcpy(w.data(), it->second.p, words * sizeof(unsigned), hipMemcpyDeviceToHost));
+    for (int nn = 0; nn < N; ++nn)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const size_t t = ((size_t)nn * th + y / tile) * tw + x / tile;
+                const int oy = y % tile, ox = x % tile;
+                unsigned char* dst = host + (((size_t)nn * H + y) * W + x) * Cc;
+                for (int c = 0; c < Cc; ++c) {
+                    const int bit = (oy * tile + ox) * vec + c % vec;
+                    dst[c] = (w[(t * C4 + c / vec) * RW + (bit >> 5)] >> (bit & 31)) & 1u;
+                }
+            }
     return FCN8S_OK;
 }
 

@@ -434,6 +434,147 @@ __global__ __launch_bounds__(256, 3) void wino_output_kernel(const VF* __restric
     }
 }
 
+// ---- forward: output transform of conv L fused with the input transform of conv L+1 (round 4) ---------------------------------------
+// Inside a VGG block conv L's output Y is read by nobody but conv L+1's input transform, on the same tile grid (same H, W, F(6x6,3x3)
+// on both sides): Y = relu(A^T M A + bias) per 6x6 tile, then V' = B^T d B over the 8x8 patch = the tile plus a one-pixel ring from its
+// eight neighbours.  This kernel goes from M to V' without Y ever reaching memory: a block owns a strip of TX tile columns (plus one
+// ring column on either side, computed but not emitted) x CPB channel pairs and WALKS DOWN the tile rows of one image.  In iteration r
+// every thread turns the 64 M values of tile (r, column) into its 6x6 Y tile (registers); the tile of iteration r - 1 is still in
+// registers (yprev), row 5 of the one before too (top); what a thread needs from its left / right neighbours -- their columns 5 / 0 of
+// tile row r - 1 and the corner pixels of rows r - 2 and r -- travels through LDS (18 values per thread).  Then tile (r - 1) has its whole
+// 8x8 patch and is transformed and stored.  Every M value is read once (the ring columns twice: 2 / TX), the halo rows above and below a
+// block's row range are recomputed (2 per range).  Arithmetic: the loops of wino_output_kernel and wino_input_kernel, in their order --
+// the V' written here has the bits the two kernels produce.  Pixels outside the image (partial edge tiles, the ring around the image)
+// enter the patch as zeros, as SAME padding wants.  rbits_out: the ReLU record of Y the backward pass masks with (layout of wino_output_kernel).
+#ifndef OI_NT_STORE
+#define OI_NT_STORE 1          // non-temporal stores of V': 2.62 instead of 2.74 ms per step over the seven launches (they measured worse in the single transforms)
+#endif
+#ifndef OI_WPS
+#define OI_WPS 2               // waves per SIMD the register allocation aims at (1 = up to 512 registers, no spills; measured below)
+#endif
+template <int CPB, int NCOL>
+__global__ __launch_bounds__(CPB * NCOL, OI_WPS == 1 ? 1 : 512 / (CPB * NCOL)) void wino_out_in_kernel(const VecF<2>* __restrict__ m, const VecF<2>* __restrict__ bias, VecF<2>* __restrict__ v,
+                                                                    unsigned* __restrict__ rbits_out, int N, int H, int W, int C4, long long slab, int rows_per_block)
+{
+    constexpr int VEC = 2, M = 6, A = 8, TX = NCOL - 2, RW = (M * M * VEC + 31) / 32;
+    typedef WinoMat<6, 3> WM;
+    __shared__ VF col0[NCOL][M][CPB], col5[NCOL][M][CPB], cornT[NCOL][2][CPB], cornB[NCOL][2][CPB];
+    const int th = (H + M - 1) / M, tw = (W + M - 1) / M;
+    const int j = threadIdx.x / CPB, cpl = threadIdx.x - j * CPB;
+    const int ngroups = C4 / CPB;
+    const int strip = blockIdx.x / ngroups, cg = blockIdx.x - strip * ngroups;
+    const int c = cg * CPB + cpl;
+    const int tx = strip * TX - 1 + j;
+    const int chunks = (th + rows_per_block - 1) / rows_per_block;
+    const int n = blockIdx.y / chunks, r0 = (blockIdx.y - n * chunks) * rows_per_block;
+    const int r1 = r0 + rows_per_block < th ? r0 + rows_per_block : th;
+    const bool colok = tx >= 0 && tx < tw;
+    const bool inner = j >= 1 && j <= TX && colok;
+    const VF bv = bias[c];
+    VF yprev[M][M], ynew[M][M], top[M];
+#pragma unroll
+    for (int a = 0; a < M; ++a) { top[a] = f4zero(); _Pragma("unroll") for (int b = 0; b < M; ++b) yprev[a][b] = f4zero(); }
+
+    for (int r = r0 - 1; r <= r1; ++r) {
+        // (the 2 x 64 slab offsets are block-uniform products: hoisted out of this loop they would sit in 256 registers for its whole
+        //  duration -- the first build spilled exactly those; opaque per iteration, they are recomputed on the scalar unit when needed)
+        long long slab_a = slab, slab_b = slab;
+        asm volatile("" : "+s"(slab_a), "+s"(slab_b));
+        // ---- A: Y of tile (r, tx) ------------------------------------------------------------------------------------------------
+        const bool valid = colok && r >= 0 && r < th;
+        const long long t = ((long long)n * th + r) * tw + tx;
+        if (valid) {
+            const VF* mp = m + t * C4 + c;
+            // Y = A^T M A accumulated column by column of M: q_b = A^T M[:, b] (six values), then the rank-one update Y[oy][ox] += q_b[oy] A[b][ox].
+            // Each Y element sees its terms in the order b = 0 .. 7 on top of the bias -- the fma chain of wino_output_kernel, same bits -- and the
+            // 6 x 8 intermediate of that kernel never exists (the previous tile and this one already fill 156 of the 256 registers).
+#pragma unroll
+            for (int oy = 0; oy < M; ++oy) _Pragma("unroll") for (int ox = 0; ox < M; ++ox) ynew[oy][ox] = bv;
+#pragma unroll
+            for (int b = 0; b < A; ++b) {
+                VF col[A];
+#pragma unroll
+                for (int a = 0; a < A; ++a) col[a] = vload_nt<VEC>(mp + (a * A + b) * slab_a);       // (plain loads: 2.96 instead of 2.74 ms per step over the seven launches)
+#pragma unroll
+                for (int o = 0; o < M; ++o) {
+                    VF sacc = f4zero();
+#pragma unroll
+                    for (int k = 0; k < A; ++k) if (WM::at(o, k) != 0.f) sacc = f4fma(WM::at(o, k), col[k], sacc);
+#pragma unroll
+                    for (int ox = 0; ox < M; ++ox) if (WM::at(ox, b) != 0.f) ynew[o][ox] = f4fma(WM::at(ox, b), sacc, ynew[o][ox]);
+                }
+            }
+            unsigned rb[RW];
+#pragma unroll
+            for (int w_ = 0; w_ < RW; ++w_) rb[w_] = 0u;
+#pragma unroll
+            for (int oy = 0; oy < M; ++oy)
+#pragma unroll
+                for (int ox = 0; ox < M; ++ox) {
+                    const bool inside = M * r + oy < H && M * tx + ox < W;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const float val = inside ? fmaxf(ynew[oy][ox].d[i], 0.f) : 0.f;
+                        ynew[oy][ox].d[i] = val;
+                        const int bit = (oy * M + ox) * VEC + i;
+                        if (val > 0.f) rb[bit >> 5] |= 1u << (bit & 31);
+                    }
+                }
+            if (rbits_out && inner && r >= r0 && r < r1) {
+#pragma unroll
+                for (int w_ = 0; w_ < RW; ++w_) rbits_out[(t * C4 + c) * RW + w_] = rb[w_];
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < M; ++a) _Pragma("unroll") for (int b = 0; b < M; ++b) ynew[a][b] = f4zero();
+        }
+        cornB[j][0][cpl] = ynew[0][0]; cornB[j][1][cpl] = ynew[0][M - 1];
+        __syncthreads();
+        // ---- B: the patch of tile (r - 1, tx) is complete: V' = B^T d B -----------------------------------------------------------
+        if (inner && r - 1 >= r0 && r - 1 < r1) {
+            // (row by row of B^T d: the patch IS yprev / top / ynew plus the two LDS columns, so only one row of the intermediate is live)
+            VF left[A], right[A];
+            left[0] = cornT[j - 1][1][cpl]; right[0] = cornT[j + 1][0][cpl];
+#pragma unroll
+            for (int a = 0; a < M; ++a) { left[a + 1] = col5[j - 1][a][cpl]; right[a + 1] = col0[j + 1][a][cpl]; }
+            left[A - 1] = cornB[j - 1][1][cpl]; right[A - 1] = cornB[j + 1][0][cpl];
+            VF* vp = v + (t - tw) * C4 + c;                       // tile (r - 1, tx)
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                VF qa[A];
+#pragma unroll
+                for (int b = 0; b < A; ++b) {
+                    VF sacc = f4zero();
+#pragma unroll
+                    for (int k = 0; k < A; ++k) if (WM::bt(a, k) != 0.f) {
+                        const VF& pe = b == 0 ? left[k] : b == A - 1 ? right[k] : k == 0 ? top[b - 1] : k == A - 1 ? ynew[0][b - 1] : yprev[k - 1][b - 1];
+                        sacc = f4fma(WM::bt(a, k), pe, sacc);
+                    }
+                    qa[b] = sacc;
+                }
+#pragma unroll
+                for (int b = 0; b < A; ++b) {
+                    VF sacc = f4zero();
+#pragma unroll
+                    for (int k = 0; k < A; ++k) if (WM::bt(b, k) != 0.f) sacc = f4fma(WM::bt(b, k), qa[k], sacc);
+                    if (OI_NT_STORE) { typedef float vt2 __attribute__((ext_vector_type(2))); vt2 o2 = {sacc.d[0], sacc.d[1]}; __builtin_nontemporal_store(o2, reinterpret_cast<vt2*>(vp + (a * A + b) * slab_b)); }
+                    else vp[(a * A + b) * slab_b] = sacc;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- C: tile r becomes the previous one --------------------------------------------------------------------------------------
+        cornT[j][0][cpl] = yprev[M - 1][0]; cornT[j][1][cpl] = yprev[M - 1][M - 1];
+#pragma unroll
+        for (int a = 0; a < M; ++a) {
+            top[a] = yprev[M - 1][a];
+            col0[j][a][cpl] = ynew[a][0]; col5[j][a][cpl] = ynew[a][M - 1];
+        }
+#pragma unroll
+        for (int a = 0; a < M; ++a) _Pragma("unroll") for (int b = 0; b < M; ++b) yprev[a][b] = ynew[a][b];
+    }
+}
+
 // ---- weight gradient: dM = A dY A^T (alpha x alpha from the m x m output-gradient tile) ------------------------------
 // POOL: dy is not materialised -- it is the max-pool backward of dpool [N,H/2,W/2,C] routed by the argmax bytes the forward output
 // transform kept (see wino_input_dout_kernel); tile origins are even, so a tile covers whole windows.
@@ -903,6 +1044,41 @@ void launch_wino_output(int tile, const float* m, const float* bias, const float
     else                              { if (dropout) FCN8S_WOUT(2, 4, true, 3); else FCN8S_WOUT(2, 4, false, 3); }
 #undef FCN8S_WOUT
 #undef FCN8S_WOUT2
+}
+// m: M of conv L [64][T][C] (its GEMM's output), v: V of conv L+1 [64][T][C]; both F(6x6,3x3) on [N,H,W,C]; C % 64 == 0.  Returns false
+// if the shape is not covered (the caller then runs the two kernels).
+// always = false: only when the launch fills the chip without cutting images into row ranges (N x strips x channel groups >= 200 blocks:
+// 16 x 1024x512 does, 4 x 2048x1024 and a single image do not) -- below that the walk is too long and too narrow and the two kernels win
+// (measured: batch-1 inference 1.97 against 1.87 ms, 4 x 2048x1024 training 60.0 against 59.6 ms per step; 16 x 1024x512: 2.62 against
+// 2.99 ms per step over the seven layer pairs).
+bool launch_wino_out_in(const float* m, const float* bias, float* v, unsigned* rbits_out, int N, int H, int W, int C, hipStream_t s, bool always)
+{
+    if (C % 64 || !bias) return false;
+    const int th = (H + 5) / 6, tw = (W + 5) / 6, C4 = C / 2;
+    const long long T = (long long)N * th * tw;
+    // 14 emitted tile columns x 32 channel pairs per block, or 6 x 64: whichever wastes fewer columns on this width (ring + last strip)
+    const int cost14 = (tw + 13) / 14 * 16, cost6 = (tw + 5) / 6 * 8;
+    bool wide = C % 128 != 0 || cost14 <= cost6;
+    static const int variant = getenv("FCN8S_OI_VARIANT") ? atoi(getenv("FCN8S_OI_VARIANT")) : 0;      // (experiments: 1..4 force a block shape)
+    int TX = wide ? 14 : 6, CPB = wide ? 32 : 64, threads = 512;
+    if (variant == 1) { TX = 14; CPB = 32; } else if (variant == 2 && C % 128 == 0) { TX = 6; CPB = 64; }
+    else if (variant == 3) { TX = 6; CPB = 32; threads = 256; } else if (variant == 4) { TX = 14; CPB = 16; threads = 256; }
+    const int strips = (tw + TX - 1) / TX, groups = C4 / CPB;
+    // enough blocks to fill the chip: cut an image's tile rows into ranges when N x strips x groups is small
+    const long long want = 256LL * (512 / threads);
+    long long cols = (long long)strips * groups * N;
+    if (!always && cols < 200) return false;
+    int chunks = (int)((want + cols - 1) / cols); if (chunks < 1) chunks = 1; if (chunks > th) chunks = th;
+    const int rpb = (th + chunks - 1) / chunks;
+    chunks = (th + rpb - 1) / rpb;
+    const dim3 grid((unsigned)(strips * groups), (unsigned)(N * chunks));
+    g_last_kernel = "wino_out_in_kernel";
+#define FCN8S_OI(CPB_, NCOL_) hipLaunchKernelGGL((wino_out_in_kernel<CPB_, NCOL_>), grid, dim3(CPB_ * NCOL_), 0, s, (const VecF<2>*)m, (const VecF<2>*)bias, (VecF<2>*)v, rbits_out, N, H, W, C4, wino_slab(T, C) / 2, rpb)
+    if (threads == 256) { if (CPB == 32) FCN8S_OI(32, 8); else FCN8S_OI(16, 16); }
+    else if (CPB == 32) FCN8S_OI(32, 16);
+    else FCN8S_OI(64, 8);
+#undef FCN8S_OI
+    return true;
 }
 void launch_wino_dout(int tile, const float* dy, float* dm, int N, int H, int W, int C, hipStream_t s, int KS, const unsigned char* pidx)
 {

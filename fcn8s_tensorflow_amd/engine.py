@@ -680,7 +680,13 @@ class Engine:
         h, w = H, W
         for b, nconv in enumerate((2, 2, 3, 3, 3), start=1):
             for i in range(1, nconv):
-                out["conv%d_%d" % (b, i)] = self.activation("conv%d_%d" % (b, i), (N, h, w, self.widths[b - 1])) > 0
+                name = "conv%d_%d" % (b, i)
+                try:
+                    out[name] = self.activation(name, (N, h, w, self.widths[b - 1])) > 0
+                except L.Fcn8sError:          # not materialised (its output transform wrote the next conv's input transform directly): the ReLU record
+                    rec = np.empty((N, h, w, self.widths[b - 1]), np.uint8)
+                    L.check(L.lib.fcn8s_get_relu_record(self.h, name.encode(), rec.ctypes.data_as(C.c_void_p), rec.size), self.h)
+                    out[name] = rec.astype(bool)
             h //= 2; w //= 2
             out["pool%d" % b] = self.activation("pool%d" % b, (N, h, w, self.widths[b - 1])) > 0
         out["fc6"] = self.activation("fc6", (N, h, w, self.widths[5])) > 0

@@ -241,6 +241,12 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *                              GEMMs on the remaining 256 - n (hipExtStreamCreateWithCUMask); 0: both share all CUs
  *     "fuse_dgrad_dout"   1    inside a VGG block the gather kernel of a conv's data gradient writes dM = A dZ A^T of the previous conv directly
  *                              (that conv's weight gradient and adjoint data gradient consume only dM): its dZ is never written; 0 = two kernels
+ *     "fuse_out_in"       1    forward, inside a VGG block: the output transform of a conv is fused with the input transform of the next one (both
+ *                              F(6x6,3x3) on the same tile grid): Y = relu(A^T M A + b) stays in registers / LDS and the kernel writes the next conv's
+ *                              V = B^T d B (bit-identical to the two-kernel form); the conv's own activation tensor is then never written and
+ *                              fcn8s_get_activation of it returns FCN8S_ERR_STATE.  0 = never, 1 = when the launch fills the chip without cutting
+ *                              images into row ranges (16 x 1024x512 does; one image or 4 x 2048x1024 do not, and the two kernels are faster
+ *                              there), 2 = whenever the shapes allow
  *     "bf16_gemm256"      1    FCN8S_PREC_BF16_FC: fc6 / fc7 forward on the 256 x 256 LDS-DMA kernel -- 0 never, 1 when the launch has at least
  *                              128 tiles (training batches), 2 whenever the shapes allow (rows and Cout multiples of 256)
  *     "conv1_tiled"       1    conv1_1 forward on the spatial-tile kernel (halo tile in LDS); 0 = the LDS-DMA gather kernel (bit-identical results)
@@ -263,6 +269,10 @@ int fcn8s_get_dropout_masks(fcn8s_model* m, float* host_mask6, size_t n6, float*
  * the recorded routes and verifies separately that every route that differs from its own is a tie to round-off.  Valid after a
  * training forward pass (fcn8s_forward_loss / fcn8s_train_step). */
 int fcn8s_get_pool_routing(fcn8s_model* m, int block, unsigned char* host, size_t nbytes);
+/* Parity instrumentation: the ReLU record the backward pass masks with, one byte (0 / 1) per element [N,h,w,c] of a conv that feeds another
+ * conv ("conv1_1" .. "conv5_2") -- what `activation > 0` says when the activation exists; with "fuse_out_in" the activation of such a layer
+ * is never written and this record is all there is.  Valid after a training forward pass whose layer kept a record (Winograd layers). */
+int fcn8s_get_relu_record(fcn8s_model* m, const char* layer, unsigned char* host, size_t nbytes);
 
 /* ---- host helper for the TF tensor-bundle writer (tf_bundle.py): CRC-32C (Castagnoli) of a host buffer ----- */
 uint32_t fcn8s_crc32c(const void* data, size_t nbytes, uint32_t crc);

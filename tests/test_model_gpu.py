@@ -773,3 +773,64 @@ def test_two_engines_with_different_options_do_not_touch_each_other():
     finally:
         L.check(L.lib.fcn8s_set_option(None, b"op_split_pieces", 0))
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("widths,n,h,w", [(None, 1, 96, 160), (None, 2, 64, 224), ((64, 64, 128, 128, 128, 128, 128), 1, 192, 192), ((64, 128, 192, 64, 64, 128, 128), 1, 96, 96)])
+def test_fused_output_and_next_input_transform_is_bit_identical(widths, n, h, w):
+    """Forward, inside a block: conv L's output transform and conv L+1's input transform as ONE kernel (wino_out_in_kernel: the tile
+    stays in registers, neighbours' borders go through LDS, a block walks down the tile rows) against the two-kernel form.  The fused
+    kernel runs the same fma chains in the same order, so everything downstream -- pooled activations, softmax, loss -- has the same bits,
+    and the gradients differ by the weight-gradient atomics' summation order only; the ReLU record it writes is the one the backward pass
+    masks with.  Sizes with partial edge tiles in both directions, strips narrower and wider than a block, widths (192) that leave the
+    kernel's channel groups ragged (C % 64 == 0 is all it needs).  Option 2 = fuse wherever the shapes allow (1, the default, waits for
+    launches that fill the chip); the activation a fused launch no longer writes is reported as such."""
+    from fcn8s_tensorflow_amd.engine import Engine
+    P, img, lab = case(widths, n, h, w, seed=5)
+    got = []
+    for fuse in (2, 0):
+        e = Engine(20, widths=widths, options={"fuse_out_in": fuse})
+        assert e.get_option("fuse_out_in") == fuse
+        e.set_params(P)
+        e.profile(2); e.profile_reset()
+        loss = e.forward_backward(img, orc.one_hot(lab, 20), keep_prob=1.0, l2_rate=1e-3)
+        ks = [k for k in e.profile_results() if k.startswith("kernel:")]
+        e.profile(0)
+        ran = any("wino_out_in_kernel" in k for k in ks)
+        assert ran == (fuse == 2), ks
+        g = e.get_grads()
+        br = e.relu_branches((n, h, w))
+        wd = e.widths
+        pools = [e.activation("pool%d" % b, (n, h >> b, w >> b, wd[b - 1])) for b in (2, 3, 4)]
+        # the ReLU record, decoded by the library, = (activation > 0) wherever the activation exists; a fused launch's activation does not
+        from fcn8s_tensorflow_amd import _lib as L
+        import ctypes as C
+        missing = []
+        for blk, nconv in enumerate((2, 2, 3, 3, 3), start=1):
+            for i in range(1, nconv):
+                name = "conv%d_%d" % (blk, i)
+                shp = (n, h >> (blk - 1), w >> (blk - 1), wd[blk - 1])
+                rec = np.empty(shp, np.uint8)
+                has_rec = L.lib.fcn8s_get_relu_record(e.h, name.encode(), rec.ctypes.data_as(C.c_void_p), rec.size) == 0
+                if has_rec:
+                    np.testing.assert_array_equal(rec.astype(bool), br[name])
+                try:
+                    act = e.activation(name, shp)
+                    if has_rec:
+                        np.testing.assert_array_equal(act > 0, rec.astype(bool))
+                except L.Fcn8sError as ex:
+                    assert "not materialised" in str(ex) and has_rec
+                    missing.append(name)
+        assert bool(missing) == (fuse == 2), missing
+        sm = e.predict(img, argmax=False)           # (inference pass: V' goes to the shared scratch instead of the kept buffer)
+        got.append((loss, g, br, pools, sm))
+        e.close()
+    assert got[0][0] == got[1][0]
+    for a, b in zip(got[0][3], got[1][3]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(got[0][4], got[1][4])
+    for k in got[1][2]:
+        np.testing.assert_array_equal(got[0][2][k], got[1][2][k])
+    for k in got[1][1]:
+        assert rel(got[0][1][k], got[1][1][k]) < 2e-5, (k, rel(got[0][1][k], got[1][1][k]))
+    with pytest.raises(ValueError):
+        Engine(20, options={"fuse_out_in": 3})
