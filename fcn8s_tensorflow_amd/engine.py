@@ -6,10 +6,11 @@ can update them) and provides the HIP stream.  All arithmetic of the FCN-8s
 path happens inside libfcn8s_hip.so.
 
 Data-parallel training: one Engine per rank, the minibatch is
-sharded by the caller, gradients are all-reduced in three buckets in
-backward-production order ({fc6, fc7, decoder} | {conv5, conv4} | {conv3..1});
-bucket b's all-reduce runs on RCCL's stream while bucket b+1's backward kernels
-run on the compute stream.
+sharded by the caller, gradients are all-reduced in four buckets in
+backward-production order ({fc7, decoder} | {fc6} | {conv5, conv4} | {conv3..1});
+a bucket's all-reduce starts behind the last kernel that writes into it
+(fcn8s_bucket_wait) and runs on RCCL's stream while the rest of the backward
+pass runs on the compute stream.
 """
 from __future__ import annotations
 
