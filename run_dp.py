@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("--save-dir", default=None)
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--comm", default="torch", choices=["torch", "native"], help="who all-reduces the gradient buckets: torch.distributed (default) or the "
+                    "library's own RCCL communicator behind the C ABI (fcn8s_comm_init / fcn8s_allreduce_bucket); the process group then only carries the id")
     ap.add_argument("--device", type=int, default=None, help="HIP device for every rank (testing on a one-GPU box with --backend gloo); default LOCAL_RANK")
     args = ap.parse_args()
 
@@ -56,6 +58,11 @@ def main():
     if world > 1:
         torch.cuda.set_device(local)
         dist.init_process_group(args.backend, **({"device_id": torch.device("cuda", local)} if args.backend == "nccl" else {}))
+        # this rank, its feeder thread and the decode workers it forks below: on the CPUs of its GPU's NUMA node
+        from fcn8s_tensorflow_amd.dp import bind_to_gpu_numa
+        numa = bind_to_gpu_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)) if args.device is None else 1)
+        if rank == 0:
+            print("rank 0 NUMA binding:", numa)
 
     images, labels = args.images, args.labels
     if images is None:
@@ -75,6 +82,9 @@ def main():
     train_gen = data.generate(batch_size=args.batch, convert_ids_to_ids=convert, convert_to_one_hot=True, void_class_id=0,
                               random_crop=(args.height, args.width), flip=0.5, shuffle=True, workers=args.workers)
     model = FCN8s(vgg16_dir=args.vgg16, num_classes=20, device_id=local)          # weights are broadcast from rank 0
+    if args.comm == "native" and world > 1:
+        model.engine.comm_init_native()                                           # one RCCL rank per model inside libfcn8s_hip.so
+        model.engine.broadcast_params(0)
     model.train(train_generator=train_gen, epochs=args.epochs, steps_per_epoch=args.steps_per_epoch,
                 learning_rate_schedule=lambda step: 1e-4 if step < 10000 else 1e-5, keep_prob=0.5, l2_regularization=0.0,
                 eval_dataset='train', eval_frequency=args.epochs, metrics={'loss', 'mean_iou', 'accuracy'},

@@ -249,6 +249,40 @@ def test_config3_training_step_1024x512_bs16_properties():
     e.close()
 
 
+def test_config3_fused_forward_transforms_at_bs16_equal_the_two_kernel_form():
+    """BASELINE's configuration (16 x 1024x512) is where the default engine fuses each inner conv's output transform with the next conv's
+    input transform (`fuse_out_in` = 1: launches that fill the chip).  At that size, against an engine with the fusion off: the kernel really
+    runs (seven launches per pass), loss and softmax are bit-identical, every gradient tensor agrees to the weight-gradient atomics' order."""
+    import torch
+    from fcn8s_tensorflow_amd.engine import Engine
+    N, H, W, C = 16, 512, 1024, 20
+    img, lab = orc.synthetic_batch(N, H, W)
+    imgd, labd = torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda()
+    got = []
+    for fuse in (1, 0):
+        e = Engine(C, seed=3, options={"fuse_out_in": fuse})
+        e.init_params(seed=1)
+        e.profile(2); e.profile_reset()
+        loss = e.forward_backward(imgd, labd, keep_prob=1.0)
+        prof = e.profile_results()
+        e.profile(0)
+        n_fused = sum(int(v["launches"]) for k, v in prof.items() if k.startswith("kernel:") and "wino_out_in_kernel" in k)
+        assert n_fused == (7 if fuse else 0), n_fused
+        got.append((loss, e.flat_grads.clone(), e.predict(imgd[:2], argmax=False).clone(), dict(e.specs)))
+        e.close()
+    assert got[0][0] == got[1][0]
+    assert torch.equal(got[0][2], got[1][2])
+    worst = ("", 0.0)
+    for name, (shape, off) in got[0][3].items():
+        n = int(np.prod(shape))
+        a, b = got[0][1][off:off + n], got[1][1][off:off + n]
+        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+        if err > worst[1]:
+            worst = (name, err)
+    print("fused vs two-kernel forward transforms at 16 x 1024x512: loss %.7f both, worst gradient difference %s %.2e" % (got[0][0], worst[0], worst[1]))
+    assert worst[1] < 1e-4, worst
+
+
 def test_config5_shape_2048x1024_bs4_properties():
     import torch
     from fcn8s_tensorflow_amd.engine import Engine
