@@ -28,7 +28,7 @@ def _check_inference(e, P, img, tol=1e-3):
     ref_arg = np.argmax(orc.softmax(ref), -1)
     assert pred.dtype == np.int64 and pred.shape == (n, h, w)
     assert (pred[safe] == ref_arg[safe]).all(), int((pred[safe] != ref_arg[safe]).sum())
-    return safe.mean(), (pred != ref_arg).mean()
+    return safe.mean(), int((pred != ref_arg).sum())
 
 
 def test_config1_single_256x256_image_forward_argmax():
@@ -37,7 +37,7 @@ def test_config1_single_256x256_image_forward_argmax():
     img = rng.integers(0, 256, (1, 256, 256, 3), dtype=np.uint8)
     e = Engine(20)
     safe, differ = _check_inference(e, orc.init_params(20, seed=0, decoder_std_scale=30.0, bias_std=0.05), img)
-    assert safe > 0.95 and differ < 1e-3
+    assert safe > 0.95 and differ <= 4, differ              # of 65 536 pixels (measured 0-1: profiles/parity_r04.json, c1)
     # the softmax output (what predict(argmax=False) returns, fcn8s_tensorflow.py:268) against the oracle's
     # (decoder scaled so that the logits are O(1): a saturated softmax would turn logit round-off into 0/1 flips)
     P = orc.init_params(20, seed=1, decoder_std_scale=5.0, bias_std=0.05)
