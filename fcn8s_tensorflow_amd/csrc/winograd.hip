@@ -1058,11 +1058,10 @@ bool launch_wino_out_in(const float* m, const float* bias, float* v, unsigned* r
     const long long T = (long long)N * th * tw;
     // 14 emitted tile columns x 32 channel pairs per block, or 6 x 64: whichever wastes fewer columns on this width (ring + last strip)
     const int cost14 = (tw + 13) / 14 * 16, cost6 = (tw + 5) / 6 * 8;
-    bool wide = C % 128 != 0 || cost14 <= cost6;
-    static const int variant = getenv("FCN8S_OI_VARIANT") ? atoi(getenv("FCN8S_OI_VARIANT")) : 0;      // (experiments: 1..4 force a block shape)
-    int TX = wide ? 14 : 6, CPB = wide ? 32 : 64, threads = 512;
-    if (variant == 1) { TX = 14; CPB = 32; } else if (variant == 2 && C % 128 == 0) { TX = 6; CPB = 64; }
-    else if (variant == 3) { TX = 6; CPB = 32; threads = 256; } else if (variant == 4) { TX = 14; CPB = 16; threads = 256; }
+    const bool wide = C % 128 != 0 || cost14 <= cost6;
+    // (block shapes measured on the seven launches of a 16 x 1024x512 step, profiles/r04_fuse_out_in_ab.txt: 512 threads as 14 x 32 + ring
+    //  2735 us, 6 x 64 + ring 2718, 256 threads as 6 x 32 or 14 x 16 + ring, two blocks per CU, 2819 / 2832)
+    const int TX = wide ? 14 : 6, CPB = wide ? 32 : 64, threads = 512;
     const int strips = (tw + TX - 1) / TX, groups = C4 / CPB;
     // enough blocks to fill the chip: cut an image's tile rows into ranges when N x strips x groups is small
     const long long want = 256LL * (512 / threads);
@@ -1074,8 +1073,7 @@ bool launch_wino_out_in(const float* m, const float* bias, float* v, unsigned* r
     const dim3 grid((unsigned)(strips * groups), (unsigned)(N * chunks));
     g_last_kernel = "wino_out_in_kernel";
 #define FCN8S_OI(CPB_, NCOL_) hipLaunchKernelGGL((wino_out_in_kernel<CPB_, NCOL_>), grid, dim3(CPB_ * NCOL_), 0, s, (const VecF<2>*)m, (const VecF<2>*)bias, (VecF<2>*)v, rbits_out, N, H, W, C4, wino_slab(T, C) / 2, rpb)
-    if (threads == 256) { if (CPB == 32) FCN8S_OI(32, 8); else FCN8S_OI(16, 16); }
-    else if (CPB == 32) FCN8S_OI(32, 16);
+    if (CPB == 32) FCN8S_OI(32, 16);
     else FCN8S_OI(64, 8);
 #undef FCN8S_OI
     return true;
