@@ -1428,6 +1428,10 @@ int do_backward_bucket(fcn8s_model* m, int bucket, int level_cap)
         m->dm_prefilled.clear();                                           // (a promise left over from a backward pass that ended in an error)
         m->on_tail = false; m->launch_stream = nullptr;                    // (a backward pass that ended in an error may have left them set)
         for (int b = 0; b < kNumBuckets; ++b) m->bucket_final[b] = false;
+        // (a caller that skipped fcn8s_apply_update after fcn8s_allreduce_bucket: the gradient buffer is about to be cleared and rewritten,
+        //  so this stream first waits for whatever the library's communicator still has in flight on it)
+        for (int b = 0; b < kNumBuckets; ++b)
+            if (m->comm_pending[b]) { hipStreamWaitEvent(m->stream, m->comm_done[b], 0); m->comm_pending[b] = false; }
         backward_head(m);
     }
     else if (bucket == 1) backward_fc6(m);
