@@ -238,6 +238,20 @@ def test_native_rccl_communicator_one_rank():
     np.testing.assert_array_equal(b.get_params()["conv1_1/filter"], b.get_params()["conv1_1/filter"])
     assert L.lib.fcn8s_comm_destroy(b.h) == 0 and b.comm_info()["world"] == 0
     a.close(); b.close()
+    # the launcher's NUMA binding starts from the GPU's PCI address and ends in a CPU set (or a reason why not)
+    import re
+    from fcn8s_tensorflow_amd import dp
+    buf = C.create_string_buffer(32)
+    assert L.lib.fcn8s_device_pci_bus_id(0, buf, 32) == 0 and re.match(r"^[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-7]$", buf.value.decode()), buf.value
+    assert L.lib.fcn8s_device_pci_bus_id(0, buf, 4) == L.ERR_BAD_ARG
+    before = os.sched_getaffinity(0)
+    try:
+        info = dp.bind_to_gpu_numa(0, 1)
+        assert info["bound"] or "why" in info, info
+        if info["bound"]:
+            assert len(os.sched_getaffinity(0)) == info["cpus"] > 0 and os.sched_getaffinity(0) <= before
+    finally:
+        os.sched_setaffinity(0, before)
 
 
 def test_bench_single_gpu_line_and_end_to_end_mode():
