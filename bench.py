@@ -562,12 +562,12 @@ def main():
             eng.train_step(images, labels, 1e-4, keep_prob=0.5, l2_rate=0.0, optimizer=opt, fetch_loss=True)
         fence()
         fetch_ms = round((time.perf_counter() - tf_) / args.steps * 1e3, 3)
-        # is the backward pass the derivative of the forward pass?  Central difference of the loss along the gradient on 2 images of
-        # the batch: (L(theta + eps g) - L(theta - eps g)) / (2 eps |g|^2) must be 1 (tests/test_fullsize_gpu.py does the same at 4 images).
+        # is the backward pass the derivative of the forward pass?  Central difference of the loss along the gradient on the batch:
+        # (L(theta + eps g) - L(theta - eps g)) / (2 eps |g|^2) must be 1 (tests/test_fullsize_gpu.py does the same at 4 images).
         try:
             keep = eng.flat_params.clone()
             theta = keep
-            nb_ = min(2, N)
+            nb_ = N            # (the whole batch: the check's launches then have the shapes of the timed steps and do not skew per-kernel averages in a profile of this command)
             eng.forward_backward(images[:nb_], labels[:nb_], keep_prob=1.0)
             g = eng.flat_grads.clone()
             norm2 = float((g.double() ** 2).sum())
@@ -579,7 +579,7 @@ def main():
                 ratios.append(round((lp - lm) / (2 * target), 4))
             eng.flat_params.copy_(keep)
             bcheck = {"directional_derivative_ratios": ratios, "ok": bool(any(0.97 < r < 1.03 for r in ratios)),
-                      "what": "central difference of the loss along its own gradient / |g|^2 at three step sizes (2 images, keep_prob 1): 1 = the backward pass is the derivative of the forward pass"}
+                      "what": "central difference of the loss along its own gradient / |g|^2 at three step sizes (the whole batch, keep_prob 1): 1 = the backward pass is the derivative of the forward pass"}
         except Exception as ex:
             bcheck = {"error": repr(ex)}
 
