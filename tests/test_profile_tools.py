@@ -12,26 +12,30 @@ DOMINANT = "void fcn8s::gemm_glds_kernel<128, 128, 2, 2, 3, false>(fcn8s::IgemmA
 
 def test_pmc_traffic_reproducible(tmp_path):
     out = tmp_path / "t.json"
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(P, "r03_pmc_fetch_counter_collection.csv"),
-                    os.path.join(P, "r03_pmc_write_counter_collection.csv"), str(out), "test"], check=True, capture_output=True)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(P, "r04_pmc_fetch_counter_collection.csv"),
+                    os.path.join(P, "r04_pmc_write_counter_collection.csv"), str(out), "test"], check=True, capture_output=True)
     got = json.load(open(out))["kernels"][DOMINANT]
     pub = json.load(open(os.path.join(P, "pmc_traffic.json")))["kernels"][DOMINANT]
     for k in ("launches", "fetch_mb_per_launch", "write_mb_per_launch", "hbm_mb_per_launch", "fetch_mb_per_launch_uncorrected"):
         assert got[k] == pub[k], k
     assert abs(got["fetch_mb_per_launch"] - 2 * got["fetch_mb_per_launch_uncorrected"]) < 0.01     # the gfx950 FETCH_SIZE correction
-    bench = json.load(open(os.path.join(P, "r03_bench_train_bs16.json")))
+    bench = json.load(open(os.path.join(P, "r04_bench_train_bs16.json")))
     assert bench["roofline"]["kernel"] in DOMINANT.replace("void fcn8s::", "")
     assert abs(bench["roofline"]["frac"] - bench["roofline"]["achieved"] / bench["roofline"]["peak"]) < 1e-3
-    if bench["roofline"]["traffic"] is not None:         # the line was printed with this very pmc_traffic.json in place
-        assert bench["roofline"]["traffic"] == round(pub["hbm_mb_per_launch"] * 1e6)
+    if bench["roofline"]["traffic"] is not None:
+        src = (bench["roofline"].get("traffic_detail") or {}).get("traffic_source", "")
+        if src.startswith("live"):         # re-measured by the bench run itself (two PMC passes of its own): the same figure to well under a percent
+            assert abs(bench["roofline"]["traffic"] - pub["hbm_mb_per_launch"] * 1e6) < 5e-3 * pub["hbm_mb_per_launch"] * 1e6
+        else:                              # the line was printed with this very pmc_traffic.json in place
+            assert bench["roofline"]["traffic"] == round(pub["hbm_mb_per_launch"] * 1e6)
 
 
 def test_clock_summary_reproducible(tmp_path):
     out = tmp_path / "c.json"
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_clock_summary.py"), os.path.join(P, "r03_pmc_clock_counter_collection.csv"), str(out)],
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_clock_summary.py"), os.path.join(P, "r04_pmc_clock_counter_collection.csv"), str(out)],
                    check=True, capture_output=True)
     got = json.load(open(out))[DOMINANT]
-    pub = json.load(open(os.path.join(P, "r03_pmc_clock.json")))[DOMINANT]
+    pub = json.load(open(os.path.join(P, "r04_pmc_clock.json")))[DOMINANT]
     assert got == pub
     assert 1.5 < got["effective_clock_ghz"] <= 2.45 and 0.5 < got["mfma_pipe_busy"] <= 1.0
 
