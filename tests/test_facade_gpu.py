@@ -203,6 +203,60 @@ def test_two_rank_data_parallel_step_equals_big_batch_step():
     assert np.abs(upd_dp - upd_ref).max() <= 2e-3 * np.abs(upd_ref).max()
 
 
+def _dp_traj_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fcn8s_tensorflow_amd.engine import Engine
+    from fcn8s_tensorflow_amd import _lib as L
+    P = orc.init_params(20, SMALL, seed=1, decoder_std_scale=5.0, bias_std=0.05)
+    e = Engine(20, widths=SMALL, device_id=0, seed=7)
+    e.set_params(P)
+    e.broadcast_params(0)
+    e.replica_check_every = 2
+    g = gen(4, 32, 64, 4, onehot=False)
+    losses = []
+    for t in range(6):
+        img, lab = next(g)
+        sl = slice(2 * rank, 2 * rank + 2)
+        loss, step = e.train_step(img[sl], lab[sl], 0.1, keep_prob=1.0, l2_rate=1e-3, optimizer=L.OPT_SGD_MOMENTUM)
+        losses.append(loss)
+    out[rank] = (e.flat_params.cpu().numpy(), losses, step)
+    e.close()
+    dist.destroy_process_group()
+
+
+def test_two_rank_free_running_training_equals_the_big_batch_run():
+    """Six SGD+momentum steps, free-running: two data-parallel ranks (half a batch each, gradients all-reduced in four buckets, 1/world in
+    the update, the replica guard firing every second step) against one process stepping on the whole batches.  The replicas stay
+    bit-identical to each other, the mean of their losses is the big batch's loss, and after six steps the parameters have moved the same way."""
+    import socket
+    import torch.multiprocessing as mp
+    from fcn8s_tensorflow_amd.engine import Engine
+    from fcn8s_tensorflow_amd import _lib as L
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_dp_traj_worker, args=(2, port, out), nprocs=2, join=True)
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    assert out[0][2] == out[1][2] == 6
+    P = orc.init_params(20, SMALL, seed=1, decoder_std_scale=5.0, bias_std=0.05)
+    e = Engine(20, widths=SMALL); e.set_params(P)
+    before = e.flat_params.cpu().numpy().copy()
+    g = gen(4, 32, 64, 4, onehot=False)
+    big = []
+    for t in range(6):
+        img, lab = next(g)
+        loss, _ = e.train_step(img, lab, 0.1, keep_prob=1.0, l2_rate=1e-3, optimizer=L.OPT_SGD_MOMENTUM)
+        big.append(loss)
+    ref = e.flat_params.cpu().numpy()
+    e.close()
+    dp_mean = 0.5 * (np.asarray(out[0][1]) + np.asarray(out[1][1]))
+    assert np.abs(dp_mean - np.asarray(big)).max() < 1e-4 * max(1.0, np.abs(big).max()), (dp_mean, big)
+    upd_ref, upd_dp = ref - before, out[0][0] - before
+    assert np.abs(upd_ref).max() > 0
+    assert np.abs(upd_dp - upd_ref).max() <= 5e-3 * np.abs(upd_ref).max(), np.abs(upd_dp - upd_ref).max() / np.abs(upd_ref).max()
+
+
 def test_onehot_labels_are_converted_on_the_gpu_and_validated():
     from fcn8s_tensorflow_amd.engine import Engine
     P = orc.init_params(20, SMALL, seed=1, decoder_std_scale=30.0, bias_std=0.05)
