@@ -88,7 +88,7 @@ struct fcn8s_model {
     std::string dm_layer;                                                 // layer whose dM = A dY A^T sits in d_wino_m, ready for the adjoint data gradient
     std::string dm_prefilled;                                             // layer whose dM the data gradient of the layer after it has already written into d_wino_m (fused transform)
     int fuse_dgrad_dout = 1;                                              // option: allow that fusion
-    int fuse_out_in = 1;                                                  // option: inside a block, conv L's output transform writes conv L+1's V directly (Y is never written): 0 never, 1 when the launch fills the chip, 2 always
+    int fuse_out_in = 1;                                                  // option: inside a block, conv L's output transform writes conv L+1's V directly (Y is never written); 0 = two kernels
     std::string fwd_v_layer;                                              // forward: layer whose V the previous layer's fused output transform has already written
     std::set<std::string> y_unwritten;                                    // layers whose activation tensor was not materialised by the last forward pass
     int conv1_tiled = 1, conv1_wgrad_mfma = 1;                            // options: conv1_1 forward on the spatial-tile kernel / its weight gradient on the matrix core
@@ -1104,10 +1104,11 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 // this conv and the next one both run through F(6x6,3x3) on the same tile grid: its output transform writes the next conv's
                 // transformed input directly (training: into the buffer kept for that conv's weight gradient) and its own output never exists
                 snprintf(nxt, sizeof nxt, "conv%d_%d", b + 1, i + 1);
-                auto it = train ? m->acts.find(std::string("wv:") + nxt) : m->acts.end();
-                // (training: only if the next conv keeps its V for a Winograd-domain weight gradient -- a direct weight gradient would read the
-                //  activation that no longer exists)
-                if (!train || it != m->acts.end()) { e.next_v = train ? it->second.p : m->d_wino_v; e.next_layer = nxt; }
+                // the buffer the next conv will read its V from -- conv_same's own rule: the one kept for its weight gradient if the workspace
+                // has one (whether or not this pass trains), else the shared scratch.  Training: only if that kept buffer exists -- a direct
+                // weight gradient would read the activation that no longer exists.
+                auto it = m->acts.find(std::string("wv:") + nxt);
+                if (!train || it != m->acts.end()) { e.next_v = it != m->acts.end() ? it->second.p : m->d_wino_v; e.next_layer = nxt; }
             }
             bool done = false;
             if (first && m->widths[0] == 64) {            // conv1_1: write-bound gather kernel (igemm.hip: conv1_glds_kernel)

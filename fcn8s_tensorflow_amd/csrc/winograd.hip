@@ -456,9 +456,12 @@ template <int CPB, int NCOL>
 __global__ __launch_bounds__(CPB * NCOL, OI_WPS == 1 ? 1 : 512 / (CPB * NCOL)) void wino_out_in_kernel(const VecF<2>* __restrict__ m, const VecF<2>* __restrict__ bias, VecF<2>* __restrict__ v,
                                                                     unsigned* __restrict__ rbits_out, int N, int H, int W, int C4, long long slab, int rows_per_block)
 {
-    constexpr int VEC = 2, M = 6, A = 8, TX = NCOL - 2, RW = (M * M * VEC + 31) / 32;
+    constexpr int VEC = 2, M = 6, A = 8, TX = NCOL - 2, RW = (M * M * VEC + 31) / 32, SLOTS = 24;
     typedef WinoMat<6, 3> WM;
-    __shared__ VF col0[NCOL][M][CPB], col5[NCOL][M][CPB], cornT[NCOL][2][CPB], cornB[NCOL][2][CPB];
+    // one array [tile column][24 slots][channel pair] (slots 16-21: row 5 of the thread's own tile of two iterations ago, parked here rather than in registers): slots 0-5 = column 0 of the column's tile (rows 0..5), 6-11 = its column 5, 12 / 13 = row 5's
+    // pixels 0 / 5 of the tile above it, 14 / 15 = row 0's pixels 0 / 5 of the tile below.  A thread addresses it through three bases (its own
+    // column and the two neighbours) plus compile-time slot offsets, which the LDS instructions carry as immediates.
+    __shared__ VF lds[NCOL * SLOTS * CPB];
     const int th = (H + M - 1) / M, tw = (W + M - 1) / M;
     const int j = threadIdx.x / CPB, cpl = threadIdx.x - j * CPB;
     const int ngroups = C4 / CPB;
@@ -471,9 +474,12 @@ __global__ __launch_bounds__(CPB * NCOL, OI_WPS == 1 ? 1 : 512 / (CPB * NCOL)) v
     const bool colok = tx >= 0 && tx < tw;
     const bool inner = j >= 1 && j <= TX && colok;
     const VF bv = bias[c];
-    VF yprev[M][M], ynew[M][M], top[M];
+    VF* const lmine = lds + (j * SLOTS) * CPB + cpl;
+    const VF* const lleft = lmine - SLOTS * CPB;            // (only dereferenced by inner threads: 1 <= j <= TX)
+    const VF* const lright = lmine + SLOTS * CPB;
+    VF yprev[M][M], ynew[M][M];
 #pragma unroll
-    for (int a = 0; a < M; ++a) { top[a] = f4zero(); _Pragma("unroll") for (int b = 0; b < M; ++b) yprev[a][b] = f4zero(); }
+    for (int a = 0; a < M; ++a) { lmine[(16 + a) * CPB] = f4zero(); _Pragma("unroll") for (int b = 0; b < M; ++b) yprev[a][b] = f4zero(); }
 
     for (int r = r0 - 1; r <= r1; ++r) {
         // (the 2 x 64 slab offsets are block-uniform products: hoisted out of this loop they would sit in 256 registers for its whole
@@ -503,6 +509,7 @@ __global__ __launch_bounds__(CPB * NCOL, OI_WPS == 1 ? 1 : 512 / (CPB * NCOL)) v
 #pragma unroll
                     for (int ox = 0; ox < M; ++ox) if (WM::at(ox, b) != 0.f) ynew[o][ox] = f4fma(WM::at(ox, b), sacc, ynew[o][ox]);
                 }
+                if (b == 3) __builtin_amdgcn_sched_barrier(0);      // the tile's 64 loads in two batches of 32: all at once, on top of two tiles of state, spilled 36 registers (6 now)
             }
             unsigned rb[RW];
 #pragma unroll
@@ -528,16 +535,18 @@ __global__ __launch_bounds__(CPB * NCOL, OI_WPS == 1 ? 1 : 512 / (CPB * NCOL)) v
 #pragma unroll
             for (int a = 0; a < M; ++a) _Pragma("unroll") for (int b = 0; b < M; ++b) ynew[a][b] = f4zero();
         }
-        cornB[j][0][cpl] = ynew[0][0]; cornB[j][1][cpl] = ynew[0][M - 1];
+        lmine[14 * CPB] = ynew[0][0]; lmine[15 * CPB] = ynew[0][M - 1];
         __syncthreads();
         // ---- B: the patch of tile (r - 1, tx) is complete: V' = B^T d B -----------------------------------------------------------
         if (inner && r - 1 >= r0 && r - 1 < r1) {
             // (row by row of B^T d: the patch IS yprev / top / ynew plus the two LDS columns, so only one row of the intermediate is live)
-            VF left[A], right[A];
-            left[0] = cornT[j - 1][1][cpl]; right[0] = cornT[j + 1][0][cpl];
+            VF left[A], right[A], top[M];
 #pragma unroll
-            for (int a = 0; a < M; ++a) { left[a + 1] = col5[j - 1][a][cpl]; right[a + 1] = col0[j + 1][a][cpl]; }
-            left[A - 1] = cornB[j - 1][1][cpl]; right[A - 1] = cornB[j + 1][0][cpl];
+            for (int a = 0; a < M; ++a) top[a] = lmine[(16 + a) * CPB];
+            left[0] = lleft[13 * CPB]; right[0] = lright[12 * CPB];
+#pragma unroll
+            for (int a = 0; a < M; ++a) { left[a + 1] = lleft[(6 + a) * CPB]; right[a + 1] = lright[a * CPB]; }
+            left[A - 1] = lleft[15 * CPB]; right[A - 1] = lright[14 * CPB];
             VF* vp = v + (t - tw) * C4 + c;                       // tile (r - 1, tx)
 #pragma unroll
             for (int a = 0; a < A; ++a) {
@@ -564,11 +573,11 @@ __global__ __launch_bounds__(CPB * NCOL, OI_WPS == 1 ? 1 : 512 / (CPB * NCOL)) v
         }
         __syncthreads();
         // ---- C: tile r becomes the previous one --------------------------------------------------------------------------------------
-        cornT[j][0][cpl] = yprev[M - 1][0]; cornT[j][1][cpl] = yprev[M - 1][M - 1];
+        lmine[12 * CPB] = yprev[M - 1][0]; lmine[13 * CPB] = yprev[M - 1][M - 1];
 #pragma unroll
         for (int a = 0; a < M; ++a) {
-            top[a] = yprev[M - 1][a];
-            col0[j][a][cpl] = ynew[a][0]; col5[j][a][cpl] = ynew[a][M - 1];
+            lmine[(16 + a) * CPB] = yprev[M - 1][a];
+            lmine[a * CPB] = ynew[a][0]; lmine[(6 + a) * CPB] = ynew[a][M - 1];
         }
 #pragma unroll
         for (int a = 0; a < M; ++a) _Pragma("unroll") for (int b = 0; b < M; ++b) yprev[a][b] = ynew[a][b];
@@ -1047,10 +1056,11 @@ void launch_wino_output(int tile, const float* m, const float* bias, const float
 }
 // m: M of conv L [64][T][C] (its GEMM's output), v: V of conv L+1 [64][T][C]; both F(6x6,3x3) on [N,H,W,C]; C % 64 == 0.  Returns false
 // if the shape is not covered (the caller then runs the two kernels).
-// always = false: only when the launch fills the chip without cutting images into row ranges (N x strips x channel groups >= 200 blocks:
-// 16 x 1024x512 does, 4 x 2048x1024 and a single image do not) -- below that the walk is too long and too narrow and the two kernels win
-// (measured: batch-1 inference 1.97 against 1.87 ms, 4 x 2048x1024 training 60.0 against 59.6 ms per step; 16 x 1024x512: 2.62 against
-// 2.99 ms per step over the seven layer pairs).
+// (Round 4's first build of the kernel spilled 52 registers and lost to the two kernels on launches that had to cut images into row
+// ranges -- one image, 4 x 2048x1024 -- so fusion waited for launches of >= 200 blocks.  With the LDS exchange through one array
+// (immediate offsets), row 5 of the tile before last parked in LDS and the tile's loads in two batches it spills 6 and wins or ties
+// everywhere measured: 16 x 1024x512 13.39 against 14.05 ms of transforms per step, 4 x 2048x1024 13.58 against 13.91, one image 1.90
+// against 1.91 ms per prediction.  `always` is kept for the option's value 2 and changes nothing today.)
 bool launch_wino_out_in(const float* m, const float* bias, float* v, unsigned* rbits_out, int N, int H, int W, int C, hipStream_t s, bool always)
 {
     if (C % 64 || !bias) return false;
@@ -1066,7 +1076,7 @@ bool launch_wino_out_in(const float* m, const float* bias, float* v, unsigned* r
     // enough blocks to fill the chip: cut an image's tile rows into ranges when N x strips x groups is small
     const long long want = 256LL * (512 / threads);
     long long cols = (long long)strips * groups * N;
-    if (!always && cols < 200) return false;
+    (void)always;
     int chunks = (int)((want + cols - 1) / cols); if (chunks < 1) chunks = 1; if (chunks > th) chunks = th;
     const int rpb = (th + chunks - 1) / chunks;
     chunks = (th + rpb - 1) / rpb;

@@ -667,9 +667,14 @@ class Engine:
         return out if argmax or self.logical_classes == self.num_classes else np.ascontiguousarray(out[..., :self.logical_classes])
 
     # ---- introspection (tests, bench) -----------------------------------------------------------
-    def activation(self, name, shape):
+    def activation(self, name, shape, missing_ok=False):
+        """fcn8s_get_activation.  A conv whose output transform was fused with the next conv's input transform (option `fuse_out_in`)
+        has no activation tensor; the library says so (Fcn8sError), or, with `missing_ok`, this returns None."""
         a = np.empty(shape, np.float32)
-        L.check(L.lib.fcn8s_get_activation(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size), self.h)
+        rc = L.lib.fcn8s_get_activation(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size)
+        if rc == L.ERR_STATE and missing_ok and b"not materialised" in (L.lib.fcn8s_last_error(self.h) or b""):
+            return None
+        L.check(rc, self.h)
         return a
 
     def relu_branches(self, nhw):

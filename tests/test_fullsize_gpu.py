@@ -155,7 +155,7 @@ def test_config3_gradients_1024x512_bs1_vs_oracle(variant, options, bound):
     g = e.get_grads()
     br = e.relu_branches((1, 512, 1024))
     rt = e.pool_routes((1, 512, 1024))
-    acts_dev = {k: e.activation(k, v.shape) for k, v in br.items()}
+    acts_dev = {k: e.activation(k, v.shape, missing_ok=True) for k, v in br.items()}      # (None for a conv fused with its successor: no tensor exists)
     e.close()
     _, acts = orc.forward(P, img, keep=True)
     n_relu = n_route = 0
@@ -163,7 +163,8 @@ def test_config3_gradients_1024x512_bs1_vs_oracle(variant, options, bound):
         d = on != (acts[k] > 0)
         n_relu += int(d.sum())
         if d.any():
-            assert np.maximum(np.abs(acts_dev[k][d]), np.abs(acts[k][d])).max() < 1e-5 * np.abs(acts[k]).max(), k
+            big = np.abs(acts[k][d]) if acts_dev[k] is None else np.maximum(np.abs(acts_dev[k][d]), np.abs(acts[k][d]))
+            assert big.max() < 1e-5 * np.abs(acts[k]).max(), k
     own, gaps = orc.pool_routes(acts)
     for k in rt:
         d = rt[k] != own[k]
@@ -250,9 +251,9 @@ def test_config3_training_step_1024x512_bs16_properties():
 
 
 def test_config3_fused_forward_transforms_at_bs16_equal_the_two_kernel_form():
-    """BASELINE's configuration (16 x 1024x512) is where the default engine fuses each inner conv's output transform with the next conv's
-    input transform (`fuse_out_in` = 1: launches that fill the chip).  At that size, against an engine with the fusion off: the kernel really
-    runs (five launches per pass: the conv5 pairs have too few blocks), loss and softmax are bit-identical, every gradient tensor agrees to the weight-gradient atomics' order."""
+    """The default engine fuses each inner conv's output transform with the next conv's input transform (`fuse_out_in` = 1).  At BASELINE's
+    size (16 x 1024x512), against an engine with the fusion off: the kernel really
+    runs (seven launches per pass), loss and softmax are bit-identical, every gradient tensor agrees to the weight-gradient atomics' order."""
     import torch
     from fcn8s_tensorflow_amd.engine import Engine
     N, H, W, C = 16, 512, 1024, 20
@@ -267,7 +268,7 @@ def test_config3_fused_forward_transforms_at_bs16_equal_the_two_kernel_form():
         prof = e.profile_results()
         e.profile(0)
         n_fused = sum(int(v["launches"]) for k, v in prof.items() if k.startswith("kernel:") and "wino_out_in_kernel" in k)
-        assert n_fused == (5 if fuse else 0), n_fused            # conv2, conv3 (x2), conv4 (x2); conv5's 128 blocks stay below the 200 that fill the chip
+        assert n_fused == (7 if fuse else 0), n_fused            # conv2_1, conv3_1, conv3_2, conv4_1, conv4_2, conv5_1, conv5_2
         got.append((loss, e.flat_grads.clone(), e.predict(imgd[:2], argmax=False).clone(), dict(e.specs)))
         e.close()
     assert got[0][0] == got[1][0]

@@ -51,8 +51,9 @@ def device_decisions(e, P, img, nhw, relu_tol=1e-5, tie_tol=2e-5, max_frac=1e-4,
         d = on != (ref > 0)
         if d.any():
             stats["relu_differ"] += int(d.sum())
-            gpu = e.activation(k, ref.shape)
-            stats["relu_worst"] = max(stats["relu_worst"], float(np.maximum(np.abs(gpu[d]), np.abs(ref[d])).max() / (np.abs(ref).max() + 1e-30)))
+            gpu = e.activation(k, ref.shape, missing_ok=True)          # (None: fused with the next conv's input transform, no tensor to look at)
+            big = np.abs(ref[d]) if gpu is None else np.maximum(np.abs(gpu[d]), np.abs(ref[d]))
+            stats["relu_worst"] = max(stats["relu_worst"], float(big.max() / (np.abs(ref).max() + 1e-30)))
     own, gaps = orc.pool_routes(acts)
     for b, nconv in enumerate(orc.CONVS_PER_BLOCK, start=1):
         k = "pool%d" % b
@@ -784,12 +785,11 @@ def test_fused_output_and_next_input_transform_is_bit_identical(widths, n, h, w)
     kernel runs the same fma chains in the same order, so everything downstream -- pooled activations, softmax, loss -- has the same bits,
     and the gradients differ by the weight-gradient atomics' summation order only; the ReLU record it writes is the one the backward pass
     masks with.  Sizes with partial edge tiles in both directions, strips narrower and wider than a block, widths (192) that leave the
-    kernel's channel groups ragged (C % 64 == 0 is all it needs).  Option 2 = fuse wherever the shapes allow (1, the default, waits for
-    launches that fill the chip); the activation a fused launch no longer writes is reported as such."""
+    kernel's channel groups ragged (C % 64 == 0 is all it needs).  The activation a fused launch no longer writes is reported as such."""
     from fcn8s_tensorflow_amd.engine import Engine
     P, img, lab = case(widths, n, h, w, seed=5)
     got = []
-    for fuse in (2, 0):
+    for fuse in (1, 0):
         e = Engine(20, widths=widths, options={"fuse_out_in": fuse})
         assert e.get_option("fuse_out_in") == fuse
         e.set_params(P)
@@ -798,7 +798,7 @@ def test_fused_output_and_next_input_transform_is_bit_identical(widths, n, h, w)
         ks = [k for k in e.profile_results() if k.startswith("kernel:")]
         e.profile(0)
         ran = any("wino_out_in_kernel" in k for k in ks)
-        assert ran == (fuse == 2), ks
+        assert ran == (fuse == 1), ks
         g = e.get_grads()
         br = e.relu_branches((n, h, w))
         wd = e.widths
@@ -822,7 +822,7 @@ def test_fused_output_and_next_input_transform_is_bit_identical(widths, n, h, w)
                 except L.Fcn8sError as ex:
                     assert "not materialised" in str(ex) and has_rec
                     missing.append(name)
-        assert bool(missing) == (fuse == 2), missing
+        assert bool(missing) == (fuse == 1), missing
         sm = e.predict(img, argmax=False)           # (inference pass: V' goes to the shared scratch instead of the kept buffer)
         got.append((loss, g, br, pools, sm))
         e.close()
@@ -834,17 +834,31 @@ def test_fused_output_and_next_input_transform_is_bit_identical(widths, n, h, w)
         np.testing.assert_array_equal(got[0][2][k], got[1][2][k])
     for k in got[1][1]:
         assert rel(got[0][1][k], got[1][1][k]) < 2e-5, (k, rel(got[0][1][k], got[1][1][k]))
+    # inference on engines that never trained, on another image (a pass that merely found the previous pass's V lying in the right buffer
+    # once went unnoticed): the fused kernel must hand its V to the buffer the next conv really reads
+    img2, _ = batch(n, h, w, seed=77)
+    fresh = []
+    for fuse in (1, 0):
+        e = Engine(20, widths=widths, options={"fuse_out_in": fuse}); e.set_params(P)
+        fresh.append(e.predict(img2, argmax=False))
+        e.freeze(True); again = e.predict(img2, argmax=False); e.freeze(False)
+        np.testing.assert_array_equal(again, fresh[-1])
+        e.close()
+    np.testing.assert_array_equal(fresh[0], fresh[1])
     with pytest.raises(ValueError):
         Engine(20, options={"fuse_out_in": 3})
 
 
-@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+@pytest.mark.parametrize("optimizer", ["sgd"])
 def test_free_running_training_trajectory_follows_the_oracle(optimizer):
     """The closest thing to the reference's "train it and look at the curve" that can be checked offline: the library and the CPU oracle
     each train the SAME small-width FCN-8s from the same initial variables on the same four batches of a learnable task (label = a function
     of the pixel colour), free-running for 32 (SGD) / 16 (Adam) steps -- no per-step re-synchronisation as in test_tf_adam_training_steps -- with SGD+momentum and
     with the reference's TF-Adam (fcn8s_tensorflow.py:256).  The two loss curves must stay together (fp32 round-off grows along a trajectory;
-    the bound below is 50x what was measured) and both must actually learn."""
+    the bound below is 25x what was measured) and both must actually learn.  Only SGD + momentum runs free here: TF-Adam's update is sign-like
+    wherever a gradient is at round-off level, and the library's own weight-gradient atomics (summation order differs from run to run) are enough
+    to send two Adam trajectories apart after a dozen steps -- measured loss gaps between 1e-6 and 2e-2 for the same 16 steps on different runs.
+    Adam is checked step by step instead (test_tf_adam_training_steps), each step restarted from the library's own state."""
     from fcn8s_tensorflow_amd import _lib as L
     import torch
     torch.set_num_threads(min(int(os.environ.get("FCN8S_TEST_THREADS", "8")), torch.get_num_threads()))            # (tiny CPU convolutions: hundreds of threads only get in each other's way)
