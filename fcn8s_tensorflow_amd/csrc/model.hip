@@ -88,7 +88,7 @@ struct fcn8s_model {
     std::string dm_layer;                                                 // layer whose dM = A dY A^T sits in d_wino_m, ready for the adjoint data gradient
     std::string dm_prefilled;                                             // layer whose dM the data gradient of the layer after it has already written into d_wino_m (fused transform)
     int fuse_dgrad_dout = 1;                                              // option: allow that fusion
-    int fuse_out_in = 1;                                                  // option: inside a block, conv L's output transform writes conv L+1's V directly (Y is never written); 0 = two kernels
+    int fuse_out_in = 1;                                                  // option: inside a block, conv L's output transform writes conv L+1's V directly (Y is never written): 0 never, 1 unless the row ranges would get too short, 2 always
     std::string fwd_v_layer;                                              // forward: layer whose V the previous layer's fused output transform has already written
     std::set<std::string> y_unwritten;                                    // layers whose activation tensor was not materialised by the last forward pass
     int conv1_tiled = 1, conv1_wgrad_mfma = 1;                            // options: conv1_1 forward on the spatial-tile kernel / its weight gradient on the matrix core

@@ -1056,11 +1056,10 @@ void launch_wino_output(int tile, const float* m, const float* bias, const float
 }
 // m: M of conv L [64][T][C] (its GEMM's output), v: V of conv L+1 [64][T][C]; both F(6x6,3x3) on [N,H,W,C]; C % 64 == 0.  Returns false
 // if the shape is not covered (the caller then runs the two kernels).
-// (Round 4's first build of the kernel spilled 52 registers and lost to the two kernels on launches that had to cut images into row
-// ranges -- one image, 4 x 2048x1024 -- so fusion waited for launches of >= 200 blocks.  With the LDS exchange through one array
-// (immediate offsets), row 5 of the tile before last parked in LDS and the tile's loads in two batches it spills 6 and wins or ties
-// everywhere measured: 16 x 1024x512 13.39 against 14.05 ms of transforms per step, 4 x 2048x1024 13.58 against 13.91, one image 1.90
-// against 1.91 ms per prediction.  `always` is kept for the option's value 2 and changes nothing today.)
+// always = false: not when the launch would have to cut images into row ranges shorter than four tile rows to fill the chip (a range
+// recomputes one halo row above and one below it): a single 1024x512 image, conv5_x at any batch.  Measured with the kernel as it is now
+// (6 spilled registers; its first build spilled 52 and lost on every launch with row ranges): 16 x 1024x512 58.9-59.1 against 59.7-59.8 ms
+// per step (transforms 13.26 against 13.96), 4 x 2048x1024 58.7 against 59.0-59.3; one image, forced: 1.91 against 1.88 ms per prediction.
 bool launch_wino_out_in(const float* m, const float* bias, float* v, unsigned* rbits_out, int N, int H, int W, int C, hipStream_t s, bool always)
 {
     if (C % 64 || !bias) return false;
@@ -1076,10 +1075,10 @@ bool launch_wino_out_in(const float* m, const float* bias, float* v, unsigned* r
     // enough blocks to fill the chip: cut an image's tile rows into ranges when N x strips x groups is small
     const long long want = 256LL * (512 / threads);
     long long cols = (long long)strips * groups * N;
-    (void)always;
     int chunks = (int)((want + cols - 1) / cols); if (chunks < 1) chunks = 1; if (chunks > th) chunks = th;
     const int rpb = (th + chunks - 1) / chunks;
     chunks = (th + rpb - 1) / rpb;
+    if (!always && chunks > 1 && rpb < 4) return false;
     const dim3 grid((unsigned)(strips * groups), (unsigned)(N * chunks));
     g_last_kernel = "wino_out_in_kernel";
 #define FCN8S_OI(CPB_, NCOL_) hipLaunchKernelGGL((wino_out_in_kernel<CPB_, NCOL_>), grid, dim3(CPB_ * NCOL_), 0, s, (const VecF<2>*)m, (const VecF<2>*)bias, (VecF<2>*)v, rbits_out, N, H, W, C4, wino_slab(T, C) / 2, rpb)

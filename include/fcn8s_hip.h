@@ -244,7 +244,9 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *     "fuse_out_in"       1    forward, inside a VGG block: the output transform of a conv is fused with the input transform of the next one (both
  *                              F(6x6,3x3) on the same tile grid): Y = relu(A^T M A + b) stays in registers / LDS and the kernel writes the next conv's
  *                              V = B^T d B (bit-identical to the two-kernel form); the conv's own activation tensor is then never written and
- *                              fcn8s_get_activation of it returns FCN8S_ERR_STATE (fcn8s_get_relu_record still answers).  0 = two kernels; 2 = 1
+ *                              fcn8s_get_activation of it returns FCN8S_ERR_STATE (fcn8s_get_relu_record still answers).  0 = two kernels; 1 = fused unless the
+ *                              launch would need row ranges of fewer than four tile rows per block to fill the chip (a single image, conv5_x: the
+ *                              recomputed halo rows then eat the gain); 2 = fused whenever the shapes allow
  *     "bf16_gemm256"      1    FCN8S_PREC_BF16_FC: fc6 / fc7 forward on the 256 x 256 LDS-DMA kernel -- 0 never, 1 when the launch has at least
  *                              128 tiles (training batches), 2 whenever the shapes allow (rows and Cout multiples of 256)
  *     "conv1_tiled"       1    conv1_1 forward on the spatial-tile kernel (halo tile in LDS); 0 = the LDS-DMA gather kernel (bit-identical results)

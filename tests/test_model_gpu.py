@@ -789,7 +789,7 @@ def test_fused_output_and_next_input_transform_is_bit_identical(widths, n, h, w)
     from fcn8s_tensorflow_amd.engine import Engine
     P, img, lab = case(widths, n, h, w, seed=5)
     got = []
-    for fuse in (1, 0):
+    for fuse in (2, 0):             # (2 = wherever the shapes allow; the default, 1, leaves launches with very short row ranges -- these small cases -- on two kernels)
         e = Engine(20, widths=widths, options={"fuse_out_in": fuse})
         assert e.get_option("fuse_out_in") == fuse
         e.set_params(P)
@@ -798,7 +798,7 @@ def test_fused_output_and_next_input_transform_is_bit_identical(widths, n, h, w)
         ks = [k for k in e.profile_results() if k.startswith("kernel:")]
         e.profile(0)
         ran = any("wino_out_in_kernel" in k for k in ks)
-        assert ran == (fuse == 1), ks
+        assert ran == (fuse == 2), ks
         g = e.get_grads()
         br = e.relu_branches((n, h, w))
         wd = e.widths
@@ -822,7 +822,7 @@ def test_fused_output_and_next_input_transform_is_bit_identical(widths, n, h, w)
                 except L.Fcn8sError as ex:
                     assert "not materialised" in str(ex) and has_rec
                     missing.append(name)
-        assert bool(missing) == (fuse == 1), missing
+        assert bool(missing) == (fuse == 2), missing
         sm = e.predict(img, argmax=False)           # (inference pass: V' goes to the shared scratch instead of the kept buffer)
         got.append((loss, g, br, pools, sm))
         e.close()
@@ -838,7 +838,7 @@ def test_fused_output_and_next_input_transform_is_bit_identical(widths, n, h, w)
     # once went unnoticed): the fused kernel must hand its V to the buffer the next conv really reads
     img2, _ = batch(n, h, w, seed=77)
     fresh = []
-    for fuse in (1, 0):
+    for fuse in (2, 0):
         e = Engine(20, widths=widths, options={"fuse_out_in": fuse}); e.set_params(P)
         fresh.append(e.predict(img2, argmax=False))
         e.freeze(True); again = e.predict(img2, argmax=False); e.freeze(False)
