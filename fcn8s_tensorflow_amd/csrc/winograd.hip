@@ -788,7 +788,11 @@ __global__ __launch_bounds__(256, 2) void wino_dgrad_output_dout_kernel(const VF
         }
     }
     const bool up = ti.ty > 0, down = ti.ty + 1 < th, left = ti.tx > 0, right = ti.tx + 1 < tw;
-    VF nrow[2][M], ncol[2][M], corner[2][2];      // [0] = top / left, [1] = bottom / right
+    // the neighbours' border contributions (28 values per thread) wait in LDS, in a slot of the thread's own, for the loop that adds them: held in
+    // registers next to tt and r they spilled 29 registers to scratch, and that scratch traffic reached the fabric (WRITE_SIZE: 1217 MB per conv3
+    // launch for 992 MB of dM).  [slot][thread]: consecutive lanes, consecutive 8-byte words.
+    __shared__ VF park[28][256];
+    VF (*const pk)[256] = reinterpret_cast<VF (*)[256]>(&park[0][threadIdx.x]);      // pk[slot][0] = this thread's slot
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const bool okr = e == 0 ? up : down, okc = e == 0 ? left : right;
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void wino_dgrad_output_dout_kernel(const VF
 #pragma unroll
             for (int k = 0; k < A; ++k) if (WM::bt(k, j + 1) != 0.f) { sr = f4fma(WM::bt(k, j + 1), r[k], sr); sc = f4fma(WM::bt(k, j + 1), c[k], sc); }
             _Pragma("unroll") for (int v = 0; v < VEC; ++v) { sr.d[v] *= edge; sc.d[v] *= edge; }
-            nrow[e][j] = sr; ncol[e][j] = sc;
+            pk[e * M + j][0] = sr; pk[2 * M + e * M + j][0] = sc;
         }
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
@@ -813,7 +817,7 @@ __global__ __launch_bounds__(256, 2) void wino_dgrad_output_dout_kernel(const VF
             const long long oc = orow + (f == 0 ? -1 : 1) * (long long)C4;
             VF v = (okr && okf) ? dv[(pa * A + pb) * slab_v + oc] : f4zero();
             _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] *= edge * WM::bt(pb, pb);
-            corner[e][f] = v;
+            pk[4 * M + e * 2 + f][0] = v;
         }
     }
     VF r[M][A];                            // r[oy][b] = sum_ox dZ[oy][ox] A^T(ox, b)
@@ -825,11 +829,11 @@ __global__ __launch_bounds__(256, 2) void wino_dgrad_output_dout_kernel(const VF
             VF v = f4zero();
 #pragma unroll
             for (int b = 0; b < A; ++b) if (WM::bt(b, ox + 1) != 0.f) v = f4fma(WM::bt(b, ox + 1), tt[oy][b], v);
-            if (oy == 0)     { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += nrow[0][ox].d[k]; }
-            if (oy == M - 1) { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += nrow[1][ox].d[k]; }
-            if (ox == 0)     { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += ncol[0][oy].d[k]; }
-            if (ox == M - 1) { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += ncol[1][oy].d[k]; }
-            if ((oy == 0 || oy == M - 1) && (ox == 0 || ox == M - 1)) { _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += corner[oy == 0 ? 0 : 1][ox == 0 ? 0 : 1].d[k]; }
+            if (oy == 0)     { const VF t_ = pk[ox][0];             _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += t_.d[k]; }
+            if (oy == M - 1) { const VF t_ = pk[M + ox][0];         _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += t_.d[k]; }
+            if (ox == 0)     { const VF t_ = pk[2 * M + oy][0];     _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += t_.d[k]; }
+            if (ox == M - 1) { const VF t_ = pk[3 * M + oy][0];     _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += t_.d[k]; }
+            if ((oy == 0 || oy == M - 1) && (ox == 0 || ox == M - 1)) { const VF t_ = pk[4 * M + (oy == 0 ? 0 : 1) * 2 + (ox == 0 ? 0 : 1)][0]; _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] += t_.d[k]; }
             const bool inside = M * ti.ty + oy < H && M * ti.tx + ox < W;              // partial edge tiles
             _Pragma("unroll") for (int k = 0; k < VEC; ++k) {
                 const int bit = (oy * M + ox) * VEC + k;
