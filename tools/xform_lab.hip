@@ -25,13 +25,29 @@ static __device__ __forceinline__ V2 xchg(const V2& v) { V2 r; r.d[0] = __shfl_x
 
 // MODE: 0 base, 1 read-only, 2 write-only, 3 16-byte stores, 4 16-byte loads and stores
 template <int MODE>
-__global__ __launch_bounds__(256) void xin(const V2* __restrict__ x, V2* __restrict__ v, int N, int H, int W, int C4, long long slab, int tpb, float* sink)
+__global__ __launch_bounds__(256) void xin(const V2* __restrict__ x, V2* __restrict__ v, int N, int H, int W, int C4, long long slab, int tpb, float* sink, int order = 0, int strip = 4)
 {
     constexpr int A = 8, M = 6;
     const int th = (H + M - 1) / M, tw = (W + M - 1) / M;
-    const int n = blockIdx.y / th, ty = blockIdx.y - n * th;
+    // block order.  0: as dispatched (x fastest; consecutive blocks go to consecutive XCDs).  1: XCD k (= dispatch id % 8) takes the k-th
+    // eighth of the row-major block list.  2: the same over a list in which a strip of `strip` chunks walks down all tile rows before the
+    // next strip starts (vertically adjacent tiles a few blocks apart on ONE XCD: their shared two pixel rows can meet in its L2).  3: strips, no XCD remap.
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (order) {
+        const unsigned gx = gridDim.x, gy = gridDim.y, B = gx * gy, L = by * gx + bx;
+        unsigned Lp = L;
+        if (order == 1 || order == 2) { const unsigned per = (B + 7) / 8; Lp = (L % 8) * per + L / 8; if (Lp >= B) return; }      // (ragged tail: a few blocks idle in the lab)
+        if (order == 1) { by = Lp / gx; bx = Lp % gx; }
+        else {
+            const unsigned S = (unsigned)strip, full = gx / S * S;          // chunks beyond the last whole strip form a narrower one
+            const unsigned in_full = full * gy;
+            if (Lp < in_full) { const unsigned st = Lp / (S * gy), rem = Lp % (S * gy); by = rem / S; bx = st * S + rem % S; }
+            else { const unsigned w = gx - full, rem = Lp - in_full; by = rem / w; bx = full + rem % w; }
+        }
+    }
+    const int n = by / th, ty = by - n * th;
     for (int it = 0; it < tpb; ++it) {
-        const int idx = (blockIdx.x * tpb + it) * 256 + threadIdx.x;
+        const int idx = (bx * tpb + it) * 256 + threadIdx.x;
         const int tx = idx / C4, c = idx - tx * C4;
         if (tx >= tw) break;
         const long long t = ((long long)n * th + ty) * tw + tx;
@@ -174,6 +190,14 @@ int main(int argc, char** argv)
         rep("16-byte stores (lane pairs swap halves)", RUN(3, 1), rd + wr);
         rep("16-byte loads and stores", RUN(4, 1), rd + wr);
         rep("16-byte loads and stores, tpb 4", RUN(4, 4), rd + wr);
+#define RUNO(MODE, order, strip) timeit([&] { hipLaunchKernelGGL((xin<MODE>), grid(1), dim3(256), 0, 0, (const V2*)x, (V2*)v, cs.N, cs.H, cs.W, C4, slabf / 2, 1, sink, order, strip); })
+        rep("order: XCD-banded, row-major", RUNO(0, 1, 4), rd + wr);
+        rep("order: XCD-banded strips of 2 chunks", RUNO(0, 2, 2), rd + wr);
+        rep("order: XCD-banded strips of 4 chunks", RUNO(0, 2, 4), rd + wr);
+        rep("order: XCD-banded strips of 8 chunks", RUNO(0, 2, 8), rd + wr);
+        rep("order: strips of 4 chunks, no XCD remap", RUNO(0, 3, 4), rd + wr);
+        rep("read-only, XCD-banded strips of 4", RUNO(1, 2, 4), rd);
+        rep("16-byte lanes + XCD-banded strips of 4", RUNO(4, 2, 4), rd + wr);
         rep("base again", RUN(0, 1), rd + wr);
         CK(hipGetLastError());
         CK(hipFree(x)); CK(hipFree(v));
