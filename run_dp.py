@@ -82,8 +82,8 @@ def main():
     train_gen = data.generate(batch_size=args.batch, convert_ids_to_ids=convert, convert_to_one_hot=True, void_class_id=0,
                               random_crop=(args.height, args.width), flip=0.5, shuffle=True, workers=args.workers)
     model = FCN8s(vgg16_dir=args.vgg16, num_classes=20, device_id=local)          # weights are broadcast from rank 0
-    if args.comm == "native" and world > 1:
-        model.engine.comm_init_native()                                           # one RCCL rank per model inside libfcn8s_hip.so
+    if args.comm == "native":
+        model.engine.comm_init_native()                                           # one RCCL rank per model inside libfcn8s_hip.so (also with a single rank)
         model.engine.broadcast_params(0)
     model.train(train_generator=train_gen, epochs=args.epochs, steps_per_epoch=args.steps_per_epoch,
                 learning_rate_schedule=lambda step: 1e-4 if step < 10000 else 1e-5, keep_prob=0.5, l2_regularization=0.0,

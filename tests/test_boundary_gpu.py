@@ -183,6 +183,16 @@ def test_run_dp_eight_ranks_dry_run():
     assert "rank 0: 8 ranks x 1 images/step, global step 2" in r.stdout, r.stdout[-1000:]
 
 
+def test_run_dp_trains_through_the_native_communicator():
+    """run_dp.py --comm native with the one rank this box has: FCN8s.train() end to end, every gradient bucket all-reduced by the library's own RCCL
+    communicator (no torch.distributed process group exists in this run at all), evaluation metrics summed through fcn8s_comm_allreduce_metrics."""
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_dp.py"), "--gpus", "1", "--comm", "native", "--batch", "2", "--height", "64", "--width", "64",
+                        "--steps-per-epoch", "3", "--workers", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rank 0: 1 ranks x 2 images/step, global step 3" in r.stdout, r.stdout[-1000:]
+
+
 def test_bench_under_torchrun_one_rank_native_rccl():
     """`--comm native`: the gradient buckets are all-reduced by the library's own RCCL communicator (fcn8s_comm_init /
     fcn8s_allreduce_bucket behind the C ABI), torch.distributed only carried the 128-byte id.  One rank is all this box has."""
