@@ -299,6 +299,7 @@ void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H,
 {
     const long long total = (long long)N * (H + 2 * pad) * (W + 2 * pad) * (C / 8);
     long long b = (total + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1;
+    g_last_kernel = "f32_to_bf16_padded_kernel";
     hipLaunchKernelGGL(f32_to_bf16_padded_kernel, dim3((unsigned)b), dim3(256), 0, s, (const float4*)x, (bf16x8*)xp, N, H, W, C / 8, pad);
 }
 

@@ -96,6 +96,10 @@ struct fcn8s_model {
     std::map<std::string, unsigned short*> wbf16_cache;                   // ... per layer, valid while frozen
     int bf16_gemm256 = 1;                                                 // bf16_fc mode: 256 x 256 LDS-DMA kernel -- 0 never, 1 when it fills the chip, 2 whenever shapes allow
     unsigned short* d_abf16 = nullptr; size_t abf16_elems = 0;            // bf16 copy of the layer's input activations
+    // bf16 modes, training: zero-bordered padded bf16 copies of the inputs of conv3_1 .. conv5_3, one per layer (the border is written once, at
+    // allocation; the interior every step by that layer's Winograd input transform, wino_input_kernel<.., XB>); keyed by layer, dropped with the workspace
+    std::map<std::string, unsigned short*> xbf16;
+    int bf16_copy_by_transform = 1;                                       // option: 0 = every bf16 layer converts its input with a pass of its own (round 3's path)
     hipStream_t stream = nullptr;
     int64_t step = 0;
     // workspace for the current (N,H,W)
@@ -711,6 +715,8 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
         return fail(m, FCN8S_ERR_SHAPE, "image height and width must be positive multiples of 32 (five 2x2 pools, then x2, x2, x8 upsampling must line up with the skip connections)");
     if (m->arena && m->N == N && m->H == H && m->W == W) return FCN8S_OK;
     if (m->arena) { hipStreamSynchronize(m->stream); hipFree(m->arena); m->arena = nullptr; }
+    for (auto& kv : m->xbf16) if (kv.second) hipFree(kv.second);
+    m->xbf16.clear();
     m->plan_N = N;                 // the batch size the per-layer Winograd tiles are chosen for (wino_tile_for), from here until the next re-plan
     m->acts.clear();
     m->have_forward = m->have_loss = false;
@@ -958,7 +964,8 @@ bool pool_backward_fused(const fcn8s_model* m, int b, bool pooled_by_transform)
 // fp32 output: fc6 / fc7 of FCN8S_PREC_BF16_FC, and conv3_1 .. conv5_3 as well in FCN8S_PREC_BF16_FWD.  Returns false if no bf16 kernel
 // takes the shape (the caller then uses the fp32 path).
 bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const char* bname, const float* in, float* out,
-                     int N, int h, int w, int cin, int cout, int k, int drop, float keep_prob, uint32_t stream_id, hipStream_t s, bool allow_small = true)
+                     int N, int h, int w, int cin, int cout, int k, int drop, float keep_prob, uint32_t stream_id, hipStream_t s, bool allow_small = true,
+                     const unsigned short* xb_ready = nullptr)          // the padded bf16 copy of `in`, already made (256 x 256 kernel only)
 {
     const int K = k * k * cin;
     const long long Mrows = (long long)N * h * w;
@@ -984,15 +991,15 @@ bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const c
                  if (big) launch_w_to_bf16_t(Wp(m, wname), wbuf, K, cout, s); else launch_w_to_bf16_tiles(Wp(m, wname), wbuf, K, cout, s); }
     const int pad = big ? (k - 1) / 2 : 0;
     const size_t nin = (size_t)N * (h + 2 * pad) * (w + 2 * pad) * cin;
-    if (nin % 8 == 0 && m->abf16_elems < nin) {
+    if (nin % 8 == 0 && m->abf16_elems < nin && !(big && xb_ready)) {
         if (m->d_abf16) { hipStreamSynchronize(s); hipFree(m->d_abf16); m->d_abf16 = nullptr; m->abf16_elems = 0; }
         if (hipMalloc((void**)&m->d_abf16, nin * sizeof(unsigned short)) == hipSuccess) m->abf16_elems = nin; else (void)hipGetLastError();
     }
     const double M = (double)Mrows;
-    if (big && m->d_abf16 && m->abf16_elems >= nin) {
-        { ProfScope ps(m, "weight_relayout", 0, 4.0 * Mrows * cin + 2.0 * nin); launch_f32_to_bf16_padded(in, m->d_abf16, N, h, w, cin, pad, s); }
+    if (big && (xb_ready || (m->d_abf16 && m->abf16_elems >= nin))) {
+        if (!xb_ready) { ProfScope ps(m, "weight_relayout", 0, 4.0 * Mrows * cin + 2.0 * nin); launch_f32_to_bf16_padded(in, m->d_abf16, N, h, w, cin, pad, s); }
         Bf16Conv256Args g{};
-        g.xp = m->d_abf16; g.wt = wbuf; g.bias = Wp(m, bname); g.y = out;
+        g.xp = xb_ready ? xb_ready : m->d_abf16; g.wt = wbuf; g.bias = Wp(m, bname); g.y = out;
         g.N = N; g.H = h; g.W = w; g.Cin = cin; g.Cout = cout; g.K = k;
         g.relu = 1; g.dropout = drop; g.keep_prob = keep_prob; g.seed = m->seed; g.stream_id = stream_id;
         ProfScope ps(m, tag, 2.0 * M * K * cout, 4.0 * M * cout + 2.0 * M * cin + 2.0 * K * cout);
@@ -1011,12 +1018,29 @@ bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const c
     return launch_conv_bf16(a, s);
 }
 
+// bf16 modes, training: the layer's Winograd input transform (run for the weight gradient anyway) can write the padded bf16 copy its direct
+// bf16 convolution reads -- if that convolution takes the 256 x 256 kernel and the transform is the F(6x6,3x3) one.  Returns the layer's copy
+// (allocated and its border zeroed on first use) or nullptr.
+unsigned short* xb_by_transform(fcn8s_model* m, const char* layer, int N, int H, int W, int Cin, int Cout, hipStream_t s)
+{
+    if (!m->bf16_copy_by_transform || Cin % 8 || !m->acts.count(std::string("wv:") + layer) || wino_tile_for(m, H, W, 3) != 6) return nullptr;
+    if (!conv_bf16_256_ok((long long)N * H * W, Cin, Cout, m->bf16_gemm256)) return nullptr;
+    unsigned short*& p = m->xbf16[layer];
+    if (!p) {
+        const size_t bytes = (size_t)N * (H + 2) * (W + 2) * Cin * sizeof(unsigned short);
+        if (hipMalloc((void**)&p, bytes) != hipSuccess) { p = nullptr; (void)hipGetLastError(); m->xbf16.erase(layer); return nullptr; }
+        hipMemsetAsync(p, 0, bytes, s);
+    }
+    return p;
+}
+
 // What the backward pass of a Winograd layer expects from the forward pass when the forward convolution itself did not run through
 // Winograd (the bf16 modes): the transformed input V (kept for the weight gradient in the Winograd domain) and, for the adjoint data
 // gradient, the forward filter bank of THIS step's weights (a bank left over from an earlier step would be silently wrong).
 // in_rbits_out / in_layer: the input is the ReLU output of conv `in_layer`, whose (x > 0) record the transform writes on the way (wino_input_kernel)
+// xb: also fill the interior of this padded bf16 copy of x (F(6x6,3x3) layers; the caller has checked xb_by_transform_ok)
 void wino_backward_operands(fcn8s_model* m, const char* layer, const float* x, const float* wk, int N, int H, int W, int Cin, int Cout, int KS, hipStream_t s,
-                            unsigned* in_rbits_out = nullptr, const char* in_layer = nullptr)
+                            unsigned* in_rbits_out = nullptr, const char* in_layer = nullptr, unsigned short* xb = nullptr)
 {
     const int tile = wino_tile_for(m, H, W, KS);
     if (!tile) return;
@@ -1024,8 +1048,9 @@ void wino_backward_operands(fcn8s_model* m, const char* layer, const float* x, c
     if (it == m->acts.end()) return;
     const int P = wino_alpha(tile, KS) * wino_alpha(tile, KS), nsub2 = wino_nsub(KS) * wino_nsub(KS), Kg = nsub2 * Cin;
     const long long T = wino_tiles(tile, N, H, W);
-    { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg));
-      launch_wino_input(tile, x, it->second.p, N, H, W, Cin, KS, s, KS == 3 ? in_rbits_out : nullptr);
+    { ProfScope ps(m, "wino_transform", 0, 4.0 * ((double)N * H * W * Cin * nsub2 + (double)P * T * Kg) + (xb ? 2.0 * N * H * W * Cin : 0.0));
+      if (xb) launch_wino_input_xb(x, it->second.p, xb, N, H, W, Cin, s, in_rbits_out);
+      else launch_wino_input(tile, x, it->second.p, N, H, W, Cin, KS, s, KS == 3 ? in_rbits_out : nullptr);
       if (in_rbits_out && in_layer && KS == 3) m->rbits_ok.insert(in_layer); }
     const std::string key = std::string(layer) + "#" + std::to_string(tile);
     if ((KS == 3 && tile == 6) || (KS == 7 && tile == 4)) {
@@ -1119,9 +1144,10 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 // FCN8S_PREC_BF16_FWD: conv3_1 .. conv5_3 as direct convolutions with bf16-rounded operands on the 256 x 256 bf16 kernel (the
                 // output is materialised, the block's pool runs as its own kernel, ReLU masks come from the activations); the backward pass
                 // stays in the Winograd domain, so the transformed input and this step's filter bank are made here
-                done = bf16_conv_layer(m, "conv3x3_fwd_bf16", (std::string(nm) + "/filter").c_str(), (std::string(nm) + "/biases").c_str(), x, A(m, nm),
-                                       N, h, w, cin, m->widths[b], 3, 0, 1.f, 0, s, /*allow_small=*/false);
-                if (done && train) {
+                // training: the transform that keeps this layer's V for the weight gradient runs first and writes the padded bf16 copy of the
+                // input on the way (the convolution then starts from it; without a kept V, or in inference, the convolution converts its input itself)
+                unsigned short* xb = train ? xb_by_transform(m, nm, N, h, w, cin, m->widths[b], s) : nullptr;
+                auto operands = [&]() {
                     // the previous conv of the block came from the bf16 kernel too (no ReLU record): this transform of its output writes one
                     unsigned* irb = nullptr; char prev[32] = "";
                     if (i > 1) {
@@ -1129,8 +1155,12 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                         auto it = m->acts.find(std::string("rb:") + prev);
                         if (it != m->acts.end() && !m->rbits_ok.count(prev)) irb = (unsigned*)it->second.p;
                     }
-                    wino_backward_operands(m, nm, x, wt, N, h, w, cin, m->widths[b], 3, s, irb, irb ? prev : nullptr);
-                }
+                    wino_backward_operands(m, nm, x, wt, N, h, w, cin, m->widths[b], 3, s, irb, irb ? prev : nullptr, xb);
+                };
+                if (xb) operands();
+                done = bf16_conv_layer(m, "conv3x3_fwd_bf16", (std::string(nm) + "/filter").c_str(), (std::string(nm) + "/biases").c_str(), x, A(m, nm),
+                                       N, h, w, cin, m->widths[b], 3, 0, 1.f, 0, s, /*allow_small=*/false, xb);
+                if (done && train && !xb) operands();
             }
             if (!done) pooled = conv_same(m, first ? "conv1_1_fwd" : "conv3x3_fwd", x, wt, A(m, nm), N, h, w, cin, m->widths[b], 3, e, s, first ? 3 : 0, nm);
             x = A(m, nm); cin = m->widths[b];
@@ -1586,6 +1616,7 @@ int fcn8s_destroy(fcn8s_model* m)
     for (auto& kv : m->wbf16_cache) if (kv.second) hipFree(kv.second);
     if (m->d_wbf16) hipFree(m->d_wbf16);
     if (m->d_abf16) hipFree(m->d_abf16);
+    for (auto& kv : m->xbf16) if (kv.second) hipFree(kv.second);
     for (int i = 0; i < 3; ++i) if (m->d_tph[i]) hipFree(m->d_tph[i]);
     if (m->d_loss) hipFree(m->d_loss);
     if (m->h_loss) hipHostFree(m->h_loss);
@@ -1671,6 +1702,7 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "winograd_hires_pixels") return &m->wino_hires_pixels;
     if (key == "conv1_tiled") return &m->conv1_tiled;
     if (key == "conv1_wgrad_mfma") return &m->conv1_wgrad_mfma;
+    if (key == "bf16_copy_by_transform") return &m->bf16_copy_by_transform;
     return nullptr;
 }
 int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
@@ -1685,7 +1717,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
         }
         return fail(nullptr, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown op-context option '" + k + "' (model options need a model)");
     }
-    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma") {        // pick a kernel per launch: nothing cached depends on them
+    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform") {        // pick a kernel per launch: nothing cached depends on them
         *model_option(m, k) = value ? 1 : 0;
         return FCN8S_OK;
     }

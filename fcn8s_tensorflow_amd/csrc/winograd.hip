@@ -186,11 +186,15 @@ static inline dim3 tile_grid(int N, int th, int tw, int C4, int z = 1)
 }
 
 // ---- input: one thread = one m x m output tile x VEC channels; alpha x alpha patch (zero outside), V = B^T d B --------
-template <int M, int VEC, int R>
+// XB (VEC = 2, pad = 1, nsub = 1): also write the tile's own M x M pixels as bf16 (RNE) into the interior of a zero-bordered padded copy
+// xb [N][H + 2][W + 2][C] -- the A operand of the bf16 direct convolution of the same layer (gemm_bf16.hip), which then needs no
+// conversion pass of its own over the activations (FCN8S_PREC_BF16_FWD* training: this transform runs anyway, for the weight gradient)
+template <int M, int VEC, int R, bool XB = false>
 __global__ __launch_bounds__(256) void wino_input_kernel(const VF* __restrict__ x, VF* __restrict__ v, int N, int H, int W, int C4, int pad, int nsub,
-                                                         long long slab, unsigned* __restrict__ rbits_out)
+                                                         long long slab, unsigned* __restrict__ rbits_out, unsigned* __restrict__ xb = nullptr)
 {
     constexpr int A = WinoMat<M, R>::A;
+    static_assert(!XB || VEC == 2, "the bf16 copy is written as packed pairs");
     // rbits_out (3x3 layers, pad = 1): also record (x > 0) of the tile's own M x M pixels (patch rows / columns 1..M), in the layout
     // of wino_output_kernel's rbits_out -- for an input that a non-Winograd kernel produced (conv1_1), so that the data gradient
     // of this layer reads 1/32 of that tensor instead of all of it
@@ -222,6 +226,19 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const VF* __restrict__ 
                     const int bit = ((a - 1) * M + (b - 1)) * VEC + i;
                     if (d[a].d[i] > 0.f) rb[bit >> 5] |= 1u << (bit & 31);
                 }
+        }
+        if constexpr (XB) {
+            if (b >= 1 && b <= M && cok[b]) {
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                unsigned* xq = xb + (((long long)ti.n * (H + 2) + (y0 + 1)) * (W + 2) + (x0 + b + 1)) * C4 + ti.c;
+#pragma unroll
+                for (int a = 1; a <= M; ++a)
+                    if (rok[a]) {
+                        const f32x2_t f = {d[a].d[0], d[a].d[1]};
+                        xq[(long long)a * (W + 2) * C4] = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+                    }
+            }
         }
 #pragma unroll
         for (int a = 0; a < A; ++a) {
@@ -1042,6 +1059,14 @@ void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, 
     else if (tile == 4)               FCN8S_WIN(4, 2, 3);
     else                              FCN8S_WIN(2, 4, 3);
 #undef FCN8S_WIN
+}
+// F(6x6,3x3) input transform that also fills the interior of the padded bf16 copy xb [N][H + 2][W + 2][C] (see wino_input_kernel, XB)
+void launch_wino_input_xb(const float* x, float* v, unsigned short* xb, int N, int H, int W, int C, hipStream_t s, unsigned* rbits_out)
+{
+    const int th = (H + 5) / 6, tw = (W + 5) / 6;
+    g_last_kernel = "wino_input_kernel<6, 2, 3, true>";
+    hipLaunchKernelGGL((wino_input_kernel<6, 2, 3, true>), tile_grid(N, th, tw, C / 2, 1), dim3(256), 0, s,
+                       (const VecF<2>*)x, (VecF<2>*)v, N, H, W, C / 2, 1, 1, wino_slab((long long)N * th * tw, C) / 2, rbits_out, (unsigned*)xb);
 }
 void launch_wino_output(int tile, const float* m, const float* bias, const float* addend, const float* mask, float mask_scale,
                         int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,

@@ -653,6 +653,52 @@ def test_bf16_fwd_mode(mode):
     e.close(); e2.close()
 
 
+@pytest.mark.parametrize("mode", ["bf16_fwd", "bf16_fwd_x2"])
+def test_bf16_copy_written_by_the_input_transform_is_bit_identical(mode):
+    """bf16 forward modes, training: the padded bf16 copy of a layer's input that its direct bf16 convolution reads is written by the layer's
+    Winograd input transform (option bf16_copy_by_transform, default 1) instead of a conversion pass of its own.  Same conversion (RNE) of the
+    same values into the same zero-bordered layout: the loss, the logits and the bf16 layers' activations carry identical bits (the gradients
+    agree to the run-to-run summation order of the atomically reduced split GEMMs, measured in the same test),
+    the conversion kernel disappears from the training pass for the F(6x6,3x3) layers among conv3_1 .. conv5_3 (layers on smaller tiles, fc6
+    and fc7 keep it), and inference -- which has no transform to ride on -- still converts.  Sizes with partial F(6x6) edge tiles in both directions (256 = 42 * 6 + 4, 64 = 10 * 6 + 4, ...)
+    and a batch of two (the per-image border of the copy)."""
+    from fcn8s_tensorflow_amd.engine import Engine
+    P = orc.init_params(20, seed=19, decoder_std_scale=6.0, bias_std=0.05)
+    for n, h, w in ((1, 256, 256), (2, 256, 512)):
+        img, lab = batch(n, h, w, seed=51)
+        outs, counts = [], []
+        for by_transform in (1, 0):
+            e = Engine(20, precision=mode, options={"bf16_gemm256": 2, "bf16_copy_by_transform": by_transform})
+            assert e.get_option("bf16_copy_by_transform") == by_transform
+            e.set_params(P)
+            e.profile(2); e.profile_reset()
+            loss = e.forward_backward(img, orc.one_hot(lab, 20), keep_prob=1.0, l2_rate=1e-3)
+            prof = e.profile_results(); e.profile(0)
+            conv = sum(int(v["launches"]) for k, v in prof.items() if k.startswith("kernel:") and "f32_to_bf16_padded_kernel" in k)
+            riding = sum(int(v["launches"]) for k, v in prof.items() if k.startswith("kernel:") and "wino_input_kernel<6, 2, 3, true>" in k)
+            counts.append((conv, riding))
+            g = e.get_grads()
+            acts = {k: e.activation(k, s) for k, s in (("conv3_2", (n, h // 4, w // 4, 256)), ("conv4_3", (n, h // 8, w // 8, 512)), ("logits", (n, h, w, 20)))}
+            # a second step on the same engine: the borders of the kept copies are still zero after the interiors were rewritten
+            loss_b = e.forward_backward(img, orc.one_hot(lab, 20), keep_prob=1.0, l2_rate=1e-3)
+            assert loss_b == loss
+            g_again = e.get_grads()                              # the same pass repeated: what the atomically reduced (split) GEMMs of the backward chain differ by, run to run
+            pred = e.predict(img, argmax=False)                  # inference on the same workspace: converts for itself
+            outs.append((loss, g, acts, pred, g_again))
+            e.close()
+        # every F(6x6) layer of blocks 3 - 5 lost its conversion pass to the transform (layers on smaller tiles, fc6 and fc7 keep theirs)
+        assert counts[1][1] == 0 and counts[0][1] >= 3 and counts[0][0] + counts[0][1] == counts[1][0], counts
+        assert outs[0][0] == outs[1][0]
+        for k in outs[0][1]:
+            # (small launches split their reductions over blocks and add the parts with atomics: the gradients of one engine differ between two
+            #  identical passes by that summation order, and the two forms may differ by no more than that)
+            noise = max(rel(outs[0][1][k], outs[0][4][k]), rel(outs[1][1][k], outs[1][4][k]))
+            assert rel(outs[0][1][k], outs[1][1][k]) <= max(2e-6, 4 * noise), (k, noise)
+        for k in outs[0][2]:
+            np.testing.assert_array_equal(outs[0][2][k], outs[1][2][k], err_msg=k)
+        np.testing.assert_array_equal(outs[0][3], outs[1][3])
+
+
 def test_conv1_1_tile_kernel_is_bit_identical_to_the_gather_kernel():
     """conv1_1 forward: the spatial-tile kernel (halo tile in LDS, MFMA fragments read straight from it) performs the same products in the
     same order as the LDS-DMA gather kernel -- identical bits -- on image sizes with partial edge handling in every direction."""
