@@ -637,6 +637,7 @@ static void corun_probe()
 #define GLDS(BM, BN, WM, WN, BK, S, OCC) [&](dim3 g, const Args& a) { hipLaunchKernelGGL((gemm_glds<BM, BN, WM, WN, BK, S, OCC>), g, dim3(WM * WN * 64), 0, 0, a); }
 #define REG(BM, BN, WM, WN, OCC) [&](dim3 g, const Args& a) { hipLaunchKernelGGL((gemm_reg<BM, BN, WM, WN, OCC>), g, dim3(WM * WN * 64), 0, 0, a); }
 
+#define BOTH(tag, L, BM, BN) do { run(tag, L, BM, BN, chk, true); run(tag, L, BM, BN, chk2, true); } while (0)
 int main(int argc, char** argv)
 {
     const Shape shapes[] = {{"conv3", 15136, 256, 256, 64}, {"conv4", 3872, 512, 512, 64}, {"conv2_2", 58996, 128, 128, 64}, {"fc6", 512, 2048, 4096, 49}};
@@ -667,6 +668,34 @@ int main(int argc, char** argv)
                 run("bf16 x3 PIPELINED occ2", GXP(2), 128, 128, s, false);
                 run("bf16 x3 PIPELINED occ3", GXP(3), 128, 128, s, false);
                 run("bf16 x1 s3 occ3", GX(1, 3), 128, 128, s, false);
+            }
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "wave1") {
+        // What do the barriers cost?  One wave per block (64 x 64 tile = the 2 x 2 MFMA tiles a wave of the 128 x 128 kernel owns): no wave ever
+        // waits for another one, every wave runs its own LDS-DMA pipeline -- for twice the L2 -> LDS traffic per flop.  And the two-wave forms between.
+        const Shape more[] = {{"conv3", 15136, 256, 256, 64}, {"conv4", 3872, 512, 512, 64}, {"conv5", 1056, 512, 512, 64}, {"conv2_2", 58996, 128, 128, 64}, {"fc6", 512, 2048, 4096, 49}};
+        const Shape chk{"check", 300, 128, 256, 3}, chk2{"check2", 300, 32, 512, 2};
+        BOTH("glds 64x64 1 wave s3", GLDS(64, 64, 1, 1, 16, 3, 1), 64, 64);
+        BOTH("glds 64x64 1 wave s2", GLDS(64, 64, 1, 1, 16, 2, 2), 64, 64);
+        BOTH("glds 64x64 1 wave s4", GLDS(64, 64, 1, 1, 16, 4, 1), 64, 64);
+        BOTH("glds 64x64 1 wave bk32 s2", GLDS(64, 64, 1, 1, 32, 2, 1), 64, 64);
+        BOTH("glds 128x64 2 waves s3", GLDS(128, 64, 2, 1, 16, 3, 2), 128, 64);
+        BOTH("glds 64x128 2 waves s3", GLDS(64, 128, 1, 2, 16, 3, 2), 64, 128);
+        for (int rep = 0; rep < 2; ++rep)
+            for (auto& s : more) {
+                printf("%s: T=%lld K=%d N=%d P=%d\n", s.name, s.T, s.K, s.N, s.P);
+                run("glds 128x128 bk16 s3 occ3 (today)", GLDS(128, 128, 2, 2, 16, 3, 3), 128, 128, s, false);
+                run("glds 64x64 1 wave s3 (6 blocks/CU)", GLDS(64, 64, 1, 1, 16, 3, 1), 64, 64, s, false);
+                run("glds 64x64 1 wave s2 (10 blocks/CU)", GLDS(64, 64, 1, 1, 16, 2, 2), 64, 64, s, false);
+                run("glds 64x64 1 wave s4 (5 blocks/CU)", GLDS(64, 64, 1, 1, 16, 4, 1), 64, 64, s, false);
+                run("glds 64x64 1 wave bk32 s2 (5 blocks/CU)", GLDS(64, 64, 1, 1, 32, 2, 1), 64, 64, s, false);
+                run("glds 128x64 2 waves s3 (4 blocks/CU)", GLDS(128, 64, 2, 1, 16, 3, 2), 128, 64, s, false);
+                run("glds 64x128 2 waves s3 (4 blocks/CU)", GLDS(64, 128, 1, 2, 16, 3, 2), 64, 128, s, false);
+                g_noload = 1;
+                run("NOLOAD 128x128 (today's loop without its LDS-DMA)", GLDS(128, 128, 2, 2, 16, 3, 3), 128, 128, s, false);
+                run("NOLOAD 64x64 1 wave s3", GLDS(64, 64, 1, 1, 16, 3, 1), 64, 64, s, false);
+                g_noload = 0;
             }
         return 0;
     }
@@ -719,7 +748,6 @@ int main(int argc, char** argv)
     }
     const Shape chk{"check", 300, 128, 256, 3};          // T not a multiple of any tile, K = 8 / 4 K-tiles
     const Shape chk2{"check2", 300, 32, 512, 2};         // fewer K-tiles than stages
-#define BOTH(tag, L, BM, BN) do { run(tag, L, BM, BN, chk, true); run(tag, L, BM, BN, chk2, true); } while (0)
     BOTH("reg 128x128 occ4", REG(128, 128, 2, 2, 4), 128, 128);
     BOTH("glds 128x128 bk16 s2 occ4", GLDS(128, 128, 2, 2, 16, 2, 4), 128, 128);
     BOTH("glds 128x128 bk16 s3 occ3", GLDS(128, 128, 2, 2, 16, 3, 3), 128, 128);
