@@ -87,9 +87,22 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
     const float* a_base = A + m0 * p.K;              // block-uniform, advanced by BK floats per K-tile
     const float* b_base = B + (BI ? n0 * 4 : n0);    // ... by BK rows
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    // noload == 2 (diagnosis): the same loads, same addresses, same vmcnt accounting -- but into registers that nobody reads instead of the
+    // LDS: what the memory side of the loop costs (fabric, L2, power) without its LDS writes.  The landing registers stay live to the end.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 sink[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) sink[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto issue = [&](int kt, int stage) {
         const float* ga = a_base + (long long)kt * BK;
         const float* gb = b_base + (long long)kt * BK * p.N;       // (same advance in both layouts: BK rows = BK / 4 k-groups of 4 N floats)
+        if (p.noload == 2 && kt >= S - 1) {
+#pragma unroll
+            for (int i = 0; i < A_PW; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(sink[i]) : "v"(a_voff[i]), "s"(ga) : "memory");
+#pragma unroll
+            for (int i = 0; i < B_PW; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(sink[A_PW + i]) : "v"(b_voff[i]), "s"(gb) : "memory");
+            return;
+        }
         const unsigned la = lds0 + (unsigned)(stage * STAGE + wave * A_PW * 256) * 4u;
         const unsigned lb = lds0 + (unsigned)(stage * STAGE + BM * BK + wave * B_PW * 256) * 4u;
 #pragma unroll
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
         auto head = [&](int kt) {               // wait for tile kt, refill the stage of tile kt - 1
             if (kt + S - 2 < nkt) wait_vm<(S - 2) * L>(); else wait_vm<0>();
             __builtin_amdgcn_s_barrier();
-            if (kt + S - 1 < nkt && !p.noload) issue(kt + S - 1, pre);
+            if (kt + S - 1 < nkt && p.noload != 1) issue(kt + S - 1, pre);
         };
         auto adv = [&]() { stage = stage + 1 == S ? 0 : stage + 1; pre = pre + 1 == S ? 0 : pre + 1; };
         head(0); load_split(stage, f0); adv();
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + S - 2 < nkt) wait_vm<(S - 2) * L>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt + S - 1 < nkt && !p.noload) issue(kt + S - 1, pre);
+        if (kt + S - 1 < nkt && p.noload != 1) issue(kt + S - 1, pre);
         compute(stage);
         stage = stage + 1 == S ? 0 : stage + 1;
         pre = pre + 1 == S ? 0 : pre + 1;
@@ -293,6 +306,13 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
             }
             __builtin_amdgcn_wave_barrier();
         }
+    if (p.noload == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < L; ++i) t += sink[i][0] + sink[i][1] + sink[i][2] + sink[i][3];
+        if (t == 123.456f) C[0] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -695,7 +715,10 @@ int main(int argc, char** argv)
                 g_noload = 1;
                 run("NOLOAD 128x128 (today's loop without its LDS-DMA)", GLDS(128, 128, 2, 2, 16, 3, 3), 128, 128, s, false);
                 run("NOLOAD 64x64 1 wave s3", GLDS(64, 64, 1, 1, 16, 3, 1), 64, 64, s, false);
+                g_noload = 2;
+                run("128x128, its loads into registers nobody reads (no LDS writes)", GLDS(128, 128, 2, 2, 16, 3, 3), 128, 128, s, false);
                 g_noload = 0;
+                run("glds 128x128 bk16 s3 occ3 (today) again", GLDS(128, 128, 2, 2, 16, 3, 3), 128, 128, s, false);
             }
         return 0;
     }
