@@ -56,3 +56,19 @@ def test_launch_gap_report_on_a_synthetic_trace(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "launch_gap_report.py"), str(path)], check=True, capture_output=True, text=True).stdout
     assert "wall span per pass           314.0 us" in out and "a kernel is running          300.0 us" in out, out
     assert "idle between its kernels       4.0 us" in out and "3 launches, 2.00 us per gap" in out and "idle before the next pass     10.0 us" in out, out
+
+
+def test_roofline_table_tool_reads_the_committed_bench_line():
+    """tools/roofline_table.py: every kernel group of the committed round-4 bench line against the roof that bounds it; the table committed
+    under profiles/ is what the tool prints for that line."""
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_table.py"), os.path.join("profiles", "r04_bench_train_bs16.json")],
+                         capture_output=True, text=True, check=True, cwd=ROOT).stdout
+    assert out == open(os.path.join(ROOT, "profiles", "r04_roofline_table.md")).read()
+    rows = [l.split("|") for l in out.splitlines() if l.startswith("| ") and "kernel group" not in l]
+    assert len(rows) >= 15
+    by = {r[1].strip(): r for r in rows}
+    assert by["wino_transform"][4].strip() == "HBM" and 0.4 < float(by["wino_transform"][7]) < 1.0
+    assert by["wino_gemm_fc6_fwd"][4].strip() == "f32 MFMA" and 0.5 < float(by["wino_gemm_fc6_fwd"][7]) <= 1.0
+    shares = sum(float(r[3].replace("%", "")) for r in rows)
+    assert 99.0 < shares < 101.0

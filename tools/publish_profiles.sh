@@ -23,4 +23,6 @@ for f in bench_c5_2048x1024_bs4_bf16_fc bench_c5_2048x1024_bs4_fp32 bench_e2e_tr
 done
 [ -f $SRC/layer_bench.txt ] && cp $SRC/layer_bench.txt $DST/${R}_layer_bench.txt
 [ -f $SRC/layer_bench_infer_bs1.txt ] && cp $SRC/layer_bench_infer_bs1.txt $DST/${R}_layer_bench_infer_bs1.txt
+python tools/roofline_table.py $DST/${R}_bench_train_bs16.json > $DST/${R}_roofline_table.md
+[ -f $DST/${R}_bench_c5_2048x1024_bs4_bf16_fwd.json ] && python tools/roofline_table.py $DST/${R}_bench_c5_2048x1024_bs4_bf16_fwd.json > $DST/${R}_roofline_table_c5_bf16_fwd.md
 echo "published $TAG as $R"
