@@ -1678,6 +1678,8 @@ int fcn8s_set_precision(fcn8s_model* m, int precision)
         for (auto& kv : m->u_train) if (kv.second) hipFree(kv.second);
         m->u_train.clear();
         drop_u_cache(m);
+        for (auto& kv : m->xbf16) if (kv.second) hipFree(kv.second);      // (the padded bf16 activation copies of the bf16 forward modes)
+        m->xbf16.clear();
     }
     m->precision = precision;
     return FCN8S_OK;

@@ -29,7 +29,7 @@ done
 # BASELINE config 5's per-GPU shape and arithmetic (2048x1024, 4 images, bf16 fc6/fc7), config 2, and the end-to-end run
 python bench.py --steps 10 --warmup 3 --height 1024 --width 2048 --batch 4 --precision bf16_fc --no-cpu-baseline > $OUT/bench_c5_2048x1024_bs4_bf16_fc.json 2>> $OUT/bench.err
 python bench.py --steps 10 --warmup 3 --height 1024 --width 2048 --batch 4 --no-cpu-baseline > $OUT/bench_c5_2048x1024_bs4_fp32.json 2>> $OUT/bench.err
-python bench.py --mode e2e --steps 10 --warmup 3 --workers 32 > $OUT/bench_e2e_train_bs16.json 2>> $OUT/bench.err
+python bench.py --mode e2e --steps 50 --warmup 5 --workers 32 > $OUT/bench_e2e_train_bs16.json 2>> $OUT/bench.err
 python bench.py --gpus 2 --backend gloo --device 0 --steps 5 --warmup 2 --batch 8 --no-cpu-baseline > $OUT/bench_2ranks_one_gpu_gloo.json 2>> $OUT/bench.err
 python tools/layer_bench.py > $OUT/layer_bench.txt 2>> $OUT/bench.err
 python tools/layer_bench.py --infer --batch 1 --steps 10 > $OUT/layer_bench_infer_bs1.txt 2>> $OUT/bench.err
