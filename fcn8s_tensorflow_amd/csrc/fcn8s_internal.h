@@ -174,6 +174,7 @@ int wino_alpha(int tile, int KS);   // tile + r - 1; the number of Winograd posi
 long long wino_slab(long long T, int C);   // floats between the slabs of consecutive Winograd positions of a [P][T][C] tensor (T*C + skew)
 void launch_wino_filter(int tile, const float* w, float* u, int Cin, int Cout, int KS, hipStream_t s, int transpose_out = 0);   // w[KS*KS][Cin][Cout] -> u[P][nsub*Cin][Cout]  (transpose_out: u[P][Cout][Cin], KS = 3 only)
 void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, int C, int KS, hipStream_t s, unsigned* rbits_out = nullptr);   // x[N,H,W,C] -> v[P][T][nsub*C]
+void launch_wino_input_conv1(const float* x0, const float* w4, const float* bias, float* v, int N, int H, int W, hipStream_t s, unsigned* rbits_out = nullptr);   // conv1_1 + conv1_2's F(6x6,3x3) input transform
 void launch_wino_input_xb(const float* x, float* v, unsigned short* xb, int N, int H, int W, int C, hipStream_t s, unsigned* rbits_out = nullptr);   // F(6x6,3x3), + padded bf16 copy of x
 // F(4x4,3x3) only: V = B^T dy B (input transform of the data-gradient conv) AND dM = A dy A^T (weight-gradient transform) from
 // one read of dy; returns false if the shape is not covered.

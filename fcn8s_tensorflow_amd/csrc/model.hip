@@ -92,6 +92,7 @@ struct fcn8s_model {
     std::string fwd_v_layer;                                              // forward: layer whose V the previous layer's fused output transform has already written
     std::set<std::string> y_unwritten;                                    // layers whose activation tensor was not materialised by the last forward pass
     int conv1_tiled = 1, conv1_wgrad_mfma = 1;                            // options: conv1_1 forward on the spatial-tile kernel / its weight gradient on the matrix core
+    int conv1_in_transform = 1;                                           // option: conv1_1 is evaluated inside conv1_2's input transform (its activation tensor is never written)
     unsigned short* d_wbf16 = nullptr; size_t wbf16_elems = 0;            // bf16 copy of one layer's kernel at a time (K-tile-major or transposed)
     std::map<std::string, unsigned short*> wbf16_cache;                   // ... per layer, valid while frozen
     int bf16_gemm256 = 1;                                                 // bf16_fc mode: 256 x 256 LDS-DMA kernel -- 0 never, 1 when it fills the chip, 2 whenever shapes allow
@@ -1136,7 +1137,24 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 if (!train || it != m->acts.end()) { e.next_v = it != m->acts.end() ? it->second.p : m->d_wino_v; e.next_layer = nxt; }
             }
             bool done = false;
-            if (first && m->widths[0] == 64) {            // conv1_1: write-bound gather kernel (igemm.hip: conv1_glds_kernel)
+            if (first && m->conv1_in_transform && m->widths[0] == 64 && kConvsPerBlock[0] == 2 && m->widths[0] >= m->wino_min_cin && m->wino_min_cin > 0 &&
+                m->d_wino_v && wino_tile_for(m, h, w, 3) == 6) {
+                // conv1_1's only reader is conv1_2's F(6x6,3x3) input transform: that transform evaluates conv1_1 on its own patches, straight from the
+                // image (winograd.hip: wino_input_conv1_kernel), writes conv1_2's V -- into the buffer conv_same will look for it in -- and, in training,
+                // the ReLU record the backward pass masks with.  conv1_1's 134 MB per image are never written or read.
+                auto wv = m->acts.find("wv:conv1_2");
+                auto rb = m->acts.find("rb:conv1_1");
+                if (!train || (wv != m->acts.end() && rb != m->acts.end())) {
+                    float* vdst = wv != m->acts.end() ? wv->second.p : m->d_wino_v;
+                    const long long T = wino_tiles(6, N, h, w);
+                    ProfScope ps(m, "wino_transform", 0, 4.0 * (4.0 * N * h * w + 64.0 * T * 64.0) + (train ? 8.0 * N * h * w : 0.0), nm);
+                    launch_wino_input_conv1(x, m->d_w1pad, e.bias, vdst, N, h, w, s, train ? (unsigned*)rb->second.p : nullptr);
+                    if (train) m->rbits_ok.insert(nm);
+                    m->fwd_v_layer = "conv1_2"; m->y_unwritten.insert(nm);
+                    done = true;
+                }
+            }
+            if (!done && first && m->widths[0] == 64) {            // conv1_1: write-bound gather kernel (igemm.hip: conv1_glds_kernel)
                 ProfScope ps(m, "conv1_1_fwd", 2.0 * N * h * w * 27.0 * m->widths[0], 4.0 * N * h * w * (3.0 + m->widths[0]), nm);
                 done = launch_conv1_fwd(x, m->d_w1pad, e.bias, A(m, nm), m->d_w1pad + 12 * 4 * (size_t)m->widths[0], N, h, w, m->widths[0], m->conv1_tiled, s);
             }
@@ -1705,6 +1723,7 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "conv1_tiled") return &m->conv1_tiled;
     if (key == "conv1_wgrad_mfma") return &m->conv1_wgrad_mfma;
     if (key == "bf16_copy_by_transform") return &m->bf16_copy_by_transform;
+    if (key == "conv1_in_transform") return &m->conv1_in_transform;
     return nullptr;
 }
 int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
@@ -1719,7 +1738,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
         }
         return fail(nullptr, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown op-context option '" + k + "' (model options need a model)");
     }
-    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform") {        // pick a kernel per launch: nothing cached depends on them
+    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform") {        // pick a kernel per launch: nothing cached depends on them
         *model_option(m, k) = value ? 1 : 0;
         return FCN8S_OK;
     }
@@ -2260,8 +2279,9 @@ int fcn8s_get_activation(fcn8s_model* m, const char* name, float* host, size_t n
     }
     if (n != it->second.n) return fail(m, FCN8S_ERR_SHAPE, std::string("activation '") + name + "' has " + std::to_string(it->second.n) + " elements");
     if (m->y_unwritten.count(name))
-        return fail(m, FCN8S_ERR_STATE, std::string("activation '") + name + "' was not materialised by the last forward pass: its output transform wrote the next conv's "
-                                        "transformed input directly (option \"fuse_out_in\" = 0 keeps it)");
+        return fail(m, FCN8S_ERR_STATE, std::string("activation '") + name + "' was not materialised by the last forward pass: " +
+                                        (std::string(name) == "conv1_1" ? "conv1_2's input transform evaluated it on its own patches (option \"conv1_in_transform\" = 0 keeps it)"
+                                                                        : "its output transform wrote the next conv's transformed input directly (option \"fuse_out_in\" = 0 keeps it)"));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     HIPCHK(m, hipMemcpy(host, it->second.p, n * sizeof(float), hipMemcpyDeviceToHost));
     return FCN8S_OK;

@@ -264,6 +264,117 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const VF* __restrict__ 
         }
 }
 
+// ---- conv1_1 inside conv1_2's input transform (option "conv1_in_transform") ---------------------------------------------------------
+// conv1_1 (3x3, 3 -> 64 channels, bias, ReLU) costs 1.8 GFLOP per image but writes 134 MB that conv1_2's input transform reads right back
+// (with the 1.78x patch over-fetch of every input transform).  Here the transform computes the conv1_1 values of its 8 x 8 patch itself, from
+// the preprocessed 4-channel image: the block's 8 tiles share a 10 x 52 pixel window staged in LDS (8 KB), the 27 x 64 weights sit
+// beside it (7 KB), and a thread builds its two channels' patch column by column -- per column three times nine weight pairs, 30 broadcast reads of
+// a pixel (b, g, r, 0) and 432 multiply-adds -- then proceeds exactly like wino_input_kernel<6, 2, 3>: ReLU record of the tile's own 6 x 6 pixels, q = B^T d, V = q B.  conv1_1's
+// activation tensor is never written (nothing else reads it: its ReLU mask is the record, its weight gradient needs the image and dY only).
+// The multiply-adds run in a fixed order on the VALU, so the values differ from the MFMA kernel's conv1_1 by summation order (1e-7 relative).
+// (RB: write the ReLU record -- a template parameter, not a test of the pointer: with the run-time branch hipcc spilled 770 registers)
+template <bool RB>
+__global__ __launch_bounds__(256) void wino_input_conv1_kernel(const float4* __restrict__ x0, const float* __restrict__ w4, const float* __restrict__ bias,
+                                                               VecF<2>* __restrict__ v, int N, int H, int W, long long slab, unsigned* __restrict__ rbits_out)
+{
+    constexpr int M = 6, A = 8, R = 3, VEC = 2, C4 = 32, RW = (M * M * VEC + 31) / 32, LW = 8 * M + 4;
+    __shared__ float4 img[A + 2][LW];
+    __shared__ VecF<2> wl[3][9][32];              // [kx][ky * 3 + ci][channel pair]
+    const int th = (H + M - 1) / M, tw = (W + M - 1) / M;
+    const int tid = threadIdx.x, tl = tid >> 5, c = tid & 31;
+    const int n = blockIdx.y / th, ty = blockIdx.y - n * th, tx0 = blockIdx.x * 8, tx = tx0 + tl;
+    {
+        const int gy0 = M * ty - 2, gx0 = M * tx0 - 2;
+        for (int i = tid; i < (A + 2) * LW; i += 256) {
+            const int r = i / LW, cc = i - r * LW, gy = gy0 + r, gx = gx0 + cc;
+            img[r][cc] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? x0[((long long)n * H + gy) * W + gx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    for (int i = tid; i < 27 * 32; i += 256) {      // (27 x 2 weights per thread in registers on top of the 128 of the transform: 400 spilled)
+        const int cp = i & 31, e = i >> 5, kx = e / 9, kc = e - kx * 9, ky = kc / 3, ci = kc - ky * 3;
+        wl[kx][kc][cp] = *reinterpret_cast<const VecF<2>*>(w4 + ((ky * 3 + kx) * 4 + ci) * 64 + 2 * cp);
+    }
+    __syncthreads();
+    if (tx >= tw) return;
+    const VecF<2> bv = *reinterpret_cast<const VecF<2>*>(bias + 2 * c);
+    const int y0 = M * ty - 1, xx0 = M * tx - 1;
+    bool rok[A], cok[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) { rok[a] = (unsigned)(y0 + a) < (unsigned)H; cok[a] = (unsigned)(xx0 + a) < (unsigned)W; }
+    unsigned rb[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) rb[j] = 0u;
+    const long long t = ((long long)n * th + ty) * tw + tx;
+    VecF<2> q[A][A];
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+        VecF<2> acc[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) acc[a] = bv;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            // (the window column is made opaque per (b, kx): hipcc otherwise keeps the pixels two neighbouring patch columns share in registers --
+            //  and hoists the reads of whole columns -- for 431 spilled registers; the scheduling barrier bounds what is in flight to one window column)
+            int col = M * tl + b + kx, cw = c;
+            asm volatile("" : "+v"(col), "+v"(cw));
+            VecF<2> wt[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) wt[e] = wl[kx][e][cw];
+#pragma unroll
+            for (int r = 0; r < A + 2; ++r) {
+                const float4 p = img[r][col];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int a = r - ky;
+                    if (a >= 0 && a < A) {
+                        acc[a] = vfma<2>(p.x, wt[ky * 3 + 0], acc[a]);
+                        acc[a] = vfma<2>(p.y, wt[ky * 3 + 1], acc[a]);
+                        acc[a] = vfma<2>(p.z, wt[ky * 3 + 2], acc[a]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        VecF<2> d[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            const bool in = rok[a] && cok[b];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) d[a].d[i] = (in && acc[a].d[i] > 0.f) ? acc[a].d[i] : 0.f;
+        }
+        if (RB && b >= 1 && b <= M) {
+#pragma unroll
+            for (int a = 1; a <= M; ++a)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const int bit = ((a - 1) * M + (b - 1)) * VEC + i;
+                    if (d[a].d[i] > 0.f) rb[bit >> 5] |= 1u << (bit & 31);
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            VecF<2> s = vzero<2>();
+#pragma unroll
+            for (int k = 0; k < A; ++k) if (WinoMat<M, R>::bt(a, k) != 0.f) s = vfma<2>(WinoMat<M, R>::bt(a, k), d[k], s);
+            q[a][b] = s;
+        }
+    }
+    if (RB) {
+#pragma unroll
+        for (int j = 0; j < RW; ++j) rbits_out[(t * C4 + c) * RW + j] = rb[j];
+    }
+    VecF<2>* vp = v + t * C4 + c;
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int b = 0; b < A; ++b) {
+            VecF<2> s = vzero<2>();
+#pragma unroll
+            for (int k = 0; k < A; ++k) if (WinoMat<M, R>::bt(b, k) != 0.f) s = vfma<2>(WinoMat<M, R>::bt(b, k), q[a][k], s);
+            vp[(a * A + b) * slab] = s;
+        }
+}
+
 // ---- F(4x4,3x3) backward pair: the data-gradient conv needs V = B^T dy B, the weight gradient dM = A dy A^T of the same
 // tensor (dM's 4x4 tile is the inside of V's 6x6 patch): both from one read of dy -------------------------------------------
 // POOL: dy is not materialised -- it is the max-pool backward of dpool [N,H/2,W/2,C] routed by the argmax bytes the forward
@@ -1059,6 +1170,16 @@ void launch_wino_input(int tile, const float* x, float* v, int N, int H, int W, 
     else if (tile == 4)               FCN8S_WIN(4, 2, 3);
     else                              FCN8S_WIN(2, 4, 3);
 #undef FCN8S_WIN
+}
+// conv1_2's V straight from the preprocessed image x0 [N,H,W,4], conv1_1's padded kernel w4 [9][4][64] and bias (64 channels; see wino_input_conv1_kernel)
+void launch_wino_input_conv1(const float* x0, const float* w4, const float* bias, float* v, int N, int H, int W, hipStream_t s, unsigned* rbits_out)
+{
+    const int th = (H + 5) / 6, tw = (W + 5) / 6;
+    g_last_kernel = "wino_input_conv1_kernel";
+    const dim3 grid((unsigned)((tw + 7) / 8), (unsigned)(N * th));
+    const long long slab = wino_slab((long long)N * th * tw, 64) / 2;
+    if (rbits_out) hipLaunchKernelGGL(wino_input_conv1_kernel<true>, grid, dim3(256), 0, s, (const float4*)x0, w4, bias, (VecF<2>*)v, N, H, W, slab, rbits_out);
+    else           hipLaunchKernelGGL(wino_input_conv1_kernel<false>, grid, dim3(256), 0, s, (const float4*)x0, w4, bias, (VecF<2>*)v, N, H, W, slab, rbits_out);
 }
 // F(6x6,3x3) input transform that also fills the interior of the padded bf16 copy xb [N][H + 2][W + 2][C] (see wino_input_kernel, XB)
 void launch_wino_input_xb(const float* x, float* v, unsigned short* xb, int N, int H, int W, int C, hipStream_t s, unsigned* rbits_out)

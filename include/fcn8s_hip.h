@@ -251,10 +251,14 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *                              128 tiles (training batches), 2 whenever the shapes allow (rows and Cout multiples of 256)
  *     "conv1_tiled"       1    conv1_1 forward on the spatial-tile kernel (halo tile in LDS); 0 = the LDS-DMA gather kernel (bit-identical results)
  *     "conv1_wgrad_mfma"  1    conv1_1 weight gradient as a (27 -> 32) x 64 MFMA product over pixels; 0 = the VALU kernel
+ *     "conv1_in_transform" 1   conv1_1 (3x3, 3 -> 64, bias, ReLU) is evaluated inside conv1_2's F(6x6,3x3) input transform, on that transform's own 8 x 8
+ *                              patches and straight from the preprocessed image: conv1_1's activation tensor (134 MB per 1024x512 image) is never written
+ *                              or read, fcn8s_get_activation("conv1_1") returns FCN8S_ERR_STATE (fcn8s_get_relu_record still answers in training).  Same
+ *                              products in another summation order (VALU fma chain instead of the MFMA kernel's).  0 = conv1_1 as a kernel of its own
  *     "bf16_copy_by_transform" 1  FCN8S_PREC_BF16_FWD / _X2, training: the padded bf16 copy of a layer's input that its direct bf16 convolution reads is
  *                              written by the layer's Winograd input transform (which runs anyway, for the weight gradient) instead of a
  *                              conversion pass of its own over the activations (identical bits); 0 = the separate pass
- *                              (these three pick a kernel per launch and drop nothing)
+ *                              (these four pick a kernel per launch and drop nothing)
  *   op-context options (m == NULL): the arithmetic of the op-level entry points below, which have no model.  The value belongs to the
  *   CALLING THREAD (thread-local) and is read by that thread's later fcn8s_op_* calls only; no model ever reads it, so two models -- or a
  *   feeder thread beside a compute thread -- cannot change each other's kernels:
