@@ -466,7 +466,9 @@ __global__ __launch_bounds__(256) void wino_input_dout_kernel(const VF* __restri
 
 // ---- output: one thread = one tile x VEC channels; Y = A^T M A, then the conv epilogue --------------------------------
 // DROPOUT is a template parameter: the inlined Philox rounds (fc6 only) otherwise cost every launch their registers.
-template <int M, int VEC, bool DROPOUT, int R, bool POOL>
+// NT: the activation / pool stores are non-temporal -- chosen by the launcher for outputs too large to be of use to the next kernel from the caches
+// (training batches: transforms -0.2 ms per step; a single image's maps are better left temporal: 1.822 against 1.831 ms per prediction)
+template <int M, int VEC, bool DROPOUT, int R, bool POOL, bool NT = false>
 __global__ __launch_bounds__(256, 3) void wino_output_kernel(const VF* __restrict__ m, const VF* __restrict__ bias, const VF* __restrict__ addend,
                                                           const VF* __restrict__ mask, float mask_scale, int relu, VF* __restrict__ y,
                                                           int N, int H, int W, int C4, float keep, unsigned long long seed, unsigned int stream_id,
@@ -531,7 +533,8 @@ __global__ __launch_bounds__(256, 3) void wino_output_kernel(const VF* __restric
                 const float ik = 1.f / keep;
                 _Pragma("unroll") for (int i = 0; i < VEC; ++i) v.d[i] = philox_uniform(e + i, seed, stream_id) < keep ? v.d[i] * ik : 0.f;
             }
-            if (!POOL || y) y[off] = v;          // POOL launches may skip the full-resolution tensor (nobody reads it: see model.hip forward())
+            if (!POOL || y) { if constexpr (NT) vstore_nt<VEC>(y + off, v); else y[off] = v; }          // POOL launches may skip the full-resolution tensor (nobody reads it: see model.hip forward())
+                     // POOL launches may skip the full-resolution tensor (nobody reads it: see model.hip forward())
             if (rbits_out) {
                 _Pragma("unroll") for (int i = 0; i < VEC; ++i) {
                     const int bit = (oy * M + ox) * VEC + i;
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(256, 3) void wino_output_kernel(const VF* __restric
             for (int px = 0; px < PW; ++px)
             if ((M / 2) * ti.ty + py < Hp && (M / 2) * ti.tx + px < Wp) {                // H, W even: a window is inside or outside as a whole
                 const long long po = (((long long)ti.n * Hp + (M / 2) * ti.ty + py) * Wp + (M / 2) * ti.tx + px) * C4 + ti.c;
-                pool[po] = pmax[py][px];
+                if constexpr (NT) vstore_nt<VEC>(pool + po, pmax[py][px]); else pool[po] = pmax[py][px];
                 if (pidx) { _Pragma("unroll") for (int i = 0; i < VEC; ++i) pidx[po * VEC + i] = pmax[py][px].d[i] > 0.f ? parg[py][px][i] : (unsigned char)4; }
             }
     }
@@ -883,7 +886,7 @@ __global__ __launch_bounds__(256, 2) void wino_dgrad_output_kernel(const VF* __r
                 const VF mk = mask[off];
                 _Pragma("unroll") for (int k = 0; k < VEC; ++k) v.d[k] = mk.d[k] > 0.f ? v.d[k] * mask_scale : 0.f;
             }
-            y[off] = v;
+            vstore_nt<VEC>(y + off, v);          // (non-temporal, with wino_output_kernel's: transforms 13.04 -> 12.83 ms per step, profiles/r04_nt_stores_ab.txt)
         }
 }
 
@@ -1199,15 +1202,18 @@ void launch_wino_output(int tile, const float* m, const float* bias, const float
                         int relu, float* y, int N, int H, int W, int C, int dropout, float keep, unsigned long long seed,
                         unsigned int stream_id, hipStream_t s, float* pool, unsigned char* pidx, int KS, unsigned* rbits_out, const unsigned* rbits_in)
 {
-#define FCN8S_WOUT(M_, V_, D_, R_) if (pool) FCN8S_WOUT2(M_, V_, D_, R_, true); else FCN8S_WOUT2(M_, V_, D_, R_, false)
-#define FCN8S_WOUT2(M_, V_, D_, R_, P_) hipLaunchKernelGGL((wino_output_kernel<M_, V_, D_, R_, P_>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / V_), dim3(256), 0, s, \
+#define FCN8S_WOUT(M_, V_, D_, R_) if (pool) FCN8S_WOUT2(M_, V_, D_, R_, true, false); else FCN8S_WOUT2(M_, V_, D_, R_, false, false)
+#define FCN8S_WOUT_NT(M_, V_, D_, R_) if (pool) FCN8S_WOUT2(M_, V_, D_, R_, true, true); else FCN8S_WOUT2(M_, V_, D_, R_, false, true)
+#define FCN8S_WOUT2(M_, V_, D_, R_, P_, NT_) hipLaunchKernelGGL((wino_output_kernel<M_, V_, D_, R_, P_, NT_>), tile_grid(N, (H + M_ - 1) / M_, (W + M_ - 1) / M_, C / V_), dim3(256), 0, s, \
         (const VecF<V_>*)m, (const VecF<V_>*)bias, (const VecF<V_>*)addend, (const VecF<V_>*)mask, mask_scale, relu, (VecF<V_>*)y, N, H, W, C / V_, keep, seed, stream_id, \
         wino_slab((long long)N * ((H + M_ - 1) / M_) * ((W + M_ - 1) / M_), C) / V_, (VecF<V_>*)pool, pidx, rbits_out, rbits_in)
-    if (tile == 6)                    { if (dropout) FCN8S_WOUT(6, 2, true, 3); else FCN8S_WOUT(6, 2, false, 3); }
+    const bool big = (double)N * H * W * C * (pool ? 1.0 : 4.0) >= 64e6;          // bytes of what this launch writes (the pool, or the activation): beyond any cache's use to the next kernel
+    if (tile == 6)                    { if (dropout) FCN8S_WOUT(6, 2, true, 3); else if (big) FCN8S_WOUT_NT(6, 2, false, 3); else FCN8S_WOUT(6, 2, false, 3); }
     else if (tile == 4 && wino_r(KS) == 4) { if (dropout) FCN8S_WOUT(4, 2, true, 4); else FCN8S_WOUT(4, 2, false, 4); }
     else if (tile == 4)               { if (dropout) FCN8S_WOUT(4, 2, true, 3); else FCN8S_WOUT(4, 2, false, 3); }
     else                              { if (dropout) FCN8S_WOUT(2, 4, true, 3); else FCN8S_WOUT(2, 4, false, 3); }
 #undef FCN8S_WOUT
+#undef FCN8S_WOUT_NT
 #undef FCN8S_WOUT2
 }
 // m: M of conv L [64][T][C] (its GEMM's output), v: V of conv L+1 [64][T][C]; both F(6x6,3x3) on [N,H,W,C]; C % 64 == 0.  Returns false
