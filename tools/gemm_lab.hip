@@ -316,6 +316,157 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_glds(const Args p)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Cooperative split (./gemm_lab coop): the split-bf16 kernels convert every fragment value in the wave that uses it -- in a 2 x 2 wave tile
+// every A and every B value is split by TWO waves.  Here the block splits each K-tile ONCE: after the fp32 tile has landed (LDS-DMA as before),
+// thread t converts 8 A values (row t / 2, k half t % 2) and 8 B values (column t / 2, k half t % 2) into bf16 pieces and writes them into a
+// plane buffer ([row][16 k] bf16 = 32-byte rows, B transposed to [n][16 k]); after a second barrier the waves read ready-made bf16x8
+// fragments (one ds_read_b128 each) and issue nothing but MFMAs.  Half the conversions, two barriers per K-tile, +NS x 8 KB of LDS.
+template <int S, int OCC, int NS>
+__global__ __launch_bounds__(256, OCC) void gemm_coop(const Args p)
+{
+    constexpr int BM = 128, BN = 128, BK = 16, CH = 4, RPI = 16, A_PW = 2, B_PW = 2, L = 4;
+    constexpr int STAGE = BM * BK + BK * BN;             // floats per fp32 stage
+    constexpr int PLANE = 128 * 16;                      // bf16 elements per plane (one operand, one piece)
+    __shared__ __attribute__((aligned(16))) float smem[S * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned short planes[2 * NS * PLANE];     // A pieces, then B pieces
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int pz = blockIdx.z;
+    const float* __restrict__ A = p.A + pz * p.sa;
+    const float* __restrict__ B = p.B + pz * p.sb;
+    float* __restrict__ C = p.C + pz * p.sc;
+    const unsigned ntn = (unsigned)(p.N / BN);
+    const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const long long m0 = (long long)(lid / ntn) * BM;
+    const int n0 = (int)(lid % ntn) * BN;
+    unsigned a_voff[A_PW], b_voff[B_PW];
+#pragma unroll
+    for (int i = 0; i < A_PW; ++i) {
+        const int row = (wave * A_PW + i) * RPI + lane / CH, pc = lane % CH;
+        const int c = pc ^ ((row >> 2) & 3);
+        long long m = m0 + row; if (m >= p.T) m = p.T - 1;
+        a_voff[i] = (unsigned)((m - m0) * p.K + c * 4) * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PW; ++i) {
+        const int f = (wave * B_PW + i) * 64 + lane;
+        const int k = f / (BN / 4), j = (f % (BN / 4)) * 4;
+        b_voff[i] = (unsigned)(k * p.N + j) * 4u;
+    }
+    const float* a_base = A + m0 * p.K;
+    const float* b_base = B + n0;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    auto issue = [&](int kt, int stage) {
+        const float* ga = a_base + (long long)kt * BK;
+        const float* gb = b_base + (long long)kt * BK * p.N;
+        const unsigned la = lds0 + (unsigned)(stage * STAGE + wave * A_PW * 256) * 4u;
+        const unsigned lb = lds0 + (unsigned)(stage * STAGE + BM * BK + wave * B_PW * 256) * 4u;
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) glds16(ga, a_voff[i], la + i * 1024);
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) glds16(gb, b_voff[i], lb + i * 1024);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // this thread's share of the split: A row / B column `sr`, k half `sh`
+    const int sr = tid >> 1, sh = tid & 1;
+    const int a_sw = (sr >> 2) & 3;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto split_store = [&](const float (&x)[8], unsigned short* dst /* piece 0; piece k at + k * PLANE */) {
+        u32x4 w[NS];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x2 r = {x[2 * i], x[2 * i + 1]};
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+                w[k][i] = pk;
+                if (k + 1 < NS) { const f32x2 back = {__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)}; r = r - back; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) *reinterpret_cast<u32x4*>(dst + k * PLANE) = w[k];
+    };
+    auto split_tile = [&](int stage) {
+        const float* sa = smem + stage * STAGE;
+        const float* sb = sa + BM * BK;
+        float x[8];
+        const float4 u = *reinterpret_cast<const float4*>(sa + sr * BK + (((2 * sh) ^ a_sw) * 4));
+        const float4 v = *reinterpret_cast<const float4*>(sa + sr * BK + (((2 * sh + 1) ^ a_sw) * 4));
+        x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+        split_store(x, planes + sr * 16 + sh * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = sb[(sh * 8 + j) * BN + sr];
+        split_store(x, planes + NS * PLANE + sr * 16 + sh * 8);
+    };
+    auto mfmas = [&]() {
+        bf16x8 af[2][NS], bf[2][NS];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                af[t][k] = *reinterpret_cast<const bf16x8*>(planes + k * PLANE + (wm * 64 + t * 32 + (lane & 31)) * 16 + (lane >> 5) * 8);
+                bf[t][k] = *reinterpret_cast<const bf16x8*>(planes + (NS + k) * PLANE + (wn * 64 + t * 32 + (lane & 31)) * 16 + (lane >> 5) * 8);
+            }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                if (NS == 3) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][2], bf[tn][0], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bf[tn][2], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][1], bf[tn][1], acc[tm][tn], 0, 0, 0);
+                }
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][1], bf[tn][0], acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bf[tn][1], acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bf[tn][0], acc[tm][tn], 0, 0, 0);
+            }
+    };
+    const int nkt = p.K / BK;
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t)
+        if (t < nkt) issue(t, t);
+    int stage = 0, pre = S - 1;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + S - 2 < nkt) wait_vm<(S - 2) * L>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                  // tile kt has landed everywhere; everybody is done with the planes of tile kt - 1
+        if (kt + S - 1 < nkt) issue(kt + S - 1, pre);
+        split_tile(stage);
+        __syncthreads();                               // the planes of tile kt are complete
+        mfmas();
+        stage = stage + 1 == S ? 0 : stage + 1;
+        pre = pre + 1 == S ? 0 : pre + 1;
+    }
+    __builtin_amdgcn_s_barrier();
+    constexpr int LDT = 36;
+    float* patch = smem + wave * 32 * LDT;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + (lane & 31)] = acc[tm][tn][r];
+            __builtin_amdgcn_wave_barrier();
+            const long long mrow = m0 + wm * 64 + tm * 32;
+            float* yb = C + n0 + wn * 64 + tn * 32 + (lane & 7) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = j * 8 + (lane >> 3);
+                const float4 v = *reinterpret_cast<const float4*>(&patch[row * LDT + (lane & 7) * 4]);
+                if (mrow + row < p.T) *reinterpret_cast<float4*>(yb + (mrow + row) * p.N) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Persistent GLDS kernel: a block walks a contiguous range of output tiles; the (tile, K-tile) pairs form one flattened
 // sequence, so the LDS-DMA pipeline never drains at a tile boundary (the first K-tiles of the next tile are in flight while the
 // last ones of this tile are multiplied).  Epilogue = direct dword stores from the accumulators (two full 128-byte lines per
@@ -670,6 +821,26 @@ int main(int argc, char** argv)
     hipLaunchKernelGGL(fill, dim3(8192), dim3(256), 0, 0, dB, capB, 7u);
     hipDeviceSynchronize();
     if (argc > 1 && std::string(argv[1]) == "corun") { corun_probe(); return 0; }
+    if (argc > 1 && std::string(argv[1]) == "coop") {
+        const Shape more[] = {{"conv3", 15136, 256, 256, 64}, {"conv4", 3872, 512, 512, 64}, {"conv5", 1056, 512, 512, 64}, {"fc6", 512, 2048, 4096, 49}};
+        const Shape chk{"check", 300, 128, 256, 3}, chk2{"check2", 300, 32, 512, 2};
+#define GXS(NS, OCC) [&](dim3 g, const Args& a) { hipLaunchKernelGGL((gemm_glds<128, 128, 2, 2, 16, 3, OCC, false, NS>), g, dim3(256), 0, 0, a); }
+#define COOP(S_, OCC, NS) [&](dim3 g, const Args& a) { hipLaunchKernelGGL((gemm_coop<S_, OCC, NS>), g, dim3(256), 0, 0, a); }
+        BOTH("coop x3 s3", COOP(3, 2, 3), 128, 128);
+        BOTH("coop x2 s3", COOP(3, 2, 2), 128, 128);
+        BOTH("coop x2 s2", COOP(2, 3, 2), 128, 128);
+        for (int rep = 0; rep < 2; ++rep)
+            for (auto& s : more) {
+                printf("%s: T=%lld K=%d N=%d P=%d\n", s.name, s.T, s.K, s.N, s.P);
+                run("fp32 mfma", GLDS(128, 128, 2, 2, 16, 3, 3), 128, 128, s, false);
+                run("x3 in-wave split (lab form)", GXS(3, 3), 128, 128, s, false);
+                run("x3 cooperative split s3 occ2", COOP(3, 2, 3), 128, 128, s, false);
+                run("x3 cooperative split s2 occ2", COOP(2, 2, 3), 128, 128, s, false);
+                run("x3 cooperative split s2 occ3", COOP(2, 3, 3), 128, 128, s, false);
+                run("x1 (one piece: the MFMA floor)", GXS(1, 3), 128, 128, s, false);
+            }
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "x3") {
         const Shape more[] = {{"conv3", 15136, 256, 256, 64}, {"conv4", 3872, 512, 512, 64}, {"conv5", 1056, 512, 512, 64}, {"conv2_2", 58996, 128, 128, 64}, {"fc6", 512, 2048, 4096, 49}};
         const Shape chk{"check", 300, 128, 256, 3}, chk2{"check2", 300, 32, 512, 2};
