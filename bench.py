@@ -222,6 +222,24 @@ def cpu_baseline(h, w, seconds_budget=200.0, optimizer="sgd"):
             "total_s": round(time.perf_counter() - t_start, 1)}
 
 
+def metric_name(args):
+    """BASELINE.json's metric string for its own configuration; any other size / batch / arithmetic says so in the metric itself."""
+    W, H, N = args.width, args.height, args.batch
+    return (("training images/sec at %dx%d bs%d" % (W, H, N) if args.mode == "train" else
+             "inference images/sec at %dx%d" % (W, H) + ("" if N == 1 else " bs%d" % N)) + ("" if args.precision == "fp32" else " (%s arithmetic)" % args.precision))
+
+
+def error_line(args, what, world=None):
+    """The ONE JSON line of a run that did not finish: same identifying keys, `value` null and an `error` field saying why --
+    so that a dead or hung rank gives the driver a record instead of a hang or an empty stdout."""
+    world = world or int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    return {"metric": metric_name(args), "value": None, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_LABEL[args.precision],
+            "data": "synthetic", "config": {"workload": "FCN-8s %s step, %dx%d, %d images/GPU" % (args.mode, args.width, args.height, args.batch),
+                                            "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+            "error": what}
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: become the launcher of N ranks (one per GPU) and
     pass rank 0's JSON line through."""
@@ -237,10 +255,16 @@ def self_launch(args, argv):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     # only the JSON line goes to stdout; whatever else the ranks print there (gloo's connection banner, ...) is moved to stderr
     p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    seen = False
     for line in p.stdout:
-        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        is_json = line.lstrip().startswith("{")
+        seen = seen or is_json
+        (sys.stdout if is_json else sys.stderr).write(line)
         sys.stdout.flush()
-    return p.wait()
+    rc = p.wait()
+    if not seen:                                  # every rank died before rank 0 could speak (or rank 0 was killed outright): still ONE line
+        print(json.dumps(error_line(args, "no rank printed a result; launcher exit code %d" % rc, world=args.gpus)), flush=True)
+    return rc
 
 
 def make_png_dataset(root, n, h, w, num_classes=20, seed=0):
@@ -362,12 +386,55 @@ def main():
                     "reading the committed profile.  Default: on for the plain one-GPU training run with the CPU baseline (the driver's "
                     "bench line), when rocprofv3 is on PATH and this process is not itself being profiled; off otherwise")
     ap.add_argument("--no-live-traffic", action="store_true", help="never spawn the rocprofv3 passes; roofline.traffic comes from profiles/pmc_traffic.json")
+    ap.add_argument("--rank-timeout", type=float, default=600.0, help="seconds a collective (or the rendezvous) may wait for a peer before the process "
+                    "group gives up; a rank that dies or hangs then ends the run with an `error` line instead of blocking it forever")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
     if args.mode == "e2e":
         return e2e(args)
+    rank = int(os.environ.get("RANK", "0"))
+    state = {"done": False}
 
+    def on_term(signum, frame):                   # torchrun ends the surviving ranks with SIGTERM when one of them has failed
+        if rank == 0 and not state["done"]:
+            state["done"] = True
+            print(json.dumps(error_line(args, "terminated by the launcher (signal %d): a peer rank failed or timed out" % signum)), flush=True)
+        os._exit(1)
+
+    if "WORLD_SIZE" in os.environ:
+        import signal
+        import threading
+        signal.signal(signal.SIGTERM, on_term)
+        # the Python-level handler only runs when the main thread is back in the interpreter; a rank blocked inside a collective or a
+        # device synchronisation never is.  The C-level handler still writes the signal number to the wake-up pipe at once: a watcher
+        # thread reads it there and speaks for the main thread.
+        rfd, wfd = os.pipe()
+        os.set_blocking(wfd, False)
+        signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
+
+        def watch():
+            while True:
+                b = os.read(rfd, 1)
+                if b and b[0] == signal.SIGTERM:
+                    on_term(signal.SIGTERM, None)
+
+        threading.Thread(target=watch, daemon=True).start()
+    try:
+        run(args, state)
+    except BaseException as ex:                   # (SystemExit / KeyboardInterrupt included: the line is the record either way)
+        if rank == 0 and not state["done"]:
+            state["done"] = True
+            print(json.dumps(error_line(args, "rank 0: %r" % (ex,))), flush=True)
+        if isinstance(ex, Exception):
+            import traceback
+            traceback.print_exc()
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(1)                           # not sys.exit: a process group whose peer is gone can block in its destructor
+        raise
+
+
+def run(args, state):
     import torch
     import torch.distributed as dist
     from fcn8s_tensorflow_amd import _lib as L
@@ -382,10 +449,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(dev)
+        import datetime
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")       # a failed / timed-out collective tears the process down instead of hanging it
+        tmo = datetime.timedelta(seconds=args.rank_timeout)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
 
     trace = os.environ.get("FCN8S_BENCH_TRACE")
     def mark(msg):
@@ -430,6 +500,8 @@ def main():
     for i in range(args.warmup):
         step()
         mark("warmup step %d enqueued" % i)
+    if os.environ.get("FCN8S_BENCH_FAIL_RANK") == str(rank):      # test hook: this rank dies after its warm-up steps (tests/test_multigpu_gpu.py)
+        raise RuntimeError("FCN8S_BENCH_FAIL_RANK: rank %d fails on purpose" % rank)
     fence()
     mark("warmup done")
     # ---- the timed region: exactly K steps between two fences (barrier + device sync), no in-library event recording; the MAX over
@@ -628,8 +700,7 @@ def main():
                         "share_of_step_time": round(g["ms"] / (dt * 1e3), 3)}
         out = {
             # BASELINE.json's metric string for its own configuration; any other size / batch / arithmetic says so in the metric itself
-            "metric": ("training images/sec at %dx%d bs%d" % (W, H, N) if args.mode == "train" else
-                       "inference images/sec at %dx%d" % (W, H) + ("" if N == 1 else " bs%d" % N)) + ("" if args.precision == "fp32" else " (%s arithmetic)" % args.precision),
+            "metric": metric_name(args),
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_LABEL[args.precision], "data": "synthetic",
@@ -670,6 +741,7 @@ def main():
                 out["cpu_baseline"] = (cpu_baseline_full if args.cpu_baseline_full else cpu_baseline)(H, W, optimizer=args.optimizer)
             except Exception as ex:  # the oracle is only a reported baseline
                 out["cpu_baseline"] = {"error": repr(ex)}
+        state["done"] = True
         print(json.dumps(out), flush=True)
     eng.close()
     if under_launcher:

@@ -177,28 +177,39 @@ def _bf16_round(t):
     return t.detach().to(torch.bfloat16).to(t.dtype)
 
 
-def _relu_branch(z, name, branches):
+def _note_relu(stats, name, z, on):
+    """Alignment record for a parity test: how many units of `name` take another ReLU branch in `on` than this restatement would, and how
+    far from zero the largest of them sits (relative to the layer's largest pre-activation): (count, units, largest |z| / max |z|)."""
+    with torch.no_grad():
+        d = (z > 0) != (on > 0)
+        n = int(d.sum())
+        stats[name] = (n, z.numel(), float(z[d].abs().max() / z.abs().max().clamp_min(1e-30)) if n else 0.0)
+
+
+def _relu_branch(z, name, branches, stats=None):
     """ReLU -- or, when `branches` holds a 0/1 tensor for `name`, multiplication by that record of which units are on.
     Gradient parity is only defined where both sides take the same ReLU branches: a pre-activation that one side computes as
     -1e-7 of the layer's range and the other as +1e-7 (both inside fp32 round-off) switches one element of dZ on.  A parity test
     feeds the branches the device took (see `branches_from_activations`) and checks separately that they differ from this
     restatement's own only at units within round-off of zero."""
     if branches is not None and name in branches:
+        if stats is not None:
+            _note_relu(stats, name, z, branches[name])
         return z * branches[name]
     return F.relu(z)
 
 
-def _fc_conv(x, w, b, bf16, name=None, branches=None):
+def _fc_conv(x, w, b, bf16, name=None, branches=None, stats=None):
     """fc6 / fc7: SAME conv + bias + ReLU.  bf16: the forward VALUE is the contraction of the bf16-rounded operands
     (fp32 products and sums); the backward pass is the fp32 conv gradient taken with the unrounded operands -- the
     mode only changes the forward arithmetic (BASELINE config 5: "bf16 fwd / fp32 accum")."""
     z = conv2d_same_t(x, w, b)
     if bf16:
         z = z + (conv2d_same_t(_bf16_round(x), _bf16_round(w), b.detach()) - z).detach()
-    return _relu_branch(z, name, branches)
+    return _relu_branch(z, name, branches, stats)
 
 
-def _pool_routed(z, route):
+def _pool_routed(z, route, stats=None, name=None):
     """2x2/2 max-pool of relu(z) taken along recorded routes instead of this restatement's own argmax: route (N,C,h/2,w/2) int64 holds
     the window element (2*row + col) the gradient goes to, 4 = ReLU off.  max-pool's argmax is discontinuous where two window entries
     agree to round-off; a parity test feeds the routes the device took and checks separately (pool_routes) that they differ from this
@@ -206,7 +217,19 @@ def _pool_routed(z, route):
     n, c, h, w = z.shape
     win = z.reshape(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
     on = (route < 4).to(z.dtype)
-    return torch.gather(win, -1, route.clamp(max=3).unsqueeze(-1)).squeeze(-1) * on
+    taken = torch.gather(win, -1, route.clamp(max=3).unsqueeze(-1)).squeeze(-1)
+    if stats is not None:
+        # (count of windows routed differently from this restatement's own rule -- first maximum, off unless > 0 --, windows, and the largest
+        # distance from a tie among them: top - taken entry where both are on, |top| where only one side is, over the layer's largest |z|)
+        with torch.no_grad():
+            top, own = win.max(-1)
+            own = torch.where(top > 0, own, torch.full_like(own, 4))
+            d = own != route
+            n = int(d.sum())
+            both = d & (own < 4) & (route < 4)
+            gap = torch.where(both, top - taken, top.abs())[d]
+            stats[name] = (n, route.numel(), float(gap.max() / z.abs().max().clamp_min(1e-30)) if n else 0.0)
+    return taken * on
 
 
 def _conv_bf16_value(x, w, b):
@@ -216,7 +239,7 @@ def _conv_bf16_value(x, w, b):
     return z + (conv2d_same_t(_bf16_round(x), _bf16_round(w), b.detach()) - z).detach()
 
 
-def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False, branches=None, routes=None, bf16_convs=False):
+def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False, branches=None, routes=None, bf16_convs=False, stats=None):
     """Forward pass on torch tensors.  P: name -> torch tensor (TF layouts).
     images_t: NHWC RGB float.  masks: optional (mask6, mask7) NHWC tensors.
     bf16_fc: BASELINE config 5 -- both operands of the fc6 / fc7 contractions rounded to bfloat16, fp32 accumulate.
@@ -225,6 +248,8 @@ def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False,
     last conv + pool, "fc6", "fc7"): the ReLU branches to take instead of this restatement's own (see _relu_branch).
     routes: optional "pool1".."pool5" -> int64 (N,C,h/2,w/2) tensor of max-pool routes (see _pool_routed); takes the place of that
     block's pool branch record (route 4 = off).
+    stats: optional dict that receives, per name in `branches` / `routes`, how the imposed decisions differ from this restatement's own
+    (see _note_relu / _pool_routed): what a test needs to assert that they differ at fp32 coin flips only.
     Returns logits NCHW (and the activation dict when keep=True)."""
     acts = OrderedDict()
     x = _nchw(preprocess_t(images_t))
@@ -236,14 +261,16 @@ def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False,
             pooled_branch = i == nconv and (routed or (branches is not None and ("pool%d" % blk) in branches))
             z = (_conv_bf16_value if (bf16_convs and blk >= 3) else conv2d_same_t)(x, P[n + "/filter"], P[n + "/biases"])
             # (a block's last conv: max(relu(z)) = relu(max(z)), so its branch record lives on the pooled tensor)
-            x = z if pooled_branch else _relu_branch(z, n, branches)
+            x = z if pooled_branch else _relu_branch(z, n, branches, stats)
             if keep:
                 acts[n] = F.relu(z) if pooled_branch else x
         if routed:
-            x = _pool_routed(x, routes["pool%d" % blk])
+            x = _pool_routed(x, routes["pool%d" % blk], stats, "pool%d" % blk)
         else:
             x = maxpool2x2_t(x)
             if branches is not None and ("pool%d" % blk) in branches:
+                if stats is not None:
+                    _note_relu(stats, "pool%d" % blk, x, branches["pool%d" % blk])
                 x = x * branches["pool%d" % blk]
         pools[blk] = x
         if keep:
@@ -251,11 +278,11 @@ def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False,
     m6 = m7 = None
     if masks is not None:
         m6, m7 = (_nchw(m) for m in masks)
-    x = _fc_conv(x, P["fc6/weights"], P["fc6/biases"], bf16_fc, "fc6", branches)
+    x = _fc_conv(x, P["fc6/weights"], P["fc6/biases"], bf16_fc, "fc6", branches, stats)
     x = dropout_t(x, keep_prob, m6)
     if keep:
         acts["fc6"] = x
-    x = _fc_conv(x, P["fc7/weights"], P["fc7/biases"], bf16_fc, "fc7", branches)
+    x = _fc_conv(x, P["fc7/weights"], P["fc7/biases"], bf16_fc, "fc7", branches, stats)
     x = dropout_t(x, keep_prob, m7)
     if keep:
         acts["fc7"] = x
@@ -330,16 +357,17 @@ def pool_routes(acts):
 
 
 def loss_and_grads(params, images, labels_onehot, l2_rate=0.0, keep_prob=1.0, masks=None,
-                   dtype=torch.float32, bf16_fc=False, branches=None, routes=None, bf16_convs=False):
+                   dtype=torch.float32, bf16_fc=False, branches=None, routes=None, bf16_convs=False, stats=None):
     """total_loss and d(total_loss)/d(every variable) -- what
     AdamOptimizer.minimize differentiates (var_list=None, :257).
+    stats: optional dict filled with the alignment record of `branches` / `routes` (forward_t).
     branches: optional name -> NHWC bool/0-1 array of post-ReLU activations that are on (activation > 0), see forward_t.
     routes: optional "pool<b>" -> NHWC uint8 array of max-pool routes (the encoding of pool_routes), see forward_t."""
     P = _params_t(params, dtype, requires_grad=True)
     mt = None if masks is None else tuple(_t(m, dtype) for m in masks)
     bt = None if branches is None else {k: _nchw(_t(np.asarray(v) > 0, dtype)) for k, v in branches.items()}
     rt = None if routes is None else {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v).transpose(0, 3, 1, 2))).to(torch.int64) for k, v in routes.items()}
-    logits = forward_t(P, _t(images, dtype), keep_prob, mt, bf16_fc=bf16_fc, branches=bt, routes=rt, bf16_convs=bf16_convs)
+    logits = forward_t(P, _t(images, dtype), keep_prob, mt, bf16_fc=bf16_fc, branches=bt, routes=rt, bf16_convs=bf16_convs, stats=stats)
     loss = total_loss_t(P, logits, _t(labels_onehot, dtype), l2_rate)
     grads = torch.autograd.grad(loss, list(P.values()))
     return (float(loss.detach()),

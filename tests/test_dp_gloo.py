@@ -140,3 +140,24 @@ def test_replica_fingerprint_sample_moves_with_the_step():
     same = [bool((dp.replica_fingerprint(a, t, samples=100) == dp.replica_fingerprint(b, t, samples=100)).all()) for t in range(10)]
     assert same == [True] * 7 + [False] + [True] * 2
     assert not bool((dp.replica_fingerprint(a, 0, samples=1000) == dp.replica_fingerprint(b, 0, samples=1000)).all())   # samples = numel: everything
+
+
+def test_bench_prints_an_error_line_when_its_ranks_cannot_run():
+    """`bench.py --gpus 2` on a box without a GPU: no rank can create its engine ("no CPU fallback").  The driver must still get exactly ONE
+    JSON line on stdout -- value null, an `error` field -- and a non-zero exit code, not a hang or an empty stdout.
+    On a GPU box the same contract is tested with a rank that dies mid-run (tests/test_multigpu_gpu.py)."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present: covered by tests/test_multigpu_gpu.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in (["--gpus", "2", "--backend", "gloo", "--device", "0"], []):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "1", "--height", "32", "--width", "32",
+                            "--no-cpu-baseline", "--rank-timeout", "30"] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out["value"] is None and out["error"] and out["n_gpus"] == (2 if extra else 1) and out["metric"].startswith("training images/sec")

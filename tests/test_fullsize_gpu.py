@@ -250,6 +250,140 @@ def test_config3_training_step_1024x512_bs16_properties():
     e.close()
 
 
+def test_config3_bs16_1024x512_each_image_vs_oracle():
+    """Config 3 at its OWN batch size against the oracle (until now bs1 vs oracle + bs16 self-consistency).
+    One forward / backward pass of the 16-image batch at 1024x512 on the device; then
+      (i)  the logits of images 0, 7 and 15 of that batch against `orc.forward` of each image alone (1e-3 of the logit scale, argmax
+           identical above the 2e-3 margin, at most 16 differing pixels per image) -- image k > 0 sits in other tiles of every Winograd
+           image, in other row blocks of every GEMM and behind other pool routing bytes than image 0 does;
+      (ii) all 42 gradient tensors of the bs16 step against the MEAN of the sixteen per-image oracle gradients (the loss is a mean over
+           N.H.W, fcn8s_tensorflow.py:253; the L2 term is the same in every per-image loss), each per-image oracle pass differentiating
+           along the ReLU / pool decisions the device took for THAT image, and recording (oracle `stats=`) that those differ from its own
+           only at fp32 coin flips: ReLU units within 1e-5 of zero, window maxima within 2e-5 of each other (of the layer's largest).
+    Bound 1e-4 of each tensor's largest entry, as for bs1."""
+    import torch
+    from fcn8s_tensorflow_amd.engine import Engine
+    N, H, W, C = 16, 512, 1024, 20
+    P = orc.init_params(C, seed=4, decoder_std_scale=30.0, bias_std=0.05)
+    img, lab = orc.synthetic_batch(N, H, W)
+    e = Engine(C)
+    e.set_params(P)
+    loss = e.forward_backward(torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda(), keep_prob=1.0, l2_rate=1e-3)
+    g = {k: np.asarray(v, np.float64) for k, v in e.get_grads().items()}
+    logits = e.activation("logits", (N, H, W, C))
+    pred = np.argmax(logits, -1)                       # (argmax of the fp32 softmax is tested on its own; here the batch position is the subject)
+    br = e.relu_branches((N, H, W))
+    rt = e.pool_routes((N, H, W))
+    e.close()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    # (i) logits of three images of the batch
+    for k in (0, 7, 15):
+        ref = orc.forward(P, img[k:k + 1])[0]
+        scale = max(1.0, float(np.abs(ref).max()))
+        err = float(np.abs(logits[k] - ref).max())
+        srt = np.sort(ref, -1)
+        safe = (srt[..., -1] - srt[..., -2]) > 2e-3 * scale
+        ref_arg = np.argmax(ref, -1)
+        n_diff = int((pred[k] != ref_arg).sum())
+        print("config 3, image %d of 16: logit error %.2e of scale %.0f, %d of %d pixels differ (%d above the margin)"
+              % (k, err / scale, scale, n_diff, ref_arg.size, int((pred[k] != ref_arg)[safe].sum())))
+        assert err < 1e-3 * scale, (k, err / scale)
+        assert safe.mean() > 0.95 and (pred[k][safe] == ref_arg[safe]).all(), k
+        assert n_diff <= 16, (k, n_diff)
+    del logits, pred
+    # (ii) gradients: mean of the per-image oracle gradients along the device's decisions
+    acc, loss_sum, n_relu, n_route, worst_relu, worst_gap = None, 0.0, 0, 0, 0.0, 0.0
+    for k in range(N):
+        st = {}
+        lk, gk, _ = orc.loss_and_grads(P, img[k:k + 1], orc.one_hot(lab[k:k + 1], C).astype(np.float32), l2_rate=1e-3,
+                                       branches={n: v[k:k + 1] for n, v in br.items()}, routes={n: v[k:k + 1] for n, v in rt.items()}, stats=st)
+        for name, (cnt, total, dist) in st.items():
+            if name in rt:
+                n_route += cnt; worst_gap = max(worst_gap, dist)
+                assert dist <= 2e-5, (k, name, cnt, dist)
+            else:
+                n_relu += cnt; worst_relu = max(worst_relu, dist)
+                assert dist < 1e-5, (k, name, cnt, dist)
+        loss_sum += lk
+        if acc is None:
+            acc = {n: np.asarray(v, np.float64) for n, v in gk.items()}
+        else:
+            for n, v in gk.items():
+                acc[n] += v
+    del br, rt
+    assert abs(loss - loss_sum / N) < 1e-4 * max(1.0, abs(loss_sum / N)), (loss, loss_sum / N)
+    assert len(acc) == 42
+    errs = {n: float(np.abs(g[n] - acc[n] / N).max() / (np.abs(acc[n] / N).max() + 1e-30)) for n in acc}
+    ranked = sorted(errs.items(), key=lambda kv: -kv[1])
+    print("config 3 gradients at 16 x 1024x512 vs the mean of 16 per-image oracle gradients: %d ReLU units (largest %.1e) and %d pool routes (largest gap %.1e) "
+          "differ from the oracle's own, all coin flips; error / max per tensor, worst five:" % (n_relu, worst_relu, n_route, worst_gap),
+          ", ".join("%s %.2e" % kv for kv in ranked[:5]), "; median %.2e" % float(np.median(list(errs.values()))))
+    for n, err in ranked:
+        assert err < 1e-4, (n, err)
+
+
+@pytest.mark.parametrize("variant,options,k_logit,k_grad", [
+    # (what runs, library options, allowed logit-error ratio, allowed gradient-error ratio -- device vs float64 over fp32 oracle vs float64)
+    ("F(6x6) for all twelve 3x3 layers, F(4x4,4x4) for fc6 (the default)", {}, 2.0, 2.5),
+    ("direct convolution everywhere (summation order is the only difference from the fp32 oracle)", {"winograd_min_cin": 0, "winograd_fc6": 0}, 1.5, 1.5)])
+def test_device_is_as_close_to_float64_as_the_fp32_cpu_path(variant, options, k_logit, k_grad):
+    """The one parity statement that needs neither the alignment of ReLU / pool decisions nor trust in an fp32 oracle (VERDICT round 4
+    item 6): the oracle run in FLOAT64 at 1024x512 is the truth of the graph the reference defines (fcn8s_tensorflow.py:154-259), the
+    fp32 oracle stands where the reference's fp32 CPU path stood, and the device must be about as close to the truth as that path is --
+      logits (O(1-10) decoder):  max |device - f64|  <=  k_logit x max |fp32 oracle - f64|   and  <= 1e-3 absolute (north_star);
+      argmax (fcn8s_tensorflow.py:268-269): device == f64 wherever the f64 top-2 margin exceeds 2e-3, and the device differs from the f64
+              argmax on at most as many pixels as the fp32 oracle does, + 8;
+      gradients (x30 decoder, all 42 tensors, UNALIGNED -- every side takes its own ReLU / pool decisions):
+              worst tensor and median tensor of max |device - f64| / max |f64|  <=  k_grad x the same two figures of the fp32 oracle.
+    Measured (profiles/parity_r05.json): F(6x6) logits 1.0-1.3x, gradients 1.7x worst / 2.3x median (the unaligned distance is a few dozen
+    pool windows whose two maxima agree to round-off, DESIGN section 2 -- either side has its own such windows); direct convolution 1.0x."""
+    import torch
+    from fcn8s_tensorflow_amd.engine import Engine
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    H, W, C = 512, 1024, 20
+    img, lab = orc.synthetic_batch(1, H, W)
+    onehot = orc.one_hot(lab, C).astype(np.float32)
+    e = Engine(C, options=options)
+    # logits / argmax
+    P = orc.init_params(C, seed=1, decoder_std_scale=5.0, bias_std=0.05)
+    e.set_params(P)
+    pred = e.predict(img, argmax=True)
+    lg = e.activation("logits", (1, H, W, C)).astype(np.float64)
+    l64 = orc.forward(P, img, dtype=torch.float64)
+    l32 = orc.forward(P, img).astype(np.float64)
+    e_dev, e_o32 = float(np.abs(lg - l64).max()), float(np.abs(l32 - l64).max())
+    a64 = np.argmax(orc.softmax(l64), -1)
+    a32 = np.argmax(orc.softmax(l32.astype(np.float32)), -1)
+    srt = np.sort(l64, -1)
+    safe = (srt[..., -1] - srt[..., -2]) > 2e-3
+    m_dev, m_o32 = int((pred != a64).sum()), int((a32 != a64).sum())
+    print("[%s] logits vs float64: device %.3e, fp32 oracle %.3e (ratio %.2f), max |logit| %.1f; argmax differs from float64's on %d pixels (fp32 oracle: %d), %d above the margin"
+          % (variant, e_dev, e_o32, e_dev / e_o32, float(np.abs(l64).max()), m_dev, m_o32, int((pred != a64)[safe].sum())))
+    assert 0.5 < float(np.abs(l64).max()) < 50.0
+    assert e_dev < 1e-3 and e_dev <= k_logit * e_o32, (e_dev, e_o32)
+    assert safe.mean() > 0.95 and (pred[safe] == a64[safe]).all()
+    assert m_dev <= m_o32 + 8, (m_dev, m_o32)
+    # gradients, unaligned
+    Pg = orc.init_params(C, seed=4, decoder_std_scale=30.0, bias_std=0.05)
+    e.set_params(Pg)
+    loss = e.forward_backward(img, lab, keep_prob=1.0, l2_rate=1e-3)
+    g = e.get_grads()
+    e.close()
+    loss64, g64, _ = orc.loss_and_grads(Pg, img, onehot, l2_rate=1e-3, dtype=torch.float64)
+    loss32, g32, _ = orc.loss_and_grads(Pg, img, onehot, l2_rate=1e-3)
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-300))
+    d_dev = {k: rel(g[k], g64[k]) for k in g64}
+    d_o32 = {k: rel(g32[k], g64[k]) for k in g64}
+    w_dev, w_o32 = max(d_dev.values()), max(d_o32.values())
+    med_dev, med_o32 = float(np.median(list(d_dev.values()))), float(np.median(list(d_o32.values())))
+    print("[%s] gradients vs float64 (42 tensors, every side on its own ReLU / pool decisions): worst tensor device %.2e (%s), fp32 oracle %.2e (%s), ratio %.2f; "
+          "median device %.2e, fp32 oracle %.2e, ratio %.2f; loss device %.7f fp32 oracle %.7f float64 %.7f"
+          % (variant, w_dev, max(d_dev, key=d_dev.get), w_o32, max(d_o32, key=d_o32.get), w_dev / w_o32, med_dev, med_o32, med_dev / med_o32, loss, loss32, loss64))
+    assert abs(loss - loss64) <= max(2.0 * abs(loss32 - loss64), 1e-5 * abs(loss64)), (loss, loss32, loss64)
+    assert w_dev <= k_grad * w_o32, (w_dev, w_o32)
+    assert med_dev <= max(k_grad, 3.0) * med_o32, (med_dev, med_o32)
+
+
 def test_config3_fused_forward_transforms_at_bs16_equal_the_two_kernel_form():
     """The default engine fuses each inner conv's output transform with the next conv's input transform (`fuse_out_in` = 1).  At BASELINE's
     size (16 x 1024x512), against an engine with the fusion off: the kernel really
