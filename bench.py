@@ -445,6 +445,10 @@ def run(args, state):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev = local_rank if args.device is None else args.device
     under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ      # torchrun, even with one rank: RCCL is initialised and used
+    numa = None
+    if under_launcher and world > 1:              # each rank (and every thread / process it starts from here on) next to its GPU's memory controller:
+        from fcn8s_tensorflow_amd.dp import bind_to_gpu_numa      # before the process group and the engine exist, so that their threads inherit the mask
+        numa = bind_to_gpu_numa(dev, int(os.environ.get("LOCAL_WORLD_SIZE", world)) if args.device is None else 1)
     if under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -465,11 +469,7 @@ def run(args, state):
     mark("process group up; creating engine")
     options = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.option}
     eng = Engine(20, device_id=dev, seed=1234 + rank, precision=args.precision, options=options)
-    numa = None
-    if under_launcher and world > 1:              # each rank (and whatever it forks) next to its GPU's memory controller
-        from fcn8s_tensorflow_amd.dp import bind_to_gpu_numa
-        numa = bind_to_gpu_numa(dev, int(os.environ.get("LOCAL_WORLD_SIZE", world)) if args.device is None else 1)
-        mark("numa: %s" % numa)
+    mark("numa: %s" % numa)
     if under_launcher and args.comm == "native":
         eng.comm_init_native()                    # the 128-byte id travels through the torch group once; the collectives are the library's
     eng.dp_always = under_launcher                # a one-rank process group still runs the bucketed all-reduces (RCCL with one rank)

@@ -4,6 +4,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// gfx950 (MI355X, CDNA4) only: the kernels rely on 160 KB of LDS per workgroup (conv_bf16_256_kernel: five 32 KB stages; wino_out_in_kernel: 96 KB
+// static), on global_load_lds_dwordx4, ds_read_b64_tr_b16 and the gfx950 MFMA shapes.  A device pass for any other target stops here with a
+// readable message instead of "local memory limit exceeded" deep inside a template; fcn8s_create checks the same thing at run time.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libfcn8s_hip is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+#define FCN8S_LDS_BYTES_NEEDED (160u * 1024u)
+
 namespace fcn8s {
 
 // symbol of the MFMA kernel the last launch_* call used (for the per-kernel profile view)

@@ -7,8 +7,10 @@
 #include "../../include/fcn8s_hip.h"
 #include "fcn8s_internal.h"
 
-#include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -23,6 +25,18 @@
 #include <vector>
 
 using namespace fcn8s;
+
+// The few RCCL (= NCCL API) types behind the entry points this file resolves with dlsym: declared here, with the values of rccl.h (RCCL 2.x; the
+// NCCL API keeps them stable), so that building the library needs no RCCL development headers -- a single-GPU user never touches RCCL at all.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4, ncclInvalidUsage = 5,
+               ncclRemoteError = 6, ncclInProgress = 7 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclFloat = 7, ncclDouble = 8 } ncclDataType_t;
+}
+static_assert(sizeof(ncclUniqueId) == FCN8S_COMM_ID_BYTES, "fcn8s_comm_unique_id hands out ncclUniqueId bytes");
 
 namespace {
 
@@ -64,6 +78,13 @@ struct fcn8s_model {
     ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1;
     hipStream_t comm_stream = nullptr;
     hipEvent_t comm_done[FCN8S_MAX_BUCKETS] = {nullptr}; bool comm_pending[FCN8S_MAX_BUCKETS] = {false};
+    // ... and its watchdog (world > 1): a thread that polls ncclCommGetAsyncError and the age of every all-reduce still in flight; on an
+    // asynchronous error or after comm_timeout_ms it calls ncclCommAbort (RCCL's kernels then leave the streams they block) and records
+    // why -- every later fcn8s_comm_* / fcn8s_apply_update call returns FCN8S_ERR_RCCL with that text instead of waiting for a dead peer
+    std::mutex comm_mu;                                                   // guards comm (enqueue vs. abort), comm_enq_ns, comm_error
+    std::thread comm_watch; std::atomic<bool> comm_watch_stop{false}, comm_failed{false};
+    std::atomic<bool> comm_inflight[FCN8S_MAX_BUCKETS] = {}; int64_t comm_enq_ns[FCN8S_MAX_BUCKETS] = {0};
+    std::string comm_error; int64_t comm_timeout_ms = 600000;
     float *d_params = nullptr, *d_grads = nullptr, *d_m = nullptr, *d_v = nullptr, *d_wt = nullptr;
     bool own_params = false, own_grads = false;
     float *d_w1pad = nullptr, *d_tph[3] = {nullptr, nullptr, nullptr};
@@ -1487,8 +1508,9 @@ int do_backward_bucket(fcn8s_model* m, int bucket, int level_cap)
     else if (bucket == 2) backward_blocks(m, 5, 4);
     else { backward_blocks(m, 3, 1); join_deferred(m); }
     // whatever this call completed and no kernel-exact point has marked yet (the conv buckets; everything held back to the last call)
+    // (the fused step, level_cap 2, marks nothing before its last call -- and there everything that is still open: bucket 2 as well)
     for (int b = 0; b < kNumBuckets; ++b)
-        if (!m->bucket_final[b] && bucket_complete_after(m, b) == bucket && (level_cap == 1 || bucket == kNumBuckets - 1)) mark_bucket_final(m, b, m->stream);
+        if (!m->bucket_final[b] && ((level_cap == 1 && bucket_complete_after(m, b) == bucket) || bucket == kNumBuckets - 1)) mark_bucket_final(m, b, m->stream);
     m->next_bucket = bucket + 1;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(m, FCN8S_ERR_HIP, std::string("backward launch: ") + hipGetErrorString(e));
@@ -1567,6 +1589,15 @@ int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
     m->device = cfg->device_id; m->seed = cfg->seed;
     hipError_t e = hipSetDevice(m->device);
     if (e != hipSuccess) { delete m; return fail(nullptr, FCN8S_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e) + " (libfcn8s_hip needs an AMD GPU; there is no CPU fallback)"); }
+    {   // the kernels are written for gfx950: up to 160 KB of LDS per workgroup (conv_bf16_256_kernel), 96 KB static in wino_out_in_kernel.  Say so
+        // here, once, instead of failing every launch with a generic error on a part that has 64 KB.
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.sharedMemPerBlock < FCN8S_LDS_BYTES_NEEDED) {
+            const std::string msg = std::string("fcn8s_create: device ") + std::to_string(m->device) + " (" + prop.gcnArchName + ") offers " + std::to_string(prop.sharedMemPerBlock) +
+                                    " bytes of LDS per workgroup; this library is written for gfx950 (MI355X) and needs " + std::to_string(FCN8S_LDS_BYTES_NEEDED);
+            delete m; return fail(nullptr, FCN8S_ERR_HIP, msg);
+        }
+    }
     build_param_table(m->C, m->widths, m->fc6k, m->params, m->total, m->bucket_off, m->bucket_n);
     for (size_t i = 0; i < m->params.size(); ++i) m->index[m->params[i].name] = (int)i;
     const size_t bytes = m->total * sizeof(float);
@@ -1738,6 +1769,10 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
         }
         return fail(nullptr, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown op-context option '" + k + "' (model options need a model)");
     }
+    if (k == "comm_timeout_ms") {
+        if (value < 1) return fail(m, FCN8S_ERR_BAD_ARG, "comm_timeout_ms must be >= 1");
+        std::lock_guard<std::mutex> lk(m->comm_mu); m->comm_timeout_ms = value; return FCN8S_OK;
+    }
     if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform") {        // pick a kernel per launch: nothing cached depends on them
         *model_option(m, k) = value ? 1 : 0;
         return FCN8S_OK;
@@ -1780,6 +1815,7 @@ int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value)
         if (k == "op_split_pieces") { *value = t_op_split; return FCN8S_OK; }
         return FCN8S_ERR_NOT_FOUND;
     }
+    if (k == "comm_timeout_ms") { *value = m->comm_timeout_ms; return FCN8S_OK; }
     const int* slot = model_option(const_cast<fcn8s_model*>(m), k);
     if (!slot) return FCN8S_ERR_NOT_FOUND;
     *value = *slot;
@@ -1813,6 +1849,7 @@ static int xfer_named(fcn8s_model* m, float* base, const char* name, void* host,
     if (i < 0) return fail(m, FCN8S_ERR_NOT_FOUND, std::string("unknown variable '") + name + "'");
     const ParamInfo& p = m->params[i];
     if (n != p.numel) return fail(m, FCN8S_ERR_SHAPE, std::string("variable '") + name + "' has " + std::to_string(p.numel) + " elements, got " + std::to_string(n));
+    if (base == m->d_grads) { int rcw = fcn8s_comm_wait(m); if (rcw) return rcw; }      // an all-reduce still rewriting the bucket in place: read behind it
     HIPCHK(m, hipStreamSynchronize(m->stream));
     if (to_dev) HIPCHK(m, hipMemcpy(base + p.offset, host, n * sizeof(float), hipMemcpyHostToDevice));
     else HIPCHK(m, hipMemcpy(host, base + p.offset, n * sizeof(float), hipMemcpyDeviceToHost));
@@ -1902,6 +1939,8 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                                   // (optional: absent in very old builds)
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;            // (optional)
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GetVersion)(int*) = nullptr;
@@ -1922,6 +1961,8 @@ RcclApi* rccl()
         api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
         api.GetVersion = (decltype(api.GetVersion))sym("ncclGetVersion");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        api.CommAbort = (decltype(api.CommAbort))dlsym(api.h, "ncclCommAbort");
+        api.CommGetAsyncError = (decltype(api.CommGetAsyncError))dlsym(api.h, "ncclCommGetAsyncError");
     });
     return &api;
 }
@@ -1931,6 +1972,58 @@ int rccl_fail(fcn8s_model* m, const char* what, ncclResult_t r)
     return fail(m, FCN8S_ERR_RCCL, std::string(what) + ": " + ((a->GetErrorString && r != ncclSuccess) ? a->GetErrorString(r) : a->err.c_str()));
 }
 #define RCCLCHK(m, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return rccl_fail(m, #call, r_); } while (0)
+
+int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// The communicator has failed (asynchronous RCCL error, or a collective older than comm_timeout_ms: a dead or hung peer).  ncclCommAbort makes
+// RCCL's kernels leave the streams they sit on, so that neither the model's stream nor a host synchronisation waits for that peer forever.
+// Caller holds comm_mu.
+void comm_abort_locked(fcn8s_model* m, const std::string& why)
+{
+    if (m->comm_failed.load()) return;
+    m->comm_error = why;
+    m->comm_failed.store(true);
+    RcclApi* a = rccl();
+    if (m->comm) {
+        if (a->CommAbort) a->CommAbort(m->comm);          // (frees the communicator like ncclCommDestroy, without waiting for its peers)
+        m->comm = nullptr;
+    }
+    for (int b = 0; b < FCN8S_MAX_BUCKETS; ++b) m->comm_inflight[b].store(false);
+}
+
+void comm_watchdog(fcn8s_model* m)
+{
+    hipSetDevice(m->device);
+    RcclApi* a = rccl();
+    while (!m->comm_watch_stop.load()) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        std::lock_guard<std::mutex> lk(m->comm_mu);
+        if (!m->comm || m->comm_failed.load()) continue;
+        ncclResult_t async = ncclSuccess;
+        if (a->CommGetAsyncError && a->CommGetAsyncError(m->comm, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+            comm_abort_locked(m, std::string("asynchronous RCCL error: ") + (a->GetErrorString ? a->GetErrorString(async) : "?") + " (communicator aborted)");
+            continue;
+        }
+        const int64_t t = now_ns();
+        for (int b = 0; b < FCN8S_MAX_BUCKETS; ++b) {
+            if (!m->comm_inflight[b].load() || !m->comm_done[b]) continue;
+            if (hipEventQuery(m->comm_done[b]) == hipSuccess) { m->comm_inflight[b].store(false); continue; }
+            (void)hipGetLastError();                      // (hipErrorNotReady is not an error)
+            if ((t - m->comm_enq_ns[b]) / 1000000 > m->comm_timeout_ms) {
+                comm_abort_locked(m, "all-reduce of gradient bucket " + std::to_string(b) + " did not complete within " + std::to_string(m->comm_timeout_ms) +
+                                     " ms (option comm_timeout_ms): a peer rank is dead or hung; communicator aborted");
+                break;
+            }
+        }
+    }
+}
+
+// FCN8S_ERR_RCCL with the recorded reason once the communicator has failed
+int comm_failed_rc(fcn8s_model* m, const char* where)
+{
+    std::lock_guard<std::mutex> lk(m->comm_mu);
+    return fail(m, FCN8S_ERR_RCCL, std::string(where) + ": " + m->comm_error);
+}
 }  // namespace
 
 int fcn8s_device_pci_bus_id(int device_id, char* out, size_t len)
@@ -1960,30 +2053,54 @@ int fcn8s_comm_init(fcn8s_model* m, const void* unique_id, size_t nbytes, int ra
     if (!a->err.empty()) return rccl_fail(m, "fcn8s_comm_init", ncclSuccess);
     HIPCHK(m, hipSetDevice(m->device));
     ncclUniqueId id; memcpy(&id, unique_id, sizeof id);
+    if (m->comm_watch.joinable()) { m->comm_watch_stop.store(true); m->comm_watch.join(); }       // (left over from a communicator that failed)
     RCCLCHK(m, a->CommInitRank(&m->comm, world, id, rank));
     m->comm_rank = rank; m->comm_world = world;
+    m->comm_failed.store(false); m->comm_error.clear();
+    for (int b = 0; b < FCN8S_MAX_BUCKETS; ++b) m->comm_inflight[b].store(false);
     if (!m->comm_stream) HIPCHK(m, hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking));
+    if (world > 1) { m->comm_watch_stop.store(false); m->comm_watch = std::thread(comm_watchdog, m); }      // (a one-rank communicator has no peer to lose)
     return FCN8S_OK;
 }
 
 int fcn8s_comm_destroy(fcn8s_model* m)
 {
     if (!m) return FCN8S_ERR_BAD_ARG;
+    int rc = FCN8S_OK;
     if (m->comm) {
-        if (m->comm_stream) hipStreamSynchronize(m->comm_stream);
-        rccl()->CommDestroy(m->comm); m->comm = nullptr;
+        // drain the communicator's stream -- but never wait for a peer that is gone: poll, with the watchdog's rules (asynchronous error or
+        // comm_timeout_ms without progress -> ncclCommAbort).  A one-rank communicator, or RCCL without the two entry points, just synchronises.
+        RcclApi* a = rccl();
+        if (m->comm_stream) {
+            const int64_t t0 = now_ns();
+            while (hipStreamQuery(m->comm_stream) == hipErrorNotReady) {
+                if (m->comm_failed.load()) break;
+                if (m->comm_world > 1 && (now_ns() - t0) / 1000000 > m->comm_timeout_ms) {
+                    std::lock_guard<std::mutex> lk(m->comm_mu);
+                    comm_abort_locked(m, "fcn8s_comm_destroy: collectives still in flight after " + std::to_string(m->comm_timeout_ms) + " ms; communicator aborted");
+                    break;
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+            (void)hipGetLastError();
+        }
+        if (m->comm_watch.joinable()) { m->comm_watch_stop.store(true); m->comm_watch.join(); }
+        std::lock_guard<std::mutex> lk(m->comm_mu);
+        if (m->comm) { a->CommDestroy(m->comm); m->comm = nullptr; }
     }
-    for (int b = 0; b < FCN8S_MAX_BUCKETS; ++b) { if (m->comm_done[b]) { hipEventDestroy(m->comm_done[b]); m->comm_done[b] = nullptr; } m->comm_pending[b] = false; }
+    if (m->comm_watch.joinable()) { m->comm_watch_stop.store(true); m->comm_watch.join(); }
+    if (m->comm_failed.load()) { rc = fail(m, FCN8S_ERR_RCCL, "fcn8s_comm_destroy: " + m->comm_error); m->comm_failed.store(false); }
+    for (int b = 0; b < FCN8S_MAX_BUCKETS; ++b) { if (m->comm_done[b]) { hipEventDestroy(m->comm_done[b]); m->comm_done[b] = nullptr; } m->comm_pending[b] = false; m->comm_inflight[b].store(false); }
     if (m->comm_stream) { hipStreamDestroy(m->comm_stream); m->comm_stream = nullptr; }
     m->comm_rank = 0; m->comm_world = 1;
-    return FCN8S_OK;
+    return rc;
 }
 
 int fcn8s_comm_info(const fcn8s_model* m, int* rank, int* world, int* rccl_version)
 {
     if (!m) return FCN8S_ERR_BAD_ARG;
     if (rank) *rank = m->comm_rank;
-    if (world) *world = m->comm ? m->comm_world : 0;
+    if (world) *world = (m->comm || m->comm_failed.load()) ? m->comm_world : 0;
     if (rccl_version) { *rccl_version = 0; RcclApi* a = rccl(); if (a->GetVersion) a->GetVersion(rccl_version); }
     return FCN8S_OK;
 }
@@ -1991,21 +2108,26 @@ int fcn8s_comm_info(const fcn8s_model* m, int* rank, int* world, int* rccl_versi
 int fcn8s_allreduce_bucket(fcn8s_model* m, int bucket)
 {
     if (!m || bucket < 0 || bucket >= kNumBuckets) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_allreduce_bucket: bad bucket");
+    if (m->comm_failed.load()) return comm_failed_rc(m, "fcn8s_allreduce_bucket");
     if (!m->comm) return fail(m, FCN8S_ERR_STATE, "fcn8s_allreduce_bucket: no communicator (fcn8s_comm_init first)");
     if (!m->bucket_final[bucket]) return fail(m, FCN8S_ERR_STATE, "fcn8s_allreduce_bucket: the bucket's gradients are not queued yet (fcn8s_bucket_complete_after)");
     if (m->comm_pending[bucket]) return fail(m, FCN8S_ERR_STATE, "fcn8s_allreduce_bucket: this bucket is already being reduced");
     HIPCHK(m, hipStreamWaitEvent(m->comm_stream, m->bucket_ev[bucket], 0));
     float* g = m->d_grads + m->bucket_off[bucket];
-    RCCLCHK(m, rccl()->AllReduce(g, g, m->bucket_n[bucket], ncclFloat, ncclSum, m->comm, m->comm_stream));
+    std::lock_guard<std::mutex> lk(m->comm_mu);          // (the watchdog may abort the communicator: not in the middle of an enqueue)
+    if (!m->comm) return fail(m, FCN8S_ERR_RCCL, "fcn8s_allreduce_bucket: " + m->comm_error);
     if (!m->comm_done[bucket]) HIPCHK(m, hipEventCreateWithFlags(&m->comm_done[bucket], hipEventDisableTiming));
+    RCCLCHK(m, rccl()->AllReduce(g, g, m->bucket_n[bucket], ncclFloat, ncclSum, m->comm, m->comm_stream));
     HIPCHK(m, hipEventRecord(m->comm_done[bucket], m->comm_stream));
     m->comm_pending[bucket] = true;
+    m->comm_enq_ns[bucket] = now_ns(); m->comm_inflight[bucket].store(true);
     return FCN8S_OK;
 }
 
 int fcn8s_comm_wait(fcn8s_model* m)
 {
     if (!m) return FCN8S_ERR_BAD_ARG;
+    if (m->comm_failed.load()) return comm_failed_rc(m, "fcn8s_comm_wait");
     for (int b = 0; b < kNumBuckets; ++b)
         if (m->comm_pending[b]) { HIPCHK(m, hipStreamWaitEvent(m->stream, m->comm_done[b], 0)); m->comm_pending[b] = false; }
     return FCN8S_OK;
@@ -2014,6 +2136,7 @@ int fcn8s_comm_wait(fcn8s_model* m)
 int fcn8s_comm_broadcast_params(fcn8s_model* m, int root)
 {
     if (!m || root < 0) return FCN8S_ERR_BAD_ARG;
+    if (m->comm_failed.load()) return comm_failed_rc(m, "fcn8s_comm_broadcast_params");
     if (!m->comm) return fail(m, FCN8S_ERR_STATE, "fcn8s_comm_broadcast_params: no communicator (fcn8s_comm_init first)");
     if (root >= m->comm_world) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_comm_broadcast_params: root outside the communicator");
     if (m->frozen) fcn8s_freeze_params(m, 0);
@@ -2024,6 +2147,7 @@ int fcn8s_comm_broadcast_params(fcn8s_model* m, int root)
 int fcn8s_comm_allreduce_metrics(fcn8s_model* m)
 {
     if (!m) return FCN8S_ERR_BAD_ARG;
+    if (m->comm_failed.load()) return comm_failed_rc(m, "fcn8s_comm_allreduce_metrics");
     if (!m->comm) return fail(m, FCN8S_ERR_STATE, "fcn8s_comm_allreduce_metrics: no communicator (fcn8s_comm_init first)");
     // confusion counts (exact as doubles below 2^53), the sum of the per-batch losses and their count: one SUM all-reduce
     const size_t cc = (size_t)m->C * m->C, n = cc + 2;
@@ -2084,8 +2208,15 @@ int fcn8s_train_step(fcn8s_model* m, const void* images, int dtype, const uint8_
 {
     if (m && m->frozen) fcn8s_freeze_params(m, 0);      // parameters are about to change (or a training pass starts): leave the frozen state
     int rc = fcn8s_forward_loss(m, images, dtype, labels, N, H, W, keep_prob, l2_rate, where); if (rc) return rc;
-    for (int b = 0; b < kNumBuckets; ++b) { rc = do_backward_bucket(m, b, 2); if (rc) return rc; }
-    rc = fcn8s_apply_update(m, FCN8S_OPT_TF_ADAM, lr, 1.f); if (rc) return rc;
+    // a model with a communicator of more than one rank trains data-parallel through this entry point too: the bucket-by-bucket
+    // backward pass, every bucket all-reduced as soon as it is final, 1/world in the update (a C caller must never get silently diverging replicas)
+    const bool dp = (m->comm || m->comm_failed.load()) && m->comm_world > 1;
+    for (int b = 0; b < kNumBuckets; ++b) {
+        rc = do_backward_bucket(m, b, dp ? 1 : 2); if (rc) return rc;
+        if (dp) for (int r = 0; r < kNumBuckets; ++r)
+            if (bucket_complete_after(m, r) == b) { rc = fcn8s_allreduce_bucket(m, r); if (rc) return rc; }
+    }
+    rc = fcn8s_apply_update(m, FCN8S_OPT_TF_ADAM, lr, dp ? 1.f / (float)m->comm_world : 1.f); if (rc) return rc;
     if (loss_out) { rc = fcn8s_read_loss(m, loss_out); if (rc) return rc; }
     if (step_out) *step_out = m->step;
     return FCN8S_OK;

@@ -72,9 +72,12 @@ def numa_share(node_of_device, cpus_of_node, device, allowed=None):
 
 
 def bind_to_gpu_numa(device, local_world=None):
-    """Bind this process (and everything it forks later: the BatchGenerator decode workers, the feeder thread) to the CPUs of the NUMA
-    node its GPU hangs off -- pinned staging copies and PNG decode then stay on the memory controller next to the GPU's PCIe root.
-    Ranks whose GPUs share a node split its CPUs evenly.  Returns a dict for the log / bench line; FCN8S_NUMA_BIND=0 switches it off."""
+    """Bind this process -- EVERY thread it has (sched_setaffinity acts on one thread: the threads listed in /proc/self/task are bound one by one)
+    and everything it starts later (threads and forked children inherit the caller's mask: the feeder thread, the BatchGenerator decode
+    workers) -- to the CPUs of the NUMA node its GPU hangs off: pinned staging copies and PNG decode then stay on the memory controller next to
+    the GPU's PCIe root.  Call it BEFORE creating the process group and the Engine, so that their helper threads are born with the mask; threads
+    that exist already are re-bound here, but memory they have touched stays where it is.  Ranks whose GPUs share a node split its CPUs evenly.
+    Returns a dict for the log / bench line; FCN8S_NUMA_BIND=0 switches it off."""
     import os
     from . import _lib as L
     info = {"bound": False}
@@ -102,7 +105,20 @@ def bind_to_gpu_numa(device, local_world=None):
         info.update({"numa_node": nodes[device], "devices_on_node": sum(1 for x in nodes if x == nodes[device] and x >= 0)})
         if mine:
             os.sched_setaffinity(0, mine)
-            info.update({"bound": True, "cpus": len(mine), "first_cpu": mine[0], "last_cpu": mine[-1]})
+            n_threads = 1
+            try:                                        # the other threads of this process (torch's pools, a process group's watchdogs, ...)
+                me = getattr(__import__("threading"), "get_native_id", lambda: None)()
+                for tid in os.listdir("/proc/self/task"):
+                    if me is not None and int(tid) == me:
+                        continue
+                    try:
+                        os.sched_setaffinity(int(tid), mine)
+                        n_threads += 1
+                    except OSError:                     # (a thread that ended meanwhile)
+                        pass
+            except OSError:
+                pass
+            info.update({"bound": True, "cpus": len(mine), "first_cpu": mine[0], "last_cpu": mine[-1], "threads_bound": n_threads})
         else:
             info["why"] = "no NUMA node reported for this GPU" if nodes[device] < 0 else "no CPUs left to bind to"
     except Exception as ex:            # binding is an optimisation: never let it stop a run

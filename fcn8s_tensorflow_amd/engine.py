@@ -498,6 +498,13 @@ class Engine:
         self.native_comm, self.comm_world, self.comm_rank = True, int(world), int(rank)
         return unique_id
 
+    def comm_destroy(self):
+        """fcn8s_comm_destroy: give the library's RCCL rank back; train_step exchanges through torch.distributed again (or not at all).
+        Raises with RCCL's / the watchdog's text if the communicator had failed (a dead or hung peer: include/fcn8s_hip.h)."""
+        self._sync_stream()
+        self.native_comm, self.comm_world, self.comm_rank = False, 1, 0
+        L.check(L.lib.fcn8s_comm_destroy(self.h), self.h)
+
     def comm_info(self):
         r, w, v = C.c_int(), C.c_int(), C.c_int()
         L.check(L.lib.fcn8s_comm_info(self.h, C.byref(r), C.byref(w), C.byref(v)), self.h)

@@ -158,8 +158,17 @@ int fcn8s_read_loss(fcn8s_model* m, float* loss_out);                /* synchron
  *     eval  : fcn8s_eval_step ...; fcn8s_comm_allreduce_metrics(m); fcn8s_metrics_get
  * fcn8s_allreduce_bucket queues an in-place SUM all-reduce of the bucket on a stream the library owns, behind the event of the last
  * kernel that writes into the bucket (never behind later backward kernels) and returns at once; fcn8s_comm_wait makes the model's
- * stream wait for all of them (fcn8s_apply_update does it implicitly).  librccl is opened with dlopen at the first fcn8s_comm_* call:
- * a failure there, or in any collective, is FCN8S_ERR_RCCL with RCCL's text in fcn8s_last_error.                                      */
+ * stream wait for all of them (fcn8s_apply_update does it implicitly, and so do fcn8s_get_grad and the next fcn8s_backward_bucket(m, 0);
+ * a caller that reads fcn8s_grad_buffer() itself calls fcn8s_comm_wait first).  fcn8s_train_step on a model whose communicator has more
+ * than one rank runs exactly this sequence (it never trains diverging replicas silently).  librccl is opened with dlopen at the first
+ * fcn8s_comm_* call (no RCCL headers are needed to build the library): a failure there, or at the enqueue of any collective, is
+ * FCN8S_ERR_RCCL with RCCL's text in fcn8s_last_error.  Failures AFTER the enqueue -- a peer that dies or hangs -- are caught by a
+ * watchdog thread every communicator of more than one rank owns: it polls ncclCommGetAsyncError and the age of each all-reduce in flight,
+ * and on an asynchronous error, or when a collective has not completed within option "comm_timeout_ms" (default 600 000), calls
+ * ncclCommAbort -- RCCL's kernels then leave the streams, so neither the model's stream nor a host synchronisation waits for that peer
+ * forever -- and every later fcn8s_allreduce_bucket / fcn8s_comm_wait / fcn8s_apply_update / fcn8s_comm_* call returns FCN8S_ERR_RCCL with
+ * the reason.  fcn8s_comm_destroy (also run by fcn8s_destroy) drains the communicator's stream by polling under the same rules, never by
+ * an unconditional synchronisation, and returns FCN8S_ERR_RCCL once if the communicator had failed.                                     */
 /* "dddd:bb:dd.f" of a HIP device (hipDeviceGetPCIBusId): lets a launcher bind each rank's host threads and decode workers to the
  * NUMA node of its GPU through /sys/bus/pci/devices/<id>/local_cpulist (fcn8s_tensorflow_amd/dp.py: bind_to_gpu_numa). */
 int fcn8s_device_pci_bus_id(int device_id, char* out, size_t len);

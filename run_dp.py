@@ -56,13 +56,14 @@ def main():
     if args.device is not None:
         local = args.device
     if world > 1:
-        torch.cuda.set_device(local)
-        dist.init_process_group(args.backend, **({"device_id": torch.device("cuda", local)} if args.backend == "nccl" else {}))
-        # this rank, its feeder thread and the decode workers it forks below: on the CPUs of its GPU's NUMA node
+        # this rank, the threads of its process group and engine, its feeder thread and the decode workers it forks below: on the CPUs of its
+        # GPU's NUMA node -- bound first, so that all of them inherit the mask
         from fcn8s_tensorflow_amd.dp import bind_to_gpu_numa
         numa = bind_to_gpu_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)) if args.device is None else 1)
         if rank == 0:
             print("rank 0 NUMA binding:", numa)
+        torch.cuda.set_device(local)
+        dist.init_process_group(args.backend, **({"device_id": torch.device("cuda", local)} if args.backend == "nccl" else {}))
 
     images, labels = args.images, args.labels
     if images is None:

@@ -89,7 +89,7 @@ def summarize(errs):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_r04.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_r05.json"))
     ap.add_argument("--variants", default="f6,f4,direct")
     ap.add_argument("--precisions", default="fp32", help="comma list out of fp32,f32x3,f32x2,bf16_fc,bf16_fwd,bf16_fwd_x2 (run for the f6 variant only; the bf16 modes "
                     "are compared with the oracle applying the same operand rounding to the same layers)")
@@ -126,9 +126,15 @@ def main():
         own_routes, route_gaps = orc.pool_routes(acts_g)
         acts_g = {k: acts_g[k] for k in orc.branch_layers()}
         g64 = loss64 = None
+        truth = None
         if want_f64:
             loss64, g64, _ = orc.loss_and_grads(P_g, img2, onehot, l2_rate=1e-3, dtype=torch.float64, **kw)
-        return {"fwd": fwd, "loss32": loss32, "g32": g32, "acts_g": acts_g, "own_routes": own_routes, "route_gaps": route_gaps, "g64": g64, "loss64": loss64}
+            # the float64 run of config 2 (O(1-10) decoder): the truth both the device and the fp32 oracle are measured against
+            l64 = orc.forward(P_lo, img2, dtype=torch.float64, **kw)
+            l32 = fwd[("c2", "decoder_x5")][2].astype(np.float64)
+            truth = {"l64": l64, "a64": np.argmax(orc.softmax(l64), -1), "oracle_fp32_max_abs_logit_error_vs_f64": float(np.abs(l32 - l64).max()),
+                     "oracle_fp32_argmax_mismatch_vs_f64": int((fwd[("c2", "decoder_x5")][3] != np.argmax(orc.softmax(l64), -1)).sum())}
+        return {"truth": truth, "fwd": fwd, "loss32": loss32, "g32": g32, "acts_g": acts_g, "own_routes": own_routes, "route_gaps": route_gaps, "g64": g64, "loss64": loss64}
 
     sides = {"": oracle_side({}, not args.skip_f64)}
     rep["oracle_seconds_fp32_and_fp64"] = time.time() - t0
@@ -150,6 +156,20 @@ def main():
         block = {"options": VARIANTS[vname], "precision": prec, "oracle_rounding": kw}
         for (cname, pname), (P, img, ref, ref_arg) in fwd.items():
             block.setdefault(cname, {})[pname] = logits_block(e, P, img, ref, ref_arg)
+        if S.get("truth"):
+            T = S["truth"]
+            e.set_params(P_lo)
+            pred = e.predict(img2, argmax=True)
+            lg = e.activation("logits", (1, H2, W2, 20)).astype(np.float64)
+            srt = np.sort(T["l64"], -1)
+            safe = (srt[..., -1] - srt[..., -2]) > 2e-3
+            dev_err = float(np.abs(lg - T["l64"]).max())
+            block["float64_truth_c2_decoder_x5"] = {
+                "what": "config 2 (1024x512, one image, O(1-10) logits) against the oracle run in float64; nothing aligned",
+                "device_max_abs_logit_error_vs_f64": dev_err, "oracle_fp32_max_abs_logit_error_vs_f64": T["oracle_fp32_max_abs_logit_error_vs_f64"],
+                "ratio": dev_err / T["oracle_fp32_max_abs_logit_error_vs_f64"],
+                "device_argmax_mismatch_vs_f64": int((pred != T["a64"]).sum()), "oracle_fp32_argmax_mismatch_vs_f64": T["oracle_fp32_argmax_mismatch_vs_f64"],
+                "device_argmax_mismatch_vs_f64_above_margin_2e-3": int((pred != T["a64"])[safe].sum()), "pixels": int(pred.size)}
         e.set_params(P_g)
         loss = e.forward_backward(img2, lab2, keep_prob=1.0, l2_rate=1e-3)
         g = e.get_grads()
@@ -158,6 +178,11 @@ def main():
         if g64 is not None:
             e64 = grad_errors(g, g64)
             block["c3"]["vs_oracle_fp64"] = {"summary": summarize(e64), "per_tensor": e64}
+            o = rep["oracle_fp32_vs_fp64"]["summary"]
+            block["c3"]["float64_truth_unaligned"] = {"device_worst": summarize(e64)["worst_max_over_max"], "oracle_fp32_worst": o["worst_max_over_max"],
+                                                      "ratio_worst": summarize(e64)["worst_max_over_max"] / o["worst_max_over_max"],
+                                                      "device_median": summarize(e64)["median_max_over_max"], "oracle_fp32_median": o["median_max_over_max"],
+                                                      "ratio_median": summarize(e64)["median_max_over_max"] / o["median_max_over_max"]}
         # the same comparison along the branches the device took
         br = e.relu_branches((1, H2, W2))
         n_units = int(sum(v.size for v in br.values()))
