@@ -111,9 +111,9 @@ def physical_cores():
 
 
 def cpu_baseline_full(h, w, optimizer="sgd"):
-    """SURVEY 8d's CPU baseline to the letter (`--cpu-baseline-full`; minutes, so not part of the default run): the oracle on ALL
-    physical cores of this host (count printed), 3 warm-up + 10 timed runs per leg, median: (c1) 256x256 forward + argmax,
-    1024x512 bs1 forward, 1024x512 bs2 training step (fwd + bwd + optimizer)."""
+    """SURVEY 8d's CPU baseline to the letter (the default `cpu_baseline` of the one-GPU training line since round 5; ~100 s): the oracle on
+    ALL physical cores of this host (count printed), the bs2 training step (fwd + bwd + optimizer) at the bench resolution 3 warm-up + 10
+    timed runs, median; beside it (c1) 256x256 forward + argmax and the bs1 forward, 1 + 3 runs each."""
     import torch
     from oracle import fcn8s_oracle as orc
     cores = physical_cores()
@@ -130,9 +130,9 @@ def cpu_baseline_full(h, w, optimizer="sgd"):
         return ts
 
     img1 = np.random.default_rng(7).integers(0, 256, (1, 256, 256, 3), dtype=np.uint8)
-    t_c1 = timed(lambda: np.argmax(orc.softmax(orc.forward(P, img1)), -1))
-    img, lab = orc.synthetic_batch(2, h, w)
-    t_c2 = timed(lambda: orc.forward(P, img[:1]))
+    t_c1 = timed(lambda: np.argmax(orc.softmax(orc.forward(P, img1)), -1), warm=1, runs=3)      # (the two forward legs are side figures: 1 + 3 runs;
+    img, lab = orc.synthetic_batch(2, h, w)                                                       #  the training leg below is SURVEY 8d's 3 + 10)
+    t_c2 = timed(lambda: orc.forward(P, img[:1]), warm=1, runs=3)
     onehot = orc.one_hot(lab, 20).astype(np.float32)
     state = {"P": P, "m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}, "t": 0}
 
@@ -157,7 +157,7 @@ def cpu_baseline_full(h, w, optimizer="sgd"):
             "total_s": round(time.perf_counter() - t_start, 1)}
 
 
-def cpu_baseline(h, w, seconds_budget=200.0, optimizer="sgd"):
+def cpu_baseline(h, w, seconds_budget=40.0, optimizer="sgd"):
     """CPU restatement of the reference graph (oracle, kind 'port'), timed on this host's cores as BASELINE.md section 3 /
     SURVEY 8d prescribe: (c1) one 256x256 image forward + argmax, (c2) one 1024x512 image forward, (c3) bs1 training steps
     (fwd + bwd + the same optimizer as the GPU run) at the bench resolution -- each leg 1 warm-up + up to 3 timed runs,
@@ -170,7 +170,7 @@ def cpu_baseline(h, w, seconds_budget=200.0, optimizer="sgd"):
     img1 = np.random.default_rng(7).integers(0, 256, (1, 256, 256, 3), dtype=np.uint8)      # c1 = one 256x256 image, seed 7
     # thread count: torch-CPU on one image does not scale to every hardware thread of a large host (256 threads made the 256x256
     # forward pass take 10 s); pick the fastest of a few counts on the small leg and use it for all legs -- `cores` reports it
-    cands = sorted({c for c in (ncpu, ncpu // 2, ncpu // 4, 64, 32, 16) if 1 <= c <= ncpu}, reverse=True)
+    cands = sorted({c for c in (ncpu // 2, 64, 32, 16) if 1 <= c <= ncpu}, reverse=True)
     best = (None, 1e30)
     for c in cands:
         torch.set_num_threads(c)
@@ -178,7 +178,7 @@ def cpu_baseline(h, w, seconds_budget=200.0, optimizer="sgd"):
         a = time.perf_counter(); orc.forward(P, img1); d = time.perf_counter() - a
         if d < best[1]:
             best = (c, d)
-        if time.perf_counter() - t_start > 40.0:
+        if time.perf_counter() - t_start > 12.0:
             break
     cores = best[0]
     torch.set_num_threads(cores)
@@ -190,9 +190,9 @@ def cpu_baseline(h, w, seconds_budget=200.0, optimizer="sgd"):
             a = time.perf_counter(); fn(); ts.append(time.perf_counter() - a)
         return ts
 
-    t_c1 = timed(lambda: np.argmax(orc.softmax(orc.forward(P, img1)), -1), leg_budget=10.0)
+    t_c1 = timed(lambda: np.argmax(orc.softmax(orc.forward(P, img1)), -1), leg_budget=4.0)
     img, lab = orc.synthetic_batch(1, h, w)
-    t_c2 = timed(lambda: orc.forward(P, img), leg_budget=25.0)
+    t_c2 = timed(lambda: orc.forward(P, img), max_runs=2, leg_budget=6.0)
     onehot = orc.one_hot(lab, 20).astype(np.float32)
     state = {"P": P, "m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}, "t": 0}
 
@@ -285,7 +285,7 @@ def make_png_dataset(root, n, h, w, num_classes=20, seed=0):
     return os.path.join(root, "images"), os.path.join(root, "gt")
 
 
-def e2e(args):
+def e2e(args, emit=True):
     """FCN8s.train() end to end: PNG files -> BatchGenerator (decode, flip augmentation, `workers` processes) -> staging slots
     (pinned copy + H2D on the copy stream, one batch ahead) -> the training step, loss fetched every step as the reference does
     (fcn8s_tensorflow.py:551-578).  Prints one JSON line with the end-to-end rate next to the resident-input rate of the same
@@ -348,9 +348,91 @@ def e2e(args):
     train_gen.close()
     with contextlib.redirect_stdout(io.StringIO()):
         model.close()
-    print(json.dumps(out), flush=True)
     import shutil
     shutil.rmtree(root, ignore_errors=True)
+    if emit:
+        print(json.dumps(out), flush=True)
+    return out
+
+
+def secondary_legs(args, dev, budget_s=75.0):
+    """What earlier rounds claimed from builder-run profiles, now inside the driver-timed default line: short legs, run
+    AFTER the headline regions on engines of their own, each 2 warm-up + a few timed steps between device synchronisations, inputs resident:
+    the f32x3 arithmetic at config 3's shape, config 5's per-GPU shape (2048x1024, 4 images) in fp32 and in its own arithmetic (bf16 forward,
+    and the bf16_train mode), batch-1 inference (config 2), and ten steps of FCN8s.train() end to end from PNG files.  Never the headline."""
+    import argparse as _ap
+    import torch
+    from fcn8s_tensorflow_amd import _lib as L
+    from fcn8s_tensorflow_amd.engine import Engine
+    t_start = time.perf_counter()
+    out = {"note": "side figures of this same run (after the timed regions; 2 warm-up + `steps` timed steps each, resident synthetic inputs); not the headline metric"}
+    opt = L.OPT_TF_ADAM if args.optimizer == "adam" else L.OPT_SGD_MOMENTUM
+
+    def train_leg(precision, N, H, W, steps):
+        e = Engine(20, device_id=dev, seed=1234, precision=precision)
+        try:
+            e.init_params(seed=0)
+            rng = np.random.default_rng(1234)
+            images = torch.from_numpy(rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)).cuda()
+            labels = torch.from_numpy(rng.integers(0, 20, (N, H, W), dtype=np.uint8)).cuda()
+            for _ in range(2):
+                e.train_step(images, labels, 1e-4, keep_prob=0.5, optimizer=opt, fetch_loss=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                e.train_step(images, labels, 1e-4, keep_prob=0.5, optimizer=opt, fetch_loss=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            loss = e.forward_backward(images, labels, keep_prob=1.0)
+            return {"images_per_sec": round(N * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "dtype": DTYPE_LABEL[precision],
+                    "workload": "train step %dx%d, %d images" % (W, H, N), "final_loss": round(float(loss), 5)}
+        finally:
+            e.close()
+
+    def infer_leg(steps):
+        e = Engine(20, device_id=dev, seed=1234)
+        try:
+            e.init_params(seed=0)
+            e.freeze(True)
+            images = torch.from_numpy(np.random.default_rng(1234).integers(0, 256, (1, 512, 1024, 3), dtype=np.uint8)).cuda()
+            for _ in range(5):
+                e.predict(images, argmax=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                e.predict(images, argmax=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            return {"images_per_sec": round(steps / dt, 1), "ms_per_image": round(dt / steps * 1e3, 4), "steps": steps, "dtype": "f32",
+                    "workload": "predict (argmax) 1024x512, 1 image, frozen parameters (BASELINE config 2)"}
+        finally:
+            e.close()
+
+    def e2e_leg():
+        a = _ap.Namespace(**vars(args))
+        a.steps, a.warmup, a.workers, a.precision, a.device = 10, 2, min(32, max(2, (os.cpu_count() or 4) // 4)), "fp32", dev
+        r = e2e(a, emit=False)
+        return {k: r[k] for k in ("value", "ms_per_step", "steps", "resident_input_images_per_sec", "e2e_over_resident", "feeder_alone_images_per_sec", "data")} | {
+            "workload": r["config"]["workload"]}
+
+    legs = [("c3_f32x3", lambda: train_leg("f32x3", args.batch, args.height, args.width, 8)),
+            ("c5_shape_fp32", lambda: train_leg("fp32", 4, 1024, 2048, 5)),
+            ("c5_shape_bf16_fwd", lambda: train_leg("bf16_fwd", 4, 1024, 2048, 5))]
+    if "bf16_train" in DTYPE_LABEL:
+        legs.append(("c5_shape_bf16_train", lambda: train_leg("bf16_train", 4, 1024, 2048, 5)))
+    legs += [("c2_inference_bs1", lambda: infer_leg(100)), ("c3_end_to_end_10_steps", e2e_leg)]
+    for name, fn in legs:
+        if time.perf_counter() - t_start > budget_s:
+            out[name] = {"skipped": "the secondary legs' %.0f s budget was used up" % budget_s}
+            continue
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+            out[name]["leg_seconds"] = round(time.perf_counter() - t0, 1)
+        except Exception as ex:
+            out[name] = {"error": repr(ex)}
+    out["total_s"] = round(time.perf_counter() - t_start, 1)
+    return out
 
 
 def main():
@@ -368,8 +450,10 @@ def main():
                     help="fp32 = the reference's arithmetic (the headline number); bf16_fc = BASELINE config 5's mode (forward "
                          "fc6/fc7 with bf16 operands on the bf16 MFMA, fp32 accumulate) -- reported as dtype 'bf16_fc+f32'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true", help="time the CPU baseline exactly as SURVEY 8d words it (bs2 training step, 3 warm-up + 10 "
-                    "timed, all physical cores) instead of the bounded default sample; takes minutes")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="(default since round 5) `cpu_baseline` = SURVEY 8d to the letter: bs2 training step, 3 warm-up + 10 "
+                    "timed, all physical cores, ~100 s; the bounded sample of earlier rounds is reported beside it as `cpu_baseline_quick`")
+    ap.add_argument("--cpu-baseline-quick", action="store_true", help="only the bounded ~25 s CPU sample (bs1, 1 + 3 runs, fastest thread count) as `cpu_baseline`")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` legs (f32x3, config 5's shape, batch-1 inference, end to end) of the default one-GPU training line")
     ap.add_argument("--comm", default="torch", choices=["torch", "native"], help="who moves the gradient buckets for --gpus > 1: torch.distributed "
                     "(the default) or the library's own RCCL communicator behind the C ABI (fcn8s_comm_init / fcn8s_allreduce_bucket)")
     ap.add_argument("--mode", default="train", choices=["train", "infer", "e2e"],
@@ -736,14 +820,26 @@ def run(args, state):
             "loss_fetch": "deferred" if args.mode == "train" else None,
             "ms_per_step_with_loss_fetch": fetch_ms,
         }
+        default_line = (world == 1 and not under_launcher and args.mode == "train" and not args.no_cpu_baseline
+                        and (N, H, W) == (16, 512, 1024) and args.precision == "fp32")
+    eng.close()
+    if rank == 0:
+        if default_line and not args.no_secondary:
+            try:
+                out["secondary"] = secondary_legs(args, dev)
+            except Exception as ex:
+                out["secondary"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = (cpu_baseline_full if args.cpu_baseline_full else cpu_baseline)(H, W, optimizer=args.optimizer)
+                if args.cpu_baseline_quick:
+                    out["cpu_baseline"] = cpu_baseline(H, W, optimizer=args.optimizer)
+                else:
+                    out["cpu_baseline"] = cpu_baseline_full(H, W, optimizer=args.optimizer)
+                    out["cpu_baseline_quick"] = cpu_baseline(H, W, optimizer=args.optimizer)
             except Exception as ex:  # the oracle is only a reported baseline
                 out["cpu_baseline"] = {"error": repr(ex)}
         state["done"] = True
         print(json.dumps(out), flush=True)
-    eng.close()
     if under_launcher:
         dist.destroy_process_group()
 
