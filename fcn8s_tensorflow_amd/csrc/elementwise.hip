@@ -332,6 +332,14 @@ void launch_softmax_xent(const float* logits, const uint8_t* labels, float* dlog
     const PixMap pm = map ? *map : PixMap{0, 0, 0, 0, 0, 0};
     const long long nslot = pixmap_slots(pm, npix, N);
     const int blocks = softmax_xent_blocks(npix);          // (the partial-sum count finalize_loss expects)
+    if (t_deterministic && colsum && dlogits && (C == 20 || C == 4)) {
+        // the fused column sums (= the last bias gradient) of the blocks meet in atomics: deterministic mode takes them from dlogits in a pass of its own
+        // (slots outside the image hold zero gradient)
+        if (C == 20) hipLaunchKernelGGL(softmax_xent_kernel_c<20>, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, nslot, grad_scale, (float*)nullptr, pm);
+        else         hipLaunchKernelGGL(softmax_xent_kernel_c<4>, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, nslot, grad_scale, (float*)nullptr, pm);
+        launch_colsum(dlogits, colsum, nslot, C, s);
+        return;
+    }
     if (C == 20)
         hipLaunchKernelGGL(softmax_xent_kernel_c<20>, dim3(blocks), dim3(256), 0, s, logits, labels, dlogits, partials, nslot, grad_scale, colsum, pm);
     else if (C == 4)
@@ -687,7 +695,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, float* out, 
 }
 void launch_sumsq(const float* x, float* out, long long n, hipStream_t s)
 {
-    hipLaunchKernelGGL(sumsq_kernel, dim3(cap_blocks(n, 1024)), dim3(256), 0, s, x, out, n);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(t_deterministic ? 1 : cap_blocks(n, 1024)), dim3(256), 0, s, x, out, n);      // (one block: no atomics between blocks)
 }
 
 __global__ void axpy_kernel(float* y, const float* x, float a, long long n)

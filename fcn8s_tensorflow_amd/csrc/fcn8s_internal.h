@@ -96,8 +96,18 @@ struct WgradArgs {
     int c_uninitialized;               // 0: C was zeroed by the caller (accumulate with atomics); 1: the launcher decides (plain store or memset)
     int plain_store;                   // set by the launcher
     int split;                         // as IgemmArgs::split
+    long long split_stride;            // set by the launcher (deterministic mode): != 0 = reduction split k stores its partial tile at C + k * split_stride
 };
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
+
+// ---- deterministic mode (model option "deterministic") ---------------------------------------------------------------
+// Every reduction that the default path splits over blocks and joins with fp32 atomics (weight gradients, bias gradients: the order of the
+// additions then depends on block scheduling, so no two runs give the same bits) instead stores one partial result per split into a scratch slab
+// and a second kernel adds the slabs in split order.  Set per thread by the model's entry points; launchers read it.
+extern thread_local int t_deterministic;
+float* det_scratch(hipStream_t s, size_t floats);              // per-stream scratch, grown on demand; nullptr if the allocation failed
+// C[r][c] (= or +=) sum_{k < nsplit, in order} ws[k * slab + r * ldc + c]   for r < rows, c < cols
+void launch_det_reduce(float* C, const float* ws, long long rows, int cols, int ldc, long long slab, int nsplit, bool accumulate, hipStream_t s);
 // 3x3 / 7x7 SAME conv weight (+bias) gradient, several taps per block (3x3: all nine, 7x7: one filter row);
 // returns false if the shape is not covered (K, Cin % 64, Cout % 64, W % 16): the caller then uses launch_wgrad.
 bool launch_wgrad_taps(const float* X, const float* dZ, float* dW, float* db, int N, int H, int W, int Cin, int Cout,

@@ -14,6 +14,8 @@
 #include "fcn8s_internal.h"
 #include <cmath>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <string>
 
 namespace fcn8s {
@@ -38,6 +40,41 @@ static __device__ __forceinline__ unsigned xcd_swizzle(unsigned p, unsigned tota
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
+thread_local int t_deterministic = 0;
+float* det_scratch(hipStream_t s, size_t floats)
+{
+    struct Buf { float* p = nullptr; size_t cap = 0; };
+    static std::mutex mu;
+    static std::map<hipStream_t, Buf> pool;        // per stream: launches on one stream are ordered, two streams never share a buffer
+    std::lock_guard<std::mutex> lk(mu);
+    Buf& b = pool[s];
+    if (b.cap < floats) {
+        if (b.p) hipFree(b.p);                     // (synchronises the device: nothing still reads the old buffer)
+        b.p = nullptr; b.cap = 0;
+        const size_t want = floats + floats / 4 + (1u << 20);
+        if (hipMalloc((void**)&b.p, want * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        b.cap = want;
+    }
+    return b.p;
+}
+__global__ __launch_bounds__(256) void det_reduce_kernel(float* __restrict__ C, const float* __restrict__ ws, const long long n, const int cols, const int ldc,
+                                                         const long long slab, const int nsplit, const int accumulate)
+{
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long off = (cols == ldc) ? i : (i / cols) * ldc + (i % cols);
+        float v = accumulate ? C[off] : 0.f;
+        const float* w = ws + off;
+        for (int k = 0; k < nsplit; ++k) v += w[(long long)k * slab];          // fixed order: split 0, 1, 2, ...
+        C[off] = v;
+    }
+}
+void launch_det_reduce(float* C, const float* ws, long long rows, int cols, int ldc, long long slab, int nsplit, bool accumulate, hipStream_t s)
+{
+    const long long n = rows * cols;
+    if (n <= 0) return;
+    long long blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, C, ws, n, cols, ldc, slab, nsplit, accumulate ? 1 : 0);
+}
 // ===========================================================================
 // forward / dgrad / transposed-conv implicit GEMM
 // ===========================================================================
@@ -932,7 +969,8 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
     const bool linear = (mode == 1 || mode == 3) && !a.relu && !a.mask && !a.dropout && !a.addend && a.out_scale == 1 && a.ldy == a.Cout;
     constexpr int splitk_min_kt = 64;        // fewest K-tiles a few-block launch must have before its reduction is split (32 measured slower at batch 1)
     const unsigned nblocks = grid.x * (unsigned)phases, nkt_all = (unsigned)(a.Ktot / BKF);
-    if (linear && ((grid.x < 512 && nkt_all >= 512) || (nblocks < 2048 && nkt_all >= (unsigned)splitk_min_kt))) {
+    // (deterministic mode: no split -- the partial sums would meet in atomics)
+    if (linear && !t_deterministic && ((grid.x < 512 && nkt_all >= 512) || (nblocks < 2048 && nkt_all >= (unsigned)splitk_min_kt))) {
         unsigned ks = nkt_all >= 512 && grid.x < 512 ? 1024 / grid.x : 4096 / nblocks;
         if (ks > 8) ks = 8;
         if (ks > nkt_all / 16) ks = nkt_all / 16;
@@ -1204,7 +1242,8 @@ __global__ __launch_bounds__(256, FAST ? 4 : 1) void wgrad_kernel(const WgradArg
         __syncthreads();
     }
 
-    float* Ct = p.C + (long long)tap * p.Areal * p.ldc;
+    // (deterministic mode: reduction split (blockIdx.y, wk) owns the slab C + its index * split_stride and stores into it)
+    float* Ct = p.C + (long long)tap * p.Areal * p.ldc + (long long)(blockIdx.y * WK + wk) * p.split_stride;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int col = j0 + wn * TN * 32 + tn * 32 + (lane & 31);
@@ -1367,6 +1406,7 @@ bool launch_wgrad_taps(const float* X, const float* dZ, float* dW, float* db, in
     Wgrad9Args a{X, dZ, dW, db, N, H, W, Cin, Cout, (long long)N * H * (W / 16), 0};
     const long long work = (long long)(Cin / 64) * (Cout / 64) * (K == 3 ? 1 : 7);
     long long splits = 4096 / work;                    // ~16 blocks per CU in total
+    if (t_deterministic) splits = 1;                   // (this kernel's splits meet in atomics; the default path does not use it)
     if (splits < 1) splits = 1;
     if (splits > (a.nseg + 7) / 8) splits = (a.nseg + 7) / 8;      // at least 8 K-tiles per block
     if (splits < 1) splits = 1;
@@ -1384,7 +1424,8 @@ bool launch_wgrad_taps(const float* X, const float* dZ, float* dW, float* db, in
 // 27 x 4 partial sums in registers; the 3 x 66 input halo sits in LDS as float4 (b, g, r, 0) and is
 // read with broadcast ds_read_b128.  One cross-thread reduction + atomics per block at the very end.
 // ===========================================================================
-struct Conv1WgradArgs { const float4* X4; const float* dZ; float* dW; float* db; int N, H, W; long long nseg; int segs_per_block; };
+struct Conv1WgradArgs { const float4* X4; const float* dZ; float* dW; float* db; int N, H, W; long long nseg; int segs_per_block;
+                        long long blk_stride; };      // != 0 (deterministic mode): block b adds into dW + b * blk_stride / db + b * blk_stride, summed in block order afterwards
 
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradArgs p)
 {
@@ -1463,8 +1504,8 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradArgs p
     for (int i = tid; i < 16 * 112; i += 256) {
         const int c = i / 112, v = i - c * 112;
         const float sum = red[(0 * 16 + c) * 112 + v] + red[(1 * 16 + c) * 112 + v] + red[(2 * 16 + c) * 112 + v] + red[(3 * 16 + c) * 112 + v];
-        if (v < 108) unsafeAtomicAdd(p.dW + (v >> 2) * 64 + c * 4 + (v & 3), sum);     // dW[tap*3+ci][co]
-        else if (p.db) unsafeAtomicAdd(p.db + c * 4 + (v - 108), sum);
+        if (v < 108) unsafeAtomicAdd(p.dW + blockIdx.x * p.blk_stride + (v >> 2) * 64 + c * 4 + (v & 3), sum);     // dW[tap*3+ci][co]
+        else if (p.db) unsafeAtomicAdd(p.db + blockIdx.x * p.blk_stride + c * 4 + (v - 108), sum);
     }
 }
 
@@ -1533,26 +1574,43 @@ __global__ __launch_bounds__(256, 4) void conv1_wgrad_mfma_kernel(const Conv1Wgr
     __syncthreads();
     for (int e = tid; e < 28 * 64; e += 256) {
         const float sum = red[e] + red[32 * 64 + e] + red[2 * 32 * 64 + e] + red[3 * 32 * 64 + e];
-        if (e < 27 * 64) unsafeAtomicAdd(p.dW + e, sum);                 // dW[tap * 3 + ci][co]
-        else if (p.db) unsafeAtomicAdd(p.db + (e - 27 * 64), sum);
+        if (e < 27 * 64) unsafeAtomicAdd(p.dW + blockIdx.x * p.blk_stride + e, sum);                 // dW[tap * 3 + ci][co]
+        else if (p.db) unsafeAtomicAdd(p.db + blockIdx.x * p.blk_stride + (e - 27 * 64), sum);
     }
 }
 
 // mfma: 1 = the matrix-core kernel, 0 = the VALU kernel above (model option "conv1_wgrad_mfma")
 bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, int N, int H, int W, int Cout, int mfma, hipStream_t s)
 {
+    // deterministic mode: every block adds into a zeroed slab of its own (27 x 64 weights + 64 biases), the slabs are summed in block order
+    constexpr long long kSlab = 27 * 64 + 64;
+    auto det_conv1 = [&](Conv1WgradArgs& a, long long blocks) -> float* {
+        if (!t_deterministic || blocks <= 1) return nullptr;
+        float* ws = det_scratch(s, (size_t)(blocks * kSlab));
+        if (!ws) { fprintf(stderr, "fcn8s: deterministic mode: scratch allocation failed\n"); abort(); }
+        hipMemsetAsync(ws, 0, (size_t)(blocks * kSlab) * sizeof(float), s);
+        a.dW = ws; a.db = db ? ws + 27 * 64 : nullptr; a.blk_stride = kSlab;
+        return ws;
+    };
+    auto det_conv1_finish = [&](float* ws, long long blocks) {
+        if (!ws) return;
+        launch_det_reduce(dW, ws, 1, 27 * 64, 27 * 64, kSlab, (int)blocks, true, s);
+        if (db) launch_det_reduce(db, ws + 27 * 64, 1, 64, 64, kSlab, (int)blocks, true, s);
+    };
     if (Cout == 64 && mfma && H % 8 == 0 && W % 16 == 0) {
-        Conv1WgradArgs a{(const float4*)X4, dZ, dW, db, N, H, W, 0, 0};
+        Conv1WgradArgs a{(const float4*)X4, dZ, dW, db, N, H, W, 0, 0, 0};
         const long long ntiles = (long long)N * (H / 8) * (W / 16);
         long long blocks = ntiles < 1024 ? ntiles : 1024;               // 4 per CU, all resident; measured flat from 1024 to 2048, slower below (0.47 ms at 512)
         const int tpb = (int)((ntiles + blocks - 1) / blocks);
         blocks = (ntiles + tpb - 1) / tpb;
         g_last_kernel = "conv1_wgrad_mfma_kernel";
+        float* ws = det_conv1(a, blocks);
         hipLaunchKernelGGL(conv1_wgrad_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, tpb, ntiles);
+        det_conv1_finish(ws, blocks);
         return true;
     }
     if (Cout != 64 || W % 64) return false;
-    Conv1WgradArgs a{(const float4*)X4, dZ, dW, db, N, H, W, (long long)N * H * (W / 64), 0};
+    Conv1WgradArgs a{(const float4*)X4, dZ, dW, db, N, H, W, (long long)N * H * (W / 64), 0, 0};
     // 512 blocks: every block ends in 1792 atomics on the same addresses, and those serialise (2048 blocks: 0.67 ms, 512: 0.60 ms;
     // a register-staged prefetch of the next segment needed 256 VGPRs and was slower)
     constexpr int maxb = 512;
@@ -1560,7 +1618,9 @@ bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, 
     a.segs_per_block = (int)((a.nseg + blocks - 1) / blocks);
     blocks = (a.nseg + a.segs_per_block - 1) / a.segs_per_block;
     g_last_kernel = "conv1_wgrad_kernel";
+    float* ws = det_conv1(a, blocks);
     hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    det_conv1_finish(ws, blocks);
     return true;
 }
 
@@ -1655,7 +1715,7 @@ __global__ __launch_bounds__(K / 2 * C) void tconv_wgrad_kernel(const TconvWgrad
 
 bool launch_tconv_wgrad(const float* X, const float* dY, float* dW, int N, int Hi, int Wi, int C, int K, int S, hipStream_t s)
 {
-    if (!(C == 20 && K == 16 && S == 8)) return false;
+    if (!(C == 20 && K == 16 && S == 8) || t_deterministic) return false;      // (its blocks meet in atomics: deterministic mode takes the generic weight gradient)
     TconvWgradArgs a{X, dY, dW, N, Hi, Wi, 0};
     const long long nrows = (long long)N * Hi;
     const int jsegs = (Wi + 63) / 64;
@@ -1818,7 +1878,7 @@ static __device__ __forceinline__ void wgrad_glds_body(const WgradArgs& p, const
         compute(0);
     }
 
-    float* Ct = p.C + (long long)z * p.Areal * p.ldc;
+    float* Ct = p.C + (long long)z * p.Areal * p.ldc + (long long)ys * p.split_stride;      // (split_stride != 0: deterministic mode, one slab per row chunk)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int col = j0 + wn * TN * 32 + tn * 32 + (lane & 31);
@@ -1854,9 +1914,21 @@ static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
     // big tiles: keep the bias-gradient accumulators out of the register budget (separate column-sum pass)
     constexpr bool fused_colsum = BM * BN < 128 * 128;
     WgradArgs b = a;
-    if (!fused_colsum && a.colsum) { launch_colsum(a.B, a.colsum, a.P, a.Bdim, s); b.colsum = nullptr; }
-    b.plain_store = 0;
-    if (a.c_uninitialized) {            // the caller did not zero C: store directly when every tile has a single writer, else zero it here
+    const bool det = t_deterministic != 0;
+    if ((!fused_colsum || det) && a.colsum) { launch_colsum(a.B, a.colsum, a.P, a.Bdim, s); b.colsum = nullptr; }     // (deterministic: never the fused atomics)
+    b.plain_store = 0; b.split_stride = 0;
+    // Deterministic mode: `nslabs` partial results -> scratch slabs (plain stores, every element of a slab has one writer), then added in slab
+    // order into C by launch_det_reduce.  Returns false (and leaves b alone) when one slab is all there is or the scratch cannot be had.
+    const long long slab = (long long)a.ntaps * a.Areal * a.ldc;
+    auto det_slabs = [&](long long nslabs) -> bool {
+        if (nslabs <= 1) { b.plain_store = a.c_uninitialized ? 1 : 0; return false; }      // a single writer per element: an atomic add onto C is reproducible
+        float* ws = det_scratch(s, (size_t)(nslabs * slab));
+        if (!ws) { fprintf(stderr, "fcn8s: deterministic mode: scratch of %lld floats cannot be allocated\n", nslabs * slab); abort(); }
+        b.C = ws; b.split_stride = slab; b.plain_store = 1;
+        return true;
+    };
+    auto det_finish = [&](long long nslabs) { launch_det_reduce(a.C, b.C, (long long)a.ntaps * a.Areal, a.Bdim, a.ldc, slab, (int)nslabs, !a.c_uninitialized, s); };
+    if (a.c_uninitialized && !det) {            // the caller did not zero C: store directly when every tile has a single writer, else zero it here
         if (splits == 1 && WK == 1) b.plain_store = 1;
         else hipMemsetAsync(a.C, 0, (size_t)a.ntaps * a.Areal * a.ldc * sizeof(float), s);
     }
@@ -1878,19 +1950,31 @@ static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
             }
             long long gchunk = ((a.P + best - 1) / best + 15) / 16 * 16;
             const int gsplits = (int)((a.P + gchunk - 1) / gchunk);
-            b.plain_store = 0;
-            if (a.c_uninitialized && gsplits == 1) b.plain_store = 1;
-            else if (a.c_uninitialized && splits == 1) hipMemsetAsync(a.C, 0, (size_t)a.ntaps * a.Areal * a.ldc * sizeof(float), s);   // (zeroed above otherwise)
+            bool slabs = false;
+            if (det) slabs = det_slabs(gsplits);
+            else {
+                b.plain_store = 0;
+                if (a.c_uninitialized && gsplits == 1) b.plain_store = 1;
+                else if (a.c_uninitialized && splits == 1) hipMemsetAsync(a.C, 0, (size_t)a.ntaps * a.Areal * a.ldc * sizeof(float), s);   // (zeroed above otherwise)
+            }
             static const std::string gbase = "wgrad_glds_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3, ";
             static const std::string gtag = gbase + "true>";     // (fragments of a whole K-tile preloaded before its MFMAs: +3 % over the interleaved order)
             g_last_kernel = gtag.c_str();
+            const dim3 ggrid((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps);
             if (a.split == 3) { static const std::string xtag = "wgrad_glds_x3_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>"; g_last_kernel = xtag.c_str();
-                                     hipLaunchKernelGGL((wgrad_glds_x3_kernel<BM, BN, WM, WN, 3>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits); return; }
-            if (a.split == 2) { static const std::string x2tag = "wgrad_glds_x2_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>"; g_last_kernel = x2tag.c_str();
-                                     hipLaunchKernelGGL((wgrad_glds_x2_kernel<BM, BN, WM, WN, 3>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits); return; }
-            hipLaunchKernelGGL((wgrad_glds_kernel<BM, BN, WM, WN, 3, true>), dim3((unsigned)(nti * ntj) * (unsigned)gsplits * (unsigned)a.ntaps), dim3(256), 0, s, b, (int)gchunk, gsplits);
+                                     hipLaunchKernelGGL((wgrad_glds_x3_kernel<BM, BN, WM, WN, 3>), ggrid, dim3(256), 0, s, b, (int)gchunk, gsplits); }
+            else if (a.split == 2) { static const std::string x2tag = "wgrad_glds_x2_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>"; g_last_kernel = x2tag.c_str();
+                                     hipLaunchKernelGGL((wgrad_glds_x2_kernel<BM, BN, WM, WN, 3>), ggrid, dim3(256), 0, s, b, (int)gchunk, gsplits); }
+            else hipLaunchKernelGGL((wgrad_glds_kernel<BM, BN, WM, WN, 3, true>), ggrid, dim3(256), 0, s, b, (int)gchunk, gsplits);
+            if (slabs) det_finish(gsplits);
             return;
         }
+    }
+    if (det && det_slabs((long long)splits * WK)) {
+        if (fast) hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK, true, false>), grid, dim3(256), 0, s, b, (int)chunk);
+        else      hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK, false, false>), grid, dim3(256), 0, s, b, (int)chunk);
+        det_finish((long long)splits * WK);
+        return;
     }
     if (fast) hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK, true, fused_colsum>), grid, dim3(256), 0, s, b, (int)chunk);
     else      hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, WK, false, fused_colsum>), grid, dim3(256), 0, s, b, (int)chunk);

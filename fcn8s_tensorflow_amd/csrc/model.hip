@@ -108,6 +108,7 @@ struct fcn8s_model {
     std::string fused_v_layer;                                            // layer whose data-gradient input transform already sits in d_wino_v
     std::string dm_layer;                                                 // layer whose dM = A dY A^T sits in d_wino_m, ready for the adjoint data gradient
     std::string dm_prefilled;                                             // layer whose dM the data gradient of the layer after it has already written into d_wino_m (fused transform)
+    int deterministic = 0;                                                // option: reductions split over blocks are joined in a fixed order (slabs + ordered sum) instead of atomics
     int fuse_dgrad_dout = 1;                                              // option: allow that fusion
     int fuse_out_in = 1;                                                  // option: inside a block, conv L's output transform writes conv L+1's V directly (Y is never written): 0 never, 1 unless the row ranges would get too short, 2 always
     std::string fwd_v_layer;                                              // forward: layer whose V the previous layer's fused output transform has already written
@@ -1085,6 +1086,7 @@ void wino_backward_operands(fcn8s_model* m, const char* layer, const float* x, c
 
 int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, bool train)
 {
+    t_deterministic = m->deterministic;
     auto drop_banks = [&]() {
         hipStreamSynchronize(m->stream);
         for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
@@ -1489,6 +1491,7 @@ int bucket_complete_after(const fcn8s_model* m, int bucket)
 // fcn8s_bucket_complete_after), 2 for the fused step
 int do_backward_bucket(fcn8s_model* m, int bucket, int level_cap)
 {
+    t_deterministic = m->deterministic;
     if (!m->have_loss || !m->train_mode) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: call fcn8s_forward_loss first");
     if (bucket != m->next_bucket) return fail(m, FCN8S_ERR_STATE, "fcn8s_backward_bucket: buckets must be run in order 0, 1, ... fcn8s_num_buckets() - 1");
     if (bucket == 0) {
@@ -1755,6 +1758,7 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "conv1_wgrad_mfma") return &m->conv1_wgrad_mfma;
     if (key == "bf16_copy_by_transform") return &m->bf16_copy_by_transform;
     if (key == "conv1_in_transform") return &m->conv1_in_transform;
+    if (key == "deterministic") return &m->deterministic;
     return nullptr;
 }
 int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
@@ -1763,6 +1767,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
     const std::string k = key;
     if (!m) {
         if (k == "op_f32x3") { t_op_split = value ? 3 : 0; return FCN8S_OK; }
+        if (k == "op_deterministic") { t_deterministic = value ? 1 : 0; return FCN8S_OK; }
         if (k == "op_split_pieces") {
             if (value != 0 && value != 2 && value != 3) return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_set_option: op_split_pieces is 0, 2 or 3");
             t_op_split = (int)value; return FCN8S_OK;
@@ -1773,7 +1778,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
         if (value < 1) return fail(m, FCN8S_ERR_BAD_ARG, "comm_timeout_ms must be >= 1");
         std::lock_guard<std::mutex> lk(m->comm_mu); m->comm_timeout_ms = value; return FCN8S_OK;
     }
-    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform") {        // pick a kernel per launch: nothing cached depends on them
+    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform" || k == "deterministic") {        // pick a kernel per launch: nothing cached depends on them
         *model_option(m, k) = value ? 1 : 0;
         return FCN8S_OK;
     }
@@ -1812,6 +1817,7 @@ int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value)
     const std::string k = key;
     if (!m) {
         if (k == "op_f32x3") { *value = t_op_split == 3; return FCN8S_OK; }
+        if (k == "op_deterministic") { *value = t_deterministic; return FCN8S_OK; }
         if (k == "op_split_pieces") { *value = t_op_split; return FCN8S_OK; }
         return FCN8S_ERR_NOT_FOUND;
     }

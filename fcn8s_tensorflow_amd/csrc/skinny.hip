@@ -158,8 +158,9 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
 // (Tried: 16-wave blocks with ds_add_f32 into one LDS tile -- 4x slower, LDS float atomics run a few lanes per clock.)
 template <int C>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                                         long long M, int K, float alpha, int ppb)
+                                                         long long M, int K, float alpha, int ppb, long long split_stride)
 {
+    dw += (long long)blockIdx.y * split_stride;                 // (deterministic mode: a zeroed slab per pixel range, summed in range order afterwards)
     __shared__ float red[4][4 * 32 * C];                        // [wave][t][(i * 2 + h) * C + class]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31, h = lane >> 5;
@@ -276,8 +277,16 @@ bool launch_head_wgrad(const float* x, const float* dy, float* dw, long long M, 
     int ppb = (int)((M + bx - 1) / bx);
     ppb = (ppb + 63) / 64 * 64;                                 // 8 pixel runs (4 waves x 2 lane halves), each a multiple of the 8-deep load batch
     bx = (M + ppb - 1) / ppb;
-    if (C == 20) hipLaunchKernelGGL(head_wgrad_kernel<20>, dim3(nct, (unsigned)bx), dim3(256), 0, s, x, dy, dw, M, K, alpha, ppb);
-    else hipLaunchKernelGGL(head_wgrad_kernel<4>, dim3(nct, (unsigned)bx), dim3(256), 0, s, x, dy, dw, M, K, alpha, ppb);
+    float* out = dw; long long stride = 0;
+    if (t_deterministic && bx > 1) {                            // the bx pixel ranges of a channel group meet in atomics: one slab each instead
+        stride = (long long)K * C;
+        out = det_scratch(s, (size_t)(bx * stride));
+        if (!out) { fprintf(stderr, "fcn8s: deterministic mode: scratch allocation failed\n"); abort(); }
+        hipMemsetAsync(out, 0, (size_t)(bx * stride) * sizeof(float), s);
+    }
+    if (C == 20) hipLaunchKernelGGL(head_wgrad_kernel<20>, dim3(nct, (unsigned)bx), dim3(256), 0, s, x, dy, out, M, K, alpha, ppb, stride);
+    else hipLaunchKernelGGL(head_wgrad_kernel<4>, dim3(nct, (unsigned)bx), dim3(256), 0, s, x, dy, out, M, K, alpha, ppb, stride);
+    if (stride) launch_det_reduce(dw, out, 1, (int)stride, (int)stride, stride, (int)bx, true, s);
     return true;
 }
 

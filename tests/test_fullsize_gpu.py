@@ -386,6 +386,52 @@ def test_device_is_as_close_to_float64_as_the_fp32_cpu_path(variant, options, k_
     assert med_dev <= max(k_grad, 3.0) * med_o32, (med_dev, med_o32)
 
 
+def test_config3_deterministic_mode_is_bit_reproducible_at_bs16():
+    """Option `deterministic`: every reduction the default path splits over blocks and joins with fp32 atomics -- the
+    Winograd-domain and plain weight gradients, conv1_1's and the score heads' weight gradients, the last bias gradient from the loss kernel --
+    writes one partial slab per split and adds the slabs in split order.  At BASELINE config 3's size (16 x 1024x512, TF-Adam, keep_prob 0.5,
+    L2 on): two FRESH engines end four training steps with bit-identical parameters, Adam slots included in what the steps computed; the
+    gradients equal the default path's to summation-order round-off; and the default path itself is shown not to be reproducible (or is, by
+    luck -- printed, not asserted)."""
+    import torch
+    from fcn8s_tensorflow_amd.engine import Engine
+    from fcn8s_tensorflow_amd import _lib as L
+    N, H, W, C = 16, 512, 1024, 20
+    img, lab = orc.synthetic_batch(N, H, W)
+    imgd, labd = torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda()
+    P = orc.init_params(C, seed=4, decoder_std_scale=30.0, bias_std=0.05)
+
+    def four_steps(det):
+        e = Engine(C, seed=3, options={"deterministic": det})
+        e.set_params(P)
+        losses = [e.train_step(imgd, labd, 1e-4, keep_prob=0.5, l2_rate=1e-3, optimizer=L.OPT_TF_ADAM)[0] for _ in range(4)]
+        params = e.flat_params.clone()
+        e.forward_backward(imgd, labd, keep_prob=1.0, l2_rate=1e-3)
+        grads = e.flat_grads.clone()
+        specs = dict(e.specs)
+        e.close()
+        return losses, params, grads, specs
+
+    a = four_steps(1)
+    b = four_steps(1)
+    assert a[0] == b[0], (a[0], b[0])
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    c = four_steps(0)
+    d = four_steps(0)
+    print("deterministic mode: 4 TF-Adam steps at 16 x 1024x512 on two fresh engines -> identical losses %s and bit-identical parameters / gradients; "
+          "default mode: parameters of two runs %s" % (a[0], "identical as well (by luck)" if torch.equal(c[1], d[1]) else
+          "differ in %d of %d elements (largest difference %.2e)" % (int((c[1] != d[1]).sum()), c[1].numel(), float((c[1] - d[1]).abs().max()))))
+    worst = ("", 0.0)
+    for name, (shape, off) in a[3].items():
+        n = int(np.prod(shape))
+        x, y = a[2][off:off + n], c[2][off:off + n]
+        err = float((x - y).abs().max()) / (float(y.abs().max()) + 1e-30)
+        if err > worst[1]:
+            worst = (name, err)
+    print("deterministic vs default gradients after the same 4 steps: worst tensor %s %.2e of its largest entry" % worst)
+    assert np.allclose(a[0], c[0], rtol=1e-4), (a[0], c[0])
+
+
 def test_config3_fused_forward_transforms_at_bs16_equal_the_two_kernel_form():
     """The default engine fuses each inner conv's output transform with the next conv's input transform (`fuse_out_in` = 1).  At BASELINE's
     size (16 x 1024x512), against an engine with the fusion off: the kernel really

@@ -15,9 +15,9 @@ from oracle import fcn8s_oracle as orc  # noqa: E402  (checker only)
 SMALL = (8, 16, 32, 64, 64, 128, 128)
 
 
-def make_engine(widths=None, C=20, seed=0):
+def make_engine(widths=None, C=20, seed=0, options=None):
     from fcn8s_tensorflow_amd.engine import Engine
-    return Engine(C, widths=widths, device_id=0, seed=seed)
+    return Engine(C, widths=widths, device_id=0, seed=seed, options=options or {})
 
 
 def batch(n, h, w, C=20, seed=0):
@@ -953,7 +953,7 @@ def test_fused_output_and_next_input_transform_is_bit_identical(widths, n, h, w)
         Engine(20, options={"fuse_out_in": 3})
 
 
-@pytest.mark.parametrize("optimizer", ["sgd"])
+@pytest.mark.parametrize("optimizer", ["sgd", "adam_deterministic"])
 def test_free_running_training_trajectory_follows_the_oracle(optimizer):
     """The closest thing to the reference's "train it and look at the curve" that can be checked offline: the library and the CPU oracle
     each train the SAME small-width FCN-8s from the same initial variables on the same four batches of a learnable task (label = a function
@@ -962,9 +962,14 @@ def test_free_running_training_trajectory_follows_the_oracle(optimizer):
     the bound below is 10x the largest gap seen) and both must actually learn.  Only SGD + momentum runs free here: TF-Adam's update is sign-like
     wherever a gradient is at round-off level, and the library's own weight-gradient atomics (summation order differs from run to run) are enough
     to send two Adam trajectories apart after a dozen steps -- measured loss gaps between 1e-6 and 2e-2 for the same 16 steps on different runs.
-    Adam is checked step by step instead (test_tf_adam_training_steps), each step restarted from the library's own state."""
+    Adam is checked step by step instead (test_tf_adam_training_steps), each step restarted from the library's own state.
+    Round 5: with the library in DETERMINISTIC mode (option `deterministic`: the split reductions are joined in a fixed order, no atomics) its
+    trajectory is the same on every run, so the TF-Adam arm runs free again ("adam_deterministic"): two fresh engines must end in bit-identical
+    parameters, and the loss curve is held against the oracle's with a bound that no longer has to cover run-to-run scatter."""
     from fcn8s_tensorflow_amd import _lib as L
     import torch
+    det = optimizer.endswith("_deterministic")
+    optimizer = optimizer.split("_")[0]
     torch.set_num_threads(min(int(os.environ.get("FCN8S_TEST_THREADS", "8")), torch.get_num_threads()))            # (tiny CPU convolutions: hundreds of threads only get in each other's way)
     widths = SMALL
     P = orc.init_params(20, widths, seed=21, decoder_std_scale=5.0, bias_std=0.05)
@@ -977,16 +982,23 @@ def test_free_running_training_trajectory_follows_the_oracle(optimizer):
         batches.append((img, lab))
     lr = 0.2 if optimizer == "sgd" else 2e-3
     STEPS = 32 if optimizer == "sgd" else 16          # (Adam's sign-like steps make two fp32 trajectories part company eventually: keep it short)
-    e = make_engine(widths)
-    e.set_params(P)
     opt = L.OPT_SGD_MOMENTUM if optimizer == "sgd" else L.OPT_TF_ADAM
-    dev = []
-    for t in range(STEPS):
-        img, lab = batches[t % 4]
-        loss, step = e.train_step(img, lab, lr, keep_prob=1.0, l2_rate=1e-4, optimizer=opt)
-        dev.append(loss)
-    final_dev = e.get_params()
-    e.close()
+    runs = []
+    for _ in range(2 if det else 1):
+        e = make_engine(widths, options={"deterministic": 1} if det else None)
+        e.set_params(P)
+        dev = []
+        for t in range(STEPS):
+            img, lab = batches[t % 4]
+            loss, step = e.train_step(img, lab, lr, keep_prob=1.0, l2_rate=1e-4, optimizer=opt)
+            dev.append(loss)
+        runs.append((dev, e.get_params()))
+        e.close()
+    dev, final_dev = runs[0]
+    if det:                                            # the whole trajectory, bit for bit, on a second engine
+        assert runs[1][0] == dev
+        for k in final_dev:
+            np.testing.assert_array_equal(runs[1][1][k], final_dev[k], err_msg=k)
     Pc = {k: v.copy() for k, v in P.items()}
     m = {k: np.zeros_like(v) for k, v in P.items()}; v2 = {k: np.zeros_like(v) for k, v in P.items()}
     ref = []
@@ -1013,5 +1025,5 @@ def test_free_running_training_trajectory_follows_the_oracle(optimizer):
     #  one max-pool tie routed the other way moves a handful of weights by that much -- and 6e-4 .. 4.7e-3 for Adam)
     #  (a later run, inside the whole suite: loss gap 2.1e-5, drift 1.1e-2 -- the library's own weight-gradient atomics make its trajectory differ
     #  from run to run by as much; the bounds leave an order of magnitude over the largest values seen)
-    assert gap.max() < 2e-4, gap
+    assert gap.max() < (2e-4 if optimizer == "sgd" else 2e-3), gap
     assert drift < 1e-1, drift
