@@ -35,7 +35,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0           # dense bf16 MFMA peak (same guide); th
 DTYPE_LABEL = {"fp32": "f32", "bf16_fc": "bf16_fc+f32", "f32x3": "f32x3 (fp32 operands as three bf16 pieces on the bf16 MFMA, fp32 accumulate)",
                "bf16_fwd": "bf16 forward (conv3_1..conv5_3, fc6, fc7: bf16-rounded operands, fp32 accumulate) + f32x3 for every other GEMM",
                "f32x2": "f32x2 (fp32 operands as two bf16 pieces = 16 significand bits on the bf16 MFMA, fp32 accumulate; reduced precision)",
-               "bf16_fwd_x2": "bf16 forward (conv3_1..conv5_3, fc6, fc7: bf16-rounded operands, fp32 accumulate) + f32x2 (two bf16 pieces per operand) for every other GEMM"}
+               "bf16_fwd_x2": "bf16 forward (conv3_1..conv5_3, fc6, fc7: bf16-rounded operands, fp32 accumulate) + f32x2 (two bf16 pieces per operand) for every other GEMM",
+               "bf16_train": "bf16 operands, fp32 accumulate in the forward pass, the data gradients and the weight gradients of conv1_2..conv5_3, fc6, fc7 (direct convolutions, "
+                             "fp32 master weights); conv1_1, the decoder, loss and optimizer fp32"}
 
 
 def pmc_traffic(kernel):
@@ -446,7 +448,7 @@ def main():
     ap.add_argument("--optimizer", default="sgd", choices=["adam", "sgd"],
                     help="sgd = SGD+momentum as BASELINE.json config 3 names; adam = TF-Adam, the reference's own optimizer "
                          "(fcn8s_tensorflow.py:256) -- same step time to within 0.1 percent")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc", "f32x3", "bf16_fwd", "f32x2", "bf16_fwd_x2"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc", "f32x3", "bf16_fwd", "f32x2", "bf16_fwd_x2", "bf16_train"],
                     help="fp32 = the reference's arithmetic (the headline number); bf16_fc = BASELINE config 5's mode (forward "
                          "fc6/fc7 with bf16 operands on the bf16 MFMA, fp32 accumulate) -- reported as dtype 'bf16_fc+f32'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -761,7 +763,7 @@ def run(args, state):
             # f32x3 mode: six bf16 MFMA products per fp32-equivalent multiply-add -> peak = bf16 dense peak / 6
             # (f32x2: three products)
             peak = (PEAK_BF16_MFMA_TFLOPS / 6.0 if "_x3_" in dom else PEAK_BF16_MFMA_TFLOPS / 3.0 if "_x2_" in dom
-                    else PEAK_BF16_MFMA_TFLOPS if "conv_bf16" in dom else PEAK_F32_MFMA_TFLOPS)
+                    else PEAK_BF16_MFMA_TFLOPS if ("conv_bf16" in dom or "wgrad_bf16" in dom) else PEAK_F32_MFMA_TFLOPS)
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     # HBM-side bytes per launch from the PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE); compare with

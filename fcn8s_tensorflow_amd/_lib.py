@@ -18,7 +18,7 @@ OPT_TF_ADAM, OPT_SGD_MOMENTUM, OPT_NONE = 0, 1, 2
 MAX_BUCKETS = 8          # the number of gradient buckets is a run-time value: lib.fcn8s_num_buckets(handle) / fcn8s_layout_num_buckets(cfg)
 COMM_ID_BYTES = 128
 NUM_STAGE_SLOTS = 3
-PREC_F32, PREC_BF16_FC, PREC_F32X3, PREC_BF16_FWD, PREC_F32X2, PREC_BF16_FWD_X2 = 0, 1, 2, 3, 4, 5
+PREC_F32, PREC_BF16_FC, PREC_F32X3, PREC_BF16_FWD, PREC_F32X2, PREC_BF16_FWD_X2, PREC_BF16_TRAIN = 0, 1, 2, 3, 4, 5, 6
 
 
 class Config(C.Structure):
@@ -104,6 +104,7 @@ SIGNATURES = {
     "fcn8s_op_conv2d_winograd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_conv3x3_winograd_fwd_bwd": (_i, [_p] * 11 + [_i] * 8),
     "fcn8s_op_conv2d_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
+    "fcn8s_op_conv2d_bf16_train": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_conv2d_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
     "fcn8s_op_maxpool2x2": (_i, [_p, _p, _p, _i, _i, _i, _i]),
     "fcn8s_op_maxpool2x2_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i]),

@@ -71,11 +71,23 @@ struct Bf16Conv256Args {
     int N, H, W, Cin, Cout, K;
     int relu, dropout; float keep_prob; unsigned long long seed; unsigned int stream_id;
     long long M; int m_fastest;        // filled in by the launcher
+    const float* addend;               // optional, [M][Cout]: added before ReLU / mask (a data gradient's skip-path term)
+    const float* mask; float mask_scale;   // optional, [M][Cout]: y = mask > 0 ? y * mask_scale : 0 (the ReLU / dropout of the layer whose input gradient this is)
+    int any_shape;                     // 1: Cout % 64 == 0 and any M are taken (64- / 128-column tiles, partial last row tile); 0: the round-3 rule
 };
 bool conv_bf16_256_ok(long long M, int Cin, int Cout, int mode);      // mode 0 never, 1 when it fills the chip, 2 whenever the shapes allow
 void launch_w_to_bf16_t(const float* w, unsigned short* wt, int K, int Cout, hipStream_t s);
 void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H, int W, int C, int pad, hipStream_t s);
 bool launch_conv_bf16_256(const Bf16Conv256Args& a, hipStream_t s);
+// the kernel of a SAME convolution's data gradient as conv_bf16_256_kernel wants it: wt[Cin][(flipped taps, Cout)] bf16 (Cout % 8 == 0)
+void launch_w_to_bf16_flip_t(const float* w, unsigned short* wt, int K, int Cin, int Cout, hipStream_t s);
+// weight gradient with bf16-rounded operands: dW[tap][ci][co] = sum_q A[q + off(tap)][ci] * B[q][co] over R flat padded-pixel rows (gemm_bf16.hip)
+struct Bf16WgradArgs {
+    const unsigned short* A; const unsigned short* B; float* C;      // A = padded bf16 input [R][Ci], B = padded bf16 output gradient [R][Cj], both with guard rows
+    long long R; int Ci, Cj, K, Wp;                                   // R = N * Hp * Wp, Wp = W + K - 1
+    long long chunk, split_stride; int plain_store;                   // set by the launcher
+};
+bool launch_wgrad_bf16(const Bf16WgradArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // Weight-gradient GEMM on the f32 MFMA:

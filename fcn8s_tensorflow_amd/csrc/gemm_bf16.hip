@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const Bf16ConvArgs p)
 // Lab, random data in [-1, 1): 1040-1065 TFLOP/s at fc7's shape, 940 at fc6's (the 128 x 128 kernel below: 680 / 880 in the model).  The same
 // loop without its loads reaches 1200, its MFMAs alone 1320 -- the data-dependent power ceiling of the bf16 pipe (guide 5.4 rule 25), not 2500.
 namespace {
-constexpr int G_BM = 256, G_BN = 256, G_BK = 32, G_S = 5, G_ROWB = G_BK * 2, G_ABYTES = G_BM * G_ROWB, G_STAGE = (G_BM + G_BN) * G_ROWB;
+constexpr int G_BM = 256, G_BN = 256, G_BK = 32, G_S = 5, G_ROWB = G_BK * 2, G_ABYTES = G_BM * G_ROWB;
 
 static __device__ __forceinline__ void glds16b(const void* sbase, unsigned voff, unsigned lds_byte_off)
 {
@@ -303,70 +303,84 @@ void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H,
     hipLaunchKernelGGL(f32_to_bf16_padded_kernel, dim3((unsigned)b), dim3(256), 0, s, (const float4*)x, (bf16x8*)xp, N, H, W, C / 8, pad);
 }
 
+// BN = 256 / 128 / 64 output channels per block (round 5: the 64- and 128-channel layers of blocks 1-2 and every data gradient run on this kernel
+// too).  The two row groups of 128 rows stay; inside a group the four waves are laid out WR x (4 / WR): BN = 256 -> 1 x 4 (a wave owns 128 rows x 64
+// columns, 4 x 2 accumulators, the round-3 kernel), BN = 128 -> 2 x 2 (64 x 64, 2 x 2), BN = 64 -> 4 x 1 (32 x 64, 1 x 2).  The B image of a stage has BN
+// rows: waves whose chunks lie beyond it issue no B loads (the vmcnt accounting is per wave: NB = its number of B instructions).
+// Rows m >= M (a partial last row tile) read row 0's window and are not stored.  Epilogue: bias, ReLU, dropout as before; for the data gradients an
+// optional addend (the skip path's gradient) and the ReLU mask of the layer input (`mask` > 0, an fp32 activation tensor of the output's shape).
+template <int BN>
 __global__ __launch_bounds__(512, 1) void conv_bf16_256_kernel(const Bf16Conv256Args p)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[G_S * G_STAGE];       // 160 KB
+    constexpr int WR = BN == 256 ? 1 : (BN == 128 ? 2 : 4), WCN = 4 / WR;         // waves of a group: WR along rows x WCN along columns
+    constexpr int TM = 4 / WR, TN = 2;                                            // 32 x 32 accumulator tiles per wave
+    constexpr int STAGE = (G_BM + BN) * G_ROWB;
+    static_assert(WCN * 64 == BN, "a wave owns 64 columns");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G_S * STAGE];       // 160 / 120 / 100 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wn = wave & 3;
-    const unsigned ntm = (unsigned)(p.M / G_BM), ntn = (unsigned)(p.Cout / G_BN);
+    const int grp = wave >> 2, wq = wave & 3, wr = wq / WCN, wn = wq % WCN;
+    const unsigned ntm = (unsigned)((p.M + G_BM - 1) / G_BM), ntn = (unsigned)(p.Cout / BN);
     const unsigned lid = xcd_run(blockIdx.x, gridDim.x);
     const unsigned tmi = p.m_fastest ? lid % ntm : lid / ntn, tni = p.m_fastest ? lid / ntm : lid % ntn;
-    const long long m0 = (long long)tmi * G_BM; const int n0 = (int)tni * G_BN;
+    const long long m0 = (long long)tmi * G_BM; const int n0 = (int)tni * BN;
     const int HW = p.H * p.W, Hp = p.H + p.K - 1, Wp = p.W + p.K - 1, Ktot = p.K * p.K * p.Cin;
 
-    // LDS-DMA: wave w fills 16-row chunks 2w, 2w + 1 of the A image and of the B image of a stage
-    unsigned a_voff[2], b_voff[2];
+    // LDS-DMA: wave w fills 16-row chunks 2w, 2w + 1 of the A image and (if they exist) of the B image of a stage
+    constexpr int NBMAX = 2;
+    // B instructions of this wave (wave-uniform; BN = 256: always two, a compile-time constant as in the round-3 kernel)
+    const int nb = BN == 256 ? 2 : ((wave * 2 + 1) * 16 < BN ? 2 : 0);
+    unsigned a_voff[2], b_voff[NBMAX];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (wave * 2 + i) * 16 + lane / 4, pc = lane % 4;
         const int lc = pc ^ ((row >> 2) & 3);                                  // logical 16-byte chunk stored at physical chunk pc
-        const long long m = m0 + row;
+        long long m = m0 + row; if (m >= p.M) m = 0;
         const int n = (int)(m / HW), r = (int)(m - (long long)n * HW), y = r / p.W, x = r - y * p.W;
         const long long pp = ((long long)n * Hp + y) * Wp + x;                // top-left pixel of the row's tap window in the padded copy
         a_voff[i] = (unsigned)((pp * p.Cin + lc * 8) * 2);
-        b_voff[i] = (unsigned)(((long long)row * Ktot + lc * 8) * 2);
+        b_voff[i] = (unsigned)(((long long)(row < BN ? row : 0) * Ktot + lc * 8) * 2);
     }
     const unsigned short* b_base = p.wt + (long long)n0 * Ktot;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     // K-tiles are issued strictly in order, one call per tile: the tap position advances incrementally
     int i_kt = 0, i_ci = 0, i_tx = 0, i_ty = 0;
     auto issue = [&]() {
-        const unsigned st = lds0 + (unsigned)((i_kt % G_S) * G_STAGE);
+        const unsigned st = lds0 + (unsigned)((i_kt % G_S) * STAGE);
         const unsigned short* ga = p.xp + ((long long)i_ty * Wp + i_tx) * p.Cin + i_ci;
         const unsigned short* gb = b_base + (long long)i_kt * G_BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) glds16b(ga, a_voff[i], st + (wave * 2 + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16b(gb, b_voff[i], st + G_ABYTES + (wave * 2 + i) * 1024);
+        for (int i = 0; i < NBMAX; ++i) if (i < nb) glds16b(gb, b_voff[i], st + G_ABYTES + (wave * 2 + i) * 1024);
         ++i_kt; i_ci += G_BK;
         if (i_ci == p.Cin) { i_ci = 0; if (++i_tx == p.K) { i_tx = 0; ++i_ty; } }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int a_row[4], b_row[2];
+    int a_row[TM], b_row[TN];
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) a_row[tm] = grp * 128 + tm * 32 + (lane & 31);
+    for (int tm = 0; tm < TM; ++tm) a_row[tm] = grp * 128 + wr * (TM * 32) + tm * 32 + (lane & 31);
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) b_row[tn] = wn * 64 + tn * 32 + (lane & 31);
-    bf16x8 af[2][4], bfr[2][2];
+    for (int tn = 0; tn < TN; ++tn) b_row[tn] = wn * 64 + tn * 32 + (lane & 31);
+    bf16x8 af[2][TM], bfr[2][TN];
     auto load_frags = [&](int kt) {
-        const unsigned char* st = smem + (kt % G_S) * G_STAGE;
+        const unsigned char* st = smem + (kt % G_S) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm) {
+            for (int tm = 0; tm < TM; ++tm) {
                 const int r = a_row[tm], pc = (2 * ks + (lane >> 5)) ^ ((r >> 2) & 3);
                 af[ks][tm] = *reinterpret_cast<const bf16x8*>(st + r * G_ROWB + pc * 16);
             }
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
+            for (int tn = 0; tn < TN; ++tn) {
                 const int r = b_row[tn], pc = (2 * ks + (lane >> 5)) ^ ((r >> 2) & 3);
                 bfr[ks][tn] = *reinterpret_cast<const bf16x8*>(st + G_ABYTES + r * G_ROWB + pc * 16);
             }
@@ -380,17 +394,22 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_256_kernel(const Bf16Conv256
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
+            for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
+                for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][tm], bfr[ks][tn], acc[tm][tn], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
 
     const int nkt = Ktot / G_BK;
+    // this wave's pieces of K-tile kt have landed when at most (tiles still allowed in flight) x (2 + nb) of its loads are outstanding
+    auto wait_n = [&](int tiles) {
+        if (BN == 256 || nb == 2) { if (tiles >= 3) wait_vm<12>(); else if (tiles == 2) wait_vm<8>(); else if (tiles == 1) wait_vm<4>(); else wait_vm<0>(); }
+        else { if (tiles >= 3) wait_vm<6>(); else if (tiles == 2) wait_vm<4>(); else if (tiles == 1) wait_vm<2>(); else wait_vm<0>(); }
+    };
 #pragma unroll
     for (int t = 0; t < G_S - 1; ++t) if (t < nkt) issue();
-    if (nkt > 3) wait_vm<12>(); else if (nkt > 2) wait_vm<8>(); else if (nkt > 1) wait_vm<4>(); else wait_vm<0>();
+    wait_n(nkt > 3 ? 3 : nkt - 1);
     __builtin_amdgcn_s_barrier();
     // tick t: group g runs step t - g; even steps read the fragments of K-tile step / 2, odd steps multiply them.  Even ticks 2 j issue the
     // LDS-DMA of K-tile j + 4 (its stage was last read in tick 2 j - 1); odd ticks 2 kt + 1 wait for K-tile kt + 1.  Each group runs its own
@@ -398,7 +417,8 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_256_kernel(const Bf16Conv256
     // hipcc from hoisting a group's MFMAs above the barrier that opens its MFMA phase.
     auto tick_end = [&]() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
     auto wait_tile = [&](int kt) {      // this wave's pieces of K-tile kt have landed; up to three newer tiles may still be in flight
-        if (kt + 3 < nkt) wait_vm<12>(); else if (kt + 2 < nkt) wait_vm<8>(); else if (kt + 1 < nkt) wait_vm<4>(); else wait_vm<0>();
+        const int newer = nkt - 1 - kt;
+        wait_n(newer > 3 ? 3 : (newer < 0 ? 0 : newer));
     };
     if (grp == 0) {
         for (int kt = 0; kt < nkt; ++kt) {
@@ -423,28 +443,35 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_256_kernel(const Bf16Conv256
         }
     }
 
-    // epilogue (fp32): bias, ReLU, dropout keyed by the element offset -- the same Philox stream as the fp32 path
+    // epilogue (fp32): bias, skip-path addend, ReLU, the ReLU mask of a data gradient, dropout keyed by the element offset -- the same Philox stream as the fp32 path
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
+    for (int tn = 0; tn < TN; ++tn) {
         const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
         const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + grp * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const long long m = m0 + grp * 128 + wr * (TM * 32) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
                 const long long off = m * p.Cout + col;
                 float v = acc[tm][tn][r] + bv;
+                if (p.addend) v += p.addend[off];
                 if (p.relu) v = v > 0.f ? v : 0.f;
+                if (p.mask) v = p.mask[off] > 0.f ? v * p.mask_scale : 0.f;
                 if (p.dropout) v = philox_uniform((unsigned long long)off, p.seed, p.stream_id) < p.keep_prob ? v / p.keep_prob : 0.f;
                 p.y[off] = v;
             }
     }
 }
 
+// mode 0 never, 1 when it fills the chip (the round-3 rule, 256-column tiles only), 2 whenever the shapes allow, 3 = 2 with the 128- and 64-column
+// tiles and a partial last row tile as well (the bf16_train mode)
 bool conv_bf16_256_ok(long long M, int Cin, int Cout, int mode)
 {
-    if (mode == 0 || M % G_BM || Cout % G_BN || Cin % G_BK || Cin % 8) return false;
+    if (mode == 0 || Cin % G_BK || Cin % 8) return false;
+    if (mode >= 3) return Cout % 64 == 0 && M >= 1;
+    if (M % G_BM || Cout % G_BN) return false;
     return mode >= 2 || (M / G_BM) * (Cout / G_BN) >= 128;         // fewer tiles than half the CUs: the 128 x 128 kernel fills the chip better
 }
 
@@ -452,11 +479,217 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
 {
     Bf16Conv256Args a = a0;
     a.M = (long long)a.N * a.H * a.W;
-    if (!conv_bf16_256_ok(a.M, a.Cin, a.Cout, 2)) return false;
+    if (!conv_bf16_256_ok(a.M, a.Cin, a.Cout, a.any_shape ? 3 : 2)) return false;
+    // padded-copy byte offsets are 32-bit in the kernel (per-lane voff): the whole padded tensor must stay below 4 GiB
+    if ((double)a.N * (a.H + a.K - 1) * (a.W + a.K - 1) * a.Cin * 2.0 >= 4294967296.0 || (double)a.Cout * a.K * a.K * a.Cin * 2.0 >= 4294967296.0) return false;
     const double abytes = 2.0 * a.M * a.K * a.K * a.Cin, bbytes = 2.0 * a.K * a.K * a.Cin * a.Cout;
     a.m_fastest = bbytes > abytes;             // the larger operand's panel stays put behind one XCD's L2 while the other one streams
-    g_last_kernel = "conv_bf16_256_kernel";
-    hipLaunchKernelGGL(conv_bf16_256_kernel, dim3((unsigned)((a.M / G_BM) * (a.Cout / G_BN))), dim3(512), 0, s, a);
+    const int bn = a.Cout % 256 == 0 ? 256 : (a.Cout % 128 == 0 ? 128 : 64);
+    const unsigned blocks = (unsigned)(((a.M + G_BM - 1) / G_BM) * (a.Cout / bn));
+    if (bn == 256) { g_last_kernel = "conv_bf16_256_kernel<256>"; hipLaunchKernelGGL(conv_bf16_256_kernel<256>, dim3(blocks), dim3(512), 0, s, a); }
+    else if (bn == 128) { g_last_kernel = "conv_bf16_256_kernel<128>"; hipLaunchKernelGGL(conv_bf16_256_kernel<128>, dim3(blocks), dim3(512), 0, s, a); }
+    else { g_last_kernel = "conv_bf16_256_kernel<64>"; hipLaunchKernelGGL(conv_bf16_256_kernel<64>, dim3(blocks), dim3(512), 0, s, a); }
+    return true;
+}
+
+// w[K*K][Cin][Cout] fp32 (HWIO) -> wt[Cin][(K*K taps, flipped)][Cout] bf16: the kernel of the convolution that IS the data gradient of a SAME
+// convolution, dX[p][ci] = sum_{t', co} dYpad[p + t'][co] * w[K*K - 1 - t'][ci][co], laid out [output channel = ci][k = (t', co)] for conv_bf16_256_kernel
+__global__ __launch_bounds__(256) void w_to_bf16_flip_t_kernel(const float4* __restrict__ w, bf16x8* __restrict__ wt, int KK, int Cin, int Cout8)
+{
+    const long long total = (long long)Cin * KK * Cout8;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c8 = (int)(i % Cout8); long long t = i / Cout8;
+        const int tp = (int)(t % KK), ci = (int)(t / KK);
+        const long long src = ((long long)(KK - 1 - tp) * Cin + ci) * Cout8 + c8;
+        const float4 a = w[2 * src], b = w[2 * src + 1];
+        bf16x8 o;
+        o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+        o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+        wt[i] = o;
+    }
+}
+void launch_w_to_bf16_flip_t(const float* w, unsigned short* wt, int K, int Cin, int Cout, hipStream_t s)      // Cout % 8 == 0
+{
+    const long long total = (long long)Cin * K * K * (Cout / 8);
+    long long b = (total + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1;
+    hipLaunchKernelGGL(w_to_bf16_flip_t_kernel, dim3((unsigned)b), dim3(256), 0, s, (const float4*)w, (bf16x8*)wt, K * K, Cin, Cout / 8);
+}
+
+// =====================================================================================================================================
+// Weight gradient with bf16-rounded operands, fp32 accumulation (round 5, the bf16_train mode)
+// =====================================================================================================================================
+//   dW[tap][ci][co] = sum over padded pixels q of  Xp[q + off(tap)][ci] * dYp[q][co],      off(ty, tx) = (ty - pad) * Wp + (tx - pad)
+// Xp and dYp are the zero-bordered bf16 copies [N][H + 2 pad][W + 2 pad][C] the forward / data-gradient convolutions read anyway.  Because the
+// border of dYp is zero, the sum may run over ALL padded positions q as one flat row index: a tap is a plain-row product A^T B whose A
+// operand is Xp moved by a constant number of rows -- no per-pixel address arithmetic, no predicates (LDS-DMA has none to offer).  Both buffers
+// carry zeroed guard rows in front and behind (pad * Wp + pad + 32), so that the moved / rounded-up row ranges stay inside the allocation and meet
+// finite values (times zero).  Both operands are k-STRIDED ([row][channel]); the MFMA fragments (8 consecutive k of one channel per lane) come out of
+// LDS through ds_read_b64_tr_b16, the hardware 4 x 4 transpose of 16-bit elements (layout and swizzle of tools/planes_lab.hip, measured in round 4).
+// Tile BM x BM channels (128, or 64 for the 64-channel layers), K-tile = 32 rows, four stages, LDS-DMA fills, one tap per blockIdx.z, the rows split
+// over blockIdx.x / ntiles chunks whose partial tiles meet in fp32 atomics -- or, in deterministic mode, in one slab per chunk added in chunk order.
+namespace {
+static __device__ __forceinline__ void glds16w(const void* sbase, unsigned voff, unsigned lds_byte_off)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte_off) : "memory", "m0");
+}
+}
+template <int BM>
+__global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void wgrad_bf16_kernel(const Bf16WgradArgs p)
+{
+    constexpr int S = 4, ROWB = BM * 2, PLANE = 16 * ROWB, STAGE = 4 * PLANE;        // planes: A rows 0-15, A rows 16-31, B rows 0-15, B rows 16-31
+    constexpr int NI = PLANE / 1024, RPI = 1024 / ROWB;                                // LDS-DMA instructions per plane, rows per instruction
+    constexpr int T = BM / 64;                                                         // 32 x 32 tiles per wave and operand
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S * STAGE];
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntj = p.Cj / BM, ntiles = (p.Ci / BM) * ntj;
+    const int tile = blockIdx.x % ntiles, ys = blockIdx.x / ntiles, tap = blockIdx.z;
+    const int i0 = (tile / ntj) * BM, j0 = (tile % ntj) * BM;
+    const long long t0 = (long long)ys * p.chunk;
+    const long long t1 = t0 + p.chunk < p.R ? t0 + p.chunk : p.R;
+    const int nkt = (int)((t1 - t0 + 31) / 32);                                       // (a last partial K-tile reads guard rows: zeros in B)
+    const int ty = tap / p.K, tx = tap - ty * p.K, pad = (p.K - 1) / 2;
+    const long long aoff = (long long)(ty - pad) * p.Wp + (tx - pad);
+    // wave 0 / 1: A rows 0-15 / 16-31 of a K-tile, wave 2 / 3: B rows 0-15 / 16-31
+    const int ld = wave < 2 ? p.Ci : p.Cj;
+    const unsigned short* mine = wave < 2 ? p.A + (t0 + aoff + (wave & 1) * 16) * p.Ci + i0 : p.B + (t0 + (wave & 1) * 16) * p.Cj + j0;
+    unsigned voff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = i * RPI + lane / (ROWB / 16), slot = lane % (ROWB / 16), c = slot ^ (2 * (row & 3));
+        voff[i] = (unsigned)(((long long)row * ld + c * 8) * 2);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto issue = [&](int kt, int stage) {
+        const unsigned short* g = mine + (long long)kt * 32 * ld;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) glds16w(g, voff[i], lds0 + stage * STAGE + wave * PLANE + i * 1024);
+    };
+    f32x16 acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // lane l of an MFMA operand: column (l & 31) of the 32-wide tile, k-half g = l >> 5 (rows 8g .. 8g+7 of a 16-row plane).  Its 16-lane group
+    // q = l >> 4 covers columns 16 (q & 1) .. +15; inside the group lane i = l & 15 SUPPLIES the address of row 8g + 4r + i / 4, columns
+    // 4 (i % 4) .. +3 of the group's 16 (8 bytes) and RECEIVES rows 8g + 4r .. +3 of column i.
+    unsigned a_addr[T][2], b_addr[T][2];
+    {
+        const int q = lane >> 4, i = lane & 15, g = q >> 1;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = 8 * g + 4 * r + (i >> 2);
+                const int ca = wm * (BM / 2) + t * 32 + 16 * (q & 1) + 4 * (i & 3), cb = wn * (BM / 2) + t * 32 + 16 * (q & 1) + 4 * (i & 3);
+                a_addr[t][r] = (unsigned)(row * ROWB + (((ca >> 3) ^ (2 * (row & 3))) * 16) + (ca & 7) * 2);
+                b_addr[t][r] = (unsigned)(row * ROWB + (((cb >> 3) ^ (2 * (row & 3))) * 16) + (cb & 7) * 2);
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t) if (t < nkt) issue(t, t);
+    int stage = 0, pre = S - 1;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + S - 2 < nkt) { if (NI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else if (kt + 1 < nkt) { if (NI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + S - 1 < nkt) issue(kt + S - 1, pre);
+        const unsigned sb = lds0 + stage * STAGE;
+        // (all transposing reads and their wait in ONE asm statement: the compiler treats an asm's outputs as ready when the statement ends)
+        bf16x8 a0[T], a1[T], b0[T], b1[T];
+        if constexpr (T == 2) {
+            u32x2 r[16];
+            asm volatile(
+                "ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %17\n\tds_read_b64_tr_b16 %2, %18\n\tds_read_b64_tr_b16 %3, %19\n\t"
+                "ds_read_b64_tr_b16 %4, %16 offset:4096\n\tds_read_b64_tr_b16 %5, %17 offset:4096\n\tds_read_b64_tr_b16 %6, %18 offset:4096\n\tds_read_b64_tr_b16 %7, %19 offset:4096\n\t"
+                "ds_read_b64_tr_b16 %8, %20 offset:8192\n\tds_read_b64_tr_b16 %9, %21 offset:8192\n\tds_read_b64_tr_b16 %10, %22 offset:8192\n\tds_read_b64_tr_b16 %11, %23 offset:8192\n\t"
+                "ds_read_b64_tr_b16 %12, %20 offset:12288\n\tds_read_b64_tr_b16 %13, %21 offset:12288\n\tds_read_b64_tr_b16 %14, %22 offset:12288\n\tds_read_b64_tr_b16 %15, %23 offset:12288\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]),
+                  "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+                : "v"(sb + a_addr[0][0]), "v"(sb + a_addr[0][1]), "v"(sb + a_addr[T - 1][0]), "v"(sb + a_addr[T - 1][1]),
+                  "v"(sb + b_addr[0][0]), "v"(sb + b_addr[0][1]), "v"(sb + b_addr[T - 1][0]), "v"(sb + b_addr[T - 1][1])
+                : "memory");
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                a0[t] = __builtin_bit_cast(bf16x8, (u32x4){r[2 * t][0], r[2 * t][1], r[2 * t + 1][0], r[2 * t + 1][1]});
+                a1[t] = __builtin_bit_cast(bf16x8, (u32x4){r[4 + 2 * t][0], r[4 + 2 * t][1], r[4 + 2 * t + 1][0], r[4 + 2 * t + 1][1]});
+                b0[t] = __builtin_bit_cast(bf16x8, (u32x4){r[8 + 2 * t][0], r[8 + 2 * t][1], r[8 + 2 * t + 1][0], r[8 + 2 * t + 1][1]});
+                b1[t] = __builtin_bit_cast(bf16x8, (u32x4){r[12 + 2 * t][0], r[12 + 2 * t][1], r[12 + 2 * t + 1][0], r[12 + 2 * t + 1][1]});
+            }
+        } else {
+            u32x2 r[8];
+            asm volatile(
+                "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\t"
+                "ds_read_b64_tr_b16 %2, %8 offset:2048\n\tds_read_b64_tr_b16 %3, %9 offset:2048\n\t"
+                "ds_read_b64_tr_b16 %4, %10 offset:4096\n\tds_read_b64_tr_b16 %5, %11 offset:4096\n\t"
+                "ds_read_b64_tr_b16 %6, %10 offset:6144\n\tds_read_b64_tr_b16 %7, %11 offset:6144\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                : "v"(sb + a_addr[0][0]), "v"(sb + a_addr[0][1]), "v"(sb + b_addr[0][0]), "v"(sb + b_addr[0][1])
+                : "memory");
+            a0[0] = __builtin_bit_cast(bf16x8, (u32x4){r[0][0], r[0][1], r[1][0], r[1][1]});
+            a1[0] = __builtin_bit_cast(bf16x8, (u32x4){r[2][0], r[2][1], r[3][0], r[3][1]});
+            b0[0] = __builtin_bit_cast(bf16x8, (u32x4){r[4][0], r[4][1], r[5][0], r[5][1]});
+            b1[0] = __builtin_bit_cast(bf16x8, (u32x4){r[6][0], r[6][1], r[7][0], r[7][1]});
+        }
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            }
+        stage = stage + 1 == S ? 0 : stage + 1; pre = pre + 1 == S ? 0 : pre + 1;
+    }
+    float* C = p.C + (long long)tap * p.Ci * p.Cj + (long long)ys * p.split_stride;
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = j0 + wn * (BM / 2) + j * 32 + (lane & 31);
+                if (p.plain_store) C[(long long)row * p.Cj + col] = acc[i][j][r];
+                else unsafeAtomicAdd(C + (long long)row * p.Cj + col, acc[i][j][r]);
+            }
+}
+
+// dW (K*K x Ci x Cj fp32, TensorFlow's HWIO) is ASSIGNED.  A / B point at padded pixel 0 of their buffers (guard rows in front of it).
+bool launch_wgrad_bf16(const Bf16WgradArgs& a0, hipStream_t s)
+{
+    Bf16WgradArgs a = a0;
+    if (a.Ci % 64 || a.Cj % 64 || (a.K & 1) == 0 || a.R < 1) return false;
+    const int bm = (a.Ci % 128 == 0 && a.Cj % 128 == 0) ? 128 : 64;
+    const int taps = a.K * a.K;
+    const long long tiles = (long long)(a.Ci / bm) * (a.Cj / bm) * taps;
+    const long long slots = 256LL * (bm == 128 ? 2 : 4);
+    long long want = (2 * slots + tiles - 1) / tiles;            // about two rounds of resident blocks
+    const long long maxsplit = (a.R + 1023) / 1024;              // at least 32 K-tiles per block
+    if (want > maxsplit) want = maxsplit;
+    if (want < 1) want = 1;
+    long long chunk = ((a.R + want - 1) / want + 31) / 32 * 32;
+    const int nsplit = (int)((a.R + chunk - 1) / chunk);
+    a.chunk = chunk;
+    const long long slab = (long long)taps * a.Ci * a.Cj;
+    float* out = a.C;
+    a.split_stride = 0; a.plain_store = nsplit == 1;
+    if (nsplit > 1) {
+        if (t_deterministic) {
+            float* ws = det_scratch(s, (size_t)(nsplit * slab));
+            if (!ws) { fprintf(stderr, "fcn8s: deterministic mode: scratch allocation failed\n"); abort(); }
+            a.C = ws; a.split_stride = slab; a.plain_store = 1;
+        } else hipMemsetAsync(out, 0, (size_t)slab * sizeof(float), s);
+    }
+    dim3 grid((unsigned)((tiles / taps) * nsplit), 1, (unsigned)taps);
+    if (bm == 128) { g_last_kernel = "wgrad_bf16_kernel<128>"; hipLaunchKernelGGL(wgrad_bf16_kernel<128>, grid, dim3(256), 0, s, a); }
+    else { g_last_kernel = "wgrad_bf16_kernel<64>"; hipLaunchKernelGGL(wgrad_bf16_kernel<64>, grid, dim3(256), 0, s, a); }
+    if (a.split_stride) launch_det_reduce(out, a.C, 1, (int)slab, (int)slab, slab, nsplit, false, s);
     return true;
 }
 

@@ -122,6 +122,12 @@ struct fcn8s_model {
     // bf16 modes, training: zero-bordered padded bf16 copies of the inputs of conv3_1 .. conv5_3, one per layer (the border is written once, at
     // allocation; the interior every step by that layer's Winograd input transform, wino_input_kernel<.., XB>); keyed by layer, dropped with the workspace
     std::map<std::string, unsigned short*> xbf16;
+    // FCN8S_PREC_BF16_TRAIN: per layer, the zero-bordered bf16 copy of its INPUT with zeroed guard rows in front and behind (bf16_guard_rows), written by
+    // the forward pass and read again by the layer's weight gradient; one shared buffer of the same kind for the output gradient dY that a layer's
+    // weight gradient converts and its data gradient reads again (dyb_src = the fp32 tensor it was made from)
+    std::map<std::string, unsigned short*> xg16; std::map<std::string, size_t> xg16_elems;
+    unsigned short* d_dyb = nullptr; size_t dyb_elems = 0; const float* dyb_src = nullptr; int dyb_shape[5] = {0, 0, 0, 0, 0};
+    int saved_wino_min_cin = -1, saved_wino_fc6 = -1;                      // the options the mode overrides (the direct path carries it), restored on leaving
     int bf16_copy_by_transform = 1;                                       // option: 0 = every bf16 layer converts its input with a pass of its own (round 3's path)
     hipStream_t stream = nullptr;
     int64_t step = 0;
@@ -325,6 +331,11 @@ int split_of(const fcn8s_model* m)
     return 0;
 }
 static inline bool bf16_fwd_mode(const fcn8s_model* m) { return m->precision == FCN8S_PREC_BF16_FWD || m->precision == FCN8S_PREC_BF16_FWD_X2; }
+static inline bool bf16_train_mode(const fcn8s_model* m) { return m && m->precision == FCN8S_PREC_BF16_TRAIN; }
+// guard rows of a padded bf16 copy that the weight-gradient kernel reads (gemm_bf16.hip): the largest tap shift + one K-tile of rounding
+static inline long long bf16_guard_rows(int K, int Wp) { return (long long)((K - 1) / 2) * Wp + (K - 1) / 2 + 32; }
+unsigned short* dyb_for(fcn8s_model* m, const float* dy, int N, int H, int W, int C, int K, hipStream_t s, bool reuse);
+
 int wino_tile_for(const fcn8s_model* m, int H, int W, int K = 3)
 {
     if (!m || H % 2 || W % 2) return 0;
@@ -402,6 +413,27 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
                int N, int H, int W, int Cin, int Cout, int K, const Epi& e, hipStream_t s, int real_cin = 0,
                const char* layer = nullptr)
 {
+    if (bf16_train_mode(m) && m->train_mode && e.w_fwd && layer && !real_cin && e.alpha == 1.f && !e.bias && !e.relu && !e.dropout && Cin % 32 == 0 && Cout % 64 == 0) {
+        // FCN8S_PREC_BF16_TRAIN, data gradient of `layer` (here Cin = channels of dY, Cout = channels of dX): the SAME convolution of the padded bf16
+        // copy of dY with the flipped kernel, wt[ci][(flipped tap, co)] bf16, on conv_bf16_256_kernel; fp32 accumulate, fp32 epilogue (skip-path addend,
+        // the ReLU / dropout mask of the layer's input).  w_fwd is the forward kernel [K][K][Cout here][Cin here].
+        const size_t wneed = (size_t)K * K * Cin * Cout;
+        bool ok = true;
+        if (m->wbf16_elems < wneed) {
+            if (m->d_wbf16) { hipStreamSynchronize(s); hipFree(m->d_wbf16); m->d_wbf16 = nullptr; m->wbf16_elems = 0; }
+            if (hipMalloc((void**)&m->d_wbf16, wneed * sizeof(unsigned short)) != hipSuccess) { (void)hipGetLastError(); ok = false; } else m->wbf16_elems = wneed;
+        }
+        unsigned short* dyb = ok ? dyb_for(m, x, N, H, W, Cin, K, s, true) : nullptr;
+        if (dyb) {
+            { ProfScope ps(m, "weight_relayout", 0, 6.0 * wneed); launch_w_to_bf16_flip_t(e.w_fwd, m->d_wbf16, K, Cout, Cin, s); }
+            Bf16Conv256Args g{};
+            g.xp = dyb; g.wt = m->d_wbf16; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K;
+            g.addend = e.addend; g.mask = e.mask; g.mask_scale = e.mask_scale; g.any_shape = 1;
+            const double M = (double)N * H * W;
+            ProfScope ps(m, K == 1 ? "fc7_dgrad_bf16" : (K == 3 ? "conv3x3_dgrad_bf16" : "fc6_dgrad_bf16"), 2.0 * M * K * K * Cin * Cout, 4.0 * M * Cout * (e.mask ? 2.0 : 1.0) + 2.0 * M * Cin + 2.0 * wneed, layer);
+            if (launch_conv_bf16_256(g, s)) return false;
+        }
+    }
     const bool wino3 = m && K == 3 && m->wino_min_cin > 0 && Cin >= m->wino_min_cin && m->d_wino_v && wino_tile_for(m, H, W, 3) && !e.dropout;
     const bool wino7 = m && K == 7 && m->wino_fc6 && m->d_wino_v && wino_tile_for(m, H, W, 7) == 4;
     if (m && wino3 && e.dgrad && layer && e.w_fwd && !m->dm_layer.empty() && m->dm_layer == layer && wino_tile_for(m, H, W, 3) == 6 &&
@@ -647,6 +679,27 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
     const double rc = a.Areal;
     const double flops = 2.0 * a.P * K * K * rc * Cout;
     const double bytes = 4.0 * (a.P * rc + (double)a.P * Cout + (double)K * K * rc * Cout);
+    if (bf16_train_mode(m) && m->train_mode && layer && !real_cin && alpha == 1.f && Cin % 64 == 0 && Cout % 64 == 0) {
+        // FCN8S_PREC_BF16_TRAIN: dW[tap] = (padded bf16 input, moved by the tap)^T (padded bf16 dY), fp32 accumulate (gemm_bf16.hip: wgrad_bf16_kernel);
+        // the bias gradient is the exact fp32 column sum of dY
+        auto it = m->xg16.find(layer);
+        if (it != m->xg16.end() && it->second) {
+            const int pad = (K - 1) / 2, Wp_ = W + 2 * pad;
+            const long long G = bf16_guard_rows(K, Wp_), R = (long long)N * (H + 2 * pad) * Wp_;
+            unsigned short* dyb = dyb_for(m, dz, N, H, W, Cout, K, s, false);
+            if (dyb) {
+                Bf16WgradArgs g{};
+                g.A = it->second + G * Cin; g.B = dyb; g.C = dw; g.R = R; g.Ci = Cin; g.Cj = Cout; g.K = K; g.Wp = Wp_;
+                bool done;
+                { ProfScope ps(m, K == 1 ? "fc7_wgrad_bf16" : (K == 3 ? "conv3x3_wgrad_bf16" : "fc6_wgrad_bf16"), flops, 2.0 * K * K * R * (Cin + Cout) + 4.0 * K * K * Cin * Cout, layer);
+                  done = launch_wgrad_bf16(g, s); }
+                if (done) {
+                    if (db) { ProfScope ps(m, "colsum", 0, 4.0 * a.P * Cout); launch_colsum(dz, db, a.P, Cout, s); }
+                    return;
+                }
+            }
+        }
+    }
     if (m && (K == 3 || K == 7) && layer && alpha == 1.f && !real_cin && m->train_mode) {
         auto it = m->acts.find(std::string("wv:") + layer);
         if (it != m->acts.end() && m->d_wino_m) {             // weight gradient in the Winograd domain (V kept by the forward pass)
@@ -740,6 +793,8 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
     if (m->arena) { hipStreamSynchronize(m->stream); hipFree(m->arena); m->arena = nullptr; }
     for (auto& kv : m->xbf16) if (kv.second) hipFree(kv.second);
     m->xbf16.clear();
+    for (auto& kv : m->xg16) if (kv.second) hipFree(kv.second);
+    m->xg16.clear(); m->xg16_elems.clear(); m->dyb_src = nullptr;
     m->plan_N = N;                 // the batch size the per-layer Winograd tiles are chosen for (wino_tile_for), from here until the next re-plan
     m->acts.clear();
     m->have_forward = m->have_loss = false;
@@ -988,11 +1043,12 @@ bool pool_backward_fused(const fcn8s_model* m, int b, bool pooled_by_transform)
 // takes the shape (the caller then uses the fp32 path).
 bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const char* bname, const float* in, float* out,
                      int N, int h, int w, int cin, int cout, int k, int drop, float keep_prob, uint32_t stream_id, hipStream_t s, bool allow_small = true,
-                     const unsigned short* xb_ready = nullptr)          // the padded bf16 copy of `in`, already made (256 x 256 kernel only)
+                     const unsigned short* xb_ready = nullptr,          // the padded bf16 copy of `in`, already made (256 x 256 kernel only)
+                     bool any_shape = false)                            // bf16_train: 64- / 128-column tiles and a partial last row tile are taken too
 {
     const int K = k * k * cin;
     const long long Mrows = (long long)N * h * w;
-    const bool big = conv_bf16_256_ok(Mrows, cin, cout, m->bf16_gemm256);      // 256 x 256 tiles, LDS-DMA, staggered wave groups
+    const bool big = conv_bf16_256_ok(Mrows, cin, cout, any_shape ? 3 : m->bf16_gemm256);      // 256-row tiles, LDS-DMA, staggered wave groups
     if (!big && (!allow_small || cin % 32 || cout % 128)) return false;
     const size_t wneed = (size_t)K * cout;
     if (m->wbf16_elems < wneed) {
@@ -1024,7 +1080,7 @@ bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const c
         Bf16Conv256Args g{};
         g.xp = xb_ready ? xb_ready : m->d_abf16; g.wt = wbuf; g.bias = Wp(m, bname); g.y = out;
         g.N = N; g.H = h; g.W = w; g.Cin = cin; g.Cout = cout; g.K = k;
-        g.relu = 1; g.dropout = drop; g.keep_prob = keep_prob; g.seed = m->seed; g.stream_id = stream_id;
+        g.relu = 1; g.dropout = drop; g.keep_prob = keep_prob; g.seed = m->seed; g.stream_id = stream_id; g.any_shape = any_shape ? 1 : 0; g.mask_scale = 1.f;
         ProfScope ps(m, tag, 2.0 * M * K * cout, 4.0 * M * cout + 2.0 * M * cin + 2.0 * K * cout);
         if (launch_conv_bf16_256(g, s)) return true;
     }
@@ -1039,6 +1095,45 @@ bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const c
     a.relu = 1; a.dropout = drop; a.keep_prob = keep_prob; a.seed = m->seed; a.stream_id = stream_id;
     ProfScope ps(m, tag, 2.0 * M * K * cout, 4.0 * M * (cin + cout) + 2.0 * K * cout);
     return launch_conv_bf16(a, s);
+}
+
+// bf16_train: the guarded, zero-bordered bf16 copy of layer `layer`'s input (allocated and zeroed on first use or when the shape grows); returns the
+// address of padded pixel 0 (the guard rows lie in front of it) or nullptr
+unsigned short* xg16_for(fcn8s_model* m, const char* layer, int N, int H, int W, int C, int K, hipStream_t s)
+{
+    const int pad = (K - 1) / 2, Wp_ = W + 2 * pad;
+    const long long G = bf16_guard_rows(K, Wp_), R = (long long)N * (H + 2 * pad) * Wp_;
+    const size_t need = (size_t)(R + 2 * G) * C;
+    unsigned short*& p = m->xg16[layer];
+    size_t& have = m->xg16_elems[layer];
+    if (!p || have < need) {
+        if (p) { hipStreamSynchronize(s); hipFree(p); p = nullptr; have = 0; }
+        if (hipMalloc((void**)&p, need * sizeof(unsigned short)) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return nullptr; }
+        have = need;
+        hipMemsetAsync(p, 0, need * sizeof(unsigned short), s);
+    }
+    return p + G * C;
+}
+// bf16_train: the padded bf16 copy of an output gradient dY [N][H][W][C] for a K x K layer, made once per tensor (the layer's weight gradient
+// converts, its data gradient finds it); returns the address of padded pixel 0
+unsigned short* dyb_for(fcn8s_model* m, const float* dy, int N, int H, int W, int C, int K, hipStream_t s, bool reuse)
+{
+    const int pad = (K - 1) / 2, Wp_ = W + 2 * pad;
+    const long long G = bf16_guard_rows(K, Wp_), R = (long long)N * (H + 2 * pad) * Wp_;
+    const size_t need = (size_t)(R + 2 * G) * C;
+    const int shape[5] = {N, H, W, C, K};
+    if (reuse && m->d_dyb && m->dyb_src == dy && !memcmp(shape, m->dyb_shape, sizeof shape)) return m->d_dyb + G * C;
+    if (m->dyb_elems < need) {
+        if (m->d_dyb) { hipStreamSynchronize(s); hipFree(m->d_dyb); m->d_dyb = nullptr; m->dyb_elems = 0; }
+        if (hipMalloc((void**)&m->d_dyb, need * sizeof(unsigned short)) != hipSuccess) { m->d_dyb = nullptr; (void)hipGetLastError(); return nullptr; }
+        m->dyb_elems = need;
+    }
+    // (the buffer serves every layer: its guard rows are another layer's pixels, so they are zeroed per use)
+    hipMemsetAsync(m->d_dyb, 0, (size_t)G * C * sizeof(unsigned short), s);
+    hipMemsetAsync(m->d_dyb + (G + R) * C, 0, (size_t)G * C * sizeof(unsigned short), s);
+    { ProfScope ps(m, "bf16_convert", 0, 4.0 * N * H * W * C + 2.0 * R * C); launch_f32_to_bf16_padded(dy, m->d_dyb + G * C, N, H, W, C, pad, s); }
+    m->dyb_src = dy; memcpy(m->dyb_shape, shape, sizeof shape);
+    return m->d_dyb + G * C;
 }
 
 // bf16 modes, training: the layer's Winograd input transform (run for the weight gradient anyway) can write the padded bf16 copy its direct
@@ -1147,7 +1242,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 e.skip_y = !train || pool_backward_fused(m, b + 1, true);
             }
             char nxt[32] = "";
-            if (m->fuse_out_in && !first && i < kConvsPerBlock[b] && !(bf16_fwd_mode(m) && b >= 2) && (!train || e.relu_bits_out) &&
+            if (m->fuse_out_in && !first && i < kConvsPerBlock[b] && !(bf16_fwd_mode(m) && b >= 2) && !bf16_train_mode(m) && (!train || e.relu_bits_out) &&
                 m->wino_min_cin > 0 && cin >= m->wino_min_cin && m->widths[b] >= m->wino_min_cin && m->widths[b] % 64 == 0 && cin % 16 == 0 &&
                 m->d_wino_v && wino_tile_for(m, h, w, 3) == 6) {
                 // this conv and the next one both run through F(6x6,3x3) on the same tile grid: its output transform writes the next conv's
@@ -1160,7 +1255,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 if (!train || it != m->acts.end()) { e.next_v = it != m->acts.end() ? it->second.p : m->d_wino_v; e.next_layer = nxt; }
             }
             bool done = false;
-            if (first && m->conv1_in_transform && m->widths[0] == 64 && kConvsPerBlock[0] == 2 && m->widths[0] >= m->wino_min_cin && m->wino_min_cin > 0 &&
+            if (first && !bf16_train_mode(m) && m->conv1_in_transform && m->widths[0] == 64 && kConvsPerBlock[0] == 2 && m->widths[0] >= m->wino_min_cin && m->wino_min_cin > 0 &&
                 m->d_wino_v && wino_tile_for(m, h, w, 3) == 6) {
                 // conv1_1's only reader is conv1_2's F(6x6,3x3) input transform: that transform evaluates conv1_1 on its own patches, straight from the
                 // image (winograd.hip: wino_input_conv1_kernel), writes conv1_2's V -- into the buffer conv_same will look for it in -- and, in training,
@@ -1180,6 +1275,14 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
             if (!done && first && m->widths[0] == 64) {            // conv1_1: write-bound gather kernel (igemm.hip: conv1_glds_kernel)
                 ProfScope ps(m, "conv1_1_fwd", 2.0 * N * h * w * 27.0 * m->widths[0], 4.0 * N * h * w * (3.0 + m->widths[0]), nm);
                 done = launch_conv1_fwd(x, m->d_w1pad, e.bias, A(m, nm), m->d_w1pad + 12 * 4 * (size_t)m->widths[0], N, h, w, m->widths[0], m->conv1_tiled, s);
+            }
+            if (!done && bf16_train_mode(m) && !first) {
+                // FCN8S_PREC_BF16_TRAIN: every convolution but conv1_1 (3 input channels) as a direct convolution with bf16-rounded operands; the
+                // training pass keeps the layer's padded bf16 input copy for its weight gradient (the convolution starts from that copy)
+                unsigned short* xb = train ? xg16_for(m, nm, N, h, w, cin, 3, s) : nullptr;
+                if (xb) { ProfScope ps(m, "bf16_convert", 0, 4.0 * N * h * w * cin + 2.0 * N * (h + 2) * (w + 2) * cin); launch_f32_to_bf16_padded(x, xb, N, h, w, cin, 1, s); }
+                done = bf16_conv_layer(m, "conv3x3_fwd_bf16", (std::string(nm) + "/filter").c_str(), (std::string(nm) + "/biases").c_str(), x, A(m, nm),
+                                       N, h, w, cin, m->widths[b], 3, 0, 1.f, 0, s, /*allow_small=*/false, xb, /*any_shape=*/true);
             }
             if (!done && bf16_fwd_mode(m) && b >= 2) {
                 // FCN8S_PREC_BF16_FWD: conv3_1 .. conv5_3 as direct convolutions with bf16-rounded operands on the 256 x 256 bf16 kernel (the
@@ -1221,7 +1324,16 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     const int h5 = h, w5 = w;
     const bool drop = train && keep_prob < 1.f;
     m->drop_stream = (uint32_t)(2 * m->step);
-    if (m->precision == FCN8S_PREC_BF16_FC || bf16_fwd_mode(m)) {
+    if (bf16_train_mode(m)) {
+        unsigned short* xb6 = train ? xg16_for(m, "fc6", N, h5, w5, m->widths[4], m->fc6k, s) : nullptr;
+        if (xb6) { ProfScope ps(m, "bf16_convert", 0, 6.0 * N * h5 * w5 * m->widths[4]); launch_f32_to_bf16_padded(x, xb6, N, h5, w5, m->widths[4], (m->fc6k - 1) / 2, s); }
+        if (!bf16_conv_layer(m, "fc6_fwd_bf16", "fc6/weights", "fc6/biases", x, A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, drop, keep_prob, m->drop_stream, s, false, xb6, true))
+            return fail(m, FCN8S_ERR_SHAPE, "bf16_train: fc6 does not fit the bf16 convolution kernel");
+        unsigned short* xb7 = train ? xg16_for(m, "fc7", N, h5, w5, m->widths[5], 1, s) : nullptr;
+        if (xb7) { ProfScope ps(m, "bf16_convert", 0, 6.0 * N * h5 * w5 * m->widths[5]); launch_f32_to_bf16_padded(A(m, "fc6"), xb7, N, h5, w5, m->widths[5], 0, s); }
+        if (!bf16_conv_layer(m, "fc7_fwd_bf16", "fc7/weights", "fc7/biases", A(m, "fc6"), A(m, "fc7"), N, h5, w5, m->widths[5], m->widths[6], 1, drop, keep_prob, m->drop_stream + 1, s, false, xb7, true))
+            return fail(m, FCN8S_ERR_SHAPE, "bf16_train: fc7 does not fit the bf16 convolution kernel");
+    } else if (m->precision == FCN8S_PREC_BF16_FC || bf16_fwd_mode(m)) {
         // config 5: bf16-rounded operands, fp32 accumulate, fp32 epilogue and output (gemm_bf16.hip)
         bf16_conv_layer(m, "fc6_fwd_bf16", "fc6/weights", "fc6/biases", x, A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, drop, keep_prob, m->drop_stream, s);
         // the fp32 gradients of fc6 run in the Winograd domain and want the transformed input and this step's filter bank
@@ -1366,7 +1478,7 @@ void backward_head(fcn8s_model* m)
         m->deferred.emplace_back(ev, [m, dz7, N, h5, w5](hipStream_t ss) {
             conv_wgrad(m, "fc7_wgrad", A(m, "fc6"), dz7, Gp(m, "fc7/weights"), Gp(m, "fc7/biases"), N, h5, w5, m->widths[5], m->widths[6], 1, 1.f, ss); });
     } else {
-        conv_wgrad(m, "fc7_wgrad", A(m, "fc6"), dz7, Gp(m, "fc7/weights"), Gp(m, "fc7/biases"), N, h5, w5, m->widths[5], m->widths[6], 1, 1.f, s);
+        conv_wgrad(m, "fc7_wgrad", A(m, "fc6"), dz7, Gp(m, "fc7/weights"), Gp(m, "fc7/biases"), N, h5, w5, m->widths[5], m->widths[6], 1, 1.f, s, 0, "fc7");
         mark_bucket_final(m, 0, s);
     }
     m->dz7_cur = dz7; m->defer_fc_cur = defer_fc;
@@ -1380,8 +1492,8 @@ void backward_fc6(fcn8s_model* m)
     const int h5 = H / 32, w5 = W / 32;
     const float inv_keep = (m->train_mode && m->keep_prob < 1.f) ? 1.f / m->keep_prob : 1.f;
     float* dz7 = m->dz7_cur; const bool defer_fc = m->defer_fc_cur;
-    { Epi e; e.mask = A(m, "fc6"); e.mask_scale = inv_keep;
-      conv_same(m, "fc7_dgrad", dz7, WTp(m, "fc7/weights"), m->gbuf[1], N, h5, w5, m->widths[6], m->widths[5], 1, e, s); }
+    { Epi e; e.mask = A(m, "fc6"); e.mask_scale = inv_keep; e.w_fwd = Wp(m, "fc7/weights");      // (w_fwd + the layer name: the bf16_train branch of conv_same)
+      conv_same(m, "fc7_dgrad", dz7, WTp(m, "fc7/weights"), m->gbuf[1], N, h5, w5, m->widths[6], m->widths[5], 1, e, s, 0, "fc7"); }
     // fc6
     if (defer_fc && m->acts.count("dmk:fc6") && m->acts.count("wv:fc6") && m->u_train.count("fc6#4")) {
         float* dz6 = m->gbuf[1];
@@ -1669,6 +1781,8 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->d_wbf16) hipFree(m->d_wbf16);
     if (m->d_abf16) hipFree(m->d_abf16);
     for (auto& kv : m->xbf16) if (kv.second) hipFree(kv.second);
+    for (auto& kv : m->xg16) if (kv.second) hipFree(kv.second);
+    if (m->d_dyb) hipFree(m->d_dyb);
     for (int i = 0; i < 3; ++i) if (m->d_tph[i]) hipFree(m->d_tph[i]);
     if (m->d_loss) hipFree(m->d_loss);
     if (m->h_loss) hipHostFree(m->h_loss);
@@ -1717,8 +1831,12 @@ int fcn8s_freeze_params(fcn8s_model* m, int frozen)
 int fcn8s_set_precision(fcn8s_model* m, int precision)
 {
     if (!m) return FCN8S_ERR_BAD_ARG;
-    if (precision < FCN8S_PREC_F32 || precision > FCN8S_PREC_BF16_FWD_X2)
+    if (precision < FCN8S_PREC_F32 || precision > FCN8S_PREC_BF16_TRAIN)
         return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_precision: unknown precision");
+    if (precision == FCN8S_PREC_BF16_TRAIN) {
+        for (int i = 0; i < 7; ++i)
+            if (m->widths[i] % 64) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_precision: the bf16_train mode needs every channel width to be a multiple of 64");
+    }
     if (precision == FCN8S_PREC_BF16_FC || precision == FCN8S_PREC_BF16_FWD || precision == FCN8S_PREC_BF16_FWD_X2) {
         if (m->widths[4] % 32 || m->widths[5] % 128 || m->widths[6] % 128)
             return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_precision: the bf16 modes need conv5 width % 32 == 0 and fc6 / fc7 widths % 128 == 0");
@@ -1732,6 +1850,18 @@ int fcn8s_set_precision(fcn8s_model* m, int precision)
         drop_u_cache(m);
         for (auto& kv : m->xbf16) if (kv.second) hipFree(kv.second);      // (the padded bf16 activation copies of the bf16 forward modes)
         m->xbf16.clear();
+        for (auto& kv : m->xg16) if (kv.second) hipFree(kv.second);
+        m->xg16.clear(); m->xg16_elems.clear(); m->dyb_src = nullptr;
+        // bf16_train runs every convolution but conv1_1 as a DIRECT convolution on the bf16 MFMA, forward and backward: it rides on the library's
+        // direct path (no Winograd transforms, the pools as kernels of their own, ReLU masks from the activations), i.e. on the settings
+        // winograd_min_cin = 0 / winograd_fc6 = 0, which it takes over while it is on (and which need another workspace)
+        const bool was = m->precision == FCN8S_PREC_BF16_TRAIN, now = precision == FCN8S_PREC_BF16_TRAIN;
+        if (was != now) {
+            if (now) { m->saved_wino_min_cin = m->wino_min_cin; m->saved_wino_fc6 = m->wino_fc6; m->wino_min_cin = 0; m->wino_fc6 = 0; }
+            else { if (m->saved_wino_min_cin >= 0) m->wino_min_cin = m->saved_wino_min_cin; if (m->saved_wino_fc6 >= 0) m->wino_fc6 = m->saved_wino_fc6; }
+            if (m->arena) { hipFree(m->arena); m->arena = nullptr; m->arena_bytes = 0; m->N = m->H = m->W = 0; m->acts.clear(); }
+            m->have_forward = m->have_loss = false;
+        }
     }
     m->precision = precision;
     return FCN8S_OK;
@@ -2658,6 +2788,54 @@ int fcn8s_op_conv2d_bf16(void* stream, const float* x, const float* w, const flo
     a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K = K; a.relu = relu;
     launch_conv_bf16(a, s);
     hipStreamSynchronize(s); hipFree(wt);
+    OPCHK(); return FCN8S_OK;
+}
+
+// One K x K SAME convolution in the arithmetic of FCN8S_PREC_BF16_TRAIN on the kernels that mode runs (gemm_bf16.hip): any of y (forward, + bias,
+// optional ReLU), dx (data gradient of dy, optional mask: dx = mask > 0 ? dx : 0), dw / db (weight / bias gradient) may be NULL.
+int fcn8s_op_conv2d_bf16_train(void* stream, const float* x, const float* w, const float* bias, float* y, int relu,
+                               const float* dy, const float* mask, float* dx, float* dw, float* db,
+                               int N, int H, int W, int Cin, int Cout, int K)
+{
+    if (Cin % 64 || Cout % 64 || K % 2 == 0) return fail(nullptr, FCN8S_ERR_BAD_ARG, "conv2d_bf16_train: needs Cin % 64 == 0, Cout % 64 == 0, K odd");
+    hipStream_t s = (hipStream_t)stream;
+    const int pad = (K - 1) / 2, Wp_ = W + 2 * pad;
+    const long long G = bf16_guard_rows(K, Wp_), R = (long long)N * (H + 2 * pad) * Wp_;
+    unsigned short *xb = nullptr, *dyb = nullptr, *wt = nullptr;
+    auto cleanup = [&]() { hipStreamSynchronize(s); if (xb) hipFree(xb); if (dyb) hipFree(dyb); if (wt) hipFree(wt); };
+    const size_t nx = (size_t)(R + 2 * G) * Cin, ny = (size_t)(R + 2 * G) * Cout, nw = (size_t)K * K * Cin * Cout;
+    if (hipMalloc((void**)&wt, nw * 2) != hipSuccess) { cleanup(); return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc"); }
+    if (x) {
+        if (hipMalloc((void**)&xb, nx * 2) != hipSuccess) { cleanup(); return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc"); }
+        hipMemsetAsync(xb, 0, nx * 2, s);
+        launch_f32_to_bf16_padded(x, xb + G * Cin, N, H, W, Cin, pad, s);
+    }
+    if (dy) {
+        if (hipMalloc((void**)&dyb, ny * 2) != hipSuccess) { cleanup(); return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc"); }
+        hipMemsetAsync(dyb, 0, ny * 2, s);
+        launch_f32_to_bf16_padded(dy, dyb + G * Cout, N, H, W, Cout, pad, s);
+    }
+    bool ok = true;
+    if (y && x && w) {
+        launch_w_to_bf16_t(w, wt, K * K * Cin, Cout, s);
+        Bf16Conv256Args g{};
+        g.xp = xb + G * Cin; g.wt = wt; g.bias = bias; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K; g.relu = relu; g.any_shape = 1; g.mask_scale = 1.f;
+        ok = ok && launch_conv_bf16_256(g, s);
+    }
+    if (dx && dy && w) {
+        launch_w_to_bf16_flip_t(w, wt, K, Cin, Cout, s);
+        Bf16Conv256Args g{};
+        g.xp = dyb + G * Cout; g.wt = wt; g.y = dx; g.N = N; g.H = H; g.W = W; g.Cin = Cout; g.Cout = Cin; g.K = K; g.mask = mask; g.mask_scale = 1.f; g.any_shape = 1;
+        ok = ok && launch_conv_bf16_256(g, s);
+    }
+    if (dw && x && dy) {
+        Bf16WgradArgs g{};
+        g.A = xb + G * Cin; g.B = dyb + G * Cout; g.C = dw; g.R = R; g.Ci = Cin; g.Cj = Cout; g.K = K; g.Wp = Wp_;
+        ok = ok && launch_wgrad_bf16(g, s);
+    }
+    if (db && dy) { hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), s); launch_colsum(dy, db, (long long)N * H * W, Cout, s); }
+    cleanup();
+    if (!ok) return fail(nullptr, FCN8S_ERR_SHAPE, "conv2d_bf16_train: a launch refused the shape");
     OPCHK(); return FCN8S_OK;
 }
 

@@ -407,11 +407,14 @@ class Engine:
         bf16 MFMA with each fp32 operand split exactly into three bf16 pieces: fp32 accuracy, not bit-identical to fp32) or
         'bf16_fwd' (config 5 taken further: conv3_1 .. conv5_3, fc6 and fc7 forward with bf16-rounded operands, every other GEMM
         in the f32x3 arithmetic: all matrix work on the bf16 MFMA); 'f32x2' / 'bf16_fwd_x2' = 'f32x3' / 'bf16_fwd' with two bf16
-        pieces per operand instead of three (16 significand bits enter each product: reduced precision, half the matrix work)."""
+        pieces per operand instead of three (16 significand bits enter each product: reduced precision, half the matrix work);
+        'bf16_train' = mixed-precision training as it is usually meant: conv1_2 .. conv5_3, fc6 and fc7 as direct convolutions whose operands are
+        rounded to bf16 in the forward pass, the data gradient AND the weight gradient (fp32 accumulate, fp32 master weights, everything else
+        exact fp32; no Winograd transforms)."""
         modes = {'fp32': L.PREC_F32, 'bf16_fc': L.PREC_BF16_FC, 'f32x3': L.PREC_F32X3, 'bf16_fwd': L.PREC_BF16_FWD,
-                 'f32x2': L.PREC_F32X2, 'bf16_fwd_x2': L.PREC_BF16_FWD_X2}
+                 'f32x2': L.PREC_F32X2, 'bf16_fwd_x2': L.PREC_BF16_FWD_X2, 'bf16_train': L.PREC_BF16_TRAIN}
         if precision not in modes:
-            raise ValueError("`precision` must be 'fp32', 'bf16_fc', 'f32x3', 'bf16_fwd', 'f32x2' or 'bf16_fwd_x2', but is '{}'.".format(precision))
+            raise ValueError("`precision` must be 'fp32', 'bf16_fc', 'f32x3', 'bf16_fwd', 'f32x2', 'bf16_fwd_x2' or 'bf16_train', but is '{}'.".format(precision))
         L.check(L.lib.fcn8s_set_precision(self.h, modes[precision]), self.h)
         self.precision = precision
 

@@ -70,6 +70,11 @@ extern "C" {
 #define FCN8S_PREC_BF16_FWD_X2 5   /* BF16_FWD with the F32X2 arithmetic in place of F32X3 for every GEMM that is not a bf16 forward convolution
                                      (conv1_2 / conv2_x forward, all data and weight gradients): config 5's "bf16 fwd / fp32 accum" with 16-bit
                                      operands in the backward pass */
+#define FCN8S_PREC_BF16_TRAIN 6    /* BASELINE.json config 5 with the backward pass on the bf16 pipe as well (round 5): every convolution
+                                    * but conv1_1 -- conv1_2 .. conv5_3, fc6, fc7 -- is a DIRECT convolution whose operands are rounded to bf16 (RNE), products and
+                                    * sums fp32: forward y = conv(bf16 x, bf16 w); data gradient dx = conv^T(bf16 dy, bf16 w); weight gradient
+                                    * dw = corr(bf16 x, bf16 dy); bias gradient, ReLU / dropout masks, pools, the loss, the decoder and the optimizer exact fp32
+                                    * on fp32 master weights.  No Winograd transform runs in this mode.  Needs channel widths % 64 == 0. */
 
 typedef struct fcn8s_model fcn8s_model;
 
@@ -347,6 +352,12 @@ int fcn8s_op_conv3x3_winograd_fwd_bwd(void* stream, const float* x, const float*
  * Cin % 32 == 0, Cout % 128 == 0, K odd */
 int fcn8s_op_conv2d_bf16(void* stream, const float* x, const float* w_hwio, const float* bias, float* y,
                          int N, int H, int W, int Cin, int Cout, int K, int relu);
+/* One K x K SAME convolution in the arithmetic of FCN8S_PREC_BF16_TRAIN, on the kernels that mode runs: forward y = conv(bf16 x, bf16 w) + bias (ReLU if
+ * relu), data gradient dx = conv^T(bf16 dy, bf16 w) (masked by `mask` > 0 if given), weight gradient dw = corr(bf16 x, bf16 dy), bias gradient
+ * db = sum dy.  Any of y, dx, dw, db may be NULL (then x / dy / w are only needed for what is asked).  Cin, Cout % 64 == 0, K odd. */
+int fcn8s_op_conv2d_bf16_train(void* stream, const float* x, const float* w_hwio, const float* bias, float* y, int relu,
+                               const float* dy, const float* mask, float* dx, float* dw, float* db,
+                               int N, int H, int W, int Cin, int Cout, int K);
 int fcn8s_op_conv2d_bwd(void* stream, const float* x, const float* w_hwio, const float* dy,
                         float* dx, float* dw, float* db,
                         int N, int H, int W, int Cin, int Cout, int K);

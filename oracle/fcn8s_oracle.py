@@ -239,11 +239,42 @@ def _conv_bf16_value(x, w, b):
     return z + (conv2d_same_t(_bf16_round(x), _bf16_round(w), b.detach()) - z).detach()
 
 
-def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False, branches=None, routes=None, bf16_convs=False, stats=None):
+class _ConvBf16Train(torch.autograd.Function):
+    """SAME conv + bias in the arithmetic of the library's bf16_train mode (FCN8S_PREC_BF16_TRAIN, include/fcn8s_hip.h): BOTH operands of each of the
+    three products are rounded to bfloat16 (round to nearest even), products and sums are fp32 --
+        forward          y  = conv(bf16 x, bf16 w) + b
+        data gradient    dx = conv^T(bf16 dy, bf16 w)
+        weight gradient  dw = corr(bf16 x, bf16 dy)          bias gradient  db = sum dy   (exact)
+    -- i.e. mixed-precision training on fp32 master weights (the rounding of x and w is straight-through)."""
+
+    @staticmethod
+    def forward(ctx, x, w_hwio, b):
+        xr, wr = _bf16_round(x), _bf16_round(w_hwio).permute(3, 2, 0, 1).contiguous()
+        k = w_hwio.shape[0]
+        ctx.save_for_backward(xr, wr)
+        ctx.k = k
+        return F.conv2d(xr, wr, b, padding=(k - 1) // 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, wr = ctx.saved_tensors
+        dyr, p = _bf16_round(dy), (ctx.k - 1) // 2
+        dx = torch.nn.grad.conv2d_input(xr.shape, wr, dyr, padding=p)
+        dw = torch.nn.grad.conv2d_weight(xr, wr.shape, dyr, padding=p)
+        return dx, dw.permute(2, 3, 1, 0).contiguous(), dy.sum((0, 2, 3))
+
+
+def _conv_bf16_train(x, w, b):
+    return _ConvBf16Train.apply(x, w, b)
+
+
+def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False, branches=None, routes=None, bf16_convs=False, stats=None, bf16_train=False):
     """Forward pass on torch tensors.  P: name -> torch tensor (TF layouts).
     images_t: NHWC RGB float.  masks: optional (mask6, mask7) NHWC tensors.
     bf16_fc: BASELINE config 5 -- both operands of the fc6 / fc7 contractions rounded to bfloat16, fp32 accumulate.
     bf16_convs: the same for the forward convolutions conv3_1 .. conv5_3 (FCN8S_PREC_BF16_FWD; implies nothing about fc6 / fc7).
+    bf16_train: FCN8S_PREC_BF16_TRAIN -- conv1_2 .. conv5_3, fc6 and fc7 with bf16-rounded operands in the forward pass AND in both gradients
+    (_ConvBf16Train); overrides bf16_fc / bf16_convs.
     branches: optional name -> 0/1 NCHW tensor ("conv1_1" ... for the convs that feed another conv, "pool1".."pool5" for each block's
     last conv + pool, "fc6", "fc7"): the ReLU branches to take instead of this restatement's own (see _relu_branch).
     routes: optional "pool1".."pool5" -> int64 (N,C,h/2,w/2) tensor of max-pool routes (see _pool_routed); takes the place of that
@@ -259,7 +290,8 @@ def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False,
             n = "conv%d_%d" % (blk, i)
             routed = routes is not None and ("pool%d" % blk) in routes
             pooled_branch = i == nconv and (routed or (branches is not None and ("pool%d" % blk) in branches))
-            z = (_conv_bf16_value if (bf16_convs and blk >= 3) else conv2d_same_t)(x, P[n + "/filter"], P[n + "/biases"])
+            conv = _conv_bf16_train if (bf16_train and not (blk == 1 and i == 1)) else (_conv_bf16_value if (bf16_convs and blk >= 3) else conv2d_same_t)
+            z = conv(x, P[n + "/filter"], P[n + "/biases"])
             # (a block's last conv: max(relu(z)) = relu(max(z)), so its branch record lives on the pooled tensor)
             x = z if pooled_branch else _relu_branch(z, n, branches, stats)
             if keep:
@@ -278,11 +310,17 @@ def forward_t(P, images_t, keep_prob=1.0, masks=None, keep=False, bf16_fc=False,
     m6 = m7 = None
     if masks is not None:
         m6, m7 = (_nchw(m) for m in masks)
-    x = _fc_conv(x, P["fc6/weights"], P["fc6/biases"], bf16_fc, "fc6", branches, stats)
+    if bf16_train:
+        x = _relu_branch(_conv_bf16_train(x, P["fc6/weights"], P["fc6/biases"]), "fc6", branches, stats)
+    else:
+        x = _fc_conv(x, P["fc6/weights"], P["fc6/biases"], bf16_fc, "fc6", branches, stats)
     x = dropout_t(x, keep_prob, m6)
     if keep:
         acts["fc6"] = x
-    x = _fc_conv(x, P["fc7/weights"], P["fc7/biases"], bf16_fc, "fc7", branches, stats)
+    if bf16_train:
+        x = _relu_branch(_conv_bf16_train(x, P["fc7/weights"], P["fc7/biases"]), "fc7", branches, stats)
+    else:
+        x = _fc_conv(x, P["fc7/weights"], P["fc7/biases"], bf16_fc, "fc7", branches, stats)
     x = dropout_t(x, keep_prob, m7)
     if keep:
         acts["fc7"] = x
@@ -316,12 +354,12 @@ def _params_t(params, dtype, requires_grad=False):
     return OrderedDict((k, _t(v, dtype).requires_grad_(requires_grad)) for k, v in params.items())
 
 
-def forward(params, images, keep_prob=1.0, masks=None, dtype=torch.float32, keep=False, bf16_fc=False, bf16_convs=False):
+def forward(params, images, keep_prob=1.0, masks=None, dtype=torch.float32, keep=False, bf16_fc=False, bf16_convs=False, bf16_train=False):
     """numpy front-end.  Returns logits NHWC (and activations NHWC if keep)."""
     with torch.no_grad():
         P = _params_t(params, dtype)
         mt = None if masks is None else tuple(_t(m, dtype) for m in masks)
-        out = forward_t(P, _t(images, dtype), keep_prob, mt, keep, bf16_fc, bf16_convs=bf16_convs)
+        out = forward_t(P, _t(images, dtype), keep_prob, mt, keep, bf16_fc, bf16_convs=bf16_convs, bf16_train=bf16_train)
         if keep:
             logits, acts = out
             return _nhwc(logits).contiguous().numpy(), {k: _nhwc(v).contiguous().numpy() for k, v in acts.items()}
@@ -357,7 +395,7 @@ def pool_routes(acts):
 
 
 def loss_and_grads(params, images, labels_onehot, l2_rate=0.0, keep_prob=1.0, masks=None,
-                   dtype=torch.float32, bf16_fc=False, branches=None, routes=None, bf16_convs=False, stats=None):
+                   dtype=torch.float32, bf16_fc=False, branches=None, routes=None, bf16_convs=False, stats=None, bf16_train=False):
     """total_loss and d(total_loss)/d(every variable) -- what
     AdamOptimizer.minimize differentiates (var_list=None, :257).
     stats: optional dict filled with the alignment record of `branches` / `routes` (forward_t).
@@ -367,7 +405,7 @@ def loss_and_grads(params, images, labels_onehot, l2_rate=0.0, keep_prob=1.0, ma
     mt = None if masks is None else tuple(_t(m, dtype) for m in masks)
     bt = None if branches is None else {k: _nchw(_t(np.asarray(v) > 0, dtype)) for k, v in branches.items()}
     rt = None if routes is None else {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v).transpose(0, 3, 1, 2))).to(torch.int64) for k, v in routes.items()}
-    logits = forward_t(P, _t(images, dtype), keep_prob, mt, bf16_fc=bf16_fc, branches=bt, routes=rt, bf16_convs=bf16_convs, stats=stats)
+    logits = forward_t(P, _t(images, dtype), keep_prob, mt, bf16_fc=bf16_fc, branches=bt, routes=rt, bf16_convs=bf16_convs, stats=stats, bf16_train=bf16_train)
     loss = total_loss_t(P, logits, _t(labels_onehot, dtype), l2_rate)
     grads = torch.autograd.grad(loss, list(P.values()))
     return (float(loss.detach()),

@@ -582,6 +582,93 @@ def test_bf16_fc_256_tile_kernel():
     assert abs(outs[2][4] - loss_dref) < 1e-3 * max(1.0, abs(loss_dref))
 
 
+def test_bf16_train_mode():
+    """FCN8S_PREC_BF16_TRAIN ('bf16_train'): conv1_2 .. conv5_3, fc6 and fc7 as direct convolutions with bf16-rounded operands in
+    the forward pass, the data gradient and the weight gradient (fp32 accumulate; conv1_1, pools, decoder, loss exact fp32; no Winograd transform
+    anywhere) -- against the oracle in the same arithmetic (`bf16_train=True`: _ConvBf16Train).  A network whose widths are multiples of 64, two
+    64 x 96 images (row counts 12 288 .. 12 per layer: whole and partial row tiles of the convolution kernel, split and unsplit weight gradients):
+      (1) each layer's forward arithmetic exactly: the device's output against the same-rounding convolution of the DEVICE's own input (1e-4);
+      (2) end to end: activations and logits against the oracle to 2e-2 of their range (inputs that differ by fp32 round-off cross bf16
+          rounding boundaries: a 2^-8 step per crossing);
+      (3) all gradients against the oracle's along the device's ReLU / pool decisions to 5e-2 in L2 (the kernels' own arithmetic is held to 1e-5 by
+          tests/test_ops_gpu.py::test_conv_bf16_train_kernels; what is left here is those boundary crossings, now also in dY);
+      (4) the kernels that ran: conv_bf16_256_kernel<64|128|256> and wgrad_bf16_kernel, no Winograd kernel, no fp32 position GEMM;
+      (5) a training step runs, and leaving the mode gives back the fp32 predictions of an engine that never entered it."""
+    import torch
+    from fcn8s_tensorflow_amd.engine import Engine
+    widths = (64, 64, 128, 256, 256, 256, 128)
+    n, h, w = 2, 64, 96
+    P = orc.init_params(20, widths, seed=9, decoder_std_scale=6.0, bias_std=0.05)
+    img, lab = batch(n, h, w, seed=31)
+    e = Engine(20, widths=widths, precision="bf16_train")
+    e.set_params(P)
+    e.profile(2); e.profile_reset()
+    onehot = orc.one_hot(lab, 20)
+    loss = e.forward_backward(img, onehot, keep_prob=1.0, l2_rate=1e-3)
+    prof = e.profile_results()
+    e.profile(0)
+    kernels = {k[7:]: int(v["launches"]) for k, v in prof.items() if k.startswith("kernel:")}
+    assert sum(v for k, v in kernels.items() if "conv_bf16_256_kernel" in k) == 14 + 14, kernels          # 14 forward convolutions + 14 data gradients (none of either for conv1_1)
+    assert sum(v for k, v in kernels.items() if "wgrad_bf16_kernel" in k) == 14, kernels
+    assert {k for k in kernels if "conv_bf16_256_kernel" in k} >= {"conv_bf16_256_kernel<64>", "conv_bf16_256_kernel<128>", "conv_bf16_256_kernel<256>"}, kernels
+    assert not any("wino" in k or "gemm_glds" in k or "wgrad_glds" in k for k in kernels), kernels
+    logits = e.activation("logits", (n, h, w, 20))
+    # (1) per layer, the device's own input
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    wd = widths
+    shp = lambda name, d, c: (n, h >> d, w >> d, c)
+    layers = [("conv1_1", "conv1_2", shp("", 0, wd[0]), shp("", 0, wd[0]), "conv1_2/filter", "conv1_2/biases"),
+              ("pool1", "conv2_1", shp("", 1, wd[0]), shp("", 1, wd[1]), "conv2_1/filter", "conv2_1/biases"),
+              ("conv3_1", "conv3_2", shp("", 2, wd[2]), shp("", 2, wd[2]), "conv3_2/filter", "conv3_2/biases"),
+              ("conv5_2", "conv5_3", shp("", 4, wd[4]), shp("", 4, wd[4]), "conv5_3/filter", "conv5_3/biases"),
+              ("pool5", "fc6", shp("", 5, wd[4]), shp("", 5, wd[5]), "fc6/weights", "fc6/biases"),
+              ("fc6", "fc7", shp("", 5, wd[5]), shp("", 5, wd[6]), "fc7/weights", "fc7/biases")]
+    for src, dst, sshape, dshape, wname, bname in layers:
+        x = torch.from_numpy(e.activation(src, sshape)).permute(0, 3, 1, 2)
+        wk = torch.from_numpy(P[wname]); k = wk.shape[0]
+        want = torch.relu(torch.nn.functional.conv2d(rb(x), rb(wk).permute(3, 2, 0, 1), torch.from_numpy(P[bname]), padding=(k - 1) // 2)).permute(0, 2, 3, 1).numpy()
+        got = e.activation(dst, dshape)
+        assert rel(got, want) < 1e-4, (dst, rel(got, want))
+    # (2) end to end
+    ref, acts = orc.forward(P, img, keep=True, bf16_train=True)
+    scale = max(1.0, float(np.abs(ref).max()))
+    for k in ("conv1_2", "conv3_1", "conv4_2", "pool5", "fc7"):
+        assert rel(e.activation(k, acts[k].shape), acts[k]) < 2e-2, (k, rel(e.activation(k, acts[k].shape), acts[k]))
+    assert np.abs(logits - ref).max() < 2e-2 * scale
+    ref32 = orc.forward(P, img)
+    cost = float(np.abs(ref - ref32).max()) / scale
+    assert 1e-5 < cost < 1e-1, cost
+    assert np.abs(logits - ref32).max() > 0.2 * np.abs(ref - ref32).max()
+    # (3) gradients along the device's decisions
+    g = e.get_grads()
+    br, rt, stats = device_decisions(e, P, img, (n, h, w), relu_tol=3e-2, tie_tol=3e-2, max_frac=5e-3, bf16_train=True)
+    loss_ref, g_ref, _ = orc.loss_and_grads(P, img, onehot.astype(np.float32), l2_rate=1e-3, bf16_train=True, branches=br, routes=rt)
+    _, g_32, _ = orc.loss_and_grads(P, img, onehot.astype(np.float32), l2_rate=1e-3, branches=br, routes=rt)
+    assert abs(loss - loss_ref) < 2e-2 * max(1.0, abs(loss_ref))
+    worst = ("", 0.0)
+    for k in g_ref:
+        gk, rk = np.asarray(g[k], np.float64), np.asarray(g_ref[k], np.float64)
+        l2 = float(np.linalg.norm(gk - rk) / (np.linalg.norm(rk) + 1e-30))
+        if l2 > worst[1]:
+            worst = (k, l2)
+        assert l2 < 5e-2, (k, l2)
+    d32 = max(float(np.linalg.norm(np.asarray(g_ref[k], np.float64) - g_32[k]) / (np.linalg.norm(g_32[k]) + 1e-30)) for k in g_ref)
+    print("bf16_train: worst gradient tensor %s %.2e in L2 against the same-arithmetic oracle (that oracle is %.2e from the fp32 graph's gradients); %s" % (worst[0], worst[1], d32, stats))
+    # (5)
+    loss2, step = e.train_step(img, lab, 1e-6, keep_prob=0.5)
+    assert step == 1 and np.isfinite(loss2)
+    assert e.get_option("winograd_min_cin") == 0
+    e.set_precision('fp32')
+    assert e.get_option("winograd_min_cin") == 64 and e.get_option("winograd_fc6") == 1
+    e.set_params(P)
+    a = e.predict(img, argmax=False)
+    e2 = Engine(20, widths=widths); e2.set_params(P)
+    np.testing.assert_array_equal(a, e2.predict(img, argmax=False))
+    e.close(); e2.close()
+    with pytest.raises(Exception):
+        Engine(20, widths=SMALL, precision="bf16_train")            # widths that are not multiples of 64
+
+
 @pytest.mark.parametrize("mode", ["bf16_fwd", "bf16_fwd_x2"])
 def test_bf16_fwd_mode(mode):
     """FCN8S_PREC_BF16_FWD_X2 ('bf16_fwd_x2') is the same mode with two bf16 pieces per operand instead of three in the non-bf16 GEMMs (16

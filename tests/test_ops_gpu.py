@@ -219,6 +219,65 @@ def test_conv_bf16_mfma(N, H, W, Cin, Cout, K):
         L.check(L.lib.fcn8s_op_conv2d_bf16(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), N, H, W, Cin, Cout + 4, K, 1))
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,K", [
+    (2, 16, 32, 64, 64, 3),        # the 64-column tile of the convolution kernel, the 64 x 64 tile of the weight gradient (conv1_2's shape class)
+    (1, 20, 24, 64, 128, 3),       # 480 rows: a partial last row tile; 128-column tile forward, 64-column tile for the data gradient (conv2_1)
+    (1, 16, 16, 128, 64, 3),
+    (2, 8, 8, 256, 256, 3),        # 256-column tiles, 128 x 128 weight-gradient tiles
+    (1, 8, 16, 512, 256, 3),
+    (1, 64, 64, 64, 64, 3),        # 4356 padded rows: the weight gradient's row range is split over several blocks
+    (3, 4, 8, 64, 128, 7),         # fc6's kernel size: guard rows of 3 * Wp + 3 + 32
+    (2, 4, 4, 128, 256, 1),        # fc7: a plain GEMM, no padding
+])
+def test_conv_bf16_train_kernels(N, H, W, Cin, Cout, K):
+    """The three products of FCN8S_PREC_BF16_TRAIN on the kernels that mode runs (fcn8s_op_conv2d_bf16_train -> conv_bf16_256_kernel<64|128|256> for
+    the forward pass and the data gradient, wgrad_bf16_kernel<64|128> for the weight gradient): against float64 evaluations of the SAME bf16-rounded
+    operands the only difference is fp32 summation order (1e-5 of the result's largest entry); the bias gradient is the exact fp32 column sum.
+    Against the unrounded float64 results the rounding must be visible (the kernels really ran in bf16)."""
+    L = _lib()
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((K, K, Cin, Cout)) / np.sqrt(K * K * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    dy = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    mask = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    rb = lambda a: torch.tensor(a).to(torch.bfloat16).double()
+    nchw = lambda t: t.permute(0, 3, 1, 2)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).numpy()
+    pad = (K - 1) // 2
+    xr, wr, dyr = nchw(rb(x)), rb(w).permute(3, 2, 0, 1), nchw(rb(dy))
+    y_ref = nhwc(torch.relu(torch.nn.functional.conv2d(xr, wr, torch.tensor(b).double(), padding=pad)))
+    dx_ref = nhwc(torch.nn.grad.conv2d_input(xr.shape, wr, dyr, padding=pad)) * (mask > 0)
+    dw_ref = torch.nn.grad.conv2d_weight(xr, wr.shape, dyr, padding=pad).permute(2, 3, 1, 0).numpy()
+    db_ref = dy.astype(np.float64).sum((0, 1, 2))
+    dw_exact = torch.nn.grad.conv2d_weight(nchw(torch.tensor(x).double()), wr.shape, nchw(torch.tensor(dy).double()), padding=pad).permute(2, 3, 1, 0).numpy()
+    xd, wd, bd, dyd, md = dev(x), dev(w), dev(b), dev(dy), dev(mask)
+    y_, dx_ = torch.empty(N, H, W, Cout).cuda(), torch.empty(N, H, W, Cin).cuda()
+    dw_, db_ = torch.full((K, K, Cin, Cout), 7.0).cuda(), torch.full((Cout,), 7.0).cuda()      # (garbage: the gradients are assigned, not accumulated)
+    L.check(L.lib.fcn8s_op_conv2d_bf16_train(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), 1, ptr(dyd), ptr(md), ptr(dx_), ptr(dw_), ptr(db_), N, H, W, Cin, Cout, K))
+    torch.cuda.synchronize()
+    assert rel_err(y_.cpu().numpy(), y_ref) < 1e-5
+    assert rel_err(dx_.cpu().numpy(), dx_ref) < 1e-5
+    assert rel_err(dw_.cpu().numpy(), dw_ref) < 1e-5
+    assert rel_err(db_.cpu().numpy(), db_ref) < 1e-5
+    assert 1e-5 < rel_err(dw_.cpu().numpy(), dw_exact) < 3e-2
+    # deterministic mode: the split weight gradient through slabs, bit-identical from run to run and equal to the default to round-off
+    L.check(L.lib.fcn8s_set_option(None, b"op_deterministic", 1))
+    try:
+        outs = []
+        for _ in range(2):
+            t = torch.empty(K, K, Cin, Cout).cuda()
+            L.check(L.lib.fcn8s_op_conv2d_bf16_train(None, ptr(xd), None, None, None, 0, ptr(dyd), None, None, ptr(t), None, N, H, W, Cin, Cout, K))
+            torch.cuda.synchronize()
+            outs.append(t.cpu().numpy())
+    finally:
+        L.check(L.lib.fcn8s_set_option(None, b"op_deterministic", 0))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    assert rel_err(outs[0], dw_ref) < 1e-5
+    with pytest.raises(ValueError):
+        L.check(L.lib.fcn8s_op_conv2d_bf16_train(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), 1, None, None, None, None, None, N, H, W, Cin + 32, Cout, K))
+
+
 @pytest.mark.parametrize("N,H,W,C", [(2, 8, 8, 64), (1, 4, 6, 8), (1, 32, 64, 128)])
 def test_maxpool(N, H, W, C):
     L = _lib()
