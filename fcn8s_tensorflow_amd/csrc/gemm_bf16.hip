@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const Bf16ConvArgs p)
 // Lab, random data in [-1, 1): 1040-1065 TFLOP/s at fc7's shape, 940 at fc6's (the 128 x 128 kernel below: 680 / 880 in the model).  The same
 // loop without its loads reaches 1200, its MFMAs alone 1320 -- the data-dependent power ceiling of the bf16 pipe (guide 5.4 rule 25), not 2500.
 namespace {
-constexpr int G_BM = 256, G_BN = 256, G_BK = 32, G_S = 5, G_ROWB = G_BK * 2, G_ABYTES = G_BM * G_ROWB;
+constexpr int G_BM = 256, G_BN = 256, G_BK = 32, G_ROWB = G_BK * 2, G_ABYTES = G_BM * G_ROWB;
 
 static __device__ __forceinline__ void glds16b(const void* sbase, unsigned voff, unsigned lds_byte_off)
 {
@@ -309,14 +309,18 @@ void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H,
 // rows: waves whose chunks lie beyond it issue no B loads (the vmcnt accounting is per wave: NB = its number of B instructions).
 // Rows m >= M (a partial last row tile) read row 0's window and are not stored.  Epilogue: bias, ReLU, dropout as before; for the data gradients an
 // optional addend (the skip path's gradient) and the ReLU mask of the layer input (`mask` > 0, an fp32 activation tensor of the output's shape).
+// Stages: five for BN = 256 (all 160 KB of LDS, one block per CU, the round-3 kernel); four / three for BN = 64 / 128 (80 / 72 KB: TWO blocks per CU, so
+// that one block's prologue and its 64 - 128 KB epilogue run under the other's K loop -- with 18 .. 36 K-tiles per tile in the 64- and 128-channel
+// layers that is a third of a block's life).
 template <int BN>
-__global__ __launch_bounds__(512, 1) void conv_bf16_256_kernel(const Bf16Conv256Args p)
+__global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(const Bf16Conv256Args p)
 {
+    constexpr int NS = BN == 256 ? 5 : (BN == 128 ? 3 : 4);                       // LDS stages; NS - 1 K-tiles in flight
     constexpr int WR = BN == 256 ? 1 : (BN == 128 ? 2 : 4), WCN = 4 / WR;         // waves of a group: WR along rows x WCN along columns
     constexpr int TM = 4 / WR, TN = 2;                                            // 32 x 32 accumulator tiles per wave
     constexpr int STAGE = (G_BM + BN) * G_ROWB;
     static_assert(WCN * 64 == BN, "a wave owns 64 columns");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[G_S * STAGE];       // 160 / 120 / 100 KB
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];        // 160 / 72 / 80 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3, wr = wq / WCN, wn = wq % WCN;
     const unsigned ntm = (unsigned)((p.M + G_BM - 1) / G_BM), ntn = (unsigned)(p.Cout / BN);
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_256_kernel(const Bf16Conv256
     // K-tiles are issued strictly in order, one call per tile: the tap position advances incrementally
     int i_kt = 0, i_ci = 0, i_tx = 0, i_ty = 0;
     auto issue = [&]() {
-        const unsigned st = lds0 + (unsigned)((i_kt % G_S) * STAGE);
+        const unsigned st = lds0 + (unsigned)((i_kt % NS) * STAGE);
         const unsigned short* ga = p.xp + ((long long)i_ty * Wp + i_tx) * p.Cin + i_ci;
         const unsigned short* gb = b_base + (long long)i_kt * G_BK;
 #pragma unroll
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_256_kernel(const Bf16Conv256
     for (int tn = 0; tn < TN; ++tn) b_row[tn] = wn * 64 + tn * 32 + (lane & 31);
     bf16x8 af[2][TM], bfr[2][TN];
     auto load_frags = [&](int kt) {
-        const unsigned char* st = smem + (kt % G_S) * STAGE;
+        const unsigned char* st = smem + (kt % NS) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -408,21 +412,21 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_256_kernel(const Bf16Conv256
         else { if (tiles >= 3) wait_vm<6>(); else if (tiles == 2) wait_vm<4>(); else if (tiles == 1) wait_vm<2>(); else wait_vm<0>(); }
     };
 #pragma unroll
-    for (int t = 0; t < G_S - 1; ++t) if (t < nkt) issue();
-    wait_n(nkt > 3 ? 3 : nkt - 1);
+    for (int t = 0; t < NS - 1; ++t) if (t < nkt) issue();
+    wait_n(nkt > NS - 2 ? NS - 2 : nkt - 1);
     __builtin_amdgcn_s_barrier();
     // tick t: group g runs step t - g; even steps read the fragments of K-tile step / 2, odd steps multiply them.  Even ticks 2 j issue the
     // LDS-DMA of K-tile j + 4 (its stage was last read in tick 2 j - 1); odd ticks 2 kt + 1 wait for K-tile kt + 1.  Each group runs its own
     // straight-line loop (one loop with per-tick branches made hipcc copy the accumulators around: 10x slower), and sched_barrier keeps
     // hipcc from hoisting a group's MFMAs above the barrier that opens its MFMA phase.
     auto tick_end = [&]() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
-    auto wait_tile = [&](int kt) {      // this wave's pieces of K-tile kt have landed; up to three newer tiles may still be in flight
+    auto wait_tile = [&](int kt) {      // this wave's pieces of K-tile kt have landed; up to NS - 2 newer tiles may still be in flight
         const int newer = nkt - 1 - kt;
-        wait_n(newer > 3 ? 3 : (newer < 0 ? 0 : newer));
+        wait_n(newer > NS - 2 ? NS - 2 : (newer < 0 ? 0 : newer));
     };
     if (grp == 0) {
         for (int kt = 0; kt < nkt; ++kt) {
-            if (kt + G_S - 1 < nkt) issue();
+            if (kt + NS - 1 < nkt) issue();
             load_frags(kt);
             tick_end();
             mfma_phase();
@@ -431,13 +435,13 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_256_kernel(const Bf16Conv256
         }
         tick_end();
     } else {
-        if (G_S - 1 < nkt) issue();
+        if (NS - 1 < nkt) issue();
         tick_end();
         for (int kt = 0; kt < nkt; ++kt) {
             load_frags(kt);
             wait_tile(kt + 1);
             tick_end();
-            if (kt + G_S < nkt) issue();
+            if (kt + NS < nkt) issue();
             mfma_phase();
             tick_end();
         }
@@ -484,8 +488,12 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
     if ((double)a.N * (a.H + a.K - 1) * (a.W + a.K - 1) * a.Cin * 2.0 >= 4294967296.0 || (double)a.Cout * a.K * a.K * a.Cin * 2.0 >= 4294967296.0) return false;
     const double abytes = 2.0 * a.M * a.K * a.K * a.Cin, bbytes = 2.0 * a.K * a.K * a.Cin * a.Cout;
     a.m_fastest = bbytes > abytes;             // the larger operand's panel stays put behind one XCD's L2 while the other one streams
-    const int bn = a.Cout % 256 == 0 ? 256 : (a.Cout % 128 == 0 ? 128 : 64);
-    const unsigned blocks = (unsigned)(((a.M + G_BM - 1) / G_BM) * (a.Cout / bn));
+    // the widest column tile that divides Cout -- unless that leaves CUs without a block (fc6's data gradient: 32 row tiles x 512 / 256 = 64 blocks for
+    // 200 704-deep dot products): then the narrower tiles, which multiply the block count
+    const long long rt = (a.M + G_BM - 1) / G_BM;
+    int bn = a.Cout % 256 == 0 ? 256 : (a.Cout % 128 == 0 ? 128 : 64);
+    if (a.any_shape) while (bn > 64 && rt * (a.Cout / bn) < 256) bn /= 2;
+    const unsigned blocks = (unsigned)(rt * (a.Cout / bn));
     if (bn == 256) { g_last_kernel = "conv_bf16_256_kernel<256>"; hipLaunchKernelGGL(conv_bf16_256_kernel<256>, dim3(blocks), dim3(512), 0, s, a); }
     else if (bn == 128) { g_last_kernel = "conv_bf16_256_kernel<128>"; hipLaunchKernelGGL(conv_bf16_256_kernel<128>, dim3(blocks), dim3(512), 0, s, a); }
     else { g_last_kernel = "conv_bf16_256_kernel<64>"; hipLaunchKernelGGL(conv_bf16_256_kernel<64>, dim3(blocks), dim3(512), 0, s, a); }

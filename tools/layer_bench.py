@@ -8,7 +8,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16); ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024); ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc", "f32x3", "bf16_fwd", "f32x2", "bf16_fwd_x2"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc", "f32x3", "bf16_fwd", "f32x2", "bf16_fwd_x2", "bf16_train"])
     ap.add_argument("--infer", action="store_true", help="predict() (frozen parameters, argmax) instead of a training step")
     args = ap.parse_args()
     import torch
