@@ -13,6 +13,7 @@
 // Block = 256 threads (4 wave64) -> 128 pixels x 128 couts, wave tile 64 x 64 = 2 x 2 MFMA tiles, 8 MFMAs per wave
 // per K-tile, global -> register -> LDS double buffering with one barrier per K-tile.
 #include "fcn8s_internal.h"
+#include <cstdlib>
 #include <string>
 
 namespace fcn8s {
@@ -668,15 +669,128 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void wgrad_bf16_kernel(cons
             }
 }
 
+// All nine taps of a 3 x 3 layer in ONE block (64 x 64 channel tile): with one tap per block every tap streams both operands again -- for the 64- and
+// 128-channel layers, whose output tiles are tiny and whose row count is huge, that is 9 x (1.08 + 1.08 GB) for conv1_2 at 4 x 2048x1024: the kernel ran
+// at the fabric's rate (3 ms).  Here a K-tile of 32 rows brings the 32 rows of dYp once and, per filter row ty, the 34 rows of Xp that its three taps
+// read (40 are loaded: whole LDS-DMA instructions of 8 rows): row j of group ty is Xp row q0 - 1 + (ty - 1) Wp + j, and tap (ty, tx) of K-tile row r reads
+// group row r + tx.  Nine accumulators (144 VGPRs) per wave, 18 MFMAs per K-tile and wave; 57 KB of LDS in three stages, two blocks per CU.
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_taps9_kernel(const Bf16WgradArgs p)
+{
+    constexpr int S = 3, ROWB = 128, AROWS = 40, AGRP = AROWS * ROWB, STAGE = 3 * AGRP + 32 * ROWB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S * STAGE];
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntj = p.Cj / 64, ntiles = (p.Ci / 64) * ntj;
+    const int tile = blockIdx.x % ntiles, ys = blockIdx.x / ntiles;
+    const int i0 = (tile / ntj) * 64, j0 = (tile % ntj) * 64;
+    const long long t0 = (long long)ys * p.chunk;
+    const long long t1 = t0 + p.chunk < p.R ? t0 + p.chunk : p.R;
+    const int nkt = (int)((t1 - t0 + 31) / 32);
+    // waves 0 .. 2: the A rows of filter row ty = wave (five instructions of 8 rows), wave 3: the B rows (four)
+    const int ld = wave < 3 ? p.Ci : p.Cj;
+    const unsigned short* mine = wave < 3 ? p.A + (t0 - 1 + (long long)(wave - 1) * p.Wp) * p.Ci + i0 : p.B + t0 * p.Cj + j0;
+    unsigned voff[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int row = i * 8 + lane / 8, slot = lane % 8, c = slot ^ (2 * (row & 3));
+        voff[i] = (unsigned)(((long long)row * ld + c * 8) * 2);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto issue = [&](int kt, int stage) {
+        const unsigned short* g = mine + (long long)kt * 32 * ld;
+        const unsigned dst = lds0 + stage * STAGE + wave * AGRP;            // (wave 3: 3 * AGRP = the B image)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16w(g, voff[i], dst + i * 1024);
+        if (wave < 3) glds16w(g, voff[4], dst + 4 * 1024);
+    };
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // lane l of an MFMA operand: column (l & 31) of its 32-wide tile, k-half g = l >> 5; inside its 16-lane group lane i supplies the address of
+    // row 8g + 4r + i / 4 (+ tx for the A operand of tap column tx), columns 4 (i % 4) .. +3 of the group's 16, and receives four k of column i
+    unsigned a_addr[3][2], b_addr[2];
+    {
+        const int q = lane >> 4, i = lane & 15, g = q >> 1;
+        const int ca = wm * 32 + 16 * (q & 1) + 4 * (i & 3), cb = wn * 32 + 16 * (q & 1) + 4 * (i & 3);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = 8 * g + 4 * r + (i >> 2);
+            b_addr[r] = (unsigned)(3 * AGRP + row * ROWB + (((cb >> 3) ^ (2 * (row & 3))) * 16) + (cb & 7) * 2);
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const int j = row + tx;
+                a_addr[tx][r] = (unsigned)(j * ROWB + (((ca >> 3) ^ (2 * (j & 3))) * 16) + (ca & 7) * 2);
+            }
+        }
+    }
+    issue(0, 0);
+    if (nkt > 1) issue(1, 1);
+    int stage = 0, pre = 2;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) { if (wave < 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkt) issue(kt + 2, pre);
+        const unsigned sb = lds0 + stage * STAGE;
+        bf16x8 b[2];
+        {
+            u32x2 r[4];
+            asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %4 offset:2048\n\tds_read_b64_tr_b16 %3, %5 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(sb + b_addr[0]), "v"(sb + b_addr[1]) : "memory");
+            b[0] = __builtin_bit_cast(bf16x8, (u32x4){r[0][0], r[0][1], r[1][0], r[1][1]});
+            b[1] = __builtin_bit_cast(bf16x8, (u32x4){r[2][0], r[2][1], r[3][0], r[3][1]});
+        }
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            const unsigned sa = sb + ty * AGRP;
+            u32x2 r[12];          // [tx][ks][r]
+            asm volatile(
+                "ds_read_b64_tr_b16 %0, %12\n\tds_read_b64_tr_b16 %1, %13\n\tds_read_b64_tr_b16 %2, %12 offset:2048\n\tds_read_b64_tr_b16 %3, %13 offset:2048\n\t"
+                "ds_read_b64_tr_b16 %4, %14\n\tds_read_b64_tr_b16 %5, %15\n\tds_read_b64_tr_b16 %6, %14 offset:2048\n\tds_read_b64_tr_b16 %7, %15 offset:2048\n\t"
+                "ds_read_b64_tr_b16 %8, %16\n\tds_read_b64_tr_b16 %9, %17\n\tds_read_b64_tr_b16 %10, %16 offset:2048\n\tds_read_b64_tr_b16 %11, %17 offset:2048\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11])
+                : "v"(sa + a_addr[0][0]), "v"(sa + a_addr[0][1]), "v"(sa + a_addr[1][0]), "v"(sa + a_addr[1][1]), "v"(sa + a_addr[2][0]), "v"(sa + a_addr[2][1])
+                : "memory");
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, (u32x4){r[4 * tx + 2 * ks][0], r[4 * tx + 2 * ks][1], r[4 * tx + 2 * ks + 1][0], r[4 * tx + 2 * ks + 1][1]});
+                    acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[ks], acc[ty * 3 + tx], 0, 0, 0);
+                }
+        }
+        stage = stage + 1 == S ? 0 : stage + 1; pre = pre + 1 == S ? 0 : pre + 1;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* C = p.C + (long long)t * p.Ci * p.Cj + (long long)ys * p.split_stride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = j0 + wn * 32 + (lane & 31);
+            if (p.plain_store) C[(long long)row * p.Cj + col] = acc[t][r];
+            else unsafeAtomicAdd(C + (long long)row * p.Cj + col, acc[t][r]);
+        }
+    }
+}
+
 // dW (K*K x Ci x Cj fp32, TensorFlow's HWIO) is ASSIGNED.  A / B point at padded pixel 0 of their buffers (guard rows in front of it).
 bool launch_wgrad_bf16(const Bf16WgradArgs& a0, hipStream_t s)
 {
     Bf16WgradArgs a = a0;
     if (a.Ci % 64 || a.Cj % 64 || (a.K & 1) == 0 || a.R < 1) return false;
-    const int bm = (a.Ci % 128 == 0 && a.Cj % 128 == 0) ? 128 : 64;
+    // 3 x 3 layers with at most 128 channels on either side: all nine taps per block (the operands are streamed once instead of nine times);
+    // FCN8S_WGRAD_TAPS9 = 0 never / 2 for every 3 x 3 layer (A/B switch)
+    static const int taps9_mode = getenv("FCN8S_WGRAD_TAPS9") ? atoi(getenv("FCN8S_WGRAD_TAPS9")) : 1;
+    const bool taps9 = a.K == 3 && (taps9_mode == 2 || (taps9_mode == 1 && (a.Ci <= 128 || a.Cj <= 128)));
+    const int bm = taps9 ? 64 : ((a.Ci % 128 == 0 && a.Cj % 128 == 0) ? 128 : 64);
     const int taps = a.K * a.K;
-    const long long tiles = (long long)(a.Ci / bm) * (a.Cj / bm) * taps;
-    const long long slots = 256LL * (bm == 128 ? 2 : 4);
+    const long long tiles = (long long)(a.Ci / bm) * (a.Cj / bm) * (taps9 ? 1 : taps);
+    const long long slots = 256LL * (taps9 ? 2 : (bm == 128 ? 2 : 4));
     long long want = (2 * slots + tiles - 1) / tiles;            // about two rounds of resident blocks
     const long long maxsplit = (a.R + 1023) / 1024;              // at least 32 K-tiles per block
     if (want > maxsplit) want = maxsplit;
@@ -693,6 +807,12 @@ bool launch_wgrad_bf16(const Bf16WgradArgs& a0, hipStream_t s)
             if (!ws) { fprintf(stderr, "fcn8s: deterministic mode: scratch allocation failed\n"); abort(); }
             a.C = ws; a.split_stride = slab; a.plain_store = 1;
         } else hipMemsetAsync(out, 0, (size_t)slab * sizeof(float), s);
+    }
+    if (taps9) {
+        g_last_kernel = "wgrad_bf16_taps9_kernel";
+        hipLaunchKernelGGL(wgrad_bf16_taps9_kernel, dim3((unsigned)(tiles * nsplit)), dim3(256), 0, s, a);
+        if (a.split_stride) launch_det_reduce(out, a.C, 1, (int)slab, (int)slab, slab, nsplit, false, s);
+        return true;
     }
     dim3 grid((unsigned)((tiles / taps) * nsplit), 1, (unsigned)taps);
     if (bm == 128) { g_last_kernel = "wgrad_bf16_kernel<128>"; hipLaunchKernelGGL(wgrad_bf16_kernel<128>, grid, dim3(256), 0, s, a); }

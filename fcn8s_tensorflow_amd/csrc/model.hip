@@ -333,7 +333,8 @@ int split_of(const fcn8s_model* m)
 static inline bool bf16_fwd_mode(const fcn8s_model* m) { return m->precision == FCN8S_PREC_BF16_FWD || m->precision == FCN8S_PREC_BF16_FWD_X2; }
 static inline bool bf16_train_mode(const fcn8s_model* m) { return m && m->precision == FCN8S_PREC_BF16_TRAIN; }
 // guard rows of a padded bf16 copy that the weight-gradient kernel reads (gemm_bf16.hip): the largest tap shift + one K-tile of rounding
-static inline long long bf16_guard_rows(int K, int Wp) { return (long long)((K - 1) / 2) * Wp + (K - 1) / 2 + 32; }
+// (... and, for the nine-tap kernel, the eight-row instruction that completes a 34-row group: 128 rows cover all of it)
+static inline long long bf16_guard_rows(int K, int Wp) { return (long long)((K - 1) / 2) * Wp + (K - 1) / 2 + 128; }
 unsigned short* dyb_for(fcn8s_model* m, const float* dy, int N, int H, int W, int C, int K, hipStream_t s, bool reuse);
 
 int wino_tile_for(const fcn8s_model* m, int H, int W, int K = 3)
