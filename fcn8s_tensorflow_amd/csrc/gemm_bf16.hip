@@ -468,6 +468,36 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
                 p.y[off] = v;
             }
     }
+    // the consumer's padded bf16 copy of this output, written here instead of by a conversion pass of its own (bf16_train): pixel (n, y, x) of the
+    // output is pixel (n, y + pad, x + pad) of a [N][H + 2 pad][W + 2 pad][Cout] buffer whose border was zeroed once and is never written
+    if (p.yb) {
+        const int Hq = p.H + 2 * p.yb_pad, Wq = p.W + 2 * p.yb_pad;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const long long mb = m0 + grp * 128 + wr * (TM * 32) + tm * 32 + 4 * (lane >> 5);
+            const int n = (int)(mb / HW), rem = (int)(mb - (long long)n * HW), y = rem / p.W, x = rem - y * p.W;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = (r & 3) + 8 * (r >> 2);
+                if (mb + o >= p.M) continue;
+                int xx = x + o, yy = y, nn = n;
+                while (xx >= p.W) { xx -= p.W; ++yy; }
+                while (yy >= p.H) { yy -= p.H; ++nn; }
+                const long long q = ((long long)nn * Hq + yy + p.yb_pad) * Wq + xx + p.yb_pad;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
+                    float v = acc[tm][tn][r] + (p.bias ? p.bias[col] : 0.f);
+                    const long long off = (mb + o) * p.Cout + col;
+                    if (p.addend) v += p.addend[off];
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    if (p.mask) v = p.mask[off] > 0.f ? v * p.mask_scale : 0.f;
+                    if (p.dropout) v = philox_uniform((unsigned long long)off, p.seed, p.stream_id) < p.keep_prob ? v / p.keep_prob : 0.f;
+                    reinterpret_cast<__bf16*>(p.yb)[q * p.Cout + col] = (__bf16)v;
+                }
+            }
+        }
+    }
 }
 
 // mode 0 never, 1 when it fills the chip (the round-3 rule, 256-column tiles only), 2 whenever the shapes allow, 3 = 2 with the 128- and 64-column

@@ -126,7 +126,9 @@ struct fcn8s_model {
     // the forward pass and read again by the layer's weight gradient; one shared buffer of the same kind for the output gradient dY that a layer's
     // weight gradient converts and its data gradient reads again (dyb_src = the fp32 tensor it was made from)
     std::map<std::string, unsigned short*> xg16; std::map<std::string, size_t> xg16_elems;
-    unsigned short* d_dyb = nullptr; size_t dyb_elems = 0; const float* dyb_src = nullptr; int dyb_shape[5] = {0, 0, 0, 0, 0};
+    std::map<std::string, unsigned short*> dyg16; std::map<std::string, size_t> dyg16_elems;     // ... per layer: the same kind of copy of its output gradient dY
+    std::set<std::string> xg16_filled, dyg16_filled;                     // copies a producing kernel's epilogue has already written in this pass (no conversion pass)
+    int bf16_fuse_convert = 1;                                            // option: let the producing convolution write its consumer's bf16 copy
     int saved_wino_min_cin = -1, saved_wino_fc6 = -1;                      // the options the mode overrides (the direct path carries it), restored on leaving
     int bf16_copy_by_transform = 1;                                       // option: 0 = every bf16 layer converts its input with a pass of its own (round 3's path)
     hipStream_t stream = nullptr;
@@ -308,6 +310,7 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
              int lazy_wt = 0;                            // data gradient: `w` is still to be filled from w_fwd (flip + transpose) if the adjoint path is not taken
              float* dm_out = nullptr; const char* dm_out_layer = nullptr;   // adjoint data gradient: write dM of the producing layer (name) here instead of its dZ into y
              float* next_v = nullptr; const char* next_layer = nullptr;   // forward, Winograd F(6x6) path: write the NEXT conv's V here instead of this conv's output
+             const char* yb_layer = nullptr; int yb_K = 3; // bf16_train data gradient: the layer whose output gradient this launch produces (its bf16 copy is written on the way), and that layer's kernel size
              int skip_y = 0; };                          // Winograd path with pool_out: do not write the full-resolution output (only its pool is consumed)            // data gradient: the layer's forward kernel [3,3,Cout_of_this_conv... = Cin here][...] (adjoint Winograd path)
 
 // 3x3 SAME conv through Winograd F(tile x tile, 3x3): filter transform, input transform, (tile+2)^2 batched GEMMs
@@ -335,7 +338,8 @@ static inline bool bf16_train_mode(const fcn8s_model* m) { return m && m->precis
 // guard rows of a padded bf16 copy that the weight-gradient kernel reads (gemm_bf16.hip): the largest tap shift + one K-tile of rounding
 // (... and, for the nine-tap kernel, the eight-row instruction that completes a 34-row group: 128 rows cover all of it)
 static inline long long bf16_guard_rows(int K, int Wp) { return (long long)((K - 1) / 2) * Wp + (K - 1) / 2 + 128; }
-unsigned short* dyb_for(fcn8s_model* m, const float* dy, int N, int H, int W, int C, int K, hipStream_t s, bool reuse);
+unsigned short* g16_for(fcn8s_model* m, std::map<std::string, unsigned short*>& bufs, std::map<std::string, size_t>& sizes, const char* layer, int N, int H, int W, int C, int K, hipStream_t s);
+unsigned short* dyb_for(fcn8s_model* m, const char* layer, const float* dy, int N, int H, int W, int C, int K, hipStream_t s);
 
 int wino_tile_for(const fcn8s_model* m, int H, int W, int K = 3)
 {
@@ -424,15 +428,17 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
             if (m->d_wbf16) { hipStreamSynchronize(s); hipFree(m->d_wbf16); m->d_wbf16 = nullptr; m->wbf16_elems = 0; }
             if (hipMalloc((void**)&m->d_wbf16, wneed * sizeof(unsigned short)) != hipSuccess) { (void)hipGetLastError(); ok = false; } else m->wbf16_elems = wneed;
         }
-        unsigned short* dyb = ok ? dyb_for(m, x, N, H, W, Cin, K, s, true) : nullptr;
+        unsigned short* dyb = ok ? dyb_for(m, layer, x, N, H, W, Cin, K, s) : nullptr;
         if (dyb) {
             { ProfScope ps(m, "weight_relayout", 0, 6.0 * wneed); launch_w_to_bf16_flip_t(e.w_fwd, m->d_wbf16, K, Cout, Cin, s); }
             Bf16Conv256Args g{};
             g.xp = dyb; g.wt = m->d_wbf16; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K;
             g.addend = e.addend; g.mask = e.mask; g.mask_scale = e.mask_scale; g.any_shape = 1;
+            // this gradient is the output gradient of layer e.yb_layer (same map): its padded bf16 copy is written by this kernel's epilogue
+            if (e.yb_layer && m->bf16_fuse_convert) { g.yb = g16_for(m, m->dyg16, m->dyg16_elems, e.yb_layer, N, H, W, Cout, e.yb_K, s); g.yb_pad = (e.yb_K - 1) / 2; }
             const double M = (double)N * H * W;
             ProfScope ps(m, K == 1 ? "fc7_dgrad_bf16" : (K == 3 ? "conv3x3_dgrad_bf16" : "fc6_dgrad_bf16"), 2.0 * M * K * K * Cin * Cout, 4.0 * M * Cout * (e.mask ? 2.0 : 1.0) + 2.0 * M * Cin + 2.0 * wneed, layer);
-            if (launch_conv_bf16_256(g, s)) return false;
+            if (launch_conv_bf16_256(g, s)) { if (g.yb) m->dyg16_filled.insert(e.yb_layer); return false; }
         }
     }
     const bool wino3 = m && K == 3 && m->wino_min_cin > 0 && Cin >= m->wino_min_cin && m->d_wino_v && wino_tile_for(m, H, W, 3) && !e.dropout;
@@ -687,7 +693,7 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
         if (it != m->xg16.end() && it->second) {
             const int pad = (K - 1) / 2, Wp_ = W + 2 * pad;
             const long long G = bf16_guard_rows(K, Wp_), R = (long long)N * (H + 2 * pad) * Wp_;
-            unsigned short* dyb = dyb_for(m, dz, N, H, W, Cout, K, s, false);
+            unsigned short* dyb = dyb_for(m, layer, dz, N, H, W, Cout, K, s);
             if (dyb) {
                 Bf16WgradArgs g{};
                 g.A = it->second + G * Cin; g.B = dyb; g.C = dw; g.R = R; g.Ci = Cin; g.Cj = Cout; g.K = K; g.Wp = Wp_;
@@ -795,7 +801,9 @@ int ensure_workspace(fcn8s_model* m, int N, int H, int W)
     for (auto& kv : m->xbf16) if (kv.second) hipFree(kv.second);
     m->xbf16.clear();
     for (auto& kv : m->xg16) if (kv.second) hipFree(kv.second);
-    m->xg16.clear(); m->xg16_elems.clear(); m->dyb_src = nullptr;
+    m->xg16.clear(); m->xg16_elems.clear();
+    for (auto& kv : m->dyg16) if (kv.second) hipFree(kv.second);
+    m->dyg16.clear(); m->dyg16_elems.clear(); m->xg16_filled.clear(); m->dyg16_filled.clear();
     m->plan_N = N;                 // the batch size the per-layer Winograd tiles are chosen for (wino_tile_for), from here until the next re-plan
     m->acts.clear();
     m->have_forward = m->have_loss = false;
@@ -1045,7 +1053,8 @@ bool pool_backward_fused(const fcn8s_model* m, int b, bool pooled_by_transform)
 bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const char* bname, const float* in, float* out,
                      int N, int h, int w, int cin, int cout, int k, int drop, float keep_prob, uint32_t stream_id, hipStream_t s, bool allow_small = true,
                      const unsigned short* xb_ready = nullptr,          // the padded bf16 copy of `in`, already made (256 x 256 kernel only)
-                     bool any_shape = false)                            // bf16_train: 64- / 128-column tiles and a partial last row tile are taken too
+                     bool any_shape = false,                            // bf16_train: 64- / 128-column tiles and a partial last row tile are taken too
+                     unsigned short* yb = nullptr, int yb_pad = 0)      // ... and the consumer's padded bf16 copy of the output is written by the epilogue
 {
     const int K = k * k * cin;
     const long long Mrows = (long long)N * h * w;
@@ -1081,7 +1090,7 @@ bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const c
         Bf16Conv256Args g{};
         g.xp = xb_ready ? xb_ready : m->d_abf16; g.wt = wbuf; g.bias = Wp(m, bname); g.y = out;
         g.N = N; g.H = h; g.W = w; g.Cin = cin; g.Cout = cout; g.K = k;
-        g.relu = 1; g.dropout = drop; g.keep_prob = keep_prob; g.seed = m->seed; g.stream_id = stream_id; g.any_shape = any_shape ? 1 : 0; g.mask_scale = 1.f;
+        g.relu = 1; g.dropout = drop; g.keep_prob = keep_prob; g.seed = m->seed; g.stream_id = stream_id; g.any_shape = any_shape ? 1 : 0; g.mask_scale = 1.f; g.yb = yb; g.yb_pad = yb_pad;
         ProfScope ps(m, tag, 2.0 * M * K * cout, 4.0 * M * cout + 2.0 * M * cin + 2.0 * K * cout);
         if (launch_conv_bf16_256(g, s)) return true;
     }
@@ -1098,16 +1107,17 @@ bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const c
     return launch_conv_bf16(a, s);
 }
 
-// bf16_train: the guarded, zero-bordered bf16 copy of layer `layer`'s input (allocated and zeroed on first use or when the shape grows); returns the
-// address of padded pixel 0 (the guard rows lie in front of it) or nullptr
-unsigned short* xg16_for(fcn8s_model* m, const char* layer, int N, int H, int W, int C, int K, hipStream_t s)
+// bf16_train: a guarded, zero-bordered bf16 buffer for layer `layer` out of `bufs` (allocated and zeroed on first use or when the shape grows: the
+// border and the guard rows are never written again, the interior is overwritten in every pass); returns the address of padded pixel 0 or nullptr
+unsigned short* g16_for(fcn8s_model* m, std::map<std::string, unsigned short*>& bufs, std::map<std::string, size_t>& sizes, const char* layer,
+                        int N, int H, int W, int C, int K, hipStream_t s)
 {
     const int pad = (K - 1) / 2, Wp_ = W + 2 * pad;
     const long long G = bf16_guard_rows(K, Wp_), R = (long long)N * (H + 2 * pad) * Wp_;
     const size_t need = (size_t)(R + 2 * G) * C;
-    unsigned short*& p = m->xg16[layer];
-    size_t& have = m->xg16_elems[layer];
-    if (!p || have < need) {
+    unsigned short*& p = bufs[layer];
+    size_t& have = sizes[layer];
+    if (!p || have != need) {           // (another shape: another border)
         if (p) { hipStreamSynchronize(s); hipFree(p); p = nullptr; have = 0; }
         if (hipMalloc((void**)&p, need * sizeof(unsigned short)) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return nullptr; }
         have = need;
@@ -1115,26 +1125,20 @@ unsigned short* xg16_for(fcn8s_model* m, const char* layer, int N, int H, int W,
     }
     return p + G * C;
 }
-// bf16_train: the padded bf16 copy of an output gradient dY [N][H][W][C] for a K x K layer, made once per tensor (the layer's weight gradient
-// converts, its data gradient finds it); returns the address of padded pixel 0
-unsigned short* dyb_for(fcn8s_model* m, const float* dy, int N, int H, int W, int C, int K, hipStream_t s, bool reuse)
+// the copy of layer `layer`'s INPUT (forward pass; read again by its weight gradient)
+unsigned short* xg16_for(fcn8s_model* m, const char* layer, int N, int H, int W, int C, int K, hipStream_t s) { return g16_for(m, m->xg16, m->xg16_elems, layer, N, H, W, C, K, s); }
+// the copy of layer `layer`'s output gradient dY [N][H][W][C]: written by the kernel that produced dY if that was a bf16 data gradient
+// (dyg16_filled), else converted here, once (the layer's weight gradient asks first, its data gradient finds it)
+unsigned short* dyb_for(fcn8s_model* m, const char* layer, const float* dy, int N, int H, int W, int C, int K, hipStream_t s)
 {
-    const int pad = (K - 1) / 2, Wp_ = W + 2 * pad;
-    const long long G = bf16_guard_rows(K, Wp_), R = (long long)N * (H + 2 * pad) * Wp_;
-    const size_t need = (size_t)(R + 2 * G) * C;
-    const int shape[5] = {N, H, W, C, K};
-    if (reuse && m->d_dyb && m->dyb_src == dy && !memcmp(shape, m->dyb_shape, sizeof shape)) return m->d_dyb + G * C;
-    if (m->dyb_elems < need) {
-        if (m->d_dyb) { hipStreamSynchronize(s); hipFree(m->d_dyb); m->d_dyb = nullptr; m->dyb_elems = 0; }
-        if (hipMalloc((void**)&m->d_dyb, need * sizeof(unsigned short)) != hipSuccess) { m->d_dyb = nullptr; (void)hipGetLastError(); return nullptr; }
-        m->dyb_elems = need;
+    unsigned short* p = g16_for(m, m->dyg16, m->dyg16_elems, layer, N, H, W, C, K, s);
+    if (!p) return nullptr;
+    if (!m->dyg16_filled.count(layer)) {
+        ProfScope ps(m, "bf16_convert", 0, 4.0 * N * H * W * C + 2.0 * N * (H + K - 1) * (W + K - 1) * C);
+        launch_f32_to_bf16_padded(dy, p, N, H, W, C, (K - 1) / 2, s);
+        m->dyg16_filled.insert(layer);
     }
-    // (the buffer serves every layer: its guard rows are another layer's pixels, so they are zeroed per use)
-    hipMemsetAsync(m->d_dyb, 0, (size_t)G * C * sizeof(unsigned short), s);
-    hipMemsetAsync(m->d_dyb + (G + R) * C, 0, (size_t)G * C * sizeof(unsigned short), s);
-    { ProfScope ps(m, "bf16_convert", 0, 4.0 * N * H * W * C + 2.0 * R * C); launch_f32_to_bf16_padded(dy, m->d_dyb + G * C, N, H, W, C, pad, s); }
-    m->dyb_src = dy; memcpy(m->dyb_shape, shape, sizeof shape);
-    return m->d_dyb + G * C;
+    return p;
 }
 
 // bf16 modes, training: the layer's Winograd input transform (run for the weight gradient anyway) can write the padded bf16 copy its direct
@@ -1215,7 +1219,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     const bool fill_fp = m->frozen && m->u_cache.empty();
     if (!m->frozen || fill_fp) prepare_forward_weights(m);        // frozen and the kept banks still valid: so are the padded / phase-packed kernels
     m->fwd_train = train;
-    m->rbits_ok.clear(); m->y_unwritten.clear(); m->fwd_v_layer.clear();
+    m->rbits_ok.clear(); m->y_unwritten.clear(); m->fwd_v_layer.clear(); m->xg16_filled.clear();
     { ProfScope ps(m, "preprocess", 0, (double)N * H * W * (16 + (dtype ? 12 : 3))); launch_preprocess(img_dev, dtype, A(m, "x0"), (long long)N * H * W, s); }
     const float* x = A(m, "x0");
     int h = H, w = W, cin = 4;
@@ -1281,9 +1285,15 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 // FCN8S_PREC_BF16_TRAIN: every convolution but conv1_1 (3 input channels) as a direct convolution with bf16-rounded operands; the
                 // training pass keeps the layer's padded bf16 input copy for its weight gradient (the convolution starts from that copy)
                 unsigned short* xb = train ? xg16_for(m, nm, N, h, w, cin, 3, s) : nullptr;
-                if (xb) { ProfScope ps(m, "bf16_convert", 0, 4.0 * N * h * w * cin + 2.0 * N * (h + 2) * (w + 2) * cin); launch_f32_to_bf16_padded(x, xb, N, h, w, cin, 1, s); }
+                if (xb && !m->xg16_filled.count(nm)) {
+                    ProfScope ps(m, "bf16_convert", 0, 4.0 * N * h * w * cin + 2.0 * N * (h + 2) * (w + 2) * cin); launch_f32_to_bf16_padded(x, xb, N, h, w, cin, 1, s);
+                }
+                // the next convolution of the block reads this output as ITS padded bf16 input: this kernel's epilogue writes that copy
+                unsigned short* yb = nullptr; char nx[32] = "";
+                if (train && m->bf16_fuse_convert && i < kConvsPerBlock[b]) { snprintf(nx, sizeof nx, "conv%d_%d", b + 1, i + 1); yb = xg16_for(m, nx, N, h, w, m->widths[b], 3, s); }
                 done = bf16_conv_layer(m, "conv3x3_fwd_bf16", (std::string(nm) + "/filter").c_str(), (std::string(nm) + "/biases").c_str(), x, A(m, nm),
-                                       N, h, w, cin, m->widths[b], 3, 0, 1.f, 0, s, /*allow_small=*/false, xb, /*any_shape=*/true);
+                                       N, h, w, cin, m->widths[b], 3, 0, 1.f, 0, s, /*allow_small=*/false, xb, /*any_shape=*/true, yb, 1);
+                if (done && yb) m->xg16_filled.insert(nx);
             }
             if (!done && bf16_fwd_mode(m) && b >= 2) {
                 // FCN8S_PREC_BF16_FWD: conv3_1 .. conv5_3 as direct convolutions with bf16-rounded operands on the 256 x 256 bf16 kernel (the
@@ -1328,10 +1338,12 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     if (bf16_train_mode(m)) {
         unsigned short* xb6 = train ? xg16_for(m, "fc6", N, h5, w5, m->widths[4], m->fc6k, s) : nullptr;
         if (xb6) { ProfScope ps(m, "bf16_convert", 0, 6.0 * N * h5 * w5 * m->widths[4]); launch_f32_to_bf16_padded(x, xb6, N, h5, w5, m->widths[4], (m->fc6k - 1) / 2, s); }
-        if (!bf16_conv_layer(m, "fc6_fwd_bf16", "fc6/weights", "fc6/biases", x, A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, drop, keep_prob, m->drop_stream, s, false, xb6, true))
-            return fail(m, FCN8S_ERR_SHAPE, "bf16_train: fc6 does not fit the bf16 convolution kernel");
         unsigned short* xb7 = train ? xg16_for(m, "fc7", N, h5, w5, m->widths[5], 1, s) : nullptr;
-        if (xb7) { ProfScope ps(m, "bf16_convert", 0, 6.0 * N * h5 * w5 * m->widths[5]); launch_f32_to_bf16_padded(A(m, "fc6"), xb7, N, h5, w5, m->widths[5], 0, s); }
+        const bool fuse7 = xb7 && m->bf16_fuse_convert;
+        if (!bf16_conv_layer(m, "fc6_fwd_bf16", "fc6/weights", "fc6/biases", x, A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, drop, keep_prob, m->drop_stream, s, false, xb6, true,
+                             fuse7 ? xb7 : nullptr, 0))
+            return fail(m, FCN8S_ERR_SHAPE, "bf16_train: fc6 does not fit the bf16 convolution kernel");
+        if (xb7 && !fuse7) { ProfScope ps(m, "bf16_convert", 0, 6.0 * N * h5 * w5 * m->widths[5]); launch_f32_to_bf16_padded(A(m, "fc6"), xb7, N, h5, w5, m->widths[5], 0, s); }
         if (!bf16_conv_layer(m, "fc7_fwd_bf16", "fc7/weights", "fc7/biases", A(m, "fc6"), A(m, "fc7"), N, h5, w5, m->widths[5], m->widths[6], 1, drop, keep_prob, m->drop_stream + 1, s, false, xb7, true))
             return fail(m, FCN8S_ERR_SHAPE, "bf16_train: fc7 does not fit the bf16 convolution kernel");
     } else if (m->precision == FCN8S_PREC_BF16_FC || bf16_fwd_mode(m)) {
@@ -1493,7 +1505,7 @@ void backward_fc6(fcn8s_model* m)
     const int h5 = H / 32, w5 = W / 32;
     const float inv_keep = (m->train_mode && m->keep_prob < 1.f) ? 1.f / m->keep_prob : 1.f;
     float* dz7 = m->dz7_cur; const bool defer_fc = m->defer_fc_cur;
-    { Epi e; e.mask = A(m, "fc6"); e.mask_scale = inv_keep; e.w_fwd = Wp(m, "fc7/weights");      // (w_fwd + the layer name: the bf16_train branch of conv_same)
+    { Epi e; e.mask = A(m, "fc6"); e.mask_scale = inv_keep; e.w_fwd = Wp(m, "fc7/weights"); e.yb_layer = "fc6"; e.yb_K = m->fc6k;      // (w_fwd + the layer name: the bf16_train branch of conv_same)
       conv_same(m, "fc7_dgrad", dz7, WTp(m, "fc7/weights"), m->gbuf[1], N, h5, w5, m->widths[6], m->widths[5], 1, e, s, 0, "fc7"); }
     // fc6
     if (defer_fc && m->acts.count("dmk:fc6") && m->acts.count("wv:fc6") && m->u_train.count("fc6#4")) {
@@ -1574,7 +1586,7 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
             if (first) break;
             Epi e; e.dgrad = 1; e.w_fwd = Wp(m, std::string(nm) + "/filter"); e.lazy_wt = 1;
             if (i > 1) {                                                   // ReLU of the previous conv
-                e.mask = xin; e.mask_scale = 1.f;
+                e.mask = xin; e.mask_scale = 1.f; e.yb_layer = inname; e.yb_K = 3;
                 if (m->rbits_ok.count(inname)) e.relu_bits_in = (const unsigned*)A(m, (std::string("rb:") + inname).c_str());
                 // The previous conv takes this gradient only through dM = A dZ A^T (weight gradient in the Winograd domain, adjoint data
                 // gradient): the gather kernel can write dM directly.  Conditions = those of conv_wgrad's adjoint branch for that layer.
@@ -1610,7 +1622,7 @@ int do_backward_bucket(fcn8s_model* m, int bucket, int level_cap)
     if (bucket == 0) {
         m->defer_level_now = m->defer_wgrad >= 3 ? 2 : std::min(m->defer_wgrad, level_cap);      // 3: the caller does not consume bucket 0 early
         if (m->profile && m->profile_detail) m->defer_level_now = 0;      // per-layer timing wants one kernel at a time
-        m->deferred.clear(); m->ev_next = 0;
+        m->deferred.clear(); m->ev_next = 0; m->dyg16_filled.clear();
         m->dm_prefilled.clear();                                           // (a promise left over from a backward pass that ended in an error)
         m->on_tail = false; m->launch_stream = nullptr;                    // (a backward pass that ended in an error may have left them set)
         for (int b = 0; b < kNumBuckets; ++b) m->bucket_final[b] = false;
@@ -1783,7 +1795,7 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->d_abf16) hipFree(m->d_abf16);
     for (auto& kv : m->xbf16) if (kv.second) hipFree(kv.second);
     for (auto& kv : m->xg16) if (kv.second) hipFree(kv.second);
-    if (m->d_dyb) hipFree(m->d_dyb);
+    for (auto& kv : m->dyg16) if (kv.second) hipFree(kv.second);
     for (int i = 0; i < 3; ++i) if (m->d_tph[i]) hipFree(m->d_tph[i]);
     if (m->d_loss) hipFree(m->d_loss);
     if (m->h_loss) hipHostFree(m->h_loss);
@@ -1852,7 +1864,9 @@ int fcn8s_set_precision(fcn8s_model* m, int precision)
         for (auto& kv : m->xbf16) if (kv.second) hipFree(kv.second);      // (the padded bf16 activation copies of the bf16 forward modes)
         m->xbf16.clear();
         for (auto& kv : m->xg16) if (kv.second) hipFree(kv.second);
-        m->xg16.clear(); m->xg16_elems.clear(); m->dyb_src = nullptr;
+        m->xg16.clear(); m->xg16_elems.clear();
+        for (auto& kv : m->dyg16) if (kv.second) hipFree(kv.second);
+        m->dyg16.clear(); m->dyg16_elems.clear(); m->xg16_filled.clear(); m->dyg16_filled.clear();
         // bf16_train runs every convolution but conv1_1 as a DIRECT convolution on the bf16 MFMA, forward and backward: it rides on the library's
         // direct path (no Winograd transforms, the pools as kernels of their own, ReLU masks from the activations), i.e. on the settings
         // winograd_min_cin = 0 / winograd_fc6 = 0, which it takes over while it is on (and which need another workspace)
@@ -1890,6 +1904,7 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "bf16_copy_by_transform") return &m->bf16_copy_by_transform;
     if (key == "conv1_in_transform") return &m->conv1_in_transform;
     if (key == "deterministic") return &m->deterministic;
+    if (key == "bf16_fuse_convert") return &m->bf16_fuse_convert;
     return nullptr;
 }
 int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
@@ -1909,7 +1924,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
         if (value < 1) return fail(m, FCN8S_ERR_BAD_ARG, "comm_timeout_ms must be >= 1");
         std::lock_guard<std::mutex> lk(m->comm_mu); m->comm_timeout_ms = value; return FCN8S_OK;
     }
-    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform" || k == "deterministic") {        // pick a kernel per launch: nothing cached depends on them
+    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform" || k == "deterministic" || k == "bf16_fuse_convert") {        // pick a kernel per launch: nothing cached depends on them
         *model_option(m, k) = value ? 1 : 0;
         return FCN8S_OK;
     }
