@@ -813,9 +813,10 @@ bool launch_wgrad_bf16(const Bf16WgradArgs& a0, hipStream_t s)
 {
     Bf16WgradArgs a = a0;
     if (a.Ci % 64 || a.Cj % 64 || (a.K & 1) == 0 || a.R < 1) return false;
-    // 3 x 3 layers with at most 128 channels on either side: all nine taps per block (the operands are streamed once instead of nine times);
-    // FCN8S_WGRAD_TAPS9 = 0 never / 2 for every 3 x 3 layer (A/B switch)
-    static const int taps9_mode = getenv("FCN8S_WGRAD_TAPS9") ? atoi(getenv("FCN8S_WGRAD_TAPS9")) : 1;
+    // 3 x 3 layers: all nine taps per block (the operands are streamed once instead of nine times).  Measured at 4 x 2048x1024 against one tap per block
+    // (profiles/r05_wgrad_taps9_ab.txt): conv1_2 3.08 -> 0.76 ms, conv2_2 1.43 -> 0.67, conv3_2 1.51 -> 0.68 (409 -> 904 TFLOP/s), conv4_2 1.13 -> 0.57
+    // (546 -> 1092), conv5_x 0.24 -> 0.20.  FCN8S_WGRAD_TAPS9 = 0 never / 1 only layers with at most 128 channels on a side / 2 (default) every 3 x 3 layer
+    static const int taps9_mode = getenv("FCN8S_WGRAD_TAPS9") ? atoi(getenv("FCN8S_WGRAD_TAPS9")) : 2;
     const bool taps9 = a.K == 3 && (taps9_mode == 2 || (taps9_mode == 1 && (a.Ci <= 128 || a.Cj <= 128)));
     const int bm = taps9 ? 64 : ((a.Ci % 128 == 0 && a.Cj % 128 == 0) ? 128 : 64);
     const int taps = a.K * a.K;

@@ -128,7 +128,7 @@ struct fcn8s_model {
     std::map<std::string, unsigned short*> xg16; std::map<std::string, size_t> xg16_elems;
     std::map<std::string, unsigned short*> dyg16; std::map<std::string, size_t> dyg16_elems;     // ... per layer: the same kind of copy of its output gradient dY
     std::set<std::string> xg16_filled, dyg16_filled;                     // copies a producing kernel's epilogue has already written in this pass (no conversion pass)
-    int bf16_fuse_convert = 1;                                            // option: let the producing convolution write its consumer's bf16 copy
+    int bf16_fuse_convert = 0;                                            // option: let the producing convolution write its consumer's bf16 copy (measured: the 2-byte epilogue stores cost more than the conversion passes they replace -- off)
     int saved_wino_min_cin = -1, saved_wino_fc6 = -1;                      // the options the mode overrides (the direct path carries it), restored on leaving
     int bf16_copy_by_transform = 1;                                       // option: 0 = every bf16 layer converts its input with a pass of its own (round 3's path)
     hipStream_t stream = nullptr;
