@@ -60,7 +60,13 @@ def main():
     ap.add_argument("--batch", type=int, default=8); ap.add_argument("--epochs", type=int, default=60)
     ap.add_argument("--lr", type=float, default=2e-4)
     ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--deterministic", action="store_true", help="library option `deterministic` (split reductions joined in a fixed order) and seeded host RNGs, batches "
+                    "made in-process: two runs must then give the SAME history, bit for bit")
+    ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
+    if args.deterministic:
+        import random
+        random.seed(args.seed); np.random.seed(args.seed)
     from fcn8s_tensorflow_amd.fcn8s import FCN8s
     from fcn8s_tensorflow_amd.batch_generator import BatchGenerator
     C = 20
@@ -70,11 +76,13 @@ def main():
         vi, vg = make_dataset(os.path.join(root, "val"), args.val_images, args.height, args.width, C, seed=2)
         mk = lambda i, g: BatchGenerator(image_dirs=[i], image_file_extension='png', ground_truth_dirs=[g], image_name_split_separator='_leftImg8bit',
                                          ground_truth_suffix='_gtFine_labelIds', check_existence=True, num_classes=C)
-        train_gen = mk(ti, tg).generate(batch_size=args.batch, convert_to_one_hot=True, flip=0.5, brightness=(0.8, 1.25, 0.5), shuffle=True, workers=8)
+        train_gen = mk(ti, tg).generate(batch_size=args.batch, convert_to_one_hot=True, flip=0.5, brightness=(0.8, 1.25, 0.5), shuffle=True, workers=0 if args.deterministic else 8)
         val_set = mk(vi, vg)
-        val_gen = val_set.generate(batch_size=args.batch, convert_to_one_hot=True, shuffle=False, workers=4)
+        val_gen = val_set.generate(batch_size=args.batch, convert_to_one_hot=True, shuffle=False, workers=0 if args.deterministic else 4)
         model = FCN8s(vgg16_dir='synthetic:0', num_classes=C)
         model.engine.set_precision(args.precision)
+        if args.deterministic:
+            model.engine.set_option("deterministic", 1)
         steps, vsteps = args.train_images // args.batch, args.val_images // args.batch
         history = []
         t0 = time.perf_counter()
@@ -109,8 +117,9 @@ def main():
         pred = restored.predict(imgs, argmax=True)
         acc = float((pred == onehot.argmax(-1)).mean())
         out = {"tool": "tools/train_demo.py", "task": "synthetic rectangles, colour -> class, %d classes, %dx%d, %d train / %d val images, batch %d, TF-Adam lr %g, keep_prob 0.5, "
-                       "random-init VGG-16 (no pretrained weights offline), flip + brightness augmentation, precision %s"
-                       % (C, args.width, args.height, args.train_images, args.val_images, args.batch, args.lr, args.precision),
+                       "random-init VGG-16 (no pretrained weights offline), flip + brightness augmentation, precision %s%s"
+                       % (C, args.width, args.height, args.train_images, args.val_images, args.batch, args.lr, args.precision,
+                          ", deterministic mode, host RNG seed %d" % args.seed if args.deterministic else ""),
                "history": history, "train_seconds": round(train_s, 1), "train_images_per_sec_incl_eval_and_feeder": round(args.epochs * steps * args.batch / train_s, 1),
                "final_eval": final, "eval_after_save_and_restore": again, "restored_global_step": restored.g_step if restored.g_step is not None else restored.engine.global_step,
                "predict_pixel_accuracy_4_val_images": round(acc, 4),
