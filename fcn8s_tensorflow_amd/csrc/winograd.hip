@@ -124,6 +124,32 @@ template <int VEC> static __device__ __forceinline__ void vstore_nt(VecF<VEC>* p
     vt t; _Pragma("unroll") for (int i = 0; i < VEC; ++i) t[i] = v.d[i];
     __builtin_nontemporal_store(t, reinterpret_cast<vt*>(p));
 }
+// 16-byte slab stores for the 8-byte-lane transforms (tools/xform_lab.hip had measured 2-12 % on the stand-alone input transform):
+// lanes 2j and 2j + 1 hold the channel pairs c and c + 1 of the same tile; for two neighbouring Winograd positions b and b + 1 they swap halves, so that
+// the even lane writes 16 bytes (four channels) of position b and the odd lane 16 bytes of position b + 1 -- half as many store instructions.
+// `p` = this lane's own 8-byte address of position b (slab stride `slab` in 8-byte units to position b + 1); needs C / 2 even (every width here is).
+// BUILT INTO wino_input_kernel, wino_input_conv1_kernel, wino_dout_kernel and wino_dgrad_output_dout_kernel in round 5 and measured in the training step
+// (profiles/r05_st16_ab.txt, three alternating rounds of library builds on one box): transforms 12.97 -> 13.08 ms per step, the step 59.01 -> 59.19 ms --
+// SLOWER.  Keeping two positions' values live until the exchange costs registers (wino_dout_kernel 90 -> 190 VGPRs, wino_input_kernel 148 -> 217: two
+// waves per SIMD instead of five / three), and these kernels live on occupancy.  Bit-identical results (the parity suite passes on that build).  Off.
+#ifndef FCN8S_ST16
+#define FCN8S_ST16 0
+#endif
+#ifndef FCN8S_ST16_GATHER
+#define FCN8S_ST16_GATHER FCN8S_ST16
+#endif
+template <bool NT> static __device__ __forceinline__ void store_pair16(VecF<2>* p, long long slab, const VecF<2>& s0, const VecF<2>& s1)
+{
+    const bool odd = threadIdx.x & 1;
+    const VecF<2> send = odd ? s0 : s1;
+    VecF<2> got; got.d[0] = __shfl_xor(send.d[0], 1); got.d[1] = __shfl_xor(send.d[1], 1);
+    VecF<4> o;
+    if (!odd) { o.d[0] = s0.d[0]; o.d[1] = s0.d[1]; o.d[2] = got.d[0]; o.d[3] = got.d[1]; }
+    else { o.d[0] = got.d[0]; o.d[1] = got.d[1]; o.d[2] = s1.d[0]; o.d[3] = s1.d[1]; }
+    VecF<4>* dst = reinterpret_cast<VecF<4>*>(odd ? p - 1 + slab : p);
+    if constexpr (NT) vstore_nt<4>(dst, o); else *dst = o;
+    __builtin_amdgcn_sched_barrier(0);          // (without it hipcc computes every position first and stores afterwards: 90 -> 192 VGPRs in wino_dout_kernel)
+}
 #define f4fma vfma<VEC>
 #define f4zero vzero<VEC>
 #define VF VecF<VEC>
@@ -259,6 +285,23 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const VF* __restrict__ 
         for (int j = 0; j < RW; ++j) rbits_out[(ti.t * C4 + ti.c) * RW + j] = rb[j];
     }
     VF* vp = v + ti.t * ldv + sub * C4 + ti.c;
+    if constexpr (FCN8S_ST16 && VEC == 2 && A % 2 == 0) {
+        if ((C4 & 1) == 0 && ((ldv * 2) & 3) == 0) {          // pairs of lanes = pairs of channel groups of one tile, 16-byte aligned rows
+#pragma unroll
+            for (int a = 0; a < A; ++a)
+#pragma unroll
+                for (int b = 0; b < A; b += 2) {
+                    VF s0 = f4zero(), s1 = f4zero();
+#pragma unroll
+                    for (int k = 0; k < A; ++k) {
+                        if (WinoMat<M, R>::bt(b, k) != 0.f) s0 = f4fma(WinoMat<M, R>::bt(b, k), q[a][k], s0);
+                        if (WinoMat<M, R>::bt(b + 1, k) != 0.f) s1 = f4fma(WinoMat<M, R>::bt(b + 1, k), q[a][k], s1);
+                    }
+                    store_pair16<XB>(vp + (a * A + b) * slab, slab, s0, s1);
+                }
+            return;
+        }
+    }
 #pragma unroll
     for (int a = 0; a < A; ++a)
 #pragma unroll
@@ -371,6 +414,20 @@ __global__ __launch_bounds__(256) void wino_input_conv1_kernel(const float4* __r
         for (int j = 0; j < RW; ++j) rbits_out[(t * C4 + c) * RW + j] = rb[j];
     }
     VecF<2>* vp = v + t * C4 + c;
+#if FCN8S_ST16
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int b = 0; b < A; b += 2) {
+            VecF<2> s0 = vzero<2>(), s1 = vzero<2>();
+#pragma unroll
+            for (int k = 0; k < A; ++k) {
+                if (WinoMat<M, R>::bt(b, k) != 0.f) s0 = vfma<2>(WinoMat<M, R>::bt(b, k), q[a][k], s0);
+                if (WinoMat<M, R>::bt(b + 1, k) != 0.f) s1 = vfma<2>(WinoMat<M, R>::bt(b + 1, k), q[a][k], s1);
+            }
+            store_pair16<true>(vp + (a * A + b) * slab, slab, s0, s1);      // (C4 = 32 channel pairs: lanes 2j, 2j + 1 are neighbours of one tile)
+        }
+#else
 #pragma unroll
     for (int a = 0; a < A; ++a)
 #pragma unroll
@@ -380,6 +437,7 @@ __global__ __launch_bounds__(256) void wino_input_conv1_kernel(const float4* __r
             for (int k = 0; k < A; ++k) if (WinoMat<M, R>::bt(b, k) != 0.f) s = vfma<2>(WinoMat<M, R>::bt(b, k), q[a][k], s);
             vstore_nt<2>(vp + (a * A + b) * slab, s);      // (non-temporal: 59.20 / 59.09 / 58.93 -> 58.94 / 58.82 / 58.75 ms per step in alternating runs on one box)
         }
+#endif
 }
 
 // ---- F(4x4,3x3) backward pair: the data-gradient conv needs V = B^T dy B, the weight gradient dM = A dy A^T of the same
@@ -784,6 +842,23 @@ __global__ __launch_bounds__(256) void wino_dout_kernel(const VF* __restrict__ d
         }
     }
     VF* dp = dm + ti.t * C4 + ti.c;
+    if constexpr (FCN8S_ST16 && VEC == 2 && A % 2 == 0) {
+        if ((C4 & 1) == 0) {
+#pragma unroll
+            for (int a = 0; a < A; ++a)
+#pragma unroll
+                for (int b = 0; b < A; b += 2) {          // dM = q A^T, two positions per 16-byte store
+                    VF s0 = f4zero(), s1 = f4zero();
+#pragma unroll
+                    for (int k = 0; k < M; ++k) {
+                        if (WinoMat<M, R>::at(k, b) != 0.f) s0 = f4fma(WinoMat<M, R>::at(k, b), q[a][k], s0);
+                        if (WinoMat<M, R>::at(k, b + 1) != 0.f) s1 = f4fma(WinoMat<M, R>::at(k, b + 1), q[a][k], s1);
+                    }
+                    store_pair16<true>(dp + (a * A + b) * slab, slab, s0, s1);
+                }
+            return;
+        }
+    }
 #pragma unroll
     for (int a = 0; a < A; ++a)
 #pragma unroll
@@ -988,6 +1063,22 @@ __global__ __launch_bounds__(256, 2) void wino_dgrad_output_dout_kernel(const VF
         }
     }
     VF* dp = dm + o;
+#if FCN8S_ST16_GATHER
+    if constexpr (VEC == 2 && A % 2 == 0) {
+        if ((C4 & 1) == 0) {
+#pragma unroll
+            for (int b = 0; b < A; b += 2)
+#pragma unroll
+                for (int a = 0; a < A; ++a) {          // two neighbouring positions (a, b), (a, b + 1) per 16-byte store (store_pair16)
+                    VF s0 = f4zero(), s1 = f4zero();
+#pragma unroll
+                    for (int k = 0; k < M; ++k) if (WM::at(k, a) != 0.f) { s0 = f4fma(WM::at(k, a), r[k][b], s0); s1 = f4fma(WM::at(k, a), r[k][b + 1], s1); }
+                    store_pair16<true>(dp + (a * A + b) * slab_m, slab_m, s0, s1);
+                }
+            return;
+        }
+    }
+#endif
 #pragma unroll
     for (int b = 0; b < A; ++b)
 #pragma unroll
