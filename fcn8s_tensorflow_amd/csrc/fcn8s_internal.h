@@ -80,6 +80,8 @@ bool conv_bf16_256_ok(long long M, int Cin, int Cout, int mode);      // mode 0 
 void launch_w_to_bf16_t(const float* w, unsigned short* wt, int K, int Cout, hipStream_t s);
 void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H, int W, int C, int pad, hipStream_t s);
 bool launch_conv_bf16_256(const Bf16Conv256Args& a, hipStream_t s);
+// the padded bf16 copy of an output gradient (interior only: the border of xp is zero already) with db[c] += column sums of x on the way
+bool launch_f32_to_bf16_padded_colsum(const float* x, unsigned short* xp, float* db, int N, int H, int W, int C, int pad, hipStream_t s);
 // the kernel of a SAME convolution's data gradient as conv_bf16_256_kernel wants it: wt[Cin][(flipped taps, Cout)] bf16 (Cout % 8 == 0)
 void launch_w_to_bf16_flip_t(const float* w, unsigned short* wt, int K, int Cin, int Cout, hipStream_t s);
 // weight gradient with bf16-rounded operands: dW[tap][ci][co] = sum_q A[q + off(tap)][ci] * B[q][co] over R flat padded-pixel rows (gemm_bf16.hip)

@@ -304,6 +304,61 @@ void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H,
     hipLaunchKernelGGL(f32_to_bf16_padded_kernel, dim3((unsigned)b), dim3(256), 0, s, (const float4*)x, (bf16x8*)xp, N, H, W, C / 8, pad);
 }
 
+// The same conversion for an output gradient dY, with the column sums of dY (the layer's bias gradient, exact fp32) taken on the way: the backward pass
+// would otherwise read the fp32 tensor twice (conversion + launch_colsum; 1.3 ms per step at 4 x 2048x1024).  A block = 256 / C8 pixel lanes x C8
+// channel octets walks the interior pixels with a block-uniform stride; each thread keeps eight running sums, the block adds its pixel lanes in LDS in
+// lane order and stores one partial row, and launch_det_reduce adds the partial rows in block order into db (+=): reproducible.
+__global__ __launch_bounds__(256) void f32_to_bf16_padded_colsum_kernel(const float4* __restrict__ x, bf16x8* __restrict__ xp, float* __restrict__ partial,
+                                                                        int N, int H, int W, int C8, int pad, int lanes)
+{
+    __shared__ float red[256 * 8];
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const int c = threadIdx.x % C8, pl = threadIdx.x / C8;
+    const long long npix = (long long)N * H * W;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (pl < lanes) {
+        for (long long p = (long long)blockIdx.x * lanes + pl; p < npix; p += (long long)gridDim.x * lanes) {
+            const int xx = (int)(p % W); long long t = p / W;
+            const int yy = (int)(t % H); const int n = (int)(t / H);
+            const long long src = p * C8 + c, dst = (((long long)n * Hp + yy + pad) * Wp + xx + pad) * C8 + c;
+            const float4 a = x[2 * src], b = x[2 * src + 1];
+            bf16x8 o;
+            o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+            o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+            xp[dst] = o;
+            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = acc[i];
+    __syncthreads();
+    if (pl == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = acc[i];
+            for (int l = 1; l < lanes; ++l) v += red[(l * C8 + c) * 8 + i];
+            partial[(long long)blockIdx.x * C8 * 8 + c * 8 + i] = v;
+        }
+    }
+}
+// the interior of xp is written here; its border must be zero already (a per-layer buffer zeroed at allocation).  db[c] += sum over pixels of x[., c]
+bool launch_f32_to_bf16_padded_colsum(const float* x, unsigned short* xp, float* db, int N, int H, int W, int C, int pad, hipStream_t s)
+{
+    const int C8 = C / 8;
+    if (C % 8 || C8 > 256) return false;
+    const int lanes = 256 / C8;
+    const long long npix = (long long)N * H * W;
+    long long blocks = (npix + lanes * 16LL - 1) / (lanes * 16LL);          // >= 16 pixels per thread
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    float* partial = det_scratch(s, (size_t)blocks * C);
+    if (!partial) return false;
+    g_last_kernel = "f32_to_bf16_padded_colsum_kernel";
+    hipLaunchKernelGGL(f32_to_bf16_padded_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)x, (bf16x8*)xp, partial, N, H, W, C8, pad, lanes);
+    launch_det_reduce(db, partial, 1, C, C, C, (int)blocks, true, s);
+    return true;
+}
+
 // BN = 256 / 128 / 64 output channels per block (round 5: the 64- and 128-channel layers of blocks 1-2 and every data gradient run on this kernel
 // too).  The two row groups of 128 rows stay; inside a group the four waves are laid out WR x (4 / WR): BN = 256 -> 1 x 4 (a wave owns 128 rows x 64
 // columns, 4 x 2 accumulators, the round-3 kernel), BN = 128 -> 2 x 2 (64 x 64, 2 x 2), BN = 64 -> 4 x 1 (32 x 64, 1 x 2).  The B image of a stage has BN
@@ -524,6 +579,13 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
     const long long rt = (a.M + G_BM - 1) / G_BM;
     int bn = a.Cout % 256 == 0 ? 256 : (a.Cout % 128 == 0 ? 128 : 64);
     if (a.any_shape) while (bn > 64 && rt * (a.Cout / bn) < 256) bn /= 2;
+    // ... and short reductions (the 3 x 3 layers: 18 .. 144 K-tiles) take the narrow tiles anyway: those run two blocks per CU, so that one block's prologue
+    // and epilogue hide under the other's K loop.  Measured at 4 x 2048x1024 (profiles/r05_bf16_conv_tile_ab.txt): data gradient of conv3_2 1.48 ms with
+    // 256 columns, 1.17 with 128, 1.08 with 64; conv4_2 1.01 / 0.84 / 0.94; fc6 forward (784 K-tiles) 1.56 / 1.64 / 2.26.
+    static const int bn_max = getenv("FCN8S_BF16_BN_MAX") ? atoi(getenv("FCN8S_BF16_BN_MAX")) : 0;      // (A/B switch: cap the column tile)
+    const long long ktot = (long long)a.K * a.K * a.Cin;
+    const int cap = bn_max ? bn_max : (ktot <= 2304 ? 64 : (ktot <= 4608 ? 128 : 256));
+    if (a.any_shape) while (bn > cap && bn > 64) bn /= 2;
     const unsigned blocks = (unsigned)(rt * (a.Cout / bn));
     if (bn == 256) { g_last_kernel = "conv_bf16_256_kernel<256>"; hipLaunchKernelGGL(conv_bf16_256_kernel<256>, dim3(blocks), dim3(512), 0, s, a); }
     else if (bn == 128) { g_last_kernel = "conv_bf16_256_kernel<128>"; hipLaunchKernelGGL(conv_bf16_256_kernel<128>, dim3(blocks), dim3(512), 0, s, a); }

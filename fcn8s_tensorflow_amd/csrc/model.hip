@@ -339,7 +339,7 @@ static inline bool bf16_train_mode(const fcn8s_model* m) { return m && m->precis
 // (... and, for the nine-tap kernel, the eight-row instruction that completes a 34-row group: 128 rows cover all of it)
 static inline long long bf16_guard_rows(int K, int Wp) { return (long long)((K - 1) / 2) * Wp + (K - 1) / 2 + 128; }
 unsigned short* g16_for(fcn8s_model* m, std::map<std::string, unsigned short*>& bufs, std::map<std::string, size_t>& sizes, const char* layer, int N, int H, int W, int C, int K, hipStream_t s);
-unsigned short* dyb_for(fcn8s_model* m, const char* layer, const float* dy, int N, int H, int W, int C, int K, hipStream_t s);
+unsigned short* dyb_for(fcn8s_model* m, const char* layer, const float* dy, int N, int H, int W, int C, int K, hipStream_t s, float* db = nullptr, bool* db_done = nullptr);
 
 int wino_tile_for(const fcn8s_model* m, int H, int W, int K = 3)
 {
@@ -693,7 +693,8 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
         if (it != m->xg16.end() && it->second) {
             const int pad = (K - 1) / 2, Wp_ = W + 2 * pad;
             const long long G = bf16_guard_rows(K, Wp_), R = (long long)N * (H + 2 * pad) * Wp_;
-            unsigned short* dyb = dyb_for(m, layer, dz, N, H, W, Cout, K, s);
+            bool db_done = false;
+            unsigned short* dyb = dyb_for(m, layer, dz, N, H, W, Cout, K, s, db, &db_done);
             if (dyb) {
                 Bf16WgradArgs g{};
                 g.A = it->second + G * Cin; g.B = dyb; g.C = dw; g.R = R; g.Ci = Cin; g.Cj = Cout; g.K = K; g.Wp = Wp_;
@@ -701,9 +702,10 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
                 { ProfScope ps(m, K == 1 ? "fc7_wgrad_bf16" : (K == 3 ? "conv3x3_wgrad_bf16" : "fc6_wgrad_bf16"), flops, 2.0 * K * K * R * (Cin + Cout) + 4.0 * K * K * Cin * Cout, layer);
                   done = launch_wgrad_bf16(g, s); }
                 if (done) {
-                    if (db) { ProfScope ps(m, "colsum", 0, 4.0 * a.P * Cout); launch_colsum(dz, db, a.P, Cout, s); }
+                    if (db && !db_done) { ProfScope ps(m, "colsum", 0, 4.0 * a.P * Cout); launch_colsum(dz, db, a.P, Cout, s); }
                     return;
                 }
+                if (db_done) { fprintf(stderr, "fcn8s: bf16_train: %s's weight-gradient launch refused its shape after the bias gradient was taken\n", layer); abort(); }
             }
         }
     }
@@ -1129,13 +1131,16 @@ unsigned short* g16_for(fcn8s_model* m, std::map<std::string, unsigned short*>& 
 unsigned short* xg16_for(fcn8s_model* m, const char* layer, int N, int H, int W, int C, int K, hipStream_t s) { return g16_for(m, m->xg16, m->xg16_elems, layer, N, H, W, C, K, s); }
 // the copy of layer `layer`'s output gradient dY [N][H][W][C]: written by the kernel that produced dY if that was a bf16 data gradient
 // (dyg16_filled), else converted here, once (the layer's weight gradient asks first, its data gradient finds it)
-unsigned short* dyb_for(fcn8s_model* m, const char* layer, const float* dy, int N, int H, int W, int C, int K, hipStream_t s)
+// db: the layer's bias gradient, db[c] += sum dY[., c] -- taken by the conversion kernel on its way through dY (*db_done says whether it was)
+unsigned short* dyb_for(fcn8s_model* m, const char* layer, const float* dy, int N, int H, int W, int C, int K, hipStream_t s, float* db, bool* db_done)
 {
+    if (db_done) *db_done = false;
     unsigned short* p = g16_for(m, m->dyg16, m->dyg16_elems, layer, N, H, W, C, K, s);
     if (!p) return nullptr;
     if (!m->dyg16_filled.count(layer)) {
-        ProfScope ps(m, "bf16_convert", 0, 4.0 * N * H * W * C + 2.0 * N * (H + K - 1) * (W + K - 1) * C);
-        launch_f32_to_bf16_padded(dy, p, N, H, W, C, (K - 1) / 2, s);
+        ProfScope ps(m, "bf16_convert", 0, 4.0 * N * H * W * C + 2.0 * N * H * W * C);
+        if (db && launch_f32_to_bf16_padded_colsum(dy, p, db, N, H, W, C, (K - 1) / 2, s)) { if (db_done) *db_done = true; }
+        else launch_f32_to_bf16_padded(dy, p, N, H, W, C, (K - 1) / 2, s);
         m->dyg16_filled.insert(layer);
     }
     return p;
