@@ -307,26 +307,28 @@ void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H,
 // The same conversion for an output gradient dY, with the column sums of dY (the layer's bias gradient, exact fp32) taken on the way: the backward pass
 // would otherwise read the fp32 tensor twice (conversion + launch_colsum; 1.3 ms per step at 4 x 2048x1024).  A block = 256 / C8 pixel lanes x C8
 // channel octets walks the interior pixels with a block-uniform stride; each thread keeps eight running sums, the block adds its pixel lanes in LDS in
-// lane order and stores one partial row, and launch_det_reduce adds the partial rows in block order into db (+=): reproducible.
+// lane order and stores one partial row, and launch_colsum adds the partial rows (fixed order) into db (+=): reproducible.
 __global__ __launch_bounds__(256) void f32_to_bf16_padded_colsum_kernel(const float4* __restrict__ x, bf16x8* __restrict__ xp, float* __restrict__ partial,
-                                                                        int N, int H, int W, int C8, int pad, int lanes)
+                                                                        int H, int W, int C8, int pad, int lanes, int rows_per_block, int nrows)
 {
     __shared__ float red[256 * 8];
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const int c = threadIdx.x % C8, pl = threadIdx.x / C8;
-    const long long npix = (long long)N * H * W;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (pl < lanes) {
-        for (long long p = (long long)blockIdx.x * lanes + pl; p < npix; p += (long long)gridDim.x * lanes) {
-            const int xx = (int)(p % W); long long t = p / W;
-            const int yy = (int)(t % H); const int n = (int)(t / H);
-            const long long src = p * C8 + c, dst = (((long long)n * Hp + yy + pad) * Wp + xx + pad) * C8 + c;
-            const float4 a = x[2 * src], b = x[2 * src + 1];
-            bf16x8 o;
-            o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
-            o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
-            xp[dst] = o;
-            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+        // a block owns `rows_per_block` image rows (n, y): no per-pixel index arithmetic beyond an add (one division per row)
+        for (int r = blockIdx.x * rows_per_block; r < (blockIdx.x + 1) * rows_per_block && r < nrows; ++r) {
+            const int n = r / H, yy = r - n * H;
+            const float4* src = x + (long long)r * W * C8 * 2;
+            bf16x8* dst = xp + (((long long)n * Hp + yy + pad) * Wp + pad) * C8;
+            for (int xx = pl; xx < W; xx += lanes) {
+                const float4 a = src[2 * (xx * C8 + c)], b = src[2 * (xx * C8 + c) + 1];
+                bf16x8 o;
+                o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+                o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+                dst[xx * C8 + c] = o;
+                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+            }
         }
     }
 #pragma unroll
@@ -347,15 +349,16 @@ bool launch_f32_to_bf16_padded_colsum(const float* x, unsigned short* xp, float*
     const int C8 = C / 8;
     if (C % 8 || C8 > 256) return false;
     const int lanes = 256 / C8;
-    const long long npix = (long long)N * H * W;
-    long long blocks = (npix + lanes * 16LL - 1) / (lanes * 16LL);          // >= 16 pixels per thread
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
+    const int nrows = N * H;
+    int rpb = (16 * lanes + W - 1) / W;                  // >= 16 pixels per thread
+    if (rpb < 1) rpb = 1;
+    while ((nrows + rpb - 1) / rpb > 2048) rpb *= 2;     // (the partial rows are added up by launch_colsum: block-order, reproducible)
+    const int blocks = (nrows + rpb - 1) / rpb;
     float* partial = det_scratch(s, (size_t)blocks * C);
     if (!partial) return false;
     g_last_kernel = "f32_to_bf16_padded_colsum_kernel";
-    hipLaunchKernelGGL(f32_to_bf16_padded_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)x, (bf16x8*)xp, partial, N, H, W, C8, pad, lanes);
-    launch_det_reduce(db, partial, 1, C, C, C, (int)blocks, true, s);
+    hipLaunchKernelGGL(f32_to_bf16_padded_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)x, (bf16x8*)xp, partial, H, W, C8, pad, lanes, rpb, nrows);
+    launch_colsum(partial, db, blocks, C, s);            // db[c] += sum over the blocks' partial rows
     return true;
 }
 
