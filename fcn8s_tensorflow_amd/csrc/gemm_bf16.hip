@@ -13,7 +13,6 @@
 // Block = 256 threads (4 wave64) -> 128 pixels x 128 couts, wave tile 64 x 64 = 2 x 2 MFMA tiles, 8 MFMAs per wave
 // per K-tile, global -> register -> LDS double buffering with one barrier per K-tile.
 #include "fcn8s_internal.h"
-#include <cstdlib>
 #include <string>
 
 namespace fcn8s {
@@ -585,9 +584,8 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
     // ... and short reductions (the 3 x 3 layers: 18 .. 144 K-tiles) take the narrow tiles anyway: those run two blocks per CU, so that one block's prologue
     // and epilogue hide under the other's K loop.  Measured at 4 x 2048x1024 (profiles/r05_bf16_conv_tile_ab.txt): data gradient of conv3_2 1.48 ms with
     // 256 columns, 1.17 with 128, 1.08 with 64; conv4_2 1.01 / 0.84 / 0.94; fc6 forward (784 K-tiles) 1.56 / 1.64 / 2.26.
-    static const int bn_max = getenv("FCN8S_BF16_BN_MAX") ? atoi(getenv("FCN8S_BF16_BN_MAX")) : 0;      // (A/B switch: cap the column tile)
     const long long ktot = (long long)a.K * a.K * a.Cin;
-    const int cap = bn_max ? bn_max : (ktot <= 2304 ? 64 : (ktot <= 4608 ? 128 : 256));
+    const int cap = ktot <= 2304 ? 64 : (ktot <= 4608 ? 128 : 256);
     if (a.any_shape) while (bn > cap && bn > 64) bn /= 2;
     const unsigned blocks = (unsigned)(rt * (a.Cout / bn));
     if (bn == 256) { g_last_kernel = "conv_bf16_256_kernel<256>"; hipLaunchKernelGGL(conv_bf16_256_kernel<256>, dim3(blocks), dim3(512), 0, s, a); }
@@ -880,9 +878,8 @@ bool launch_wgrad_bf16(const Bf16WgradArgs& a0, hipStream_t s)
     if (a.Ci % 64 || a.Cj % 64 || (a.K & 1) == 0 || a.R < 1) return false;
     // 3 x 3 layers: all nine taps per block (the operands are streamed once instead of nine times).  Measured at 4 x 2048x1024 against one tap per block
     // (profiles/r05_wgrad_taps9_ab.txt): conv1_2 3.08 -> 0.76 ms, conv2_2 1.43 -> 0.67, conv3_2 1.51 -> 0.68 (409 -> 904 TFLOP/s), conv4_2 1.13 -> 0.57
-    // (546 -> 1092), conv5_x 0.24 -> 0.20.  FCN8S_WGRAD_TAPS9 = 0 never / 1 only layers with at most 128 channels on a side / 2 (default) every 3 x 3 layer
-    static const int taps9_mode = getenv("FCN8S_WGRAD_TAPS9") ? atoi(getenv("FCN8S_WGRAD_TAPS9")) : 2;
-    const bool taps9 = a.K == 3 && (taps9_mode == 2 || (taps9_mode == 1 && (a.Ci <= 128 || a.Cj <= 128)));
+    // (546 -> 1092), conv5_x 0.24 -> 0.20.  (The A/B ran on an environment switch that is gone again: the library reads no environment variable.)
+    const bool taps9 = a.K == 3;
     const int bm = taps9 ? 64 : ((a.Ci % 128 == 0 && a.Cj % 128 == 0) ? 128 : 64);
     const int taps = a.K * a.K;
     const long long tiles = (long long)(a.Ci / bm) * (a.Cj / bm) * (taps9 ? 1 : taps);
