@@ -1296,8 +1296,14 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 // the next convolution of the block reads this output as ITS padded bf16 input: this kernel's epilogue writes that copy
                 unsigned short* yb = nullptr; char nx[32] = "";
                 if (train && m->bf16_fuse_convert && i < kConvsPerBlock[b]) { snprintf(nx, sizeof nx, "conv%d_%d", b + 1, i + 1); yb = xg16_for(m, nx, N, h, w, m->widths[b], 3, s); }
+                // (the convolution kernel addresses its padded copies with 32-bit byte offsets: a layer whose padded input OR padded output gradient reaches
+                //  4 GiB cannot run in this mode -- say so instead of letting that one layer fall back to another arithmetic)
+                const double padded_px = (double)N * (h + 2) * (w + 2);
+                if (padded_px * std::max(cin, m->widths[b]) * 2.0 >= 4294967296.0)
+                    return fail(m, FCN8S_ERR_SHAPE, std::string("bf16_train: the padded bf16 copy of ") + nm + "'s input or output gradient would reach 4 GiB at this batch size; use a smaller batch per GPU");
                 done = bf16_conv_layer(m, "conv3x3_fwd_bf16", (std::string(nm) + "/filter").c_str(), (std::string(nm) + "/biases").c_str(), x, A(m, nm),
                                        N, h, w, cin, m->widths[b], 3, 0, 1.f, 0, s, /*allow_small=*/false, xb, /*any_shape=*/true, yb, 1);
+                if (!done) return fail(m, FCN8S_ERR_SHAPE, std::string("bf16_train: ") + nm + " does not fit the bf16 convolution kernel");
                 if (done && yb) m->xg16_filled.insert(nx);
             }
             if (!done && bf16_fwd_mode(m) && b >= 2) {

@@ -734,3 +734,18 @@ def test_batch_of_64_is_its_four_images_sixteen_times():
         d = float(np.abs(logits64[i] - logits4[i % R]).max())
         assert d <= 1e-5 * scale, (i, d, scale)
     e.close()
+
+
+def test_bf16_train_refuses_a_batch_whose_padded_copies_pass_4_gib():
+    """conv_bf16_256_kernel addresses the padded bf16 copies with 32-bit byte offsets.  A batch whose padded conv1_2 input reaches 4 GiB (64 x 1024x512:
+    64 x 514 x 1026 x 64 x 2 bytes) must be refused with a shape error naming the layer -- not run with that one layer silently on the fp32 kernels."""
+    import torch
+    from fcn8s_tensorflow_amd.engine import Engine
+    e = Engine(20, precision="bf16_train")
+    e.init_params(seed=0)
+    img = torch.zeros((64, 512, 1024, 3), dtype=torch.uint8, device="cuda")
+    lab = torch.zeros((64, 512, 1024), dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError, match="4 GiB"):
+        e.forward_backward(img, lab, keep_prob=1.0)
+    assert np.isfinite(e.forward_backward(img[:16], lab[:16], keep_prob=1.0))      # the model is usable afterwards
+    e.close()
