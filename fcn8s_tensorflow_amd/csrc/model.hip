@@ -123,8 +123,7 @@ struct fcn8s_model {
     // allocation; the interior every step by that layer's Winograd input transform, wino_input_kernel<.., XB>); keyed by layer, dropped with the workspace
     std::map<std::string, unsigned short*> xbf16;
     // FCN8S_PREC_BF16_TRAIN: per layer, the zero-bordered bf16 copy of its INPUT with zeroed guard rows in front and behind (bf16_guard_rows), written by
-    // the forward pass and read again by the layer's weight gradient; one shared buffer of the same kind for the output gradient dY that a layer's
-    // weight gradient converts and its data gradient reads again (dyb_src = the fp32 tensor it was made from)
+    // the forward pass and read again by the layer's weight gradient
     std::map<std::string, unsigned short*> xg16; std::map<std::string, size_t> xg16_elems;
     std::map<std::string, unsigned short*> dyg16; std::map<std::string, size_t> dyg16_elems;     // ... per layer: the same kind of copy of its output gradient dY
     std::set<std::string> xg16_filled, dyg16_filled;                     // copies a producing kernel's epilogue has already written in this pass (no conversion pass)

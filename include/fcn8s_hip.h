@@ -272,12 +272,20 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *     "bf16_copy_by_transform" 1  FCN8S_PREC_BF16_FWD / _X2, training: the padded bf16 copy of a layer's input that its direct bf16 convolution reads is
  *                              written by the layer's Winograd input transform (which runs anyway, for the weight gradient) instead of a
  *                              conversion pass of its own over the activations (identical bits); 0 = the separate pass
- *                              (these four pick a kernel per launch and drop nothing)
+ *     "deterministic"     0    1 = every reduction that the default path splits over blocks and joins with fp32 atomics (weight gradients in and out of
+ *                              the Winograd domain, conv1_1's and the score heads' weight gradients, the bf16 weight gradients, the last bias gradient, the L2
+ *                              sum; split-K GEMMs are simply not split) stores one partial result per split into a scratch slab, and a second kernel adds
+ *                              the slabs in split order: two runs of the same steps on the same inputs give the same bits.  +2.4 % at 16 x 1024x512
+ *     "bf16_fuse_convert" 0    FCN8S_PREC_BF16_TRAIN: the producing convolution's epilogue also writes its consumer's padded bf16 copy (measured slower)
+ *                              (these six pick a kernel per launch and drop nothing)
+ *     "comm_timeout_ms" 600000 the communicator's watchdog (see fcn8s_comm_init): a collective older than this is given up, the communicator aborted
  *   op-context options (m == NULL): the arithmetic of the op-level entry points below, which have no model.  The value belongs to the
  *   CALLING THREAD (thread-local) and is read by that thread's later fcn8s_op_* calls only; no model ever reads it, so two models -- or a
  *   feeder thread beside a compute thread -- cannot change each other's kernels:
  *     "op_f32x3"          0    their LDS-DMA GEMMs use the split-bf16 arithmetic of FCN8S_PREC_F32X3
  *     "op_split_pieces"   0    the same switch by piece count: 0 = f32 MFMA, 3 = FCN8S_PREC_F32X3, 2 = FCN8S_PREC_F32X2
+ *     "op_deterministic"  0    the slab reductions of "deterministic" for the op-level entry points (a model call on the same thread sets the
+ *                              thread's switch from that model's option: set it again before the next op-level call)
  * Unknown keys return FCN8S_ERR_NOT_FOUND. */
 int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value);
 int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value);
