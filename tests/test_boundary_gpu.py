@@ -264,6 +264,34 @@ def test_native_rccl_communicator_one_rank():
         os.sched_setaffinity(0, before)
 
 
+def test_fused_step_marks_every_bucket_final():
+    """after the fused fcn8s_train_step (no per-bucket calls) every gradient bucket -- bucket 2 included -- must be waitable
+    (fcn8s_bucket_wait) and, with a communicator, reducible; the gradient readers order themselves behind pending all-reduces."""
+    from fcn8s_tensorflow_amd import _lib as L
+    P = orc.init_params(20, SMALL, seed=1, decoder_std_scale=30.0, bias_std=0.05)
+    img, lab = _batch(2, 32, 64, 3)
+    e = _engine(); e.set_params(P)
+    loss, step = e.train_step(img, lab, 1e-3, keep_prob=1.0)          # TF-Adam, one rank, no process group: the fused C entry point
+    assert step == 1 and np.isfinite(loss)
+    side = torch.cuda.Stream()
+    for b in range(e.num_buckets):
+        assert L.lib.fcn8s_bucket_wait(e.h, b, C.c_void_p(side.cuda_stream)) == 0, (b, L.lib.fcn8s_last_error(e.h))
+    side.synchronize()
+    e.comm_init_native()                                               # world 1
+    loss2, step2 = e.train_step(img, lab, 1e-3, keep_prob=1.0)
+    assert step2 == 2 and np.isfinite(loss2)
+    e.forward_backward(img, lab, keep_prob=1.0)
+    for b in range(e.num_buckets):
+        assert L.lib.fcn8s_allreduce_bucket(e.h, b) == 0
+    g = e.get_grads()                                                  # (waits for the four all-reduces itself)
+    assert all(np.isfinite(v).all() for v in g.values())
+    assert e.get_option("comm_timeout_ms") == 600000
+    e.set_option("comm_timeout_ms", 1234); assert e.get_option("comm_timeout_ms") == 1234
+    e.comm_destroy()
+    assert not e.native_comm and e.comm_info()["world"] == 0
+    e.close()
+
+
 def test_bench_single_gpu_line_and_end_to_end_mode():
     out = _run_bench("--steps", "2", "--warmup", "1", "--batch", "2", "--height", "64", "--width", "64", "--no-cpu-baseline")
     assert out["n_gpus"] == 1 and out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
