@@ -11,7 +11,9 @@ kernels (unpinned; tutorial output shows 1.3.0, `fcn8s_tutorial.ipynb:311`)
 and an un-vendored VGG-16 SavedModel (`README.md:42`).  Neither is available
 offline and the reference holds no tests or golden vectors for the path, so
 this restatement is pinned only by (a) the explicit-loop C restatement in
-``oracle/fcn8s_oracle.c`` (known-answer tests in ``tests/test_oracle.py``) and
+``oracle/fcn8s_oracle.c`` (known-answer tests in ``tests/test_oracle.py``),
+(a') SciPy's correlate2d / convolve2d / special.log_softmax for the float building
+blocks (``test_float_ops_against_scipy``: third-party code, not TensorFlow) and
 (b) golden vectors captured from the reference modules that *do* import here
 (``tests/golden/make_golden.py``: one-hot / ID-LUT helpers, the native
 confusion-matrix C file, the BatchGenerator contract).

@@ -299,3 +299,40 @@ def test_bf16_convs_mode_of_the_oracle():
     assert np.isfinite(l16) and abs(l16 - l32) < 0.1 * abs(l32)
     for k in g32:
         assert np.isfinite(g16[k]).all() and g16[k].shape == g32[k].shape
+
+
+def test_float_ops_against_scipy():
+    """A pin of the oracle's floating-point building blocks that is neither TensorFlow (not installable here) nor this repository's own restatements:
+    SciPy.  SAME convolution = scipy.signal.correlate2d(mode='same') summed over input channels; the stride-s, k = 2s transposed convolution of
+    tf.layers.conv2d_transpose(padding='same') = scipy.signal.convolve2d(mode='full') of the zero-stuffed input with the kernel, cropped by
+    p = (k - s) / 2 on every side; log-softmax / softmax = scipy.special; all in float64, agreement to 1e-12."""
+    import torch
+    from scipy import signal, special
+    rng = np.random.default_rng(3)
+    # SAME conv, 3x3 and 7x7
+    for K in (3, 7):
+        x = rng.standard_normal((1, 9, 11, 3)); w = rng.standard_normal((K, K, 3, 2)); b = rng.standard_normal(2)
+        got = orc.conv2d_same_t(torch.tensor(x).permute(0, 3, 1, 2), torch.tensor(w), torch.tensor(b)).permute(0, 2, 3, 1).numpy()
+        want = np.stack([sum(signal.correlate2d(x[0, :, :, ci], w[:, :, ci, co], mode="same") for ci in range(3)) + b[co] for co in range(2)], -1)[None]
+        assert np.abs(got - want).max() < 1e-12
+    # transposed conv (k, s) = (4, 2) and (16, 8): kernel [k, k, Cout, Cin]
+    for K, S in ((4, 2), (16, 8)):
+        x = rng.standard_normal((1, 5, 6, 2)); w = rng.standard_normal((K, K, 3, 2)); b = rng.standard_normal(3)
+        got = orc.conv2d_transpose_same_t(torch.tensor(x).permute(0, 3, 1, 2), torch.tensor(w), torch.tensor(b), S).permute(0, 2, 3, 1).numpy()
+        p = (K - S) // 2
+        want = np.zeros((1, 5 * S, 6 * S, 3))
+        for co in range(3):
+            acc = 0.0
+            for ci in range(2):
+                up = np.zeros(((5 - 1) * S + 1, (6 - 1) * S + 1)); up[::S, ::S] = x[0, :, :, ci]        # zero-stuffed input
+                acc = acc + signal.convolve2d(up, w[:, :, co, ci], mode="full")                       # y[i s + ky, j s + kx] += x[i, j] w[ky, kx]
+            want[0, :, :, co] = acc[p:p + 5 * S, p:p + 6 * S] + b[co]
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-12
+    # softmax / cross entropy
+    lg = rng.standard_normal((2, 3, 4, 5)) * 4
+    assert np.abs(orc.softmax(lg) - special.softmax(lg, -1)).max() < 1e-12
+    lab = rng.integers(0, 5, (2, 3, 4))
+    P = {k: torch.zeros(1, dtype=torch.float64) for k in orc.DECODER_KERNELS}
+    loss = float(orc.total_loss_t(P, torch.tensor(lg).permute(0, 3, 1, 2), torch.tensor(orc.one_hot(lab, 5).astype(np.float64)), 0.0))
+    want = float(-np.take_along_axis(special.log_softmax(lg, -1), lab[..., None], -1).mean())
+    assert abs(loss - want) < 1e-12
