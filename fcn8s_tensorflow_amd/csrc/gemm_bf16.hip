@@ -557,6 +557,114 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
     }
 }
 
+// 3 x 3 layers on the 64-column tile, round 5: the same product over FLAT positions of the padded map, one K-tile = one filter row.
+// conv_bf16_256_kernel<64> fetches a 256-row A tile per tap -- nine times per channel chunk -- and runs 4 MFMAs per wave between two barriers: its matrix
+// pipes were 0.21 busy (profiles/r05_c5_bf16_train_pmc_clock_summary.txt).  Here the rows of a tile are 256 consecutive positions q of the padded map
+// [N][H + 2][W + 2] (border positions are computed and not stored: 0.3 % of them at 2048x1024, 9 % at 32x64), so the window of position q under tap
+// (ty, tx) is row q + (ty - 1) Wp + (tx - 1) of the padded copy and the three taps of a filter row read the SAME 258 rows moved by one: a K-tile
+// (ty, 32 channels) brings 272 rows of A once (17 LDS-DMA instructions) and the three 64 x 32 weight slices, and feeds 12 MFMAs per wave.
+// A third of the A traffic, a third of the barriers.  Two stages (58 KB), two blocks per CU; plain loop, one barrier per K-tile.
+__global__ __launch_bounds__(512, 4) void conv_bf16_r64_kernel(const Bf16Conv256Args p)
+{
+    constexpr int BM = 256, BN = 64, AROWS = 272, ABYTES = AROWS * G_ROWB, BBYTES = 3 * BN * G_ROWB, STAGE = ABYTES + BBYTES, NS = 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Hp = p.H + 2, Wp = p.W + 2, Ktot = 9 * p.Cin;
+    const long long R = (long long)p.N * Hp * Wp;
+    const unsigned ntm = (unsigned)((R + BM - 1) / BM), ntn = (unsigned)(p.Cout / BN);
+    const unsigned lid = xcd_run(blockIdx.x, gridDim.x);
+    const unsigned tmi = lid / ntn, tni = lid % ntn;               // column tiles of one row tile are neighbours: they share its A rows behind one L2
+    const long long q0 = (long long)tmi * BM; const int n0 = (int)tni * BN;
+    // A chunks (16 rows each) c = wave, wave + 8, (wave 0: + 16); B chunks (tx, 16 couts) c = wave, wave + 8 (< 12)
+    const int na = wave == 0 ? 3 : 2, nbk = wave < 4 ? 2 : 1;
+    unsigned a_voff[3], b_voff[2]; unsigned a_dst[3], b_dst[2]; int b_tx[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int chunk = wave + 8 * i, row = chunk * 16 + lane / 4, pc = lane % 4, lc = pc ^ ((row >> 2) & 3);
+        a_voff[i] = (unsigned)(((long long)row * p.Cin + lc * 8) * 2);
+        a_dst[i] = (unsigned)(chunk * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = wave + 8 * i, tx = (c < 12 ? c : 0) / 4, c4 = (c < 12 ? c : 0) % 4, row = c4 * 16 + lane / 4, pc = lane % 4, lc = pc ^ ((row >> 2) & 3);
+        b_voff[i] = (unsigned)(((long long)row * Ktot + lc * 8) * 2);
+        b_dst[i] = (unsigned)(ABYTES + tx * (BN * G_ROWB) + c4 * 1024);
+        b_tx[i] = tx;
+    }
+    // (row 0 of the A image of filter row ty is padded position q0 - Wp - 1 + ty Wp: the guard rows in front of the copy make that readable for q0 = 0)
+    const unsigned short* a_base = p.xp + (q0 - Wp - 1) * p.Cin;
+    const unsigned short* b_base = p.wt + (long long)n0 * Ktot;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int nci = p.Cin / G_BK, nkt = 3 * nci;                   // K-tile kt = (channel chunk kt / 3, filter row kt % 3)
+    auto issue = [&](int kt) {
+        const int ci = (kt / 3) * G_BK, ty = kt % 3;
+        const unsigned st = lds0 + (unsigned)((kt & 1) * STAGE);
+        const unsigned short* ga = a_base + (long long)ty * Wp * p.Cin + ci;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) if (i < na) glds16b(ga, a_voff[i], st + a_dst[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) if (i < nbk) glds16b(b_base + (long long)(ty * 3 + b_tx[i]) * p.Cin + ci, b_voff[i], st + b_dst[i]);
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int arow = wave * 32 + (lane & 31);
+    issue(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                              // tile kt has landed everywhere; everybody is done reading the other stage
+        if (kt + 1 < nkt) issue(kt + 1);
+        const unsigned char* st = smem + (kt & 1) * STAGE;
+        bf16x8 af[3][2], bfr[3][2][2];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int r = arow + tx, pc = (2 * ks + (lane >> 5)) ^ ((r >> 2) & 3);
+                af[tx][ks] = *reinterpret_cast<const bf16x8*>(st + r * G_ROWB + pc * 16);
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    const int rb = tn * 32 + (lane & 31), pb = (2 * ks + (lane >> 5)) ^ ((rb >> 2) & 3);
+                    bfr[tx][ks][tn] = *reinterpret_cast<const bf16x8*>(st + ABYTES + tx * (BN * G_ROWB) + rb * G_ROWB + pb * 16);
+                }
+            }
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tx][ks], bfr[tx][ks][tn], acc[tn], 0, 0, 0);
+    }
+    // epilogue: position -> pixel; border positions and positions beyond the last image are not stored
+    const long long qb = q0 + wave * 32 + 4 * (lane >> 5);
+    const long long HpWp = (long long)Hp * Wp;
+    int n = (int)(qb / HpWp), rem = (int)(qb - (long long)n * HpWp), yp = rem / Wp, xp0 = rem - yp * Wp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = (r & 3) + 8 * (r >> 2);
+        if (qb + o >= R) continue;
+        int xx = xp0 + o, yy = yp, nn = n;
+        while (xx >= Wp) { xx -= Wp; ++yy; }
+        while (yy >= Hp) { yy -= Hp; ++nn; }
+        if (yy < 1 || yy > p.H || xx < 1 || xx > p.W) continue;
+        const long long pix = ((long long)nn * p.H + yy - 1) * p.W + xx - 1;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = n0 + tn * 32 + (lane & 31);
+            const long long off = pix * p.Cout + col;
+            float v = acc[tn][r] + (p.bias ? p.bias[col] : 0.f);
+            if (p.addend) v += p.addend[off];
+            if (p.relu) v = v > 0.f ? v : 0.f;
+            if (p.mask) v = p.mask[off] > 0.f ? v * p.mask_scale : 0.f;
+            if (p.dropout) v = philox_uniform((unsigned long long)off, p.seed, p.stream_id) < p.keep_prob ? v / p.keep_prob : 0.f;
+            p.y[off] = v;
+        }
+    }
+}
+
 // mode 0 never, 1 when it fills the chip (the round-3 rule, 256-column tiles only), 2 whenever the shapes allow, 3 = 2 with the 128- and 64-column
 // tiles and a partial last row tile as well (the bf16_train mode)
 bool conv_bf16_256_ok(long long M, int Cin, int Cout, int mode)
@@ -587,6 +695,12 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
     const long long ktot = (long long)a.K * a.K * a.Cin;
     const int cap = ktot <= 2304 ? 64 : (ktot <= 4608 ? 128 : 256);
     if (a.any_shape) while (bn > cap && bn > 64) bn /= 2;
+    if (bn == 64 && a.K == 3 && a.any_shape && a.guarded && !a.yb) {
+        const long long R = (long long)a.N * (a.H + 2) * (a.W + 2);
+        g_last_kernel = "conv_bf16_r64_kernel";
+        hipLaunchKernelGGL(conv_bf16_r64_kernel, dim3((unsigned)(((R + 255) / 256) * (a.Cout / 64))), dim3(512), 0, s, a);
+        return true;
+    }
     const unsigned blocks = (unsigned)(rt * (a.Cout / bn));
     if (bn == 256) { g_last_kernel = "conv_bf16_256_kernel<256>"; hipLaunchKernelGGL(conv_bf16_256_kernel<256>, dim3(blocks), dim3(512), 0, s, a); }
     else if (bn == 128) { g_last_kernel = "conv_bf16_256_kernel<128>"; hipLaunchKernelGGL(conv_bf16_256_kernel<128>, dim3(blocks), dim3(512), 0, s, a); }

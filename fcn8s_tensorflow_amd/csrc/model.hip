@@ -336,7 +336,8 @@ static inline bool bf16_fwd_mode(const fcn8s_model* m) { return m->precision == 
 static inline bool bf16_train_mode(const fcn8s_model* m) { return m && m->precision == FCN8S_PREC_BF16_TRAIN; }
 // guard rows of a padded bf16 copy that the weight-gradient kernel reads (gemm_bf16.hip): the largest tap shift + one K-tile of rounding
 // (... and, for the nine-tap kernel, the eight-row instruction that completes a 34-row group: 128 rows cover all of it)
-static inline long long bf16_guard_rows(int K, int Wp) { return (long long)((K - 1) / 2) * Wp + (K - 1) / 2 + 128; }
+//  ... and conv_bf16_r64_kernel's last row tile, which runs up to 255 positions past the last one and reads 272 rows from one filter row above it: 640)
+static inline long long bf16_guard_rows(int K, int Wp) { return (long long)((K - 1) / 2) * Wp + (K - 1) / 2 + 640; }
 unsigned short* g16_for(fcn8s_model* m, std::map<std::string, unsigned short*>& bufs, std::map<std::string, size_t>& sizes, const char* layer, int N, int H, int W, int C, int K, hipStream_t s);
 unsigned short* dyb_for(fcn8s_model* m, const char* layer, const float* dy, int N, int H, int W, int C, int K, hipStream_t s, float* db = nullptr, bool* db_done = nullptr);
 
@@ -432,7 +433,7 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
             { ProfScope ps(m, "weight_relayout", 0, 6.0 * wneed); launch_w_to_bf16_flip_t(e.w_fwd, m->d_wbf16, K, Cout, Cin, s); }
             Bf16Conv256Args g{};
             g.xp = dyb; g.wt = m->d_wbf16; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K;
-            g.addend = e.addend; g.mask = e.mask; g.mask_scale = e.mask_scale; g.any_shape = 1;
+            g.addend = e.addend; g.mask = e.mask; g.mask_scale = e.mask_scale; g.any_shape = 1; g.guarded = 1;
             // this gradient is the output gradient of layer e.yb_layer (same map): its padded bf16 copy is written by this kernel's epilogue
             if (e.yb_layer && m->bf16_fuse_convert) { g.yb = g16_for(m, m->dyg16, m->dyg16_elems, e.yb_layer, N, H, W, Cout, e.yb_K, s); g.yb_pad = (e.yb_K - 1) / 2; }
             const double M = (double)N * H * W;
@@ -1092,6 +1093,7 @@ bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const c
         g.xp = xb_ready ? xb_ready : m->d_abf16; g.wt = wbuf; g.bias = Wp(m, bname); g.y = out;
         g.N = N; g.H = h; g.W = w; g.Cin = cin; g.Cout = cout; g.K = k;
         g.relu = 1; g.dropout = drop; g.keep_prob = keep_prob; g.seed = m->seed; g.stream_id = stream_id; g.any_shape = any_shape ? 1 : 0; g.mask_scale = 1.f; g.yb = yb; g.yb_pad = yb_pad;
+        g.guarded = (any_shape && xb_ready) ? 1 : 0;          // (the per-layer training copies carry guard rows; the shared inference copy does not)
         ProfScope ps(m, tag, 2.0 * M * K * cout, 4.0 * M * cout + 2.0 * M * cin + 2.0 * K * cout);
         if (launch_conv_bf16_256(g, s)) return true;
     }
@@ -2845,13 +2847,13 @@ int fcn8s_op_conv2d_bf16_train(void* stream, const float* x, const float* w, con
     if (y && x && w) {
         launch_w_to_bf16_t(w, wt, K * K * Cin, Cout, s);
         Bf16Conv256Args g{};
-        g.xp = xb + G * Cin; g.wt = wt; g.bias = bias; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K; g.relu = relu; g.any_shape = 1; g.mask_scale = 1.f;
+        g.xp = xb + G * Cin; g.wt = wt; g.bias = bias; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K; g.relu = relu; g.any_shape = 1; g.mask_scale = 1.f; g.guarded = 1;
         ok = ok && launch_conv_bf16_256(g, s);
     }
     if (dx && dy && w) {
         launch_w_to_bf16_flip_t(w, wt, K, Cin, Cout, s);
         Bf16Conv256Args g{};
-        g.xp = dyb + G * Cout; g.wt = wt; g.y = dx; g.N = N; g.H = H; g.W = W; g.Cin = Cout; g.Cout = Cin; g.K = K; g.mask = mask; g.mask_scale = 1.f; g.any_shape = 1;
+        g.xp = dyb + G * Cout; g.wt = wt; g.y = dx; g.N = N; g.H = H; g.W = W; g.Cin = Cout; g.Cout = Cin; g.K = K; g.mask = mask; g.mask_scale = 1.f; g.any_shape = 1; g.guarded = 1;
         ok = ok && launch_conv_bf16_256(g, s);
     }
     if (dw && x && dy) {
