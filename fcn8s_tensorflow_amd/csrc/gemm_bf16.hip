@@ -564,29 +564,33 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
 // (ty, tx) is row q + (ty - 1) Wp + (tx - 1) of the padded copy and the three taps of a filter row read the SAME 258 rows moved by one: a K-tile
 // (ty, 32 channels) brings 272 rows of A once (17 LDS-DMA instructions) and the three 64 x 32 weight slices, and feeds 12 MFMAs per wave.
 // A third of the A traffic, a third of the barriers.  Two stages (58 KB), two blocks per CU; plain loop, one barrier per K-tile.
-__global__ __launch_bounds__(512, 4) void conv_bf16_r64_kernel(const Bf16Conv256Args p)
+template <int BN>
+__global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv256Args p)
 {
-    constexpr int BM = 256, BN = 64, AROWS = 272, ABYTES = AROWS * G_ROWB, BBYTES = 3 * BN * G_ROWB, STAGE = ABYTES + BBYTES, NS = 2;
+    // BN = 64: 256 positions x 64 columns per block, eight waves of 32 x 64; BN = 128: 128 positions x 128 columns, waves 4 x 2 of 32 x 64
+    constexpr int WCN = BN / 64, BM = 256 / WCN, AROWS = BM + 16, NAC = AROWS / 16, NBC = 3 * BN / 16;
+    constexpr int ABYTES = AROWS * G_ROWB, BBYTES = 3 * BN * G_ROWB, STAGE = ABYTES + BBYTES, NS = 2;
+    constexpr int NAI = (NAC + 7) / 8, NBI = (NBC + 7) / 8;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WCN, wn = wave % WCN;
     const int Hp = p.H + 2, Wp = p.W + 2, Ktot = 9 * p.Cin;
     const long long R = (long long)p.N * Hp * Wp;
-    const unsigned ntm = (unsigned)((R + BM - 1) / BM), ntn = (unsigned)(p.Cout / BN);
+    const unsigned ntn = (unsigned)(p.Cout / BN);
     const unsigned lid = xcd_run(blockIdx.x, gridDim.x);
     const unsigned tmi = lid / ntn, tni = lid % ntn;               // column tiles of one row tile are neighbours: they share its A rows behind one L2
     const long long q0 = (long long)tmi * BM; const int n0 = (int)tni * BN;
-    // A chunks (16 rows each) c = wave, wave + 8, (wave 0: + 16); B chunks (tx, 16 couts) c = wave, wave + 8 (< 12)
-    const int na = wave == 0 ? 3 : 2, nbk = wave < 4 ? 2 : 1;
-    unsigned a_voff[3], b_voff[2]; unsigned a_dst[3], b_dst[2]; int b_tx[2];
+    // A chunks (16 rows each) c = wave + 8 i < NAC; B chunks (tx, 16 couts) c = wave + 8 i < NBC
+    unsigned a_voff[NAI], b_voff[NBI]; unsigned a_dst[NAI], b_dst[NBI]; int b_tx[NBI];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NAI; ++i) {
         const int chunk = wave + 8 * i, row = chunk * 16 + lane / 4, pc = lane % 4, lc = pc ^ ((row >> 2) & 3);
         a_voff[i] = (unsigned)(((long long)row * p.Cin + lc * 8) * 2);
         a_dst[i] = (unsigned)(chunk * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = wave + 8 * i, tx = (c < 12 ? c : 0) / 4, c4 = (c < 12 ? c : 0) % 4, row = c4 * 16 + lane / 4, pc = lane % 4, lc = pc ^ ((row >> 2) & 3);
+    for (int i = 0; i < NBI; ++i) {
+        const int c0 = wave + 8 * i, c = c0 < NBC ? c0 : 0, tx = c / (BN / 16), c4 = c % (BN / 16), row = c4 * 16 + lane / 4, pc = lane % 4, lc = pc ^ ((row >> 2) & 3);
         b_voff[i] = (unsigned)(((long long)row * Ktot + lc * 8) * 2);
         b_dst[i] = (unsigned)(ABYTES + tx * (BN * G_ROWB) + c4 * 1024);
         b_tx[i] = tx;
@@ -601,16 +605,16 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_r64_kernel(const Bf16Conv256
         const unsigned st = lds0 + (unsigned)((kt & 1) * STAGE);
         const unsigned short* ga = a_base + (long long)ty * Wp * p.Cin + ci;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) if (i < na) glds16b(ga, a_voff[i], st + a_dst[i]);
+        for (int i = 0; i < NAI; ++i) if (wave + 8 * i < NAC) glds16b(ga, a_voff[i], st + a_dst[i]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) if (i < nbk) glds16b(b_base + (long long)(ty * 3 + b_tx[i]) * p.Cin + ci, b_voff[i], st + b_dst[i]);
+        for (int i = 0; i < NBI; ++i) if (wave + 8 * i < NBC) glds16b(b_base + (long long)(ty * 3 + b_tx[i]) * p.Cin + ci, b_voff[i], st + b_dst[i]);
     };
     f32x16 acc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    const int arow = wave * 32 + (lane & 31);
+    const int arow = wr * 32 + (lane & 31);
     issue(0);
     for (int kt = 0; kt < nkt; ++kt) {
         wait_vm<0>();
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_r64_kernel(const Bf16Conv256
                 af[tx][ks] = *reinterpret_cast<const bf16x8*>(st + r * G_ROWB + pc * 16);
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
-                    const int rb = tn * 32 + (lane & 31), pb = (2 * ks + (lane >> 5)) ^ ((rb >> 2) & 3);
+                    const int rb = wn * 64 + tn * 32 + (lane & 31), pb = (2 * ks + (lane >> 5)) ^ ((rb >> 2) & 3);
                     bfr[tx][ks][tn] = *reinterpret_cast<const bf16x8*>(st + ABYTES + tx * (BN * G_ROWB) + rb * G_ROWB + pb * 16);
                 }
             }
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_r64_kernel(const Bf16Conv256
                     acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tx][ks], bfr[tx][ks][tn], acc[tn], 0, 0, 0);
     }
     // epilogue: position -> pixel; border positions and positions beyond the last image are not stored
-    const long long qb = q0 + wave * 32 + 4 * (lane >> 5);
+    const long long qb = q0 + wr * 32 + 4 * (lane >> 5);
     const long long HpWp = (long long)Hp * Wp;
     int n = (int)(qb / HpWp), rem = (int)(qb - (long long)n * HpWp), yp = rem / Wp, xp0 = rem - yp * Wp;
 #pragma unroll
@@ -653,7 +657,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_r64_kernel(const Bf16Conv256
         const long long pix = ((long long)nn * p.H + yy - 1) * p.W + xx - 1;
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
-            const int col = n0 + tn * 32 + (lane & 31);
+            const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
             const long long off = pix * p.Cout + col;
             float v = acc[tn][r] + (p.bias ? p.bias[col] : 0.f);
             if (p.addend) v += p.addend[off];
@@ -693,12 +697,18 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
     // and epilogue hide under the other's K loop.  Measured at 4 x 2048x1024 (profiles/r05_bf16_conv_tile_ab.txt): data gradient of conv3_2 1.48 ms with
     // 256 columns, 1.17 with 128, 1.08 with 64; conv4_2 1.01 / 0.84 / 0.94; fc6 forward (784 K-tiles) 1.56 / 1.64 / 2.26.
     const long long ktot = (long long)a.K * a.K * a.Cin;
-    const int cap = ktot <= 2304 ? 64 : (ktot <= 4608 ? 128 : 256);
+    const int cap = ktot <= 4608 ? 64 : 256;
     if (a.any_shape) while (bn > cap && bn > 64) bn /= 2;
-    if (bn == 64 && a.K == 3 && a.any_shape && a.guarded && !a.yb) {
+    if (a.K == 3 && a.any_shape && a.guarded && !a.yb) {
         const long long R = (long long)a.N * (a.H + 2) * (a.W + 2);
-        g_last_kernel = "conv_bf16_r64_kernel";
-        hipLaunchKernelGGL(conv_bf16_r64_kernel, dim3((unsigned)(((R + 255) / 256) * (a.Cout / 64))), dim3(512), 0, s, a);
+        // (the 128-column form, 128 positions x 128 columns, halves the A re-reads of the wide layers and measured 1-2 % SLOWER: 39.23 against 38.71 ms per step)
+        if (a.Cout % 128 == 0 && a.rows_bn == 128) {
+            g_last_kernel = "conv_bf16_rows_kernel<128>";
+            hipLaunchKernelGGL(conv_bf16_rows_kernel<128>, dim3((unsigned)(((R + 127) / 128) * (a.Cout / 128))), dim3(512), 0, s, a);
+        } else {
+            g_last_kernel = "conv_bf16_rows_kernel<64>";
+            hipLaunchKernelGGL(conv_bf16_rows_kernel<64>, dim3((unsigned)(((R + 255) / 256) * (a.Cout / 64))), dim3(512), 0, s, a);
+        }
         return true;
     }
     const unsigned blocks = (unsigned)(rt * (a.Cout / bn));

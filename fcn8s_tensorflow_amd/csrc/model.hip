@@ -127,6 +127,7 @@ struct fcn8s_model {
     std::map<std::string, unsigned short*> xg16; std::map<std::string, size_t> xg16_elems;
     std::map<std::string, unsigned short*> dyg16; std::map<std::string, size_t> dyg16_elems;     // ... per layer: the same kind of copy of its output gradient dY
     std::set<std::string> xg16_filled, dyg16_filled;                     // copies a producing kernel's epilogue has already written in this pass (no conversion pass)
+    int bf16_rows_bn = 0;                                                 // option (A/B): 128 = the flat-position bf16 convolution takes its 128-column tile where it can (default: 64 columns)
     int bf16_fuse_convert = 0;                                            // option: let the producing convolution write its consumer's bf16 copy (measured: the 2-byte epilogue stores cost more than the conversion passes they replace -- off)
     int saved_wino_min_cin = -1, saved_wino_fc6 = -1;                      // the options the mode overrides (the direct path carries it), restored on leaving
     int bf16_copy_by_transform = 1;                                       // option: 0 = every bf16 layer converts its input with a pass of its own (round 3's path)
@@ -433,7 +434,7 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
             { ProfScope ps(m, "weight_relayout", 0, 6.0 * wneed); launch_w_to_bf16_flip_t(e.w_fwd, m->d_wbf16, K, Cout, Cin, s); }
             Bf16Conv256Args g{};
             g.xp = dyb; g.wt = m->d_wbf16; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K;
-            g.addend = e.addend; g.mask = e.mask; g.mask_scale = e.mask_scale; g.any_shape = 1; g.guarded = 1;
+            g.addend = e.addend; g.mask = e.mask; g.mask_scale = e.mask_scale; g.any_shape = 1; g.guarded = 1; g.rows_bn = m->bf16_rows_bn;
             // this gradient is the output gradient of layer e.yb_layer (same map): its padded bf16 copy is written by this kernel's epilogue
             if (e.yb_layer && m->bf16_fuse_convert) { g.yb = g16_for(m, m->dyg16, m->dyg16_elems, e.yb_layer, N, H, W, Cout, e.yb_K, s); g.yb_pad = (e.yb_K - 1) / 2; }
             const double M = (double)N * H * W;
@@ -1093,6 +1094,7 @@ bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const c
         g.xp = xb_ready ? xb_ready : m->d_abf16; g.wt = wbuf; g.bias = Wp(m, bname); g.y = out;
         g.N = N; g.H = h; g.W = w; g.Cin = cin; g.Cout = cout; g.K = k;
         g.relu = 1; g.dropout = drop; g.keep_prob = keep_prob; g.seed = m->seed; g.stream_id = stream_id; g.any_shape = any_shape ? 1 : 0; g.mask_scale = 1.f; g.yb = yb; g.yb_pad = yb_pad;
+        g.rows_bn = m->bf16_rows_bn;
         g.guarded = (any_shape && xb_ready) ? 1 : 0;          // (the per-layer training copies carry guard rows; the shared inference copy does not)
         ProfScope ps(m, tag, 2.0 * M * K * cout, 4.0 * M * cout + 2.0 * M * cin + 2.0 * K * cout);
         if (launch_conv_bf16_256(g, s)) return true;
@@ -1917,6 +1919,7 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "conv1_in_transform") return &m->conv1_in_transform;
     if (key == "deterministic") return &m->deterministic;
     if (key == "bf16_fuse_convert") return &m->bf16_fuse_convert;
+    if (key == "bf16_rows_bn") return &m->bf16_rows_bn;
     return nullptr;
 }
 int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
@@ -1936,8 +1939,8 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
         if (value < 1) return fail(m, FCN8S_ERR_BAD_ARG, "comm_timeout_ms must be >= 1");
         std::lock_guard<std::mutex> lk(m->comm_mu); m->comm_timeout_ms = value; return FCN8S_OK;
     }
-    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform" || k == "deterministic" || k == "bf16_fuse_convert") {        // pick a kernel per launch: nothing cached depends on them
-        *model_option(m, k) = value ? 1 : 0;
+    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform" || k == "deterministic" || k == "bf16_fuse_convert" || k == "bf16_rows_bn") {        // pick a kernel per launch: nothing cached depends on them
+        *model_option(m, k) = k == "bf16_rows_bn" ? (int)value : (value ? 1 : 0);
         return FCN8S_OK;
     }
     int* slot = model_option(m, k);

@@ -9,11 +9,12 @@ def main():
     ap.add_argument("--batch", type=int, default=16); ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024); ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc", "f32x3", "bf16_fwd", "f32x2", "bf16_fwd_x2", "bf16_train"])
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE")
     ap.add_argument("--infer", action="store_true", help="predict() (frozen parameters, argmax) instead of a training step")
     args = ap.parse_args()
     import torch
     from fcn8s_tensorflow_amd.engine import Engine
-    e = Engine(20, precision=args.precision); e.init_params(0)
+    e = Engine(20, precision=args.precision, options={kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.option}); e.init_params(0)
     rng = np.random.default_rng(0)
     img = torch.from_numpy(rng.integers(0, 256, (args.batch, args.height, args.width, 3), dtype=np.uint8)).cuda()
     lab = torch.from_numpy(rng.integers(0, 20, (args.batch, args.height, args.width), dtype=np.uint8)).cuda()
