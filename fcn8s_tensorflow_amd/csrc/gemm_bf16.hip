@@ -697,7 +697,7 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
     // and epilogue hide under the other's K loop.  Measured at 4 x 2048x1024 (profiles/r05_bf16_conv_tile_ab.txt): data gradient of conv3_2 1.48 ms with
     // 256 columns, 1.17 with 128, 1.08 with 64; conv4_2 1.01 / 0.84 / 0.94; fc6 forward (784 K-tiles) 1.56 / 1.64 / 2.26.
     const long long ktot = (long long)a.K * a.K * a.Cin;
-    const int cap = ktot <= 4608 ? 64 : 256;
+    const int cap = ktot <= 2304 ? 64 : (ktot <= 4608 ? 128 : 256);      // (K = 1 and K = 7 launches; the 3 x 3 layers of the training pass take conv_bf16_rows_kernel below)
     if (a.any_shape) while (bn > cap && bn > 64) bn /= 2;
     if (a.K == 3 && a.any_shape && a.guarded && !a.yb) {
         const long long R = (long long)a.N * (a.H + 2) * (a.W + 2);
