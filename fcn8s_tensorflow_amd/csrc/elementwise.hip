@@ -115,6 +115,71 @@ void launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H
                        (const float4*)x, (const float4*)dy, (float4*)dx, N, H, W, C / 4, relu_mask);
 }
 
+// bf16_train: the same routing, but what leaves the kernel is what the block's last convolution consumes -- the interior of the zero-bordered bf16 copy
+// [N][H + 2][W + 2][C] of dZ (read by its weight and data gradients) and the column sums of dZ (its bias gradient, exact fp32) -- instead of the fp32 tensor
+// that a conversion pass would read back: 2.15 GB written and read again per step for block 1 at 4 x 2048x1024.  A block owns pooled rows (n, h); thread
+// (c, pl) = channel quad c, pixel lane pl walks the row; the column sum of a window is its routed gradient; block partial rows, added by launch_colsum.
+__global__ __launch_bounds__(256) void maxpool_bwd_bf16_kernel(const float4* __restrict__ x, const float4* __restrict__ dy, unsigned short* __restrict__ dzb,
+                                                               float* __restrict__ partial, int H, int W, int C4, int lanes, int rows_per_block, int nrows)
+{
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    __shared__ float red[256 * 4];
+    const int Ho = H / 2, Wo = W / 2, Wp = W + 2, Hp = H + 2;
+    const int c = threadIdx.x % C4, pl = threadIdx.x / C4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pl < lanes) {
+        for (int r = blockIdx.x * rows_per_block; r < (blockIdx.x + 1) * rows_per_block && r < nrows; ++r) {
+            const int n = r / Ho, h = r - n * Ho;
+            const float4* x0 = x + (((long long)n * H + 2 * h) * W) * C4;
+            const float4* g0 = dy + (long long)r * Wo * C4;
+            bf16x4* d0 = reinterpret_cast<bf16x4*>(dzb) + (((long long)n * Hp + 2 * h + 1) * Wp + 1) * C4;       // padded pixel (2h + 1, 1)
+            for (int w = pl; w < Wo; w += lanes) {
+                const long long b0 = (long long)(2 * w) * C4 + c, b2 = b0 + (long long)W * C4;
+                const float4 a = x0[b0], b = x0[b0 + C4], cc = x0[b2], d = x0[b2 + C4], g = g0[(long long)w * C4 + c];
+                float4 oa, ob, oc, od;
+                route(a.x, b.x, cc.x, d.x, g.x, 1, oa.x, ob.x, oc.x, od.x);
+                route(a.y, b.y, cc.y, d.y, g.y, 1, oa.y, ob.y, oc.y, od.y);
+                route(a.z, b.z, cc.z, d.z, g.z, 1, oa.z, ob.z, oc.z, od.z);
+                route(a.w, b.w, cc.w, d.w, g.w, 1, oa.w, ob.w, oc.w, od.w);
+                const long long p0 = (long long)(2 * w) * C4 + c, p2 = p0 + (long long)Wp * C4;
+                d0[p0] = bf16x4{(__bf16)oa.x, (__bf16)oa.y, (__bf16)oa.z, (__bf16)oa.w};
+                d0[p0 + C4] = bf16x4{(__bf16)ob.x, (__bf16)ob.y, (__bf16)ob.z, (__bf16)ob.w};
+                d0[p2] = bf16x4{(__bf16)oc.x, (__bf16)oc.y, (__bf16)oc.z, (__bf16)oc.w};
+                d0[p2 + C4] = bf16x4{(__bf16)od.x, (__bf16)od.y, (__bf16)od.z, (__bf16)od.w};
+                acc[0] += (oa.x + ob.x) + (oc.x + od.x); acc[1] += (oa.y + ob.y) + (oc.y + od.y);
+                acc[2] += (oa.z + ob.z) + (oc.z + od.z); acc[3] += (oa.w + ob.w) + (oc.w + od.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[threadIdx.x * 4 + i] = acc[i];
+    __syncthreads();
+    if (pl == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = acc[i];
+            for (int l = 1; l < lanes; ++l) v += red[(l * C4 + c) * 4 + i];
+            partial[(long long)blockIdx.x * C4 * 4 + c * 4 + i] = v;
+        }
+    }
+}
+// dzb points at padded pixel 0 of the copy (border zero already); db[c] += column sums of dZ.  Returns false if the shape is not covered.
+bool launch_maxpool_bwd_bf16(const float* x, const float* dy, unsigned short* dzb, float* db, int N, int H, int W, int C, hipStream_t s)
+{
+    const int C4 = C / 4;
+    if (C % 4 || C4 > 256 || H % 2 || W % 2) return false;
+    const int lanes = 256 / C4, nrows = N * (H / 2), Wo = W / 2;
+    int rpb = (8 * lanes + Wo - 1) / Wo;                 // >= 8 windows per thread
+    if (rpb < 1) rpb = 1;
+    while ((nrows + rpb - 1) / rpb > 2048) rpb *= 2;
+    const int blocks = (nrows + rpb - 1) / rpb;
+    float* partial = det_scratch(s, (size_t)blocks * C);
+    if (!partial) return false;
+    hipLaunchKernelGGL(maxpool_bwd_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)x, (const float4*)dy, dzb, partial, H, W, C4, lanes, rpb, nrows);
+    if (db) launch_colsum(partial, db, blocks, C, s);
+    return true;
+}
+
 // which element of each 2x2 window maxpool_bwd_kernel routes to (0..3, first maximum; 4 = the maximum is not > 0: no gradient) -- the
 // record fcn8s_get_pool_routing hands to the parity checker for blocks whose routing is not already kept as argmax bytes
 __global__ void maxpool_route_kernel(const float* x, unsigned char* r, int N, int H, int W, int C)

@@ -186,6 +186,8 @@ bool launch_head_fwd(const float* x, const float* w, const float* bias, float* y
 bool launch_head_dgrad(const float* dy, const float* wt, const float* mask, float mask_scale, float* dx, long long M, int K, int C, float alpha,
                        hipStream_t s);
 bool launch_head_wgrad(const float* x, const float* dy, float* dw, long long M, int K, int C, float alpha, hipStream_t s);
+// bf16_train: max-pool backward (ReLU fused) whose output is the padded bf16 copy of dZ (interior; border zero already) plus db[c] += column sums of dZ
+bool launch_maxpool_bwd_bf16(const float* x, const float* dy, unsigned short* dzb, float* db, int N, int H, int W, int C, hipStream_t s);
 void launch_colsum(const float* x, float* out, long long rows, int C, hipStream_t s);      // out[c] += sum_r x[r,c]
 void launch_sumsq(const float* x, float* out, long long n, hipStream_t s);                  // out[0] += sum x^2
 void launch_axpy(float* y, const float* x, float a, long long n, hipStream_t s);           // y += a*x

@@ -642,29 +642,47 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
                 for (int tn = 0; tn < 2; ++tn)
                     acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tx][ks], bfr[tx][ks][tn], acc[tn], 0, 0, 0);
     }
-    // epilogue: position -> pixel; border positions and positions beyond the last image are not stored
+    // epilogue: position -> pixel; border positions and positions beyond the last image are not stored.
+    // p.yb: the consumer is another 3 x 3 layer on the same map, so its padded bf16 copy has THIS geometry and position q of the output is row q of that copy:
+    // the wave parks its 32 x 64 tile as bf16 in LDS (the stages are free by now), zeros at border positions, and stores it 16 bytes per lane.
+    if (p.yb) __syncthreads();
+    unsigned short* patch = reinterpret_cast<unsigned short*>(smem) + wave * (32 * 64);
     const long long qb = q0 + wr * 32 + 4 * (lane >> 5);
     const long long HpWp = (long long)Hp * Wp;
     int n = (int)(qb / HpWp), rem = (int)(qb - (long long)n * HpWp), yp = rem / Wp, xp0 = rem - yp * Wp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int o = (r & 3) + 8 * (r >> 2);
-        if (qb + o >= R) continue;
         int xx = xp0 + o, yy = yp, nn = n;
         while (xx >= Wp) { xx -= Wp; ++yy; }
         while (yy >= Hp) { yy -= Hp; ++nn; }
-        if (yy < 1 || yy > p.H || xx < 1 || xx > p.W) continue;
+        const bool valid = qb + o < R && yy >= 1 && yy <= p.H && xx >= 1 && xx <= p.W;
         const long long pix = ((long long)nn * p.H + yy - 1) * p.W + xx - 1;
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
             const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
-            const long long off = pix * p.Cout + col;
-            float v = acc[tn][r] + (p.bias ? p.bias[col] : 0.f);
-            if (p.addend) v += p.addend[off];
-            if (p.relu) v = v > 0.f ? v : 0.f;
-            if (p.mask) v = p.mask[off] > 0.f ? v * p.mask_scale : 0.f;
-            if (p.dropout) v = philox_uniform((unsigned long long)off, p.seed, p.stream_id) < p.keep_prob ? v / p.keep_prob : 0.f;
-            p.y[off] = v;
+            float v = 0.f;
+            if (valid) {
+                const long long off = pix * p.Cout + col;
+                v = acc[tn][r] + (p.bias ? p.bias[col] : 0.f);
+                if (p.addend) v += p.addend[off];
+                if (p.relu) v = v > 0.f ? v : 0.f;
+                if (p.mask) v = p.mask[off] > 0.f ? v * p.mask_scale : 0.f;
+                if (p.dropout) v = philox_uniform((unsigned long long)off, p.seed, p.stream_id) < p.keep_prob ? v / p.keep_prob : 0.f;
+                p.y[off] = v;
+            }
+            if (p.yb) reinterpret_cast<__bf16*>(patch)[(o + 4 * (lane >> 5)) * 64 + tn * 32 + (lane & 31)] = (__bf16)v;
+        }
+    }
+    if (p.yb) {
+        __builtin_amdgcn_wave_barrier();                // (the patch is this wave's own)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = i * 64 + lane, row = id >> 3, ch = id & 7;
+            const long long q = q0 + wr * 32 + row;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + row * 64 + ch * 8);
+            *reinterpret_cast<bf16x8*>(p.yb + q * p.Cout + n0 + wn * 64 + ch * 8) = v;
         }
     }
 }
@@ -699,7 +717,7 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
     const long long ktot = (long long)a.K * a.K * a.Cin;
     const int cap = ktot <= 2304 ? 64 : (ktot <= 4608 ? 128 : 256);      // (K = 1 and K = 7 launches; the 3 x 3 layers of the training pass take conv_bf16_rows_kernel below)
     if (a.any_shape) while (bn > cap && bn > 64) bn /= 2;
-    if (a.K == 3 && a.any_shape && a.guarded && !a.yb) {
+    if (a.K == 3 && a.any_shape && a.guarded && (!a.yb || a.yb_pad == 1)) {
         const long long R = (long long)a.N * (a.H + 2) * (a.W + 2);
         // (the 128-column form, 128 positions x 128 columns, halves the A re-reads of the wide layers and measured 1-2 % SLOWER: 39.23 against 38.71 ms per step)
         if (a.Cout % 128 == 0 && a.rows_bn == 128) {

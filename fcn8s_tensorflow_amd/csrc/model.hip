@@ -126,6 +126,8 @@ struct fcn8s_model {
     // the forward pass and read again by the layer's weight gradient
     std::map<std::string, unsigned short*> xg16; std::map<std::string, size_t> xg16_elems;
     std::map<std::string, unsigned short*> dyg16; std::map<std::string, size_t> dyg16_elems;     // ... per layer: the same kind of copy of its output gradient dY
+    std::set<std::string> db_taken;                                      // layers whose bias gradient the producer of their dY copy has already added (this backward pass)
+    int bf16_fuse_pool = 1;                                               // option: bf16_train, the max-pool backward writes the last conv's bf16 dZ copy and bias gradient directly
     std::set<std::string> xg16_filled, dyg16_filled;                     // copies a producing kernel's epilogue has already written in this pass (no conversion pass)
     int bf16_rows_bn = 0;                                                 // option (A/B): 128 = the flat-position bf16 convolution takes its 128-column tile where it can (default: 64 columns)
     int bf16_fuse_convert = 0;                                            // option: let the producing convolution write its consumer's bf16 copy (measured: the 2-byte epilogue stores cost more than the conversion passes they replace -- off)
@@ -436,7 +438,7 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
             g.xp = dyb; g.wt = m->d_wbf16; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K;
             g.addend = e.addend; g.mask = e.mask; g.mask_scale = e.mask_scale; g.any_shape = 1; g.guarded = 1; g.rows_bn = m->bf16_rows_bn;
             // this gradient is the output gradient of layer e.yb_layer (same map): its padded bf16 copy is written by this kernel's epilogue
-            if (e.yb_layer && m->bf16_fuse_convert) { g.yb = g16_for(m, m->dyg16, m->dyg16_elems, e.yb_layer, N, H, W, Cout, e.yb_K, s); g.yb_pad = (e.yb_K - 1) / 2; }
+            if (e.yb_layer && m->bf16_fuse_convert && K == 3 && e.yb_K == 3) { g.yb = g16_for(m, m->dyg16, m->dyg16_elems, e.yb_layer, N, H, W, Cout, e.yb_K, s); g.yb_pad = (e.yb_K - 1) / 2; }
             const double M = (double)N * H * W;
             ProfScope ps(m, K == 1 ? "fc7_dgrad_bf16" : (K == 3 ? "conv3x3_dgrad_bf16" : "fc6_dgrad_bf16"), 2.0 * M * K * K * Cin * Cout, 4.0 * M * Cout * (e.mask ? 2.0 : 1.0) + 2.0 * M * Cin + 2.0 * wneed, layer);
             if (launch_conv_bf16_256(g, s)) { if (g.yb) m->dyg16_filled.insert(e.yb_layer); return false; }
@@ -696,6 +698,7 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             const long long G = bf16_guard_rows(K, Wp_), R = (long long)N * (H + 2 * pad) * Wp_;
             bool db_done = false;
             unsigned short* dyb = dyb_for(m, layer, dz, N, H, W, Cout, K, s, db, &db_done);
+            if (m->db_taken.count(layer)) db_done = true;          // (the kernel that wrote this layer's dY copy added the bias gradient too)
             if (dyb) {
                 Bf16WgradArgs g{};
                 g.A = it->second + G * Cin; g.B = dyb; g.C = dw; g.R = R; g.Ci = Cin; g.Cj = Cout; g.K = K; g.Wp = Wp_;
@@ -1353,7 +1356,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
         unsigned short* xb6 = train ? xg16_for(m, "fc6", N, h5, w5, m->widths[4], m->fc6k, s) : nullptr;
         if (xb6) { ProfScope ps(m, "bf16_convert", 0, 6.0 * N * h5 * w5 * m->widths[4]); launch_f32_to_bf16_padded(x, xb6, N, h5, w5, m->widths[4], (m->fc6k - 1) / 2, s); }
         unsigned short* xb7 = train ? xg16_for(m, "fc7", N, h5, w5, m->widths[5], 1, s) : nullptr;
-        const bool fuse7 = xb7 && m->bf16_fuse_convert;
+        const bool fuse7 = false;          // (fc6 runs on the tile kernel, whose bf16 side output is 2-byte stores: its 134 MB are converted by a pass of their own)
         if (!bf16_conv_layer(m, "fc6_fwd_bf16", "fc6/weights", "fc6/biases", x, A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, drop, keep_prob, m->drop_stream, s, false, xb6, true,
                              fuse7 ? xb7 : nullptr, 0))
             return fail(m, FCN8S_ERR_SHAPE, "bf16_train: fc6 does not fit the bf16 convolution kernel");
@@ -1567,7 +1570,18 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
             const bool wino_both = pool_backward_fused(m, b, m->pool_fused[b - 1]);
             if (wino_both) pidx = (const unsigned char*)A(m, ix);
         }
-        if (!pidx) {
+        bool pool_done = false;
+        if (!pidx && bf16_train_mode(m) && m->bf16_fuse_pool && m->train_mode && cw % 64 == 0) {
+            // bf16_train: nobody reads the fp32 dZ of the block's last conv -- its weight and data gradients take the padded bf16 copy, its bias gradient the
+            // column sums: the pool's backward kernel writes exactly those (gbuf[gcur ^ 1] stays unwritten; the "dz" handed on below is never dereferenced)
+            unsigned short* dzb = g16_for(m, m->dyg16, m->dyg16_elems, last, N, h, w, cw, 3, s);
+            if (dzb) {
+                ProfScope ps(m, "maxpool_bwd", 0, 4.0 * N * h * w * cw * 1.25 + 2.0 * N * h * w * cw);
+                pool_done = launch_maxpool_bwd_bf16(A(m, last), m->gbuf[m->gcur], dzb, Gp(m, std::string(last) + "/biases"), N, h, w, cw, s);
+            }
+            if (pool_done) { m->dyg16_filled.insert(last); m->db_taken.insert(last); m->gcur ^= 1; }
+        }
+        if (!pidx && !pool_done) {
             ProfScope ps(m, "maxpool_bwd", 0, 4.0 * N * h * w * cw * 2.25);
             launch_maxpool_bwd(A(m, last), m->gbuf[m->gcur], m->gbuf[m->gcur ^ 1], N, h, w, cw, 1, s);
             m->gcur ^= 1;
@@ -1636,7 +1650,7 @@ int do_backward_bucket(fcn8s_model* m, int bucket, int level_cap)
     if (bucket == 0) {
         m->defer_level_now = m->defer_wgrad >= 3 ? 2 : std::min(m->defer_wgrad, level_cap);      // 3: the caller does not consume bucket 0 early
         if (m->profile && m->profile_detail) m->defer_level_now = 0;      // per-layer timing wants one kernel at a time
-        m->deferred.clear(); m->ev_next = 0; m->dyg16_filled.clear();
+        m->deferred.clear(); m->ev_next = 0; m->dyg16_filled.clear(); m->db_taken.clear();
         m->dm_prefilled.clear();                                           // (a promise left over from a backward pass that ended in an error)
         m->on_tail = false; m->launch_stream = nullptr;                    // (a backward pass that ended in an error may have left them set)
         for (int b = 0; b < kNumBuckets; ++b) m->bucket_final[b] = false;
@@ -1920,6 +1934,7 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "deterministic") return &m->deterministic;
     if (key == "bf16_fuse_convert") return &m->bf16_fuse_convert;
     if (key == "bf16_rows_bn") return &m->bf16_rows_bn;
+    if (key == "bf16_fuse_pool") return &m->bf16_fuse_pool;
     return nullptr;
 }
 int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
@@ -1939,7 +1954,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
         if (value < 1) return fail(m, FCN8S_ERR_BAD_ARG, "comm_timeout_ms must be >= 1");
         std::lock_guard<std::mutex> lk(m->comm_mu); m->comm_timeout_ms = value; return FCN8S_OK;
     }
-    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform" || k == "deterministic" || k == "bf16_fuse_convert" || k == "bf16_rows_bn") {        // pick a kernel per launch: nothing cached depends on them
+    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform" || k == "deterministic" || k == "bf16_fuse_convert" || k == "bf16_rows_bn" || k == "bf16_fuse_pool") {        // pick a kernel per launch: nothing cached depends on them
         *model_option(m, k) = k == "bf16_rows_bn" ? (int)value : (value ? 1 : 0);
         return FCN8S_OK;
     }
