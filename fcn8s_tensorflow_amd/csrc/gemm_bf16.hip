@@ -402,10 +402,16 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
         a_voff[i] = (unsigned)((pp * p.Cin + lc * 8) * 2);
         b_voff[i] = (unsigned)(((long long)(row < BN ? row : 0) * Ktot + lc * 8) * 2);
     }
-    const unsigned short* b_base = p.wt + (long long)n0 * Ktot;
+    // split K (p.ksplit > 1, blockIdx.y): this block reduces K-tiles [kt0, kt0 + nkt) and stores its raw accumulators into slab blockIdx.y (launcher: only
+    // launches whose epilogue is the identity -- fc6's data gradient: 64 row x column tiles of 256 x 256 for a 200 704-deep reduction)
+    const int nkt_all = Ktot / G_BK;
+    const int kt0 = p.ksplit > 1 ? (int)((long long)nkt_all * blockIdx.y / p.ksplit) : 0;
+    const int nkt = (p.ksplit > 1 ? (int)((long long)nkt_all * (blockIdx.y + 1) / p.ksplit) : nkt_all) - kt0;
+    const unsigned short* b_base = p.wt + (long long)n0 * Ktot + (long long)kt0 * G_BK;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     // K-tiles are issued strictly in order, one call per tile: the tap position advances incrementally
-    int i_kt = 0, i_ci = 0, i_tx = 0, i_ty = 0;
+    const int cpt = p.Cin / G_BK;                                      // K-tiles per tap
+    int i_kt = 0, i_ci = (kt0 % cpt) * G_BK, i_tx = (kt0 / cpt) % p.K, i_ty = (kt0 / cpt) / p.K;
     auto issue = [&]() {
         const unsigned st = lds0 + (unsigned)((i_kt % NS) * STAGE);
         const unsigned short* ga = p.xp + ((long long)i_ty * Wp + i_tx) * p.Cin + i_ci;
@@ -463,7 +469,6 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
         __builtin_amdgcn_s_setprio(0);
     };
 
-    const int nkt = Ktot / G_BK;
     // this wave's pieces of K-tile kt have landed when at most (tiles still allowed in flight) x (2 + nb) of its loads are outstanding
     auto wait_n = [&](int tiles) {
         if (BN == 256 || nb == 2) { if (tiles >= 3) wait_vm<12>(); else if (tiles == 2) wait_vm<8>(); else if (tiles == 1) wait_vm<4>(); else wait_vm<0>(); }
@@ -505,6 +510,19 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
         }
     }
 
+    if (p.ksplit > 1) {
+        float* part = p.part + (long long)blockIdx.y * p.M * p.Cout;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long m = m0 + grp * 128 + wr * (TM * 32) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < p.M) part[m * p.Cout + n0 + wn * 64 + tn * 32 + (lane & 31)] = acc[tm][tn][r];
+                }
+        return;
+    }
     // epilogue (fp32): bias, skip-path addend, ReLU, the ReLU mask of a data gradient, dropout keyed by the element offset -- the same Philox stream as the fp32 path
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -706,6 +724,26 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
     if ((double)a.N * (a.H + a.K - 1) * (a.W + a.K - 1) * a.Cin * 2.0 >= 4294967296.0 || (double)a.Cout * a.K * a.K * a.Cin * 2.0 >= 4294967296.0) return false;
     const double abytes = 2.0 * a.M * a.K * a.K * a.Cin, bbytes = 2.0 * a.K * a.K * a.Cin * a.Cout;
     a.m_fastest = bbytes > abytes;             // the larger operand's panel stays put behind one XCD's L2 while the other one streams
+    // a long reduction behind few output tiles and an identity epilogue (fc6's data gradient): keep the wide tile and split K over blockIdx.y into slabs that
+    // a second kernel adds in split order (reproducible: no atomics)
+    a.ksplit = 1;
+    {
+        const long long rt0 = (a.M + G_BM - 1) / G_BM;
+        const long long nkt_all = (long long)a.K * a.K * a.Cin / G_BK;
+        const bool plain = !a.bias && !a.addend && !a.mask && !a.relu && !a.dropout && !a.yb;
+        if (a.any_shape && plain && a.Cout % 256 == 0 && rt0 * (a.Cout / 256) < 128 && nkt_all >= 512) {
+            long long ks = 256 / (rt0 * (a.Cout / 256));
+            if (ks > 8) ks = 8;
+            float* part = ks >= 2 ? det_scratch(s, (size_t)(ks * a.M * a.Cout)) : nullptr;
+            if (part) {
+                a.ksplit = (int)ks; a.part = part;
+                g_last_kernel = "conv_bf16_256_kernel<256>";
+                hipLaunchKernelGGL(conv_bf16_256_kernel<256>, dim3((unsigned)(rt0 * (a.Cout / 256)), (unsigned)ks), dim3(512), 0, s, a);
+                launch_det_reduce(a.y, part, a.M, a.Cout, a.Cout, a.M * (long long)a.Cout, (int)ks, false, s);
+                return true;
+            }
+        }
+    }
     // the widest column tile that divides Cout -- unless that leaves CUs without a block (fc6's data gradient: 32 row tiles x 512 / 256 = 64 blocks for
     // 200 704-deep dot products): then the narrower tiles, which multiply the block count
     const long long rt = (a.M + G_BM - 1) / G_BM;

@@ -228,6 +228,7 @@ def test_conv_bf16_mfma(N, H, W, Cin, Cout, K):
     (1, 64, 64, 64, 64, 3),        # 4356 padded rows: the weight gradient's row range is split over several blocks
     (3, 4, 8, 64, 128, 7),         # fc6's kernel size: guard rows of 3 * Wp + 3 + 32
     (2, 4, 4, 128, 256, 1),        # fc7: a plain GEMM, no padding
+    (1, 8, 16, 256, 512, 7),       # fc6's shape class: the data gradient (one 256 x 256 tile, 784 K-tiles) splits K into eight slabs added in order
 ])
 def test_conv_bf16_train_kernels(N, H, W, Cin, Cout, K):
     """The three products of FCN8S_PREC_BF16_TRAIN on the kernels that mode runs (fcn8s_op_conv2d_bf16_train -> conv_bf16_256_kernel<64|128|256> for
@@ -261,6 +262,11 @@ def test_conv_bf16_train_kernels(N, H, W, Cin, Cout, K):
     assert rel_err(dw_.cpu().numpy(), dw_ref) < 1e-5
     assert rel_err(db_.cpu().numpy(), db_ref) < 1e-5
     assert 1e-5 < rel_err(dw_.cpu().numpy(), dw_exact) < 3e-2
+    # the data gradient without a mask (fc6's case: an identity epilogue -- few output tiles behind a long reduction split K into slabs added in split order)
+    dx2 = torch.full((N, H, W, Cin), 7.0).cuda()
+    L.check(L.lib.fcn8s_op_conv2d_bf16_train(None, None, ptr(wd), None, None, 0, ptr(dyd), None, ptr(dx2), None, None, N, H, W, Cin, Cout, K))
+    torch.cuda.synchronize()
+    assert rel_err(dx2.cpu().numpy(), nhwc(torch.nn.grad.conv2d_input(xr.shape, wr, dyr, padding=pad))) < 1e-5
     # deterministic mode: the split weight gradient through slabs, bit-identical from run to run and equal to the default to round-off
     L.check(L.lib.fcn8s_set_option(None, b"op_deterministic", 1))
     try:
