@@ -277,8 +277,9 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *                              sum; split-K GEMMs are simply not split) stores one partial result per split into a scratch slab, and a second kernel adds
  *                              the slabs in split order: two runs of the same steps on the same inputs give the same bits.  +2.4 % at 16 x 1024x512
  *     "bf16_fuse_convert" 0    FCN8S_PREC_BF16_TRAIN: the producing convolution's epilogue also writes its consumer's padded bf16 copy (measured slower)
+ *     "bf16_fuse_pool"    1    FCN8S_PREC_BF16_TRAIN: the max-pool backward kernel writes the last conv's padded bf16 dZ copy and bias gradient itself; 0 = two passes
  *     "bf16_rows_bn"      0    FCN8S_PREC_BF16_TRAIN: 128 = the flat-position 3 x 3 convolution kernel takes its 128-column tile where it can (A/B; slower)
- *                              (these seven pick a kernel per launch and drop nothing)
+ *                              (these eight pick a kernel per launch and drop nothing)
  *     "comm_timeout_ms" 600000 the communicator's watchdog (see fcn8s_comm_init): a collective older than this is given up, the communicator aborted
  *   op-context options (m == NULL): the arithmetic of the op-level entry points below, which have no model.  The value belongs to the
  *   CALLING THREAD (thread-local) and is read by that thread's later fcn8s_op_* calls only; no model ever reads it, so two models -- or a
