@@ -74,6 +74,7 @@ struct Bf16Conv256Args {
     const float* addend;               // optional, [M][Cout]: added before ReLU / mask (a data gradient's skip-path term)
     const float* mask; float mask_scale;   // optional, [M][Cout]: y = mask > 0 ? y * mask_scale : 0 (the ReLU / dropout of the layer whose input gradient this is)
     int any_shape;                     // 1: Cout % 64 == 0 and any M are taken (64- / 128-column tiles, partial last row tile); 0: the round-3 rule
+    const unsigned short* mask16;      // optional (flat-position kernel only): the padded bf16 copy [N][H + 2][W + 2][Cout] whose sign is the mask, instead of `mask`
     int ksplit; float* part;           // set by the launcher: K split over blockIdx.y into `ksplit` slabs of raw accumulators at `part`
     int rows_bn;                       // (A/B) 128: the flat-position kernel takes its 128-column form where Cout % 128 == 0 (default: 64 columns everywhere)
     int guarded;                       // 1: xp has zeroed guard rows in front and behind (>= W + 3 + 16 rows of Cin): the flat-position kernel may be taken

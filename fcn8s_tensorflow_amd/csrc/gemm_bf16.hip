@@ -685,7 +685,10 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
                 v = acc[tn][r] + (p.bias ? p.bias[col] : 0.f);
                 if (p.addend) v += p.addend[off];
                 if (p.relu) v = v > 0.f ? v : 0.f;
-                if (p.mask) v = p.mask[off] > 0.f ? v * p.mask_scale : 0.f;
+                // (the ReLU mask of a data gradient: the sign of the layer's padded bf16 INPUT copy, which has this kernel's geometry -- row q, half the bytes of
+                //  the fp32 activation and no pixel arithmetic; bf16 keeps fp32's exponent range, so x > 0 <=> bf16(x) > 0 for every normal x)
+                if (p.mask16) v = (short)p.mask16[(qb + o) * p.Cout + col] > 0 ? v * p.mask_scale : 0.f;
+                else if (p.mask) v = p.mask[off] > 0.f ? v * p.mask_scale : 0.f;
                 if (p.dropout) v = philox_uniform((unsigned long long)off, p.seed, p.stream_id) < p.keep_prob ? v / p.keep_prob : 0.f;
                 p.y[off] = v;
             }

@@ -437,6 +437,10 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
             Bf16Conv256Args g{};
             g.xp = dyb; g.wt = m->d_wbf16; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K;
             g.addend = e.addend; g.mask = e.mask; g.mask_scale = e.mask_scale; g.any_shape = 1; g.guarded = 1; g.rows_bn = m->bf16_rows_bn;
+            if (e.mask && K == 3 && e.mask_scale == 1.f) {          // the mask is the ReLU of this layer's input: its sign is in the layer's own bf16 input copy
+                auto xi = m->xg16.find(layer);
+                if (xi != m->xg16.end() && xi->second) g.mask16 = xi->second + bf16_guard_rows(3, W + 2) * Cout;
+            }
             // this gradient is the output gradient of layer e.yb_layer (same map): its padded bf16 copy is written by this kernel's epilogue
             if (e.yb_layer && m->bf16_fuse_convert && K == 3 && e.yb_K == 3) { g.yb = g16_for(m, m->dyg16, m->dyg16_elems, e.yb_layer, N, H, W, Cout, e.yb_K, s); g.yb_pad = (e.yb_K - 1) / 2; }
             const double M = (double)N * H * W;
