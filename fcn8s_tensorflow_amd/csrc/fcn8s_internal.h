@@ -138,7 +138,7 @@ bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, 
 
 // conv1_1 forward with bias + ReLU on the LDS-DMA gather kernel (Cout = 64 only; returns false otherwise): x4 [N,H,W,4], w48 [48][64]
 // (taps x 4 channels, rows 36..47 zero), zero16 = 16 zero bytes in device memory (what taps outside the image read)
-bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, int tiled, hipStream_t s);
+bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, int tiled, hipStream_t s, unsigned short* yb16 = nullptr);
 
 // weight gradient of the 16x16 / stride-8 transposed conv with 20 channels (VALU; dW zero-initialised, accumulated with atomics);
 // returns false for any other shape: the caller then uses launch_wgrad.

@@ -690,7 +690,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
                 if (p.mask16) v = (short)p.mask16[(qb + o) * p.Cout + col] > 0 ? v * p.mask_scale : 0.f;
                 else if (p.mask) v = p.mask[off] > 0.f ? v * p.mask_scale : 0.f;
                 if (p.dropout) v = philox_uniform((unsigned long long)off, p.seed, p.stream_id) < p.keep_prob ? v / p.keep_prob : 0.f;
-                p.y[off] = v;
+                if (p.y) p.y[off] = v;                  // (no fp32 output: the padded bf16 copy below is the layer's only reader's input)
             }
             if (p.yb) reinterpret_cast<__bf16*>(patch)[(o + 4 * (lane >> 5)) * 64 + tn * 32 + (lane & 31)] = (__bf16)v;
         }
@@ -733,7 +733,7 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
     {
         const long long rt0 = (a.M + G_BM - 1) / G_BM;
         const long long nkt_all = (long long)a.K * a.K * a.Cin / G_BK;
-        const bool plain = !a.bias && !a.addend && !a.mask && !a.relu && !a.dropout && !a.yb;
+        const bool plain = !a.bias && !a.addend && !a.mask && !a.relu && !a.dropout && !a.yb && a.y;
         if (a.any_shape && plain && a.Cout % 256 == 0 && rt0 * (a.Cout / 256) < 128 && nkt_all >= 512) {
             long long ks = 256 / (rt0 * (a.Cout / 256));
             if (ks > 8) ks = 8;
@@ -770,6 +770,7 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
         }
         return true;
     }
+    if (!a.y) return false;                    // (only the flat-position kernel runs without an fp32 output)
     const unsigned blocks = (unsigned)(rt * (a.Cout / bn));
     if (bn == 256) { g_last_kernel = "conv_bf16_256_kernel<256>"; hipLaunchKernelGGL(conv_bf16_256_kernel<256>, dim3(blocks), dim3(512), 0, s, a); }
     else if (bn == 128) { g_last_kernel = "conv_bf16_256_kernel<128>"; hipLaunchKernelGGL(conv_bf16_256_kernel<128>, dim3(blocks), dim3(512), 0, s, a); }

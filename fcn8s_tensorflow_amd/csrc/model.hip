@@ -112,6 +112,7 @@ struct fcn8s_model {
     int fuse_dgrad_dout = 1;                                              // option: allow that fusion
     int fuse_out_in = 1;                                                  // option: inside a block, conv L's output transform writes conv L+1's V directly (Y is never written): 0 never, 1 unless the row ranges would get too short, 2 always
     std::string fwd_v_layer;                                              // forward: layer whose V the previous layer's fused output transform has already written
+    std::set<std::string> in_bf16_only;                                   // bf16_train, option bf16_acts: layers whose fp32 INPUT was not written by the last training forward pass (their padded bf16 copy is all there is)
     std::set<std::string> y_unwritten;                                    // layers whose activation tensor was not materialised by the last forward pass
     int conv1_tiled = 1, conv1_wgrad_mfma = 1;                            // options: conv1_1 forward on the spatial-tile kernel / its weight gradient on the matrix core
     int conv1_in_transform = 1;                                           // option: conv1_1 is evaluated inside conv1_2's input transform (its activation tensor is never written)
@@ -130,6 +131,7 @@ struct fcn8s_model {
     int bf16_fuse_pool = 1;                                               // option: bf16_train, the max-pool backward writes the last conv's bf16 dZ copy and bias gradient directly
     std::set<std::string> xg16_filled, dyg16_filled;                     // copies a producing kernel's epilogue has already written in this pass (no conversion pass)
     int bf16_rows_bn = 0;                                                 // option (A/B): 128 = the flat-position bf16 convolution takes its 128-column tile where it can (default: 64 columns)
+    int bf16_acts = 1;                                                    // option: bf16_train training passes keep a conv -> conv activation only as the consumer's padded bf16 copy (the producer's epilogue writes it; no fp32 tensor, no conversion pass)
     int bf16_fuse_convert = 0;                                            // option: let the producing convolution write its consumer's bf16 copy (measured: the 2-byte epilogue stores cost more than the conversion passes they replace -- off)
     int saved_wino_min_cin = -1, saved_wino_fc6 = -1;                      // the options the mode overrides (the direct path carries it), restored on leaving
     int bf16_copy_by_transform = 1;                                       // option: 0 = every bf16 layer converts its input with a pass of its own (round 3's path)
@@ -448,6 +450,9 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
             if (launch_conv_bf16_256(g, s)) { if (g.yb) m->dyg16_filled.insert(e.yb_layer); return false; }
         }
     }
+    if (bf16_train_mode(m) && m->train_mode && layer && e.mask && m->in_bf16_only.count(layer)) {
+        fprintf(stderr, "fcn8s: bf16_train: %s's data gradient could not run on the bf16 kernel and its fp32 mask was not kept (option \"bf16_acts\" = 0 keeps it)\n", layer); abort();
+    }
     const bool wino3 = m && K == 3 && m->wino_min_cin > 0 && Cin >= m->wino_min_cin && m->d_wino_v && wino_tile_for(m, H, W, 3) && !e.dropout;
     const bool wino7 = m && K == 7 && m->wino_fc6 && m->d_wino_v && wino_tile_for(m, H, W, 7) == 4;
     if (m && wino3 && e.dgrad && layer && e.w_fwd && !m->dm_layer.empty() && m->dm_layer == layer && wino_tile_for(m, H, W, 3) == 6 &&
@@ -716,6 +721,9 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
                 if (db_done) { fprintf(stderr, "fcn8s: bf16_train: %s's weight-gradient launch refused its shape after the bias gradient was taken\n", layer); abort(); }
             }
         }
+    }
+    if (bf16_train_mode(m) && m->train_mode && layer && m->in_bf16_only.count(layer)) {
+        fprintf(stderr, "fcn8s: bf16_train: %s's weight gradient could not run on the bf16 kernel and its fp32 input was not kept (option \"bf16_acts\" = 0 keeps it)\n", layer); abort();
     }
     if (m && (K == 3 || K == 7) && layer && alpha == 1.f && !real_cin && m->train_mode) {
         auto it = m->acts.find(std::string("wv:") + layer);
@@ -1103,9 +1111,10 @@ bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const c
         g.relu = 1; g.dropout = drop; g.keep_prob = keep_prob; g.seed = m->seed; g.stream_id = stream_id; g.any_shape = any_shape ? 1 : 0; g.mask_scale = 1.f; g.yb = yb; g.yb_pad = yb_pad;
         g.rows_bn = m->bf16_rows_bn;
         g.guarded = (any_shape && xb_ready) ? 1 : 0;          // (the per-layer training copies carry guard rows; the shared inference copy does not)
-        ProfScope ps(m, tag, 2.0 * M * K * cout, 4.0 * M * cout + 2.0 * M * cin + 2.0 * K * cout);
+        ProfScope ps(m, tag, 2.0 * M * K * cout, (out ? 4.0 : 0.0) * M * cout + (yb ? 2.0 : 0.0) * M * cout + 2.0 * M * cin + 2.0 * K * cout);
         if (launch_conv_bf16_256(g, s)) return true;
     }
+    if (!out) return false;
     if (!allow_small || cin % 32 || cout % 128) return false;
     if (big) { launch_w_to_bf16_tiles(Wp(m, wname), m->d_wbf16, K, cout, s); wbuf = m->d_wbf16; }      // (could not take the 256 path after all)
     Bf16ConvArgs a{};
@@ -1234,7 +1243,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     const bool fill_fp = m->frozen && m->u_cache.empty();
     if (!m->frozen || fill_fp) prepare_forward_weights(m);        // frozen and the kept banks still valid: so are the padded / phase-packed kernels
     m->fwd_train = train;
-    m->rbits_ok.clear(); m->y_unwritten.clear(); m->fwd_v_layer.clear(); m->xg16_filled.clear();
+    m->rbits_ok.clear(); m->y_unwritten.clear(); m->in_bf16_only.clear(); m->fwd_v_layer.clear(); m->xg16_filled.clear();
     { ProfScope ps(m, "preprocess", 0, (double)N * H * W * (16 + (dtype ? 12 : 3))); launch_preprocess(img_dev, dtype, A(m, "x0"), (long long)N * H * W, s); }
     const float* x = A(m, "x0");
     int h = H, w = W, cin = 4;
@@ -1293,8 +1302,15 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 }
             }
             if (!done && first && m->widths[0] == 64) {            // conv1_1: write-bound gather kernel (igemm.hip: conv1_glds_kernel)
-                ProfScope ps(m, "conv1_1_fwd", 2.0 * N * h * w * 27.0 * m->widths[0], 4.0 * N * h * w * (3.0 + m->widths[0]), nm);
-                done = launch_conv1_fwd(x, m->d_w1pad, e.bias, A(m, nm), m->d_w1pad + 12 * 4 * (size_t)m->widths[0], N, h, w, m->widths[0], m->conv1_tiled, s);
+                // bf16_train, training: conv1_2 reads this layer as its padded bf16 copy and nobody else reads it (the mask of conv1_2's data gradient is the
+                // sign of that copy): the tile kernel writes the copy and no fp32 tensor
+                unsigned short* y16 = nullptr;
+                if (bf16_train_mode(m) && train && m->bf16_acts && m->conv1_tiled && h % 8 == 0 && w % 16 == 0 && kConvsPerBlock[0] >= 2 && m->widths[0] % 64 == 0 &&
+                    (double)N * (h + 2) * (w + 2) * m->widths[0] * 2.0 < 4294967296.0)
+                    y16 = xg16_for(m, "conv1_2", N, h, w, m->widths[0], 3, s);
+                ProfScope ps(m, "conv1_1_fwd", 2.0 * N * h * w * 27.0 * m->widths[0], 4.0 * N * h * w * 3.0 + (y16 ? 2.0 : 4.0) * N * h * w * m->widths[0], nm);
+                done = launch_conv1_fwd(x, m->d_w1pad, e.bias, y16 ? nullptr : A(m, nm), m->d_w1pad + 12 * 4 * (size_t)m->widths[0], N, h, w, m->widths[0], m->conv1_tiled, s, y16);
+                if (done && y16) { m->xg16_filled.insert("conv1_2"); m->y_unwritten.insert(nm); m->in_bf16_only.insert("conv1_2"); }
             }
             if (!done && bf16_train_mode(m) && !first) {
                 // FCN8S_PREC_BF16_TRAIN: every convolution but conv1_1 (3 input channels) as a direct convolution with bf16-rounded operands; the
@@ -1305,16 +1321,20 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 }
                 // the next convolution of the block reads this output as ITS padded bf16 input: this kernel's epilogue writes that copy
                 unsigned short* yb = nullptr; char nx[32] = "";
-                if (train && m->bf16_fuse_convert && i < kConvsPerBlock[b]) { snprintf(nx, sizeof nx, "conv%d_%d", b + 1, i + 1); yb = xg16_for(m, nx, N, h, w, m->widths[b], 3, s); }
+                if (train && (m->bf16_fuse_convert || m->bf16_acts) && i < kConvsPerBlock[b]) { snprintf(nx, sizeof nx, "conv%d_%d", b + 1, i + 1); yb = xg16_for(m, nx, N, h, w, m->widths[b], 3, s); }
+                // ... and if that is the output's only reader (option bf16_acts; the mask of the consumer's data gradient is the sign of the copy), the fp32
+                // tensor is not written at all.  (Both layers' gradients must fit the bf16 kernels: a fallback would look for the fp32 tensor.)
+                const bool only16 = yb && m->bf16_acts && cin % 64 == 0 && m->widths[b] % 64 == 0;
                 // (the convolution kernel addresses its padded copies with 32-bit byte offsets: a layer whose padded input OR padded output gradient reaches
                 //  4 GiB cannot run in this mode -- say so instead of letting that one layer fall back to another arithmetic)
                 const double padded_px = (double)N * (h + 2) * (w + 2);
                 if (padded_px * std::max(cin, m->widths[b]) * 2.0 >= 4294967296.0)
                     return fail(m, FCN8S_ERR_SHAPE, std::string("bf16_train: the padded bf16 copy of ") + nm + "'s input or output gradient would reach 4 GiB at this batch size; use a smaller batch per GPU");
-                done = bf16_conv_layer(m, "conv3x3_fwd_bf16", (std::string(nm) + "/filter").c_str(), (std::string(nm) + "/biases").c_str(), x, A(m, nm),
+                done = bf16_conv_layer(m, "conv3x3_fwd_bf16", (std::string(nm) + "/filter").c_str(), (std::string(nm) + "/biases").c_str(), x, only16 ? nullptr : A(m, nm),
                                        N, h, w, cin, m->widths[b], 3, 0, 1.f, 0, s, /*allow_small=*/false, xb, /*any_shape=*/true, yb, 1);
                 if (!done) return fail(m, FCN8S_ERR_SHAPE, std::string("bf16_train: ") + nm + " does not fit the bf16 convolution kernel");
                 if (done && yb) m->xg16_filled.insert(nx);
+                if (done && only16) { m->y_unwritten.insert(nm); m->in_bf16_only.insert(nx); }
             }
             if (!done && bf16_fwd_mode(m) && b >= 2) {
                 // FCN8S_PREC_BF16_FWD: conv3_1 .. conv5_3 as direct convolutions with bf16-rounded operands on the 256 x 256 bf16 kernel (the
@@ -1937,6 +1957,7 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "conv1_in_transform") return &m->conv1_in_transform;
     if (key == "deterministic") return &m->deterministic;
     if (key == "bf16_fuse_convert") return &m->bf16_fuse_convert;
+    if (key == "bf16_acts") return &m->bf16_acts;
     if (key == "bf16_rows_bn") return &m->bf16_rows_bn;
     if (key == "bf16_fuse_pool") return &m->bf16_fuse_pool;
     return nullptr;
@@ -1958,7 +1979,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
         if (value < 1) return fail(m, FCN8S_ERR_BAD_ARG, "comm_timeout_ms must be >= 1");
         std::lock_guard<std::mutex> lk(m->comm_mu); m->comm_timeout_ms = value; return FCN8S_OK;
     }
-    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform" || k == "deterministic" || k == "bf16_fuse_convert" || k == "bf16_rows_bn" || k == "bf16_fuse_pool") {        // pick a kernel per launch: nothing cached depends on them
+    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform" || k == "deterministic" || k == "bf16_fuse_convert" || k == "bf16_acts" || k == "bf16_rows_bn" || k == "bf16_fuse_pool") {        // pick a kernel per launch: nothing cached depends on them
         *model_option(m, k) = k == "bf16_rows_bn" ? (int)value : (value ? 1 : 0);
         return FCN8S_OK;
     }
@@ -2597,7 +2618,8 @@ int fcn8s_get_activation(fcn8s_model* m, const char* name, float* host, size_t n
     if (n != it->second.n) return fail(m, FCN8S_ERR_SHAPE, std::string("activation '") + name + "' has " + std::to_string(it->second.n) + " elements");
     if (m->y_unwritten.count(name))
         return fail(m, FCN8S_ERR_STATE, std::string("activation '") + name + "' was not materialised by the last forward pass: " +
-                                        (std::string(name) == "conv1_1" ? "conv1_2's input transform evaluated it on its own patches (option \"conv1_in_transform\" = 0 keeps it)"
+                                        (bf16_train_mode(m) ? "bf16_train keeps a conv -> conv activation only as the consumer's padded bf16 copy (option \"bf16_acts\" = 0 keeps the fp32 tensor too)" :
+                                         std::string(name) == "conv1_1" ? "conv1_2's input transform evaluated it on its own patches (option \"conv1_in_transform\" = 0 keeps it)"
                                                                         : "its output transform wrote the next conv's transformed input directly (option \"fuse_out_in\" = 0 keeps it)"));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     HIPCHK(m, hipMemcpy(host, it->second.p, n * sizeof(float), hipMemcpyDeviceToHost));

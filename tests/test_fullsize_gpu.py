@@ -636,9 +636,18 @@ def test_config5_bf16_train_2048x1024_bs4():
     P = orc.init_params(C, seed=6, decoder_std_scale=6.0, bias_std=0.05)
     e.set_params(P)
     e.profile(2); e.profile_reset()
-    loss = e.forward_backward(imgd, labd, keep_prob=1.0)
+    loss_default = e.forward_backward(imgd, labd, keep_prob=1.0)
     prof = e.profile_results()
     e.profile(0)
+    lg_default = e.activation("logits", (N, H, W, C))[3].copy()
+    with pytest.raises(Exception, match="bf16_acts"):           # (the default keeps a conv -> conv activation only as the consumer's padded bf16 copy)
+        e.activation("conv3_1", (N, H >> 2, W >> 2, e.widths[2]))
+    # the same pass with every activation kept as an fp32 tensor too (what (i) looks at): the same logits bit for bit
+    e.set_option("bf16_acts", 0)
+    loss = e.forward_backward(imgd, labd, keep_prob=1.0)
+    np.testing.assert_array_equal(e.activation("logits", (N, H, W, C))[3], lg_default)
+    assert abs(loss - loss_default) <= 1e-6 * abs(loss)
+    del lg_default
     assert np.isfinite(loss)
     kernels = {k[7:]: int(v["launches"]) for k, v in prof.items() if k.startswith("kernel:")}
     assert sum(v for k, v in kernels.items() if "conv_bf16_" in k) == 28 and sum(v for k, v in kernels.items() if "wgrad_bf16" in k) == 14, kernels
@@ -661,6 +670,7 @@ def test_config5_bf16_train_2048x1024_bs4():
     print("config 5 [bf16_train] 2048x1024 x 4: per-layer forward error against the same-rounding convolution of the device's own input:", ", ".join("%s %.2e" % kv for kv in worst.items()))
     for k, v in worst.items():
         assert v < 1e-4, (k, v)
+    e.set_option("bf16_acts", 1)
     full = np.asarray(torch.as_tensor(e.predict(imgd, argmax=True)).cpu())[K]
     lg_full = e.activation("logits", (N, H, W, C))[K].copy()
     one = np.asarray(torch.as_tensor(e.predict(imgd[K:K + 1], argmax=True)).cpu())[0]

@@ -600,7 +600,9 @@ def test_bf16_train_mode():
     n, h, w = 2, 64, 96
     P = orc.init_params(20, widths, seed=9, decoder_std_scale=6.0, bias_std=0.05)
     img, lab = batch(n, h, w, seed=31)
-    e = Engine(20, widths=widths, precision="bf16_train")
+    # (option bf16_acts = 0: every activation also as an fp32 tensor, for (1)-(3) to look at; the default keeps a conv -> conv activation only as the
+    #  consumer's bf16 copy -- same values into every product: test_bf16_train_without_fp32_inner_activations holds it to this engine's gradients bit for bit)
+    e = Engine(20, widths=widths, precision="bf16_train", options={"bf16_acts": 0})
     e.set_params(P)
     e.profile(2); e.profile_reset()
     onehot = orc.one_hot(lab, 20)
@@ -668,6 +670,47 @@ def test_bf16_train_mode():
     e.close(); e2.close()
     with pytest.raises(Exception):
         Engine(20, widths=SMALL, precision="bf16_train")            # widths that are not multiples of 64
+
+
+def test_bf16_train_without_fp32_inner_activations():
+    """Option `bf16_acts` (default 1) of FCN8S_PREC_BF16_TRAIN: in a training pass the output of a conv that feeds another conv (conv1_1, conv2_1,
+    conv3_1, conv3_2, ...) is written ONLY as the consumer's padded bf16 copy -- by the producer's epilogue (conv1_tile_kernel, conv_bf16_rows_kernel) --
+    and the ReLU mask of the consumer's data gradient is the sign of that copy.  Every product sees the values it saw with the fp32 tensors kept
+    (bf16(y) either way), so with reductions in a fixed order (option `deterministic`) loss, logits and all 42 gradient tensors are BIT-identical
+    between `bf16_acts` 1 and 0; test_bf16_train_mode holds the 0 side to the oracle.  The activations that no longer exist say so."""
+    from fcn8s_tensorflow_amd.engine import Engine
+    from fcn8s_tensorflow_amd._lib import Fcn8sError
+    widths = (64, 64, 128, 256, 256, 256, 128)
+    n, h, w = 2, 64, 96
+    P = orc.init_params(20, widths, seed=9, decoder_std_scale=6.0, bias_std=0.05)
+    img, lab = batch(n, h, w, seed=31)
+    out = {}
+    for acts in (1, 0):
+        e = Engine(20, widths=widths, precision="bf16_train", options={"bf16_acts": acts, "deterministic": 1})
+        assert e.get_option("bf16_acts") == acts
+        e.set_params(P)
+        e.profile(2); e.profile_reset()
+        loss = e.forward_backward(img, lab, keep_prob=0.5, l2_rate=1e-3)
+        groups = {k: int(v["launches"]) for k, v in e.profile_results().items() if ":" not in k}
+        e.profile(0)
+        out[acts] = (loss, e.activation("logits", (n, h, w, 20)), e.activation("conv1_2", (n, h, w, 64)), e.activation("pool3", (n, h // 8, w // 8, 128)), e.get_grads(), groups)
+        for name, shape in (("conv1_1", (n, h, w, 64)), ("conv3_2", (n, h // 4, w // 4, 128)), ("conv5_1", (n, h // 16, w // 16, 256))):
+            if acts:
+                with pytest.raises(Fcn8sError, match="bf16_acts"):
+                    e.activation(name, shape)
+            else:
+                assert np.isfinite(e.activation(name, shape)).all()
+        # an inference pass on the same engine writes them again
+        e.predict(img, argmax=False)
+        assert np.isfinite(e.activation("conv3_2", (n, h // 4, w // 4, 128))).all()
+        e.close()
+    assert out[1][0] == out[0][0]
+    for i in (1, 2, 3):
+        np.testing.assert_array_equal(out[1][i], out[0][i])
+    for k in out[0][4]:
+        np.testing.assert_array_equal(out[1][4][k], out[0][4][k], err_msg=k)
+    # the conversion passes that went away: 8 conv -> conv copies (13 convs - 5 block heads; conv1_2's comes from conv1_1's kernel)
+    assert out[0][5]["bf16_convert"] - out[1][5]["bf16_convert"] == 8, (out[0][5], out[1][5])
 
 
 @pytest.mark.parametrize("mode", ["bf16_fwd", "bf16_fwd_x2"])
