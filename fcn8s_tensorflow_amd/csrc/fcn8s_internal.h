@@ -75,6 +75,7 @@ struct Bf16Conv256Args {
     const float* mask; float mask_scale;   // optional, [M][Cout]: y = mask > 0 ? y * mask_scale : 0 (the ReLU / dropout of the layer whose input gradient this is)
     int any_shape;                     // 1: Cout % 64 == 0 and any M are taken (64- / 128-column tiles, partial last row tile); 0: the round-3 rule
     const unsigned short* mask16;      // optional (flat-position kernel only): the padded bf16 copy [N][H + 2][W + 2][Cout] whose sign is the mask, instead of `mask`
+    float* colpart;                    // optional (flat-position kernel only): [row tiles][Cout] column sums of the tile's stored values, one row per row tile
     int ksplit; float* part;           // set by the launcher: K split over blockIdx.y into `ksplit` slabs of raw accumulators at `part`
     int rows_bn;                       // (A/B) 128: the flat-position kernel takes its 128-column form where Cout % 128 == 0 (default: 64 columns everywhere)
     int guarded;                       // 1: xp has zeroed guard rows in front and behind (>= W + 3 + 16 rows of Cin): the flat-position kernel may be taken
@@ -83,6 +84,7 @@ struct Bf16Conv256Args {
 bool conv_bf16_256_ok(long long M, int Cin, int Cout, int mode);      // mode 0 never, 1 when it fills the chip, 2 whenever the shapes allow
 void launch_w_to_bf16_t(const float* w, unsigned short* wt, int K, int Cout, hipStream_t s);
 void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H, int W, int C, int pad, hipStream_t s);
+int conv_bf16_rows_bm(int Cout, int rows_bn);
 bool launch_conv_bf16_256(const Bf16Conv256Args& a, hipStream_t s);
 // the padded bf16 copy of an output gradient (interior only: the border of xp is zero already) with db[c] += column sums of x on the way
 bool launch_f32_to_bf16_padded_colsum(const float* x, unsigned short* xp, float* db, int N, int H, int W, int C, int pad, hipStream_t s);

@@ -663,8 +663,11 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
     // epilogue: position -> pixel; border positions and positions beyond the last image are not stored.
     // p.yb: the consumer is another 3 x 3 layer on the same map, so its padded bf16 copy has THIS geometry and position q of the output is row q of that copy:
     // the wave parks its 32 x 64 tile as bf16 in LDS (the stages are free by now), zeros at border positions, and stores it 16 bytes per lane.
-    if (p.yb) __syncthreads();
+    // p.colpart: the column sums of this tile's stored values (fp32, before any rounding: the consumer layer's bias gradient when this is a data gradient whose
+    // fp32 output nobody reads) -- lane, wave, block in a fixed order; one partial row per row tile, added up by launch_colsum.
+    if (p.yb || p.colpart) __syncthreads();
     unsigned short* patch = reinterpret_cast<unsigned short*>(smem) + wave * (32 * 64);
+    float csum[2] = {0.f, 0.f};
     const long long qb = q0 + wr * 32 + 4 * (lane >> 5);
     const long long HpWp = (long long)Hp * Wp;
     int n = (int)(qb / HpWp), rem = (int)(qb - (long long)n * HpWp), yp = rem / Wp, xp0 = rem - yp * Wp;
@@ -692,6 +695,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
                 if (p.dropout) v = philox_uniform((unsigned long long)off, p.seed, p.stream_id) < p.keep_prob ? v / p.keep_prob : 0.f;
                 if (p.y) p.y[off] = v;                  // (no fp32 output: the padded bf16 copy below is the layer's only reader's input)
             }
+            csum[tn] += v;
             if (p.yb) reinterpret_cast<__bf16*>(patch)[(o + 4 * (lane >> 5)) * 64 + tn * 32 + (lane & 31)] = (__bf16)v;
         }
     }
@@ -706,6 +710,22 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
             *reinterpret_cast<bf16x8*>(p.yb + q * p.Cout + n0 + wn * 64 + ch * 8) = v;
         }
     }
+    if (p.colpart) {
+        float* red = reinterpret_cast<float*>(smem + 8 * 32 * 64 * 2);        // behind the eight patches
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const float t = csum[tn] + __shfl_xor(csum[tn], 32);                // (lanes l and l + 32: the same column, rows 4 apart)
+            if (lane < 32) red[wave * 64 + tn * 32 + lane] = t;
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int cw_ = tid / 64, c = tid % 64;
+            float t = 0.f;
+#pragma unroll
+            for (int r_ = 0; r_ < 8 / WCN; ++r_) t += red[(r_ * WCN + cw_) * 64 + c];
+            p.colpart[(long long)tmi * p.Cout + n0 + tid] = t;
+        }
+    }
 }
 
 // mode 0 never, 1 when it fills the chip (the round-3 rule, 256-column tiles only), 2 whenever the shapes allow, 3 = 2 with the 128- and 64-column
@@ -717,6 +737,9 @@ bool conv_bf16_256_ok(long long M, int Cin, int Cout, int mode)
     if (M % G_BM || Cout % G_BN) return false;
     return mode >= 2 || (M / G_BM) * (Cout / G_BN) >= 128;         // fewer tiles than half the CUs: the 128 x 128 kernel fills the chip better
 }
+
+// rows of a row tile of conv_bf16_rows_kernel as launch_conv_bf16_256 picks it (= positions per partial row of `colpart`)
+int conv_bf16_rows_bm(int Cout, int rows_bn) { return (Cout % 128 == 0 && rows_bn == 128) ? 128 : 256; }
 
 bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
 {
@@ -733,7 +756,7 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
     {
         const long long rt0 = (a.M + G_BM - 1) / G_BM;
         const long long nkt_all = (long long)a.K * a.K * a.Cin / G_BK;
-        const bool plain = !a.bias && !a.addend && !a.mask && !a.relu && !a.dropout && !a.yb && a.y;
+        const bool plain = !a.bias && !a.addend && !a.mask && !a.relu && !a.dropout && !a.yb && a.y && !a.colpart;
         if (a.any_shape && plain && a.Cout % 256 == 0 && rt0 * (a.Cout / 256) < 128 && nkt_all >= 512) {
             long long ks = 256 / (rt0 * (a.Cout / 256));
             if (ks > 8) ks = 8;
@@ -770,7 +793,7 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
         }
         return true;
     }
-    if (!a.y) return false;                    // (only the flat-position kernel runs without an fp32 output)
+    if (!a.y || a.colpart) return false;       // (only the flat-position kernel runs without an fp32 output or takes column sums)
     const unsigned blocks = (unsigned)(rt * (a.Cout / bn));
     if (bn == 256) { g_last_kernel = "conv_bf16_256_kernel<256>"; hipLaunchKernelGGL(conv_bf16_256_kernel<256>, dim3(blocks), dim3(512), 0, s, a); }
     else if (bn == 128) { g_last_kernel = "conv_bf16_256_kernel<128>"; hipLaunchKernelGGL(conv_bf16_256_kernel<128>, dim3(blocks), dim3(512), 0, s, a); }

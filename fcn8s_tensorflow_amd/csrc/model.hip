@@ -112,6 +112,7 @@ struct fcn8s_model {
     int fuse_dgrad_dout = 1;                                              // option: allow that fusion
     int fuse_out_in = 1;                                                  // option: inside a block, conv L's output transform writes conv L+1's V directly (Y is never written): 0 never, 1 unless the row ranges would get too short, 2 always
     std::string fwd_v_layer;                                              // forward: layer whose V the previous layer's fused output transform has already written
+    std::set<std::string> dy_bf16_only;                                   // ... and layers whose fp32 OUTPUT GRADIENT was not written by this backward pass (their padded bf16 copy + the bias gradient were)
     std::set<std::string> in_bf16_only;                                   // bf16_train, option bf16_acts: layers whose fp32 INPUT was not written by the last training forward pass (their padded bf16 copy is all there is)
     std::set<std::string> y_unwritten;                                    // layers whose activation tensor was not materialised by the last forward pass
     int conv1_tiled = 1, conv1_wgrad_mfma = 1;                            // options: conv1_1 forward on the spatial-tile kernel / its weight gradient on the matrix core
@@ -314,7 +315,7 @@ struct Epi { const float* bias = nullptr; const float* addend = nullptr; const f
              int lazy_wt = 0;                            // data gradient: `w` is still to be filled from w_fwd (flip + transpose) if the adjoint path is not taken
              float* dm_out = nullptr; const char* dm_out_layer = nullptr;   // adjoint data gradient: write dM of the producing layer (name) here instead of its dZ into y
              float* next_v = nullptr; const char* next_layer = nullptr;   // forward, Winograd F(6x6) path: write the NEXT conv's V here instead of this conv's output
-             const char* yb_layer = nullptr; int yb_K = 3; // bf16_train data gradient: the layer whose output gradient this launch produces (its bf16 copy is written on the way), and that layer's kernel size
+             const char* yb_layer = nullptr; int yb_K = 3; bool yb_only = false;    // (yb_only: both of that layer's gradients take its bf16 copy -- the fp32 tensor may stay unwritten) // bf16_train data gradient: the layer whose output gradient this launch produces (its bf16 copy is written on the way), and that layer's kernel size
              int skip_y = 0; };                          // Winograd path with pool_out: do not write the full-resolution output (only its pool is consumed)            // data gradient: the layer's forward kernel [3,3,Cout_of_this_conv... = Cin here][...] (adjoint Winograd path)
 
 // 3x3 SAME conv through Winograd F(tile x tile, 3x3): filter transform, input transform, (tile+2)^2 batched GEMMs
@@ -444,11 +445,35 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
                 if (xi != m->xg16.end() && xi->second) g.mask16 = xi->second + bf16_guard_rows(3, W + 2) * Cout;
             }
             // this gradient is the output gradient of layer e.yb_layer (same map): its padded bf16 copy is written by this kernel's epilogue
-            if (e.yb_layer && m->bf16_fuse_convert && K == 3 && e.yb_K == 3) { g.yb = g16_for(m, m->dyg16, m->dyg16_elems, e.yb_layer, N, H, W, Cout, e.yb_K, s); g.yb_pad = (e.yb_K - 1) / 2; }
+            const bool only16 = e.yb_layer && e.yb_only && m->bf16_acts && K == 3 && e.yb_K == 3 && Cout % 64 == 0;
+            if (e.yb_layer && (m->bf16_fuse_convert || only16) && K == 3 && e.yb_K == 3) { g.yb = g16_for(m, m->dyg16, m->dyg16_elems, e.yb_layer, N, H, W, Cout, e.yb_K, s); g.yb_pad = (e.yb_K - 1) / 2; }
+            // ... and if that layer's gradients read nothing else (option bf16_acts), the fp32 gradient is not written: the epilogue also takes its column sums,
+            // that layer's bias gradient, from the fp32 values
+            long long prow = 0;
+            if (g.yb && only16) {
+                prow = ((long long)N * (H + 2) * (W + 2) + conv_bf16_rows_bm(Cout, g.rows_bn) - 1) / conv_bf16_rows_bm(Cout, g.rows_bn);
+                g.colpart = det_scratch(s, (size_t)prow * Cout);
+                if (g.colpart) g.y = nullptr; else prow = 0;
+            }
             const double M = (double)N * H * W;
-            ProfScope ps(m, K == 1 ? "fc7_dgrad_bf16" : (K == 3 ? "conv3x3_dgrad_bf16" : "fc6_dgrad_bf16"), 2.0 * M * K * K * Cin * Cout, 4.0 * M * Cout * (e.mask ? 2.0 : 1.0) + 2.0 * M * Cin + 2.0 * wneed, layer);
-            if (launch_conv_bf16_256(g, s)) { if (g.yb) m->dyg16_filled.insert(e.yb_layer); return false; }
+            bool done;
+            { ProfScope ps(m, K == 1 ? "fc7_dgrad_bf16" : (K == 3 ? "conv3x3_dgrad_bf16" : "fc6_dgrad_bf16"), 2.0 * M * K * K * Cin * Cout,
+                           (g.y ? 4.0 : 0.0) * M * Cout + (g.yb ? 2.0 : 0.0) * M * Cout + (g.mask16 ? 2.0 : (e.mask ? 4.0 : 0.0)) * M * Cout + 2.0 * M * Cin + 2.0 * wneed, layer);
+              done = launch_conv_bf16_256(g, s); }
+            if (done) {
+                if (g.yb) m->dyg16_filled.insert(e.yb_layer);
+                if (g.colpart) {
+                    ProfScope ps(m, "colsum", 0, 4.0 * prow * Cout);
+                    launch_colsum(g.colpart, Gp(m, std::string(e.yb_layer) + "/biases"), prow, Cout, s);
+                    m->db_taken.insert(e.yb_layer); m->dy_bf16_only.insert(e.yb_layer);
+                }
+                return false;
+            }
+            if (g.colpart) { fprintf(stderr, "fcn8s: bf16_train: %s's data gradient was refused by the flat-position kernel\n", layer); abort(); }
         }
+    }
+    if (bf16_train_mode(m) && m->train_mode && layer && e.dgrad && m->dy_bf16_only.count(layer)) {
+        fprintf(stderr, "fcn8s: bf16_train: %s's data gradient could not run on the bf16 kernel and its fp32 output gradient was not kept (option \"bf16_acts\" = 0 keeps it)\n", layer); abort();
     }
     if (bf16_train_mode(m) && m->train_mode && layer && e.mask && m->in_bf16_only.count(layer)) {
         fprintf(stderr, "fcn8s: bf16_train: %s's data gradient could not run on the bf16 kernel and its fp32 mask was not kept (option \"bf16_acts\" = 0 keeps it)\n", layer); abort();
@@ -722,7 +747,7 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             }
         }
     }
-    if (bf16_train_mode(m) && m->train_mode && layer && m->in_bf16_only.count(layer)) {
+    if (bf16_train_mode(m) && m->train_mode && layer && (m->in_bf16_only.count(layer) || m->dy_bf16_only.count(layer))) {
         fprintf(stderr, "fcn8s: bf16_train: %s's weight gradient could not run on the bf16 kernel and its fp32 input was not kept (option \"bf16_acts\" = 0 keeps it)\n", layer); abort();
     }
     if (m && (K == 3 || K == 7) && layer && alpha == 1.f && !real_cin && m->train_mode) {
@@ -1644,6 +1669,7 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
                 // gradient): the gather kernel can write dM directly.  Conditions = those of conv_wgrad's adjoint branch for that layer.
                 const int cin_prev = i > 2 ? cw : (b > 1 ? m->widths[b - 2] : 4);
                 const bool prev_first = (b == 1 && i == 2);
+                e.yb_only = !prev_first && cin_prev % 64 == 0 && cw % 64 == 0;      // (conv1_1's weight gradient is exact fp32 and reads the fp32 tensor)
                 if (m->fuse_dgrad_dout && e.relu_bits_in && !prev_first && m->defer_level_now == 0 && m->train_mode && m->d_wino_m &&
                     wino_tile_for(m, h, w) == 6 && cw % 64 == 0 && cin_prev % 64 == 0 && m->acts.count(std::string("wv:") + inname)) {
                     e.dm_out = m->d_wino_m; e.dm_out_layer = inname;
@@ -1674,7 +1700,7 @@ int do_backward_bucket(fcn8s_model* m, int bucket, int level_cap)
     if (bucket == 0) {
         m->defer_level_now = m->defer_wgrad >= 3 ? 2 : std::min(m->defer_wgrad, level_cap);      // 3: the caller does not consume bucket 0 early
         if (m->profile && m->profile_detail) m->defer_level_now = 0;      // per-layer timing wants one kernel at a time
-        m->deferred.clear(); m->ev_next = 0; m->dyg16_filled.clear(); m->db_taken.clear();
+        m->deferred.clear(); m->ev_next = 0; m->dyg16_filled.clear(); m->db_taken.clear(); m->dy_bf16_only.clear();
         m->dm_prefilled.clear();                                           // (a promise left over from a backward pass that ended in an error)
         m->on_tail = false; m->launch_stream = nullptr;                    // (a backward pass that ended in an error may have left them set)
         for (int b = 0; b < kNumBuckets; ++b) m->bucket_final[b] = false;

@@ -675,7 +675,8 @@ def test_bf16_train_mode():
 def test_bf16_train_without_fp32_inner_activations():
     """Option `bf16_acts` (default 1) of FCN8S_PREC_BF16_TRAIN: in a training pass the output of a conv that feeds another conv (conv1_1, conv2_1,
     conv3_1, conv3_2, ...) is written ONLY as the consumer's padded bf16 copy -- by the producer's epilogue (conv1_tile_kernel, conv_bf16_rows_kernel) --
-    and the ReLU mask of the consumer's data gradient is the sign of that copy.  Every product sees the values it saw with the fp32 tensors kept
+    and the ReLU mask of the consumer's data gradient is the sign of that copy; the data gradient of such a consumer writes ONLY the padded bf16 copy of
+    its output (the producer's dY) and that layer's bias gradient.  Every product sees the values it saw with the fp32 tensors kept
     (bf16(y) either way), so with reductions in a fixed order (option `deterministic`) loss, logits and all 42 gradient tensors are BIT-identical
     between `bf16_acts` 1 and 0; test_bf16_train_mode holds the 0 side to the oracle.  The activations that no longer exist say so."""
     from fcn8s_tensorflow_amd.engine import Engine
@@ -707,10 +708,18 @@ def test_bf16_train_without_fp32_inner_activations():
     assert out[1][0] == out[0][0]
     for i in (1, 2, 3):
         np.testing.assert_array_equal(out[1][i], out[0][i])
+    # ... and the same in the backward pass: the output gradient of a conv that FOLLOWS a bf16 conv (conv2_1, conv3_1, conv3_2, ... -- not conv1_1, whose
+    # weight gradient is exact fp32) is written only as its padded bf16 copy, and its bias gradient is summed from the fp32 values in the producing
+    # kernel's epilogue: another summation order for those seven bias gradients (1e-5), everything else bit for bit
+    inner = {"conv%d_%d/biases" % (b, i) for b, n_ in ((2, 2), (3, 3), (4, 3), (5, 3)) for i in range(1, n_)}
     for k in out[0][4]:
-        np.testing.assert_array_equal(out[1][4][k], out[0][4][k], err_msg=k)
-    # the conversion passes that went away: 8 conv -> conv copies (13 convs - 5 block heads; conv1_2's comes from conv1_1's kernel)
-    assert out[0][5]["bf16_convert"] - out[1][5]["bf16_convert"] == 8, (out[0][5], out[1][5])
+        if k in inner:
+            assert rel(out[1][4][k], out[0][4][k]) < 1e-5, k
+            assert np.abs(out[0][4][k]).max() > 0
+        else:
+            np.testing.assert_array_equal(out[1][4][k], out[0][4][k], err_msg=k)
+    # the conversion passes that went away: 8 forward copies (13 convs - 5 block heads; conv1_2's comes from conv1_1's kernel) and those 7 gradients
+    assert out[0][5]["bf16_convert"] - out[1][5]["bf16_convert"] == 8 + 7, (out[0][5], out[1][5])
 
 
 @pytest.mark.parametrize("mode", ["bf16_fwd", "bf16_fwd_x2"])
