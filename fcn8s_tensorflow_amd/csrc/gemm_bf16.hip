@@ -637,11 +637,9 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
     for (int kt = 0; kt < nkt; ++kt) {
         wait_vm<0>();
         __builtin_amdgcn_s_barrier();                              // tile kt has landed everywhere; everybody is done reading the other stage
-        if (kt + 1 < nkt) issue(kt + 1);
         const unsigned char* st = smem + (kt & 1) * STAGE;
         bf16x8 af[3][2], bfr[3][2][2];
-#pragma unroll
-        for (int tx = 0; tx < 3; ++tx)
+        auto frags = [&](int tx) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int r = arow + tx, pc = (2 * ks + (lane >> 5)) ^ ((r >> 2) & 3);
@@ -652,13 +650,24 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
                     bfr[tx][ks][tn] = *reinterpret_cast<const bf16x8*>(st + ABYTES + tx * (BN * G_ROWB) + rb * G_ROWB + pb * 16);
                 }
             }
-#pragma unroll
-        for (int tx = 0; tx < 3; ++tx)
+        };
+        auto mfmas = [&](int tx) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
                     acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tx][ks], bfr[tx][ks][tn], acc[tn], 0, 0, 0);
+        };
+        // the next tile's LDS-DMA first, then the fragments of two taps together (12 reads in flight), the third tap's under the first tap's MFMAs -- pinned:
+        // left alone the compiler keeps 72 registers and waits for one read in front of every MFMA (conv4_2's data gradient 0.68 -> 0.65 ms; all 18 reads
+        // first: 0.67; the DMA issue moved behind the reads: 0.71)
+        if (kt + 1 < nkt) issue(kt + 1);
+        frags(0); frags(1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        frags(2);
+        mfmas(1);
+        mfmas(2);
     }
     // epilogue: position -> pixel; border positions and positions beyond the last image are not stored.
     // p.yb: the consumer is another 3 x 3 layer on the same map, so its padded bf16 copy has THIS geometry and position q of the output is row q of that copy:
