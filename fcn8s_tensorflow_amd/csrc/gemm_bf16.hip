@@ -857,6 +857,11 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void wgrad_bf16_kernel(cons
     constexpr int S = 4, ROWB = BM * 2, PLANE = 16 * ROWB, STAGE = 4 * PLANE;        // planes: A rows 0-15, A rows 16-31, B rows 0-15, B rows 16-31
     constexpr int NI = PLANE / 1024, RPI = 1024 / ROWB;                                // LDS-DMA instructions per plane, rows per instruction
     constexpr int T = BM / 64;                                                         // 32 x 32 tiles per wave and operand
+    // 16-byte chunk c of row r sits at chunk c ^ SWZ (r & 3).  A transposing read's 32-lane group takes 64 contiguous bytes of each of four rows: with
+    // 128-byte rows (BM = 64) a row's parity picks the bank half and SWZ = 2 .. 6 the quarter; with 256-byte rows (BM = 128) every row starts at bank 0 and
+    // the four rows need the four 64-byte quarters: SWZ = 4 (with 2, rows r and r + 1 shared 16 banks: SQ_LDS_BANK_CONFLICT = half of the LDS cycles of
+    // fc6's weight gradient, profiles/r05_c5_bf16_train_wave_state.txt)
+    constexpr int SWZ = BM == 128 ? 4 : 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[S * STAGE];
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -876,7 +881,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void wgrad_bf16_kernel(cons
     unsigned voff[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int row = i * RPI + lane / (ROWB / 16), slot = lane % (ROWB / 16), c = slot ^ (2 * (row & 3));
+        const int row = i * RPI + lane / (ROWB / 16), slot = lane % (ROWB / 16), c = slot ^ (SWZ * (row & 3));
         voff[i] = (unsigned)(((long long)row * ld + c * 8) * 2);
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -904,8 +909,8 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void wgrad_bf16_kernel(cons
             for (int r = 0; r < 2; ++r) {
                 const int row = 8 * g + 4 * r + (i >> 2);
                 const int ca = wm * (BM / 2) + t * 32 + 16 * (q & 1) + 4 * (i & 3), cb = wn * (BM / 2) + t * 32 + 16 * (q & 1) + 4 * (i & 3);
-                a_addr[t][r] = (unsigned)(row * ROWB + (((ca >> 3) ^ (2 * (row & 3))) * 16) + (ca & 7) * 2);
-                b_addr[t][r] = (unsigned)(row * ROWB + (((cb >> 3) ^ (2 * (row & 3))) * 16) + (cb & 7) * 2);
+                a_addr[t][r] = (unsigned)(row * ROWB + (((ca >> 3) ^ (SWZ * (row & 3))) * 16) + (ca & 7) * 2);
+                b_addr[t][r] = (unsigned)(row * ROWB + (((cb >> 3) ^ (SWZ * (row & 3))) * 16) + (cb & 7) * 2);
             }
     }
 #pragma unroll
