@@ -154,7 +154,7 @@ void launch_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, hi
 void launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C,
                         int relu_mask, hipStream_t s);
 void launch_maxpool_route(const float* x, unsigned char* route, int N, int H, int W, int C, hipStream_t s);
-void launch_maxpool_fwd_route(const float* x, float* y, unsigned char* r, int N, int H, int W, int C, hipStream_t s);   // forward pool + those bytes in one pass
+void launch_maxpool_fwd_route(const float* x, float* y, unsigned char* r, int N, int H, int W, int C, hipStream_t s, unsigned short* yb16 = nullptr, int pad = 0);   // forward pool + those bytes in one pass
 // Where the logits of pixel slot p live.  blocked == 0: slot = pixel, NHWC.  blocked != 0: the layout the last transposed conv
 // (k = 2s, stride s, pad s/2) produces when it runs as ONE GEMM (model.hip: tconv_gemm_*): rows = (n, q, qx) over an (H/s + 1) x (W/s + 1)
 // grid of s x s output blocks that start at pixel (s q - s/2, s qx - s/2), columns = (r, rx, class); slots of the half blocks that
@@ -191,7 +191,7 @@ bool launch_head_dgrad(const float* dy, const float* wt, const float* mask, floa
                        hipStream_t s);
 bool launch_head_wgrad(const float* x, const float* dy, float* dw, long long M, int K, int C, float alpha, hipStream_t s);
 // bf16_train: max-pool backward (ReLU fused) whose output is the padded bf16 copy of dZ (interior; border zero already) plus db[c] += column sums of dZ
-bool launch_maxpool_bwd_bf16(const float* x, const float* dy, unsigned short* dzb, float* db, int N, int H, int W, int C, hipStream_t s);
+bool launch_maxpool_bwd_bf16(const float* x, const float* dy, unsigned short* dzb, float* db, int N, int H, int W, int C, hipStream_t s, const unsigned char* route = nullptr);
 void launch_colsum(const float* x, float* out, long long rows, int C, hipStream_t s);      // out[c] += sum_r x[r,c]
 void launch_sumsq(const float* x, float* out, long long n, hipStream_t s);                  // out[0] += sum x^2
 void launch_axpy(float* y, const float* x, float a, long long n, hipStream_t s);           // y += a*x

@@ -112,6 +112,7 @@ struct fcn8s_model {
     int fuse_dgrad_dout = 1;                                              // option: allow that fusion
     int fuse_out_in = 1;                                                  // option: inside a block, conv L's output transform writes conv L+1's V directly (Y is never written): 0 never, 1 unless the row ranges would get too short, 2 always
     std::string fwd_v_layer;                                              // forward: layer whose V the previous layer's fused output transform has already written
+    bool pool_routed[5] = {false, false, false, false, false};           // bf16_train: the forward pool of block b kept its routing bytes (pidx<b>) for maxpool_bwd_bf16_route_kernel
     std::set<std::string> dy_bf16_only;                                   // ... and layers whose fp32 OUTPUT GRADIENT was not written by this backward pass (their padded bf16 copy + the bias gradient were)
     std::set<std::string> in_bf16_only;                                   // bf16_train, option bf16_acts: layers whose fp32 INPUT was not written by the last training forward pass (their padded bf16 copy is all there is)
     std::set<std::string> y_unwritten;                                    // layers whose activation tensor was not materialised by the last forward pass
@@ -1388,6 +1389,24 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
         }
         snprintf(pn, sizeof pn, "pool%d", b + 1);
         m->pool_fused[b] = pooled && train;
+        m->pool_routed[b] = false;
+        if (!pooled && bf16_train_mode(m) && train && m->bf16_fuse_pool && cin % 4 == 0) {
+            // bf16_train, training: the pool keeps its routing bytes (the backward pass reads one byte per window instead of the block's last activation)
+            // and writes the consumer's padded bf16 copy itself -- conv<b+2>_1 (pad 1) or fc6 (pad 3); pool1, pool2 and pool5 have no other reader, so
+            // with option bf16_acts their fp32 tensors are not written (pool3 / pool4 feed the fp32 skip heads)
+            char cons[32]; int ck = 3, cout_c = 0;
+            if (b < 4) { snprintf(cons, sizeof cons, "conv%d_1", b + 2); cout_c = m->widths[b + 1]; } else { snprintf(cons, sizeof cons, "fc6"); ck = m->fc6k; cout_c = m->widths[5]; }
+            unsigned short* yb = nullptr;
+            if (m->bf16_acts && cin % 64 == 0 && cout_c % 64 == 0 && (double)N * (h / 2 + ck - 1) * (w / 2 + ck - 1) * cin * 2.0 < 4294967296.0)
+                yb = xg16_for(m, cons, N, h / 2, w / 2, cin, ck, s);
+            const bool only16 = yb && b != 2 && b != 3;
+            char ix[16]; snprintf(ix, sizeof ix, "pidx%d", b + 1);
+            ProfScope ps(m, "maxpool_fwd", 0, 4.0 * N * h * w * cin * (only16 ? 1.0625 : 1.3125) + (yb ? 0.5 * N * h * w * cin : 0.0));
+            launch_maxpool_fwd_route(x, only16 ? nullptr : A(m, pn), (unsigned char*)A(m, ix), N, h, w, cin, s, yb, (ck - 1) / 2);
+            m->pool_routed[b] = true; pooled = true;
+            if (yb) m->xg16_filled.insert(cons);
+            if (only16) { m->y_unwritten.insert(pn); m->in_bf16_only.insert(cons); }
+        }
         if (!pooled) {
             // a block whose last conv did not run through the Winograd output transform (bf16 modes) but whose backward pass does run in the
             // Winograd domain: keep the same routing bytes, so that d(pool) is routed inside wino_dout_kernel and dZ is never written
@@ -1403,7 +1422,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     m->drop_stream = (uint32_t)(2 * m->step);
     if (bf16_train_mode(m)) {
         unsigned short* xb6 = train ? xg16_for(m, "fc6", N, h5, w5, m->widths[4], m->fc6k, s) : nullptr;
-        if (xb6) { ProfScope ps(m, "bf16_convert", 0, 6.0 * N * h5 * w5 * m->widths[4]); launch_f32_to_bf16_padded(x, xb6, N, h5, w5, m->widths[4], (m->fc6k - 1) / 2, s); }
+        if (xb6 && !m->xg16_filled.count("fc6")) { ProfScope ps(m, "bf16_convert", 0, 6.0 * N * h5 * w5 * m->widths[4]); launch_f32_to_bf16_padded(x, xb6, N, h5, w5, m->widths[4], (m->fc6k - 1) / 2, s); }
         unsigned short* xb7 = train ? xg16_for(m, "fc7", N, h5, w5, m->widths[5], 1, s) : nullptr;
         const bool fuse7 = false;          // (fc6 runs on the tile kernel, whose bf16 side output is 2-byte stores: its 134 MB are converted by a pass of their own)
         if (!bf16_conv_layer(m, "fc6_fwd_bf16", "fc6/weights", "fc6/biases", x, A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, drop, keep_prob, m->drop_stream, s, false, xb6, true,
@@ -1625,8 +1644,10 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
             // column sums: the pool's backward kernel writes exactly those (gbuf[gcur ^ 1] stays unwritten; the "dz" handed on below is never dereferenced)
             unsigned short* dzb = g16_for(m, m->dyg16, m->dyg16_elems, last, N, h, w, cw, 3, s);
             if (dzb) {
-                ProfScope ps(m, "maxpool_bwd", 0, 4.0 * N * h * w * cw * 1.25 + 2.0 * N * h * w * cw);
-                pool_done = launch_maxpool_bwd_bf16(A(m, last), m->gbuf[m->gcur], dzb, Gp(m, std::string(last) + "/biases"), N, h, w, cw, s);
+                ProfScope ps(m, "maxpool_bwd", 0, 4.0 * N * h * w * cw * (m->pool_routed[b - 1] ? 0.3125 : 1.25) + 2.0 * N * h * w * cw);
+                char ix[16]; snprintf(ix, sizeof ix, "pidx%d", b);
+                pool_done = launch_maxpool_bwd_bf16(A(m, last), m->gbuf[m->gcur], dzb, Gp(m, std::string(last) + "/biases"), N, h, w, cw, s,
+                                                    m->pool_routed[b - 1] ? (const unsigned char*)A(m, ix) : nullptr);
             }
             if (pool_done) { m->dyg16_filled.insert(last); m->db_taken.insert(last); m->gcur ^= 1; }
         }

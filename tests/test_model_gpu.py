@@ -695,7 +695,8 @@ def test_bf16_train_without_fp32_inner_activations():
         groups = {k: int(v["launches"]) for k, v in e.profile_results().items() if ":" not in k}
         e.profile(0)
         out[acts] = (loss, e.activation("logits", (n, h, w, 20)), e.activation("conv1_2", (n, h, w, 64)), e.activation("pool3", (n, h // 8, w // 8, 128)), e.get_grads(), groups)
-        for name, shape in (("conv1_1", (n, h, w, 64)), ("conv3_2", (n, h // 4, w // 4, 128)), ("conv5_1", (n, h // 16, w // 16, 256))):
+        for name, shape in (("conv1_1", (n, h, w, 64)), ("conv3_2", (n, h // 4, w // 4, 128)), ("conv5_1", (n, h // 16, w // 16, 256)), ("pool1", (n, h // 2, w // 2, 64)),
+                            ("pool5", (n, h // 32, w // 32, 256))):
             if acts:
                 with pytest.raises(Fcn8sError, match="bf16_acts"):
                     e.activation(name, shape)
@@ -718,8 +719,9 @@ def test_bf16_train_without_fp32_inner_activations():
             assert np.abs(out[0][4][k]).max() > 0
         else:
             np.testing.assert_array_equal(out[1][4][k], out[0][4][k], err_msg=k)
-    # the conversion passes that went away: 8 forward copies (13 convs - 5 block heads; conv1_2's comes from conv1_1's kernel) and those 7 gradients
-    assert out[0][5]["bf16_convert"] - out[1][5]["bf16_convert"] == 8 + 7, (out[0][5], out[1][5])
+    # the conversion passes that went away: 8 forward copies (13 convs - 5 block heads; conv1_2's comes from conv1_1's kernel), those 7 gradients, and the
+    # 5 copies of the pooled maps (conv2_1 .. conv5_1, fc6), which the pools write themselves (pool1, pool2 and pool5 as nothing else)
+    assert out[0][5]["bf16_convert"] - out[1][5]["bf16_convert"] == 8 + 7 + 5, (out[0][5], out[1][5])
 
 
 @pytest.mark.parametrize("mode", ["bf16_fwd", "bf16_fwd_x2"])
