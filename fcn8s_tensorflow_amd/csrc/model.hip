@@ -1137,7 +1137,8 @@ bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const c
         g.relu = 1; g.dropout = drop; g.keep_prob = keep_prob; g.seed = m->seed; g.stream_id = stream_id; g.any_shape = any_shape ? 1 : 0; g.mask_scale = 1.f; g.yb = yb; g.yb_pad = yb_pad;
         g.rows_bn = m->bf16_rows_bn;
         g.guarded = (any_shape && xb_ready) ? 1 : 0;          // (the per-layer training copies carry guard rows; the shared inference copy does not)
-        ProfScope ps(m, tag, 2.0 * M * K * cout, (out ? 4.0 : 0.0) * M * cout + (yb ? 2.0 : 0.0) * M * cout + 2.0 * M * cin + 2.0 * K * cout);
+        const std::string lname = std::string(wname).substr(0, std::string(wname).find('/'));
+        ProfScope ps(m, tag, 2.0 * M * K * cout, (out ? 4.0 : 0.0) * M * cout + (yb ? 2.0 : 0.0) * M * cout + 2.0 * M * cin + 2.0 * K * cout, any_shape ? lname.c_str() : nullptr);
         if (launch_conv_bf16_256(g, s)) return true;
     }
     if (!out) return false;

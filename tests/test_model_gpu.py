@@ -315,7 +315,10 @@ def test_tf_adam_training_steps():
     into a chaotic divergence between the two trajectories."""
     widths = SMALL
     P = orc.init_params(20, widths, seed=6, decoder_std_scale=30.0, bias_std=0.05)
-    e = make_engine(widths)
+    # (reductions in a fixed order: the parameters steps 2 and 3 start from are then the same in every run -- with float atomics they differ in the last
+    #  bit from run to run, and once in a few hundred runs of this small network a ReLU unit sits within that bit of zero: one full-suite run of round 5 saw
+    #  conv1_1/filter 3.7 % off at step 3 and three reruns did not)
+    e = make_engine(widths, options={"deterministic": 1})
     e.set_params(P)
     lr = 1e-3
 

@@ -40,3 +40,8 @@ python bench.py --gpus 2 --backend gloo --device 0 --steps 5 --warmup 2 --batch 
 python tools/layer_bench.py > $OUT/layer_bench.txt 2>> $OUT/bench.err
 python tools/layer_bench.py --infer --batch 1 --steps 10 > $OUT/layer_bench_infer_bs1.txt 2>> $OUT/bench.err
 cat $OUT/bench_train_bs16.json
+# where the waves of the bf16_train kernels spend their cycles (two more PMC passes of the same command; tools/pmc_wave_summary.py)
+C5="python bench.py --steps 2 --warmup 1 --height 1024 --width 2048 --batch 4 --precision bf16_train --no-cpu-baseline --no-secondary"
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/wave_a -o bench -- $C5 > /dev/null 2>> $OUT/bench.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM --kernel-trace --output-format csv -d $OUT/wave_b -o bench -- $C5 > /dev/null 2>> $OUT/bench.err
+python tools/pmc_wave_summary.py bf16 $OUT/wave_a/bench_counter_collection.csv $OUT/wave_b/bench_counter_collection.csv > $OUT/c5_bf16_train_wave_state.txt

@@ -30,4 +30,5 @@ python tools/roofline_table.py $DST/${R}_bench_train_bs16.json > $DST/${R}_roofl
 [ -f $SRC/pmc_clock_c5_bf16_train_summary.txt ] && cp $SRC/pmc_clock_c5_bf16_train_summary.txt $DST/${R}_c5_bf16_train_pmc_clock_summary.txt
 [ -f $SRC/pmc_clock_c5_bf16_train.json ] && cp $SRC/pmc_clock_c5_bf16_train.json $DST/${R}_c5_bf16_train_pmc_clock.json
 [ -f $SRC/layer_bench_c5_bf16_train.txt ] && cp $SRC/layer_bench_c5_bf16_train.txt $DST/${R}_layer_bench_c5_bf16_train.txt
+[ -f $SRC/c5_bf16_train_wave_state.txt ] && cp $SRC/c5_bf16_train_wave_state.txt $DST/${R}_c5_bf16_train_wave_state.txt
 echo "published $TAG as $R"
