@@ -276,8 +276,13 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *                              the Winograd domain, conv1_1's and the score heads' weight gradients, the bf16 weight gradients, the last bias gradient, the L2
  *                              sum; split-K GEMMs are simply not split) stores one partial result per split into a scratch slab, and a second kernel adds
  *                              the slabs in split order: two runs of the same steps on the same inputs give the same bits.  +2.4 % at 16 x 1024x512
+ *     "bf16_acts"         1    FCN8S_PREC_BF16_TRAIN, training passes: a tensor between two bf16 convolutions exists only as the consumer's padded bf16 copy -- written by the
+ *                              producer's epilogue (conv -> conv activations, conv1_1 included; the pooled maps pool1 / pool2 / pool5; the output gradient of a conv that
+ *                              follows a bf16 conv, together with that layer's bias gradient).  fcn8s_get_activation of such a layer then returns FCN8S_ERR_STATE naming
+ *                              this option; 0 keeps every fp32 tensor too (same values into every product: bit-identical losses and weight gradients)
  *     "bf16_fuse_convert" 0    FCN8S_PREC_BF16_TRAIN: the producing convolution's epilogue also writes its consumer's padded bf16 copy (measured slower)
- *     "bf16_fuse_pool"    1    FCN8S_PREC_BF16_TRAIN: the max-pool backward kernel writes the last conv's padded bf16 dZ copy and bias gradient itself; 0 = two passes
+ *     "bf16_fuse_pool"    1    FCN8S_PREC_BF16_TRAIN: the forward pools keep routing bytes (and write their consumer's bf16 copy), the max-pool backward kernel reads those bytes and
+ *                              writes the last conv's padded bf16 dZ copy and bias gradient itself; 0 = plain pools + conversion passes
  *     "bf16_rows_bn"      0    FCN8S_PREC_BF16_TRAIN: 128 = the flat-position 3 x 3 convolution kernel takes its 128-column tile where it can (A/B; slower)
  *                              (these eight pick a kernel per launch and drop nothing)
  *     "comm_timeout_ms" 600000 the communicator's watchdog (see fcn8s_comm_init): a collective older than this is given up, the communicator aborted
