@@ -669,63 +669,111 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
         mfmas(1);
         mfmas(2);
     }
-    // epilogue: position -> pixel; border positions and positions beyond the last image are not stored.
-    // p.yb: the consumer is another 3 x 3 layer on the same map, so its padded bf16 copy has THIS geometry and position q of the output is row q of that copy:
-    // the wave parks its 32 x 64 tile as bf16 in LDS (the stages are free by now), zeros at border positions, and stores it 16 bytes per lane.
-    // p.colpart: the column sums of this tile's stored values (fp32, before any rounding: the consumer layer's bias gradient when this is a data gradient whose
-    // fp32 output nobody reads) -- lane, wave, block in a fixed order; one partial row per row tile, added up by launch_colsum.
-    if (p.yb || p.colpart) __syncthreads();
-    unsigned short* patch = reinterpret_cast<unsigned short*>(smem) + wave * (32 * 64);
-    float csum[2] = {0.f, 0.f};
-    const long long qb = q0 + wr * 32 + 4 * (lane >> 5);
+    // Epilogue through LDS, row-major: the MFMA layout gives a lane one column of 16 scattered rows -- 4-byte stores, 2-byte mask loads, and for the 64-channel
+    // layers (six K-tiles per tile) that epilogue WAS the kernel: conv1_2's forward pass took 1.24 ms with its MFMAs and LDS reads switched off and 1.29 with its
+    // LDS-DMA switched off, 1.34 complete (profiles/r05_bf16_conv_tile_ab.txt).  Each wave parks one 32 x 32 half of its tile (fp32, raw accumulators) in its own
+    // patch of the free stage buffers; then a lane owns (row, 8 consecutive channels): bias, skip-path addend, ReLU, the mask (16 bytes of the layer's bf16
+    // input copy, or 32 of the fp32 activation), two 16-byte fp32 stores and / or one 16-byte store into the consumer's bf16 copy, and the column sums.
+    // Border positions and positions beyond the last image: nothing stored in y, zeros in the copy.
+    __syncthreads();                                                       // every wave is done reading the stage buffers
+    constexpr int LDP = 36;
+    float* patch = reinterpret_cast<float*>(smem) + wave * (32 * LDP);
     const long long HpWp = (long long)Hp * Wp;
-    int n = (int)(qb / HpWp), rem = (int)(qb - (long long)n * HpWp), yp = rem / Wp, xp0 = rem - yp * Wp;
+    const int prow0 = lane >> 2, pc8 = (lane & 3) * 8;
+    long long qrow[2], pixv[2]; bool valid[2];
+    {
+        const long long qb = q0 + wr * 32 + prow0;
+        int n = (int)(qb / HpWp), rem = (int)(qb - (long long)n * HpWp), yy = rem / Wp, xx = rem - yy * Wp;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int o = (r & 3) + 8 * (r >> 2);
-        int xx = xp0 + o, yy = yp, nn = n;
-        while (xx >= Wp) { xx -= Wp; ++yy; }
-        while (yy >= Hp) { yy -= Hp; ++nn; }
-        const bool valid = qb + o < R && yy >= 1 && yy <= p.H && xx >= 1 && xx <= p.W;
-        const long long pix = ((long long)nn * p.H + yy - 1) * p.W + xx - 1;
+        for (int it = 0; it < 2; ++it) {
+            qrow[it] = qb + 16 * it;
+            valid[it] = qrow[it] < R && yy >= 1 && yy <= p.H && xx >= 1 && xx <= p.W;
+            pixv[it] = ((long long)n * p.H + yy - 1) * p.W + xx - 1;
+            xx += 16;
+            while (xx >= Wp) { xx -= Wp; ++yy; }
+            while (yy >= Hp) { yy -= Hp; ++n; }
+        }
+    }
+    float csum[2][8];
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
-            float v = 0.f;
-            if (valid) {
-                const long long off = pix * p.Cout + col;
-                v = acc[tn][r] + (p.bias ? p.bias[col] : 0.f);
-                if (p.addend) v += p.addend[off];
-                if (p.relu) v = v > 0.f ? v : 0.f;
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) csum[tn][k] = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDP + (lane & 31)] = acc[tn][r];
+        __builtin_amdgcn_wave_barrier();
+        const int col8 = n0 + wn * 64 + tn * 32 + pc8;
+        float bv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bv[k] = p.bias ? p.bias[col8 + k] : 0.f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const float4 u0 = *reinterpret_cast<const float4*>(&patch[(prow0 + 16 * it) * LDP + pc8]);
+            const float4 u1 = *reinterpret_cast<const float4*>(&patch[(prow0 + 16 * it) * LDP + pc8 + 4]);
+            float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+            if (valid[it]) {
+                const long long off = pixv[it] * p.Cout + col8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += bv[k];
+                if (p.addend) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(p.addend + off), a1 = *reinterpret_cast<const float4*>(p.addend + off + 4);
+                    v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                }
                 // (the ReLU mask of a data gradient: the sign of the layer's padded bf16 INPUT copy, which has this kernel's geometry -- row q, half the bytes of
                 //  the fp32 activation and no pixel arithmetic; bf16 keeps fp32's exponent range, so x > 0 <=> bf16(x) > 0 for every normal x)
-                if (p.mask16) v = (short)p.mask16[(qb + o) * p.Cout + col] > 0 ? v * p.mask_scale : 0.f;
-                else if (p.mask) v = p.mask[off] > 0.f ? v * p.mask_scale : 0.f;
-                if (p.dropout) v = philox_uniform((unsigned long long)off, p.seed, p.stream_id) < p.keep_prob ? v / p.keep_prob : 0.f;
-                if (p.y) p.y[off] = v;                  // (no fp32 output: the padded bf16 copy below is the layer's only reader's input)
+                if (p.mask16) {
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const s16x8 mk = *reinterpret_cast<const s16x8*>(p.mask16 + qrow[it] * p.Cout + col8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = mk[k] > 0 ? v[k] * p.mask_scale : 0.f;
+                } else if (p.mask) {
+                    const float4 m0 = *reinterpret_cast<const float4*>(p.mask + off), m1 = *reinterpret_cast<const float4*>(p.mask + off + 4);
+                    const float mk[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = mk[k] > 0.f ? v[k] * p.mask_scale : 0.f;
+                }
+                if (p.dropout) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = philox_uniform((unsigned long long)(off + k), p.seed, p.stream_id) < p.keep_prob ? v[k] / p.keep_prob : 0.f;
+                }
+                if (p.y) {
+                    *reinterpret_cast<float4*>(p.y + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(p.y + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = 0.f;
             }
-            csum[tn] += v;
-            if (p.yb) reinterpret_cast<__bf16*>(patch)[(o + 4 * (lane >> 5)) * 64 + tn * 32 + (lane & 31)] = (__bf16)v;
-        }
-    }
-    if (p.yb) {
-        __builtin_amdgcn_wave_barrier();                // (the patch is this wave's own)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // p.yb: the consumer is another 3 x 3 layer on the same map, so its padded bf16 copy has THIS geometry and position q of the output is row q of that copy
+            if (p.yb) {
+                bf16x8 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = i * 64 + lane, row = id >> 3, ch = id & 7;
-            const long long q = q0 + wr * 32 + row;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + row * 64 + ch * 8);
-            *reinterpret_cast<bf16x8*>(p.yb + q * p.Cout + n0 + wn * 64 + ch * 8) = v;
+                for (int k = 0; k < 8; ++k) o[k] = (__bf16)v[k];
+                *reinterpret_cast<bf16x8*>(p.yb + qrow[it] * p.Cout + col8) = o;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) csum[tn][k] += v[k];
         }
+        __builtin_amdgcn_wave_barrier();                                   // (the patch is this wave's own: the second half overwrites it)
     }
+    // p.colpart: the column sums of this tile's stored values (fp32, before any rounding: the consumer layer's bias gradient when this is a data gradient whose
+    // fp32 output nobody reads) -- lane, wave, block in a fixed order; one partial row per row tile, added up by launch_colsum.
     if (p.colpart) {
-        float* red = reinterpret_cast<float*>(smem + 8 * 32 * 64 * 2);        // behind the eight patches
+        float* red = reinterpret_cast<float*>(smem) + 8 * (32 * LDP);         // behind the eight patches
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const float t = csum[tn] + __shfl_xor(csum[tn], 32);                // (lanes l and l + 32: the same column, rows 4 apart)
-            if (lane < 32) red[wave * 64 + tn * 32 + lane] = t;
-        }
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float t = csum[tn][k];
+                t += __shfl_xor(t, 4); t += __shfl_xor(t, 8); t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);      // the 16 lanes that share these columns
+                if (lane < 4) red[wave * 64 + tn * 32 + pc8 + k] = t;
+            }
         __syncthreads();
         if (tid < BN) {
             const int cw_ = tid / 64, c = tid % 64;
