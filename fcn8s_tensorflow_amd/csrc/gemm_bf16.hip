@@ -587,9 +587,12 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
 {
     // BN = 64: 256 positions x 64 columns per block, eight waves of 32 x 64; BN = 128: 128 positions x 128 columns, waves 4 x 2 of 32 x 64
     constexpr int WCN = BN / 64, BM = 256 / WCN, AROWS = BM + 16, NAC = AROWS / 16, NBC = 3 * BN / 16;
-    constexpr int ABYTES = AROWS * G_ROWB, BBYTES = 3 * BN * G_ROWB, STAGE = ABYTES + BBYTES, NS = 2;
+    // LDS: THREE stages of the A image (the activation rows, from HBM / a cold L2: two K-tiles ahead) and TWO of the B image (the weight slices, L2-hot: one
+    // K-tile ahead) -- 76.8 KB, still two blocks per CU.  With two stages of both, a tile's LDS-DMA had one K-tile of MFMAs to land in and did not: the loop
+    // with its MFMAs switched off took 0.46 ms at conv4_2's shape, with its DMA switched off 0.50, complete 0.63 (profiles/r05_bf16_conv_tile_ab.txt).
+    constexpr int ABYTES = AROWS * G_ROWB, BBYTES = 3 * BN * G_ROWB, NSA = 3, NSB = 2, BOFF = NSA * ABYTES;
     constexpr int NAI = (NAC + 7) / 8, NBI = (NBC + 7) / 8;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSA * ABYTES + NSB * BBYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WCN, wn = wave % WCN;
     const int Hp = p.H + 2, Wp = p.W + 2, Ktot = 9 * p.Cin;
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
     for (int i = 0; i < NBI; ++i) {
         const int c0 = wave + 8 * i, c = c0 < NBC ? c0 : 0, tx = c / (BN / 16), c4 = c % (BN / 16), row = c4 * 16 + lane / 4, pc = lane % 4, lc = pc ^ ((row >> 2) & 3);
         b_voff[i] = (unsigned)(((long long)row * Ktot + lc * 8) * 2);
-        b_dst[i] = (unsigned)(ABYTES + tx * (BN * G_ROWB) + c4 * 1024);
+        b_dst[i] = (unsigned)(tx * (BN * G_ROWB) + c4 * 1024);
         b_tx[i] = tx;
     }
     // (row 0 of the A image of filter row ty is padded position q0 - Wp - 1 + ty Wp: the guard rows in front of the copy make that readable for q0 = 0)
@@ -618,26 +621,39 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
     const unsigned short* b_base = p.wt + (long long)n0 * Ktot;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int nci = p.Cin / G_BK, nkt = 3 * nci;                   // K-tile kt = (channel chunk kt / 3, filter row kt % 3)
-    auto issue = [&](int kt) {
+    auto issue_a = [&](int kt, int sa) {
         const int ci = (kt / 3) * G_BK, ty = kt % 3;
-        const unsigned st = lds0 + (unsigned)((kt & 1) * STAGE);
+        const unsigned st = lds0 + (unsigned)(sa * ABYTES);
         const unsigned short* ga = a_base + (long long)ty * Wp * p.Cin + ci;
 #pragma unroll
         for (int i = 0; i < NAI; ++i) if (wave + 8 * i < NAC) glds16b(ga, a_voff[i], st + a_dst[i]);
+    };
+    auto issue_b = [&](int kt, int sb) {
+        const int ci = (kt / 3) * G_BK, ty = kt % 3;
+        const unsigned st = lds0 + (unsigned)(BOFF + sb * BBYTES);
 #pragma unroll
         for (int i = 0; i < NBI; ++i) if (wave + 8 * i < NBC) glds16b(b_base + (long long)(ty * 3 + b_tx[i]) * p.Cin + ci, b_voff[i], st + b_dst[i]);
     };
+    // this wave's A instructions per K-tile (chunks wave, wave + 8, ...): what may stay in flight at the head of a tile is exactly the A image two tiles ahead
+    int na = 0;
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) na += (wave + 8 * i < NAC) ? 1 : 0;
     f32x16 acc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int arow = wr * 32 + (lane & 31);
-    issue(0);
+    issue_b(0, 0); issue_a(0, 0);
+    if (nkt > 1) issue_a(1, 1);
+    int sa = 0, sa2 = 2;                                           // A stage of tile kt / of tile kt + 2
     for (int kt = 0; kt < nkt; ++kt) {
-        wait_vm<0>();
-        __builtin_amdgcn_s_barrier();                              // tile kt has landed everywhere; everybody is done reading the other stage
-        const unsigned char* st = smem + (kt & 1) * STAGE;
+        // in issue order the youngest instructions are A(kt + 1): everything older -- A(kt), B(kt) -- has landed once only they are left
+        if (kt + 1 < nkt) { if (na == 3) wait_vm<3>(); else if (na == 2) wait_vm<2>(); else if (na == 1) wait_vm<1>(); else wait_vm<0>(); }
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                              // tile kt has landed everywhere; everybody is done reading tile kt - 1's stages
+        const unsigned char* st = smem + sa * ABYTES;
+        const unsigned char* stb = smem + BOFF + (kt & 1) * BBYTES;
         bf16x8 af[3][2], bfr[3][2][2];
         auto frags = [&](int tx) {
 #pragma unroll
@@ -647,7 +663,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
                     const int rb = wn * 64 + tn * 32 + (lane & 31), pb = (2 * ks + (lane >> 5)) ^ ((rb >> 2) & 3);
-                    bfr[tx][ks][tn] = *reinterpret_cast<const bf16x8*>(st + ABYTES + tx * (BN * G_ROWB) + rb * G_ROWB + pb * 16);
+                    bfr[tx][ks][tn] = *reinterpret_cast<const bf16x8*>(stb + tx * (BN * G_ROWB) + rb * G_ROWB + pb * 16);
                 }
             }
         };
@@ -661,11 +677,15 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
         // the next tile's LDS-DMA first, then the fragments of two taps together (12 reads in flight), the third tap's under the first tap's MFMAs -- pinned:
         // left alone the compiler keeps 72 registers and waits for one read in front of every MFMA (conv4_2's data gradient 0.68 -> 0.65 ms; all 18 reads
         // first: 0.67; the DMA issue moved behind the reads: 0.71)
-        if (kt + 1 < nkt) issue(kt + 1);
+        if (kt + 1 < nkt) issue_b(kt + 1, (kt + 1) & 1);
         frags(0); frags(1);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(0);
         frags(2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nkt) issue_a(kt + 2, sa2);                    // (two tiles ahead: it can wait for the cheap issue slot behind the first MFMAs)
+        sa = sa + 1 == NSA ? 0 : sa + 1; sa2 = sa2 + 1 == NSA ? 0 : sa2 + 1;
+        __builtin_amdgcn_sched_barrier(0);
         mfmas(1);
         mfmas(2);
     }
