@@ -677,17 +677,33 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
         // the next tile's LDS-DMA first, then the fragments of two taps together (12 reads in flight), the third tap's under the first tap's MFMAs -- pinned:
         // left alone the compiler keeps 72 registers and waits for one read in front of every MFMA (conv4_2's data gradient 0.68 -> 0.65 ms; all 18 reads
         // first: 0.67; the DMA issue moved behind the reads: 0.71)
-        if (kt + 1 < nkt) issue_b(kt + 1, (kt + 1) & 1);
+        // Where the LDS-DMA of the coming tiles is issued: 0 = at the head of the tile, 1 = behind the first twelve fragment reads, 2 = behind the first tap's
+        // MFMAs and the last reads, 3 = behind the second tap's MFMAs.  B behind the reads, A behind the first MFMAs (12) is the best of six placements by
+        // 0.4 % in a same-box A/B (tools/ab_variants.sh; profiles/r05_bf16_conv_tile_ab.txt) -- what calls from different boxes had shown as +-3 % was the boxes.
+#ifndef ROWS_VARIANT
+#define ROWS_VARIANT 12
+#endif
+        constexpr int PB = ROWS_VARIANT / 10, PA = ROWS_VARIANT % 10;
+        auto dma = [&](int pos) {
+            if (PB == pos && kt + 1 < nkt) issue_b(kt + 1, (kt + 1) & 1);
+            if (PA == pos && kt + 2 < nkt) issue_a(kt + 2, sa2);
+        };
+        dma(0);
         frags(0); frags(1);
+        __builtin_amdgcn_sched_barrier(0);
+        dma(1);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(0);
         frags(2);
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nkt) issue_a(kt + 2, sa2);                    // (two tiles ahead: it can wait for the cheap issue slot behind the first MFMAs)
-        sa = sa + 1 == NSA ? 0 : sa + 1; sa2 = sa2 + 1 == NSA ? 0 : sa2 + 1;
+        dma(2);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        dma(3);
+        __builtin_amdgcn_sched_barrier(0);
         mfmas(2);
+        sa = sa + 1 == NSA ? 0 : sa + 1; sa2 = sa2 + 1 == NSA ? 0 : sa2 + 1;
     }
     // Epilogue through LDS, row-major: the MFMA layout gives a lane one column of 16 scattered rows -- 4-byte stores, 2-byte mask loads, and for the 64-channel
     // layers (six K-tiles per tile) that epilogue WAS the kernel: conv1_2's forward pass took 1.24 ms with its MFMAs and LDS reads switched off and 1.29 with its
