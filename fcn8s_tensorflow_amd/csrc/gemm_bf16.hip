@@ -248,7 +248,14 @@ static __device__ __forceinline__ void glds16b(const void* sbase, unsigned voff,
 template <int N> static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 }
 
-// w[K][Cout] fp32 (HWIO flattened) -> wt[Cout][K] bf16
+// The transposed bf16 kernels are stored as K-chunk PLANES, wt[K / 32][Cout][32]: the 64-byte slice (one output channel, 32 consecutive k) that is one LDS row of a
+// K-tile lies next to the slices of the neighbouring output channels, so an LDS-DMA instruction (16 rows) reads 1 KB of contiguous memory -- whole 128-byte lines.
+// With wt[Cout][K] every row was half a line whose other half belongs to the next K-tile: a lab that paired the rows into whole lines (same bytes, wrong data)
+// cut the DMA-only time of fc6's forward product from 1.21 to 0.95 ms (profiles/r05_bf16_conv_tile_ab.txt).
+#ifndef W_PLANES
+#define W_PLANES 1
+#endif
+// w[K][Cout] fp32 (HWIO flattened) -> wt bf16 (planes [K / 32][Cout][32]; W_PLANES 0: [Cout][K])
 __global__ __launch_bounds__(256) void w_to_bf16_t_kernel(const float* __restrict__ w, unsigned short* __restrict__ wt, int K, int Cout)
 {
     __shared__ float tile[32][65];
@@ -264,7 +271,8 @@ __global__ __launch_bounds__(256) void w_to_bf16_t_kernel(const float* __restric
         bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (__bf16)tile[kq + i][c];
-        *reinterpret_cast<bf16x8*>(wt + (long long)(c0 + c) * K + k0 + kq) = o;
+        if (W_PLANES) *reinterpret_cast<bf16x8*>(wt + ((long long)blockIdx.y * Cout + c0 + c) * 32 + kq) = o;
+        else *reinterpret_cast<bf16x8*>(wt + (long long)(c0 + c) * K + k0 + kq) = o;
     }
 }
 void launch_w_to_bf16_t(const float* w, unsigned short* wt, int K, int Cout, hipStream_t s)      // K % 32 == 0
@@ -400,14 +408,14 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
         const int n = (int)(m / HW), r = (int)(m - (long long)n * HW), y = r / p.W, x = r - y * p.W;
         const long long pp = ((long long)n * Hp + y) * Wp + x;                // top-left pixel of the row's tap window in the padded copy
         a_voff[i] = (unsigned)((pp * p.Cin + lc * 8) * 2);
-        b_voff[i] = (unsigned)(((long long)(row < BN ? row : 0) * Ktot + lc * 8) * 2);
+        b_voff[i] = W_PLANES ? (unsigned)(((row < BN ? row : 0) * 32 + lc * 8) * 2) : (unsigned)(((long long)(row < BN ? row : 0) * Ktot + lc * 8) * 2);
     }
     // split K (p.ksplit > 1, blockIdx.y): this block reduces K-tiles [kt0, kt0 + nkt) and stores its raw accumulators into slab blockIdx.y (launcher: only
     // launches whose epilogue is the identity -- fc6's data gradient: 64 row x column tiles of 256 x 256 for a 200 704-deep reduction)
     const int nkt_all = Ktot / G_BK;
     const int kt0 = p.ksplit > 1 ? (int)((long long)nkt_all * blockIdx.y / p.ksplit) : 0;
     const int nkt = (p.ksplit > 1 ? (int)((long long)nkt_all * (blockIdx.y + 1) / p.ksplit) : nkt_all) - kt0;
-    const unsigned short* b_base = p.wt + (long long)n0 * Ktot + (long long)kt0 * G_BK;
+    const unsigned short* b_base = W_PLANES ? p.wt + (long long)n0 * 32 + (long long)kt0 * p.Cout * 32 : p.wt + (long long)n0 * Ktot + (long long)kt0 * G_BK;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     // K-tiles are issued strictly in order, one call per tile: the tap position advances incrementally
     const int cpt = p.Cin / G_BK;                                      // K-tiles per tap
@@ -415,7 +423,7 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
     auto issue = [&]() {
         const unsigned st = lds0 + (unsigned)((i_kt % NS) * STAGE);
         const unsigned short* ga = p.xp + ((long long)i_ty * Wp + i_tx) * p.Cin + i_ci;
-        const unsigned short* gb = b_base + (long long)i_kt * G_BK;
+        const unsigned short* gb = b_base + (W_PLANES ? (long long)i_kt * p.Cout * 32 : (long long)i_kt * G_BK);
 #pragma unroll
         for (int i = 0; i < 2; ++i) glds16b(ga, a_voff[i], st + (wave * 2 + i) * 1024);
 #pragma unroll
@@ -612,13 +620,13 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
 #pragma unroll
     for (int i = 0; i < NBI; ++i) {
         const int c0 = wave + 8 * i, c = c0 < NBC ? c0 : 0, tx = c / (BN / 16), c4 = c % (BN / 16), row = c4 * 16 + lane / 4, pc = lane % 4, lc = pc ^ ((row >> 2) & 3);
-        b_voff[i] = (unsigned)(((long long)row * Ktot + lc * 8) * 2);
+        b_voff[i] = W_PLANES ? (unsigned)((row * 32 + lc * 8) * 2) : (unsigned)(((long long)row * Ktot + lc * 8) * 2);
         b_dst[i] = (unsigned)(tx * (BN * G_ROWB) + c4 * 1024);
         b_tx[i] = tx;
     }
     // (row 0 of the A image of filter row ty is padded position q0 - Wp - 1 + ty Wp: the guard rows in front of the copy make that readable for q0 = 0)
     const unsigned short* a_base = p.xp + (q0 - Wp - 1) * p.Cin;
-    const unsigned short* b_base = p.wt + (long long)n0 * Ktot;
+    const unsigned short* b_base = W_PLANES ? p.wt + (long long)n0 * 32 : p.wt + (long long)n0 * Ktot;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int nci = p.Cin / G_BK, nkt = 3 * nci;                   // K-tile kt = (channel chunk kt / 3, filter row kt % 3)
     auto issue_a = [&](int kt, int sa) {
@@ -632,7 +640,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
         const int ci = (kt / 3) * G_BK, ty = kt % 3;
         const unsigned st = lds0 + (unsigned)(BOFF + sb * BBYTES);
 #pragma unroll
-        for (int i = 0; i < NBI; ++i) if (wave + 8 * i < NBC) glds16b(b_base + (long long)(ty * 3 + b_tx[i]) * p.Cin + ci, b_voff[i], st + b_dst[i]);
+        for (int i = 0; i < NBI; ++i) if (wave + 8 * i < NBC) glds16b(W_PLANES ? b_base + (((long long)(ty * 3 + b_tx[i]) * p.Cin + ci) >> 5) * p.Cout * 32 : b_base + (long long)(ty * 3 + b_tx[i]) * p.Cin + ci, b_voff[i], st + b_dst[i]);
     };
     // this wave's A instructions per K-tile (chunks wave, wave + 8, ...): what may stay in flight at the head of a tile is exactly the A image two tiles ahead
     int na = 0;
@@ -907,7 +915,8 @@ __global__ __launch_bounds__(256) void w_to_bf16_flip_t_kernel(const float4* __r
         bf16x8 o;
         o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
         o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
-        wt[i] = o;
+        if (W_PLANES) { const long long k = (long long)tp * Cout8 * 8 + c8 * 8; wt[((k >> 5) * Cin + ci) * 4 + ((k & 31) >> 3)] = o; }      // planes [k / 32][ci][32]
+        else wt[i] = o;
     }
 }
 void launch_w_to_bf16_flip_t(const float* w, unsigned short* wt, int K, int Cin, int Cout, hipStream_t s)      // Cout % 8 == 0
