@@ -120,7 +120,7 @@ void launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H
 // that a conversion pass would read back: 2.15 GB written and read again per step for block 1 at 4 x 2048x1024.  A block owns pooled rows (n, h); thread
 // (c, pl) = channel quad c, pixel lane pl walks the row; the column sum of a window is its routed gradient; block partial rows, added by launch_colsum.
 __global__ __launch_bounds__(256) void maxpool_bwd_bf16_kernel(const float4* __restrict__ x, const float4* __restrict__ dy, unsigned short* __restrict__ dzb,
-                                                               float* __restrict__ partial, int H, int W, int C4, int lanes, int rows_per_block, int nrows)
+                                                               float* __restrict__ partial, int H, int W, int C4, int lanes, int rows_per_block, int nrows, long long ps4)
 {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     __shared__ float red[256 * 4];
@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bf16_kernel(const float4* __r
             const int n = r / Ho, h = r - n * Ho;
             const float4* x0 = x + (((long long)n * H + 2 * h) * W) * C4;
             const float4* g0 = dy + (long long)r * Wo * C4;
-            bf16x4* d0 = reinterpret_cast<bf16x4*>(dzb) + (((long long)n * Hp + 2 * h + 1) * Wp + 1) * C4;       // padded pixel (2h + 1, 1)
+            const long long q1 = ((long long)n * Hp + 2 * h + 1) * Wp + 1;                                       // padded pixel (2h + 1, 1)
+            bf16x4* d0 = reinterpret_cast<bf16x4*>(dzb) + (ps4 ? (long long)(c >> 3) * ps4 + q1 * 8 + (c & 7) - c : q1 * C4);      // (d0[pix * C4 + c] below: planes step 8 per pixel)
             for (int w = pl; w < Wo; w += lanes) {
                 const long long b0 = (long long)(2 * w) * C4 + c, b2 = b0 + (long long)W * C4;
                 const float4 a = x0[b0], b = x0[b0 + C4], cc = x0[b2], d = x0[b2 + C4], g = g0[(long long)w * C4 + c];
@@ -141,11 +142,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bf16_kernel(const float4* __r
                 route(a.y, b.y, cc.y, d.y, g.y, 1, oa.y, ob.y, oc.y, od.y);
                 route(a.z, b.z, cc.z, d.z, g.z, 1, oa.z, ob.z, oc.z, od.z);
                 route(a.w, b.w, cc.w, d.w, g.w, 1, oa.w, ob.w, oc.w, od.w);
-                const long long p0 = (long long)(2 * w) * C4 + c, p2 = p0 + (long long)Wp * C4;
+                const long long pst = ps4 ? 8 : C4;                                                                 // 4-element units per pixel
+                const long long p0 = (long long)(2 * w) * pst + c, p2 = p0 + (long long)Wp * pst;
                 d0[p0] = bf16x4{(__bf16)oa.x, (__bf16)oa.y, (__bf16)oa.z, (__bf16)oa.w};
-                d0[p0 + C4] = bf16x4{(__bf16)ob.x, (__bf16)ob.y, (__bf16)ob.z, (__bf16)ob.w};
+                d0[p0 + pst] = bf16x4{(__bf16)ob.x, (__bf16)ob.y, (__bf16)ob.z, (__bf16)ob.w};
                 d0[p2] = bf16x4{(__bf16)oc.x, (__bf16)oc.y, (__bf16)oc.z, (__bf16)oc.w};
-                d0[p2 + C4] = bf16x4{(__bf16)od.x, (__bf16)od.y, (__bf16)od.z, (__bf16)od.w};
+                d0[p2 + pst] = bf16x4{(__bf16)od.x, (__bf16)od.y, (__bf16)od.z, (__bf16)od.w};
                 acc[0] += (oa.x + ob.x) + (oc.x + od.x); acc[1] += (oa.y + ob.y) + (oc.y + od.y);
                 acc[2] += (oa.z + ob.z) + (oc.z + od.z); acc[3] += (oa.w + ob.w) + (oc.w + od.w);
             }
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bf16_kernel(const float4* __r
 // The same from the routing bytes the forward pool kept (maxpool_fwd_route_kernel: 0..3 = the window's first maximum, 4 = not > 0): one byte per window
 // instead of the four fp32 values of the block's last activation -- 4.1 GB less to read per step at 4 x 2048x1024.  Same rule, same sums: bit-identical.
 __global__ __launch_bounds__(256) void maxpool_bwd_bf16_route_kernel(const unsigned* __restrict__ rt, const float4* __restrict__ dy, unsigned short* __restrict__ dzb,
-                                                                     float* __restrict__ partial, int H, int W, int C4, int lanes, int rows_per_block, int nrows)
+                                                                     float* __restrict__ partial, int H, int W, int C4, int lanes, int rows_per_block, int nrows, long long ps4)
 {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     __shared__ float red[256 * 4];
@@ -178,7 +180,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bf16_route_kernel(const unsig
             const int n = r / Ho, h = r - n * Ho;
             const float4* g0 = dy + (long long)r * Wo * C4;
             const unsigned* r0 = rt + (long long)r * Wo * C4;
-            bf16x4* d0 = reinterpret_cast<bf16x4*>(dzb) + (((long long)n * Hp + 2 * h + 1) * Wp + 1) * C4;       // padded pixel (2h + 1, 1)
+            const long long q1 = ((long long)n * Hp + 2 * h + 1) * Wp + 1;                                       // padded pixel (2h + 1, 1)
+            bf16x4* d0 = reinterpret_cast<bf16x4*>(dzb) + (ps4 ? (long long)(c >> 3) * ps4 + q1 * 8 + (c & 7) - c : q1 * C4);      // (d0[pix * C4 + c] below: planes step 8 per pixel)
             for (int w = pl; w < Wo; w += lanes) {
                 const float4 g = g0[(long long)w * C4 + c];
                 const unsigned word = r0[(long long)w * C4 + c];
@@ -190,11 +193,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bf16_route_kernel(const unsig
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e][k] = bi == (unsigned)e ? gv[k] : 0.f;
                 }
-                const long long p0 = (long long)(2 * w) * C4 + c, p2 = p0 + (long long)Wp * C4;
+                const long long pst = ps4 ? 8 : C4;                                                                 // 4-element units per pixel
+                const long long p0 = (long long)(2 * w) * pst + c, p2 = p0 + (long long)Wp * pst;
                 d0[p0] = bf16x4{(__bf16)o[0][0], (__bf16)o[0][1], (__bf16)o[0][2], (__bf16)o[0][3]};
-                d0[p0 + C4] = bf16x4{(__bf16)o[1][0], (__bf16)o[1][1], (__bf16)o[1][2], (__bf16)o[1][3]};
+                d0[p0 + pst] = bf16x4{(__bf16)o[1][0], (__bf16)o[1][1], (__bf16)o[1][2], (__bf16)o[1][3]};
                 d0[p2] = bf16x4{(__bf16)o[2][0], (__bf16)o[2][1], (__bf16)o[2][2], (__bf16)o[2][3]};
-                d0[p2 + C4] = bf16x4{(__bf16)o[3][0], (__bf16)o[3][1], (__bf16)o[3][2], (__bf16)o[3][3]};
+                d0[p2 + pst] = bf16x4{(__bf16)o[3][0], (__bf16)o[3][1], (__bf16)o[3][2], (__bf16)o[3][3]};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) acc[k] += (o[0][k] + o[1][k]) + (o[2][k] + o[3][k]);
             }
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bf16_route_kernel(const unsig
 }
 // dzb points at padded pixel 0 of the copy (border zero already); db[c] += column sums of dZ.  Returns false if the shape is not covered.
 // x: the block's last activation, or nullptr with `route` = the forward pool's routing bytes
-bool launch_maxpool_bwd_bf16(const float* x, const float* dy, unsigned short* dzb, float* db, int N, int H, int W, int C, hipStream_t s, const unsigned char* route)
+bool launch_maxpool_bwd_bf16(const float* x, const float* dy, unsigned short* dzb, float* db, int N, int H, int W, int C, hipStream_t s, const unsigned char* route, long long dzb_ps)
 {
     const int C4 = C / 4;
     if (C % 4 || C4 > 256 || H % 2 || W % 2) return false;
@@ -225,8 +229,8 @@ bool launch_maxpool_bwd_bf16(const float* x, const float* dy, unsigned short* dz
     const int blocks = (nrows + rpb - 1) / rpb;
     float* partial = det_scratch(s, (size_t)blocks * C);
     if (!partial) return false;
-    if (route) hipLaunchKernelGGL(maxpool_bwd_bf16_route_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned*)route, (const float4*)dy, dzb, partial, H, W, C4, lanes, rpb, nrows);
-    else hipLaunchKernelGGL(maxpool_bwd_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)x, (const float4*)dy, dzb, partial, H, W, C4, lanes, rpb, nrows);
+    if (route) hipLaunchKernelGGL(maxpool_bwd_bf16_route_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned*)route, (const float4*)dy, dzb, partial, H, W, C4, lanes, rpb, nrows, dzb_ps / 4);
+    else hipLaunchKernelGGL(maxpool_bwd_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)x, (const float4*)dy, dzb, partial, H, W, C4, lanes, rpb, nrows, dzb_ps / 4);
     if (db) launch_colsum(partial, db, blocks, C, s);
     return true;
 }
@@ -252,7 +256,8 @@ __global__ void maxpool_route_kernel(const float* x, unsigned char* r, int N, in
 // forward max-pool that also keeps the routing bytes (same rule, same layout as the Winograd output transform's argmax bytes): the backward
 // pass of a block whose last conv did not come from that transform (the bf16 modes) can then route d(pool) inside wino_dout_kernel too
 // yb16 (bf16_train): the pooled map also -- or, with y == nullptr, only -- as the interior of the consumer's zero-bordered bf16 copy [N][H/2 + 2 pad][W/2 + 2 pad][C]
-__global__ void maxpool_fwd_route_kernel(const float4* x, float4* y, unsigned* r, int N, int H, int W, int C4, unsigned short* yb16, int pad)
+// ps4: plane stride of yb16 in 4-element units (channel-chunk planes [C / 32][rows][32]), 0 = [rows][C]
+__global__ void maxpool_fwd_route_kernel(const float4* x, float4* y, unsigned* r, int N, int H, int W, int C4, unsigned short* yb16, int pad, long long ps4)
 {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     const int Ho = H / 2, Wo = W / 2;
@@ -281,14 +286,14 @@ __global__ void maxpool_fwd_route_kernel(const float4* x, float4* y, unsigned* r
         r[i] = word;
         if (yb16) {
             const long long q = ((long long)n * (Ho + 2 * pad) + h + pad) * (Wo + 2 * pad) + w + pad;
-            reinterpret_cast<bf16x4*>(yb16)[q * C4 + c] = bf16x4{(__bf16)mv[0], (__bf16)mv[1], (__bf16)mv[2], (__bf16)mv[3]};
+            reinterpret_cast<bf16x4*>(yb16)[ps4 ? (long long)(c >> 3) * ps4 + q * 8 + (c & 7) : q * C4 + c] = bf16x4{(__bf16)mv[0], (__bf16)mv[1], (__bf16)mv[2], (__bf16)mv[3]};
         }
     }
 }
-void launch_maxpool_fwd_route(const float* x, float* y, unsigned char* r, int N, int H, int W, int C, hipStream_t s, unsigned short* yb16, int pad)
+void launch_maxpool_fwd_route(const float* x, float* y, unsigned char* r, int N, int H, int W, int C, hipStream_t s, unsigned short* yb16, int pad, long long yb16_ps)
 {
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool_fwd_route_kernel, dim3(cap_blocks(total, 256)), dim3(256), 0, s, (const float4*)x, (float4*)y, (unsigned*)r, N, H, W, C / 4, yb16, pad);
+    hipLaunchKernelGGL(maxpool_fwd_route_kernel, dim3(cap_blocks(total, 256)), dim3(256), 0, s, (const float4*)x, (float4*)y, (unsigned*)r, N, H, W, C / 4, yb16, pad, yb16_ps / 4);
 }
 void launch_maxpool_route(const float* x, unsigned char* r, int N, int H, int W, int C, hipStream_t s)
 {

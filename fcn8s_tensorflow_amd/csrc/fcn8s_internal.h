@@ -80,14 +80,19 @@ struct Bf16Conv256Args {
     int rows_bn;                       // (A/B) 128: the flat-position kernel takes its 128-column form where Cout % 128 == 0 (default: 64 columns everywhere)
     int guarded;                       // 1: xp has zeroed guard rows in front and behind (>= W + 3 + 16 rows of Cin): the flat-position kernel may be taken
     unsigned short* yb; int yb_pad;    // optional: also write the output as bf16 into the interior of a padded copy [N][H + 2 yb_pad][W + 2 yb_pad][Cout] (points at its pixel 0)
+    // Channel-chunk PLANES (bf16_train's per-layer copies): a padded copy may be stored as [C / 32][rows][32] instead of [rows][C] -- the 64-byte slice (one
+    // position, 32 channels) that is one LDS row of a K-tile then lies next to its neighbour positions' slices and an LDS-DMA instruction reads 1 KB of contiguous
+    // memory, whole 128-byte lines, instead of sixteen half lines.  *_ps = elements between two planes ((rows + guard rows) * 32); 0 = [rows][C].  The pointers
+    // point at padded pixel 0 of plane 0.
+    long long xp_ps, yb_ps, mask16_ps;
 };
 bool conv_bf16_256_ok(long long M, int Cin, int Cout, int mode);      // mode 0 never, 1 when it fills the chip, 2 whenever the shapes allow
 void launch_w_to_bf16_t(const float* w, unsigned short* wt, int K, int Cout, hipStream_t s);
-void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H, int W, int C, int pad, hipStream_t s);
+void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H, int W, int C, int pad, hipStream_t s, long long ps = 0);      // ps: plane stride of xp in elements, 0 = [rows][C]
 int conv_bf16_rows_bm(int Cout, int rows_bn);
 bool launch_conv_bf16_256(const Bf16Conv256Args& a, hipStream_t s);
 // the padded bf16 copy of an output gradient (interior only: the border of xp is zero already) with db[c] += column sums of x on the way
-bool launch_f32_to_bf16_padded_colsum(const float* x, unsigned short* xp, float* db, int N, int H, int W, int C, int pad, hipStream_t s);
+bool launch_f32_to_bf16_padded_colsum(const float* x, unsigned short* xp, float* db, int N, int H, int W, int C, int pad, hipStream_t s, long long ps = 0);
 // the kernel of a SAME convolution's data gradient as conv_bf16_256_kernel wants it: wt[Cin][(flipped taps, Cout)] bf16 (Cout % 8 == 0)
 void launch_w_to_bf16_flip_t(const float* w, unsigned short* wt, int K, int Cin, int Cout, hipStream_t s);
 // weight gradient with bf16-rounded operands: dW[tap][ci][co] = sum_q A[q + off(tap)][ci] * B[q][co] over R flat padded-pixel rows (gemm_bf16.hip)
@@ -95,6 +100,7 @@ struct Bf16WgradArgs {
     const unsigned short* A; const unsigned short* B; float* C;      // A = padded bf16 input [R][Ci], B = padded bf16 output gradient [R][Cj], both with guard rows
     long long R; int Ci, Cj, K, Wp;                                   // R = N * Hp * Wp, Wp = W + K - 1
     long long chunk, split_stride; int plain_store;                   // set by the launcher
+    long long a_ps, b_ps;                                             // channel-chunk planes (see Bf16Conv256Args): elements between two 32-channel planes of A / B, 0 = [R][C]
 };
 bool launch_wgrad_bf16(const Bf16WgradArgs& a, hipStream_t s);
 
@@ -140,7 +146,7 @@ bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, 
 
 // conv1_1 forward with bias + ReLU on the LDS-DMA gather kernel (Cout = 64 only; returns false otherwise): x4 [N,H,W,4], w48 [48][64]
 // (taps x 4 channels, rows 36..47 zero), zero16 = 16 zero bytes in device memory (what taps outside the image read)
-bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, int tiled, hipStream_t s, unsigned short* yb16 = nullptr);
+bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, int tiled, hipStream_t s, unsigned short* yb16 = nullptr, long long yb16_ps = 0);
 
 // weight gradient of the 16x16 / stride-8 transposed conv with 20 channels (VALU; dW zero-initialised, accumulated with atomics);
 // returns false for any other shape: the caller then uses launch_wgrad.
@@ -154,7 +160,7 @@ void launch_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, hi
 void launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C,
                         int relu_mask, hipStream_t s);
 void launch_maxpool_route(const float* x, unsigned char* route, int N, int H, int W, int C, hipStream_t s);
-void launch_maxpool_fwd_route(const float* x, float* y, unsigned char* r, int N, int H, int W, int C, hipStream_t s, unsigned short* yb16 = nullptr, int pad = 0);   // forward pool + those bytes in one pass
+void launch_maxpool_fwd_route(const float* x, float* y, unsigned char* r, int N, int H, int W, int C, hipStream_t s, unsigned short* yb16 = nullptr, int pad = 0, long long yb16_ps = 0);   // forward pool + those bytes in one pass
 // Where the logits of pixel slot p live.  blocked == 0: slot = pixel, NHWC.  blocked != 0: the layout the last transposed conv
 // (k = 2s, stride s, pad s/2) produces when it runs as ONE GEMM (model.hip: tconv_gemm_*): rows = (n, q, qx) over an (H/s + 1) x (W/s + 1)
 // grid of s x s output blocks that start at pixel (s q - s/2, s qx - s/2), columns = (r, rx, class); slots of the half blocks that
@@ -191,7 +197,7 @@ bool launch_head_dgrad(const float* dy, const float* wt, const float* mask, floa
                        hipStream_t s);
 bool launch_head_wgrad(const float* x, const float* dy, float* dw, long long M, int K, int C, float alpha, hipStream_t s);
 // bf16_train: max-pool backward (ReLU fused) whose output is the padded bf16 copy of dZ (interior; border zero already) plus db[c] += column sums of dZ
-bool launch_maxpool_bwd_bf16(const float* x, const float* dy, unsigned short* dzb, float* db, int N, int H, int W, int C, hipStream_t s, const unsigned char* route = nullptr);
+bool launch_maxpool_bwd_bf16(const float* x, const float* dy, unsigned short* dzb, float* db, int N, int H, int W, int C, hipStream_t s, const unsigned char* route = nullptr, long long dzb_ps = 0);
 void launch_colsum(const float* x, float* out, long long rows, int C, hipStream_t s);      // out[c] += sum_r x[r,c]
 void launch_sumsq(const float* x, float* out, long long n, hipStream_t s);                  // out[0] += sum x^2
 void launch_axpy(float* y, const float* x, float a, long long n, hipStream_t s);           // y += a*x

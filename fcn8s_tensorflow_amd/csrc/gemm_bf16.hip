@@ -282,7 +282,8 @@ void launch_w_to_bf16_t(const float* w, unsigned short* wt, int K, int Cout, hip
 }
 
 // x [N][H][W][C] fp32 -> xp [N][H + 2 pad][W + 2 pad][C] bf16 (RNE), zero border; 8 channels per thread
-__global__ __launch_bounds__(256) void f32_to_bf16_padded_kernel(const float4* __restrict__ x, bf16x8* __restrict__ xp, int N, int H, int W, int C8, int pad)
+// ps8: plane stride of xp in 8-element units (channel-chunk planes [C / 32][rows][32], see Bf16Conv256Args), 0 = [rows][C]
+__global__ __launch_bounds__(256) void f32_to_bf16_padded_kernel(const float4* __restrict__ x, bf16x8* __restrict__ xp, int N, int H, int W, int C8, int pad, long long ps8)
 {
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const long long total = (long long)N * Hp * Wp * C8;
@@ -300,15 +301,15 @@ __global__ __launch_bounds__(256) void f32_to_bf16_padded_kernel(const float4* _
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (__bf16)0.f;
         }
-        xp[i] = o;
+        if (ps8) xp[(long long)(c >> 2) * ps8 + (i / C8) * 4 + (c & 3)] = o; else xp[i] = o;
     }
 }
-void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H, int W, int C, int pad, hipStream_t s)     // C % 8 == 0
+void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H, int W, int C, int pad, hipStream_t s, long long ps)     // C % 8 == 0 (planes: C % 32 == 0)
 {
     const long long total = (long long)N * (H + 2 * pad) * (W + 2 * pad) * (C / 8);
     long long b = (total + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1;
     g_last_kernel = "f32_to_bf16_padded_kernel";
-    hipLaunchKernelGGL(f32_to_bf16_padded_kernel, dim3((unsigned)b), dim3(256), 0, s, (const float4*)x, (bf16x8*)xp, N, H, W, C / 8, pad);
+    hipLaunchKernelGGL(f32_to_bf16_padded_kernel, dim3((unsigned)b), dim3(256), 0, s, (const float4*)x, (bf16x8*)xp, N, H, W, C / 8, pad, ps / 8);
 }
 
 // The same conversion for an output gradient dY, with the column sums of dY (the layer's bias gradient, exact fp32) taken on the way: the backward pass
@@ -316,7 +317,7 @@ void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H,
 // channel octets walks the interior pixels with a block-uniform stride; each thread keeps eight running sums, the block adds its pixel lanes in LDS in
 // lane order and stores one partial row, and launch_colsum adds the partial rows (fixed order) into db (+=): reproducible.
 __global__ __launch_bounds__(256) void f32_to_bf16_padded_colsum_kernel(const float4* __restrict__ x, bf16x8* __restrict__ xp, float* __restrict__ partial,
-                                                                        int H, int W, int C8, int pad, int lanes, int rows_per_block, int nrows)
+                                                                        int H, int W, int C8, int pad, int lanes, int rows_per_block, int nrows, long long ps8)
 {
     __shared__ float red[256 * 8];
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
@@ -327,13 +328,14 @@ __global__ __launch_bounds__(256) void f32_to_bf16_padded_colsum_kernel(const fl
         for (int r = blockIdx.x * rows_per_block; r < (blockIdx.x + 1) * rows_per_block && r < nrows; ++r) {
             const int n = r / H, yy = r - n * H;
             const float4* src = x + (long long)r * W * C8 * 2;
-            bf16x8* dst = xp + (((long long)n * Hp + yy + pad) * Wp + pad) * C8;
+            const long long t0 = ((long long)n * Hp + yy + pad) * Wp + pad;         // padded position of the row's first pixel
+            bf16x8* dst = xp + t0 * C8;
             for (int xx = pl; xx < W; xx += lanes) {
                 const float4 a = src[2 * (xx * C8 + c)], b = src[2 * (xx * C8 + c) + 1];
                 bf16x8 o;
                 o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
                 o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
-                dst[xx * C8 + c] = o;
+                if (ps8) xp[(long long)(c >> 2) * ps8 + (t0 + xx) * 4 + (c & 3)] = o; else dst[xx * C8 + c] = o;
                 acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
             }
         }
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256) void f32_to_bf16_padded_colsum_kernel(const fl
     }
 }
 // the interior of xp is written here; its border must be zero already (a per-layer buffer zeroed at allocation).  db[c] += sum over pixels of x[., c]
-bool launch_f32_to_bf16_padded_colsum(const float* x, unsigned short* xp, float* db, int N, int H, int W, int C, int pad, hipStream_t s)
+bool launch_f32_to_bf16_padded_colsum(const float* x, unsigned short* xp, float* db, int N, int H, int W, int C, int pad, hipStream_t s, long long ps)
 {
     const int C8 = C / 8;
     if (C % 8 || C8 > 256) return false;
@@ -364,7 +366,7 @@ bool launch_f32_to_bf16_padded_colsum(const float* x, unsigned short* xp, float*
     float* partial = det_scratch(s, (size_t)blocks * C);
     if (!partial) return false;
     g_last_kernel = "f32_to_bf16_padded_colsum_kernel";
-    hipLaunchKernelGGL(f32_to_bf16_padded_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)x, (bf16x8*)xp, partial, H, W, C8, pad, lanes, rpb, nrows);
+    hipLaunchKernelGGL(f32_to_bf16_padded_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)x, (bf16x8*)xp, partial, H, W, C8, pad, lanes, rpb, nrows, ps / 8);
     launch_colsum(partial, db, blocks, C, s);            // db[c] += sum over the blocks' partial rows
     return true;
 }
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
         long long m = m0 + row; if (m >= p.M) m = 0;
         const int n = (int)(m / HW), r = (int)(m - (long long)n * HW), y = r / p.W, x = r - y * p.W;
         const long long pp = ((long long)n * Hp + y) * Wp + x;                // top-left pixel of the row's tap window in the padded copy
-        a_voff[i] = (unsigned)((pp * p.Cin + lc * 8) * 2);
+        a_voff[i] = p.xp_ps ? (unsigned)((pp * 32 + lc * 8) * 2) : (unsigned)((pp * p.Cin + lc * 8) * 2);
         b_voff[i] = W_PLANES ? (unsigned)(((row < BN ? row : 0) * 32 + lc * 8) * 2) : (unsigned)(((long long)(row < BN ? row : 0) * Ktot + lc * 8) * 2);
     }
     // split K (p.ksplit > 1, blockIdx.y): this block reduces K-tiles [kt0, kt0 + nkt) and stores its raw accumulators into slab blockIdx.y (launcher: only
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
     int i_kt = 0, i_ci = (kt0 % cpt) * G_BK, i_tx = (kt0 / cpt) % p.K, i_ty = (kt0 / cpt) / p.K;
     auto issue = [&]() {
         const unsigned st = lds0 + (unsigned)((i_kt % NS) * STAGE);
-        const unsigned short* ga = p.xp + ((long long)i_ty * Wp + i_tx) * p.Cin + i_ci;
+        const unsigned short* ga = p.xp_ps ? p.xp + (long long)(i_ci >> 5) * p.xp_ps + ((long long)i_ty * Wp + i_tx) * 32 : p.xp + ((long long)i_ty * Wp + i_tx) * p.Cin + i_ci;
         const unsigned short* gb = b_base + (W_PLANES ? (long long)i_kt * p.Cout * 32 : (long long)i_kt * G_BK);
 #pragma unroll
         for (int i = 0; i < 2; ++i) glds16b(ga, a_voff[i], st + (wave * 2 + i) * 1024);
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
                     if (p.relu) v = v > 0.f ? v : 0.f;
                     if (p.mask) v = p.mask[off] > 0.f ? v * p.mask_scale : 0.f;
                     if (p.dropout) v = philox_uniform((unsigned long long)off, p.seed, p.stream_id) < p.keep_prob ? v / p.keep_prob : 0.f;
-                    reinterpret_cast<__bf16*>(p.yb)[q * p.Cout + col] = (__bf16)v;
+                    reinterpret_cast<__bf16*>(p.yb)[p.yb_ps ? (long long)(col >> 5) * p.yb_ps + q * 32 + (col & 31) : q * p.Cout + col] = (__bf16)v;
                 }
             }
         }
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
 #pragma unroll
     for (int i = 0; i < NAI; ++i) {
         const int chunk = wave + 8 * i, row = chunk * 16 + lane / 4, pc = lane % 4, lc = pc ^ ((row >> 2) & 3);
-        a_voff[i] = (unsigned)(((long long)row * p.Cin + lc * 8) * 2);
+        a_voff[i] = p.xp_ps ? (unsigned)((row * 32 + lc * 8) * 2) : (unsigned)(((long long)row * p.Cin + lc * 8) * 2);
         a_dst[i] = (unsigned)(chunk * 1024);
     }
 #pragma unroll
@@ -625,14 +627,14 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
         b_tx[i] = tx;
     }
     // (row 0 of the A image of filter row ty is padded position q0 - Wp - 1 + ty Wp: the guard rows in front of the copy make that readable for q0 = 0)
-    const unsigned short* a_base = p.xp + (q0 - Wp - 1) * p.Cin;
+    const unsigned short* a_base = p.xp + (q0 - Wp - 1) * (p.xp_ps ? 32 : p.Cin);
     const unsigned short* b_base = W_PLANES ? p.wt + (long long)n0 * 32 : p.wt + (long long)n0 * Ktot;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int nci = p.Cin / G_BK, nkt = 3 * nci;                   // K-tile kt = (channel chunk kt / 3, filter row kt % 3)
     auto issue_a = [&](int kt, int sa) {
         const int ci = (kt / 3) * G_BK, ty = kt % 3;
         const unsigned st = lds0 + (unsigned)(sa * ABYTES);
-        const unsigned short* ga = a_base + (long long)ty * Wp * p.Cin + ci;
+        const unsigned short* ga = p.xp_ps ? a_base + (long long)(ci >> 5) * p.xp_ps + (long long)ty * Wp * 32 : a_base + (long long)ty * Wp * p.Cin + ci;
 #pragma unroll
         for (int i = 0; i < NAI; ++i) if (wave + 8 * i < NAC) glds16b(ga, a_voff[i], st + a_dst[i]);
     };
@@ -773,7 +775,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
                 //  the fp32 activation and no pixel arithmetic; bf16 keeps fp32's exponent range, so x > 0 <=> bf16(x) > 0 for every normal x)
                 if (p.mask16) {
                     typedef short s16x8 __attribute__((ext_vector_type(8)));
-                    const s16x8 mk = *reinterpret_cast<const s16x8*>(p.mask16 + qrow[it] * p.Cout + col8);
+                    const s16x8 mk = *reinterpret_cast<const s16x8*>(p.mask16 + (p.mask16_ps ? (long long)(col8 >> 5) * p.mask16_ps + qrow[it] * 32 + (col8 & 31) : qrow[it] * p.Cout + col8));
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = mk[k] > 0 ? v[k] * p.mask_scale : 0.f;
                 } else if (p.mask) {
@@ -799,7 +801,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
                 bf16x8 o;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) o[k] = (__bf16)v[k];
-                *reinterpret_cast<bf16x8*>(p.yb + qrow[it] * p.Cout + col8) = o;
+                *reinterpret_cast<bf16x8*>(p.yb + (p.yb_ps ? (long long)(col8 >> 5) * p.yb_ps + qrow[it] * 32 + (col8 & 31) : qrow[it] * p.Cout + col8)) = o;
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) csum[tn][k] += v[k];
@@ -970,16 +972,19 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void wgrad_bf16_kernel(cons
     const long long aoff = (long long)(ty - pad) * p.Wp + (tx - pad);
     // wave 0 / 1: A rows 0-15 / 16-31 of a K-tile, wave 2 / 3: B rows 0-15 / 16-31
     const int ld = wave < 2 ? p.Ci : p.Cj;
-    const unsigned short* mine = wave < 2 ? p.A + (t0 + aoff + (wave & 1) * 16) * p.Ci + i0 : p.B + (t0 + (wave & 1) * 16) * p.Cj + j0;
+    const long long ps = wave < 2 ? p.a_ps : p.b_ps;               // channel-chunk planes [C / 32][rows][32] (0: [rows][C])
+    const long long rstep = ps ? 32 : ld;                          // elements from one row to the next
+    const unsigned short* mine = wave < 2 ? p.A + (ps ? (long long)(i0 >> 5) * ps + (t0 + aoff + (wave & 1) * 16) * 32 : (t0 + aoff + (wave & 1) * 16) * p.Ci + i0)
+                                          : p.B + (ps ? (long long)(j0 >> 5) * ps + (t0 + (wave & 1) * 16) * 32 : (t0 + (wave & 1) * 16) * p.Cj + j0);
     unsigned voff[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int row = i * RPI + lane / (ROWB / 16), slot = lane % (ROWB / 16), c = slot ^ (SWZ * (row & 3));
-        voff[i] = (unsigned)(((long long)row * ld + c * 8) * 2);
+        voff[i] = ps ? (unsigned)(((long long)(c >> 2) * ps + row * 32 + (c & 3) * 8) * 2) : (unsigned)(((long long)row * ld + c * 8) * 2);
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     auto issue = [&](int kt, int stage) {
-        const unsigned short* g = mine + (long long)kt * 32 * ld;
+        const unsigned short* g = mine + (long long)kt * 32 * rstep;
 #pragma unroll
         for (int i = 0; i < NI; ++i) glds16w(g, voff[i], lds0 + stage * STAGE + wave * PLANE + i * 1024);
     };
@@ -1097,16 +1102,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_taps9_kernel(const Bf16Wgra
     const int nkt = (int)((t1 - t0 + 31) / 32);
     // waves 0 .. 2: the A rows of filter row ty = wave (five instructions of 8 rows), wave 3: the B rows (four)
     const int ld = wave < 3 ? p.Ci : p.Cj;
-    const unsigned short* mine = wave < 3 ? p.A + (t0 - 1 + (long long)(wave - 1) * p.Wp) * p.Ci + i0 : p.B + t0 * p.Cj + j0;
+    const long long ps = wave < 3 ? p.a_ps : p.b_ps;               // channel-chunk planes [C / 32][rows][32] (0: [rows][C])
+    const long long rstep = ps ? 32 : ld;
+    const unsigned short* mine = wave < 3 ? p.A + (ps ? (long long)(i0 >> 5) * ps + (t0 - 1 + (long long)(wave - 1) * p.Wp) * 32 : (t0 - 1 + (long long)(wave - 1) * p.Wp) * p.Ci + i0)
+                                          : p.B + (ps ? (long long)(j0 >> 5) * ps + t0 * 32 : t0 * p.Cj + j0);
     unsigned voff[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int row = i * 8 + lane / 8, slot = lane % 8, c = slot ^ (2 * (row & 3));
-        voff[i] = (unsigned)(((long long)row * ld + c * 8) * 2);
+        voff[i] = ps ? (unsigned)(((long long)(c >> 2) * ps + row * 32 + (c & 3) * 8) * 2) : (unsigned)(((long long)row * ld + c * 8) * 2);
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     auto issue = [&](int kt, int stage) {
-        const unsigned short* g = mine + (long long)kt * 32 * ld;
+        const unsigned short* g = mine + (long long)kt * 32 * rstep;
         const unsigned dst = lds0 + stage * STAGE + wave * AGRP;            // (wave 3: 3 * AGRP = the B image)
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16w(g, voff[i], dst + i * 1024);
@@ -1190,6 +1198,7 @@ bool launch_wgrad_bf16(const Bf16WgradArgs& a0, hipStream_t s)
 {
     Bf16WgradArgs a = a0;
     if (a.Ci % 64 || a.Cj % 64 || (a.K & 1) == 0 || a.R < 1) return false;
+    if ((double)a.a_ps * 2.0 * 3.0 + 4096.0 >= 4294967296.0 || (double)a.b_ps * 2.0 * 3.0 + 4096.0 >= 4294967296.0) return false;      // (per-lane byte offsets span up to four planes)
     // 3 x 3 layers: all nine taps per block (the operands are streamed once instead of nine times).  Measured at 4 x 2048x1024 against one tap per block
     // (profiles/r05_wgrad_taps9_ab.txt): conv1_2 3.08 -> 0.76 ms, conv2_2 1.43 -> 0.67, conv3_2 1.51 -> 0.68 (409 -> 904 TFLOP/s), conv4_2 1.13 -> 0.57
     // (546 -> 1092), conv5_x 0.24 -> 0.20.  (The A/B ran on an environment switch that is gone again: the library reads no environment variable.)

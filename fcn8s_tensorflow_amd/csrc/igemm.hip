@@ -752,7 +752,7 @@ static __device__ __forceinline__ void glds16v(const float* vaddr, unsigned lds_
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vaddr), "s"(lds_byte_off) : "memory", "m0");
 }
 struct Conv1Args { const float* x4; const float* w48; const float* bias; float* y; const float* zero16; int N, H, W; long long M;
-                   unsigned short* yb16; };        // (tile kernel) the consumer's padded bf16 copy [N][H + 2][W + 2][64], padded pixel 0; y may then be null
+                   unsigned short* yb16; long long yb16_ps; };        // (tile kernel) the consumer's padded bf16 copy [N][H + 2][W + 2][64], padded pixel 0; y may then be null
 
 __global__ __launch_bounds__(256, 4) void conv1_glds_kernel(const Conv1Args p)
 {
@@ -935,7 +935,8 @@ __global__ __launch_bounds__(256, 4) void conv1_tile_kernel(const Conv1Args p)
                 o[0] = (__bf16)fmaxf(u.x + b0.x, 0.f); o[1] = (__bf16)fmaxf(u.y + b0.y, 0.f); o[2] = (__bf16)fmaxf(u.z + b0.z, 0.f); o[3] = (__bf16)fmaxf(u.w + b0.w, 0.f);
                 o[4] = (__bf16)fmaxf(w_.x + b1.x, 0.f); o[5] = (__bf16)fmaxf(w_.y + b1.y, 0.f); o[6] = (__bf16)fmaxf(w_.z + b1.z, 0.f); o[7] = (__bf16)fmaxf(w_.w + b1.w, 0.f);
                 const long long q = ((long long)n * (p.H + 2) + y0 + 2 * g + (row >> 4) + 1) * (p.W + 2) + x0 + (row & 15) + 1;
-                *reinterpret_cast<__attribute__((ext_vector_type(8))) __bf16*>(p.yb16 + q * BN + wn * 32 + (lane & 3) * 8) = o;
+                // (channel-chunk planes: this wave's 32 channels are plane wn)
+                *reinterpret_cast<__attribute__((ext_vector_type(8))) __bf16*>(p.yb16 + (p.yb16_ps ? (long long)wn * p.yb16_ps + q * 32 + (lane & 3) * 8 : q * BN + wn * 32 + (lane & 3) * 8)) = o;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -946,11 +947,11 @@ __global__ __launch_bounds__(256, 4) void conv1_tile_kernel(const Conv1Args p)
 // x4: [N,H,W,4] (b, g, r, 0); w48: [48][64] = taps 0..8 x 4 channels, rows 36..47 zero; y = relu(conv + bias), [N,H,W,64]
 // tiled: 1 = the spatial-tile kernel, 0 = the LDS-DMA gather kernel (model option "conv1_tiled"; bit-identical results)
 // yb16 (tile kernel only): also -- or, with y == nullptr, only -- the padded bf16 copy of the output, [N][H + 2][W + 2][64] from padded pixel 0 (border kept zero by its owner)
-bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, int tiled, hipStream_t s, unsigned short* yb16)
+bool launch_conv1_fwd(const float* x4, const float* w48, const float* bias, float* y, const float* zero16, int N, int H, int W, int Cout, int tiled, hipStream_t s, unsigned short* yb16, long long yb16_ps)
 {
     if (Cout != 64 || !bias || !zero16) return false;
     if ((yb16 || !y) && !(tiled && H % 8 == 0 && W % 16 == 0)) return false;
-    Conv1Args a{x4, w48, bias, y, zero16, N, H, W, (long long)N * H * W, yb16};
+    Conv1Args a{x4, w48, bias, y, zero16, N, H, W, (long long)N * H * W, yb16, yb16_ps};
     if (tiled && H % 8 == 0 && W % 16 == 0) {
         g_last_kernel = "conv1_tile_kernel";
         const long long tiles = (long long)N * (H / 8) * (W / 16);

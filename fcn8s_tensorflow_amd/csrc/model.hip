@@ -345,6 +345,12 @@ static inline bool bf16_train_mode(const fcn8s_model* m) { return m && m->precis
 // (... and, for the nine-tap kernel, the eight-row instruction that completes a 34-row group: 128 rows cover all of it)
 //  ... and conv_bf16_r64_kernel's last row tile, which runs up to 255 positions past the last one and reads 272 rows from one filter row above it: 640)
 static inline long long bf16_guard_rows(int K, int Wp) { return (long long)((K - 1) / 2) * Wp + (K - 1) / 2 + 640; }
+// bf16_train's per-layer padded copies are stored as channel-chunk PLANES [C / 32][guard + rows + guard][32] (Bf16Conv256Args): elements between two planes
+#ifndef A_PLANES
+#define A_PLANES 1                   // (0: the copies as [rows][C] -- the A/B switch of tools/ab_variants.sh; every kernel takes both)
+#endif
+static inline long long g16_ps(int N, int H, int W, int K) { const int pad = (K - 1) / 2, Wp_ = W + 2 * pad; return A_PLANES ? ((long long)N * (H + 2 * pad) * Wp_ + 2 * bf16_guard_rows(K, Wp_)) * 32 : 0; }
+static inline long long g16_off(long long G, int C) { return A_PLANES ? G * 32 : G * C; }      // elements from the start of a copy's buffer to its padded pixel 0
 unsigned short* g16_for(fcn8s_model* m, std::map<std::string, unsigned short*>& bufs, std::map<std::string, size_t>& sizes, const char* layer, int N, int H, int W, int C, int K, hipStream_t s);
 unsigned short* dyb_for(fcn8s_model* m, const char* layer, const float* dy, int N, int H, int W, int C, int K, hipStream_t s, float* db = nullptr, bool* db_done = nullptr);
 
@@ -439,15 +445,15 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
         if (dyb) {
             { ProfScope ps(m, "weight_relayout", 0, 6.0 * wneed); launch_w_to_bf16_flip_t(e.w_fwd, m->d_wbf16, K, Cout, Cin, s); }
             Bf16Conv256Args g{};
-            g.xp = dyb; g.wt = m->d_wbf16; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K;
+            g.xp = dyb; g.xp_ps = g16_ps(N, H, W, K); g.wt = m->d_wbf16; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K;
             g.addend = e.addend; g.mask = e.mask; g.mask_scale = e.mask_scale; g.any_shape = 1; g.guarded = 1; g.rows_bn = m->bf16_rows_bn;
             if (e.mask && K == 3 && e.mask_scale == 1.f) {          // the mask is the ReLU of this layer's input: its sign is in the layer's own bf16 input copy
                 auto xi = m->xg16.find(layer);
-                if (xi != m->xg16.end() && xi->second) g.mask16 = xi->second + bf16_guard_rows(3, W + 2) * Cout;
+                if (xi != m->xg16.end() && xi->second) { g.mask16 = xi->second + g16_off(bf16_guard_rows(3, W + 2), Cout); g.mask16_ps = g16_ps(N, H, W, 3); }
             }
             // this gradient is the output gradient of layer e.yb_layer (same map): its padded bf16 copy is written by this kernel's epilogue
             const bool only16 = e.yb_layer && e.yb_only && m->bf16_acts && K == 3 && e.yb_K == 3 && Cout % 64 == 0;
-            if (e.yb_layer && (m->bf16_fuse_convert || only16) && K == 3 && e.yb_K == 3) { g.yb = g16_for(m, m->dyg16, m->dyg16_elems, e.yb_layer, N, H, W, Cout, e.yb_K, s); g.yb_pad = (e.yb_K - 1) / 2; }
+            if (e.yb_layer && (m->bf16_fuse_convert || only16) && K == 3 && e.yb_K == 3) { g.yb = g16_for(m, m->dyg16, m->dyg16_elems, e.yb_layer, N, H, W, Cout, e.yb_K, s); g.yb_pad = (e.yb_K - 1) / 2; g.yb_ps = g16_ps(N, H, W, e.yb_K); }
             // ... and if that layer's gradients read nothing else (option bf16_acts), the fp32 gradient is not written: the epilogue also takes its column sums,
             // that layer's bias gradient, from the fp32 values
             long long prow = 0;
@@ -736,7 +742,7 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
             if (m->db_taken.count(layer)) db_done = true;          // (the kernel that wrote this layer's dY copy added the bias gradient too)
             if (dyb) {
                 Bf16WgradArgs g{};
-                g.A = it->second + G * Cin; g.B = dyb; g.C = dw; g.R = R; g.Ci = Cin; g.Cj = Cout; g.K = K; g.Wp = Wp_;
+                g.A = it->second + g16_off(G, Cin); g.B = dyb; g.C = dw; g.R = R; g.Ci = Cin; g.Cj = Cout; g.K = K; g.Wp = Wp_; g.a_ps = g.b_ps = g16_ps(N, H, W, K);
                 bool done;
                 { ProfScope ps(m, K == 1 ? "fc7_wgrad_bf16" : (K == 3 ? "conv3x3_wgrad_bf16" : "fc6_wgrad_bf16"), flops, 2.0 * K * K * R * (Cin + Cout) + 4.0 * K * K * Cin * Cout, layer);
                   done = launch_wgrad_bf16(g, s); }
@@ -1098,7 +1104,8 @@ bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const c
                      int N, int h, int w, int cin, int cout, int k, int drop, float keep_prob, uint32_t stream_id, hipStream_t s, bool allow_small = true,
                      const unsigned short* xb_ready = nullptr,          // the padded bf16 copy of `in`, already made (256 x 256 kernel only)
                      bool any_shape = false,                            // bf16_train: 64- / 128-column tiles and a partial last row tile are taken too
-                     unsigned short* yb = nullptr, int yb_pad = 0)      // ... and the consumer's padded bf16 copy of the output is written by the epilogue
+                     unsigned short* yb = nullptr, int yb_pad = 0,      // ... and the consumer's padded bf16 copy of the output is written by the epilogue
+                     long long xb_ps = 0, long long yb_ps = 0)          // plane strides of xb_ready / yb (bf16_train's per-layer copies: channel-chunk planes), 0 = [rows][C]
 {
     const int K = k * k * cin;
     const long long Mrows = (long long)N * h * w;
@@ -1135,6 +1142,7 @@ bool bf16_conv_layer(fcn8s_model* m, const char* tag, const char* wname, const c
         g.xp = xb_ready ? xb_ready : m->d_abf16; g.wt = wbuf; g.bias = Wp(m, bname); g.y = out;
         g.N = N; g.H = h; g.W = w; g.Cin = cin; g.Cout = cout; g.K = k;
         g.relu = 1; g.dropout = drop; g.keep_prob = keep_prob; g.seed = m->seed; g.stream_id = stream_id; g.any_shape = any_shape ? 1 : 0; g.mask_scale = 1.f; g.yb = yb; g.yb_pad = yb_pad;
+        g.xp_ps = xb_ready ? xb_ps : 0; g.yb_ps = yb_ps;
         g.rows_bn = m->bf16_rows_bn;
         g.guarded = (any_shape && xb_ready) ? 1 : 0;          // (the per-layer training copies carry guard rows; the shared inference copy does not)
         const std::string lname = std::string(wname).substr(0, std::string(wname).find('/'));
@@ -1171,7 +1179,7 @@ unsigned short* g16_for(fcn8s_model* m, std::map<std::string, unsigned short*>& 
         have = need;
         hipMemsetAsync(p, 0, need * sizeof(unsigned short), s);
     }
-    return p + G * C;
+    return p + g16_off(G, C);           // padded pixel 0 of plane 0 (planes are g16_ps() apart)
 }
 // the copy of layer `layer`'s INPUT (forward pass; read again by its weight gradient)
 unsigned short* xg16_for(fcn8s_model* m, const char* layer, int N, int H, int W, int C, int K, hipStream_t s) { return g16_for(m, m->xg16, m->xg16_elems, layer, N, H, W, C, K, s); }
@@ -1185,8 +1193,8 @@ unsigned short* dyb_for(fcn8s_model* m, const char* layer, const float* dy, int 
     if (!p) return nullptr;
     if (!m->dyg16_filled.count(layer)) {
         ProfScope ps(m, "bf16_convert", 0, 4.0 * N * H * W * C + 2.0 * N * H * W * C);
-        if (db && launch_f32_to_bf16_padded_colsum(dy, p, db, N, H, W, C, (K - 1) / 2, s)) { if (db_done) *db_done = true; }
-        else launch_f32_to_bf16_padded(dy, p, N, H, W, C, (K - 1) / 2, s);
+        if (db && launch_f32_to_bf16_padded_colsum(dy, p, db, N, H, W, C, (K - 1) / 2, s, g16_ps(N, H, W, K))) { if (db_done) *db_done = true; }
+        else launch_f32_to_bf16_padded(dy, p, N, H, W, C, (K - 1) / 2, s, g16_ps(N, H, W, K));
         m->dyg16_filled.insert(layer);
     }
     return p;
@@ -1336,7 +1344,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                     (double)N * (h + 2) * (w + 2) * m->widths[0] * 2.0 < 4294967296.0)
                     y16 = xg16_for(m, "conv1_2", N, h, w, m->widths[0], 3, s);
                 ProfScope ps(m, "conv1_1_fwd", 2.0 * N * h * w * 27.0 * m->widths[0], 4.0 * N * h * w * 3.0 + (y16 ? 2.0 : 4.0) * N * h * w * m->widths[0], nm);
-                done = launch_conv1_fwd(x, m->d_w1pad, e.bias, y16 ? nullptr : A(m, nm), m->d_w1pad + 12 * 4 * (size_t)m->widths[0], N, h, w, m->widths[0], m->conv1_tiled, s, y16);
+                done = launch_conv1_fwd(x, m->d_w1pad, e.bias, y16 ? nullptr : A(m, nm), m->d_w1pad + 12 * 4 * (size_t)m->widths[0], N, h, w, m->widths[0], m->conv1_tiled, s, y16, g16_ps(N, h, w, 3));
                 if (done && y16) { m->xg16_filled.insert("conv1_2"); m->y_unwritten.insert(nm); m->in_bf16_only.insert("conv1_2"); }
             }
             if (!done && bf16_train_mode(m) && !first) {
@@ -1344,7 +1352,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 // training pass keeps the layer's padded bf16 input copy for its weight gradient (the convolution starts from that copy)
                 unsigned short* xb = train ? xg16_for(m, nm, N, h, w, cin, 3, s) : nullptr;
                 if (xb && !m->xg16_filled.count(nm)) {
-                    ProfScope ps(m, "bf16_convert", 0, 4.0 * N * h * w * cin + 2.0 * N * (h + 2) * (w + 2) * cin); launch_f32_to_bf16_padded(x, xb, N, h, w, cin, 1, s);
+                    ProfScope ps(m, "bf16_convert", 0, 4.0 * N * h * w * cin + 2.0 * N * (h + 2) * (w + 2) * cin); launch_f32_to_bf16_padded(x, xb, N, h, w, cin, 1, s, g16_ps(N, h, w, 3));
                 }
                 // the next convolution of the block reads this output as ITS padded bf16 input: this kernel's epilogue writes that copy
                 unsigned short* yb = nullptr; char nx[32] = "";
@@ -1358,7 +1366,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 if (padded_px * std::max(cin, m->widths[b]) * 2.0 >= 4294967296.0)
                     return fail(m, FCN8S_ERR_SHAPE, std::string("bf16_train: the padded bf16 copy of ") + nm + "'s input or output gradient would reach 4 GiB at this batch size; use a smaller batch per GPU");
                 done = bf16_conv_layer(m, "conv3x3_fwd_bf16", (std::string(nm) + "/filter").c_str(), (std::string(nm) + "/biases").c_str(), x, only16 ? nullptr : A(m, nm),
-                                       N, h, w, cin, m->widths[b], 3, 0, 1.f, 0, s, /*allow_small=*/false, xb, /*any_shape=*/true, yb, 1);
+                                       N, h, w, cin, m->widths[b], 3, 0, 1.f, 0, s, /*allow_small=*/false, xb, /*any_shape=*/true, yb, 1, g16_ps(N, h, w, 3), g16_ps(N, h, w, 3));
                 if (!done) return fail(m, FCN8S_ERR_SHAPE, std::string("bf16_train: ") + nm + " does not fit the bf16 convolution kernel");
                 if (done && yb) m->xg16_filled.insert(nx);
                 if (done && only16) { m->y_unwritten.insert(nm); m->in_bf16_only.insert(nx); }
@@ -1403,7 +1411,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
             const bool only16 = yb && b != 2 && b != 3;
             char ix[16]; snprintf(ix, sizeof ix, "pidx%d", b + 1);
             ProfScope ps(m, "maxpool_fwd", 0, 4.0 * N * h * w * cin * (only16 ? 1.0625 : 1.3125) + (yb ? 0.5 * N * h * w * cin : 0.0));
-            launch_maxpool_fwd_route(x, only16 ? nullptr : A(m, pn), (unsigned char*)A(m, ix), N, h, w, cin, s, yb, (ck - 1) / 2);
+            launch_maxpool_fwd_route(x, only16 ? nullptr : A(m, pn), (unsigned char*)A(m, ix), N, h, w, cin, s, yb, (ck - 1) / 2, g16_ps(N, h / 2, w / 2, ck));
             m->pool_routed[b] = true; pooled = true;
             if (yb) m->xg16_filled.insert(cons);
             if (only16) { m->y_unwritten.insert(pn); m->in_bf16_only.insert(cons); }
@@ -1423,14 +1431,14 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     m->drop_stream = (uint32_t)(2 * m->step);
     if (bf16_train_mode(m)) {
         unsigned short* xb6 = train ? xg16_for(m, "fc6", N, h5, w5, m->widths[4], m->fc6k, s) : nullptr;
-        if (xb6 && !m->xg16_filled.count("fc6")) { ProfScope ps(m, "bf16_convert", 0, 6.0 * N * h5 * w5 * m->widths[4]); launch_f32_to_bf16_padded(x, xb6, N, h5, w5, m->widths[4], (m->fc6k - 1) / 2, s); }
+        if (xb6 && !m->xg16_filled.count("fc6")) { ProfScope ps(m, "bf16_convert", 0, 6.0 * N * h5 * w5 * m->widths[4]); launch_f32_to_bf16_padded(x, xb6, N, h5, w5, m->widths[4], (m->fc6k - 1) / 2, s, g16_ps(N, h5, w5, m->fc6k)); }
         unsigned short* xb7 = train ? xg16_for(m, "fc7", N, h5, w5, m->widths[5], 1, s) : nullptr;
         const bool fuse7 = false;          // (fc6 runs on the tile kernel, whose bf16 side output is 2-byte stores: its 134 MB are converted by a pass of their own)
         if (!bf16_conv_layer(m, "fc6_fwd_bf16", "fc6/weights", "fc6/biases", x, A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, drop, keep_prob, m->drop_stream, s, false, xb6, true,
-                             fuse7 ? xb7 : nullptr, 0))
+                             fuse7 ? xb7 : nullptr, 0, g16_ps(N, h5, w5, m->fc6k), g16_ps(N, h5, w5, 1)))
             return fail(m, FCN8S_ERR_SHAPE, "bf16_train: fc6 does not fit the bf16 convolution kernel");
-        if (xb7 && !fuse7) { ProfScope ps(m, "bf16_convert", 0, 6.0 * N * h5 * w5 * m->widths[5]); launch_f32_to_bf16_padded(A(m, "fc6"), xb7, N, h5, w5, m->widths[5], 0, s); }
-        if (!bf16_conv_layer(m, "fc7_fwd_bf16", "fc7/weights", "fc7/biases", A(m, "fc6"), A(m, "fc7"), N, h5, w5, m->widths[5], m->widths[6], 1, drop, keep_prob, m->drop_stream + 1, s, false, xb7, true))
+        if (xb7 && !fuse7) { ProfScope ps(m, "bf16_convert", 0, 6.0 * N * h5 * w5 * m->widths[5]); launch_f32_to_bf16_padded(A(m, "fc6"), xb7, N, h5, w5, m->widths[5], 0, s, g16_ps(N, h5, w5, 1)); }
+        if (!bf16_conv_layer(m, "fc7_fwd_bf16", "fc7/weights", "fc7/biases", A(m, "fc6"), A(m, "fc7"), N, h5, w5, m->widths[5], m->widths[6], 1, drop, keep_prob, m->drop_stream + 1, s, false, xb7, true, nullptr, 0, g16_ps(N, h5, w5, 1)))
             return fail(m, FCN8S_ERR_SHAPE, "bf16_train: fc7 does not fit the bf16 convolution kernel");
     } else if (m->precision == FCN8S_PREC_BF16_FC || bf16_fwd_mode(m)) {
         // config 5: bf16-rounded operands, fp32 accumulate, fp32 epilogue and output (gemm_bf16.hip)
@@ -1648,7 +1656,7 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
                 ProfScope ps(m, "maxpool_bwd", 0, 4.0 * N * h * w * cw * (m->pool_routed[b - 1] ? 0.3125 : 1.25) + 2.0 * N * h * w * cw);
                 char ix[16]; snprintf(ix, sizeof ix, "pidx%d", b);
                 pool_done = launch_maxpool_bwd_bf16(A(m, last), m->gbuf[m->gcur], dzb, Gp(m, std::string(last) + "/biases"), N, h, w, cw, s,
-                                                    m->pool_routed[b - 1] ? (const unsigned char*)A(m, ix) : nullptr);
+                                                    m->pool_routed[b - 1] ? (const unsigned char*)A(m, ix) : nullptr, g16_ps(N, h, w, 3));
             }
             if (pool_done) { m->dyg16_filled.insert(last); m->db_taken.insert(last); m->gcur ^= 1; }
         }
@@ -2921,6 +2929,7 @@ int fcn8s_op_conv2d_bf16_train(void* stream, const float* x, const float* w, con
     hipStream_t s = (hipStream_t)stream;
     const int pad = (K - 1) / 2, Wp_ = W + 2 * pad;
     const long long G = bf16_guard_rows(K, Wp_), R = (long long)N * (H + 2 * pad) * Wp_;
+    const long long PS = (R + 2 * G) * 32;          // the padded copies as channel-chunk planes [C / 32][G + R + G][32], as the bf16_train mode keeps them
     unsigned short *xb = nullptr, *dyb = nullptr, *wt = nullptr;
     auto cleanup = [&]() { hipStreamSynchronize(s); if (xb) hipFree(xb); if (dyb) hipFree(dyb); if (wt) hipFree(wt); };
     const size_t nx = (size_t)(R + 2 * G) * Cin, ny = (size_t)(R + 2 * G) * Cout, nw = (size_t)K * K * Cin * Cout;
@@ -2928,29 +2937,29 @@ int fcn8s_op_conv2d_bf16_train(void* stream, const float* x, const float* w, con
     if (x) {
         if (hipMalloc((void**)&xb, nx * 2) != hipSuccess) { cleanup(); return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc"); }
         hipMemsetAsync(xb, 0, nx * 2, s);
-        launch_f32_to_bf16_padded(x, xb + G * Cin, N, H, W, Cin, pad, s);
+        launch_f32_to_bf16_padded(x, xb + G * 32, N, H, W, Cin, pad, s, PS);
     }
     if (dy) {
         if (hipMalloc((void**)&dyb, ny * 2) != hipSuccess) { cleanup(); return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc"); }
         hipMemsetAsync(dyb, 0, ny * 2, s);
-        launch_f32_to_bf16_padded(dy, dyb + G * Cout, N, H, W, Cout, pad, s);
+        launch_f32_to_bf16_padded(dy, dyb + G * 32, N, H, W, Cout, pad, s, PS);
     }
     bool ok = true;
     if (y && x && w) {
         launch_w_to_bf16_t(w, wt, K * K * Cin, Cout, s);
         Bf16Conv256Args g{};
-        g.xp = xb + G * Cin; g.wt = wt; g.bias = bias; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K; g.relu = relu; g.any_shape = 1; g.mask_scale = 1.f; g.guarded = 1;
+        g.xp = xb + G * 32; g.xp_ps = PS; g.wt = wt; g.bias = bias; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K; g.relu = relu; g.any_shape = 1; g.mask_scale = 1.f; g.guarded = 1;
         ok = ok && launch_conv_bf16_256(g, s);
     }
     if (dx && dy && w) {
         launch_w_to_bf16_flip_t(w, wt, K, Cin, Cout, s);
         Bf16Conv256Args g{};
-        g.xp = dyb + G * Cout; g.wt = wt; g.y = dx; g.N = N; g.H = H; g.W = W; g.Cin = Cout; g.Cout = Cin; g.K = K; g.mask = mask; g.mask_scale = 1.f; g.any_shape = 1; g.guarded = 1;
+        g.xp = dyb + G * 32; g.xp_ps = PS; g.wt = wt; g.y = dx; g.N = N; g.H = H; g.W = W; g.Cin = Cout; g.Cout = Cin; g.K = K; g.mask = mask; g.mask_scale = 1.f; g.any_shape = 1; g.guarded = 1;
         ok = ok && launch_conv_bf16_256(g, s);
     }
     if (dw && x && dy) {
         Bf16WgradArgs g{};
-        g.A = xb + G * Cin; g.B = dyb + G * Cout; g.C = dw; g.R = R; g.Ci = Cin; g.Cj = Cout; g.K = K; g.Wp = Wp_;
+        g.A = xb + G * 32; g.B = dyb + G * 32; g.a_ps = g.b_ps = PS; g.C = dw; g.R = R; g.Ci = Cin; g.Cj = Cout; g.K = K; g.Wp = Wp_;
         ok = ok && launch_wgrad_bf16(g, s);
     }
     if (db && dy) { hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), s); launch_colsum(dy, db, (long long)N * H * W, Cout, s); }
