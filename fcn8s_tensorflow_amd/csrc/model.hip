@@ -332,6 +332,7 @@ static bool bt_gemm_ok(int K, int N) { return K % 16 == 0 && (N == 64 || N % 128
 // Arithmetic of the op-level entry points, which have no model: the context of the CALLING THREAD (fcn8s_set_option(NULL, "op_split_pieces", n)
 // from that thread), copied into the bare model each such call builds -- never read by a real model, never shared between threads.
 thread_local int t_op_split = 0;
+thread_local int t_op_planes = 1;        // op context: fcn8s_op_conv2d_bf16_train keeps its padded copies as channel-chunk planes (option "op_bf16_planes")
 int split_of(const fcn8s_model* m)
 {
     if (!m) return t_op_split;
@@ -2025,6 +2026,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
     if (!m) {
         if (k == "op_f32x3") { t_op_split = value ? 3 : 0; return FCN8S_OK; }
         if (k == "op_deterministic") { t_deterministic = value ? 1 : 0; return FCN8S_OK; }
+        if (k == "op_bf16_planes") { t_op_planes = value ? 1 : 0; return FCN8S_OK; }
         if (k == "op_split_pieces") {
             if (value != 0 && value != 2 && value != 3) return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_set_option: op_split_pieces is 0, 2 or 3");
             t_op_split = (int)value; return FCN8S_OK;
@@ -2075,6 +2077,7 @@ int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value)
     if (!m) {
         if (k == "op_f32x3") { *value = t_op_split == 3; return FCN8S_OK; }
         if (k == "op_deterministic") { *value = t_deterministic; return FCN8S_OK; }
+        if (k == "op_bf16_planes") { *value = t_op_planes; return FCN8S_OK; }
         if (k == "op_split_pieces") { *value = t_op_split; return FCN8S_OK; }
         return FCN8S_ERR_NOT_FOUND;
     }
@@ -2929,7 +2932,10 @@ int fcn8s_op_conv2d_bf16_train(void* stream, const float* x, const float* w, con
     hipStream_t s = (hipStream_t)stream;
     const int pad = (K - 1) / 2, Wp_ = W + 2 * pad;
     const long long G = bf16_guard_rows(K, Wp_), R = (long long)N * (H + 2 * pad) * Wp_;
-    const long long PS = (R + 2 * G) * 32;          // the padded copies as channel-chunk planes [C / 32][G + R + G][32], as the bf16_train mode keeps them
+    // the padded copies as channel-chunk planes [C / 32][G + R + G][32], as the bf16_train mode keeps them (op option "op_bf16_planes" = 0: [rows][C], the
+    // layout every kernel still takes -- plane stride 0 -- and the other bf16 modes use)
+    const long long PS = t_op_planes ? (R + 2 * G) * 32 : 0;
+    const long long OX = t_op_planes ? G * 32 : G * Cin, OY = t_op_planes ? G * 32 : G * Cout;
     unsigned short *xb = nullptr, *dyb = nullptr, *wt = nullptr;
     auto cleanup = [&]() { hipStreamSynchronize(s); if (xb) hipFree(xb); if (dyb) hipFree(dyb); if (wt) hipFree(wt); };
     const size_t nx = (size_t)(R + 2 * G) * Cin, ny = (size_t)(R + 2 * G) * Cout, nw = (size_t)K * K * Cin * Cout;
@@ -2937,29 +2943,29 @@ int fcn8s_op_conv2d_bf16_train(void* stream, const float* x, const float* w, con
     if (x) {
         if (hipMalloc((void**)&xb, nx * 2) != hipSuccess) { cleanup(); return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc"); }
         hipMemsetAsync(xb, 0, nx * 2, s);
-        launch_f32_to_bf16_padded(x, xb + G * 32, N, H, W, Cin, pad, s, PS);
+        launch_f32_to_bf16_padded(x, xb + OX, N, H, W, Cin, pad, s, PS);
     }
     if (dy) {
         if (hipMalloc((void**)&dyb, ny * 2) != hipSuccess) { cleanup(); return fail(nullptr, FCN8S_ERR_OOM, "hipMalloc"); }
         hipMemsetAsync(dyb, 0, ny * 2, s);
-        launch_f32_to_bf16_padded(dy, dyb + G * 32, N, H, W, Cout, pad, s, PS);
+        launch_f32_to_bf16_padded(dy, dyb + OY, N, H, W, Cout, pad, s, PS);
     }
     bool ok = true;
     if (y && x && w) {
         launch_w_to_bf16_t(w, wt, K * K * Cin, Cout, s);
         Bf16Conv256Args g{};
-        g.xp = xb + G * 32; g.xp_ps = PS; g.wt = wt; g.bias = bias; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K; g.relu = relu; g.any_shape = 1; g.mask_scale = 1.f; g.guarded = 1;
+        g.xp = xb + OX; g.xp_ps = PS; g.wt = wt; g.bias = bias; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K; g.relu = relu; g.any_shape = 1; g.mask_scale = 1.f; g.guarded = 1;
         ok = ok && launch_conv_bf16_256(g, s);
     }
     if (dx && dy && w) {
         launch_w_to_bf16_flip_t(w, wt, K, Cin, Cout, s);
         Bf16Conv256Args g{};
-        g.xp = dyb + G * 32; g.xp_ps = PS; g.wt = wt; g.y = dx; g.N = N; g.H = H; g.W = W; g.Cin = Cout; g.Cout = Cin; g.K = K; g.mask = mask; g.mask_scale = 1.f; g.any_shape = 1; g.guarded = 1;
+        g.xp = dyb + OY; g.xp_ps = PS; g.wt = wt; g.y = dx; g.N = N; g.H = H; g.W = W; g.Cin = Cout; g.Cout = Cin; g.K = K; g.mask = mask; g.mask_scale = 1.f; g.any_shape = 1; g.guarded = 1;
         ok = ok && launch_conv_bf16_256(g, s);
     }
     if (dw && x && dy) {
         Bf16WgradArgs g{};
-        g.A = xb + G * 32; g.B = dyb + G * 32; g.a_ps = g.b_ps = PS; g.C = dw; g.R = R; g.Ci = Cin; g.Cj = Cout; g.K = K; g.Wp = Wp_;
+        g.A = xb + OX; g.B = dyb + OY; g.a_ps = g.b_ps = PS; g.C = dw; g.R = R; g.Ci = Cin; g.Cj = Cout; g.K = K; g.Wp = Wp_;
         ok = ok && launch_wgrad_bf16(g, s);
     }
     if (db && dy) { hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), s); launch_colsum(dy, db, (long long)N * H * W, Cout, s); }

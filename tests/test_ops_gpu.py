@@ -280,6 +280,17 @@ def test_conv_bf16_train_kernels(N, H, W, Cin, Cout, K):
         L.check(L.lib.fcn8s_set_option(None, b"op_deterministic", 0))
     np.testing.assert_array_equal(outs[0], outs[1])
     assert rel_err(outs[0], dw_ref) < 1e-5
+    # the padded copies as [rows][C] instead of channel-chunk planes (the layout the other bf16 modes hand these kernels): the same results
+    L.check(L.lib.fcn8s_set_option(None, b"op_bf16_planes", 0))
+    try:
+        y2, dx3, dw2 = torch.empty(N, H, W, Cout).cuda(), torch.empty(N, H, W, Cin).cuda(), torch.empty(K, K, Cin, Cout).cuda()
+        L.check(L.lib.fcn8s_op_conv2d_bf16_train(None, ptr(xd), ptr(wd), ptr(bd), ptr(y2), 1, ptr(dyd), ptr(md), ptr(dx3), ptr(dw2), None, N, H, W, Cin, Cout, K))
+        torch.cuda.synchronize()
+    finally:
+        L.check(L.lib.fcn8s_set_option(None, b"op_bf16_planes", 1))
+    np.testing.assert_array_equal(y2.cpu().numpy(), y_.cpu().numpy())
+    np.testing.assert_array_equal(dx3.cpu().numpy(), dx_.cpu().numpy())
+    assert rel_err(dw2.cpu().numpy(), dw_ref) < 1e-5
     with pytest.raises(ValueError):
         L.check(L.lib.fcn8s_op_conv2d_bf16_train(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), 1, None, None, None, None, None, N, H, W, Cin + 32, Cout, K))
 
