@@ -533,54 +533,69 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
                 }
         return;
     }
-    // epilogue (fp32): bias, skip-path addend, ReLU, the ReLU mask of a data gradient, dropout keyed by the element offset -- the same Philox stream as the fp32 path
+    // epilogue (fp32): bias, skip-path addend, ReLU, the ReLU mask of a data gradient, dropout keyed by the element offset -- the same Philox stream as the fp32
+    // path.  Through LDS, row-major, like the flat-position kernel's: the MFMA layout gives a lane one column of sixteen scattered rows (4-byte stores and mask
+    // loads -- 0.12-0.14 ms of fc7's 0.40-0.42 with the K loop switched off, profiles/r05_bf16_conv_tile_ab.txt); each wave parks one 32 x 32 tile at a time
+    // (raw accumulators) in its own patch of the free stage buffers, then a lane owns (row, 8 consecutive channels): 16-byte loads and stores.
+    // p.yb: the consumer's padded bf16 copy of this output (pixel (n, y, x) -> pixel (n, y + pad, x + pad) of [N][H + 2 pad][W + 2 pad][Cout], border never written).
+    __builtin_amdgcn_s_barrier();                                          // (every wave is behind its last fragment reads: the loops end in a barrier)
+    constexpr int LDP = 36;
+    float* patch = reinterpret_cast<float*>(smem) + wave * (32 * LDP);
+    const int prow0 = lane >> 2, pc8 = (lane & 3) * 8;
+    const int Hq = p.H + 2 * p.yb_pad, Wq = p.W + 2 * p.yb_pad;
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
-        const float bv = p.bias ? p.bias[col] : 0.f;
+    for (int tm = 0; tm < TM; ++tm) {
+        const long long mt = m0 + grp * 128 + wr * (TM * 32) + tm * 32;      // first row of this 32-row tile
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + grp * 128 + wr * (TM * 32) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= p.M) continue;
-                const long long off = m * p.Cout + col;
-                float v = acc[tm][tn][r] + bv;
-                if (p.addend) v += p.addend[off];
-                if (p.relu) v = v > 0.f ? v : 0.f;
-                if (p.mask) v = p.mask[off] > 0.f ? v * p.mask_scale : 0.f;
-                if (p.dropout) v = philox_uniform((unsigned long long)off, p.seed, p.stream_id) < p.keep_prob ? v / p.keep_prob : 0.f;
-                p.y[off] = v;
-            }
-    }
-    // the consumer's padded bf16 copy of this output, written here instead of by a conversion pass of its own (bf16_train): pixel (n, y, x) of the
-    // output is pixel (n, y + pad, x + pad) of a [N][H + 2 pad][W + 2 pad][Cout] buffer whose border was zeroed once and is never written
-    if (p.yb) {
-        const int Hq = p.H + 2 * p.yb_pad, Wq = p.W + 2 * p.yb_pad;
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDP + (lane & 31)] = acc[tm][tn][r];
+            __builtin_amdgcn_wave_barrier();
+            const int col8 = n0 + wn * 64 + tn * 32 + pc8;
+            float bv[8];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const long long mb = m0 + grp * 128 + wr * (TM * 32) + tm * 32 + 4 * (lane >> 5);
-            const int n = (int)(mb / HW), rem = (int)(mb - (long long)n * HW), y = rem / p.W, x = rem - y * p.W;
+            for (int k = 0; k < 8; ++k) bv[k] = p.bias ? p.bias[col8 + k] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = (r & 3) + 8 * (r >> 2);
-                if (mb + o >= p.M) continue;
-                int xx = x + o, yy = y, nn = n;
-                while (xx >= p.W) { xx -= p.W; ++yy; }
-                while (yy >= p.H) { yy -= p.H; ++nn; }
-                const long long q = ((long long)nn * Hq + yy + p.yb_pad) * Wq + xx + p.yb_pad;
+            for (int it = 0; it < 2; ++it) {
+                const long long m = mt + prow0 + 16 * it;
+                if (m < p.M) {
+                    const float4 u0 = *reinterpret_cast<const float4*>(&patch[(prow0 + 16 * it) * LDP + pc8]);
+                    const float4 u1 = *reinterpret_cast<const float4*>(&patch[(prow0 + 16 * it) * LDP + pc8 + 4]);
+                    float v[8] = {u0.x + bv[0], u0.y + bv[1], u0.z + bv[2], u0.w + bv[3], u1.x + bv[4], u1.y + bv[5], u1.z + bv[6], u1.w + bv[7]};
+                    const long long off = m * p.Cout + col8;
+                    if (p.addend) {
+                        const float4 a0 = *reinterpret_cast<const float4*>(p.addend + off), a1 = *reinterpret_cast<const float4*>(p.addend + off + 4);
+                        v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+                    }
+                    if (p.relu) {
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
-                    float v = acc[tm][tn][r] + (p.bias ? p.bias[col] : 0.f);
-                    const long long off = (mb + o) * p.Cout + col;
-                    if (p.addend) v += p.addend[off];
-                    if (p.relu) v = v > 0.f ? v : 0.f;
-                    if (p.mask) v = p.mask[off] > 0.f ? v * p.mask_scale : 0.f;
-                    if (p.dropout) v = philox_uniform((unsigned long long)off, p.seed, p.stream_id) < p.keep_prob ? v / p.keep_prob : 0.f;
-                    reinterpret_cast<__bf16*>(p.yb)[p.yb_ps ? (long long)(col >> 5) * p.yb_ps + q * 32 + (col & 31) : q * p.Cout + col] = (__bf16)v;
+                        for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                    }
+                    if (p.mask) {
+                        const float4 q0 = *reinterpret_cast<const float4*>(p.mask + off), q1 = *reinterpret_cast<const float4*>(p.mask + off + 4);
+                        const float mk[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = mk[k] > 0.f ? v[k] * p.mask_scale : 0.f;
+                    }
+                    if (p.dropout) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = philox_uniform((unsigned long long)(off + k), p.seed, p.stream_id) < p.keep_prob ? v[k] / p.keep_prob : 0.f;
+                    }
+                    if (p.y) {
+                        *reinterpret_cast<float4*>(p.y + off) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(p.y + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                    if (p.yb) {
+                        const int n = (int)(m / HW), rem = (int)(m - (long long)n * HW), yy = rem / p.W, xx = rem - yy * p.W;
+                        const long long q = ((long long)n * Hq + yy + p.yb_pad) * Wq + xx + p.yb_pad;
+                        bf16x8 o;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = (__bf16)v[k];
+                        *reinterpret_cast<bf16x8*>(p.yb + (p.yb_ps ? (long long)(col8 >> 5) * p.yb_ps + q * 32 + (col8 & 31) : q * p.Cout + col8)) = o;
+                    }
                 }
             }
+            __builtin_amdgcn_wave_barrier();                               // (the patch is this wave's own: the next tile overwrites it)
         }
     }
 }
