@@ -1222,7 +1222,10 @@ bool launch_wgrad_bf16(const Bf16WgradArgs& a0, hipStream_t s)
     const int taps = a.K * a.K;
     const long long tiles = (long long)(a.Ci / bm) * (a.Cj / bm) * (taps9 ? 1 : taps);
     const long long slots = 256LL * (taps9 ? 2 : (bm == 128 ? 2 : 4));
-    long long want = (2 * slots + tiles - 1) / tiles;            // about two rounds of resident blocks
+    // splits: ONE round of resident blocks for the nine-tap kernel (every block ends with 9 x 16 float atomics per lane: with its K loop switched on and the
+    // epilogue off conv5_x took 0.13 instead of 0.20 ms, conv3 / conv4 8-13 % less), half a round where all blocks add into one 64 x 64 x 9 tile (conv1_2);
+    // same-box A/B (profiles/r05_bf16_conv_tile_ab.txt): two rounds / one / half = conv5_2 0.202 / 0.170 / 0.200, conv4_2 0.527 / 0.505 / 0.657, conv1_2 0.77 / 0.76 / 0.70
+    long long want = taps9 ? (tiles == 1 ? slots / 2 : (slots + tiles - 1) / tiles) : (2 * slots + tiles - 1) / tiles;
     const long long maxsplit = (a.R + 1023) / 1024;              // at least 32 K-tiles per block
     if (want > maxsplit) want = maxsplit;
     if (want < 1) want = 1;
