@@ -1101,26 +1101,34 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void wgrad_bf16_kernel(cons
 // at the fabric's rate (3 ms).  Here a K-tile of 32 rows brings the 32 rows of dYp once and, per filter row ty, the 34 rows of Xp that its three taps
 // read (40 are loaded: whole LDS-DMA instructions of 8 rows): row j of group ty is Xp row q0 - 1 + (ty - 1) Wp + j, and tap (ty, tx) of K-tile row r reads
 // group row r + tx.  Nine accumulators (144 VGPRs) per wave, 18 MFMAs per K-tile and wave; 57 KB of LDS in three stages, two blocks per CU.
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_taps9_kernel(const Bf16WgradArgs p)
+// NJ = 2 (layers with Cj % 128 == 0): the block owns 64 x 128 channels -- eight waves, the upper four on the second 64 columns of dY -- so the A rows (three
+// groups of 40, 79 % of a K-tile's bytes) are fetched once for twice the products: 23.4 KB per K-tile instead of 2 x 19.4.  The lab that switches parts of the K
+// loop off had shown the 64 x 64 form bound by its LDS-DMA stream on the 128- / 256-channel layers (conv2_2: 0.63 ms without MFMAs, 0.65 complete, 0.42 without
+// DMA).  One block of eight waves per CU (the nine accumulators need 2 waves per SIMD either way), four stages.
+template <int NJ>
+__global__ __launch_bounds__(256 * NJ, NJ == 1 ? 2 : 1) void wgrad_bf16_taps9_kernel(const Bf16WgradArgs p)
 {
-    constexpr int S = 3, ROWB = 128, AROWS = 40, AGRP = AROWS * ROWB, STAGE = 3 * AGRP + 32 * ROWB;
+    constexpr int S = NJ == 1 ? 3 : 4, ROWB = 128, AROWS = 40, AGRP = AROWS * ROWB, BIMG = 32 * ROWB, STAGE = 3 * AGRP + NJ * BIMG;
     __shared__ __attribute__((aligned(16))) unsigned char smem[S * STAGE];
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntj = p.Cj / 64, ntiles = (p.Ci / 64) * ntj;
+    const int w4 = wave & 3, jh = wave >> 2;                         // jh: which 64-column half of the block's dY tile this wave multiplies
+    const int wm = w4 >> 1, wn = w4 & 1;
+    const int ntj = p.Cj / (64 * NJ), ntiles = (p.Ci / 64) * ntj;
     const int tile = blockIdx.x % ntiles, ys = blockIdx.x / ntiles;
-    const int i0 = (tile / ntj) * 64, j0 = (tile % ntj) * 64;
+    const int i0 = (tile / ntj) * 64, j0 = (tile % ntj) * (64 * NJ);
     const long long t0 = (long long)ys * p.chunk;
     const long long t1 = t0 + p.chunk < p.R ? t0 + p.chunk : p.R;
     const int nkt = (int)((t1 - t0 + 31) / 32);
-    // waves 0 .. 2: the A rows of filter row ty = wave (five instructions of 8 rows), wave 3: the B rows (four)
-    const int ld = wave < 3 ? p.Ci : p.Cj;
-    const long long ps = wave < 3 ? p.a_ps : p.b_ps;               // channel-chunk planes [C / 32][rows][32] (0: [rows][C])
+    // waves 0 .. 2: the A rows of filter row ty = wave (five instructions of 8 rows); wave 3 (and 7): the B rows of column half 0 (1), four instructions; waves 4 .. 6: none
+    const bool is_a = wave < 3, is_b = w4 == 3;
+    const int ld = is_a ? p.Ci : p.Cj;
+    const long long ps = is_a ? p.a_ps : p.b_ps;                   // channel-chunk planes [C / 32][rows][32] (0: [rows][C])
     const long long rstep = ps ? 32 : ld;
-    const unsigned short* mine = wave < 3 ? p.A + (ps ? (long long)(i0 >> 5) * ps + (t0 - 1 + (long long)(wave - 1) * p.Wp) * 32 : (t0 - 1 + (long long)(wave - 1) * p.Wp) * p.Ci + i0)
-                                          : p.B + (ps ? (long long)(j0 >> 5) * ps + t0 * 32 : t0 * p.Cj + j0);
+    const int jb = j0 + jh * 64;
+    const unsigned short* mine = is_a ? p.A + (ps ? (long long)(i0 >> 5) * ps + (t0 - 1 + (long long)(wave - 1) * p.Wp) * 32 : (t0 - 1 + (long long)(wave - 1) * p.Wp) * p.Ci + i0)
+                                      : p.B + (ps ? (long long)(jb >> 5) * ps + t0 * 32 : t0 * p.Cj + jb);
     unsigned voff[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -1130,10 +1138,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_taps9_kernel(const Bf16Wgra
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     auto issue = [&](int kt, int stage) {
         const unsigned short* g = mine + (long long)kt * 32 * rstep;
-        const unsigned dst = lds0 + stage * STAGE + wave * AGRP;            // (wave 3: 3 * AGRP = the B image)
+        if (!is_a && !is_b) return;
+        const unsigned dst = lds0 + stage * STAGE + (is_a ? wave * AGRP : 3 * AGRP + jh * BIMG);
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16w(g, voff[i], dst + i * 1024);
-        if (wave < 3) glds16w(g, voff[4], dst + 4 * 1024);
+        if (is_a) glds16w(g, voff[4], dst + 4 * 1024);
     };
     f32x16 acc[9];
 #pragma unroll
@@ -1149,7 +1158,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_taps9_kernel(const Bf16Wgra
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int row = 8 * g + 4 * r + (i >> 2);
-            b_addr[r] = (unsigned)(3 * AGRP + row * ROWB + (((cb >> 3) ^ (2 * (row & 3))) * 16) + (cb & 7) * 2);
+            b_addr[r] = (unsigned)(3 * AGRP + jh * BIMG + row * ROWB + (((cb >> 3) ^ (2 * (row & 3))) * 16) + (cb & 7) * 2);
 #pragma unroll
             for (int tx = 0; tx < 3; ++tx) {
                 const int j = row + tx;
@@ -1157,14 +1166,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_taps9_kernel(const Bf16Wgra
             }
         }
     }
-    issue(0, 0);
-    if (nkt > 1) issue(1, 1);
-    int stage = 0, pre = 2;
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t) if (t < nkt) issue(t, t);
+    int stage = 0, pre = S - 1;
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) { if (wave < 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile kt has landed when at most min(S - 2, tiles after it) newer tiles of this wave's instructions are outstanding
+        const int newer = nkt - 1 - kt < S - 2 ? nkt - 1 - kt : S - 2;
+        if (is_a) { if (newer >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else if (newer == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        else if (is_b) { if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nkt) issue(kt + 2, pre);
+        if (kt + S - 1 < nkt) issue(kt + S - 1, pre);
         const unsigned sb = lds0 + stage * STAGE;
         bf16x8 b[2];
         {
@@ -1201,7 +1212,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_taps9_kernel(const Bf16Wgra
         float* C = p.C + (long long)t * p.Ci * p.Cj + (long long)ys * p.split_stride;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = j0 + wn * 32 + (lane & 31);
+            const int row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = j0 + jh * 64 + wn * 32 + (lane & 31);
             if (p.plain_store) C[(long long)row * p.Cj + col] = acc[t][r];
             else unsafeAtomicAdd(C + (long long)row * p.Cj + col, acc[t][r]);
         }
@@ -1218,10 +1229,14 @@ bool launch_wgrad_bf16(const Bf16WgradArgs& a0, hipStream_t s)
     // (profiles/r05_wgrad_taps9_ab.txt): conv1_2 3.08 -> 0.76 ms, conv2_2 1.43 -> 0.67, conv3_2 1.51 -> 0.68 (409 -> 904 TFLOP/s), conv4_2 1.13 -> 0.57
     // (546 -> 1092), conv5_x 0.24 -> 0.20.  (The A/B ran on an environment switch that is gone again: the library reads no environment variable.)
     const bool taps9 = a.K == 3;
+    // the nine-tap kernel's 64 x 128 form where it measured faster (same-box A/B, profiles/r05_bf16_conv_tile_ab.txt): the 128- / 256-channel layers with at
+    // least two tiles -- conv2_2 0.63 -> 0.55 ms, conv3_2 0.55 -> 0.52, conv3_1 0.33 -> 0.305; conv4_x the same either way, conv5_x 0.168 -> 0.18 (short K
+    // loops: one block per CU hides less), conv2_1 (a single tile) 0.33 -> 0.46
+    const int nj = (taps9 && a.Cj % 128 == 0 && a.Cj <= 256 && (a.Ci / 64) * (a.Cj / 128) >= 2) ? 2 : 1;
     const int bm = taps9 ? 64 : ((a.Ci % 128 == 0 && a.Cj % 128 == 0) ? 128 : 64);
     const int taps = a.K * a.K;
-    const long long tiles = (long long)(a.Ci / bm) * (a.Cj / bm) * (taps9 ? 1 : taps);
-    const long long slots = 256LL * (taps9 ? 2 : (bm == 128 ? 2 : 4));
+    const long long tiles = (long long)(a.Ci / bm) * (a.Cj / (bm * nj)) * (taps9 ? 1 : taps);
+    const long long slots = 256LL * (taps9 ? (nj == 2 ? 1 : 2) : (bm == 128 ? 2 : 4));
     // splits: ONE round of resident blocks for the nine-tap kernel (every block ends with 9 x 16 float atomics per lane: with its K loop switched on and the
     // epilogue off conv5_x took 0.13 instead of 0.20 ms, conv3 / conv4 8-13 % less), half a round where all blocks add into one 64 x 64 x 9 tile (conv1_2);
     // same-box A/B (profiles/r05_bf16_conv_tile_ab.txt): two rounds / one / half = conv5_2 0.202 / 0.170 / 0.200, conv4_2 0.527 / 0.505 / 0.657, conv1_2 0.77 / 0.76 / 0.70
@@ -1244,7 +1259,8 @@ bool launch_wgrad_bf16(const Bf16WgradArgs& a0, hipStream_t s)
     }
     if (taps9) {
         g_last_kernel = "wgrad_bf16_taps9_kernel";
-        hipLaunchKernelGGL(wgrad_bf16_taps9_kernel, dim3((unsigned)(tiles * nsplit)), dim3(256), 0, s, a);
+        if (nj == 2) hipLaunchKernelGGL(wgrad_bf16_taps9_kernel<2>, dim3((unsigned)(tiles * nsplit)), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL(wgrad_bf16_taps9_kernel<1>, dim3((unsigned)(tiles * nsplit)), dim3(256), 0, s, a);
         if (a.split_stride) launch_det_reduce(out, a.C, 1, (int)slab, (int)slab, slab, nsplit, false, s);
         return true;
     }
