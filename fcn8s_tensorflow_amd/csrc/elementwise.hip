@@ -257,7 +257,9 @@ __global__ void maxpool_route_kernel(const float* x, unsigned char* r, int N, in
 // pass of a block whose last conv did not come from that transform (the bf16 modes) can then route d(pool) inside wino_dout_kernel too
 // yb16 (bf16_train): the pooled map also -- or, with y == nullptr, only -- as the interior of the consumer's zero-bordered bf16 copy [N][H/2 + 2 pad][W/2 + 2 pad][C]
 // ps4: plane stride of yb16 in 4-element units (channel-chunk planes [C / 32][rows][32]), 0 = [rows][C]
-__global__ void maxpool_fwd_route_kernel(const float4* x, float4* y, unsigned* r, int N, int H, int W, int C4, unsigned short* yb16, int pad, long long ps4)
+// round16 (bf16_train, the pools whose output only bf16 convolutions read): the window's maximum is picked among the values ROUNDED to bf16 -- the values the
+// consumers see, and the rule of maxpool_fwd_route16_kernel below, which reads the block's last activation as its bf16 copy
+__global__ void maxpool_fwd_route_kernel(const float4* x, float4* y, unsigned* r, int N, int H, int W, int C4, unsigned short* yb16, int pad, long long ps4, int round16)
 {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     const int Ho = H / 2, Wo = W / 2;
@@ -274,10 +276,12 @@ __global__ void maxpool_fwd_route_kernel(const float4* x, float4* y, unsigned* r
         float mv[4]; unsigned word = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            unsigned bi = 0; float m = av[k];
-            if (bv[k] > m) { m = bv[k]; bi = 1; }
-            if (cv[k] > m) { m = cv[k]; bi = 2; }
-            if (dv[k] > m) { m = dv[k]; bi = 3; }
+            const float ra = round16 ? (float)(__bf16)av[k] : av[k], rbv = round16 ? (float)(__bf16)bv[k] : bv[k];
+            const float rc = round16 ? (float)(__bf16)cv[k] : cv[k], rd = round16 ? (float)(__bf16)dv[k] : dv[k];
+            unsigned bi = 0; float m = ra;
+            if (rbv > m) { m = rbv; bi = 1; }
+            if (rc > m) { m = rc; bi = 2; }
+            if (rd > m) { m = rd; bi = 3; }
             if (!(m > 0.f)) bi = 4;
             mv[k] = fmaxf(fmaxf(av[k], bv[k]), fmaxf(cv[k], dv[k]));
             word |= bi << (8 * k);
@@ -290,10 +294,50 @@ __global__ void maxpool_fwd_route_kernel(const float4* x, float4* y, unsigned* r
         }
     }
 }
-void launch_maxpool_fwd_route(const float* x, float* y, unsigned char* r, int N, int H, int W, int C, hipStream_t s, unsigned short* yb16, int pad, long long yb16_ps)
+void launch_maxpool_fwd_route(const float* x, float* y, unsigned char* r, int N, int H, int W, int C, hipStream_t s, unsigned short* yb16, int pad, long long yb16_ps, int round16)
 {
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool_fwd_route_kernel, dim3(cap_blocks(total, 256)), dim3(256), 0, s, (const float4*)x, (float4*)y, (unsigned*)r, N, H, W, C / 4, yb16, pad, yb16_ps / 4);
+    hipLaunchKernelGGL(maxpool_fwd_route_kernel, dim3(cap_blocks(total, 256)), dim3(256), 0, s, (const float4*)x, (float4*)y, (unsigned*)r, N, H, W, C / 4, yb16, pad, yb16_ps / 4, round16);
+}
+// The same pool over the block's last activation kept ONLY as a bf16 copy (bf16_train: channel-chunk planes [C / 32][rows][32] of the zero-bordered map
+// [N][H + 2][W + 2]): half the bytes to read, and the producing convolution wrote half the bytes.  The maximum of the bf16 values IS the bf16 rounding of the
+// fp32 maximum (rounding is monotone), so the consumer's copy gets the same values; the routing bytes pick the first maximum among the bf16 values (round16 above).
+__global__ void maxpool_fwd_route16_kernel(const unsigned short* __restrict__ xb, long long xps4, unsigned* r, int N, int H, int W, int C4, unsigned short* yb16, int pad, long long ps4)
+{
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const int Ho = H / 2, Wo = W / 2, Wp = W + 2, Hp = H + 2;
+    const long long total = (long long)N * Ho * Wo * C4;
+    const bf16x4* x4 = reinterpret_cast<const bf16x4*>(xb);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long t = i / C4;
+        const int w = (int)(t % Wo); t /= Wo;
+        const int h = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const long long q0 = ((long long)n * Hp + 2 * h + 1) * Wp + 2 * w + 1;                 // padded position of the window's first pixel
+        const long long b0 = (long long)(c >> 3) * xps4 + q0 * 8 + (c & 7);
+        const bf16x4 a = x4[b0], b = x4[b0 + 8], cc = x4[b0 + (long long)Wp * 8], d = x4[b0 + (long long)Wp * 8 + 8];
+        bf16x4 mx; unsigned word = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float fa = (float)a[k], fb = (float)b[k], fc = (float)cc[k], fd = (float)d[k];
+            unsigned bi = 0; float m = fa;
+            if (fb > m) { m = fb; bi = 1; }
+            if (fc > m) { m = fc; bi = 2; }
+            if (fd > m) { m = fd; bi = 3; }
+            if (!(m > 0.f)) bi = 4;
+            mx[k] = (__bf16)fmaxf(fmaxf(fa, fb), fmaxf(fc, fd));
+            word |= bi << (8 * k);
+        }
+        r[i] = word;
+        const long long q = ((long long)n * (Ho + 2 * pad) + h + pad) * (Wo + 2 * pad) + w + pad;
+        reinterpret_cast<bf16x4*>(yb16)[(long long)(c >> 3) * ps4 + q * 8 + (c & 7)] = mx;
+    }
+}
+void launch_maxpool_fwd_route16(const unsigned short* xb, long long xb_ps, unsigned char* r, int N, int H, int W, int C, hipStream_t s, unsigned short* yb16, int pad, long long yb16_ps)
+{
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_route16_kernel, dim3(cap_blocks(total, 256)), dim3(256), 0, s, xb, xb_ps / 4, (unsigned*)r, N, H, W, C / 4, yb16, pad, yb16_ps / 4);
 }
 void launch_maxpool_route(const float* x, unsigned char* r, int N, int H, int W, int C, hipStream_t s)
 {

@@ -160,7 +160,9 @@ void launch_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, hi
 void launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C,
                         int relu_mask, hipStream_t s);
 void launch_maxpool_route(const float* x, unsigned char* route, int N, int H, int W, int C, hipStream_t s);
-void launch_maxpool_fwd_route(const float* x, float* y, unsigned char* r, int N, int H, int W, int C, hipStream_t s, unsigned short* yb16 = nullptr, int pad = 0, long long yb16_ps = 0);   // forward pool + those bytes in one pass
+void launch_maxpool_fwd_route(const float* x, float* y, unsigned char* r, int N, int H, int W, int C, hipStream_t s, unsigned short* yb16 = nullptr, int pad = 0, long long yb16_ps = 0, int round16 = 0);
+// ... the same over the block's last activation kept only as its bf16 copy (channel-chunk planes of the zero-bordered map, plane stride xb_ps); yb16 likewise
+void launch_maxpool_fwd_route16(const unsigned short* xb, long long xb_ps, unsigned char* r, int N, int H, int W, int C, hipStream_t s, unsigned short* yb16, int pad, long long yb16_ps);   // forward pool + those bytes in one pass
 // Where the logits of pixel slot p live.  blocked == 0: slot = pixel, NHWC.  blocked != 0: the layout the last transposed conv
 // (k = 2s, stride s, pad s/2) produces when it runs as ONE GEMM (model.hip: tconv_gemm_*): rows = (n, q, qx) over an (H/s + 1) x (W/s + 1)
 // grid of s x s output blocks that start at pixel (s q - s/2, s qx - s/2), columns = (r, rx, class); slots of the half blocks that

@@ -1358,6 +1358,12 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 // the next convolution of the block reads this output as ITS padded bf16 input: this kernel's epilogue writes that copy
                 unsigned short* yb = nullptr; char nx[32] = "";
                 if (train && (m->bf16_fuse_convert || m->bf16_acts) && i < kConvsPerBlock[b]) { snprintf(nx, sizeof nx, "conv%d_%d", b + 1, i + 1); yb = xg16_for(m, nx, N, h, w, m->widths[b], 3, s); }
+                // the block's LAST convolution is read by its pool only, and pool1 / pool2 / pool5 only by bf16 convolutions: the pool then takes this output
+                // as a bf16 copy of the kernel's own geometry ("pool<b>in"), picks its maxima among the bf16 values (what bf16(max of the fp32 values) is anyway)
+                // and no fp32 tensor is written (pool3 / pool4 also feed the fp32 skip heads: their blocks keep the fp32 tensor)
+                const bool pool16 = train && m->bf16_acts && m->bf16_fuse_pool && i == kConvsPerBlock[b] && b != 2 && b != 3 && cin % 64 == 0 && m->widths[b] % 64 == 0 &&
+                                    m->widths[b == 4 ? 5 : b + 1] % 64 == 0;
+                if (pool16) { snprintf(nx, sizeof nx, "pool%din", b + 1); yb = xg16_for(m, nx, N, h, w, m->widths[b], 3, s); }
                 // ... and if that is the output's only reader (option bf16_acts; the mask of the consumer's data gradient is the sign of the copy), the fp32
                 // tensor is not written at all.  (Both layers' gradients must fit the bf16 kernels: a fallback would look for the fp32 tensor.)
                 const bool only16 = yb && m->bf16_acts && cin % 64 == 0 && m->widths[b] % 64 == 0;
@@ -1370,7 +1376,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                                        N, h, w, cin, m->widths[b], 3, 0, 1.f, 0, s, /*allow_small=*/false, xb, /*any_shape=*/true, yb, 1, g16_ps(N, h, w, 3), g16_ps(N, h, w, 3));
                 if (!done) return fail(m, FCN8S_ERR_SHAPE, std::string("bf16_train: ") + nm + " does not fit the bf16 convolution kernel");
                 if (done && yb) m->xg16_filled.insert(nx);
-                if (done && only16) { m->y_unwritten.insert(nm); m->in_bf16_only.insert(nx); }
+                if (done && only16) { m->y_unwritten.insert(nm); if (!pool16) m->in_bf16_only.insert(nx); }
             }
             if (!done && bf16_fwd_mode(m) && b >= 2) {
                 // FCN8S_PREC_BF16_FWD: conv3_1 .. conv5_3 as direct convolutions with bf16-rounded operands on the 256 x 256 bf16 kernel (the
@@ -1411,8 +1417,13 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 yb = xg16_for(m, cons, N, h / 2, w / 2, cin, ck, s);
             const bool only16 = yb && b != 2 && b != 3;
             char ix[16]; snprintf(ix, sizeof ix, "pidx%d", b + 1);
-            ProfScope ps(m, "maxpool_fwd", 0, 4.0 * N * h * w * cin * (only16 ? 1.0625 : 1.3125) + (yb ? 0.5 * N * h * w * cin : 0.0));
-            launch_maxpool_fwd_route(x, only16 ? nullptr : A(m, pn), (unsigned char*)A(m, ix), N, h, w, cin, s, yb, (ck - 1) / 2, g16_ps(N, h / 2, w / 2, ck));
+            char pin[32]; snprintf(pin, sizeof pin, "pool%din", b + 1);
+            auto pi = m->xg16.find(pin);
+            const bool in16 = only16 && pi != m->xg16.end() && pi->second && m->xg16_filled.count(pin);      // the last conv wrote only its bf16 copy
+            ProfScope ps(m, "maxpool_fwd", 0, (in16 ? 2.0 : 4.0) * N * h * w * cin + 4.0 * N * h * w * cin * (only16 ? 0.0625 : 0.3125) + (yb ? 0.5 * N * h * w * cin : 0.0));
+            if (in16) launch_maxpool_fwd_route16(pi->second + g16_off(bf16_guard_rows(3, w + 2), cin), g16_ps(N, h, w, 3), (unsigned char*)A(m, ix), N, h, w, cin, s, yb, (ck - 1) / 2, g16_ps(N, h / 2, w / 2, ck));
+            else launch_maxpool_fwd_route(x, only16 ? nullptr : A(m, pn), (unsigned char*)A(m, ix), N, h, w, cin, s, yb, (ck - 1) / 2, g16_ps(N, h / 2, w / 2, ck),
+                                          /*round16=*/(b != 2 && b != 3) ? 1 : 0);
             m->pool_routed[b] = true; pooled = true;
             if (yb) m->xg16_filled.insert(cons);
             if (only16) { m->y_unwritten.insert(pn); m->in_bf16_only.insert(cons); }
@@ -2727,7 +2738,7 @@ int fcn8s_get_pool_routing(fcn8s_model* m, int block, unsigned char* host, size_
     if (n != want) return fail(m, FCN8S_ERR_SHAPE, "pool routing of block " + std::to_string(block) + " has " + std::to_string(want) + " bytes");
     char ix[16]; snprintf(ix, sizeof ix, "pidx%d", block);
     unsigned char* d = (unsigned char*)A(m, ix);
-    if (!pool_backward_fused(m, block, m->pool_fused[block - 1])) {
+    if (!pool_backward_fused(m, block, m->pool_fused[block - 1]) && !m->pool_routed[block - 1]) {      // (pool_routed: the forward pool of bf16_train kept the bytes)
         // the backward pass routes through maxpool_bwd_kernel on the block's last conv output (materialised in this case): same rule
         char last[32]; snprintf(last, sizeof last, "conv%d_%d", block, kConvsPerBlock[block - 1]);
         launch_maxpool_route(A(m, last), d, m->N, h, w, cw, m->stream);

@@ -697,9 +697,9 @@ def test_bf16_train_without_fp32_inner_activations():
         loss = e.forward_backward(img, lab, keep_prob=0.5, l2_rate=1e-3)
         groups = {k: int(v["launches"]) for k, v in e.profile_results().items() if ":" not in k}
         e.profile(0)
-        out[acts] = (loss, e.activation("logits", (n, h, w, 20)), e.activation("conv1_2", (n, h, w, 64)), e.activation("pool3", (n, h // 8, w // 8, 128)), e.get_grads(), groups)
+        out[acts] = (loss, e.activation("logits", (n, h, w, 20)), e.activation("conv3_3", (n, h // 4, w // 4, 128)), e.activation("pool3", (n, h // 8, w // 8, 128)), e.get_grads(), groups)
         for name, shape in (("conv1_1", (n, h, w, 64)), ("conv3_2", (n, h // 4, w // 4, 128)), ("conv5_1", (n, h // 16, w // 16, 256)), ("pool1", (n, h // 2, w // 2, 64)),
-                            ("pool5", (n, h // 32, w // 32, 256))):
+                            ("pool5", (n, h // 32, w // 32, 256)), ("conv1_2", (n, h, w, 64)), ("conv5_3", (n, h // 16, w // 16, 256))):
             if acts:
                 with pytest.raises(Fcn8sError, match="bf16_acts"):
                     e.activation(name, shape)
