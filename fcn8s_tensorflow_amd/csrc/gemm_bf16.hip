@@ -936,8 +936,34 @@ __global__ __launch_bounds__(256) void w_to_bf16_flip_t_kernel(const float4* __r
         else wt[i] = o;
     }
 }
+// The same through an LDS tile (planes layout, Cin % 32 == 0, Cout % 64 == 0): a block = one tap, 32 input channels, 64 output channels (two k-chunks); it reads
+// 32 rows of 256 bytes and writes, per k-chunk, the 32 rows ci of that plane -- 2 KB of contiguous memory -- where the kernel above scatters 64-byte pieces
+// Cin * 64 bytes apart.
+__global__ __launch_bounds__(256) void w_to_bf16_flip_t_tiled_kernel(const float4* __restrict__ w, bf16x8* __restrict__ wt, int KK, int Cin, int Cout)
+{
+    __shared__ float tile[32][68];
+    const int tp = blockIdx.z, ci0 = blockIdx.y * 32, co0 = blockIdx.x * 64, tid = threadIdx.x;
+    const long long src = ((long long)(KK - 1 - tp) * Cin + ci0) * Cout + co0;        // w[(KK - 1 - tp)][ci0 ..][co0 ..]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int f = tid + 256 * j, r = f >> 4, c4 = f & 15;
+        const float4 v = w[(src + (long long)r * Cout) / 4 + c4];
+        tile[r][c4 * 4] = v.x; tile[r][c4 * 4 + 1] = v.y; tile[r][c4 * 4 + 2] = v.z; tile[r][c4 * 4 + 3] = v.w;
+    }
+    __syncthreads();
+    const int kc = tid >> 7, ci = (tid >> 2) & 31, oct = tid & 3;
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (__bf16)tile[ci][kc * 32 + oct * 8 + i];
+    const long long k = (long long)tp * Cout + co0 + kc * 32;                          // first k of this chunk
+    wt[((k >> 5) * Cin + ci0 + ci) * 4 + oct] = o;
+}
 void launch_w_to_bf16_flip_t(const float* w, unsigned short* wt, int K, int Cin, int Cout, hipStream_t s)      // Cout % 8 == 0
 {
+    if (W_PLANES && Cin % 32 == 0 && Cout % 64 == 0 && (long long)K * K <= 65535 && Cin / 32 <= 65535) {
+        hipLaunchKernelGGL(w_to_bf16_flip_t_tiled_kernel, dim3((unsigned)(Cout / 64), (unsigned)(Cin / 32), (unsigned)(K * K)), dim3(256), 0, s, (const float4*)w, (bf16x8*)wt, K * K, Cin, Cout);
+        return;
+    }
     const long long total = (long long)Cin * K * K * (Cout / 8);
     long long b = (total + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1;
     hipLaunchKernelGGL(w_to_bf16_flip_t_kernel, dim3((unsigned)b), dim3(256), 0, s, (const float4*)w, (bf16x8*)wt, K * K, Cin, Cout / 8);
