@@ -277,7 +277,8 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *                              sum; split-K GEMMs are simply not split) stores one partial result per split into a scratch slab, and a second kernel adds
  *                              the slabs in split order: two runs of the same steps on the same inputs give the same bits.  +2.4 % at 16 x 1024x512
  *     "bf16_acts"         1    FCN8S_PREC_BF16_TRAIN, training passes: a tensor between two bf16 convolutions exists only as the consumer's padded bf16 copy -- written by the
- *                              producer's epilogue (conv -> conv activations, conv1_1 included; the pooled maps pool1 / pool2 / pool5; the output gradient of a conv that
+ *                              producer's epilogue (conv -> conv activations, conv1_1 included; the last convolutions of blocks 1, 2, 5, which their pools read as
+ *                              bf16 copies -- maxima and gradient routing among the bf16 values; the pooled maps pool1 / pool2 / pool5; the output gradient of a conv that
  *                              follows a bf16 conv, together with that layer's bias gradient).  fcn8s_get_activation of such a layer then returns FCN8S_ERR_STATE naming
  *                              this option; 0 keeps every fp32 tensor too (same values into every product: bit-identical losses and weight gradients)
  *     "bf16_fuse_convert" 0    FCN8S_PREC_BF16_TRAIN: the producing convolution's epilogue also writes its consumer's padded bf16 copy (measured slower)
