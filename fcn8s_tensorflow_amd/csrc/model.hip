@@ -1445,7 +1445,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
         unsigned short* xb6 = train ? xg16_for(m, "fc6", N, h5, w5, m->widths[4], m->fc6k, s) : nullptr;
         if (xb6 && !m->xg16_filled.count("fc6")) { ProfScope ps(m, "bf16_convert", 0, 6.0 * N * h5 * w5 * m->widths[4]); launch_f32_to_bf16_padded(x, xb6, N, h5, w5, m->widths[4], (m->fc6k - 1) / 2, s, g16_ps(N, h5, w5, m->fc6k)); }
         unsigned short* xb7 = train ? xg16_for(m, "fc7", N, h5, w5, m->widths[5], 1, s) : nullptr;
-        const bool fuse7 = false;          // (fc6 runs on the tile kernel, whose bf16 side output is 2-byte stores: its 134 MB are converted by a pass of their own)
+        const bool fuse7 = xb7 != nullptr && m->bf16_acts;      // fc7's input copy comes out of fc6's epilogue (16-byte stores since the tile kernel's epilogue goes through LDS)
         if (!bf16_conv_layer(m, "fc6_fwd_bf16", "fc6/weights", "fc6/biases", x, A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, drop, keep_prob, m->drop_stream, s, false, xb6, true,
                              fuse7 ? xb7 : nullptr, 0, g16_ps(N, h5, w5, m->fc6k), g16_ps(N, h5, w5, 1)))
             return fail(m, FCN8S_ERR_SHAPE, "bf16_train: fc6 does not fit the bf16 convolution kernel");

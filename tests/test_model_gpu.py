@@ -723,8 +723,9 @@ def test_bf16_train_without_fp32_inner_activations():
         else:
             np.testing.assert_array_equal(out[1][4][k], out[0][4][k], err_msg=k)
     # the conversion passes that went away: 8 forward copies (13 convs - 5 block heads; conv1_2's comes from conv1_1's kernel), those 7 gradients, and the
-    # 5 copies of the pooled maps (conv2_1 .. conv5_1, fc6), which the pools write themselves (pool1, pool2 and pool5 as nothing else)
-    assert out[0][5]["bf16_convert"] - out[1][5]["bf16_convert"] == 8 + 7 + 5, (out[0][5], out[1][5])
+    # 5 copies of the pooled maps (conv2_1 .. conv5_1, fc6), which the pools write themselves (pool1, pool2 and pool5 as nothing else), and fc7's input copy,
+    # which comes out of fc6's epilogue
+    assert out[0][5]["bf16_convert"] - out[1][5]["bf16_convert"] == 8 + 7 + 5 + 1, (out[0][5], out[1][5])
 
 
 @pytest.mark.parametrize("mode", ["bf16_fwd", "bf16_fwd_x2"])
