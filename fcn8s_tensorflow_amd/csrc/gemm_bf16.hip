@@ -993,11 +993,13 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 4) void wgrad_bf16_kernel(cons
     constexpr int S = 4, ROWB = BM * 2, PLANE = 16 * ROWB, STAGE = 4 * PLANE;        // planes: A rows 0-15, A rows 16-31, B rows 0-15, B rows 16-31
     constexpr int NI = PLANE / 1024, RPI = 1024 / ROWB;                                // LDS-DMA instructions per plane, rows per instruction
     constexpr int T = BM / 64;                                                         // 32 x 32 tiles per wave and operand
-    // 16-byte chunk c of row r sits at chunk c ^ SWZ (r & 3), SWZ = 2.  With 256-byte rows (BM = 128) every row starts at bank 0 and the four rows of a
-    // transposing read's 32-lane group share 32 of the 64 banks two by two (SQ_LDS_BANK_CONFLICT = half of this kernel's LDS cycles); SWZ = 4 puts them in
-    // four different quarters and the counter at zero -- and fc6's weight gradient from 1.71 to 2.3-2.4 ms in the step (A/B/A on one box,
-    // profiles/r05_bf16_conv_tile_ab.txt; 1.96 -> 1.86 ms when rocprofv3 serialises the launches).  Measured, not understood: 2 stays.
-    constexpr int SWZ = 2;
+    // 16-byte chunk c of row r sits at chunk c ^ SWZ (r & 3).  A transposing read's 32-lane group takes 64 contiguous bytes of each of four rows: with 128-byte
+    // rows (BM = 64) a row's parity picks the bank half and SWZ = 2 the quarter; with 256-byte rows (BM = 128) every row starts at bank 0 and the four rows need
+    // the four 64-byte quarters: SWZ = 4 (with 2, rows r and r + 1 share 16 banks: SQ_LDS_BANK_CONFLICT = half of the kernel's LDS cycles).  History: with the
+    // copies stored [rows][C] the conflict-free swizzle made fc6's weight gradient 35 % SLOWER in the step (1.71 -> 2.3-2.4 ms, A/B/A on one box) and was
+    // reverted; with the copies stored as channel-chunk planes it is 6.5 % faster (1.81 1.84 -> 1.69 1.72 ms, same-box A/B): what had hurt was the global side of
+    // the permuted LDS-DMA rows, not the LDS reads (profiles/r05_bf16_conv_tile_ab.txt).
+    constexpr int SWZ = BM == 128 ? 4 : 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[S * STAGE];
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
