@@ -77,13 +77,15 @@ struct fcn8s_model {
     // the library's own RCCL communicator (fcn8s_comm_*): one rank per model, collectives on a stream of its own behind the bucket events
     ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1;
     hipStream_t comm_stream = nullptr;
-    hipEvent_t comm_done[FCN8S_MAX_BUCKETS] = {nullptr}; bool comm_pending[FCN8S_MAX_BUCKETS] = {false};
+    // slot b < FCN8S_MAX_BUCKETS: the all-reduce of gradient bucket b; slot FCN8S_MAX_BUCKETS: the parameter broadcast / the metrics all-reduce
+    static constexpr int kCommSlots = FCN8S_MAX_BUCKETS + 1, kCommMisc = FCN8S_MAX_BUCKETS;
+    hipEvent_t comm_done[kCommSlots] = {nullptr}; bool comm_pending[FCN8S_MAX_BUCKETS] = {false};
     // ... and its watchdog (world > 1): a thread that polls ncclCommGetAsyncError and the age of every all-reduce still in flight; on an
     // asynchronous error or after comm_timeout_ms it calls ncclCommAbort (RCCL's kernels then leave the streams they block) and records
     // why -- every later fcn8s_comm_* / fcn8s_apply_update call returns FCN8S_ERR_RCCL with that text instead of waiting for a dead peer
     std::mutex comm_mu;                                                   // guards comm (enqueue vs. abort), comm_enq_ns, comm_error
     std::thread comm_watch; std::atomic<bool> comm_watch_stop{false}, comm_failed{false};
-    std::atomic<bool> comm_inflight[FCN8S_MAX_BUCKETS] = {}; int64_t comm_enq_ns[FCN8S_MAX_BUCKETS] = {0};
+    std::atomic<bool> comm_inflight[kCommSlots] = {}; int64_t comm_enq_ns[kCommSlots] = {0};
     std::string comm_error; int64_t comm_timeout_ms = 600000;
     float *d_params = nullptr, *d_grads = nullptr, *d_m = nullptr, *d_v = nullptr, *d_wt = nullptr;
     bool own_params = false, own_grads = false;
@@ -1892,6 +1894,10 @@ int fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out)
 int fcn8s_destroy(fcn8s_model* m)
 {
     if (!m) return FCN8S_OK;
+    // the communicator first: its stream is drained by polling (a dead peer ends in an abort after comm_timeout_ms), and only then is the device
+    // synchronised -- the other way round a collective that waits for a peer that is gone would hold hipDeviceSynchronize until the watchdog fires
+    const int rc_comm = fcn8s_comm_destroy(m);
+    const std::string comm_text = rc_comm ? m->err : std::string();
     hipDeviceSynchronize();
     for (auto& g : m->groups) for (auto& ev : g.ev) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     if (m->own_params && m->d_params) hipFree(m->d_params);
@@ -1905,7 +1911,6 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->tail_done) hipEventDestroy(m->tail_done);
     if (m->side_done) hipEventDestroy(m->side_done);
     for (auto e : m->ev_pool) hipEventDestroy(e);
-    fcn8s_comm_destroy(m);
     for (auto& e : m->bucket_ev) if (e) { hipEventDestroy(e); e = nullptr; }
     for (auto& kv : m->u_train) if (kv.second) hipFree(kv.second);
     if (m->d_wino_u) hipFree(m->d_wino_u);
@@ -1939,6 +1944,8 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->copy_stream) hipStreamDestroy(m->copy_stream);
     if (m->arena) hipFree(m->arena);
     delete m;
+    // the model is gone either way; a communicator that had failed is reported once, with its reason in fcn8s_last_error(NULL)
+    if (rc_comm) { g_last_error = comm_text; return rc_comm; }
     return FCN8S_OK;
 }
 
@@ -2228,8 +2235,11 @@ RcclApi* rccl()
 {
     static RcclApi api; static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { api.h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (api.h) break; }
-        if (!api.h) { const char* e = dlerror(); api.err = std::string("dlopen(librccl.so.1): ") + (e ? e : "not found"); return; }
+        // FCN8S_RCCL_LIBRARY: the RCCL build to use, by path (a site's own build; the shared-memory stand-in of tests/fake_rccl) -- no fallback if it is set
+        const char* forced = getenv("FCN8S_RCCL_LIBRARY");
+        if (forced && *forced) api.h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        else for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { api.h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (api.h) break; }
+        if (!api.h) { const char* e = dlerror(); api.err = std::string("dlopen(") + (forced && *forced ? forced : "librccl.so.1") + "): " + (e ? e : "not found"); return; }
         auto sym = [&](const char* n) { void* p = dlsym(api.h, n); if (!p && api.err.empty()) api.err = std::string("librccl has no symbol ") + n; return p; };
         api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
         api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
@@ -2265,7 +2275,17 @@ void comm_abort_locked(fcn8s_model* m, const std::string& why)
         if (a->CommAbort) a->CommAbort(m->comm);          // (frees the communicator like ncclCommDestroy, without waiting for its peers)
         m->comm = nullptr;
     }
-    for (int b = 0; b < FCN8S_MAX_BUCKETS; ++b) m->comm_inflight[b].store(false);
+    for (int b = 0; b < fcn8s_model::kCommSlots; ++b) m->comm_inflight[b].store(false);
+    for (int b = 0; b < FCN8S_MAX_BUCKETS; ++b) m->comm_pending[b] = false;      // (the model's stream must not wait for events of a communicator that is gone)
+}
+
+// a collective has just been enqueued on `s` (caller holds comm_mu): the watchdog measures its age from now and learns of its completion from the event
+int comm_track_locked(fcn8s_model* m, int slot, hipStream_t s)
+{
+    if (!m->comm_done[slot]) HIPCHK(m, hipEventCreateWithFlags(&m->comm_done[slot], hipEventDisableTiming));
+    HIPCHK(m, hipEventRecord(m->comm_done[slot], s));
+    m->comm_enq_ns[slot] = now_ns(); m->comm_inflight[slot].store(true);
+    return FCN8S_OK;
 }
 
 void comm_watchdog(fcn8s_model* m)
@@ -2282,12 +2302,13 @@ void comm_watchdog(fcn8s_model* m)
             continue;
         }
         const int64_t t = now_ns();
-        for (int b = 0; b < FCN8S_MAX_BUCKETS; ++b) {
+        for (int b = 0; b < fcn8s_model::kCommSlots; ++b) {
             if (!m->comm_inflight[b].load() || !m->comm_done[b]) continue;
             if (hipEventQuery(m->comm_done[b]) == hipSuccess) { m->comm_inflight[b].store(false); continue; }
             (void)hipGetLastError();                      // (hipErrorNotReady is not an error)
             if ((t - m->comm_enq_ns[b]) / 1000000 > m->comm_timeout_ms) {
-                comm_abort_locked(m, "all-reduce of gradient bucket " + std::to_string(b) + " did not complete within " + std::to_string(m->comm_timeout_ms) +
+                comm_abort_locked(m, (b == fcn8s_model::kCommMisc ? std::string("the parameter broadcast / metrics all-reduce") : "all-reduce of gradient bucket " + std::to_string(b)) +
+                                     " did not complete within " + std::to_string(m->comm_timeout_ms) +
                                      " ms (option comm_timeout_ms): a peer rank is dead or hung; communicator aborted");
                 break;
             }
@@ -2331,10 +2352,15 @@ int fcn8s_comm_init(fcn8s_model* m, const void* unique_id, size_t nbytes, int ra
     HIPCHK(m, hipSetDevice(m->device));
     ncclUniqueId id; memcpy(&id, unique_id, sizeof id);
     if (m->comm_watch.joinable()) { m->comm_watch_stop.store(true); m->comm_watch.join(); }       // (left over from a communicator that failed)
+    // the enum values this file declares for itself (ncclFloat = 7, ncclDouble = 8, ncclSum = 0, the result codes) are those of NCCL / RCCL 2.x
+    { int v = 0; RCCLCHK(m, a->GetVersion(&v));
+      const int major = v >= 10000 ? v / 10000 : v / 1000;       // (NCCL_VERSION_CODE: major * 10000 + minor * 100 + patch since 2.9, major * 1000 + ... before)
+      if (major != 2) return fail(m, FCN8S_ERR_RCCL, "fcn8s_comm_init: librccl reports version code " + std::to_string(v) + "; this library speaks the RCCL 2.x ABI only"); }
     RCCLCHK(m, a->CommInitRank(&m->comm, world, id, rank));
     m->comm_rank = rank; m->comm_world = world;
     m->comm_failed.store(false); m->comm_error.clear();
-    for (int b = 0; b < FCN8S_MAX_BUCKETS; ++b) m->comm_inflight[b].store(false);
+    for (int b = 0; b < fcn8s_model::kCommSlots; ++b) m->comm_inflight[b].store(false);
+    for (int b = 0; b < FCN8S_MAX_BUCKETS; ++b) m->comm_pending[b] = false;
     if (!m->comm_stream) HIPCHK(m, hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking));
     if (world > 1) { m->comm_watch_stop.store(false); m->comm_watch = std::thread(comm_watchdog, m); }      // (a one-rank communicator has no peer to lose)
     return FCN8S_OK;
@@ -2367,7 +2393,8 @@ int fcn8s_comm_destroy(fcn8s_model* m)
     }
     if (m->comm_watch.joinable()) { m->comm_watch_stop.store(true); m->comm_watch.join(); }
     if (m->comm_failed.load()) { rc = fail(m, FCN8S_ERR_RCCL, "fcn8s_comm_destroy: " + m->comm_error); m->comm_failed.store(false); }
-    for (int b = 0; b < FCN8S_MAX_BUCKETS; ++b) { if (m->comm_done[b]) { hipEventDestroy(m->comm_done[b]); m->comm_done[b] = nullptr; } m->comm_pending[b] = false; m->comm_inflight[b].store(false); }
+    for (int b = 0; b < fcn8s_model::kCommSlots; ++b) { if (m->comm_done[b]) { hipEventDestroy(m->comm_done[b]); m->comm_done[b] = nullptr; } m->comm_inflight[b].store(false); }
+    for (int b = 0; b < FCN8S_MAX_BUCKETS; ++b) m->comm_pending[b] = false;
     if (m->comm_stream) { hipStreamDestroy(m->comm_stream); m->comm_stream = nullptr; }
     m->comm_rank = 0; m->comm_world = 1;
     return rc;
@@ -2393,11 +2420,9 @@ int fcn8s_allreduce_bucket(fcn8s_model* m, int bucket)
     float* g = m->d_grads + m->bucket_off[bucket];
     std::lock_guard<std::mutex> lk(m->comm_mu);          // (the watchdog may abort the communicator: not in the middle of an enqueue)
     if (!m->comm) return fail(m, FCN8S_ERR_RCCL, "fcn8s_allreduce_bucket: " + m->comm_error);
-    if (!m->comm_done[bucket]) HIPCHK(m, hipEventCreateWithFlags(&m->comm_done[bucket], hipEventDisableTiming));
     RCCLCHK(m, rccl()->AllReduce(g, g, m->bucket_n[bucket], ncclFloat, ncclSum, m->comm, m->comm_stream));
-    HIPCHK(m, hipEventRecord(m->comm_done[bucket], m->comm_stream));
+    { int rc = comm_track_locked(m, bucket, m->comm_stream); if (rc) return rc; }
     m->comm_pending[bucket] = true;
-    m->comm_enq_ns[bucket] = now_ns(); m->comm_inflight[bucket].store(true);
     return FCN8S_OK;
 }
 
@@ -2410,6 +2435,23 @@ int fcn8s_comm_wait(fcn8s_model* m)
     return FCN8S_OK;
 }
 
+namespace {
+// The HOST waits until every pending all-reduce has completed -- polling, so that the watchdog's abort ends the wait -- and reports a failed communicator.
+// fcn8s_apply_update calls it when the communicator has more than one rank: an update must never be applied to gradients whose exchange was aborted (the
+// stream-ordered fcn8s_comm_wait alone would let the update kernel run behind an aborted all-reduce and report the failure one call too late).  What it
+// costs is the host's run-ahead over the update kernel: a few microseconds of launch latency per step.
+int comm_wait_host(fcn8s_model* m, const char* where)
+{
+    for (int b = 0; b < kNumBuckets; ++b) {
+        if (!m->comm_pending[b]) continue;
+        while (!m->comm_failed.load() && m->comm_done[b] && hipEventQuery(m->comm_done[b]) == hipErrorNotReady) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        (void)hipGetLastError();
+    }
+    if (m->comm_failed.load()) return comm_failed_rc(m, where);
+    return FCN8S_OK;
+}
+}  // namespace
+
 int fcn8s_comm_broadcast_params(fcn8s_model* m, int root)
 {
     if (!m || root < 0) return FCN8S_ERR_BAD_ARG;
@@ -2417,8 +2459,10 @@ int fcn8s_comm_broadcast_params(fcn8s_model* m, int root)
     if (!m->comm) return fail(m, FCN8S_ERR_STATE, "fcn8s_comm_broadcast_params: no communicator (fcn8s_comm_init first)");
     if (root >= m->comm_world) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_comm_broadcast_params: root outside the communicator");
     if (m->frozen) fcn8s_freeze_params(m, 0);
+    std::lock_guard<std::mutex> lk(m->comm_mu);          // (the watchdog may abort the communicator: not in the middle of an enqueue)
+    if (!m->comm) return fail(m, FCN8S_ERR_RCCL, "fcn8s_comm_broadcast_params: " + m->comm_error);
     RCCLCHK(m, rccl()->Broadcast(m->d_params, m->d_params, m->total, ncclFloat, root, m->comm, m->stream));
-    return FCN8S_OK;
+    return comm_track_locked(m, fcn8s_model::kCommMisc, m->stream);      // stream-ordered like every parameter write; a root that never sends trips the watchdog
 }
 
 int fcn8s_comm_allreduce_metrics(fcn8s_model* m)
@@ -2436,11 +2480,26 @@ int fcn8s_comm_allreduce_metrics(fcn8s_model* m)
     double* d = nullptr;
     HIPCHK(m, hipMalloc((void**)&d, n * sizeof(double)));
     hipMemcpyAsync(d, h.data(), n * sizeof(double), hipMemcpyHostToDevice, m->stream);
-    ncclResult_t r = rccl()->AllReduce(d, d, n, ncclDouble, ncclSum, m->comm, m->stream);
-    hipMemcpyAsync(h.data(), d, n * sizeof(double), hipMemcpyDeviceToHost, m->stream);
-    hipStreamSynchronize(m->stream);
+    ncclResult_t r = ncclSuccess; int rct = FCN8S_OK; bool gone = false;
+    {
+        std::lock_guard<std::mutex> lk(m->comm_mu);      // (the watchdog may abort the communicator: not in the middle of an enqueue)
+        if (!m->comm) gone = true;
+        else {
+            r = rccl()->AllReduce(d, d, n, ncclDouble, ncclSum, m->comm, m->stream);
+            if (r == ncclSuccess) rct = comm_track_locked(m, fcn8s_model::kCommMisc, m->stream);
+        }
+    }
+    // the host needs the sums: wait for them by polling, so that a peer that never arrives ends in the watchdog's abort (which releases the stream), not in a hang
+    if (!gone && r == ncclSuccess && rct == FCN8S_OK) {
+        while (hipEventQuery(m->comm_done[fcn8s_model::kCommMisc]) == hipErrorNotReady && !m->comm_failed.load()) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        (void)hipGetLastError();
+    }
+    if (!gone && r == ncclSuccess && rct == FCN8S_OK && !m->comm_failed.load()) hipMemcpyAsync(h.data(), d, n * sizeof(double), hipMemcpyDeviceToHost, m->stream);
+    hipStreamSynchronize(m->stream);                     // (behind a completed or aborted collective: returns)
     hipFree(d);
+    if (gone || m->comm_failed.load()) return comm_failed_rc(m, "fcn8s_comm_allreduce_metrics");
     if (r != ncclSuccess) return rccl_fail(m, "ncclAllReduce(metrics)", r);
+    if (rct) return rct;
     for (size_t i = 0; i < cc; ++i) conf[i] = (int64_t)llround(h[i]);
     return fcn8s_metrics_set_raw(m, conf.data(), h[cc], (int64_t)llround(h[cc + 1]));
 }
@@ -2449,6 +2508,7 @@ int fcn8s_apply_update(fcn8s_model* m, int optimizer, float lr, float grad_scale
 {
     if (m && m->frozen) fcn8s_freeze_params(m, 0);      // parameters are about to change (or a training pass starts): leave the frozen state
     if (!m) return FCN8S_ERR_BAD_ARG;
+    if (m->comm_world > 1 && (m->comm || m->comm_failed.load())) { int rch = comm_wait_host(m, "fcn8s_apply_update"); if (rch) return rch; }
     { int rcw = fcn8s_comm_wait(m); if (rcw) return rcw; }      // gradient buckets still being all-reduced by the library's own communicator
     const int64_t t = m->step + 1;
     if (optimizer == FCN8S_OPT_TF_ADAM) {

@@ -98,7 +98,7 @@ int         fcn8s_layout_bucket(const fcn8s_config* cfg, int bucket, size_t* off
 
 /* ---- lifetime: FCN8s.__init__ :19-125 / close :946-952 ------------------- */
 int         fcn8s_create(const fcn8s_config* cfg, fcn8s_model** out);
-int         fcn8s_destroy(fcn8s_model* m);
+int         fcn8s_destroy(fcn8s_model* m);                           /* frees everything; FCN8S_ERR_RCCL (text: fcn8s_last_error(NULL)) if the model's communicator had failed */
 const char* fcn8s_last_error(const fcn8s_model* m);                  /* m may be NULL: last create() error */
 int         fcn8s_set_stream(fcn8s_model* m, void* hip_stream);      /* run on the caller's stream (e.g. torch's current stream) */
 int         fcn8s_synchronize(fcn8s_model* m);
@@ -166,14 +166,20 @@ int fcn8s_read_loss(fcn8s_model* m, float* loss_out);                /* synchron
  * stream wait for all of them (fcn8s_apply_update does it implicitly, and so do fcn8s_get_grad and the next fcn8s_backward_bucket(m, 0);
  * a caller that reads fcn8s_grad_buffer() itself calls fcn8s_comm_wait first).  fcn8s_train_step on a model whose communicator has more
  * than one rank runs exactly this sequence (it never trains diverging replicas silently).  librccl is opened with dlopen at the first
- * fcn8s_comm_* call (no RCCL headers are needed to build the library): a failure there, or at the enqueue of any collective, is
- * FCN8S_ERR_RCCL with RCCL's text in fcn8s_last_error.  Failures AFTER the enqueue -- a peer that dies or hangs -- are caught by a
- * watchdog thread every communicator of more than one rank owns: it polls ncclCommGetAsyncError and the age of each all-reduce in flight,
- * and on an asynchronous error, or when a collective has not completed within option "comm_timeout_ms" (default 600 000), calls
- * ncclCommAbort -- RCCL's kernels then leave the streams, so neither the model's stream nor a host synchronisation waits for that peer
- * forever -- and every later fcn8s_allreduce_bucket / fcn8s_comm_wait / fcn8s_apply_update / fcn8s_comm_* call returns FCN8S_ERR_RCCL with
- * the reason.  fcn8s_comm_destroy (also run by fcn8s_destroy) drains the communicator's stream by polling under the same rules, never by
- * an unconditional synchronisation, and returns FCN8S_ERR_RCCL once if the communicator had failed.                                     */
+ * fcn8s_comm_* call (no RCCL headers are needed to build the library; environment variable FCN8S_RCCL_LIBRARY names the file to open
+ * instead of the soname -- a site's own RCCL build, or the shared-memory stand-in of tests/fake_rccl -- and fcn8s_comm_init refuses a
+ * library whose ncclGetVersion is not 2.x, the ABI whose enum values this library declares for itself): a failure there, or at the
+ * enqueue of any collective, is FCN8S_ERR_RCCL with RCCL's text in fcn8s_last_error.  Failures AFTER the enqueue -- a peer that dies or
+ * hangs -- are caught by a watchdog thread every communicator of more than one rank owns: it polls ncclCommGetAsyncError and the age of
+ * EVERY collective in flight (the bucket all-reduces, the parameter broadcast, the metrics all-reduce; each is enqueued under the mutex
+ * the watchdog aborts under), and on an asynchronous error, or when a collective has not completed within option "comm_timeout_ms"
+ * (default 600 000), calls ncclCommAbort -- RCCL's kernels then leave the streams, so neither the model's stream nor a host
+ * synchronisation waits for that peer forever -- and fcn8s_allreduce_bucket / fcn8s_comm_wait / fcn8s_apply_update / fcn8s_comm_* return
+ * FCN8S_ERR_RCCL with the reason.  With more than one rank fcn8s_apply_update waits ON THE HOST (polling) for the pending all-reduces
+ * before it queues the update: gradients whose exchange was aborted are never applied, and the failure is reported by the very call
+ * that would have used them (cost: the host's run-ahead over one kernel launch per step).  fcn8s_comm_allreduce_metrics waits for its
+ * sums the same way.  fcn8s_comm_destroy (also run by fcn8s_destroy, before anything else) drains the communicator's stream by polling
+ * under the same rules, never by an unconditional synchronisation, and returns FCN8S_ERR_RCCL once if the communicator had failed.      */
 /* "dddd:bb:dd.f" of a HIP device (hipDeviceGetPCIBusId): lets a launcher bind each rank's host threads and decode workers to the
  * NUMA node of its GPU through /sys/bus/pci/devices/<id>/local_cpulist (fcn8s_tensorflow_amd/dp.py: bind_to_gpu_numa). */
 int fcn8s_device_pci_bus_id(int device_id, char* out, size_t len);
