@@ -893,7 +893,7 @@ void launch_colsum(const float* x, float* out, long long rows, int C, hipStream_
     float4* partial = nullptr;
     if (gx > 1) {
         ColsumScratch* sc = colsum_scratch(s, (size_t)gx * C);
-        if (!sc) { fprintf(stderr, "fcn8s: column-sum scratch allocation failed\n"); abort(); }
+        if (!sc) { defer_error(FCN8S_ERR_OOM, "the column sums' scratch (%zu floats) cannot be allocated", (size_t)gx * C); return; }
         partial = (float4*)sc->partial;
     }
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, ctiles), dim3(256), 0, s, (const float4*)x, out, rows, C4, tpr, rpb, partial);

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/fcn8s_hip.h"      // the status codes (defer_error)
 
 // gfx950 (MI355X, CDNA4) only: the kernels rely on 160 KB of LDS per workgroup (conv_bf16_256_kernel: five 32 KB stages; wino_out_in_kernel: 96 KB
 // static), on global_load_lds_dwordx4, ds_read_b64_tr_b16 and the gfx950 MFMA shapes.  A device pass for any other target stops here with a
@@ -12,10 +13,17 @@
 #endif
 #define FCN8S_LDS_BYTES_NEEDED (160u * 1024u)
 
+#include <string>
 namespace fcn8s {
 
 // symbol of the MFMA kernel the last launch_* call used (for the per-kernel profile view)
 extern thread_local const char* g_last_kernel;
+// A launcher that cannot run -- a shape no kernel of the chosen arithmetic takes, a scratch allocation that failed, a broken internal promise -- records why and
+// returns WITHOUT launching; the C entry point that called it (fcn8s_forward_loss, fcn8s_backward_bucket, fcn8s_predict, ..., every fcn8s_op_*) then returns `code`
+// with the text in fcn8s_last_error instead of the process dying in abort() (in a data-parallel run an aborted rank also cost its peers a full watchdog timeout).
+// The first error wins; the slot belongs to the calling thread.
+void defer_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int take_deferred_error(std::string* text);       // the recorded code (0: none) and its text; clears the slot
 
 // ---------------------------------------------------------------------------
 // Implicit-GEMM convolution on the f32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -89,7 +97,7 @@ struct Bf16Conv256Args {
 bool conv_bf16_256_ok(long long M, int Cin, int Cout, int mode);      // mode 0 never, 1 when it fills the chip, 2 whenever the shapes allow
 void launch_w_to_bf16_t(const float* w, unsigned short* wt, int K, int Cout, hipStream_t s);
 void launch_f32_to_bf16_padded(const float* x, unsigned short* xp, int N, int H, int W, int C, int pad, hipStream_t s, long long ps = 0);      // ps: plane stride of xp in elements, 0 = [rows][C]
-int conv_bf16_rows_bm(int Cout, int rows_bn);
+int conv_bf16_rows_bm(int Cout, int rows_bn);      // positions per row tile (= per partial row of `colpart`) of the form launch_conv_bf16_256 picks
 bool launch_conv_bf16_256(const Bf16Conv256Args& a, hipStream_t s);
 // the padded bf16 copy of an output gradient (interior only: the border of xp is zero already) with db[c] += column sums of x on the way
 bool launch_f32_to_bf16_padded_colsum(const float* x, unsigned short* xp, float* db, int N, int H, int W, int C, int pad, hipStream_t s, long long ps = 0);

@@ -600,6 +600,135 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
     }
 }
 
+// The epilogue of the flat-position kernels, through LDS, row-major.  NW waves laid out WRN (rows) x WCN (columns), a wave owns TM x 2 accumulator tiles of
+// 32 x 32: 32 TM positions x 64 columns; the block's row tile is tmi (BM = WRN * TM * 32 positions from q0), its columns start at n0.
+// Epilogue through LDS, row-major: the MFMA layout gives a lane one column of 16 scattered rows -- 4-byte stores, 2-byte mask loads, and for the 64-channel
+// layers (six K-tiles per tile) that epilogue WAS the kernel: conv1_2's forward pass took 1.24 ms with its MFMAs and LDS reads switched off and 1.29 with its
+// LDS-DMA switched off, 1.34 complete (profiles/r05_bf16_conv_tile_ab.txt).  Each wave parks one 32 x 32 half of its tile (fp32, raw accumulators) in its own
+// patch of the free stage buffers; then a lane owns (row, 8 consecutive channels): bias, skip-path addend, ReLU, the mask (16 bytes of the layer's bf16
+// input copy, or 32 of the fp32 activation), two 16-byte fp32 stores and / or one 16-byte store into the consumer's bf16 copy, and the column sums.
+// Border positions and positions beyond the last image: nothing stored in y, zeros in the copy.
+template <int TM, int WCN, int WRN>
+static __device__ __forceinline__ void conv_rows_epilogue(const Bf16Conv256Args& p, f32x16 (&acc)[TM][2], unsigned char* smem, int tid, long long q0, int n0, unsigned tmi)
+{
+    constexpr int NW = WCN * WRN, BN = WCN * 64;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WCN, wn = wave % WCN;
+    const int Hp = p.H + 2, Wp = p.W + 2;
+    const long long R = (long long)p.N * Hp * Wp;
+    __syncthreads();                                                       // every wave is done reading the stage buffers
+    constexpr int LDP = 36;
+    float* patch = reinterpret_cast<float*>(smem) + wave * (32 * LDP);
+    const long long HpWp = (long long)Hp * Wp;
+    const int prow0 = lane >> 2, pc8 = (lane & 3) * 8;
+    float csum[2][8];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) csum[tn][k] = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        long long qrow[2], pixv[2]; bool valid[2];
+        {
+            const long long qb = q0 + wr * (TM * 32) + tm * 32 + prow0;
+            int n = (int)(qb / HpWp), rem = (int)(qb - (long long)n * HpWp), yy = rem / Wp, xx = rem - yy * Wp;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                qrow[it] = qb + 16 * it;
+                valid[it] = qrow[it] < R && yy >= 1 && yy <= p.H && xx >= 1 && xx <= p.W;
+                pixv[it] = ((long long)n * p.H + yy - 1) * p.W + xx - 1;
+                xx += 16;
+                while (xx >= Wp) { xx -= Wp; ++yy; }
+                while (yy >= Hp) { yy -= Hp; ++n; }
+            }
+        }
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDP + (lane & 31)] = acc[tm][tn][r];
+            __builtin_amdgcn_wave_barrier();
+            const int col8 = n0 + wn * 64 + tn * 32 + pc8;
+            float bv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bv[k] = p.bias ? p.bias[col8 + k] : 0.f;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const float4 u0 = *reinterpret_cast<const float4*>(&patch[(prow0 + 16 * it) * LDP + pc8]);
+                const float4 u1 = *reinterpret_cast<const float4*>(&patch[(prow0 + 16 * it) * LDP + pc8 + 4]);
+                float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+                if (valid[it]) {
+                    const long long off = pixv[it] * p.Cout + col8;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += bv[k];
+                    if (p.addend) {
+                        const float4 a0 = *reinterpret_cast<const float4*>(p.addend + off), a1 = *reinterpret_cast<const float4*>(p.addend + off + 4);
+                        v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                    }
+                    // (the ReLU mask of a data gradient: the sign of the layer's padded bf16 INPUT copy, which has this kernel's geometry -- row q, half the bytes of
+                    //  the fp32 activation and no pixel arithmetic; bf16 keeps fp32's exponent range, so x > 0 <=> bf16(x) > 0 for every normal x)
+                    if (p.mask16) {
+                        typedef short s16x8 __attribute__((ext_vector_type(8)));
+                        const s16x8 mk = *reinterpret_cast<const s16x8*>(p.mask16 + (p.mask16_ps ? (long long)(col8 >> 5) * p.mask16_ps + qrow[it] * 32 + (col8 & 31) : qrow[it] * p.Cout + col8));
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = mk[k] > 0 ? v[k] * p.mask_scale : 0.f;
+                    } else if (p.mask) {
+                        const float4 m0 = *reinterpret_cast<const float4*>(p.mask + off), m1 = *reinterpret_cast<const float4*>(p.mask + off + 4);
+                        const float mk[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = mk[k] > 0.f ? v[k] * p.mask_scale : 0.f;
+                    }
+                    if (p.dropout) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = philox_uniform((unsigned long long)(off + k), p.seed, p.stream_id) < p.keep_prob ? v[k] / p.keep_prob : 0.f;
+                    }
+                    if (p.y) {
+                        *reinterpret_cast<float4*>(p.y + off) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(p.y + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+                }
+                // p.yb: the consumer is another 3 x 3 layer on the same map, so its padded bf16 copy has THIS geometry and position q of the output is row q of that copy
+                // (rows q >= R of a last partial row tile lie in the zeroed guard rows behind the copy and are written with the zeros they hold)
+                if (p.yb) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = (__bf16)v[k];
+                    *reinterpret_cast<bf16x8*>(p.yb + (p.yb_ps ? (long long)(col8 >> 5) * p.yb_ps + qrow[it] * 32 + (col8 & 31) : qrow[it] * p.Cout + col8)) = o;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) csum[tn][k] += v[k];
+            }
+            __builtin_amdgcn_wave_barrier();                               // (the patch is this wave's own: the next tile overwrites it)
+        }
+    }
+    // p.colpart: the column sums of this tile's stored values (fp32, before any rounding: the consumer layer's bias gradient when this is a data gradient whose
+    // fp32 output nobody reads) -- lane, wave, block in a fixed order; one partial row per row tile, added up by launch_colsum.
+    if (p.colpart) {
+        float* red = reinterpret_cast<float*>(smem) + NW * (32 * LDP);        // behind the patches
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float t = csum[tn][k];
+                t += __shfl_xor(t, 4); t += __shfl_xor(t, 8); t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);      // the 16 lanes that share these columns
+                if (lane < 4) red[wave * 64 + tn * 32 + pc8 + k] = t;
+            }
+        __syncthreads();
+        if (tid < BN) {
+            const int cw_ = tid / 64, c = tid % 64;
+            float t = 0.f;
+#pragma unroll
+            for (int r_ = 0; r_ < WRN; ++r_) t += red[(r_ * WCN + cw_) * 64 + c];
+            p.colpart[(long long)tmi * p.Cout + n0 + tid] = t;
+        }
+    }
+}
+
 // 3 x 3 layers on the 64-column tile, round 5: the same product over FLAT positions of the padded map, one K-tile = one filter row.
 // conv_bf16_256_kernel<64> fetches a 256-row A tile per tap -- nine times per channel chunk -- and runs 4 MFMAs per wave between two barriers: its matrix
 // pipes were 0.21 busy (profiles/r05_c5_bf16_train_pmc_clock_summary.txt).  Here the rows of a tile are 256 consecutive positions q of the padded map
@@ -730,119 +859,9 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
         mfmas(2);
         sa = sa + 1 == NSA ? 0 : sa + 1; sa2 = sa2 + 1 == NSA ? 0 : sa2 + 1;
     }
-    // Epilogue through LDS, row-major: the MFMA layout gives a lane one column of 16 scattered rows -- 4-byte stores, 2-byte mask loads, and for the 64-channel
-    // layers (six K-tiles per tile) that epilogue WAS the kernel: conv1_2's forward pass took 1.24 ms with its MFMAs and LDS reads switched off and 1.29 with its
-    // LDS-DMA switched off, 1.34 complete (profiles/r05_bf16_conv_tile_ab.txt).  Each wave parks one 32 x 32 half of its tile (fp32, raw accumulators) in its own
-    // patch of the free stage buffers; then a lane owns (row, 8 consecutive channels): bias, skip-path addend, ReLU, the mask (16 bytes of the layer's bf16
-    // input copy, or 32 of the fp32 activation), two 16-byte fp32 stores and / or one 16-byte store into the consumer's bf16 copy, and the column sums.
-    // Border positions and positions beyond the last image: nothing stored in y, zeros in the copy.
-    __syncthreads();                                                       // every wave is done reading the stage buffers
-    constexpr int LDP = 36;
-    float* patch = reinterpret_cast<float*>(smem) + wave * (32 * LDP);
-    const long long HpWp = (long long)Hp * Wp;
-    const int prow0 = lane >> 2, pc8 = (lane & 3) * 8;
-    long long qrow[2], pixv[2]; bool valid[2];
     {
-        const long long qb = q0 + wr * 32 + prow0;
-        int n = (int)(qb / HpWp), rem = (int)(qb - (long long)n * HpWp), yy = rem / Wp, xx = rem - yy * Wp;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            qrow[it] = qb + 16 * it;
-            valid[it] = qrow[it] < R && yy >= 1 && yy <= p.H && xx >= 1 && xx <= p.W;
-            pixv[it] = ((long long)n * p.H + yy - 1) * p.W + xx - 1;
-            xx += 16;
-            while (xx >= Wp) { xx -= Wp; ++yy; }
-            while (yy >= Hp) { yy -= Hp; ++n; }
-        }
-    }
-    float csum[2][8];
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) csum[tn][k] = 0.f;
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDP + (lane & 31)] = acc[tn][r];
-        __builtin_amdgcn_wave_barrier();
-        const int col8 = n0 + wn * 64 + tn * 32 + pc8;
-        float bv[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) bv[k] = p.bias ? p.bias[col8 + k] : 0.f;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const float4 u0 = *reinterpret_cast<const float4*>(&patch[(prow0 + 16 * it) * LDP + pc8]);
-            const float4 u1 = *reinterpret_cast<const float4*>(&patch[(prow0 + 16 * it) * LDP + pc8 + 4]);
-            float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-            if (valid[it]) {
-                const long long off = pixv[it] * p.Cout + col8;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += bv[k];
-                if (p.addend) {
-                    const float4 a0 = *reinterpret_cast<const float4*>(p.addend + off), a1 = *reinterpret_cast<const float4*>(p.addend + off + 4);
-                    v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
-                }
-                // (the ReLU mask of a data gradient: the sign of the layer's padded bf16 INPUT copy, which has this kernel's geometry -- row q, half the bytes of
-                //  the fp32 activation and no pixel arithmetic; bf16 keeps fp32's exponent range, so x > 0 <=> bf16(x) > 0 for every normal x)
-                if (p.mask16) {
-                    typedef short s16x8 __attribute__((ext_vector_type(8)));
-                    const s16x8 mk = *reinterpret_cast<const s16x8*>(p.mask16 + (p.mask16_ps ? (long long)(col8 >> 5) * p.mask16_ps + qrow[it] * 32 + (col8 & 31) : qrow[it] * p.Cout + col8));
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = mk[k] > 0 ? v[k] * p.mask_scale : 0.f;
-                } else if (p.mask) {
-                    const float4 m0 = *reinterpret_cast<const float4*>(p.mask + off), m1 = *reinterpret_cast<const float4*>(p.mask + off + 4);
-                    const float mk[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = mk[k] > 0.f ? v[k] * p.mask_scale : 0.f;
-                }
-                if (p.dropout) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = philox_uniform((unsigned long long)(off + k), p.seed, p.stream_id) < p.keep_prob ? v[k] / p.keep_prob : 0.f;
-                }
-                if (p.y) {
-                    *reinterpret_cast<float4*>(p.y + off) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(p.y + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = 0.f;
-            }
-            // p.yb: the consumer is another 3 x 3 layer on the same map, so its padded bf16 copy has THIS geometry and position q of the output is row q of that copy
-            if (p.yb) {
-                bf16x8 o;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] = (__bf16)v[k];
-                *reinterpret_cast<bf16x8*>(p.yb + (p.yb_ps ? (long long)(col8 >> 5) * p.yb_ps + qrow[it] * 32 + (col8 & 31) : qrow[it] * p.Cout + col8)) = o;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) csum[tn][k] += v[k];
-        }
-        __builtin_amdgcn_wave_barrier();                                   // (the patch is this wave's own: the second half overwrites it)
-    }
-    // p.colpart: the column sums of this tile's stored values (fp32, before any rounding: the consumer layer's bias gradient when this is a data gradient whose
-    // fp32 output nobody reads) -- lane, wave, block in a fixed order; one partial row per row tile, added up by launch_colsum.
-    if (p.colpart) {
-        float* red = reinterpret_cast<float*>(smem) + 8 * (32 * LDP);         // behind the eight patches
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float t = csum[tn][k];
-                t += __shfl_xor(t, 4); t += __shfl_xor(t, 8); t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);      // the 16 lanes that share these columns
-                if (lane < 4) red[wave * 64 + tn * 32 + pc8 + k] = t;
-            }
-        __syncthreads();
-        if (tid < BN) {
-            const int cw_ = tid / 64, c = tid % 64;
-            float t = 0.f;
-#pragma unroll
-            for (int r_ = 0; r_ < 8 / WCN; ++r_) t += red[(r_ * WCN + cw_) * 64 + c];
-            p.colpart[(long long)tmi * p.Cout + n0 + tid] = t;
-        }
+        f32x16 accw[1][2] = {{acc[0], acc[1]}};
+        conv_rows_epilogue<1, WCN, 8 / WCN>(p, accw, smem, tid, q0, n0, tmi);
     }
 }
 
@@ -857,7 +876,13 @@ bool conv_bf16_256_ok(long long M, int Cin, int Cout, int mode)
 }
 
 // rows of a row tile of conv_bf16_rows_kernel as launch_conv_bf16_256 picks it (= positions per partial row of `colpart`)
-int conv_bf16_rows_bm(int Cout, int rows_bn) { return (Cout % 128 == 0 && rows_bn == 128) ? 128 : 256; }
+// Which form of conv_bf16_rows_kernel a 3 x 3 layer takes: 256 positions x 64 columns, or (rows_bn = 128, A/B) 128 x 128 where Cout % 128 == 0.
+void conv_bf16_rows_tile(int Cout, int rows_bn, int* bn, int* bm)
+{
+    *bn = 64; *bm = 256;
+    if (rows_bn == 128 && Cout % 128 == 0) { *bn = 128; *bm = 128; }
+}
+int conv_bf16_rows_bm(int Cout, int rows_bn) { int bn, bm; conv_bf16_rows_tile(Cout, rows_bn, &bn, &bm); return bm; }
 
 bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
 {
@@ -902,13 +927,10 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
     if (a.K == 3 && a.any_shape && a.guarded && (!a.yb || a.yb_pad == 1)) {
         const long long R = (long long)a.N * (a.H + 2) * (a.W + 2);
         // (the 128-column form, 128 positions x 128 columns, halves the A re-reads of the wide layers and measured 1-2 % SLOWER: 39.23 against 38.71 ms per step)
-        if (a.Cout % 128 == 0 && a.rows_bn == 128) {
-            g_last_kernel = "conv_bf16_rows_kernel<128>";
-            hipLaunchKernelGGL(conv_bf16_rows_kernel<128>, dim3((unsigned)(((R + 127) / 128) * (a.Cout / 128))), dim3(512), 0, s, a);
-        } else {
-            g_last_kernel = "conv_bf16_rows_kernel<64>";
-            hipLaunchKernelGGL(conv_bf16_rows_kernel<64>, dim3((unsigned)(((R + 255) / 256) * (a.Cout / 64))), dim3(512), 0, s, a);
-        }
+        int tbn, tbm; conv_bf16_rows_tile(a.Cout, a.rows_bn, &tbn, &tbm);
+        const unsigned blocks = (unsigned)(((R + tbm - 1) / tbm) * (a.Cout / tbn));
+        if (tbn == 128) { g_last_kernel = "conv_bf16_rows_kernel<128>"; hipLaunchKernelGGL(conv_bf16_rows_kernel<128>, dim3(blocks), dim3(512), 0, s, a); }
+        else { g_last_kernel = "conv_bf16_rows_kernel<64>"; hipLaunchKernelGGL(conv_bf16_rows_kernel<64>, dim3(blocks), dim3(512), 0, s, a); }
         return true;
     }
     if (!a.y || a.colpart) return false;       // (only the flat-position kernel runs without an fp32 output or takes column sums)
@@ -1281,7 +1303,7 @@ bool launch_wgrad_bf16(const Bf16WgradArgs& a0, hipStream_t s)
     if (nsplit > 1) {
         if (t_deterministic) {
             float* ws = det_scratch(s, (size_t)(nsplit * slab));
-            if (!ws) { fprintf(stderr, "fcn8s: deterministic mode: scratch allocation failed\n"); abort(); }
+            if (!ws) { defer_error(FCN8S_ERR_OOM, "deterministic mode: the weight gradient's slab scratch (%lld floats) cannot be allocated", (long long)nsplit * slab); return true; }
             a.C = ws; a.split_stride = slab; a.plain_store = 1;
         } else hipMemsetAsync(out, 0, (size_t)slab * sizeof(float), s);
     }

@@ -1016,7 +1016,7 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
             if (a.bt) {                                         // transposed B: plain batched GEMMs only (the adjoint Winograd data gradient)
                 static const std::string nb = "gemm_glds_nt_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>";
                 static const std::string nbx = "gemm_glds_nt_x3_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>";
-                if (mode != 3 || (long long)(BN - 1) * a.ldw >= (1LL << 29)) { fprintf(stderr, "fcn8s: transposed-B GEMM needs the plain batched form\n"); abort(); }
+                if (mode != 3 || (long long)(BN - 1) * a.ldw >= (1LL << 29)) { defer_error(FCN8S_ERR_STATE, "transposed-B GEMM needs the plain batched form"); return; }
                 static const std::string nbx2 = "gemm_glds_nt_x2_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", 3>";
                 g_last_kernel = (a.split == 3 ? nbx : a.split == 2 ? nbx2 : nb).c_str();
                 if (a.split == 3) hipLaunchKernelGGL((gemm_glds_nt_x3_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, s, a);
@@ -1044,8 +1044,8 @@ static void launch_igemm_cfg(const IgemmArgs& a0, int phases, hipStream_t s)
         }
     }
     if (a.bt) {      // igemm_fwd_kernel would read w[z][n][k] as if it were [k][n]: callers must only set bt for launches the branch above takes
-        fprintf(stderr, "fcn8s: transposed-B GEMM (M %lld, K %d, N %d, tile %dx%d) does not fit the LDS-DMA kernel\n", a.M, a.Ktot, a.Cout, BM, BN);
-        abort();
+        defer_error(FCN8S_ERR_STATE, "transposed-B GEMM (M %lld, K %d, N %d, tile %dx%d) does not fit the LDS-DMA kernel", a.M, a.Ktot, a.Cout, BM, BN);
+        return;
     }
     if (mode == 3)      hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 3, BKF>), grid, dim3(256), 0, s, a);
     else if (mode == 2) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, 2, BKF>), grid, dim3(256), 0, s, a);
@@ -1606,7 +1606,7 @@ bool launch_conv1_wgrad(const float* X4, const float* dZ, float* dW, float* db, 
     auto det_conv1 = [&](Conv1WgradArgs& a, long long blocks) -> float* {
         if (!t_deterministic || blocks <= 1) return nullptr;
         float* ws = det_scratch(s, (size_t)(blocks * kSlab));
-        if (!ws) { fprintf(stderr, "fcn8s: deterministic mode: scratch allocation failed\n"); abort(); }
+        if (!ws) { defer_error(FCN8S_ERR_OOM, "deterministic mode: conv1_1's weight-gradient scratch (%lld floats) cannot be allocated", blocks * kSlab); return nullptr; }
         hipMemsetAsync(ws, 0, (size_t)(blocks * kSlab) * sizeof(float), s);
         a.dW = ws; a.db = db ? ws + 27 * 64 : nullptr; a.blk_stride = kSlab;
         return ws;
@@ -1942,7 +1942,7 @@ static void launch_wgrad_cfg(const WgradArgs& a, hipStream_t s)
     auto det_slabs = [&](long long nslabs) -> bool {
         if (nslabs <= 1) { b.plain_store = a.c_uninitialized ? 1 : 0; return false; }      // a single writer per element: an atomic add onto C is reproducible
         float* ws = det_scratch(s, (size_t)(nslabs * slab));
-        if (!ws) { fprintf(stderr, "fcn8s: deterministic mode: scratch of %lld floats cannot be allocated\n", nslabs * slab); abort(); }
+        if (!ws) { defer_error(FCN8S_ERR_OOM, "deterministic mode: a weight gradient's slab scratch (%lld floats) cannot be allocated", nslabs * slab); b.plain_store = a.c_uninitialized ? 1 : 0; return false; }
         b.C = ws; b.split_stride = slab; b.plain_store = 1;
         return true;
     };

@@ -6,6 +6,7 @@
 // predictions).
 #include "../../include/fcn8s_hip.h"
 #include "fcn8s_internal.h"
+#include <cstdarg>
 
 #include <dlfcn.h>
 #include <atomic>
@@ -41,6 +42,8 @@ static_assert(sizeof(ncclUniqueId) == FCN8S_COMM_ID_BYTES, "fcn8s_comm_unique_id
 namespace {
 
 thread_local std::string g_last_error;
+thread_local int t_deferred_code = 0;
+thread_local std::string t_deferred_text;
 
 struct ParamInfo {
     std::string name;
@@ -62,6 +65,23 @@ struct Act { float* p = nullptr; size_t n = 0; int H = 0, W = 0, C = 0; };
 const int kConvsPerBlock[5] = {2, 2, 3, 3, 3};
 
 }  // namespace
+
+namespace fcn8s {
+void defer_error(int code, const char* fmt, ...)
+{
+    if (t_deferred_code) return;
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    t_deferred_code = code; t_deferred_text = buf;
+}
+int take_deferred_error(std::string* text)
+{
+    const int c = t_deferred_code;
+    if (c && text) *text = t_deferred_text;
+    t_deferred_code = 0; t_deferred_text.clear();
+    return c;
+}
+}  // namespace fcn8s
 
 struct fcn8s_model {
     int C = 20, fc6k = 7, device = 0;
@@ -202,6 +222,12 @@ int fail(fcn8s_model* m, int code, const std::string& msg)
     g_last_error = msg;
     return code;
 }
+// what a launcher recorded with defer_error during the call that is about to return (0: nothing)
+int deferred_rc(fcn8s_model* m)
+{
+    std::string t; const int c = take_deferred_error(&t);
+    return c ? fail(m, c, t) : FCN8S_OK;
+}
 #define HIPCHK(m, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
     return fail(m, e_ == hipErrorOutOfMemory ? FCN8S_ERR_OOM : FCN8S_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
@@ -334,6 +360,7 @@ static bool bt_gemm_ok(int K, int N) { return K % 16 == 0 && (N == 64 || N % 128
 // Arithmetic of the op-level entry points, which have no model: the context of the CALLING THREAD (fcn8s_set_option(NULL, "op_split_pieces", n)
 // from that thread), copied into the bare model each such call builds -- never read by a real model, never shared between threads.
 thread_local int t_op_split = 0;
+thread_local int t_op_rows_bn = 0;       // op context: the form of the flat-position 3 x 3 kernel fcn8s_op_conv2d_bf16_train asks for (option "op_bf16_rows_bn")
 thread_local int t_op_planes = 1;        // op context: fcn8s_op_conv2d_bf16_train keeps its padded copies as channel-chunk planes (option "op_bf16_planes")
 int split_of(const fcn8s_model* m)
 {
@@ -479,14 +506,14 @@ bool conv_same(fcn8s_model* m, const char* group, const float* x, const float* w
                 }
                 return false;
             }
-            if (g.colpart) { fprintf(stderr, "fcn8s: bf16_train: %s's data gradient was refused by the flat-position kernel\n", layer); abort(); }
+            if (g.colpart) { defer_error(FCN8S_ERR_SHAPE, "bf16_train: %s's data gradient was refused by the flat-position kernel", layer); return false; }
         }
     }
     if (bf16_train_mode(m) && m->train_mode && layer && e.dgrad && m->dy_bf16_only.count(layer)) {
-        fprintf(stderr, "fcn8s: bf16_train: %s's data gradient could not run on the bf16 kernel and its fp32 output gradient was not kept (option \"bf16_acts\" = 0 keeps it)\n", layer); abort();
+        defer_error(FCN8S_ERR_SHAPE, "bf16_train: %s's data gradient could not run on the bf16 kernel and its fp32 output gradient was not kept (option \"bf16_acts\" = 0 keeps it)", layer); return false;
     }
     if (bf16_train_mode(m) && m->train_mode && layer && e.mask && m->in_bf16_only.count(layer)) {
-        fprintf(stderr, "fcn8s: bf16_train: %s's data gradient could not run on the bf16 kernel and its fp32 mask was not kept (option \"bf16_acts\" = 0 keeps it)\n", layer); abort();
+        defer_error(FCN8S_ERR_SHAPE, "bf16_train: %s's data gradient could not run on the bf16 kernel and its fp32 mask was not kept (option \"bf16_acts\" = 0 keeps it)", layer); return false;
     }
     const bool wino3 = m && K == 3 && m->wino_min_cin > 0 && Cin >= m->wino_min_cin && m->d_wino_v && wino_tile_for(m, H, W, 3) && !e.dropout;
     const bool wino7 = m && K == 7 && m->wino_fc6 && m->d_wino_v && wino_tile_for(m, H, W, 7) == 4;
@@ -722,7 +749,7 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
     // the data gradient of the layer after this one may have written this layer's dM instead of dz (backward_blocks): dz then holds nothing
     const bool promised = m && layer && phase != 2 && !m->dm_prefilled.empty() && m->dm_prefilled == layer;
     if (m && phase != 2) m->dm_prefilled.clear();
-    auto broken_promise = [&]() { fprintf(stderr, "fcn8s: %s was handed dM instead of dZ but does not take the Winograd-domain path\n", layer); abort(); };
+    auto broken_promise = [&]() { defer_error(FCN8S_ERR_STATE, "%s was handed dM instead of dZ but does not take the Winograd-domain path", layer); };
     WgradArgs a{}; a.split = split_of(m);
     a.A = x; a.B = dz; a.C = dw;
     a.N = N; a.Pa = H; a.Pb = W; a.P = (long long)N * H * W;
@@ -753,12 +780,12 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
                     if (db && !db_done) { ProfScope ps(m, "colsum", 0, 4.0 * a.P * Cout); launch_colsum(dz, db, a.P, Cout, s); }
                     return;
                 }
-                if (db_done) { fprintf(stderr, "fcn8s: bf16_train: %s's weight-gradient launch refused its shape after the bias gradient was taken\n", layer); abort(); }
+                if (db_done) { defer_error(FCN8S_ERR_SHAPE, "bf16_train: %s's weight-gradient launch refused its shape after the bias gradient was taken", layer); return; }
             }
         }
     }
     if (bf16_train_mode(m) && m->train_mode && layer && (m->in_bf16_only.count(layer) || m->dy_bf16_only.count(layer))) {
-        fprintf(stderr, "fcn8s: bf16_train: %s's weight gradient could not run on the bf16 kernel and its fp32 input was not kept (option \"bf16_acts\" = 0 keeps it)\n", layer); abort();
+        defer_error(FCN8S_ERR_SHAPE, "bf16_train: %s's weight gradient could not run on the bf16 kernel and its fp32 input was not kept (option \"bf16_acts\" = 0 keeps it)", layer); return;
     }
     if (m && (K == 3 || K == 7) && layer && alpha == 1.f && !real_cin && m->train_mode) {
         auto it = m->acts.find(std::string("wv:") + layer);
@@ -2045,6 +2072,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
         if (k == "op_f32x3") { t_op_split = value ? 3 : 0; return FCN8S_OK; }
         if (k == "op_deterministic") { t_deterministic = value ? 1 : 0; return FCN8S_OK; }
         if (k == "op_bf16_planes") { t_op_planes = value ? 1 : 0; return FCN8S_OK; }
+        if (k == "op_bf16_rows_bn") { if (value != 0 && value != 64 && value != 128) return fail(nullptr, FCN8S_ERR_BAD_ARG, "op_bf16_rows_bn must be 0, 64 or 128"); t_op_rows_bn = (int)value; return FCN8S_OK; }
         if (k == "op_split_pieces") {
             if (value != 0 && value != 2 && value != 3) return fail(nullptr, FCN8S_ERR_BAD_ARG, "fcn8s_set_option: op_split_pieces is 0, 2 or 3");
             t_op_split = (int)value; return FCN8S_OK;
@@ -2096,6 +2124,7 @@ int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value)
         if (k == "op_f32x3") { *value = t_op_split == 3; return FCN8S_OK; }
         if (k == "op_deterministic") { *value = t_deterministic; return FCN8S_OK; }
         if (k == "op_bf16_planes") { *value = t_op_planes; return FCN8S_OK; }
+        if (k == "op_bf16_rows_bn") { *value = t_op_rows_bn; return FCN8S_OK; }
         if (k == "op_split_pieces") { *value = t_op_split; return FCN8S_OK; }
         return FCN8S_ERR_NOT_FOUND;
     }
@@ -2187,6 +2216,7 @@ int fcn8s_forward_loss(fcn8s_model* m, const void* images, int dtype, const uint
     const void* img; const uint8_t* lab;
     rc = stage_inputs(m, images, dtype, labels, where, &img, &lab); if (rc) return rc;
     rc = forward(m, img, dtype, keep_prob, true); if (rc) return rc;
+    rc = deferred_rc(m); if (rc) return rc;
     rc = compute_loss(m, lab, l2_rate, true); if (rc) return rc;
     m->next_bucket = 0;
     HIPCHK(m, hipGetLastError());
@@ -2196,7 +2226,8 @@ int fcn8s_forward_loss(fcn8s_model* m, const void* images, int dtype, const uint
 int fcn8s_backward_bucket(fcn8s_model* m, int bucket)
 {
     if (!m || bucket < 0 || bucket >= kNumBuckets) return fail(m, FCN8S_ERR_BAD_ARG, "bad bucket");
-    return do_backward_bucket(m, bucket, 1);
+    int rc = do_backward_bucket(m, bucket, 1); if (rc) { take_deferred_error(nullptr); return rc; }
+    return deferred_rc(m);
 }
 
 int fcn8s_bucket_wait(fcn8s_model* m, int bucket, void* hip_stream)
@@ -2549,7 +2580,8 @@ int fcn8s_train_step(fcn8s_model* m, const void* images, int dtype, const uint8_
     // backward pass, every bucket all-reduced as soon as it is final, 1/world in the update (a C caller must never get silently diverging replicas)
     const bool dp = (m->comm || m->comm_failed.load()) && m->comm_world > 1;
     for (int b = 0; b < kNumBuckets; ++b) {
-        rc = do_backward_bucket(m, b, dp ? 1 : 2); if (rc) return rc;
+        rc = do_backward_bucket(m, b, dp ? 1 : 2); if (rc) { take_deferred_error(nullptr); return rc; }
+        rc = deferred_rc(m); if (rc) return rc;
         if (dp) for (int r = 0; r < kNumBuckets; ++r)
             if (bucket_complete_after(m, r) == b) { rc = fcn8s_allreduce_bucket(m, r); if (rc) return rc; }
     }
@@ -2567,6 +2599,7 @@ int fcn8s_eval_step(fcn8s_model* m, const void* images, int dtype, const uint8_t
     const void* img; const uint8_t* lab;
     rc = stage_inputs(m, images, dtype, labels, where, &img, &lab); if (rc) return rc;
     rc = forward(m, img, dtype, 1.0f, false); if (rc) return rc;
+    rc = deferred_rc(m); if (rc) return rc;
     rc = compute_loss(m, lab, l2_rate, false); if (rc) return rc;
     const long long npix = (long long)N * H * W;
     { ProfScope ps(m, "softmax_argmax", 0, (double)npix * (m->C * 4 + 8)); launch_softmax_argmax(LG(m), nullptr, m->d_pred, npix, m->C, m->stream, LGM(m), m->N); }
@@ -2641,6 +2674,7 @@ int fcn8s_predict(fcn8s_model* m, const void* images, int dtype, int N, int H, i
     const void* img; const uint8_t* lab;
     rc = stage_inputs(m, images, dtype, nullptr, where, &img, &lab); if (rc) return rc;
     rc = forward(m, img, dtype, 1.0f, false); if (rc) return rc;
+    rc = deferred_rc(m); if (rc) return rc;
     const long long npix = (long long)N * H * W;
     if (where == FCN8S_DEVICE) {
         ProfScope ps(m, "softmax_argmax", 0, (double)npix * (m->C * 4 + 8));
@@ -2853,7 +2887,8 @@ int fcn8s_profile_get(fcn8s_model* m, int gi, const char** name, double* total_m
 }
 
 // ---- single ops ------------------------------------------------------------------------------
-#define OPCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(nullptr, FCN8S_ERR_HIP, hipGetErrorString(e_)); } while (0)
+#define OPCHK() do { { std::string t_; const int c_ = take_deferred_error(&t_); if (c_) return fail(nullptr, c_, t_); } \
+                     hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(nullptr, FCN8S_ERR_HIP, hipGetErrorString(e_)); } while (0)
 
 uint32_t fcn8s_crc32c(const void* data, size_t n, uint32_t crc)
 {
@@ -3025,13 +3060,13 @@ int fcn8s_op_conv2d_bf16_train(void* stream, const float* x, const float* w, con
     if (y && x && w) {
         launch_w_to_bf16_t(w, wt, K * K * Cin, Cout, s);
         Bf16Conv256Args g{};
-        g.xp = xb + OX; g.xp_ps = PS; g.wt = wt; g.bias = bias; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K; g.relu = relu; g.any_shape = 1; g.mask_scale = 1.f; g.guarded = 1;
+        g.xp = xb + OX; g.xp_ps = PS; g.wt = wt; g.bias = bias; g.y = y; g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.K = K; g.relu = relu; g.any_shape = 1; g.mask_scale = 1.f; g.guarded = 1; g.rows_bn = t_op_rows_bn;
         ok = ok && launch_conv_bf16_256(g, s);
     }
     if (dx && dy && w) {
         launch_w_to_bf16_flip_t(w, wt, K, Cin, Cout, s);
         Bf16Conv256Args g{};
-        g.xp = dyb + OY; g.xp_ps = PS; g.wt = wt; g.y = dx; g.N = N; g.H = H; g.W = W; g.Cin = Cout; g.Cout = Cin; g.K = K; g.mask = mask; g.mask_scale = 1.f; g.any_shape = 1; g.guarded = 1;
+        g.xp = dyb + OY; g.xp_ps = PS; g.wt = wt; g.y = dx; g.N = N; g.H = H; g.W = W; g.Cin = Cout; g.Cout = Cin; g.K = K; g.mask = mask; g.mask_scale = 1.f; g.any_shape = 1; g.guarded = 1; g.rows_bn = t_op_rows_bn;
         ok = ok && launch_conv_bf16_256(g, s);
     }
     if (dw && x && dy) {

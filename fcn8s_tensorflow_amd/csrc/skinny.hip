@@ -281,7 +281,7 @@ bool launch_head_wgrad(const float* x, const float* dy, float* dw, long long M, 
     if (t_deterministic && bx > 1) {                            // the bx pixel ranges of a channel group meet in atomics: one slab each instead
         stride = (long long)K * C;
         out = det_scratch(s, (size_t)(bx * stride));
-        if (!out) { fprintf(stderr, "fcn8s: deterministic mode: scratch allocation failed\n"); abort(); }
+        if (!out) { defer_error(FCN8S_ERR_OOM, "deterministic mode: the score heads' weight-gradient scratch (%lld floats) cannot be allocated", (long long)bx * stride); return true; }
         hipMemsetAsync(out, 0, (size_t)(bx * stride) * sizeof(float), s);
     }
     if (C == 20) hipLaunchKernelGGL(head_wgrad_kernel<20>, dim3(nct, (unsigned)bx), dim3(256), 0, s, x, dy, out, M, K, alpha, ppb, stride);

@@ -300,6 +300,7 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *     "op_split_pieces"   0    the same switch by piece count: 0 = f32 MFMA, 3 = FCN8S_PREC_F32X3, 2 = FCN8S_PREC_F32X2
  *     "op_bf16_planes"    1    fcn8s_op_conv2d_bf16_train keeps its padded bf16 copies as channel-chunk planes [C / 32][rows][32] (what FCN8S_PREC_BF16_TRAIN does);
  *                              0 = [rows][C], the layout the kernels also take (same results)
+ *     "op_bf16_rows_bn"   0    the same switch ("bf16_rows_bn": 0 / 64 = 256 x 64 blocks, 128 = 128 x 128) for fcn8s_op_conv2d_bf16_train
  *     "op_deterministic"  0    the slab reductions of "deterministic" for the op-level entry points (a model call on the same thread sets the
  *                              thread's switch from that model's option: set it again before the next op-level call)
  * Unknown keys return FCN8S_ERR_NOT_FOUND. */

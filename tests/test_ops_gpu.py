@@ -295,6 +295,51 @@ def test_conv_bf16_train_kernels(N, H, W, Cin, Cout, K):
         L.check(L.lib.fcn8s_op_conv2d_bf16_train(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), 1, None, None, None, None, None, N, H, W, Cin + 32, Cout, K))
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [
+    (1, 16, 16, 64, 256),          # two channel chunks (18 steps: the ring of five B slots wraps), a partial last row tile (324 padded positions), two column tiles
+    (2, 24, 40, 256, 256),         # several row tiles, eight channel chunks, tiles that straddle the two images
+    (1, 16, 32, 512, 512),         # four column tiles
+    (1, 30, 34, 128, 128),         # one column tile; five row tiles, the last one partial
+    (2, 8, 8, 256, 384),           # 384 = 3 x 128
+    (1, 8, 8, 64, 128),            # 100 padded positions: a single, mostly empty row tile
+])
+def test_conv_bf16_train_rows_forms(N, H, W, Cin, Cout):
+    """The two forms of the flat-position 3 x 3 kernel (conv_bf16_rows_kernel<64>: blocks of 256 positions x 64 channels, the default; <128>: 128 x 128, op option
+    `op_bf16_rows_bn`) on shapes with partial last row tiles, tiles that straddle images and several column tiles: forward (bias, ReLU) and masked data
+    gradient against float64 evaluations of the same bf16-rounded operands (1e-5: fp32 summation order), and BIT-identical to each other -- both add the products
+    of a dot product in the same order (K-tile by K-tile, tap by tap, 16 channels at a time).  [Round 6 ran a third form with fat waves, 128 positions x 64
+    channels per wave, through this test: bit-identical, 12-50 % slower, not shipped -- tools/labs/conv_bf16_taps_lab.hip, profiles/r06_bf16_fat_tile_lab.txt.]"""
+    L = _lib()
+    K = 3
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((K, K, Cin, Cout)) / np.sqrt(K * K * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    dy = rng.standard_normal((N, H, W, Cout)).astype(np.float32)
+    mask = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    rb = lambda a: torch.tensor(a).to(torch.bfloat16).double()
+    nchw = lambda t: t.permute(0, 3, 1, 2)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).numpy()
+    xr, wr, dyr = nchw(rb(x)), rb(w).permute(3, 2, 0, 1), nchw(rb(dy))
+    y_ref = nhwc(torch.relu(torch.nn.functional.conv2d(xr, wr, torch.tensor(b).double(), padding=1)))
+    dx_ref = nhwc(torch.nn.grad.conv2d_input(xr.shape, wr, dyr, padding=1)) * (mask > 0)
+    xd, wd, bd, dyd, md = dev(x), dev(w), dev(b), dev(dy), dev(mask)
+    out = {}
+    for form in (128, 64):
+        L.check(L.lib.fcn8s_set_option(None, b"op_bf16_rows_bn", form))
+        try:
+            y_, dx_ = torch.full((N, H, W, Cout), 7.0).cuda(), torch.full((N, H, W, Cin), 7.0).cuda()
+            L.check(L.lib.fcn8s_op_conv2d_bf16_train(None, ptr(xd), ptr(wd), ptr(bd), ptr(y_), 1, ptr(dyd), ptr(md), ptr(dx_), None, None, N, H, W, Cin, Cout, K))
+            torch.cuda.synchronize()
+        finally:
+            L.check(L.lib.fcn8s_set_option(None, b"op_bf16_rows_bn", 0))
+        out[form] = (y_.cpu().numpy(), dx_.cpu().numpy())
+        assert rel_err(out[form][0], y_ref) < 1e-5, form
+        assert rel_err(out[form][1], dx_ref) < 1e-5, form
+    np.testing.assert_array_equal(out[128][0], out[64][0])
+    np.testing.assert_array_equal(out[128][1], out[64][1])
+
+
 @pytest.mark.parametrize("N,H,W,C", [(2, 8, 8, 64), (1, 4, 6, 8), (1, 32, 64, 128)])
 def test_maxpool(N, H, W, C):
     L = _lib()
