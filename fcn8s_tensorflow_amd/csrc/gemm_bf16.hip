@@ -14,6 +14,7 @@
 // per K-tile, global -> register -> LDS double buffering with one barrier per K-tile.
 #include "fcn8s_internal.h"
 #include <string>
+#include <algorithm>
 
 namespace fcn8s {
 
@@ -375,7 +376,7 @@ bool launch_f32_to_bf16_padded_colsum(const float* x, unsigned short* xp, float*
 // too).  The two row groups of 128 rows stay; inside a group the four waves are laid out WR x (4 / WR): BN = 256 -> 1 x 4 (a wave owns 128 rows x 64
 // columns, 4 x 2 accumulators, the round-3 kernel), BN = 128 -> 2 x 2 (64 x 64, 2 x 2), BN = 64 -> 4 x 1 (32 x 64, 1 x 2).  The B image of a stage has BN
 // rows: waves whose chunks lie beyond it issue no B loads (the vmcnt accounting is per wave: NB = its number of B instructions).
-// Rows m >= M (a partial last row tile) read row 0's window and are not stored.  Epilogue: bias, ReLU, dropout as before; for the data gradients an
+// Rows m >= M (a partial last row tile) read the tile's first row's window and are not stored.  Epilogue: bias, ReLU, dropout as before; for the data gradients an
 // optional addend (the skip path's gradient) and the ReLU mask of the layer input (`mask` > 0, an fp32 activation tensor of the output's shape).
 // Stages: five for BN = 256 (all 160 KB of LDS, one block per CU, the round-3 kernel); four / three for BN = 64 / 128 (80 / 72 KB: TWO blocks per CU, so
 // that one block's prologue and its 64 - 128 KB epilogue run under the other's K loop -- with 18 .. 36 K-tiles per tile in the 64- and 128-channel
@@ -402,13 +403,20 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
     // B instructions of this wave (wave-uniform; BN = 256: always two, a compile-time constant as in the round-3 kernel)
     const int nb = BN == 256 ? 2 : ((wave * 2 + 1) * 16 < BN ? 2 : 0);
     unsigned a_voff[2], b_voff[NBMAX];
+    // The padded copy may be larger than 4 GiB (64 x 1024x512 x 64 channels): the 32-bit per-lane byte offsets are taken from the window of the tile's FIRST row, whose
+    // position pp0 goes into the 64-bit scalar base.  Rows of a tile are consecutive output pixels, so their windows lie within a few map rows of pp0.
+    long long pp0;
+    {
+        const int n = (int)(m0 / HW), r = (int)(m0 - (long long)n * HW), y = r / p.W, x = r - y * p.W;
+        pp0 = ((long long)n * Hp + y) * Wp + x;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (wave * 2 + i) * 16 + lane / 4, pc = lane % 4;
         const int lc = pc ^ ((row >> 2) & 3);                                  // logical 16-byte chunk stored at physical chunk pc
-        long long m = m0 + row; if (m >= p.M) m = 0;
+        long long m = m0 + row; if (m >= p.M) m = m0;
         const int n = (int)(m / HW), r = (int)(m - (long long)n * HW), y = r / p.W, x = r - y * p.W;
-        const long long pp = ((long long)n * Hp + y) * Wp + x;                // top-left pixel of the row's tap window in the padded copy
+        const long long pp = ((long long)n * Hp + y) * Wp + x - pp0;          // top-left pixel of the row's tap window in the padded copy, from the tile's first
         a_voff[i] = p.xp_ps ? (unsigned)((pp * 32 + lc * 8) * 2) : (unsigned)((pp * p.Cin + lc * 8) * 2);
         b_voff[i] = W_PLANES ? (unsigned)(((row < BN ? row : 0) * 32 + lc * 8) * 2) : (unsigned)(((long long)(row < BN ? row : 0) * Ktot + lc * 8) * 2);
     }
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(512, BN == 256 ? 2 : 4) void conv_bf16_256_kernel(c
     int i_kt = 0, i_ci = (kt0 % cpt) * G_BK, i_tx = (kt0 / cpt) % p.K, i_ty = (kt0 / cpt) / p.K;
     auto issue = [&]() {
         const unsigned st = lds0 + (unsigned)((i_kt % NS) * STAGE);
-        const unsigned short* ga = p.xp_ps ? p.xp + (long long)(i_ci >> 5) * p.xp_ps + ((long long)i_ty * Wp + i_tx) * 32 : p.xp + ((long long)i_ty * Wp + i_tx) * p.Cin + i_ci;
+        const unsigned short* ga = p.xp_ps ? p.xp + (long long)(i_ci >> 5) * p.xp_ps + (pp0 + (long long)i_ty * Wp + i_tx) * 32 : p.xp + (pp0 + (long long)i_ty * Wp + i_tx) * p.Cin + i_ci;
         const unsigned short* gb = b_base + (W_PLANES ? (long long)i_kt * p.Cout * 32 : (long long)i_kt * G_BK);
 #pragma unroll
         for (int i = 0; i < 2; ++i) glds16b(ga, a_voff[i], st + (wave * 2 + i) * 1024);
@@ -889,8 +897,8 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
     Bf16Conv256Args a = a0;
     a.M = (long long)a.N * a.H * a.W;
     if (!conv_bf16_256_ok(a.M, a.Cin, a.Cout, a.any_shape ? 3 : 2)) return false;
-    // padded-copy byte offsets are 32-bit in the kernel (per-lane voff): the whole padded tensor must stay below 4 GiB
-    if ((double)a.N * (a.H + a.K - 1) * (a.W + a.K - 1) * a.Cin * 2.0 >= 4294967296.0 || (double)a.Cout * a.K * a.K * a.Cin * 2.0 >= 4294967296.0) return false;
+    // 32-bit per-lane byte offsets: inside a tile's window of the padded copy (a few map rows; the tile's position is in the 64-bit base), and over the weights
+    if ((double)(G_BM + (a.K + 2) * (a.W + a.K - 1)) * (a.xp_ps ? 32 : a.Cin) * 2.0 >= 4294967296.0 || (double)a.Cout * a.K * a.K * a.Cin * 2.0 >= 4294967296.0) return false;
     const double abytes = 2.0 * a.M * a.K * a.K * a.Cin, bbytes = 2.0 * a.K * a.K * a.Cin * a.Cout;
     a.m_fastest = bbytes > abytes;             // the larger operand's panel stays put behind one XCD's L2 while the other one streams
     // a long reduction behind few output tiles and an identity epilogue (fc6's data gradient): keep the wide tile and split K over blockIdx.y into slabs that
@@ -1274,7 +1282,10 @@ bool launch_wgrad_bf16(const Bf16WgradArgs& a0, hipStream_t s)
 {
     Bf16WgradArgs a = a0;
     if (a.Ci % 64 || a.Cj % 64 || (a.K & 1) == 0 || a.R < 1) return false;
-    if ((double)a.a_ps * 2.0 * 3.0 + 4096.0 >= 4294967296.0 || (double)a.b_ps * 2.0 * 3.0 + 4096.0 >= 4294967296.0) return false;      // (per-lane byte offsets span up to four planes)
+    // per-lane byte offsets are 32-bit and span the channel-chunk planes one 16-row LDS-DMA instruction touches: TWO planes (128-byte LDS rows: the nine-tap kernel and
+    // the 64-channel tile) or FOUR (256-byte rows: the 128-channel tile).  A plane of 64 x 1024x512 is 2.2 GB: two are addressable, four are not.
+    auto spans = [&](int planes) { return (double)a.a_ps * 2.0 * (planes - 1) + 65536.0 < 4294967296.0 && (double)a.b_ps * 2.0 * (planes - 1) + 65536.0 < 4294967296.0; };
+    if (!spans(2)) return false;      // (plane stride 0 = [rows][C]: offsets stay inside a K-tile's 40 rows)
     // 3 x 3 layers: all nine taps per block (the operands are streamed once instead of nine times).  Measured at 4 x 2048x1024 against one tap per block
     // (profiles/r05_wgrad_taps9_ab.txt): conv1_2 3.08 -> 0.76 ms, conv2_2 1.43 -> 0.67, conv3_2 1.51 -> 0.68 (409 -> 904 TFLOP/s), conv4_2 1.13 -> 0.57
     // (546 -> 1092), conv5_x 0.24 -> 0.20.  (The A/B ran on an environment switch that is gone again: the library reads no environment variable.)
@@ -1283,7 +1294,7 @@ bool launch_wgrad_bf16(const Bf16WgradArgs& a0, hipStream_t s)
     // least two tiles -- conv2_2 0.63 -> 0.55 ms, conv3_2 0.55 -> 0.52, conv3_1 0.33 -> 0.305; conv4_x the same either way, conv5_x 0.168 -> 0.18 (short K
     // loops: one block per CU hides less), conv2_1 (a single tile) 0.33 -> 0.46
     const int nj = (taps9 && a.Cj % 128 == 0 && a.Cj <= 256 && (a.Ci / 64) * (a.Cj / 128) >= 2) ? 2 : 1;
-    const int bm = taps9 ? 64 : ((a.Ci % 128 == 0 && a.Cj % 128 == 0) ? 128 : 64);
+    const int bm = taps9 ? 64 : ((a.Ci % 128 == 0 && a.Cj % 128 == 0 && spans(4)) ? 128 : 64);
     const int taps = a.K * a.K;
     const long long tiles = (long long)(a.Ci / bm) * (a.Cj / (bm * nj)) * (taps9 ? 1 : taps);
     const long long slots = 256LL * (taps9 ? (nj == 2 ? 1 : 2) : (bm == 128 ? 2 : 4));

@@ -1370,8 +1370,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 // bf16_train, training: conv1_2 reads this layer as its padded bf16 copy and nobody else reads it (the mask of conv1_2's data gradient is the
                 // sign of that copy): the tile kernel writes the copy and no fp32 tensor
                 unsigned short* y16 = nullptr;
-                if (bf16_train_mode(m) && train && m->bf16_acts && m->conv1_tiled && h % 8 == 0 && w % 16 == 0 && kConvsPerBlock[0] >= 2 && m->widths[0] % 64 == 0 &&
-                    (double)N * (h + 2) * (w + 2) * m->widths[0] * 2.0 < 4294967296.0)
+                if (bf16_train_mode(m) && train && m->bf16_acts && m->conv1_tiled && h % 8 == 0 && w % 16 == 0 && kConvsPerBlock[0] >= 2 && m->widths[0] % 64 == 0)
                     y16 = xg16_for(m, "conv1_2", N, h, w, m->widths[0], 3, s);
                 ProfScope ps(m, "conv1_1_fwd", 2.0 * N * h * w * 27.0 * m->widths[0], 4.0 * N * h * w * 3.0 + (y16 ? 2.0 : 4.0) * N * h * w * m->widths[0], nm);
                 done = launch_conv1_fwd(x, m->d_w1pad, e.bias, y16 ? nullptr : A(m, nm), m->d_w1pad + 12 * 4 * (size_t)m->widths[0], N, h, w, m->widths[0], m->conv1_tiled, s, y16, g16_ps(N, h, w, 3));
@@ -1396,11 +1395,11 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 // ... and if that is the output's only reader (option bf16_acts; the mask of the consumer's data gradient is the sign of the copy), the fp32
                 // tensor is not written at all.  (Both layers' gradients must fit the bf16 kernels: a fallback would look for the fp32 tensor.)
                 const bool only16 = yb && m->bf16_acts && cin % 64 == 0 && m->widths[b] % 64 == 0;
-                // (the convolution kernel addresses its padded copies with 32-bit byte offsets: a layer whose padded input OR padded output gradient reaches
-                //  4 GiB cannot run in this mode -- say so instead of letting that one layer fall back to another arithmetic)
-                const double padded_px = (double)N * (h + 2) * (w + 2);
-                if (padded_px * std::max(cin, m->widths[b]) * 2.0 >= 4294967296.0)
-                    return fail(m, FCN8S_ERR_SHAPE, std::string("bf16_train: the padded bf16 copy of ") + nm + "'s input or output gradient would reach 4 GiB at this batch size; use a smaller batch per GPU");
+                // (the convolution kernels address their padded copies through a 64-bit tile base; the weight-gradient kernels' 32-bit per-lane byte offsets span TWO
+                //  32-channel planes of a copy -- launch_wgrad_bf16's limit, applied HERE, before anything is launched: a 32-channel plane of the padded map must stay
+                //  below 4 GiB, i.e. about 67 million padded positions (127 images of 1024x512).  Round 5 refused a whole copy of 4 GiB: 64 x 1024x512.)
+                if ((double)g16_ps(N, h, w, 3) * 2.0 + 65536.0 >= 4294967296.0)
+                    return fail(m, FCN8S_ERR_SHAPE, std::string("bf16_train: a 32-channel plane of the padded bf16 copy of ") + nm + "'s input would reach 4 GiB at this batch size; use a smaller batch per GPU");
                 done = bf16_conv_layer(m, "conv3x3_fwd_bf16", (std::string(nm) + "/filter").c_str(), (std::string(nm) + "/biases").c_str(), x, only16 ? nullptr : A(m, nm),
                                        N, h, w, cin, m->widths[b], 3, 0, 1.f, 0, s, /*allow_small=*/false, xb, /*any_shape=*/true, yb, 1, g16_ps(N, h, w, 3), g16_ps(N, h, w, 3));
                 if (!done) return fail(m, FCN8S_ERR_SHAPE, std::string("bf16_train: ") + nm + " does not fit the bf16 convolution kernel");
@@ -1442,7 +1441,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
             char cons[32]; int ck = 3, cout_c = 0;
             if (b < 4) { snprintf(cons, sizeof cons, "conv%d_1", b + 2); cout_c = m->widths[b + 1]; } else { snprintf(cons, sizeof cons, "fc6"); ck = m->fc6k; cout_c = m->widths[5]; }
             unsigned short* yb = nullptr;
-            if (m->bf16_acts && cin % 64 == 0 && cout_c % 64 == 0 && (double)N * (h / 2 + ck - 1) * (w / 2 + ck - 1) * cin * 2.0 < 4294967296.0)
+            if (m->bf16_acts && cin % 64 == 0 && cout_c % 64 == 0)
                 yb = xg16_for(m, cons, N, h / 2, w / 2, cin, ck, s);
             const bool only16 = yb && b != 2 && b != 3;
             char ix[16]; snprintf(ix, sizeof ix, "pidx%d", b + 1);

@@ -746,16 +746,44 @@ def test_batch_of_64_is_its_four_images_sixteen_times():
     e.close()
 
 
-def test_bf16_train_refuses_a_batch_whose_padded_copies_pass_4_gib():
-    """conv_bf16_256_kernel addresses the padded bf16 copies with 32-bit byte offsets.  A batch whose padded conv1_2 input reaches 4 GiB (64 x 1024x512:
-    64 x 514 x 1026 x 64 x 2 bytes) must be refused with a shape error naming the layer -- not run with that one layer silently on the fp32 kernels."""
+def test_bf16_train_batch_of_64_is_its_four_images_sixteen_times():
+    """bf16_train past 4 GiB per padded copy (64 x 1024x512: conv1_2's padded bf16 input is 64 x 514 x 1026 x 64 x 2 bytes = 4.3 GB, each of its two 32-channel
+    planes 2.2 GB).  Round 5 refused this batch (32-bit byte offsets from the start of a copy); the convolution kernels now carry the tile's position in their
+    64-bit base and the weight-gradient kernels' per-lane offsets span two planes.  A batch made of four images repeated sixteen times must give the loss of
+    the four-image batch, its logits image by image, and -- the loss being a mean over the batch, and 1/16 a power of two that bf16 rounding commutes with --
+    its gradients up to fp32 summation order (16x more rows per weight-gradient reduction).  A wrapped offset anywhere shows up in the late images."""
     import torch
     from fcn8s_tensorflow_amd.engine import Engine
-    e = Engine(20, precision="bf16_train")
-    e.init_params(seed=0)
-    img = torch.zeros((64, 512, 1024, 3), dtype=torch.uint8, device="cuda")
-    lab = torch.zeros((64, 512, 1024), dtype=torch.uint8, device="cuda")
-    with pytest.raises(ValueError, match="4 GiB"):
-        e.forward_backward(img, lab, keep_prob=1.0)
-    assert np.isfinite(e.forward_backward(img[:16], lab[:16], keep_prob=1.0))      # the model is usable afterwards
+    R, REP, H, W, C = 4, 16, 512, 1024, 20
+    P = orc.init_params(C, seed=4, decoder_std_scale=30.0, bias_std=0.05)
+    img, lab = orc.synthetic_batch(R, H, W)
+    imgd, labd = torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda()
+    e = Engine(C, precision="bf16_train")
+    e.set_params(P)
+    loss4 = e.forward_backward(imgd, labd, keep_prob=1.0, l2_rate=1e-3)
+    g4 = e.flat_grads.clone()
+    logits4 = e.activation("logits", (R, H, W, C))
+    scale = float(np.abs(logits4).max())
+    big_i, big_l = imgd.repeat(REP, 1, 1, 1).contiguous(), labd.repeat(REP, 1, 1).contiguous()
+    loss64 = e.forward_backward(big_i, big_l, keep_prob=1.0, l2_rate=1e-3)
+    assert abs(loss64 - loss4) < 1e-5 * max(1.0, abs(loss4)), (loss64, loss4)
+    g64 = e.flat_grads
+    worst = ("", 0.0)
+    for name, (shape, off) in e.specs.items():
+        n = int(np.prod(shape))
+        a, b = g64[off:off + n], g4[off:off + n]
+        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+        if err > worst[1]:
+            worst = (name, err)
+    print("bf16_train, batch 64 vs its 4 images: loss %.7f / %.7f, worst gradient difference %s %.2e of the tensor's largest entry" % (loss64, loss4, worst[0], worst[1]))
+    assert worst[1] < 1e-3, worst
+    logits64 = e.activation("logits", (R * REP, H, W, C))
+    dmax = 0.0
+    for i in (0, 5, 37, 62, 63):
+        d = float(np.abs(logits64[i] - logits4[i % R]).max())
+        dmax = max(dmax, d)
+        assert d <= 1e-5 * scale, (i, d, scale)            # (measured 6.4e-7: the forward kernels add a dot product's terms in the same order whatever the batch)
+    print("bf16_train, batch 64: logits of images 0, 5, 37, 62, 63 differ from the four-image batch's by at most %.2e of their scale" % (dmax / scale))
+    loss, step = e.train_step(big_i, big_l, 1e-4, keep_prob=0.5)
+    assert np.isfinite(loss) and step == 1
     e.close()
