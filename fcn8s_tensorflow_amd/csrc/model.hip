@@ -166,6 +166,9 @@ struct fcn8s_model {
     int plan_N = 0;
     char* arena = nullptr; size_t arena_bytes = 0;
     std::map<std::string, Act> acts;
+    // option "keep_output_gradients" (tests): every weighted layer's fp32 output gradient dY, copied as the backward pass hands it to the layer's weight gradient;
+    // read back through fcn8s_get_activation("dy:<layer>")
+    int keep_dy = 0; std::map<std::string, Act> kept_dy; std::set<std::string> dz_unwritten;      // dz_unwritten: layers whose fp32 dY the pool's backward kernel skipped
     // the last transposed conv (k = 2s = 16) as one GEMM over output blocks (PixMap, elementwise.hip): logits / dlogits live in that blocked layout
     int tconv_gemm = 1; PixMap pm{0, 0, 0, 0, 0, 0}; int tg_kp = 0;
     float *logits_b = nullptr, *dlogits_b = nullptr, *tg_A = nullptr, *tg_dA = nullptr;      // arena
@@ -749,6 +752,17 @@ void conv_wgrad(fcn8s_model* m, const char* group, const float* x, const float* 
     // the data gradient of the layer after this one may have written this layer's dM instead of dz (backward_blocks): dz then holds nothing
     const bool promised = m && layer && phase != 2 && !m->dm_prefilled.empty() && m->dm_prefilled == layer;
     if (m && phase != 2) m->dm_prefilled.clear();
+    if (m && m->keep_dy && layer && phase != 2) {
+        // (dz holds the layer's fp32 dY unless it was handed over in another form: dM from the next layer's data gradient, d(pool) with routing bytes, a bf16 copy only)
+        Act& k = m->kept_dy[layer];
+        const size_t n = (size_t)N * H * W * Cout;
+        if (promised || pool_idx || m->dy_bf16_only.count(layer) || m->dz_unwritten.count(layer)) k.n = 0;
+        else {
+            if (k.p && k.H != (int)(n >> 20)) { hipStreamSynchronize(s); hipFree(k.p); k.p = nullptr; }
+            if (!k.p && hipMalloc((void**)&k.p, n * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); k.p = nullptr; defer_error(FCN8S_ERR_OOM, "keep_output_gradients: %s's copy cannot be allocated", layer); }
+            if (k.p) { k.n = n; k.H = (int)(n >> 20); hipMemcpyAsync(k.p, dz, n * sizeof(float), hipMemcpyDeviceToDevice, s); }
+        }
+    }
     auto broken_promise = [&]() { defer_error(FCN8S_ERR_STATE, "%s was handed dM instead of dZ but does not take the Winograd-domain path", layer); };
     WgradArgs a{}; a.split = split_of(m);
     a.A = x; a.B = dz; a.C = dw;
@@ -1623,7 +1637,7 @@ void backward_head(fcn8s_model* m)
     if (defer_fc) {
         hipEvent_t ev = defer_event(m); hipEventRecord(ev, s);
         m->deferred.emplace_back(ev, [m, dz7, N, h5, w5](hipStream_t ss) {
-            conv_wgrad(m, "fc7_wgrad", A(m, "fc6"), dz7, Gp(m, "fc7/weights"), Gp(m, "fc7/biases"), N, h5, w5, m->widths[5], m->widths[6], 1, 1.f, ss); });
+            conv_wgrad(m, "fc7_wgrad", A(m, "fc6"), dz7, Gp(m, "fc7/weights"), Gp(m, "fc7/biases"), N, h5, w5, m->widths[5], m->widths[6], 1, 1.f, ss, 0, "fc7"); });
     } else {
         conv_wgrad(m, "fc7_wgrad", A(m, "fc6"), dz7, Gp(m, "fc7/weights"), Gp(m, "fc7/biases"), N, h5, w5, m->widths[5], m->widths[6], 1, 1.f, s, 0, "fc7");
         mark_bucket_final(m, 0, s);
@@ -1698,7 +1712,7 @@ void backward_blocks(fcn8s_model* m, int b_hi, int b_lo)
                 pool_done = launch_maxpool_bwd_bf16(A(m, last), m->gbuf[m->gcur], dzb, Gp(m, std::string(last) + "/biases"), N, h, w, cw, s,
                                                     m->pool_routed[b - 1] ? (const unsigned char*)A(m, ix) : nullptr, g16_ps(N, h, w, 3));
             }
-            if (pool_done) { m->dyg16_filled.insert(last); m->db_taken.insert(last); m->gcur ^= 1; }
+            if (pool_done) { m->dyg16_filled.insert(last); m->db_taken.insert(last); m->dz_unwritten.insert(last); m->gcur ^= 1; }
         }
         if (!pidx && !pool_done) {
             ProfScope ps(m, "maxpool_bwd", 0, 4.0 * N * h * w * cw * 2.25);
@@ -1770,7 +1784,10 @@ int do_backward_bucket(fcn8s_model* m, int bucket, int level_cap)
     if (bucket == 0) {
         m->defer_level_now = m->defer_wgrad >= 3 ? 2 : std::min(m->defer_wgrad, level_cap);      // 3: the caller does not consume bucket 0 early
         if (m->profile && m->profile_detail) m->defer_level_now = 0;      // per-layer timing wants one kernel at a time
-        m->deferred.clear(); m->ev_next = 0; m->dyg16_filled.clear(); m->db_taken.clear(); m->dy_bf16_only.clear();
+        // bf16_train has no Winograd-domain weight gradients to hold back, and a held-back fc6 / fc7 weight gradient would have to convert its operands on the side
+        // stream: the arithmetic of the mode must not depend on "defer_wgrad" (round 5's deferred fc7 lambda ran the fp32 kernel: ADVICE round 5)
+        if (bf16_train_mode(m)) m->defer_level_now = 0;
+        m->deferred.clear(); m->ev_next = 0; m->dyg16_filled.clear(); m->db_taken.clear(); m->dy_bf16_only.clear(); m->dz_unwritten.clear();
         m->dm_prefilled.clear();                                           // (a promise left over from a backward pass that ended in an error)
         m->on_tail = false; m->launch_stream = nullptr;                    // (a backward pass that ended in an error may have left them set)
         for (int b = 0; b < kNumBuckets; ++b) m->bucket_final[b] = false;
@@ -1938,6 +1955,7 @@ int fcn8s_destroy(fcn8s_model* m)
     if (m->side_done) hipEventDestroy(m->side_done);
     for (auto e : m->ev_pool) hipEventDestroy(e);
     for (auto& e : m->bucket_ev) if (e) { hipEventDestroy(e); e = nullptr; }
+    for (auto& kv : m->kept_dy) if (kv.second.p) hipFree(kv.second.p);
     for (auto& kv : m->u_train) if (kv.second) hipFree(kv.second);
     if (m->d_wino_u) hipFree(m->d_wino_u);
     for (auto& kv : m->u_cache) if (kv.second) hipFree(kv.second);
@@ -2060,6 +2078,7 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "bf16_fuse_convert") return &m->bf16_fuse_convert;
     if (key == "bf16_acts") return &m->bf16_acts;
     if (key == "bf16_rows_bn") return &m->bf16_rows_bn;
+    if (key == "keep_output_gradients") return &m->keep_dy;
     if (key == "bf16_fuse_pool") return &m->bf16_fuse_pool;
     return nullptr;
 }
@@ -2082,12 +2101,19 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
         if (value < 1) return fail(m, FCN8S_ERR_BAD_ARG, "comm_timeout_ms must be >= 1");
         std::lock_guard<std::mutex> lk(m->comm_mu); m->comm_timeout_ms = value; return FCN8S_OK;
     }
-    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform" || k == "deterministic" || k == "bf16_fuse_convert" || k == "bf16_acts" || k == "bf16_rows_bn" || k == "bf16_fuse_pool") {        // pick a kernel per launch: nothing cached depends on them
+    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform" || k == "deterministic" || k == "bf16_fuse_convert" || k == "bf16_acts" || k == "bf16_rows_bn" || k == "bf16_fuse_pool" || k == "keep_output_gradients") {        // pick a kernel per launch: nothing cached depends on them
         *model_option(m, k) = k == "bf16_rows_bn" ? (int)value : (value ? 1 : 0);
         return FCN8S_OK;
     }
     int* slot = model_option(m, k);
     if (!slot) return fail(m, FCN8S_ERR_NOT_FOUND, "fcn8s_set_option: unknown option '" + k + "'");
+    // FCN8S_PREC_BF16_TRAIN runs without Winograd transforms whatever these two say: while the mode is on a new value is kept for the day it is left
+    // (round 5 overwrote the live slot: the value was used by nobody and lost on leaving)
+    if (bf16_train_mode(m) && (k == "winograd_min_cin" || k == "winograd_fc6")) {
+        if (value < 0) return fail(m, FCN8S_ERR_BAD_ARG, "fcn8s_set_option: negative value");
+        (k == "winograd_min_cin" ? m->saved_wino_min_cin : m->saved_wino_fc6) = (int)value;
+        return FCN8S_OK;
+    }
     if (k == "winograd_tile" && value != 2 && value != 4 && value != 6) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_tile must be 2, 4 or 6");
     if (k == "winograd_tile_hires" && value != 0 && value != 2 && value != 4 && value != 6) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_tile_hires must be 0, 2, 4 or 6");
     if (k == "winograd_min_cin" && value < 0) return fail(m, FCN8S_ERR_BAD_ARG, "winograd_min_cin must be >= 0 (0 = direct convolution everywhere)");
@@ -2131,6 +2157,9 @@ int fcn8s_get_option(const fcn8s_model* m, const char* key, int64_t* value)
     const int* slot = model_option(const_cast<fcn8s_model*>(m), k);
     if (!slot) return FCN8S_ERR_NOT_FOUND;
     *value = *slot;
+    // (the caller's own setting, also while FCN8S_PREC_BF16_TRAIN keeps the live slots at 0)
+    if (bf16_train_mode(m) && k == "winograd_min_cin" && m->saved_wino_min_cin >= 0) *value = m->saved_wino_min_cin;
+    if (bf16_train_mode(m) && k == "winograd_fc6" && m->saved_wino_fc6 >= 0) *value = m->saved_wino_fc6;
     return FCN8S_OK;
 }
 
@@ -2772,6 +2801,16 @@ int fcn8s_get_activation(fcn8s_model* m, const char* name, float* host, size_t n
 {
     if (!m || !name || !host) return FCN8S_ERR_BAD_ARG;
     if (!m->have_forward) return fail(m, FCN8S_ERR_STATE, "no forward pass has been run");
+    if (strncmp(name, "dy:", 3) == 0) {      // a layer's output gradient as the last backward pass handed it to the weight gradient (option "keep_output_gradients")
+        auto k = m->kept_dy.find(name + 3);
+        if (k == m->kept_dy.end() || !k->second.p || !k->second.n)
+            return fail(m, FCN8S_ERR_STATE, std::string("no fp32 output gradient of '") + (name + 3) + "' was kept: set option \"keep_output_gradients\" before the backward pass (bf16_train: with \"bf16_acts\" = 0; "
+                                            "a gradient handed on as routing bytes, as a Winograd-domain image or as a bf16 copy only has no fp32 tensor)");
+        if (n != k->second.n) return fail(m, FCN8S_ERR_SHAPE, std::string("output gradient of '") + (name + 3) + "' has " + std::to_string(k->second.n) + " elements");
+        HIPCHK(m, hipDeviceSynchronize());
+        HIPCHK(m, hipMemcpy(host, k->second.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        return FCN8S_OK;
+    }
     auto it = m->acts.find(name);
     if (it == m->acts.end()) return fail(m, FCN8S_ERR_NOT_FOUND, std::string("unknown activation '") + name + "'");
     if (std::string(name) == "logits" && !m->logits_nhwc_valid && m->logits_b) {      // kept in the blocked GEMM layout: convert for the caller

@@ -710,6 +710,88 @@ def test_config5_bf16_train_2048x1024_bs4():
     e.close()
 
 
+def test_config5_bf16_train_backward_2048x1024_bs4_layer_by_layer():
+    """The BACKWARD pass of bf16_train at BASELINE.json configs[4]'s shape, layer by layer (the forward pass had such a check, the
+    backward pass only batch linearity and closed forms, which a gradient that is wrong CONSISTENTLY at this size -- row splits, offsets near the guard rows,
+    the 64 x 128 nine-tap form, fc6's split-K slabs -- would pass).  One forward / backward pass of the 4-image batch with every fp32 tensor kept
+    (`bf16_acts` = 0, `bf16_fuse_pool` = 0: plain pools) and every layer's output gradient captured (`keep_output_gradients`); then, for conv1_2, conv2_2, conv4_2, fc6 and fc7:
+      * dW of the layer (all four images) against torch's `conv2d_weight` of the device's OWN bf16-rounded layer input and bf16-rounded dY (fp32 on the CPU);
+      * dX of the layer for image 3 -- which the device hands to the previous layer as ITS dY, behind that layer's ReLU (and, for fc6, behind pool5 and conv5_3's
+        ReLU) -- against torch's `conv2d_input` of the same rounded dY and rounded weights;
+    bound 1e-4 of the tensor's largest entry (fp32 summation order is all that differs).  And the default configuration (`bf16_acts` = 1: conv -> conv tensors
+    only as bf16 copies) gives the same 42 gradient tensors as `bf16_acts` = 0 to 1e-5 (same values into every product; the split sums meet in atomics)."""
+    import torch
+    import torch.nn.functional as F
+    from fcn8s_tensorflow_amd.engine import Engine
+    N, H, W, C = 4, 1024, 2048, 20
+    K = 3                                                   # the image whose data gradients are checked
+    e = Engine(C, seed=5, precision="bf16_train")
+    img, lab = orc.synthetic_batch(N, H, W)
+    imgd, labd = torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda()
+    P = orc.init_params(C, seed=6, decoder_std_scale=30.0, bias_std=0.05)
+    e.set_params(P)
+    e.forward_backward(imgd, labd, keep_prob=1.0)
+    g_default = e.flat_grads.clone()
+    e.set_option("bf16_acts", 0)
+    e.forward_backward(imgd, labd, keep_prob=1.0)
+    g_kept = e.flat_grads.clone()
+    worst = ("", 0.0)
+    for name, (shape, off) in e.specs.items():
+        n = int(np.prod(shape))
+        a, b = g_default[off:off + n], g_kept[off:off + n]
+        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+        if err > worst[1]:
+            worst = (name, err)
+    print("config 5 [bf16_train] backward: default configuration vs every fp32 tensor kept: worst gradient difference %s %.2e" % worst)
+    assert worst[1] < 1e-5, worst
+    del g_default, g_kept
+    # (plain pools for the layer-by-layer part: the routed pools pick their maxima among the bf16 values and write the last conv's dY only as a bf16 copy -- another,
+    #  equally valid subgradient at rounding ties, and no fp32 tensor to look at)
+    e.set_option("bf16_fuse_pool", 0); e.set_option("keep_output_gradients", 1)
+    e.forward_backward(imgd, labd, keep_prob=1.0)
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    nchw = lambda a: torch.from_numpy(a).permute(0, 3, 1, 2)
+    wd = e.widths
+    grads = e.get_grads()
+    report = {}
+    #        layer     its input  level (stride 2^d)  Cin    Cout   weights          the layer before it (None: pool5 -> conv5_3)
+    for layer, src, d, cin, cout, wname, prev in (("conv1_2", "conv1_1", 0, wd[0], wd[0], "conv1_2/filter", "conv1_1"),
+                                                  ("conv2_2", "conv2_1", 1, wd[1], wd[1], "conv2_2/filter", "conv2_1"),
+                                                  ("conv4_2", "conv4_1", 3, wd[3], wd[3], "conv4_2/filter", "conv4_1"),
+                                                  ("fc6", "pool5", 5, wd[4], wd[5], "fc6/weights", None),
+                                                  ("fc7", "fc6", 5, wd[5], wd[6], "fc7/weights", "fc6")):
+        h, w = H >> d, W >> d
+        wk = torch.from_numpy(P[wname]); k = wk.shape[0]; pad = (k - 1) // 2
+        wt = rb(wk).permute(3, 2, 0, 1).contiguous()                       # [Cout][Cin][k][k]
+        x = e.activation(src, (N, h, w, cin))
+        dy = e.activation("dy:" + layer, (N, h, w, cout))
+        assert np.abs(dy).max() > 0
+        xr, dyr = rb(nchw(x)).contiguous(), rb(nchw(dy)).contiguous()
+        dw_ref = torch.nn.grad.conv2d_weight(xr, wt.shape, dyr, padding=pad).permute(2, 3, 1, 0).numpy()
+        dw_err = float(np.abs(grads[wname] - dw_ref).max() / np.abs(dw_ref).max())
+        # dX of image K, as the previous layer received it
+        dx_ref = torch.nn.grad.conv2d_input((1, cin, h, w), wt, dyr[K:K + 1], padding=pad)
+        if prev is not None:
+            got = e.activation("dy:" + prev, (N, h, w, cin))[K]
+            want = (dx_ref[0].permute(1, 2, 0).numpy()) * (x[K] > 0)
+        else:
+            # pool5 between conv5_3 and fc6: route the reference d(pool5) through torch's max-pool backward of the device's own conv5_3, then conv5_3's ReLU
+            c53 = torch.from_numpy(e.activation("conv5_3", (N, 2 * h, 2 * w, cin))[K:K + 1]).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+            F.max_pool2d(c53, 2).backward(dx_ref)
+            want = (c53.grad[0].permute(1, 2, 0).numpy()) * (c53.detach()[0].permute(1, 2, 0).numpy() > 0)
+            got = e.activation("dy:conv5_3", (N, 2 * h, 2 * w, cin))[K]
+        assert np.abs(want).max() > 0
+        dx_err = float(np.abs(got - want).max() / np.abs(want).max())
+        report[layer] = (dw_err, dx_err)
+        del x, dy, xr, dyr, dw_ref, dx_ref, got, want
+    print("config 5 [bf16_train] backward at 2048x1024 x 4 against torch on the device's own rounded operands (dW all images, dX image %d): " % K
+          + ", ".join("%s dW %.2e dX %.2e" % (k, v[0], v[1]) for k, v in report.items()))
+    for k, v in report.items():
+        assert v[0] < 1e-4 and v[1] < 1e-4, (k, v)
+    e.close()
+
+
 def test_batch_of_64_is_its_four_images_sixteen_times():
     """Size independence at the top of the range (1024x512 x 64 images: 160 GB of the 288 GB, Winograd images of 4 G elements -- past
     every 32-bit index): a batch made of four images repeated sixteen times must give the loss, all 42 gradient tensors (the loss is a

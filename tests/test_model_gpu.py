@@ -593,7 +593,7 @@ def test_bf16_train_mode():
       (1) each layer's forward arithmetic exactly: the device's output against the same-rounding convolution of the DEVICE's own input (1e-4);
       (2) end to end: activations and logits against the oracle to 2e-2 of their range (inputs that differ by fp32 round-off cross bf16
           rounding boundaries: a 2^-8 step per crossing);
-      (3) all gradients against the oracle's along the device's ReLU / pool decisions to 5e-2 in L2 (the kernels' own arithmetic is held to 1e-5 by
+      (3) all gradients against the oracle's along the device's ReLU / pool decisions to 2e-2 in L2 (measured 7.3e-3) (the kernels' own arithmetic is held to 1e-5 by
           tests/test_ops_gpu.py::test_conv_bf16_train_kernels; what is left here is those boundary crossings, now also in dY);
       (4) the kernels that ran: conv_bf16_256_kernel<64|128|256> and wgrad_bf16_kernel, no Winograd kernel, no fp32 position GEMM;
       (5) a training step runs, and leaving the mode gives back the fp32 predictions of an engine that never entered it."""
@@ -657,15 +657,28 @@ def test_bf16_train_mode():
         l2 = float(np.linalg.norm(gk - rk) / (np.linalg.norm(rk) + 1e-30))
         if l2 > worst[1]:
             worst = (k, l2)
-        assert l2 < 5e-2, (k, l2)
+        assert l2 < 2e-2, (k, l2)
     d32 = max(float(np.linalg.norm(np.asarray(g_ref[k], np.float64) - g_32[k]) / (np.linalg.norm(g_32[k]) + 1e-30)) for k in g_ref)
     print("bf16_train: worst gradient tensor %s %.2e in L2 against the same-arithmetic oracle (that oracle is %.2e from the fp32 graph's gradients); %s" % (worst[0], worst[1], d32, stats))
+    # the mode's arithmetic does not depend on `defer_wgrad` (round 5's held-back fc7 weight gradient ran the fp32 kernel: ADVICE round 5): the same fc6 / fc7
+    # weight gradients at every level, to the round-off of their atomically joined split sums
+    for level in (2, 3):
+        e.set_option("defer_wgrad", level)
+        e.forward_backward(img, onehot, keep_prob=1.0, l2_rate=1e-3)
+        g2 = e.get_grads()
+        for k in ("fc7/weights", "fc6/weights", "conv4_2/filter", "fc7/biases"):
+            assert rel(g2[k], g[k]) < 1e-5, (level, k, rel(g2[k], g[k]))
+    e.set_option("defer_wgrad", 0)
     # (5)
     loss2, step = e.train_step(img, lab, 1e-6, keep_prob=0.5)
     assert step == 1 and np.isfinite(loss2)
-    assert e.get_option("winograd_min_cin") == 0
-    e.set_precision('fp32')
+    # the two options the mode overrides keep the CALLER's values: reported while the mode is on, and a change made meanwhile takes effect on leaving
     assert e.get_option("winograd_min_cin") == 64 and e.get_option("winograd_fc6") == 1
+    e.set_option("winograd_min_cin", 128)
+    assert e.get_option("winograd_min_cin") == 128
+    e.set_precision('fp32')
+    assert e.get_option("winograd_min_cin") == 128 and e.get_option("winograd_fc6") == 1
+    e.set_option("winograd_min_cin", 64)
     e.set_params(P)
     a = e.predict(img, argmax=False)
     e2 = Engine(20, widths=widths); e2.set_params(P)
