@@ -859,25 +859,6 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float4* __restr
         o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
     }
 }
-namespace {
-struct ColsumScratch { float* partial = nullptr; size_t cap = 0; };
-// per stream: two streams may run column sums at the same time, launches on one stream are ordered
-ColsumScratch* colsum_scratch(hipStream_t s, size_t floats)
-{
-    static std::mutex mu;
-    static std::map<hipStream_t, ColsumScratch> pool;
-    std::lock_guard<std::mutex> lk(mu);
-    ColsumScratch& e = pool[s];
-    if (e.cap < floats) {
-        if (e.partial) hipFree(e.partial);                  // (synchronises the device: nothing still reads the old buffer)
-        e.partial = nullptr; e.cap = 0;
-        const size_t want = floats < (1u << 18) ? (1u << 18) : floats;
-        if (hipMalloc((void**)&e.partial, want * sizeof(float)) != hipSuccess) return nullptr;
-        e.cap = want;
-    }
-    return &e;
-}
-}
 void launch_colsum(const float* x, float* out, long long rows, int C, hipStream_t s)   // C % 4 == 0 (all channel counts here are)
 {
     const int C4 = C / 4;
@@ -892,9 +873,8 @@ void launch_colsum(const float* x, float* out, long long rows, int C, hipStream_
     const unsigned gx = (unsigned)((rows + rpb - 1) / rpb);
     float4* partial = nullptr;
     if (gx > 1) {
-        ColsumScratch* sc = colsum_scratch(s, (size_t)gx * C);
-        if (!sc) { defer_error(FCN8S_ERR_OOM, "the column sums' scratch (%zu floats) cannot be allocated", (size_t)gx * C); return; }
-        partial = (float4*)sc->partial;
+        partial = (float4*)scratch2(s, (size_t)gx * C);
+        if (!partial) { defer_error(FCN8S_ERR_OOM, "the column sums' scratch (%zu floats) cannot be allocated", (size_t)gx * C); return; }
     }
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, ctiles), dim3(256), 0, s, (const float4*)x, out, rows, C4, tpr, rpb, partial);
     if (gx > 1) hipLaunchKernelGGL(colsum_final_kernel, dim3((C4 + 15) / 16), dim3(256), 0, s, (const float4*)partial, out, (int)gx, C4);

@@ -140,7 +140,9 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s);
 // additions then depends on block scheduling, so no two runs give the same bits) instead stores one partial result per split into a scratch slab
 // and a second kernel adds the slabs in split order.  Set per thread by the model's entry points; launchers read it.
 extern thread_local int t_deterministic;
-float* det_scratch(hipStream_t s, size_t floats);              // per-stream scratch, grown on demand; nullptr if the allocation failed
+float* det_scratch(hipStream_t s, size_t floats);              // per-(device, stream) scratch, grown on demand; nullptr if the allocation failed
+float* scratch2(hipStream_t s, size_t floats);                 // a second such buffer (the column sums' partials, which run beside a det_scratch user)
+void scratch_release(hipStream_t s);                           // frees both buffers of the calling device's stream s (fcn8s_destroy; the stream is idle)
 // C[r][c] (= or +=) sum_{k < nsplit, in order} ws[k * slab + r * ldc + c]   for r < rows, c < cols
 void launch_det_reduce(float* C, const float* ws, long long rows, int cols, int ldc, long long slab, int nsplit, bool accumulate, hipStream_t s);
 // 3x3 / 7x7 SAME conv weight (+bias) gradient, several taps per block (3x3: all nine, 7x7: one filter row);

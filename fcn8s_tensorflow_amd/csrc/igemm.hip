@@ -41,21 +41,41 @@ static __device__ __forceinline__ unsigned xcd_swizzle(unsigned p, unsigned tota
 }
 
 thread_local int t_deterministic = 0;
-float* det_scratch(hipStream_t s, size_t floats)
+// Scratch for the slab reductions, the column-sum partials and the split-K slabs: one buffer per (device, stream) -- launches on one stream are ordered, two streams
+// never share a buffer, and a stream handle (the NULL stream above all) means a different queue on every device.  Grown on demand; released by
+// scratch_release when the model that owns the stream is destroyed (round 5 kept every buffer for the life of the process, keyed by the handle alone: a handle
+// reused after fcn8s_destroy, or the NULL stream on a second device, got memory of the wrong device -- ADVICE round 5).
+namespace {
+struct ScratchBuf { float* p = nullptr; size_t cap = 0; };
+std::mutex g_scratch_mu;
+std::map<std::pair<int, hipStream_t>, ScratchBuf> g_scratch[2];      // [0] det_scratch, [1] scratch2 (column sums)
+float* scratch_get(int which, hipStream_t s, size_t floats, size_t floor_)
 {
-    struct Buf { float* p = nullptr; size_t cap = 0; };
-    static std::mutex mu;
-    static std::map<hipStream_t, Buf> pool;        // per stream: launches on one stream are ordered, two streams never share a buffer
-    std::lock_guard<std::mutex> lk(mu);
-    Buf& b = pool[s];
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    ScratchBuf& b = g_scratch[which][std::make_pair(dev, s)];
     if (b.cap < floats) {
         if (b.p) hipFree(b.p);                     // (synchronises the device: nothing still reads the old buffer)
         b.p = nullptr; b.cap = 0;
-        const size_t want = floats + floats / 4 + (1u << 20);
+        size_t want = floats + floats / 4 + (1u << 20);
+        if (want < floor_) want = floor_;
         if (hipMalloc((void**)&b.p, want * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         b.cap = want;
     }
     return b.p;
+}
+}
+float* det_scratch(hipStream_t s, size_t floats) { return scratch_get(0, s, floats, 0); }
+float* scratch2(hipStream_t s, size_t floats) { return scratch_get(1, s, floats, 1u << 18); }
+// frees what the calling device's stream `s` holds (the caller has synchronised it)
+void scratch_release(hipStream_t s)
+{
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    for (auto& pool : g_scratch) {
+        auto it = pool.find(std::make_pair(dev, s));
+        if (it != pool.end()) { if (it->second.p) hipFree(it->second.p); pool.erase(it); }
+    }
 }
 __global__ __launch_bounds__(256) void det_reduce_kernel(float* __restrict__ C, const float* __restrict__ ws, const long long n, const int cols, const int ldc,
                                                          const long long slab, const int nsplit, const int accumulate)

@@ -1942,6 +1942,8 @@ int fcn8s_destroy(fcn8s_model* m)
     const int rc_comm = fcn8s_comm_destroy(m);
     const std::string comm_text = rc_comm ? m->err : std::string();
     hipDeviceSynchronize();
+    // the per-stream scratch of the streams this model ran on (the caller's stream may live on: what it holds is given back, the next user grows its own)
+    scratch_release(m->stream); if (m->side) scratch_release(m->side); if (m->tail) scratch_release(m->tail);
     for (auto& g : m->groups) for (auto& ev : g.ev) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     if (m->own_params && m->d_params) hipFree(m->d_params);
     if (m->own_grads && m->d_grads) hipFree(m->d_grads);
