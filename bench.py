@@ -40,29 +40,65 @@ DTYPE_LABEL = {"fp32": "f32", "bf16_fc": "bf16_fc+f32", "f32x3": "f32x3 (fp32 op
                              "fp32 master weights); conv1_1, the decoder, loss and optimizer fp32"}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/pmc_traffic.json, written by tools/pmc_summary.py); None if not collected."""
+COMMITTED_NOTE = ("committed profile (profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                  "command on an MI355X, tools/collect_profiles.sh) -- not measured in this run (`--live-traffic` re-measures it; the default one-GPU training run does)")
+LIVE_NOTE = "live (two rocprofv3 --pmc passes of this command, 2 steps each, run by bench.py after its timed regions)"
+
+# kernel symbols of the HBM-bound groups (the library's HIP-event groups are keyed by what a launch is FOR; the PMC passes see symbols)
+GROUP_SYMBOLS = {"wino_transform": r"fcn8s::wino_(?!gemm)\w+_kernel", "maxpool_fwd": r"fcn8s::maxpool_fwd", "maxpool_bwd": r"fcn8s::maxpool_bwd",
+                 "softmax_xent": r"fcn8s::softmax_xent", "adam": r"fcn8s::tf_adam_kernel", "sgd_momentum": r"fcn8s::sgd_momentum_kernel"}
+
+
+def committed_pmc():
+    """The committed rocprofv3 PMC summary of this command (profiles/pmc_traffic.json, tools/pmc_summary.py); None if not collected."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        for name, v in d.get("kernels", {}).items():
-            if name.replace(" ", "").startswith("voidfcn8s::" + kernel.replace(" ", "")) or name.replace(" ", "").startswith("fcn8s::" + kernel.replace(" ", "")):
-                out = {"hbm_mb_per_launch": v["hbm_mb_per_launch"], "fetch_mb": v["fetch_mb_per_launch"],
-                       "write_mb": v["write_mb_per_launch"], "source": d.get("source"),
-                       "traffic_source": "committed profile (profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                         "command on an MI355X, tools/collect_profiles.sh) -- not measured in this run (`--live-traffic` re-measures it; the default one-GPU training run does)"}
-                if "fetch_mb_per_launch_uncorrected" in v:      # the x2 FETCH_SIZE correction is an upper bound for 64-byte row-segment loads
-                    out["hbm_mb_per_launch_lower_bound"] = round(v["fetch_mb_per_launch_uncorrected"] + v["write_mb_per_launch"], 3)
-                return out
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:
-        pass
+        return None
+
+
+def kernel_traffic(d, kernel, note):
+    """HBM bytes per launch of one kernel symbol out of a PMC summary."""
+    if not d or "kernels" not in d:
+        return None
+    for name, v in d["kernels"].items():
+        n = name.replace(" ", "")
+        if n.startswith("voidfcn8s::" + kernel.replace(" ", "")) or n.startswith("fcn8s::" + kernel.replace(" ", "")):
+            out = {"hbm_mb_per_launch": v["hbm_mb_per_launch"], "fetch_mb": v["fetch_mb_per_launch"], "write_mb": v["write_mb_per_launch"],
+                   "source": d.get("source"), "traffic_source": note}
+            if "fetch_mb_per_launch_uncorrected" in v:      # the x2 FETCH_SIZE correction is an upper bound for 64-byte row-segment loads
+                out["hbm_mb_per_launch_lower_bound"] = round(v["fetch_mb_per_launch_uncorrected"] + v["write_mb_per_launch"], 3)
+            return out
     return None
 
 
-def live_traffic(argv, kernel):
-    """Re-measure the HBM traffic of `kernel` now: two rocprofv3 PMC passes (FETCH_SIZE; WRITE_SIZE; --kernel-trace only, as the
-    microarch guide prescribes) over a 2-step run of this same command, summarised by tools/pmc_summary.py.  About a minute; runs after
-    the timed regions, so it cannot disturb them.  Any failure falls back to the committed profile."""
+def group_traffic(d, group, note):
+    """HBM megabytes per forward + backward pass of every kernel symbol of an HBM-bound group, out of a PMC summary.  The profiled command runs
+    timed steps, a profiled pass and gradient checks: the number of passes it contains is the launch count of the loss kernel (one per pass)."""
+    import re
+    pat = GROUP_SYMBOLS.get(group)
+    if not d or "kernels" not in d or not pat:
+        return None
+    passes = sum(v["launches"] for k, v in d["kernels"].items() if "softmax_xent_kernel" in k)
+    if group in ("adam", "sgd_momentum"):       # (once per optimizer step, not per pass)
+        passes = sum(v["launches"] for k, v in d["kernels"].items() if re.search(pat, k))
+    if not passes:
+        return None
+    tot = lo = 0.0; syms = 0
+    for k, v in d["kernels"].items():
+        if re.search(pat, k):
+            tot += v["hbm_mb_per_launch"] * v["launches"]; syms += 1
+            lo += (v.get("fetch_mb_per_launch_uncorrected", v["fetch_mb_per_launch"]) + v["write_mb_per_launch"]) * v["launches"]
+    if not syms:
+        return None
+    return {"hbm_mb_per_pass": round(tot / passes, 1), "hbm_mb_per_pass_lower_bound": round(lo / passes, 1), "kernel_symbols": syms, "passes_in_profile": passes,
+            "traffic_source": note}
+
+
+def live_pmc(argv):
+    """Re-measure HBM traffic now: two rocprofv3 PMC passes (FETCH_SIZE; WRITE_SIZE; --kernel-trace only, as the microarch guide prescribes)
+    over a 2-step run of this same command, summarised by tools/pmc_summary.py.  About a minute; runs after the timed regions, so it cannot
+    disturb them.  Returns the summary (kernel symbol -> bytes per launch), {"error": ...} or None; any failure falls back to the committed profile."""
     import shutil
     import subprocess
     import tempfile
@@ -82,18 +118,29 @@ def live_traffic(argv, kernel):
         out = os.path.join(tmp, "t.json")
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), f, w, out, "live: rocprofv3 --pmc passes inside this bench run"],
                        stdout=subprocess.DEVNULL, check=True)
-        d = json.load(open(out))
-        for name, v in d["kernels"].items():
-            n = name.replace(" ", "")
-            if n.startswith("voidfcn8s::" + kernel.replace(" ", "")) or n.startswith("fcn8s::" + kernel.replace(" ", "")):
-                return {"hbm_mb_per_launch": v["hbm_mb_per_launch"], "fetch_mb": v["fetch_mb_per_launch"], "write_mb": v["write_mb_per_launch"],
-                        "hbm_mb_per_launch_lower_bound": round(v["fetch_mb_per_launch_uncorrected"] + v["write_mb_per_launch"], 3),
-                        "traffic_source": "live (two rocprofv3 --pmc passes of this command, 2 steps each, run by bench.py after its timed regions)"}
+        return json.load(open(out))
     except Exception as ex:
         return {"error": repr(ex)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return None
+
+
+def group_roof(group, v, precision):
+    """a kernel group is bound by whichever roof it sits closer to -- max(algorithmic bytes / t / 8 TB/s, algorithmic flops / t / matrix peak of the
+    arithmetic it runs in).  `v` = the library's HIP-event record of the group (ms, flops, bytes)."""
+    if v["ms"] <= 0:
+        return None
+    hbm = v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS if v["bytes"] > 0 else 0.0
+    if group.split(":")[0].endswith("_bf16"):
+        peak = PEAK_BF16_MFMA_TFLOPS
+    elif precision in ("f32x3", "bf16_fwd") and group.startswith(("wino_gemm", "fc7_", "tconv_")):
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+    elif precision in ("f32x2", "bf16_fwd_x2") and group.startswith(("wino_gemm", "fc7_", "tconv_")):
+        peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+    else:
+        peak = PEAK_F32_MFMA_TFLOPS
+    mf = v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak if v["flops"] > 0 else 0.0
+    return {"bound": "hbm" if hbm >= mf else "mfma", "frac": round(max(hbm, mf), 4), "hbm_frac": round(hbm, 4), "mfma_frac": round(mf, 4), "mfma_peak_tflops": round(peak, 1)}
 
 
 def _median(xs):
@@ -757,9 +804,12 @@ def run(args, state):
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
             profiled = any(k.startswith(("ROCPROF", "ROCP_")) or k == "HSA_TOOLS_LIB" for k in os.environ)
             auto_live = world == 1 and not under_launcher and args.mode == "train" and not args.no_cpu_baseline and not profiled
-            tr = live_traffic(sys.argv[1:], dom) if (args.live_traffic or auto_live) and not args.no_live_traffic else None
-            if not tr or "error" in tr:
-                tr = pmc_traffic(dom)
+            pmc = live_pmc(sys.argv[1:]) if (args.live_traffic or auto_live) and not args.no_live_traffic else None
+            pmc_note = LIVE_NOTE
+            tr = kernel_traffic(pmc, dom, pmc_note) if pmc and "error" not in pmc else None
+            if not tr:
+                pmc, pmc_note = committed_pmc(), COMMITTED_NOTE
+                tr = kernel_traffic(pmc, dom, pmc_note)
             # f32x3 mode: six bf16 MFMA products per fp32-equivalent multiply-add -> peak = bf16 dense peak / 6
             # (f32x2: three products)
             peak = (PEAK_BF16_MFMA_TFLOPS / 6.0 if "_x3_" in dom else PEAK_BF16_MFMA_TFLOPS / 3.0 if "_x2_" in dom
@@ -783,7 +833,16 @@ def run(args, state):
             hbm_roof = {"kernel_group": hdom, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(gbs / PEAK_HBM_GBS, 4), "launches": g["launches"],
                         "algorithmic_mb_per_launch": round(g["bytes"] / g["launches"] / 1e6, 2),
+                        "algorithmic_mb_per_step": round(g["bytes"] / args.steps / 1e6, 1),
                         "share_of_step_time": round(g["ms"] / (dt * 1e3), 3)}
+            # the group's HBM-side bytes from the PMC passes (every kernel symbol of the group, per forward + backward pass) against its algorithmic
+            # bytes: well above 1 = re-reads (the backward gathers of the Winograd transforms), below 1 = reads served by the Infinity Cache
+            gt = group_traffic(pmc if (dom and pmc and "error" not in pmc) else committed_pmc(), hdom, pmc_note if dom else COMMITTED_NOTE)
+            if gt:
+                hbm_roof["traffic"] = round(gt["hbm_mb_per_pass"] * 1e6); hbm_roof["traffic_unit"] = "bytes/step (all kernels of the group)"
+                hbm_roof["traffic_over_algorithmic"] = round(gt["hbm_mb_per_pass"] * 1e6 / (g["bytes"] / args.steps), 3)
+                hbm_roof["traffic_over_algorithmic_lower_bound"] = round(gt["hbm_mb_per_pass_lower_bound"] * 1e6 / (g["bytes"] / args.steps), 3)
+                hbm_roof["traffic_detail"] = gt
         out = {
             # BASELINE.json's metric string for its own configuration; any other size / batch / arithmetic says so in the metric itself
             "metric": metric_name(args),
@@ -809,7 +868,10 @@ def run(args, state):
             "comm": comm,
             "kernel_groups_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
             "kernel_groups_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0},
-            "kernel_groups_gbs": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in prof.items() if v["flops"] == 0 and v["ms"] > 0},
+            "kernel_groups_gbs": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in prof.items() if v["bytes"] > 0 and v["ms"] > 0},
+            # which roof bounds each group: max(bytes / t / 8 TB/s, flops / t / matrix peak) -- the score heads, conv1_1 and the 4 x 4 transposed
+            # convolutions come out HBM-bound, as the survey classes them
+            "kernel_groups_roof": {k: group_roof(k, v, args.precision) for k, v in prof.items() if v["ms"] > 0},
             "final_loss": loss,
             # synthetic labels are uniform noise, so nothing can be learned: with the reference's decoder init (sigma 1e-3 / 1e-2,
             # fcn8s_tensorflow.py:159-160) the logits stay ~0 and the loss stays at ln 20 -- a NaN, a diverging or a sign-flipped update

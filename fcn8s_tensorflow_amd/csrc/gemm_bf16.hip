@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const Bf16ConvArgs p)
 }
 
 // =====================================================================================================================================
-// 256 x 256 tile, 8 waves, LDS-DMA, two staggered wave groups (round 3; tools/bf16_lab.hip has the stand-alone version and its diagnosis)
+// 256 x 256 tile, 8 waves, LDS-DMA, two staggered wave groups (round 3; tools/labs/bf16_lab.hip has the stand-alone version and its diagnosis)
 // =====================================================================================================================================
 // y[M][Cout] = epilogue( A[M][K] * Wt[Cout][K]^T ) with K = (ty, tx, ci): A row m, tap (ty, tx) is pixel (y + ty, x + tx) of a ZERO-PADDED bf16
 // copy of the activations (launch_f32_to_bf16_padded), so that every tap of every row is an in-bounds, unconditional load -- LDS-DMA has no
@@ -1008,7 +1008,7 @@ void launch_w_to_bf16_flip_t(const float* w, unsigned short* wt, int K, int Cin,
 // operand is Xp moved by a constant number of rows -- no per-pixel address arithmetic, no predicates (LDS-DMA has none to offer).  Both buffers
 // carry zeroed guard rows in front and behind (pad * Wp + pad + 32), so that the moved / rounded-up row ranges stay inside the allocation and meet
 // finite values (times zero).  Both operands are k-STRIDED ([row][channel]); the MFMA fragments (8 consecutive k of one channel per lane) come out of
-// LDS through ds_read_b64_tr_b16, the hardware 4 x 4 transpose of 16-bit elements (layout and swizzle of tools/planes_lab.hip, measured in round 4).
+// LDS through ds_read_b64_tr_b16, the hardware 4 x 4 transpose of 16-bit elements (layout and swizzle of tools/labs/planes_lab.hip, measured in round 4).
 // Tile BM x BM channels (128, or 64 for the 64-channel layers), K-tile = 32 rows, four stages, LDS-DMA fills, one tap per blockIdx.z, the rows split
 // over blockIdx.x / ntiles chunks whose partial tiles meet in fp32 atomics -- or, in deterministic mode, in one slab per chunk added in chunk order.
 namespace {

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, (MODE != 0 && BM * BN <= 128 * 128) ? 4 : 1) v
 // Y[z] (M x Cout) = epilogue( X[z] (M x K, row stride ldx) * W[z] (K x Cout) ), the MODE 3 / 1x1 cases of igemm_fwd_kernel with a
 // different way of filling LDS: global_load_lds_dwordx4 moves 64 lanes x 16 B from global memory straight into LDS (no VGPR
 // staging, no ds_write, no vmcnt wait in front of a store pass), S = 3 stages, and one K-tile stays in flight ACROSS the K-tile
-// barrier (counted vmcnt + raw s_barrier).  Measured on the bare batched GEMM (tools/gemm_lab.hip, random data, MI355X):
+// barrier (counted vmcnt + raw s_barrier).  Measured on the bare batched GEMM (tools/labs/gemm_lab.hip, random data, MI355X):
 // 125-129 / 132-134 / 138-141 TFLOP/s at K = 256 / 512 / 2048 against 116-122 / 121-125 / 126-129 for the register-staged loop.
 //   * the LDS destination of one instruction is M0 + lane * 16 B (wave-uniform base, lane-linear): the A image therefore has
 //     unpadded 64-byte rows, and ds_read_b128 stays conflict-free through an XOR swizzle of the 16-byte chunk index with
@@ -454,7 +454,7 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt() { asm volat
 // Every fp32 operand x is split exactly into three bf16 pieces x = hi + mid + lo (each residual is representable, so the split has
 // no error) and a*b is taken as hi*hi + hi*mid + mid*hi + hi*lo + mid*mid + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
 // accumulation; the three dropped terms are below 2^-23 |a b|, i.e. below the rounding of one fp32 multiply.  Against a float64
-// reference the result is as close as the f32 MFMA's (tools/gemm_lab.hip x3: max error 6.4e-6 vs 7.5e-6 on K = 128).  Six bf16 MFMAs
+// reference the result is as close as the f32 MFMA's (tools/labs/gemm_lab.hip x3: max error 6.4e-6 vs 7.5e-6 on K = 128).  Six bf16 MFMAs
 // (32 cycles, K = 16) replace eight f32 MFMAs (64 cycles, K = 2): 2.7x less matrix-pipe time, of which the ~190 VALU instructions
 // of the split take half back -- VALU and MFMA issue did not overlap in any arrangement tried (interleaved by hand or by
 // sched_group_barrier, or software-pipelined over K-tiles): 155-170 "TFLOP/s" against 122-136.  Not the default: the headline

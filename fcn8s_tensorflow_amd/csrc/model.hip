@@ -201,7 +201,7 @@ struct fcn8s_model {
     // 2 and 1), and the two kinds of work share the CUs.  Each deferred layer keeps its dM = A dY A^T in a buffer of its own.
     int defer_wgrad = 0, defer_start_block = 2;                          // measured zero-sum (profiles/r03_overlap_*.txt): off by default
     // Sharing CUs between the two kinds of work is zero-sum on gfx950 (profiles/r03_overlap_shared_cus.txt: both slow down by what the other
-    // gains); on DISJOINT CUs they do not disturb each other at all (tools/cumask_lab.hip).  defer_tail_cus = n > 0: from the start block on
+    // gains); on DISJOINT CUs they do not disturb each other at all (tools/labs/cumask_lab.hip).  defer_tail_cus = n > 0: from the start block on
     // the data-gradient chain moves to a stream restricted to the first n CUs and the held-back GEMMs run on the other 256 - n.
     int defer_tail_cus = 0;
     hipStream_t tail = nullptr; hipEvent_t tail_done = nullptr; bool on_tail = false;
@@ -671,7 +671,7 @@ hipEvent_t defer_event(fcn8s_model* m)
     return m->ev_pool[m->ev_next++];
 }
 // CU-masked streams are made once per (device, mask) and never destroyed (destroying one and creating another hung on ROCm 7.2 in
-// tools/cumask_lab.hip); models of one process share them, which only serialises their held-back work
+// tools/labs/cumask_lab.hip); models of one process share them, which only serialises their held-back work
 hipStream_t masked_stream(int device, int first, int count)
 {
     static std::mutex mu;

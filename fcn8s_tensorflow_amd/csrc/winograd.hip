@@ -124,7 +124,7 @@ template <int VEC> static __device__ __forceinline__ void vstore_nt(VecF<VEC>* p
     vt t; _Pragma("unroll") for (int i = 0; i < VEC; ++i) t[i] = v.d[i];
     __builtin_nontemporal_store(t, reinterpret_cast<vt*>(p));
 }
-// 16-byte slab stores for the 8-byte-lane transforms (tools/xform_lab.hip had measured 2-12 % on the stand-alone input transform):
+// 16-byte slab stores for the 8-byte-lane transforms (tools/labs/xform_lab.hip had measured 2-12 % on the stand-alone input transform):
 // lanes 2j and 2j + 1 hold the channel pairs c and c + 1 of the same tile; for two neighbouring Winograd positions b and b + 1 they swap halves, so that
 // the even lane writes 16 bytes (four channels) of position b and the odd lane 16 bytes of position b + 1 -- half as many store instructions.
 // `p` = this lane's own 8-byte address of position b (slab stride `slab` in 8-byte units to position b + 1); needs C / 2 even (every width here is).

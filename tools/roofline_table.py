@@ -4,7 +4,8 @@ HIP events on the launch stream, one pair per launch, recorded in a pass of thei
 
     python tools/roofline_table.py profiles/r04_bench_train_bs16.json > profiles/r04_roofline_table.md
 
-Every group is held against the roof that bounds it: an MFMA group (it reports flops) against the dense matrix peak of the arithmetic it runs
+Every group is held against the roof that bounds it (max(algorithmic bytes / t / 8 TB/s, algorithmic flops / t / matrix peak), the line's
+`kernel_groups_roof`; lines of rounds 1-5 lack that block: there a group that reports flops counts as an MFMA group): an MFMA group against the dense matrix peak of the arithmetic it runs
 in -- 157.3 TFLOP/s for v_mfma_f32_32x32x2_f32, 2500 / 3 and 2500 / 6 "fp32-equivalent" TFLOP/s for the two- and three-piece bf16 modes, 2500
 for the bf16 direct convolutions -- and an HBM group (it reports algorithmic bytes, no flops) against 8 TB/s.  The flops are the ALGORITHM's
 (Winograd-domain multiplies for the Winograd GEMMs, not the direct-convolution count), the bytes are each tensor once per producing /
@@ -43,8 +44,15 @@ def main(path):
     print("|---|---:|---:|---|---:|---:|---:|")
     mfma_ms = hbm_ms = 0.0
     mfma_w = hbm_w = 0.0
+    roof = d.get("kernel_groups_roof") or {}
     for g, t in sorted(ms.items(), key=lambda kv: -kv[1]):
-        if g in tf:
+        r = roof.get(g)
+        # a group is held against the roof it sits closer to, max(bytes / t / 8 TB/s, flops / t / matrix peak); lines without that block (rounds 1-5)
+        # fall back to "reports flops = MFMA group"
+        if r and r["bound"] == "hbm" and g in gb:
+            print("| %s | %.3f | %.1f %% | HBM%s | %.0f GB/s | %.0f | %.2f |" % (g, t, 100 * t / total, (" (MFMA %.2f)" % r["mfma_frac"]) if r["mfma_frac"] else "", gb[g], PEAK_HBM, r["frac"]))
+            hbm_ms += t; hbm_w += t * r["frac"]
+        elif g in tf:
             peak, what = peak_for(g, d["dtype"])
             frac = tf[g] / peak
             print("| %s | %.3f | %.1f %% | %s | %.1f TFLOP/s | %.1f | %.2f |" % (g, t, 100 * t / total, what, tf[g], peak, frac))
@@ -60,6 +68,11 @@ def main(path):
         print("MFMA-bound groups: %.2f ms (%.0f %% of the step) at a time-weighted %.2f of their peaks.  " % (mfma_ms, 100 * mfma_ms / total, mfma_w / mfma_ms), end="")
     if hbm_ms:
         print("HBM-bound groups: %.2f ms (%.0f %%) at a time-weighted %.2f of 8 TB/s." % (hbm_ms, 100 * hbm_ms / total, hbm_w / hbm_ms))
+    h = d.get("roofline_hbm")
+    if h and h.get("traffic"):
+        print()
+        print("Largest HBM-bound group `%s`: %.0f MB algorithmic per step; HBM-side traffic of all its kernels (PMC, FETCH_SIZE x2-corrected + WRITE_SIZE) %.0f MB per step = "
+              "%.2fx (uncorrected fetch: %.2fx)." % (h["kernel_group"], h["algorithmic_mb_per_step"], h["traffic"] / 1e6, h["traffic_over_algorithmic"], h["traffic_over_algorithmic_lower_bound"]))
     r = d.get("roofline")
     if r:
         print()
