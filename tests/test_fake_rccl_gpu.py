@@ -91,6 +91,41 @@ def test_two_native_ranks_step_equals_big_batch_step(tmp_path):
     assert np.abs(upd_dp - upd_ref).max() <= 2e-3 * np.abs(upd_ref).max(), np.abs(upd_dp - upd_ref).max() / np.abs(upd_ref).max()
 
 
+def test_four_native_ranks_stay_bit_identical(tmp_path):
+    """Four ranks of the native communicator on the one GPU (the sums of four buffers in rank order: every replica gets the same bits), three steps each,
+    the evaluation metrics summed over all four."""
+    res = run_ranks("step", tmp_path, world=4, timeout=400)
+    z = [np.load(str(tmp_path / ("out%d.json.npz" % r))) for r in range(4)]
+    for r in range(1, 4):
+        np.testing.assert_array_equal(z[0]["params"], z[r]["params"])
+        np.testing.assert_array_equal(z[0]["params2"], z[r]["params2"])
+    for r in res:
+        assert r["step3"] == 3 and r["conf_sum"] == 8 * 32 * 64 and r["loss_count"] == 4, r
+
+
+def test_bench_and_run_dp_over_the_native_communicator_two_ranks_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2 --comm native` and `run_dp.py --gpus 2 --comm native` as tests/test_multigpu_gpu.py runs them on a two-GPU box, here with both ranks
+    on GPU 0: the torch group (gloo) only carries the 128-byte id, every gradient bucket goes through fcn8s_allreduce_bucket of the library's own
+    communicator (over the stand-in), the replicas stay bit-identical, four buckets leave in backward-production order."""
+    env = dict(os.environ); env["FCN8S_RCCL_LIBRARY"] = FAKE; env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device", "0", "--comm", "native", "--steps", "3",
+                        "--warmup", "1", "--repeats", "1", "--batch", "2", "--height", "64", "--width", "64", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out.get("error") is None and out["n_gpus"] == 2 and out["config"]["global_batch"] == 4, out
+    c = out["comm"]
+    assert c["collectives_by"].startswith("libfcn8s_hip") and c["ranks"] == 2 and c["replicas_identical_after_timed_steps"] is True, c
+    assert len(c["bucket_mb"]) == 4 and c["bucket_issue_ms"] == sorted(c["bucket_issue_ms"]), c
+    assert out["value"] > 0 and np.isfinite(out["final_loss"])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_dp.py"), "--gpus", "2", "--backend", "gloo", "--device", "0", "--comm", "native", "--batch", "2",
+                        "--height", "64", "--width", "64", "--steps-per-epoch", "3", "--workers", "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "rank 0: 2 ranks x 2 images/step, global step 3" in r.stdout, r.stdout[-1000:]
+
+
 def test_a_stalled_peer_fails_the_update_within_the_timeout(tmp_path):
     """Rank 1 never arrives at the all-reduce.  Both ranks' fcn8s_apply_update must return FCN8S_ERR_RCCL about comm_timeout_ms (1.5 s) after
     the buckets were queued -- not hang, and not apply an update to gradients that were never exchanged; every later collective call says
