@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): bench line, rocprofv3 kernel stats and the two PMC passes of the same
 # bench command.  Outputs under gpurun_out/prof_<tag>/ ; copy what should be judged into profiles/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copies the judged summaries of one tools/collect_profiles.sh run (gpurun_out/prof_<tag>/) into profiles/ under round names.
 TAG=${1:?usage: publish_profiles.sh <tag> [round prefix, default r02]}
-R=${2:-r05}
+R=${2:-r06}
 SRC=gpurun_out/prof_$TAG
 DST=profiles
 set -e
