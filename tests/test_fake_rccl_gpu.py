@@ -103,6 +103,23 @@ def test_four_native_ranks_stay_bit_identical(tmp_path):
         assert r["step3"] == 3 and r["conf_sum"] == 8 * 32 * 64 and r["loss_count"] == 4, r
 
 
+def test_bench_eight_native_ranks_on_one_gpu(tmp_path):
+    """The driver's N = 8 command with `--comm native`, all eight ranks on GPU 0 over the stand-in: BASELINE config 4's rank count through the library's own
+    communicator -- eight per-rank times, the 538 MB of gradients of the full-width network summed over eight ranks in four buckets, replicas bit-identical."""
+    env = dict(os.environ); env["FCN8S_RCCL_LIBRARY"] = FAKE; env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--device", "0", "--comm", "native", "--steps", "2",
+                        "--warmup", "1", "--repeats", "1", "--batch", "1", "--height", "64", "--width", "64", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out.get("error") is None and out["n_gpus"] == 8 and out["config"]["global_batch"] == 8 and len(out["per_rank_ms"]) == 8, out
+    c = out["comm"]
+    assert c["collectives_by"].startswith("libfcn8s_hip") and c["ranks"] == 8 and c["replicas_identical_after_timed_steps"] is True, c
+    assert len(c["bucket_mb"]) == 4 and abs(sum(c["bucket_mb"]) - 537.9) < 1.0
+
+
 def test_bench_and_run_dp_over_the_native_communicator_two_ranks_on_one_gpu(tmp_path):
     """`bench.py --gpus 2 --comm native` and `run_dp.py --gpus 2 --comm native` as tests/test_multigpu_gpu.py runs them on a two-GPU box, here with both ranks
     on GPU 0: the torch group (gloo) only carries the 128-byte id, every gradient bucket goes through fcn8s_allreduce_bucket of the library's own
