@@ -2245,7 +2245,8 @@ int fcn8s_forward_loss(fcn8s_model* m, const void* images, int dtype, const uint
     int rc = ensure_workspace(m, N, H, W); if (rc) return rc;
     const void* img; const uint8_t* lab;
     rc = stage_inputs(m, images, dtype, labels, where, &img, &lab); if (rc) return rc;
-    rc = forward(m, img, dtype, keep_prob, true); if (rc) return rc;
+    take_deferred_error(nullptr);                      // (a slot left set by a call that returned early on this thread)
+    rc = forward(m, img, dtype, keep_prob, true); if (rc) { take_deferred_error(nullptr); return rc; }
     rc = deferred_rc(m); if (rc) return rc;
     rc = compute_loss(m, lab, l2_rate, true); if (rc) return rc;
     m->next_bucket = 0;
@@ -2256,6 +2257,7 @@ int fcn8s_forward_loss(fcn8s_model* m, const void* images, int dtype, const uint
 int fcn8s_backward_bucket(fcn8s_model* m, int bucket)
 {
     if (!m || bucket < 0 || bucket >= kNumBuckets) return fail(m, FCN8S_ERR_BAD_ARG, "bad bucket");
+    take_deferred_error(nullptr);
     int rc = do_backward_bucket(m, bucket, 1); if (rc) { take_deferred_error(nullptr); return rc; }
     return deferred_rc(m);
 }
@@ -2610,6 +2612,7 @@ int fcn8s_train_step(fcn8s_model* m, const void* images, int dtype, const uint8_
     // backward pass, every bucket all-reduced as soon as it is final, 1/world in the update (a C caller must never get silently diverging replicas)
     const bool dp = (m->comm || m->comm_failed.load()) && m->comm_world > 1;
     for (int b = 0; b < kNumBuckets; ++b) {
+        take_deferred_error(nullptr);
         rc = do_backward_bucket(m, b, dp ? 1 : 2); if (rc) { take_deferred_error(nullptr); return rc; }
         rc = deferred_rc(m); if (rc) return rc;
         if (dp) for (int r = 0; r < kNumBuckets; ++r)
@@ -2628,7 +2631,8 @@ int fcn8s_eval_step(fcn8s_model* m, const void* images, int dtype, const uint8_t
     int rc = ensure_workspace(m, N, H, W); if (rc) return rc;
     const void* img; const uint8_t* lab;
     rc = stage_inputs(m, images, dtype, labels, where, &img, &lab); if (rc) return rc;
-    rc = forward(m, img, dtype, 1.0f, false); if (rc) return rc;
+    take_deferred_error(nullptr);
+    rc = forward(m, img, dtype, 1.0f, false); if (rc) { take_deferred_error(nullptr); return rc; }
     rc = deferred_rc(m); if (rc) return rc;
     rc = compute_loss(m, lab, l2_rate, false); if (rc) return rc;
     const long long npix = (long long)N * H * W;
@@ -2703,7 +2707,8 @@ int fcn8s_predict(fcn8s_model* m, const void* images, int dtype, int N, int H, i
     int rc = ensure_workspace(m, N, H, W); if (rc) return rc;
     const void* img; const uint8_t* lab;
     rc = stage_inputs(m, images, dtype, nullptr, where, &img, &lab); if (rc) return rc;
-    rc = forward(m, img, dtype, 1.0f, false); if (rc) return rc;
+    take_deferred_error(nullptr);
+    rc = forward(m, img, dtype, 1.0f, false); if (rc) { take_deferred_error(nullptr); return rc; }
     rc = deferred_rc(m); if (rc) return rc;
     const long long npix = (long long)N * H * W;
     if (where == FCN8S_DEVICE) {
