@@ -12,14 +12,14 @@ DOMINANT = "void fcn8s::gemm_glds_kernel<128, 128, 2, 2, 3, false>(fcn8s::IgemmA
 
 def test_pmc_traffic_reproducible(tmp_path):
     out = tmp_path / "t.json"
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(P, "r05_pmc_fetch_counter_collection.csv"),
-                    os.path.join(P, "r05_pmc_write_counter_collection.csv"), str(out), "test"], check=True, capture_output=True)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(P, "r06_pmc_fetch_counter_collection.csv"),
+                    os.path.join(P, "r06_pmc_write_counter_collection.csv"), str(out), "test"], check=True, capture_output=True)
     got = json.load(open(out))["kernels"][DOMINANT]
     pub = json.load(open(os.path.join(P, "pmc_traffic.json")))["kernels"][DOMINANT]
     for k in ("launches", "fetch_mb_per_launch", "write_mb_per_launch", "hbm_mb_per_launch", "fetch_mb_per_launch_uncorrected"):
         assert got[k] == pub[k], k
     assert abs(got["fetch_mb_per_launch"] - 2 * got["fetch_mb_per_launch_uncorrected"]) < 0.01     # the gfx950 FETCH_SIZE correction
-    bench = json.load(open(os.path.join(P, "r05_bench_train_bs16.json")))
+    bench = json.load(open(os.path.join(P, "r06_bench_train_bs16.json")))
     assert bench["roofline"]["kernel"] in DOMINANT.replace("void fcn8s::", "")
     assert abs(bench["roofline"]["frac"] - bench["roofline"]["achieved"] / bench["roofline"]["peak"]) < 1e-3
     if bench["roofline"]["traffic"] is not None:
@@ -32,10 +32,10 @@ def test_pmc_traffic_reproducible(tmp_path):
 
 def test_clock_summary_reproducible(tmp_path):
     out = tmp_path / "c.json"
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_clock_summary.py"), os.path.join(P, "r05_pmc_clock_counter_collection.csv"), str(out)],
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_clock_summary.py"), os.path.join(P, "r06_pmc_clock_counter_collection.csv"), str(out)],
                    check=True, capture_output=True)
     got = json.load(open(out))[DOMINANT]
-    pub = json.load(open(os.path.join(P, "r05_pmc_clock.json")))[DOMINANT]
+    pub = json.load(open(os.path.join(P, "r06_pmc_clock.json")))[DOMINANT]
     assert got == pub
     assert 1.5 < got["effective_clock_ghz"] <= 2.45 and 0.5 < got["mfma_pipe_busy"] <= 1.0
 
@@ -62,9 +62,9 @@ def test_roofline_table_tool_reads_the_committed_bench_line():
     """tools/roofline_table.py: every kernel group of the committed bench line of the current round against the roof that bounds it; the table committed
     under profiles/ is what the tool prints for that line."""
     import subprocess, sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_table.py"), os.path.join("profiles", "r05_bench_train_bs16.json")],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_table.py"), os.path.join("profiles", "r06_bench_train_bs16.json")],
                          capture_output=True, text=True, check=True, cwd=ROOT).stdout
-    assert out == open(os.path.join(ROOT, "profiles", "r05_roofline_table.md")).read()
+    assert out == open(os.path.join(ROOT, "profiles", "r06_roofline_table.md")).read()
     rows = [l.split("|") for l in out.splitlines() if l.startswith("| ") and "kernel group" not in l]
     assert len(rows) >= 15
     by = {r[1].strip(): r for r in rows}
