@@ -438,12 +438,12 @@ def secondary_legs(args, dev, budget_s=75.0):
         finally:
             e.close()
 
-    def infer_leg(steps):
-        e = Engine(20, device_id=dev, seed=1234)
+    def infer_leg(steps, precision="fp32", N=1):
+        e = Engine(20, device_id=dev, seed=1234, precision=precision)
         try:
             e.init_params(seed=0)
             e.freeze(True)
-            images = torch.from_numpy(np.random.default_rng(1234).integers(0, 256, (1, 512, 1024, 3), dtype=np.uint8)).cuda()
+            images = torch.from_numpy(np.random.default_rng(1234).integers(0, 256, (N, 512, 1024, 3), dtype=np.uint8)).cuda()
             for _ in range(5):
                 e.predict(images, argmax=True)
             torch.cuda.synchronize()
@@ -452,8 +452,9 @@ def secondary_legs(args, dev, budget_s=75.0):
                 e.predict(images, argmax=True)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            return {"images_per_sec": round(steps / dt, 1), "ms_per_image": round(dt / steps * 1e3, 4), "steps": steps, "dtype": "f32",
-                    "workload": "predict (argmax) 1024x512, 1 image, frozen parameters (BASELINE config 2)"}
+            return {"images_per_sec": round(N * steps / dt, 1), "ms_per_image": round(dt / steps / N * 1e3, 4), "ms_per_batch": round(dt / steps * 1e3, 4), "steps": steps,
+                    "dtype": "f32" if precision == "fp32" else DTYPE_LABEL[precision],
+                    "workload": "predict (argmax) 1024x512, %d image%s, frozen parameters%s" % (N, "" if N == 1 else "s", " (BASELINE config 2)" if (N == 1 and precision == "fp32") else "")}
         finally:
             e.close()
 
@@ -469,7 +470,10 @@ def secondary_legs(args, dev, budget_s=75.0):
             ("c5_shape_bf16_fwd", lambda: train_leg("bf16_fwd", 4, 1024, 2048, 5))]
     if "bf16_train" in DTYPE_LABEL:
         legs.append(("c5_shape_bf16_train", lambda: train_leg("bf16_train", 4, 1024, 2048, 5)))
-    legs += [("c2_inference_bs1", lambda: infer_leg(100)), ("c3_end_to_end_10_steps", e2e_leg)]
+    legs += [("c2_inference_bs1", lambda: infer_leg(100))]
+    if "bf16_train" in DTYPE_LABEL:     # serving in config 5's arithmetic: batch 1 and batch 16 (round 6: prediction takes the training pass's data flow)
+        legs += [("inference_bs1_bf16_train", lambda: infer_leg(100, "bf16_train", 1)), ("inference_bs16_bf16_train", lambda: infer_leg(20, "bf16_train", 16))]
+    legs += [("c3_end_to_end_10_steps", e2e_leg)]
     for name, fn in legs:
         if time.perf_counter() - t_start > budget_s:
             out[name] = {"skipped": "the secondary legs' %.0f s budget was used up" % budget_s}

@@ -154,6 +154,7 @@ struct fcn8s_model {
     std::set<std::string> db_taken;                                      // layers whose bias gradient the producer of their dY copy has already added (this backward pass)
     int bf16_fuse_pool = 1;                                               // option: bf16_train, the max-pool backward writes the last conv's bf16 dZ copy and bias gradient directly
     std::set<std::string> xg16_filled, dyg16_filled;                     // copies a producing kernel's epilogue has already written in this pass (no conversion pass)
+    int bf16_infer_copies = 1;                                            // option: bf16_train's evaluation / prediction passes take the training pass's data flow (see forward())
     int bf16_rows_bn = 0;                                                 // option (A/B): 128 = the flat-position bf16 convolution takes its 128-column tile where it can (default: 64 columns)
     int bf16_acts = 1;                                                    // option: bf16_train training passes keep a conv -> conv activation only as the consumer's padded bf16 copy (the producer's epilogue writes it; no fp32 tensor, no conversion pass)
     int bf16_fuse_convert = 0;                                            // option: let the producing convolution write its consumer's bf16 copy (measured: the 2-byte epilogue stores cost more than the conversion passes they replace -- off)
@@ -1322,6 +1323,11 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     const bool fill_fp = m->frozen && m->u_cache.empty();
     if (!m->frozen || fill_fp) prepare_forward_weights(m);        // frozen and the kept banks still valid: so are the padded / phase-packed kernels
     m->fwd_train = train;
+    // bf16_train, evaluation / prediction (round 6): the pass takes the TRAINING pass's data flow -- every layer's input as a padded bf16 copy written by its
+    // producer's epilogue (no fp32 conv -> conv tensor, no conversion pass), the flat-position kernel, pools on the bf16 copies -- instead of fp32 tensors converted
+    // layer by layer for the tile kernel: 13.3 -> 9.3 ms per 16 x 1024x512 batch, 1.55 -> 1.18 ms per single image (profiles/r06_bf16_infer.txt).  Same products in the same order as the training pass:
+    // its logits are the training pass's bit for bit (keep_prob 1).  What it keeps for a backward pass that never comes (routing bytes) costs one byte per window.
+    const bool cp = train || (bf16_train_mode(m) && m->bf16_infer_copies);
     m->rbits_ok.clear(); m->y_unwritten.clear(); m->in_bf16_only.clear(); m->fwd_v_layer.clear(); m->xg16_filled.clear();
     { ProfScope ps(m, "preprocess", 0, (double)N * H * W * (16 + (dtype ? 12 : 3))); launch_preprocess(img_dev, dtype, A(m, "x0"), (long long)N * H * W, s); }
     const float* x = A(m, "x0");
@@ -1384,7 +1390,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
                 // bf16_train, training: conv1_2 reads this layer as its padded bf16 copy and nobody else reads it (the mask of conv1_2's data gradient is the
                 // sign of that copy): the tile kernel writes the copy and no fp32 tensor
                 unsigned short* y16 = nullptr;
-                if (bf16_train_mode(m) && train && m->bf16_acts && m->conv1_tiled && h % 8 == 0 && w % 16 == 0 && kConvsPerBlock[0] >= 2 && m->widths[0] % 64 == 0)
+                if (bf16_train_mode(m) && cp && m->bf16_acts && m->conv1_tiled && h % 8 == 0 && w % 16 == 0 && kConvsPerBlock[0] >= 2 && m->widths[0] % 64 == 0)
                     y16 = xg16_for(m, "conv1_2", N, h, w, m->widths[0], 3, s);
                 ProfScope ps(m, "conv1_1_fwd", 2.0 * N * h * w * 27.0 * m->widths[0], 4.0 * N * h * w * 3.0 + (y16 ? 2.0 : 4.0) * N * h * w * m->widths[0], nm);
                 done = launch_conv1_fwd(x, m->d_w1pad, e.bias, y16 ? nullptr : A(m, nm), m->d_w1pad + 12 * 4 * (size_t)m->widths[0], N, h, w, m->widths[0], m->conv1_tiled, s, y16, g16_ps(N, h, w, 3));
@@ -1393,17 +1399,17 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
             if (!done && bf16_train_mode(m) && !first) {
                 // FCN8S_PREC_BF16_TRAIN: every convolution but conv1_1 (3 input channels) as a direct convolution with bf16-rounded operands; the
                 // training pass keeps the layer's padded bf16 input copy for its weight gradient (the convolution starts from that copy)
-                unsigned short* xb = train ? xg16_for(m, nm, N, h, w, cin, 3, s) : nullptr;
+                unsigned short* xb = cp ? xg16_for(m, nm, N, h, w, cin, 3, s) : nullptr;
                 if (xb && !m->xg16_filled.count(nm)) {
                     ProfScope ps(m, "bf16_convert", 0, 4.0 * N * h * w * cin + 2.0 * N * (h + 2) * (w + 2) * cin); launch_f32_to_bf16_padded(x, xb, N, h, w, cin, 1, s, g16_ps(N, h, w, 3));
                 }
                 // the next convolution of the block reads this output as ITS padded bf16 input: this kernel's epilogue writes that copy
                 unsigned short* yb = nullptr; char nx[32] = "";
-                if (train && (m->bf16_fuse_convert || m->bf16_acts) && i < kConvsPerBlock[b]) { snprintf(nx, sizeof nx, "conv%d_%d", b + 1, i + 1); yb = xg16_for(m, nx, N, h, w, m->widths[b], 3, s); }
+                if (cp && (m->bf16_fuse_convert || m->bf16_acts) && i < kConvsPerBlock[b]) { snprintf(nx, sizeof nx, "conv%d_%d", b + 1, i + 1); yb = xg16_for(m, nx, N, h, w, m->widths[b], 3, s); }
                 // the block's LAST convolution is read by its pool only, and pool1 / pool2 / pool5 only by bf16 convolutions: the pool then takes this output
                 // as a bf16 copy of the kernel's own geometry ("pool<b>in"), picks its maxima among the bf16 values (what bf16(max of the fp32 values) is anyway)
                 // and no fp32 tensor is written (pool3 / pool4 also feed the fp32 skip heads: their blocks keep the fp32 tensor)
-                const bool pool16 = train && m->bf16_acts && m->bf16_fuse_pool && i == kConvsPerBlock[b] && b != 2 && b != 3 && cin % 64 == 0 && m->widths[b] % 64 == 0 &&
+                const bool pool16 = cp && m->bf16_acts && m->bf16_fuse_pool && i == kConvsPerBlock[b] && b != 2 && b != 3 && cin % 64 == 0 && m->widths[b] % 64 == 0 &&
                                     m->widths[b == 4 ? 5 : b + 1] % 64 == 0;
                 if (pool16) { snprintf(nx, sizeof nx, "pool%din", b + 1); yb = xg16_for(m, nx, N, h, w, m->widths[b], 3, s); }
                 // ... and if that is the output's only reader (option bf16_acts; the mask of the consumer's data gradient is the sign of the copy), the fp32
@@ -1448,7 +1454,7 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
         snprintf(pn, sizeof pn, "pool%d", b + 1);
         m->pool_fused[b] = pooled && train;
         m->pool_routed[b] = false;
-        if (!pooled && bf16_train_mode(m) && train && m->bf16_fuse_pool && cin % 4 == 0) {
+        if (!pooled && bf16_train_mode(m) && cp && m->bf16_fuse_pool && cin % 4 == 0) {
             // bf16_train, training: the pool keeps its routing bytes (the backward pass reads one byte per window instead of the block's last activation)
             // and writes the consumer's padded bf16 copy itself -- conv<b+2>_1 (pad 1) or fc6 (pad 3); pool1, pool2 and pool5 have no other reader, so
             // with option bf16_acts their fp32 tensors are not written (pool3 / pool4 feed the fp32 skip heads)
@@ -1484,9 +1490,9 @@ int forward(fcn8s_model* m, const void* img_dev, int dtype, float keep_prob, boo
     const bool drop = train && keep_prob < 1.f;
     m->drop_stream = (uint32_t)(2 * m->step);
     if (bf16_train_mode(m)) {
-        unsigned short* xb6 = train ? xg16_for(m, "fc6", N, h5, w5, m->widths[4], m->fc6k, s) : nullptr;
+        unsigned short* xb6 = cp ? xg16_for(m, "fc6", N, h5, w5, m->widths[4], m->fc6k, s) : nullptr;
         if (xb6 && !m->xg16_filled.count("fc6")) { ProfScope ps(m, "bf16_convert", 0, 6.0 * N * h5 * w5 * m->widths[4]); launch_f32_to_bf16_padded(x, xb6, N, h5, w5, m->widths[4], (m->fc6k - 1) / 2, s, g16_ps(N, h5, w5, m->fc6k)); }
-        unsigned short* xb7 = train ? xg16_for(m, "fc7", N, h5, w5, m->widths[5], 1, s) : nullptr;
+        unsigned short* xb7 = cp ? xg16_for(m, "fc7", N, h5, w5, m->widths[5], 1, s) : nullptr;
         const bool fuse7 = xb7 != nullptr && m->bf16_acts;      // fc7's input copy comes out of fc6's epilogue (16-byte stores since the tile kernel's epilogue goes through LDS)
         if (!bf16_conv_layer(m, "fc6_fwd_bf16", "fc6/weights", "fc6/biases", x, A(m, "fc6"), N, h5, w5, m->widths[4], m->widths[5], m->fc6k, drop, keep_prob, m->drop_stream, s, false, xb6, true,
                              fuse7 ? xb7 : nullptr, 0, g16_ps(N, h5, w5, m->fc6k), g16_ps(N, h5, w5, 1)))
@@ -2081,6 +2087,7 @@ static int* model_option(fcn8s_model* m, const std::string& key)
     if (key == "bf16_acts") return &m->bf16_acts;
     if (key == "bf16_rows_bn") return &m->bf16_rows_bn;
     if (key == "keep_output_gradients") return &m->keep_dy;
+    if (key == "bf16_infer_copies") return &m->bf16_infer_copies;
     if (key == "bf16_fuse_pool") return &m->bf16_fuse_pool;
     return nullptr;
 }
@@ -2103,7 +2110,7 @@ int fcn8s_set_option(fcn8s_model* m, const char* key, int64_t value)
         if (value < 1) return fail(m, FCN8S_ERR_BAD_ARG, "comm_timeout_ms must be >= 1");
         std::lock_guard<std::mutex> lk(m->comm_mu); m->comm_timeout_ms = value; return FCN8S_OK;
     }
-    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform" || k == "deterministic" || k == "bf16_fuse_convert" || k == "bf16_acts" || k == "bf16_rows_bn" || k == "bf16_fuse_pool" || k == "keep_output_gradients") {        // pick a kernel per launch: nothing cached depends on them
+    if (k == "conv1_tiled" || k == "conv1_wgrad_mfma" || k == "bf16_copy_by_transform" || k == "conv1_in_transform" || k == "deterministic" || k == "bf16_fuse_convert" || k == "bf16_acts" || k == "bf16_rows_bn" || k == "bf16_fuse_pool" || k == "keep_output_gradients" || k == "bf16_infer_copies") {        // pick a kernel per launch: nothing cached depends on them
         *model_option(m, k) = k == "bf16_rows_bn" ? (int)value : (value ? 1 : 0);
         return FCN8S_OK;
     }

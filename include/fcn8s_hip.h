@@ -291,9 +291,11 @@ int fcn8s_get_precision(const fcn8s_model* m);
  *     "bf16_fuse_pool"    1    FCN8S_PREC_BF16_TRAIN: the forward pools keep routing bytes (and write their consumer's bf16 copy), the max-pool backward kernel reads those bytes and
  *                              writes the last conv's padded bf16 dZ copy and bias gradient itself; 0 = plain pools + conversion passes
  *     "bf16_rows_bn"      0    FCN8S_PREC_BF16_TRAIN: 128 = the flat-position 3 x 3 convolution kernel takes its 128-column tile where it can (A/B; slower)
+ *     "bf16_infer_copies" 1    FCN8S_PREC_BF16_TRAIN: evaluation / prediction passes take the training pass's data flow (padded bf16 copies written by the producers' epilogues, the
+ *                              flat-position kernel, pools on the bf16 copies; logits = the training pass's, bit for bit); 0 = fp32 tensors converted layer by layer (round 5)
  *     "keep_output_gradients" 0 (tests) every weighted layer's fp32 output gradient dY is copied as the backward pass hands it to the layer's weight gradient and can be read with
  *                              fcn8s_get_activation(m, "dy:<layer>", ...) (conv1_1 .. conv5_3, fc6, fc7); FCN8S_ERR_STATE for a layer whose gradient travelled in another form
- *                              (these nine pick a kernel per launch and drop nothing)
+ *                              (these ten pick a kernel per launch and drop nothing)
  *     "comm_timeout_ms" 600000 the communicator's watchdog (see fcn8s_comm_init): a collective older than this is given up, the communicator aborted
  *   op-context options (m == NULL): the arithmetic of the op-level entry points below, which have no model.  The value belongs to the
  *   CALLING THREAD (thread-local) and is read by that thread's later fcn8s_op_* calls only; no model ever reads it, so two models -- or a

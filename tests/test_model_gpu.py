@@ -688,6 +688,39 @@ def test_bf16_train_mode():
         Engine(20, widths=SMALL, precision="bf16_train")            # widths that are not multiples of 64
 
 
+def test_bf16_train_prediction_takes_the_training_data_flow():
+    """Option `bf16_infer_copies` (default 1; round 6): an evaluation / prediction pass of FCN8S_PREC_BF16_TRAIN runs the training pass's kernels and data flow (padded
+    bf16 copies from the producers' epilogues, flat-position kernel, pools on the copies), so its logits are the training pass's BIT FOR BIT at keep_prob 1; the
+    round-5 flow (0: fp32 tensors converted layer by layer, tile kernel) adds a dot product's taps in another order: outputs that differ in their last fp32 bit
+    round to the other bf16 neighbour in the next layer (a 2^-8 step per crossing), so the two flows agree to 2e-2 of the logit scale (measured 7.5e-3; the
+    bound test_bf16_train_mode holds the mode to against its oracle) and give the same argmax wherever the top-2 margin exceeds 4e-2; metrics agree accordingly."""
+    import torch
+    from fcn8s_tensorflow_amd.engine import Engine
+    widths = (64, 64, 128, 256, 256, 256, 128)
+    n, h, w = 2, 64, 96
+    P = orc.init_params(20, widths, seed=9, decoder_std_scale=6.0, bias_std=0.05)
+    img, lab = batch(n, h, w, seed=31)
+    e = Engine(20, widths=widths, precision="bf16_train")
+    e.set_params(P)
+    e.forward_backward(img, lab, keep_prob=1.0)
+    lg_train = e.activation("logits", (n, h, w, 20)).copy()
+    pred = e.predict(img, argmax=True)
+    lg_pred = e.activation("logits", (n, h, w, 20)).copy()
+    np.testing.assert_array_equal(lg_pred, lg_train)
+    e.metrics_reset(); e.eval_step(img, lab); cm_new = e.metrics_raw()[0].copy()
+    e.set_option("bf16_infer_copies", 0)
+    pred0 = e.predict(img, argmax=True)
+    lg0 = e.activation("logits", (n, h, w, 20))
+    scale = max(1.0, float(np.abs(lg_train).max()))
+    assert np.abs(lg0 - lg_train).max() < 2e-2 * scale, np.abs(lg0 - lg_train).max() / scale
+    srt = np.sort(lg_train, -1)
+    safe = (srt[..., -1] - srt[..., -2]) > 4e-2 * scale
+    assert safe.mean() > 0.1 and (np.asarray(pred)[safe] == np.asarray(pred0)[safe]).all()
+    e.metrics_reset(); e.eval_step(img, lab); cm_old = e.metrics_raw()[0]
+    assert np.abs(cm_new.astype(np.int64) - cm_old.astype(np.int64)).sum() <= 2 * int((~safe).sum())
+    e.close()
+
+
 def test_bf16_train_without_fp32_inner_activations():
     """Option `bf16_acts` (default 1) of FCN8S_PREC_BF16_TRAIN: in a training pass the output of a conv that feeds another conv (conv1_1, conv2_1,
     conv3_1, conv3_2, ...) is written ONLY as the consumer's padded bf16 copy -- by the producer's epilogue (conv1_tile_kernel, conv_bf16_rows_kernel) --
@@ -718,7 +751,15 @@ def test_bf16_train_without_fp32_inner_activations():
                     e.activation(name, shape)
             else:
                 assert np.isfinite(e.activation(name, shape)).all()
-        # an inference pass on the same engine writes them again
+        # an inference pass takes the training pass's data flow (option bf16_infer_copies, default 1: the same tensors exist or do not); with that option off
+        # it writes every fp32 tensor again
+        e.predict(img, argmax=False)
+        if acts:
+            with pytest.raises(Fcn8sError, match="bf16_acts"):
+                e.activation("conv3_2", (n, h // 4, w // 4, 128))
+        else:
+            assert np.isfinite(e.activation("conv3_2", (n, h // 4, w // 4, 128))).all()
+        e.set_option("bf16_infer_copies", 0)
         e.predict(img, argmax=False)
         assert np.isfinite(e.activation("conv3_2", (n, h // 4, w // 4, 128))).all()
         e.close()
