@@ -873,6 +873,38 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
     }
 }
 
+// The split-K slabs of conv_bf16_256_kernel added in split order, with the FORWARD epilogue (bias, ReLU; the fp32 output and / or the consumer's bf16 copy of an
+// unpadded map): fc6 / fc7 at batch 1 are 2 row tiles x 16 column tiles behind reductions of 784 / 128 K-tiles -- 32 blocks on 256 CUs -- and run split into
+// slabs like fc6's data gradient (round 6: fc6 at one 1024x512 image 0.32 -> see profiles/r06_bf16_infer.txt).  8 columns per thread, reproducible.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y, unsigned short* __restrict__ yb,
+                                                              long long yb_ps, long long M, int Cout, int nsplit, int relu)
+{
+    const int c8n = Cout / 8;
+    const long long total = M * c8n, slab = M * Cout;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / c8n; const int col8 = (int)(i - m * c8n) * 8;
+        const long long off = m * Cout + col8;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = bias ? bias[col8 + k] : 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float4 a = *reinterpret_cast<const float4*>(part + sp * slab + off), b = *reinterpret_cast<const float4*>(part + sp * slab + off + 4);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        }
+        if (y) { *reinterpret_cast<float4*>(y + off) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(y + off + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+        if (yb) {
+            bf16x8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (__bf16)v[k];
+            *reinterpret_cast<bf16x8*>(yb + (yb_ps ? (long long)(col8 >> 5) * yb_ps + m * 32 + (col8 & 31) : off)) = o;
+        }
+    }
+}
+
 // mode 0 never, 1 when it fills the chip (the round-3 rule, 256-column tiles only), 2 whenever the shapes allow, 3 = 2 with the 128- and 64-column
 // tiles and a partial last row tile as well (the bf16_train mode)
 bool conv_bf16_256_ok(long long M, int Cin, int Cout, int mode)
@@ -908,6 +940,25 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
         const long long rt0 = (a.M + G_BM - 1) / G_BM;
         const long long nkt_all = (long long)a.K * a.K * a.Cin / G_BK;
         const bool plain = !a.bias && !a.addend && !a.mask && !a.relu && !a.dropout && !a.yb && a.y && !a.colpart;
+        // ... and the forward pass of the same shapes at batch 1 (bias, ReLU, the consumer's copy of an UNPADDED map): the slabs are added by splitk_epilogue_kernel
+        // (note: the bias is added FIRST there, before the slabs -- in the one-pass kernel it is added last; both are the fp32 sum of the same terms to round-off)
+        const bool fwd_epi = !plain && a.K != 3 && !a.addend && !a.mask && !a.dropout && !a.colpart && (a.y || a.yb) && (!a.yb || a.yb_pad == 0) && a.Cout % 8 == 0;      // (3 x 3 layers: the flat-position kernel)
+        if (a.any_shape && fwd_epi && a.Cout % 256 == 0 && rt0 * (a.Cout / 256) <= 64 && nkt_all >= 64) {
+            long long ks = 256 / (rt0 * (a.Cout / 256));
+            if (ks > 8) ks = 8;
+            if (ks > nkt_all / 16) ks = nkt_all / 16;            // at least 16 K-tiles per slab
+            float* part = ks >= 2 ? det_scratch(s, (size_t)(ks * a.M * a.Cout)) : nullptr;
+            if (part) {
+                Bf16Conv256Args k = a;
+                k.ksplit = (int)ks; k.part = part;
+                g_last_kernel = "conv_bf16_256_kernel<256>";
+                hipLaunchKernelGGL(conv_bf16_256_kernel<256>, dim3((unsigned)(rt0 * (a.Cout / 256)), (unsigned)ks), dim3(512), 0, s, k);
+                const long long n8 = a.M * (a.Cout / 8);
+                long long blocks = (n8 + 255) / 256; if (blocks > 4096) blocks = 4096;
+                hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, part, a.bias, a.y, a.yb, a.yb_ps, a.M, a.Cout, (int)ks, a.relu);
+                return true;
+            }
+        }
         if (a.any_shape && plain && a.Cout % 256 == 0 && rt0 * (a.Cout / 256) < 128 && nkt_all >= 512) {
             long long ks = 256 / (rt0 * (a.Cout / 256));
             if (ks > 8) ks = 8;
