@@ -782,7 +782,11 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
     const unsigned short* a_base = p.xp + (q0 - Wp - 1) * (p.xp_ps ? 32 : p.Cin);
     const unsigned short* b_base = W_PLANES ? p.wt + (long long)n0 * 32 : p.wt + (long long)n0 * Ktot;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const int nci = p.Cin / G_BK, nkt = 3 * nci;                   // K-tile kt = (channel chunk kt / 3, filter row kt % 3)
+    const int nci = p.Cin / G_BK, nkt_all = 3 * nci;               // K-tile kt = (channel chunk kt / 3, filter row kt % 3)
+    // split K (p.ksplit > 1, blockIdx.y; maps of a few hundred positions -- conv4_x / conv5_x of ONE image -- whose 10-70 blocks would each walk 48 K-tiles on a
+    // mostly idle chip): this block reduces K-tiles [kbeg, kbeg + nkt) and stores its raw accumulators into slab blockIdx.y; rows_splitk_epilogue_kernel adds them
+    const int kbeg = p.ksplit > 1 ? (int)((long long)nkt_all * blockIdx.y / p.ksplit) : 0;
+    const int nkt = (p.ksplit > 1 ? (int)((long long)nkt_all * (blockIdx.y + 1) / p.ksplit) : nkt_all) - kbeg;
     auto issue_a = [&](int kt, int sa) {
         const int ci = (kt / 3) * G_BK, ty = kt % 3;
         const unsigned st = lds0 + (unsigned)(sa * ABYTES);
@@ -806,8 +810,8 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int arow = wr * 32 + (lane & 31);
-    issue_b(0, 0); issue_a(0, 0);
-    if (nkt > 1) issue_a(1, 1);
+    issue_b(kbeg, 0); issue_a(kbeg, 0);
+    if (nkt > 1) issue_a(kbeg + 1, 1);
     int sa = 0, sa2 = 2;                                           // A stage of tile kt / of tile kt + 2
     for (int kt = 0; kt < nkt; ++kt) {
         // in issue order the youngest instructions are A(kt + 1): everything older -- A(kt), B(kt) -- has landed once only they are left
@@ -847,8 +851,8 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
 #endif
         constexpr int PB = ROWS_VARIANT / 10, PA = ROWS_VARIANT % 10;
         auto dma = [&](int pos) {
-            if (PB == pos && kt + 1 < nkt) issue_b(kt + 1, (kt + 1) & 1);
-            if (PA == pos && kt + 2 < nkt) issue_a(kt + 2, sa2);
+            if (PB == pos && kt + 1 < nkt) issue_b(kbeg + kt + 1, (kt + 1) & 1);
+            if (PA == pos && kt + 2 < nkt) issue_a(kbeg + kt + 2, sa2);
         };
         dma(0);
         frags(0); frags(1);
@@ -867,9 +871,56 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_rows_kernel(const Bf16Conv25
         mfmas(2);
         sa = sa + 1 == NSA ? 0 : sa + 1; sa2 = sa2 + 1 == NSA ? 0 : sa2 + 1;
     }
+    if (p.ksplit > 1) {
+        // raw accumulators of this K range, rows = flat positions of the padded map (border positions included: the reducing kernel knows which are pixels)
+        const long long Rq = (long long)p.N * Hp * Wp;
+        float* part = p.part + (long long)blockIdx.y * Rq * p.Cout;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long q = q0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (q < Rq) part[q * p.Cout + n0 + wn * 64 + tn * 32 + (lane & 31)] = acc[tn][r];
+            }
+        return;
+    }
     {
         f32x16 accw[1][2] = {{acc[0], acc[1]}};
         conv_rows_epilogue<1, WCN, 8 / WCN>(p, accw, smem, tid, q0, n0, tmi);
+    }
+}
+
+// The slabs of conv_bf16_rows_kernel's split-K form added in split order, with the forward epilogue of a 3 x 3 layer: row q of a slab is flat position q of the padded
+// map [N][H + 2][W + 2]; interior positions get bias and ReLU and are stored as the fp32 pixel and / or as row q of the consumer's padded bf16 copy (same geometry),
+// border positions store zeros into the copy.  8 columns per thread.
+__global__ __launch_bounds__(256) void rows_splitk_epilogue_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y, unsigned short* __restrict__ yb,
+                                                                   long long yb_ps, int N, int H, int W, int Cout, int nsplit, int relu)
+{
+    const int c8n = Cout / 8, Hp = H + 2, Wp = W + 2;
+    const long long R = (long long)N * Hp * Wp, total = R * c8n, slab = R * Cout;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long q = i / c8n; const int col8 = (int)(i - q * c8n) * 8;
+        const int n = (int)(q / ((long long)Hp * Wp)), rem = (int)(q - (long long)n * Hp * Wp), yy = rem / Wp, xx = rem - yy * Wp;
+        const bool valid = yy >= 1 && yy <= H && xx >= 1 && xx <= W;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            for (int sp = 0; sp < nsplit; ++sp) {
+                const float4 a = *reinterpret_cast<const float4*>(part + sp * slab + q * Cout + col8), b = *reinterpret_cast<const float4*>(part + sp * slab + q * Cout + col8 + 4);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[k] += bias ? bias[col8 + k] : 0.f; if (relu) v[k] = v[k] > 0.f ? v[k] : 0.f; }
+            if (y) {
+                const long long off = (((long long)n * H + yy - 1) * W + xx - 1) * Cout + col8;
+                *reinterpret_cast<float4*>(y + off) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(y + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        }
+        if (yb) {
+            bf16x8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (__bf16)v[k];
+            *reinterpret_cast<bf16x8*>(yb + (yb_ps ? (long long)(col8 >> 5) * yb_ps + q * 32 + (col8 & 31) : q * Cout + col8)) = o;
+        }
     }
 }
 
@@ -988,6 +1039,22 @@ bool launch_conv_bf16_256(const Bf16Conv256Args& a0, hipStream_t s)
         // (the 128-column form, 128 positions x 128 columns, halves the A re-reads of the wide layers and measured 1-2 % SLOWER: 39.23 against 38.71 ms per step)
         int tbn, tbm; conv_bf16_rows_tile(a.Cout, a.rows_bn, &tbn, &tbm);
         const unsigned blocks = (unsigned)(((R + tbm - 1) / tbm) * (a.Cout / tbn));
+        // few blocks behind many K-tiles (conv5_x of one image: 24 blocks x 48 K-tiles, 0.046 -> 0.030 ms; conv4_x's 72 blocks gained nothing from three slabs): split K over blockIdx.y into slabs, forward epilogue only
+        // (bias, ReLU, fp32 pixels and / or the consumer's copy); the sum is bias LAST here as in the one-pass kernel, its terms in slab order
+        const long long nkt_all = 3LL * (a.Cin / G_BK);
+        if (tbn == 64 && blocks <= 48 && nkt_all >= 24 && !a.addend && !a.mask && !a.mask16 && !a.dropout && !a.colpart && (a.y || a.yb)) {
+            long long ks = 256 / blocks; if (ks > 8) ks = 8; if (ks > nkt_all / 6) ks = nkt_all / 6;
+            float* part = ks >= 2 ? det_scratch(s, (size_t)(ks * R * a.Cout)) : nullptr;
+            if (part) {
+                Bf16Conv256Args k = a; k.ksplit = (int)ks; k.part = part;
+                g_last_kernel = "conv_bf16_rows_kernel<64>";
+                hipLaunchKernelGGL(conv_bf16_rows_kernel<64>, dim3(blocks, (unsigned)ks), dim3(512), 0, s, k);
+                const long long n8 = R * (a.Cout / 8);
+                long long eb = (n8 + 255) / 256; if (eb > 4096) eb = 4096;
+                hipLaunchKernelGGL(rows_splitk_epilogue_kernel, dim3((unsigned)eb), dim3(256), 0, s, part, a.bias, a.y, a.yb, a.yb_ps, a.N, a.H, a.W, a.Cout, (int)ks, a.relu);
+                return true;
+            }
+        }
         if (tbn == 128) { g_last_kernel = "conv_bf16_rows_kernel<128>"; hipLaunchKernelGGL(conv_bf16_rows_kernel<128>, dim3(blocks), dim3(512), 0, s, a); }
         else { g_last_kernel = "conv_bf16_rows_kernel<64>"; hipLaunchKernelGGL(conv_bf16_rows_kernel<64>, dim3(blocks), dim3(512), 0, s, a); }
         return true;

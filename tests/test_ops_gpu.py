@@ -336,7 +336,12 @@ def test_conv_bf16_train_rows_forms(N, H, W, Cin, Cout):
         out[form] = (y_.cpu().numpy(), dx_.cpu().numpy())
         assert rel_err(out[form][0], y_ref) < 1e-5, form
         assert rel_err(out[form][1], dx_ref) < 1e-5, form
-    np.testing.assert_array_equal(out[128][0], out[64][0])
+    # (a forward launch with few blocks behind >= 24 K-tiles -- Cin >= 256 at these sizes -- splits K into slabs added in slab order, and the two forms cut the
+    #  K range differently: the same terms in another order)
+    if Cin >= 256:
+        assert rel_err(out[128][0], out[64][0]) < 2e-6
+    else:
+        np.testing.assert_array_equal(out[128][0], out[64][0])
     np.testing.assert_array_equal(out[128][1], out[64][1])
 
 
